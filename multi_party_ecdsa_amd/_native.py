@@ -1,0 +1,62 @@
+"""ctypes binding of libmpecdsa_hip.so (the C-ABI declared in include/mpecdsa_hip.h).
+
+The HIP library is the product; there is no CPU fallback.  Importing this module without the
+built shared object raises ImportError with the build command.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpecdsa_hip.so")
+
+MPE_OK, MPE_E_ARG, MPE_E_HIP, MPE_E_NOMEM = 0, -1, -2, -3
+
+
+class MpeError(RuntimeError):
+    pass
+
+
+class LaunchInfo(C.Structure):
+    _fields_ = [("waves", C.c_int), ("ints_per_wave", C.c_int), ("limbs", C.c_int), ("limb_bits", C.c_int),
+                ("lds_bytes_per_wave", C.c_int), ("table_scratch_bytes", C.c_size_t)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, u32p, i32p = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p
+    sig = {
+        "mpe_version": (C.c_char_p, []),
+        "mpe_last_error": (C.c_char_p, []),
+        "mpe_ctx_create": (ip, [C.POINTER(vp), ip]),
+        "mpe_ctx_destroy": (ip, [vp]),
+        "mpe_sync": (ip, [vp, vp]),
+        "mpe_modset_create": (ip, [vp, ip, ip, u32p, C.POINTER(vp), vp]),
+        "mpe_modset_destroy": (ip, [vp]),
+        "mpe_modset_count": (ip, [vp]),
+        "mpe_modset_bits": (ip, [vp]),
+        "mpe_modexp": (ip, [vp, vp, ip, i32p, u32p, u32p, ip, u32p, vp]),
+        "mpe_modmul": (ip, [vp, vp, ip, i32p, u32p, u32p, u32p, vp]),
+        "mpe_last_launch_info": (ip, [vp, C.POINTER(LaunchInfo)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+# every symbol include/mpecdsa_hip.h declares; tests check the library exports all of them
+EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy", "mpe_sync",
+            "mpe_modset_create", "mpe_modset_destroy", "mpe_modset_count", "mpe_modset_bits",
+            "mpe_modexp", "mpe_modmul", "mpe_last_launch_info"]
+
+
+def check(rc, what):
+    if rc != MPE_OK:
+        raise MpeError(f"{what} failed: rc={rc} ({lib.mpe_last_error().decode()})")
