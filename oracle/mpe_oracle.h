@@ -1,0 +1,136 @@
+/* mpe_oracle.h — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement, over libgmp (the reference's own arithmetic engine: curv-kzen feature
+ * `rust-gmp-kzen`, Cargo.toml:29,36), of the GG20 hot-path formulas of ZenGo-X/multi-party-ecdsa
+ * v0.8.1.  Each function cites the reference file:line it follows.  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may call this library; the product
+ * (libmpecdsa_hip.so) never links or loads it.
+ *
+ * PARITY UNPINNED: the reference ships no golden vectors / KATs for this path (every test there
+ * is a randomized round trip) and no Rust toolchain exists in this image, so
+ * this oracle cannot be checked against the reference's own outputs.  It is pinned instead by
+ * (1) an independent pure-Python restatement (tests/pyref.py: Python ints + hashlib),
+ * (2) the reference's round-trip properties (prove->verify, MtA alpha+beta=ab, sign->verify),
+ * (3) SHA-256 / secp256k1 published test vectors.
+ *
+ * Data convention = the product's C-ABI (include/mpecdsa_hip.h): little-endian uint32 words,
+ * item-major batches.  All pointers are HOST pointers.  Randomness is always an explicit input
+ * (the reference draws from OsRng inside the primitives; SURVEY.md §7 "Randomness").
+ */
+#ifndef MPE_ORACLE_H
+#define MPE_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* field widths in 32-bit words */
+#define ORC_W256 8      /* scalars, e, SHA-256 digests            */
+#define ORC_W768 24     /* alpha < q^3                             */
+#define ORC_WS1 25      /* s1 = e*a + alpha < 2^769                */
+#define ORC_W1024 32    /* Paillier primes p, q                    */
+#define ORC_W2048 64    /* N, N~, h1, h2, z, s, plaintexts         */
+#define ORC_W2304 72    /* rho < q*N~                              */
+#define ORC_W2560 80    /* Bob's gamma < q^2*N                     */
+#define ORC_WT1 81      /* Bob's t1 = e*beta' + gamma < 2^2561     */
+#define ORC_W2816 88    /* gamma < q^3*N~                          */
+#define ORC_WS2 89      /* s2 = e*rho + gamma < 2^2817             */
+#define ORC_W4096 128   /* N^2, ciphertexts                        */
+#define ORC_WPOINT 16   /* affine point: x[8] | y[8]; all-zero = point at infinity */
+
+const char* orc_version(void);
+
+/* ---- curv BigInt (A.1) ---------------------------------------------------------------- */
+/* out = base^exp mod m  (mpz_powm; BigInt::mod_pow).  mods: [nmods][k32]; mod_idx NULL -> (nmods==1?0:i) */
+void orc_modexp(int k32, int batch, int nmods, const uint32_t* mods, const int32_t* mod_idx,
+                const uint32_t* base, const uint32_t* exp, int exp_words, uint32_t* out);
+void orc_modmul(int k32, int batch, int nmods, const uint32_t* mods, const int32_t* mod_idx,
+                const uint32_t* a, const uint32_t* b, uint32_t* out);
+/* out = a^-1 mod m, ok[i]=0 when not invertible (BigInt::mod_inv -> Option) */
+void orc_modinv(int k32, int batch, int nmods, const uint32_t* mods, const int32_t* mod_idx,
+                const uint32_t* a, uint32_t* out, uint8_t* ok);
+
+/* ---- kzen-paillier (A.4) ---------------------------------------------------------------- */
+/* c = (1 + m*N) * r^N mod N^2     Paillier::encrypt_with_chosen_randomness (mta/mod.rs:68-75,133-137) */
+void orc_paillier_encrypt(int batch, int nkeys, const uint32_t* N /*[nkeys][64]*/, const int32_t* key_idx,
+                          const uint32_t* m /*[B][64]*/, const uint32_t* r /*[B][64]*/, uint32_t* c /*[B][128]*/);
+/* CRT decryption, Paillier::decrypt (mta/mod.rs:165) */
+void orc_paillier_decrypt(int batch, int nkeys, const uint32_t* p /*[nkeys][32]*/, const uint32_t* q,
+                          const int32_t* key_idx, const uint32_t* c /*[B][128]*/, uint32_t* m /*[B][64]*/);
+/* c1*c2 mod N^2 (Paillier::add, mta/mod.rs:145);  c^k mod N^2 (Paillier::mul, mta/mod.rs:140-144; k: [B][64]) */
+void orc_paillier_add(int batch, int nkeys, const uint32_t* N, const int32_t* key_idx,
+                      const uint32_t* c1, const uint32_t* c2, uint32_t* out);
+void orc_paillier_mul(int batch, int nkeys, const uint32_t* N, const int32_t* key_idx,
+                      const uint32_t* c, const uint32_t* k, uint32_t* out);
+
+/* ---- SHA-256 / curv DigestExt ------------------------------------------------------------ */
+void orc_sha256(const uint8_t* msg, uint64_t len, uint8_t out[32]);
+
+/* ---- secp256k1 (A.2) ---------------------------------------------------------------------- */
+/* out = k*G (fixed base) ; out = k*P (variable base) ; scalars reduced mod q first (Scalar::from(&BigInt)) */
+void orc_ec_mul_base(int batch, const uint32_t* k /*[B][8]*/, uint32_t* out /*[B][16]*/);
+void orc_ec_mul(int batch, const uint32_t* k, const uint32_t* P /*[B][16]*/, uint32_t* out);
+void orc_ec_add(int batch, const uint32_t* P, const uint32_t* Q, uint32_t* out);
+void orc_ec_compress(int batch, const uint32_t* P, uint8_t* out33 /*[B][33]*/);
+
+/* ---- MtA range proofs (src/utilities/mta/range_proofs.rs) --------------------------------- */
+/* Statement tables: Nt/h1/h2 [nst][64] (DLogStatement{N,g,ni}, party_i.rs:225-229); ek N [nkeys][64]. */
+/* AliceProof::generate  range_proofs.rs:160-193 (+ AliceZkpRound1/2 :39-90) */
+void orc_alice_generate(int batch, int nkeys, const uint32_t* N, int nst, const uint32_t* Nt, const uint32_t* h1,
+                        const uint32_t* h2, const int32_t* key_idx, const int32_t* st_idx,
+                        const uint32_t* a /*[B][8]*/, const uint32_t* cipher /*[B][128]*/, const uint32_t* r /*[B][64]*/,
+                        const uint32_t* alpha /*[B][24]*/, const uint32_t* beta /*[B][64]*/,
+                        const uint32_t* gamma /*[B][88]*/, const uint32_t* rho /*[B][72]*/,
+                        uint32_t* z /*[B][64]*/, uint32_t* e /*[B][8]*/, uint32_t* s /*[B][64]*/,
+                        uint32_t* s1 /*[B][25]*/, uint32_t* s2 /*[B][89]*/);
+/* AliceProof::verify  range_proofs.rs:105-156 */
+void orc_alice_verify(int batch, int nkeys, const uint32_t* N, int nst, const uint32_t* Nt, const uint32_t* h1,
+                      const uint32_t* h2, const int32_t* key_idx, const int32_t* st_idx, const uint32_t* cipher,
+                      const uint32_t* z, const uint32_t* e, const uint32_t* s, const uint32_t* s1,
+                      const uint32_t* s2, uint8_t* ok);
+
+/* BobProof::generate range_proofs.rs:414-487 (+ BobZkpRound1/2 :218-297); check!=0 -> also u = alpha*G, X = b*G */
+void orc_bob_generate(int batch, int nkeys, const uint32_t* N, int nst, const uint32_t* Nt, const uint32_t* h1,
+                      const uint32_t* h2, const int32_t* key_idx, const int32_t* st_idx,
+                      const uint32_t* a_enc /*[B][128]*/, const uint32_t* mta_enc /*[B][128]*/,
+                      const uint32_t* b /*[B][8]*/, const uint32_t* beta_prim /*[B][64]*/, const uint32_t* r /*[B][64]*/,
+                      const uint32_t* alpha /*[B][24]*/, const uint32_t* beta /*[B][64]*/, const uint32_t* gamma /*[B][80]*/,
+                      const uint32_t* rho /*[B][72]*/, const uint32_t* rho_prim /*[B][88]*/,
+                      const uint32_t* sigma /*[B][72]*/, const uint32_t* tau /*[B][88]*/, int check,
+                      uint32_t* t /*[B][64]*/, uint32_t* z /*[B][64]*/, uint32_t* e /*[B][8]*/, uint32_t* s /*[B][64]*/,
+                      uint32_t* s1 /*[B][25]*/, uint32_t* s2 /*[B][89]*/, uint32_t* t1 /*[B][81]*/, uint32_t* t2 /*[B][89]*/,
+                      uint32_t* u /*[B][16] or NULL*/);
+/* BobProof::verify range_proofs.rs:321-412; X,u non-NULL -> BobProofExt::verify :499-534 */
+void orc_bob_verify(int batch, int nkeys, const uint32_t* N, int nst, const uint32_t* Nt, const uint32_t* h1,
+                    const uint32_t* h2, const int32_t* key_idx, const int32_t* st_idx, const uint32_t* a_enc,
+                    const uint32_t* mta_enc, const uint32_t* t, const uint32_t* z, const uint32_t* e,
+                    const uint32_t* s, const uint32_t* s1, const uint32_t* s2, const uint32_t* t1,
+                    const uint32_t* t2, const uint32_t* X, const uint32_t* u, uint8_t* ok);
+
+/* ---- PDL with slack (src/utilities/zk_pdl_with_slack/mod.rs) ------------------------------ */
+/* PDLwSlackProof::prove :68-125.  Q,G: statement points; x: witness scalar; r: Paillier randomness */
+void orc_pdl_prove(int batch, int nkeys, const uint32_t* N, int nst, const uint32_t* Nt, const uint32_t* h1,
+                   const uint32_t* h2, const int32_t* key_idx, const int32_t* st_idx,
+                   const uint32_t* cipher, const uint32_t* Q, const uint32_t* G, const uint32_t* x, const uint32_t* r,
+                   const uint32_t* alpha /*[B][24]*/, const uint32_t* beta /*[B][64]*/, const uint32_t* rho /*[B][72]*/,
+                   const uint32_t* gamma /*[B][88]*/,
+                   uint32_t* z /*[B][64]*/, uint32_t* u1 /*[B][16]*/, uint32_t* u2 /*[B][128]*/, uint32_t* u3 /*[B][64]*/,
+                   uint32_t* s1 /*[B][25]*/, uint32_t* s2 /*[B][64]*/, uint32_t* s3 /*[B][89]*/);
+/* PDLwSlackProof::verify :127-179 */
+void orc_pdl_verify(int batch, int nkeys, const uint32_t* N, int nst, const uint32_t* Nt, const uint32_t* h1,
+                    const uint32_t* h2, const int32_t* key_idx, const int32_t* st_idx, const uint32_t* cipher,
+                    const uint32_t* Q, const uint32_t* G, const uint32_t* z, const uint32_t* u1, const uint32_t* u2,
+                    const uint32_t* u3, const uint32_t* s1, const uint32_t* s2, const uint32_t* s3, uint8_t* ok);
+
+/* ---- curv sigma proofs (A.3) --------------------------------------------------------------- */
+/* DLogProof::prove(sk) with nonce rho: pk = sk*G, R = rho*G, c = H(R,G,pk), z = rho - c*sk */
+void orc_dlog_prove(int batch, const uint32_t* sk, const uint32_t* nonce, uint32_t* pk, uint32_t* R, uint32_t* z);
+void orc_dlog_verify(int batch, const uint32_t* pk, const uint32_t* R, const uint32_t* z, uint8_t* ok);
+
+/* fixture helper (test key material only): smallest prime > start */
+void orc_nextprime(int k32, const uint32_t* start, uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

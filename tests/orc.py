@@ -1,0 +1,202 @@
+"""ctypes binding of the CPU oracle (oracle/libmpe_oracle.so) for tests / bench cpu_baseline.
+Arrays are numpy uint32 [batch, words] (same layout as the product's C-ABI)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "libmpe_oracle.so")
+
+W256, W768, WS1, W1024, W2048, W2304, W2560, WT1, W2816, WS2, W4096, WPOINT = 8, 24, 25, 32, 64, 72, 80, 81, 88, 89, 128, 16
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+def load():
+    if not os.path.exists(LIB):
+        build()
+    return C.CDLL(LIB)
+
+
+lib = load()
+lib.orc_version.restype = C.c_char_p
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _idx(idx):
+    return None if idx is None else np.ascontiguousarray(idx, dtype=np.int32)
+
+
+def u32(shape):
+    return np.zeros(shape, dtype=np.uint32)
+
+
+def modexp(mods, base, exp, mod_idx=None):
+    B, k32 = base.shape
+    out = u32((B, k32))
+    mi = _idx(mod_idx)
+    lib.orc_modexp(k32, B, mods.shape[0], _p(mods), _p(mi), _p(base), _p(exp), exp.shape[1], _p(out))
+    return out
+
+
+def modmul(mods, a, b, mod_idx=None):
+    B, k32 = a.shape
+    out = u32((B, k32))
+    mi = _idx(mod_idx)
+    lib.orc_modmul(k32, B, mods.shape[0], _p(mods), _p(mi), _p(a), _p(b), _p(out))
+    return out
+
+
+def modinv(mods, a, mod_idx=None):
+    B, k32 = a.shape
+    out, ok = u32((B, k32)), np.zeros(B, dtype=np.uint8)
+    mi = _idx(mod_idx)
+    lib.orc_modinv(k32, B, mods.shape[0], _p(mods), _p(mi), _p(a), _p(out), _p(ok))
+    return out, ok
+
+
+def paillier_encrypt(N, m, r, key_idx=None):
+    B = m.shape[0]
+    c = u32((B, W4096))
+    ki = _idx(key_idx)
+    lib.orc_paillier_encrypt(B, N.shape[0], _p(N), _p(ki), _p(m), _p(r), _p(c))
+    return c
+
+
+def paillier_decrypt(p, q, c, key_idx=None):
+    B = c.shape[0]
+    m = u32((B, W2048))
+    ki = _idx(key_idx)
+    lib.orc_paillier_decrypt(B, p.shape[0], _p(p), _p(q), _p(ki), _p(c), _p(m))
+    return m
+
+
+def paillier_add(N, c1, c2, key_idx=None):
+    B = c1.shape[0]
+    out = u32((B, W4096))
+    ki = _idx(key_idx)
+    lib.orc_paillier_add(B, N.shape[0], _p(N), _p(ki), _p(c1), _p(c2), _p(out))
+    return out
+
+
+def paillier_mul(N, c, k, key_idx=None):
+    B = c.shape[0]
+    out = u32((B, W4096))
+    ki = _idx(key_idx)
+    lib.orc_paillier_mul(B, N.shape[0], _p(N), _p(ki), _p(c), _p(k), _p(out))
+    return out
+
+
+def sha256(msg: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib.orc_sha256(msg, C.c_uint64(len(msg)), out)
+    return bytes(out)
+
+
+def ec_mul_base(k):
+    out = u32((k.shape[0], WPOINT))
+    lib.orc_ec_mul_base(k.shape[0], _p(k), _p(out))
+    return out
+
+
+def ec_mul(k, P):
+    out = u32((k.shape[0], WPOINT))
+    lib.orc_ec_mul(k.shape[0], _p(k), _p(P), _p(out))
+    return out
+
+
+def ec_add(P, Q):
+    out = u32((P.shape[0], WPOINT))
+    lib.orc_ec_add(P.shape[0], _p(P), _p(Q), _p(out))
+    return out
+
+
+def ec_compress(P):
+    out = np.zeros((P.shape[0], 33), dtype=np.uint8)
+    lib.orc_ec_compress(P.shape[0], _p(P), _p(out))
+    return out
+
+
+def alice_generate(N, Nt, h1, h2, key_idx, st_idx, a, cipher, r, alpha, beta, gamma, rho):
+    B = a.shape[0]
+    z, e, s, s1, s2 = u32((B, W2048)), u32((B, W256)), u32((B, W2048)), u32((B, WS1)), u32((B, WS2))
+    ki, si = _idx(key_idx), _idx(st_idx)
+    lib.orc_alice_generate(B, N.shape[0], _p(N), Nt.shape[0], _p(Nt), _p(h1), _p(h2), _p(ki), _p(si), _p(a), _p(cipher),
+                           _p(r), _p(alpha), _p(beta), _p(gamma), _p(rho), _p(z), _p(e), _p(s), _p(s1), _p(s2))
+    return dict(z=z, e=e, s=s, s1=s1, s2=s2)
+
+
+def alice_verify(N, Nt, h1, h2, key_idx, st_idx, cipher, pr):
+    B = cipher.shape[0]
+    ok = np.zeros(B, dtype=np.uint8)
+    ki, si = _idx(key_idx), _idx(st_idx)
+    lib.orc_alice_verify(B, N.shape[0], _p(N), Nt.shape[0], _p(Nt), _p(h1), _p(h2), _p(ki), _p(si), _p(cipher),
+                         _p(pr["z"]), _p(pr["e"]), _p(pr["s"]), _p(pr["s1"]), _p(pr["s2"]), _p(ok))
+    return ok
+
+
+def pdl_prove(N, Nt, h1, h2, key_idx, st_idx, cipher, Q, G, x, r, alpha, beta, rho, gamma):
+    B = x.shape[0]
+    o = dict(z=u32((B, W2048)), u1=u32((B, WPOINT)), u2=u32((B, W4096)), u3=u32((B, W2048)), s1=u32((B, WS1)),
+             s2=u32((B, W2048)), s3=u32((B, WS2)))
+    ki, si = _idx(key_idx), _idx(st_idx)
+    lib.orc_pdl_prove(B, N.shape[0], _p(N), Nt.shape[0], _p(Nt), _p(h1), _p(h2), _p(ki), _p(si), _p(cipher), _p(Q), _p(G),
+                      _p(x), _p(r), _p(alpha), _p(beta), _p(rho), _p(gamma), _p(o["z"]), _p(o["u1"]), _p(o["u2"]),
+                      _p(o["u3"]), _p(o["s1"]), _p(o["s2"]), _p(o["s3"]))
+    return o
+
+
+def pdl_verify(N, Nt, h1, h2, key_idx, st_idx, cipher, Q, G, pr):
+    B = cipher.shape[0]
+    ok = np.zeros(B, dtype=np.uint8)
+    ki, si = _idx(key_idx), _idx(st_idx)
+    lib.orc_pdl_verify(B, N.shape[0], _p(N), Nt.shape[0], _p(Nt), _p(h1), _p(h2), _p(ki), _p(si), _p(cipher), _p(Q), _p(G),
+                       _p(pr["z"]), _p(pr["u1"]), _p(pr["u2"]), _p(pr["u3"]), _p(pr["s1"]), _p(pr["s2"]), _p(pr["s3"]), _p(ok))
+    return ok
+
+
+def bob_generate(N, Nt, h1, h2, key_idx, st_idx, a_enc, mta_enc, b, beta_prim, r, alpha, beta, gamma, rho, rho_prim,
+                 sigma, tau, check):
+    B = b.shape[0]
+    o = dict(t=u32((B, W2048)), z=u32((B, W2048)), e=u32((B, W256)), s=u32((B, W2048)), s1=u32((B, WS1)),
+             s2=u32((B, WS2)), t1=u32((B, WT1)), t2=u32((B, WS2)))
+    u = u32((B, WPOINT)) if check else None
+    ki, si = _idx(key_idx), _idx(st_idx)
+    lib.orc_bob_generate(B, N.shape[0], _p(N), Nt.shape[0], _p(Nt), _p(h1), _p(h2), _p(ki), _p(si), _p(a_enc), _p(mta_enc),
+                         _p(b), _p(beta_prim), _p(r), _p(alpha), _p(beta), _p(gamma), _p(rho), _p(rho_prim), _p(sigma),
+                         _p(tau), int(bool(check)), _p(o["t"]), _p(o["z"]), _p(o["e"]), _p(o["s"]), _p(o["s1"]),
+                         _p(o["s2"]), _p(o["t1"]), _p(o["t2"]), _p(u))
+    return o, u
+
+
+def bob_verify(N, Nt, h1, h2, key_idx, st_idx, a_enc, mta_enc, pr, X=None, u=None):
+    B = a_enc.shape[0]
+    ok = np.zeros(B, dtype=np.uint8)
+    ki, si = _idx(key_idx), _idx(st_idx)
+    lib.orc_bob_verify(B, N.shape[0], _p(N), Nt.shape[0], _p(Nt), _p(h1), _p(h2), _p(ki), _p(si), _p(a_enc), _p(mta_enc),
+                       _p(pr["t"]), _p(pr["z"]), _p(pr["e"]), _p(pr["s"]), _p(pr["s1"]), _p(pr["s2"]), _p(pr["t1"]),
+                       _p(pr["t2"]), _p(X), _p(u), _p(ok))
+    return ok
+
+
+def dlog_prove(sk, nonce):
+    B = sk.shape[0]
+    pk, R, z = u32((B, WPOINT)), u32((B, WPOINT)), u32((B, W256))
+    lib.orc_dlog_prove(B, _p(sk), _p(nonce), _p(pk), _p(R), _p(z))
+    return pk, R, z
+
+
+def dlog_verify(pk, R, z):
+    ok = np.zeros(pk.shape[0], dtype=np.uint8)
+    lib.orc_dlog_verify(pk.shape[0], _p(pk), _p(R), _p(z), _p(ok))
+    return ok
