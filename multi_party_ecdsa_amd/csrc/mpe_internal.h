@@ -11,7 +11,7 @@
 struct mpe_ctx {
   int device = 0;
   int cus = 256;
-  int modexp_waves_per_cu = 20;   // 5 waves/SIMD at <= 96 VGPRs
+  int modexp_waves_per_cu = 8;    // 2 waves/SIMD: the montmul loop holds ~230 VGPRs and already issues back-to-back
   void* tables = nullptr;         // window-table scratch, grown on demand
   size_t tables_bytes = 0;
   mpe_launch_info last = {};

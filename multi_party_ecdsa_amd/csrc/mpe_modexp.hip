@@ -332,12 +332,15 @@ static ModsetView view_of(const mpe_modset* ms) {
   return v;
 }
 
-// persistent grid: enough waves to fill the chip at the kernel's occupancy, never more than needed
+// persistent grid: at most the resident-wave capacity; when the batch needs several trips the
+// grid shrinks to the smallest one that still finishes in that many trips (no half-empty tail)
 template <class C>
 static int grid_for(const mpe_ctx* ctx, int batch, int waves_per_cu) {
   const int need = (batch + C::GROUPS - 1) / C::GROUPS;
   const int cap = ctx->cus * waves_per_cu;
-  return need < cap ? need : cap;
+  if (need <= cap) return need;
+  const int trips = (need + cap - 1) / cap;
+  return (need + trips - 1) / trips;
 }
 
 template <class C>
