@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 mkdir -p build
-SRC="multi_party_ecdsa_amd/csrc/mpe_modexp.hip"
+SRC="multi_party_ecdsa_amd/csrc/mpe_lib.hip"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -save-temps=obj \
   -Rpass-analysis=kernel-resource-usage "$@" -o build/libmpecdsa_hip.so $SRC 2> build/resource_usage.txt
 cp build/libmpecdsa_hip.so multi_party_ecdsa_amd/libmpecdsa_hip.so

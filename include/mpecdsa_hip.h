@@ -75,6 +75,38 @@ int mpe_modexp(mpe_ctx* ctx, const mpe_modset* ms, int batch, const int32_t* d_m
 int mpe_modmul(mpe_ctx* ctx, const mpe_modset* ms, int batch, const int32_t* d_mod_idx,
                const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, void* stream);
 
+/* ---- kzen-paillier ------------------------------------------------------------------------ */
+/* A set of Paillier-2048 keys resident in HBM.  Public sets hold N, N^2 and their Montgomery
+ * constants; private sets are built from (p, q) and additionally hold p^2, q^2, h_p, h_q and the CRT
+ * constants — all computed ON THE GPU at creation (the reference recomputes them in every
+ * Paillier::decrypt call; reuse is output-identical).
+ *  d_N: [nkeys][64]   d_p, d_q: [nkeys][32]  (1024-bit primes)
+ * key_idx arguments: per-item key index, or NULL meaning (nkeys==1 ? 0 : i). */
+typedef struct mpe_paillier mpe_paillier;
+int mpe_paillier_create_public(mpe_ctx* ctx, int nkeys, const uint32_t* d_N, mpe_paillier** out, void* stream);
+int mpe_paillier_create_private(mpe_ctx* ctx, int nkeys, const uint32_t* d_p, const uint32_t* d_q,
+                                mpe_paillier** out, void* stream);
+int mpe_paillier_destroy(mpe_paillier* pk);
+int mpe_paillier_nkeys(const mpe_paillier* pk);
+/* device pointer to the [nkeys][64] table of moduli N (valid for the life of the key set) */
+const uint32_t* mpe_paillier_n(const mpe_paillier* pk);
+
+/* c = (1 + m*N) * r^N mod N^2     `Paillier::encrypt_with_chosen_randomness(ek, m, r)`
+ * (src/utilities/mta/mod.rs:68-75,133-137).  m, r: [batch][64] (m < N);  c: [batch][128]. */
+int mpe_paillier_encrypt(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const int32_t* d_key_idx,
+                         const uint32_t* d_m, const uint32_t* d_r, uint32_t* d_c, void* stream);
+/* m = Dec(c), CRT form            `Paillier::decrypt(dk, c)` (src/utilities/mta/mod.rs:165,
+ * src/protocols/multi_party_ecdsa/gg_2020/party_i.rs:455-457).  c: [batch][128] -> m: [batch][64].
+ * Requires a private key set.  Ciphertexts must be units mod N (as the reference assumes). */
+int mpe_paillier_decrypt(mpe_ctx* ctx, const mpe_paillier* sk, int batch, const int32_t* d_key_idx,
+                         const uint32_t* d_c, uint32_t* d_m, void* stream);
+/* c1*c2 mod N^2                   `Paillier::add` (src/utilities/mta/mod.rs:145) */
+int mpe_paillier_add(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const int32_t* d_key_idx,
+                     const uint32_t* d_c1, const uint32_t* d_c2, uint32_t* d_out, void* stream);
+/* c^k mod N^2                     `Paillier::mul` (src/utilities/mta/mod.rs:140-144); k: [batch][k_words] */
+int mpe_paillier_mul(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const int32_t* d_key_idx,
+                     const uint32_t* d_c, const uint32_t* d_k, int k_words, uint32_t* d_out, void* stream);
+
 /* Kernel geometry chosen for the last launch (for bench.py's roofline accounting). */
 typedef struct {
   int waves;              /* workgroups (= waves) launched */
@@ -85,6 +117,12 @@ typedef struct {
   size_t table_scratch_bytes;
 } mpe_launch_info;
 int mpe_last_launch_info(const mpe_ctx* ctx, mpe_launch_info* out);
+
+/* Per-launch timing of the heavy kernels with HIP events recorded on the launch stream (used by
+ * bench.py for the roofline line).  kind: 0 = modexp kernel, 1 = modmul kernel. */
+typedef struct { int kind; int bits; int exp_words; int batch; float ms; } mpe_prof_rec;
+int mpe_prof_enable(mpe_ctx* ctx, int on);       /* clears earlier records */
+int mpe_prof_collect(mpe_ctx* ctx, mpe_prof_rec* out, int max_records, int* n_out);  /* waits for the events */
 
 #ifdef __cplusplus
 }

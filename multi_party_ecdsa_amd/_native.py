@@ -21,6 +21,10 @@ class LaunchInfo(C.Structure):
                 ("lds_bytes_per_wave", C.c_int), ("table_scratch_bytes", C.c_size_t)]
 
 
+class ProfRec(C.Structure):
+    _fields_ = [("kind", C.c_int), ("bits", C.c_int), ("exp_words", C.c_int), ("batch", C.c_int), ("ms", C.c_float)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -41,6 +45,17 @@ def _load():
         "mpe_modexp": (ip, [vp, vp, ip, i32p, u32p, u32p, ip, u32p, vp]),
         "mpe_modmul": (ip, [vp, vp, ip, i32p, u32p, u32p, u32p, vp]),
         "mpe_last_launch_info": (ip, [vp, C.POINTER(LaunchInfo)]),
+        "mpe_prof_enable": (ip, [vp, ip]),
+        "mpe_prof_collect": (ip, [vp, C.POINTER(ProfRec), ip, C.POINTER(C.c_int)]),
+        "mpe_paillier_create_public": (ip, [vp, ip, u32p, C.POINTER(vp), vp]),
+        "mpe_paillier_create_private": (ip, [vp, ip, u32p, u32p, C.POINTER(vp), vp]),
+        "mpe_paillier_destroy": (ip, [vp]),
+        "mpe_paillier_nkeys": (ip, [vp]),
+        "mpe_paillier_n": (vp, [vp]),
+        "mpe_paillier_encrypt": (ip, [vp, vp, ip, i32p, u32p, u32p, u32p, vp]),
+        "mpe_paillier_decrypt": (ip, [vp, vp, ip, i32p, u32p, u32p, vp]),
+        "mpe_paillier_add": (ip, [vp, vp, ip, i32p, u32p, u32p, u32p, vp]),
+        "mpe_paillier_mul": (ip, [vp, vp, ip, i32p, u32p, u32p, ip, u32p, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -54,7 +69,10 @@ lib = _load()
 # every symbol include/mpecdsa_hip.h declares; tests check the library exports all of them
 EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy", "mpe_sync",
             "mpe_modset_create", "mpe_modset_destroy", "mpe_modset_count", "mpe_modset_bits",
-            "mpe_modexp", "mpe_modmul", "mpe_last_launch_info"]
+            "mpe_modexp", "mpe_modmul", "mpe_last_launch_info", "mpe_paillier_create_public",
+            "mpe_paillier_create_private", "mpe_paillier_destroy", "mpe_paillier_nkeys", "mpe_paillier_n",
+            "mpe_paillier_encrypt", "mpe_paillier_decrypt", "mpe_paillier_add", "mpe_paillier_mul",
+            "mpe_prof_enable", "mpe_prof_collect"]
 
 
 def check(rc, what):

@@ -261,12 +261,12 @@ __device__ __forceinline__ uint32_t word_from_limbs(const uint32_t* xl, int q) {
 // Stage one K32-word integer from global memory into the group's LDS region (coalesced per
 // group) and zero the padding words; the whole wave must call wave_lds_sync() afterwards.
 template <class C>
-__device__ __forceinline__ void stage_words(uint32_t* gl, const uint32_t* __restrict__ src, const Lane& ln) {
-  for (int q = ln.t; q < C::K32; q += C::TPI) gl[q] = src[q];
-  // limbs_from_words reads words q, q+1 for bit positions up to W*K - 1 (> BITS): zero them
+__device__ __forceinline__ void stage_words(uint32_t* gl, const uint32_t* __restrict__ src, const Lane& ln,
+                                            int nwords = C::K32) {
+  // limbs_from_words reads words q, q+1 for bit positions up to W*K - 1 (> BITS): zero the tail
   constexpr int LAST = (C::W * C::K - 1) / 32 + 1;
   static_assert(LAST < C::STRIDE, "staging padding must fit the group's LDS region");
-  for (int q = C::K32 + ln.t; q <= LAST; q += C::TPI) gl[q] = 0;
+  for (int q = ln.t; q <= LAST; q += C::TPI) gl[q] = q < nwords ? src[q] : 0u;
 }
 // Write this lane's limbs into the group's LDS region in limb order (the "b" operand layout).
 template <class C>

@@ -1,12 +1,13 @@
-// Internal definitions shared by the translation units of libmpecdsa_hip.so.
+// Internal definitions shared by the parts of libmpecdsa_hip.so (one translation unit: mpe_lib.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/mpecdsa_hip.h"
-#include "mpe_bigint.h"
+#include "mpe_kernels_heavy.h"
 
 struct mpe_ctx {
   int device = 0;
@@ -14,7 +15,14 @@ struct mpe_ctx {
   int modexp_waves_per_cu = 8;    // 2 waves/SIMD: the montmul loop holds ~230 VGPRs and already issues back-to-back
   void* tables = nullptr;         // window-table scratch, grown on demand
   size_t tables_bytes = 0;
+  // bump-allocated workspace for the intermediates of composite operations (Paillier, proofs)
+  void* ws = nullptr;
+  size_t ws_bytes = 0, ws_off = 0;
   mpe_launch_info last = {};
+  // optional per-launch timing of the heavy kernels (HIP events on the launch stream)
+  bool prof_on = false;
+  struct ProfEvt { hipEvent_t a, b; int kind, bits, exp_words, batch; };
+  std::vector<ProfEvt> prof;
 };
 
 struct mpe_modset {
@@ -25,7 +33,33 @@ struct mpe_modset {
   uint32_t* n_limbs = nullptr;    // [count][K]   modulus, internal radix
   uint32_t* one_limbs = nullptr;  // [count][K]   R mod n
   uint32_t* r2_limbs = nullptr;   // [count][K]   R^2 mod n
+  uint32_t* r2h_limbs = nullptr;  // [count][K]   2^bits R^2 mod n
   uint32_t* n0inv = nullptr;      // [count]      -n^-1 mod 2^W
 };
 
 void mpe_set_error(const char* what, hipError_t e);
+void mpe_set_error_msg(const char* what);
+
+namespace mpe {
+
+inline Rows rows(const uint32_t* p, int stride, const int32_t* idx = nullptr, int words = 0) {
+  return Rows{p, idx, stride, words};
+}
+inline Rows no_rows() { return Rows{nullptr, nullptr, 0, 0}; }
+
+// mod_sel: idx != null -> idx[i];  stride != 0 -> i;  else modulus 0
+int launch_modexp(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows base_lo, Rows base_hi, Rows exps,
+                  int exp_words, uint32_t* out, hipStream_t st);
+int launch_modmul(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows a, Rows b, uint32_t* out,
+                  hipStream_t st);
+int modset_create_dev(mpe_ctx* ctx, int bits, int count, const uint32_t* d_moduli, mpe_modset** out, hipStream_t st);
+
+// workspace: reserve once per composite call (may reallocate -> synchronises the stream), then bump-allocate
+int ws_reserve(mpe_ctx* ctx, size_t bytes, hipStream_t st);
+void* ws_alloc(mpe_ctx* ctx, size_t bytes);
+template <class T>
+inline T* ws_array(mpe_ctx* ctx, size_t count) { return (T*)ws_alloc(ctx, count * sizeof(T)); }
+
+inline int blocks_for(int n, int threads) { return (n + threads - 1) / threads; }
+
+}  // namespace mpe

@@ -1,0 +1,345 @@
+// Heavy kernels: modulus set-up, batched modular exponentiation and multiplication.
+// (device code only; the C-ABI wrappers live in mpe_lib.hip)
+#pragma once
+#include "mpe_bigint.h"
+
+namespace mpe {
+
+// A batch operand: row(i) = p + (idx ? idx[i] : i) * stride words.  stride = 0 broadcasts row 0.
+// words = number of valid words in a row (the rest of the integer is zero); 0 means "full width".
+struct Rows {
+  const uint32_t* p;
+  const int32_t* idx;
+  int stride;
+  int words;
+};
+__device__ __forceinline__ const uint32_t* row_of(const Rows& r, int i) {
+  return r.p + (size_t)(r.idx ? r.idx[i] : i) * (size_t)r.stride;
+}
+
+struct ModsetView {
+  const uint32_t* n_limbs;
+  const uint32_t* one_limbs;
+  const uint32_t* r2_limbs;
+  const uint32_t* r2h_limbs;   // 2^BITS * R^2 mod n (for double-width bases)
+  const uint32_t* n0inv;
+  int count;
+};
+
+// ---------------------------------------------------------------------------------------------
+// modulus set-up kernel: one group per modulus
+//   n limbs, n0inv = -n^-1 mod 2^W, one = R mod n, r2 = R^2 mod n, r2h = 2^BITS R^2 mod n
+//   (R = 2^(W*K))
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(64) modset_setup_kernel(int count, const uint32_t* __restrict__ moduli,
+                                                          uint32_t* __restrict__ n_limbs,
+                                                          uint32_t* __restrict__ one_limbs,
+                                                          uint32_t* __restrict__ r2_limbs,
+                                                          uint32_t* __restrict__ r2h_limbs,
+                                                          uint32_t* __restrict__ n0inv_out) {
+  __shared__ uint32_t lds[C::LDS_WORDS];
+  const Lane ln = make_lane<C>();
+  uint32_t* gl = lds + ln.g * C::STRIDE;
+  const int slot = blockIdx.x * C::GROUPS + ln.g;
+  const bool active = slot < count;
+  const int idx = active ? slot : count - 1;
+
+  stage_words<C>(gl, moduli + (size_t)idx * C::K32, ln);
+  wave_lds_sync();
+  uint32_t n[C::L];
+  limbs_from_words<C>(n, gl, ln);
+  // -n^-1 mod 2^32 by Newton iteration on the low word, then truncated to W bits
+  const uint32_t n0 = gl[0];
+  uint32_t inv = n0;                       // correct to 3 bits for odd n0
+#pragma unroll
+  for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
+  const uint32_t n0inv = (0u - inv) & C::MASK;
+  // bit length of n (lane 0 of the group scans the staged words)
+  int bl = 0;
+  if (ln.t0) {
+    for (int q = C::K32 - 1; q >= 0; --q) {
+      const uint32_t w = gl[q];
+      if (w != 0) { bl = q * 32 + (32 - __builtin_clz(w)); break; }
+    }
+  }
+  bl = (int)bcast0<C::TPI>((uint32_t)bl);
+  wave_lds_sync();
+
+  // x = 2^(bl-1) < n, then double (mod n) up to 2^(W*K) mod n
+  int64_t x[C::L];
+#pragma unroll
+  for (int i = 0; i < C::L; ++i) {
+    const int p = ln.t * C::L + i;
+    x[i] = (p == (bl - 1) / C::W) ? ((int64_t)1 << ((bl - 1) % C::W)) : 0;
+  }
+  const int doublings = C::W * C::K - (bl - 1);
+#pragma unroll 1
+  for (int d = 0; d < doublings; ++d) {
+#pragma unroll
+    for (int i = 0; i < C::L; ++i) x[i] *= 2;
+    full_normalize<C>(x, ln);
+    if (cmp_ge<C>(x, n, ln)) {
+#pragma unroll
+      for (int i = 0; i < C::L; ++i) x[i] -= (int64_t)n[i];
+      full_normalize<C>(x, ln);
+    }
+  }
+  uint32_t one[C::L];
+#pragma unroll
+  for (int i = 0; i < C::L; ++i) one[i] = (uint32_t)x[i];
+
+  auto dbl = [&](uint32_t (&v)[C::L]) {
+    int64_t z[C::L];
+#pragma unroll
+    for (int i = 0; i < C::L; ++i) z[i] = 2 * (int64_t)v[i];
+    full_normalize<C>(z, ln);
+    if (cmp_ge<C>(z, n, ln)) {
+#pragma unroll
+      for (int i = 0; i < C::L; ++i) z[i] -= (int64_t)n[i];
+      full_normalize<C>(z, ln);
+    }
+#pragma unroll
+    for (int i = 0; i < C::L; ++i) v[i] = (uint32_t)z[i];
+  };
+  // Mont(2^e) by square-and-double in the Montgomery domain, for e = W*K (-> r2) and e = BITS
+  // (-> Mont(2^BITS), then r2h = montmul(r2, Mont(2^BITS)) = 2^BITS R^2).  One montmul call site:
+  // pass 0 computes r2, pass 1 computes Mont(2^BITS), pass 2 is the single product for r2h.
+  uint32_t mont2[C::L], r2[C::L], y[C::L];
+#pragma unroll
+  for (int i = 0; i < C::L; ++i) mont2[i] = one[i];
+  dbl(mont2);                                         // Mont(2^1)
+#pragma unroll
+  for (int i = 0; i < C::L; ++i) { y[i] = mont2[i]; r2[i] = 0; }
+  constexpr int E0 = C::W * C::K, E1 = C::BITS;
+  constexpr int TOP0 = 31 - __builtin_clz((unsigned)E0), TOP1 = 31 - __builtin_clz((unsigned)E1);
+  int pass = 0, b = TOP0 - 1;
+#pragma unroll 1
+  while (pass < 3) {
+    if (pass == 2) {
+      put_limbs<C>(gl, r2, ln);                      // y = Mont(2^BITS); multiply by r2
+    } else {
+      put_limbs<C>(gl, y, ln);                       // square
+    }
+    wave_lds_sync();
+    uint32_t r[C::L];
+    montmul<C>(r, y, gl, n, n0inv, ln);
+    wave_lds_sync();
+    reduce_once<C>(r, n, ln);
+#pragma unroll
+    for (int i = 0; i < C::L; ++i) y[i] = r[i];
+    if (pass == 2) break;
+    const int E = pass == 0 ? E0 : E1;
+    if ((E >> b) & 1) dbl(y);
+    if (--b < 0) {
+      if (pass == 0) {
+#pragma unroll
+        for (int i = 0; i < C::L; ++i) { r2[i] = y[i]; y[i] = mont2[i]; }
+        b = TOP1 - 1;
+      }
+      ++pass;
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < C::L; ++i) {
+      const size_t o = (size_t)idx * C::K + ln.t * C::L + i;
+      n_limbs[o] = n[i];
+      one_limbs[o] = one[i];
+      r2_limbs[o] = r2[i];
+      r2h_limbs[o] = y[i];
+    }
+    if (ln.t0) n0inv_out[idx] = n0inv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers shared by the modexp / modmul kernels
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void load_owner(uint32_t (&v)[C::L], const uint32_t* __restrict__ src, const Lane& ln) {
+#pragma unroll
+  for (int i = 0; i < C::L; ++i) v[i] = src[ln.t * C::L + i];
+}
+template <class C>
+__device__ __forceinline__ void store_owner(uint32_t* __restrict__ dst, const uint32_t (&v)[C::L], const Lane& ln) {
+#pragma unroll
+  for (int i = 0; i < C::L; ++i) dst[ln.t * C::L + i] = v[i];
+}
+// global limb array (K words) -> the group's LDS "b" region, coalesced within the group
+template <class C>
+__device__ __forceinline__ void copy_to_lds(uint32_t* gl, const uint32_t* __restrict__ src, const Lane& ln) {
+#pragma unroll
+  for (int i = 0; i < C::L; ++i) gl[ln.t + C::TPI * i] = src[ln.t + C::TPI * i];
+}
+// interface words in global memory -> this lane's limbs (through the group's LDS region)
+template <class C>
+__device__ __forceinline__ void load_words_as_limbs(uint32_t (&v)[C::L], uint32_t* gl, const uint32_t* __restrict__ src,
+                                                    int nwords, const Lane& ln) {
+  stage_words<C>(gl, src, ln, nwords ? nwords : C::K32);
+  wave_lds_sync();
+  limbs_from_words<C>(v, gl, ln);
+  wave_lds_sync();
+}
+// canonical residue (exact limbs) -> interface words in global memory
+template <class C>
+__device__ __forceinline__ void store_limbs_as_words(uint32_t* __restrict__ dst, uint32_t* gl, const uint32_t (&v)[C::L],
+                                                     bool active, const Lane& ln) {
+  put_limbs<C>(gl, v, ln);
+  if (ln.t0) { gl[C::K] = 0; gl[C::K + 1] = 0; }
+  wave_lds_sync();
+  if (active)
+    for (int q = ln.t; q < C::K32; q += C::TPI) dst[q] = word_from_limbs<C>(gl, q);
+  wave_lds_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// modexp kernel: persistent waves, each group walks the batch with a grid stride.
+//   out[i] = (base_lo[i] + 2^BITS * base_hi[i]) ^ exp[i]  mod  modulus[mod(i)]
+// base_hi.p == nullptr -> single-width base.  Fixed 4-bit windows, constant operation sequence.
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Rows mod_sel, Rows base_lo, Rows base_hi,
+                                                    Rows exps, int exp_words, uint32_t* __restrict__ out,
+                                                    uint32_t* __restrict__ tables) {
+  __shared__ uint32_t lds[C::LDS_WORDS];
+  const Lane ln = make_lane<C>();
+  uint32_t* gl = lds + ln.g * C::STRIDE;
+  const int slot = blockIdx.x * C::GROUPS + ln.g;
+  const int nslots = gridDim.x * C::GROUPS;
+  uint32_t* tab = tables + (size_t)slot * 16 * C::K;     // this group's 16-entry window table
+  const int trips = (batch + nslots - 1) / nslots;
+  const int nwin = exp_words * 8;
+  const bool wide = base_hi.p != nullptr;
+  // One Montgomery multiplication per step; the step index alone (wave-uniform) decides where the
+  // multiplier comes from and where the product goes, so montmul is instantiated exactly once:
+  //   step -1 (wide)    : hi * (2^BITS R^2)           -> Mont(2^BITS hi), kept aside
+  //   step 0            : cur = base * R^2 (+ aside)  -> Mont(base) = tab[1]
+  //   step 1..14        : cur = cur * Mont(base)      -> tab[2..15]
+  //   then per window   : 4 squarings, 1 multiplication by tab[window]
+  //   last step         : cur = cur * 1               -> leaves the Montgomery domain
+  const int nsteps = 15 + 5 * (nwin - 1) + 1;
+
+#pragma unroll 1
+  for (int trip = 0; trip < trips; ++trip) {
+    const int inst = trip * nslots + slot;
+    const bool active = inst < batch;
+    const int idx = active ? inst : batch - 1;
+    const int mi = mod_sel.idx ? mod_sel.idx[idx] : (mod_sel.stride ? idx : 0);
+    const uint32_t* ex = row_of(exps, idx);
+
+    uint32_t n[C::L];
+    load_owner<C>(n, ms.n_limbs + (size_t)mi * C::K, ln);
+    const uint32_t n0inv = ms.n0inv[mi];
+
+    uint32_t cur[C::L], aside[C::L];
+#pragma unroll
+    for (int i = 0; i < C::L; ++i) aside[i] = 0;
+    load_words_as_limbs<C>(cur, gl, wide ? row_of(base_hi, idx) : row_of(base_lo, idx),
+                           wide ? base_hi.words : base_lo.words, ln);
+    {
+      uint32_t one[C::L];
+      load_owner<C>(one, ms.one_limbs + (size_t)mi * C::K, ln);
+      store_owner<C>(tab, one, ln);                         // tab[0] = Mont(1)
+    }
+
+#pragma unroll 1
+    for (int step = wide ? -1 : 0; step < nsteps; ++step) {
+      // ---- multiplier -> LDS ----
+      if (step == -1) {
+        copy_to_lds<C>(gl, ms.r2h_limbs + (size_t)mi * C::K, ln);
+      } else if (step == 0) {
+        copy_to_lds<C>(gl, ms.r2_limbs + (size_t)mi * C::K, ln);
+      } else if (step == 1) {
+        put_limbs<C>(gl, cur, ln);                          // Mont(base) stays in LDS for steps 1..14
+      } else if (step >= 15 && step < nsteps - 1) {
+        const int k = step - 15;
+        const int wi = nwin - 2 - k / 5;
+        if (k % 5 == 4) {
+          const uint32_t w = (ex[wi >> 3] >> ((wi & 7) * 4)) & 15u;
+          copy_to_lds<C>(gl, tab + (size_t)w * C::K, ln);
+        } else {
+          put_limbs<C>(gl, cur, ln);                        // squaring
+        }
+      } else if (step == nsteps - 1) {
+#pragma unroll
+        for (int i = 0; i < C::L; ++i) gl[ln.t * C::L + i] = (ln.t == 0 && i == 0) ? 1u : 0u;
+      }
+      wave_lds_sync();
+      uint32_t r[C::L];
+      montmul<C>(r, cur, gl, n, n0inv, ln);
+      wave_lds_sync();
+#pragma unroll
+      for (int i = 0; i < C::L; ++i) cur[i] = r[i];
+      if (step == -1) {
+#pragma unroll
+        for (int i = 0; i < C::L; ++i) aside[i] = cur[i];
+        load_words_as_limbs<C>(cur, gl, row_of(base_lo, idx), base_lo.words, ln);
+      } else if (step == 0 && wide) {
+        // Mont(lo) + Mont(2^BITS hi): value < 4n, settle the limbs exactly before it is squared
+        int64_t z[C::L];
+#pragma unroll
+        for (int i = 0; i < C::L; ++i) z[i] = (int64_t)cur[i] + (int64_t)aside[i];
+        full_normalize<C>(z, ln);
+#pragma unroll
+        for (int i = 0; i < C::L; ++i) cur[i] = (uint32_t)z[i];
+      }
+      // ---- product -> window table ----
+      if (step >= 0 && step < 15) {
+        store_owner<C>(tab + (size_t)(step + 1) * C::K, cur, ln);
+        if (step == 14) {
+          // table complete: start the ladder from the top window
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          const uint32_t w = (ex[(nwin - 1) >> 3] >> (((nwin - 1) & 7) * 4)) & 15u;
+          load_owner<C>(cur, tab + (size_t)w * C::K, ln);
+        }
+      }
+    }
+    // canonical residue -> interface words
+    reduce_once<C>(cur, n, ln);
+    store_limbs_as_words<C>(out + (size_t)idx * C::K32, gl, cur, active, ln);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// modmul kernel: out = a*b mod n   (two Montgomery multiplications: by b, then by R^2)
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(64) modmul_kernel(int batch, ModsetView ms, Rows mod_sel, Rows A, Rows B,
+                                                    uint32_t* __restrict__ out) {
+  __shared__ uint32_t lds[C::LDS_WORDS];
+  const Lane ln = make_lane<C>();
+  uint32_t* gl = lds + ln.g * C::STRIDE;
+  const int slot = blockIdx.x * C::GROUPS + ln.g;
+  const int nslots = gridDim.x * C::GROUPS;
+  const int trips = (batch + nslots - 1) / nslots;
+#pragma unroll 1
+  for (int trip = 0; trip < trips; ++trip) {
+    const int inst = trip * nslots + slot;
+    const bool active = inst < batch;
+    const int idx = active ? inst : batch - 1;
+    const int mi = mod_sel.idx ? mod_sel.idx[idx] : (mod_sel.stride ? idx : 0);
+    uint32_t n[C::L];
+    load_owner<C>(n, ms.n_limbs + (size_t)mi * C::K, ln);
+    const uint32_t n0inv = ms.n0inv[mi];
+
+    uint32_t cur[C::L], b[C::L];
+    load_words_as_limbs<C>(cur, gl, row_of(A, idx), A.words, ln);
+    load_words_as_limbs<C>(b, gl, row_of(B, idx), B.words, ln);
+#pragma unroll 1
+    for (int step = 0; step < 2; ++step) {
+      if (step == 0) put_limbs<C>(gl, b, ln);                                  // a*b/R
+      else copy_to_lds<C>(gl, ms.r2_limbs + (size_t)mi * C::K, ln);           // * R^2 / R
+      wave_lds_sync();
+      uint32_t r[C::L];
+      montmul<C>(r, cur, gl, n, n0inv, ln);
+      wave_lds_sync();
+#pragma unroll
+      for (int i = 0; i < C::L; ++i) cur[i] = r[i];
+    }
+    reduce_once<C>(cur, n, ln);
+    store_limbs_as_words<C>(out + (size_t)idx * C::K32, gl, cur, active, ln);
+  }
+}
+
+}  // namespace mpe

@@ -1,0 +1,257 @@
+// libmpecdsa_hip.so — C-ABI (include/mpecdsa_hip.h) over the gfx950 kernels.  Single translation unit.
+#include "mpe_internal.h"
+
+using namespace mpe;
+
+thread_local std::string g_last_error;
+void mpe_set_error(const char* what, hipError_t e) { g_last_error = std::string(what) + ": " + hipGetErrorString(e); }
+void mpe_set_error_msg(const char* what) { g_last_error = what; }
+
+// =============================================================================================
+// core: contexts, workspace, modulus sets, modexp / modmul launches
+// =============================================================================================
+namespace mpe {
+
+int ws_reserve(mpe_ctx* ctx, size_t bytes, hipStream_t st) {
+  ctx->ws_off = 0;
+  if (bytes <= ctx->ws_bytes) return MPE_OK;
+  if (ctx->ws) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+  const size_t want = bytes + (bytes >> 2) + (1u << 20);
+  hipError_t e = hipMalloc(&ctx->ws, want);
+  if (e != hipSuccess) { mpe_set_error("hipMalloc(workspace)", e); return MPE_E_NOMEM; }
+  ctx->ws_bytes = want;
+  return MPE_OK;
+}
+void* ws_alloc(mpe_ctx* ctx, size_t bytes) {
+  const size_t off = (ctx->ws_off + 255) & ~(size_t)255;
+  if (off + bytes > ctx->ws_bytes) return nullptr;     // ws_reserve under-estimated: a library bug
+  ctx->ws_off = off + bytes;
+  return (char*)ctx->ws + off;
+}
+
+static void prof_begin(mpe_ctx* ctx, hipStream_t st, int kind, int bits, int exp_words, int batch) {
+  if (!ctx->prof_on) return;
+  mpe_ctx::ProfEvt ev;
+  ev.kind = kind; ev.bits = bits; ev.exp_words = exp_words; ev.batch = batch;
+  (void)hipEventCreate(&ev.a);
+  (void)hipEventCreate(&ev.b);
+  (void)hipEventRecord(ev.a, st);
+  ctx->prof.push_back(ev);
+}
+static void prof_end(mpe_ctx* ctx, hipStream_t st) {
+  if (ctx->prof_on && !ctx->prof.empty()) (void)hipEventRecord(ctx->prof.back().b, st);
+}
+
+static ModsetView view_of(const mpe_modset* ms) {
+  ModsetView v;
+  v.n_limbs = ms->n_limbs; v.one_limbs = ms->one_limbs; v.r2_limbs = ms->r2_limbs; v.r2h_limbs = ms->r2h_limbs;
+  v.n0inv = ms->n0inv; v.count = ms->count;
+  return v;
+}
+
+// persistent grid: at most the resident-wave capacity; when the batch needs several trips the
+// grid shrinks to the smallest one that still finishes in that many trips (no half-empty tail)
+template <class C>
+static int grid_for(const mpe_ctx* ctx, int batch, int waves_per_cu) {
+  const int need = (batch + C::GROUPS - 1) / C::GROUPS;
+  const int cap = ctx->cus * waves_per_cu;
+  if (need <= cap) return need;
+  const int trips = (need + cap - 1) / cap;
+  return (need + trips - 1) / trips;
+}
+
+template <class C>
+static int modset_create_impl(int count, const uint32_t* d_moduli, mpe_modset** out, hipStream_t st) {
+  mpe_modset* ms = new (std::nothrow) mpe_modset();
+  if (!ms) return MPE_E_NOMEM;
+  ms->bits = C::BITS;
+  ms->count = count;
+  ms->K = C::K;
+  const size_t words = (size_t)count * C::K;
+  const size_t total = (4 * words + (size_t)count) * sizeof(uint32_t);
+  hipError_t e = hipMalloc(&ms->blob, total);
+  if (e != hipSuccess) { delete ms; mpe_set_error("hipMalloc(modset)", e); return MPE_E_NOMEM; }
+  uint32_t* p = (uint32_t*)ms->blob;
+  ms->n_limbs = p;
+  ms->one_limbs = p + words;
+  ms->r2_limbs = p + 2 * words;
+  ms->r2h_limbs = p + 3 * words;
+  ms->n0inv = p + 4 * words;
+  const int blocks = (count + C::GROUPS - 1) / C::GROUPS;
+  hipLaunchKernelGGL(modset_setup_kernel<C>, dim3(blocks), dim3(64), 0, st, count, d_moduli, ms->n_limbs,
+                     ms->one_limbs, ms->r2_limbs, ms->r2h_limbs, ms->n0inv);
+  e = hipGetLastError();
+  if (e != hipSuccess) { (void)hipFree(ms->blob); delete ms; mpe_set_error("modset_setup_kernel", e); return MPE_E_HIP; }
+  *out = ms;
+  return MPE_OK;
+}
+
+int modset_create_dev(mpe_ctx* ctx, int bits, int count, const uint32_t* d_moduli, mpe_modset** out, hipStream_t st) {
+  (void)ctx;
+  if (bits == 4096) return modset_create_impl<Cfg4096>(count, d_moduli, out, st);
+  if (bits == 2048) return modset_create_impl<Cfg2048>(count, d_moduli, out, st);
+  return MPE_E_ARG;
+}
+
+template <class C>
+static int modexp_impl(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows base_lo, Rows base_hi, Rows exps,
+                       int exp_words, uint32_t* d_out, hipStream_t st) {
+  const int grid = grid_for<C>(ctx, batch, ctx->modexp_waves_per_cu);
+  const size_t need = (size_t)grid * C::GROUPS * 16 * C::K * sizeof(uint32_t);
+  if (need > ctx->tables_bytes) {
+    if (ctx->tables) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->tables); ctx->tables = nullptr; ctx->tables_bytes = 0; }
+    hipError_t e = hipMalloc(&ctx->tables, need);
+    if (e != hipSuccess) { mpe_set_error("hipMalloc(window tables)", e); return MPE_E_NOMEM; }
+    ctx->tables_bytes = need;
+  }
+  prof_begin(ctx, st, 0, C::BITS, exp_words, batch);
+  hipLaunchKernelGGL(modexp_kernel<C>, dim3(grid), dim3(64), 0, st, batch, view_of(ms), mod_sel, base_lo, base_hi, exps,
+                     exp_words, d_out, (uint32_t*)ctx->tables);
+  prof_end(ctx, st);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mpe_set_error("modexp_kernel", e); return MPE_E_HIP; }
+  ctx->last.waves = grid;
+  ctx->last.ints_per_wave = C::GROUPS;
+  ctx->last.limbs = C::K;
+  ctx->last.limb_bits = C::W;
+  ctx->last.lds_bytes_per_wave = C::LDS_WORDS * 4;
+  ctx->last.table_scratch_bytes = need;
+  return MPE_OK;
+}
+
+int launch_modexp(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows base_lo, Rows base_hi, Rows exps,
+                  int exp_words, uint32_t* out, hipStream_t st) {
+  if (batch == 0) return MPE_OK;
+  if (ms->bits == 4096) return modexp_impl<Cfg4096>(ctx, ms, batch, mod_sel, base_lo, base_hi, exps, exp_words, out, st);
+  if (ms->bits == 2048) return modexp_impl<Cfg2048>(ctx, ms, batch, mod_sel, base_lo, base_hi, exps, exp_words, out, st);
+  return MPE_E_ARG;
+}
+
+template <class C>
+static int modmul_impl(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows a, Rows b, uint32_t* d_out,
+                       hipStream_t st) {
+  const int grid = grid_for<C>(ctx, batch, 16);
+  prof_begin(ctx, st, 1, C::BITS, 0, batch);
+  hipLaunchKernelGGL(modmul_kernel<C>, dim3(grid), dim3(64), 0, st, batch, view_of(ms), mod_sel, a, b, d_out);
+  prof_end(ctx, st);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mpe_set_error("modmul_kernel", e); return MPE_E_HIP; }
+  return MPE_OK;
+}
+
+int launch_modmul(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows a, Rows b, uint32_t* out,
+                  hipStream_t st) {
+  if (batch == 0) return MPE_OK;
+  if (ms->bits == 4096) return modmul_impl<Cfg4096>(ctx, ms, batch, mod_sel, a, b, out, st);
+  if (ms->bits == 2048) return modmul_impl<Cfg2048>(ctx, ms, batch, mod_sel, a, b, out, st);
+  return MPE_E_ARG;
+}
+
+// mod_idx == NULL means: one modulus for everybody when count == 1, else modulus i for item i
+static Rows mod_selector(const mpe_modset* ms, const int32_t* d_mod_idx) {
+  return Rows{nullptr, d_mod_idx, (d_mod_idx == nullptr && ms->count != 1) ? 1 : 0, 0};
+}
+
+}  // namespace mpe
+
+#include "mpe_paillier.h"
+
+extern "C" {
+
+const char* mpe_version(void) { return "mpecdsa-hip 0.2.0 (gfx950)"; }
+const char* mpe_last_error(void) { return g_last_error.c_str(); }
+
+int mpe_ctx_create(mpe_ctx** out, int device) {
+  if (!out) return MPE_E_ARG;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) { mpe_set_error("hipSetDevice", e); return MPE_E_HIP; }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) { mpe_set_error("hipGetDeviceProperties", e); return MPE_E_HIP; }
+  mpe_ctx* c = new (std::nothrow) mpe_ctx();
+  if (!c) return MPE_E_NOMEM;
+  c->device = device;
+  c->cus = prop.multiProcessorCount;
+  *out = c;
+  return MPE_OK;
+}
+
+int mpe_ctx_destroy(mpe_ctx* ctx) {
+  if (!ctx) return MPE_E_ARG;
+  if (ctx->tables) (void)hipFree(ctx->tables);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  for (auto& ev : ctx->prof) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  delete ctx;
+  return MPE_OK;
+}
+
+int mpe_sync(mpe_ctx* ctx, void* stream) {
+  (void)ctx;
+  hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) { mpe_set_error("hipStreamSynchronize", e); return MPE_E_HIP; }
+  return MPE_OK;
+}
+
+int mpe_last_launch_info(const mpe_ctx* ctx, mpe_launch_info* out) {
+  if (!ctx || !out) return MPE_E_ARG;
+  *out = ctx->last;
+  return MPE_OK;
+}
+
+int mpe_prof_enable(mpe_ctx* ctx, int on) {
+  if (!ctx) return MPE_E_ARG;
+  for (auto& ev : ctx->prof) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  ctx->prof.clear();
+  ctx->prof_on = on != 0;
+  return MPE_OK;
+}
+
+int mpe_prof_collect(mpe_ctx* ctx, mpe_prof_rec* out, int max_records, int* n_out) {
+  if (!ctx || !out || !n_out) return MPE_E_ARG;
+  int n = 0;
+  for (auto& ev : ctx->prof) {
+    if (n >= max_records) break;
+    if (hipEventSynchronize(ev.b) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev.a, ev.b) != hipSuccess) continue;
+    out[n].kind = ev.kind; out[n].bits = ev.bits; out[n].exp_words = ev.exp_words; out[n].batch = ev.batch; out[n].ms = ms;
+    ++n;
+  }
+  *n_out = n;
+  return MPE_OK;
+}
+
+int mpe_modset_count(const mpe_modset* ms) { return ms ? ms->count : MPE_E_ARG; }
+int mpe_modset_bits(const mpe_modset* ms) { return ms ? ms->bits : MPE_E_ARG; }
+
+int mpe_modset_destroy(mpe_modset* ms) {
+  if (!ms) return MPE_E_ARG;
+  if (ms->blob) (void)hipFree(ms->blob);
+  delete ms;
+  return MPE_OK;
+}
+
+int mpe_modset_create(mpe_ctx* ctx, int bits, int count, const uint32_t* d_moduli, mpe_modset** out, void* stream) {
+  if (!ctx || !out || !d_moduli || count <= 0) return MPE_E_ARG;
+  return modset_create_dev(ctx, bits, count, d_moduli, out, (hipStream_t)stream);
+}
+
+int mpe_modexp(mpe_ctx* ctx, const mpe_modset* ms, int batch, const int32_t* d_mod_idx, const uint32_t* d_base,
+               const uint32_t* d_exp, int exp_words, uint32_t* d_out, void* stream) {
+  if (!ctx || !ms || !d_base || !d_exp || !d_out || batch < 0 || exp_words <= 0) return MPE_E_ARG;
+  if (!d_mod_idx && ms->count != 1 && ms->count < batch) return MPE_E_ARG;
+  const int k32 = ms->bits / 32;
+  return launch_modexp(ctx, ms, batch, mod_selector(ms, d_mod_idx), rows(d_base, k32), no_rows(), rows(d_exp, exp_words),
+                       exp_words, d_out, (hipStream_t)stream);
+}
+
+int mpe_modmul(mpe_ctx* ctx, const mpe_modset* ms, int batch, const int32_t* d_mod_idx, const uint32_t* d_a,
+               const uint32_t* d_b, uint32_t* d_out, void* stream) {
+  if (!ctx || !ms || !d_a || !d_b || !d_out || batch < 0) return MPE_E_ARG;
+  if (!d_mod_idx && ms->count != 1 && ms->count < batch) return MPE_E_ARG;
+  const int k32 = ms->bits / 32;
+  return launch_modmul(ctx, ms, batch, mod_selector(ms, d_mod_idx), rows(d_a, k32), rows(d_b, k32), d_out,
+                       (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from . import _native as N
+N_ = N
 from .words import ints_to_words, words_to_ints
 
 
@@ -38,6 +39,15 @@ class Context:
         li = N.LaunchInfo()
         N.check(N.lib.mpe_last_launch_info(self.h, C.byref(li)), "mpe_last_launch_info")
         return {k: getattr(li, k) for k, _ in li._fields_}
+
+    def prof_enable(self, on=True):
+        N.check(N.lib.mpe_prof_enable(self.h, int(on)), "mpe_prof_enable")
+
+    def prof_collect(self, max_records=4096):
+        arr = (N.ProfRec * max_records)()
+        n = C.c_int(0)
+        N.check(N.lib.mpe_prof_collect(self.h, arr, max_records, C.byref(n)), "mpe_prof_collect")
+        return [dict(kind=r.kind, bits=r.bits, exp_words=r.exp_words, batch=r.batch, ms=r.ms) for r in arr[:n.value]]
 
     def close(self):
         if self.h:
@@ -121,3 +131,98 @@ def mod_mul(ctx, ms, a, b, mod_idx=None):
     d_out = modmul_device(ctx, ms, d_a, d_b, d_mod_idx=d_idx)
     ctx.sync()
     return words_to_ints(_to_np_u32(d_out))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class PaillierKeys:
+    """A set of Paillier-2048 keys in HBM (`EncryptionKey{n,nn}` / `DecryptionKey{p,q}` of kzen-paillier).
+    Build from moduli (public) or from primes (private; enables decrypt)."""
+
+    def __init__(self, ctx, N=None, p=None, q=None):
+        self.ctx = ctx
+        h = C.c_void_p()
+        if p is not None:
+            self.d_p = _dev_u32(ints_to_words(p, 32), ctx.device)
+            self.d_q = _dev_u32(ints_to_words(q, 32), ctx.device)
+            N_.check(N_.lib.mpe_paillier_create_private(ctx.h, len(p), _ptr(self.d_p), _ptr(self.d_q), C.byref(h),
+                                                        ctx.stream()), "mpe_paillier_create_private")
+            self.private = True
+        else:
+            self.d_N = _dev_u32(ints_to_words(N, 64), ctx.device)
+            N_.check(N_.lib.mpe_paillier_create_public(ctx.h, len(N), _ptr(self.d_N), C.byref(h), ctx.stream()),
+                     "mpe_paillier_create_public")
+            self.private = False
+        self.h = h
+        self.nkeys = N_.lib.mpe_paillier_nkeys(h)
+
+    def close(self):
+        if self.h:
+            N_.lib.mpe_paillier_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- device-tensor API (int32 tensors holding u32 words) ----
+    def encrypt_device(self, d_m, d_r, d_key_idx=None, d_c=None):
+        """`Paillier::encrypt_with_chosen_randomness` batched: m,r [B,64] -> c [B,128]"""
+        B = d_m.shape[0]
+        if d_c is None:
+            d_c = torch.empty((B, 128), dtype=torch.int32, device=d_m.device)
+        N_.check(N_.lib.mpe_paillier_encrypt(self.ctx.h, self.h, B, _ptr(d_key_idx), _ptr(d_m), _ptr(d_r), _ptr(d_c),
+                                             self.ctx.stream()), "mpe_paillier_encrypt")
+        return d_c
+
+    def decrypt_device(self, d_c, d_key_idx=None, d_m=None):
+        """`Paillier::decrypt` batched: c [B,128] -> m [B,64]"""
+        B = d_c.shape[0]
+        if d_m is None:
+            d_m = torch.empty((B, 64), dtype=torch.int32, device=d_c.device)
+        N_.check(N_.lib.mpe_paillier_decrypt(self.ctx.h, self.h, B, _ptr(d_key_idx), _ptr(d_c), _ptr(d_m),
+                                             self.ctx.stream()), "mpe_paillier_decrypt")
+        return d_m
+
+    def add_device(self, d_c1, d_c2, d_key_idx=None):
+        out = torch.empty_like(d_c1)
+        N_.check(N_.lib.mpe_paillier_add(self.ctx.h, self.h, d_c1.shape[0], _ptr(d_key_idx), _ptr(d_c1), _ptr(d_c2),
+                                         _ptr(out), self.ctx.stream()), "mpe_paillier_add")
+        return out
+
+    def mul_device(self, d_c, d_k, d_key_idx=None):
+        out = torch.empty_like(d_c)
+        N_.check(N_.lib.mpe_paillier_mul(self.ctx.h, self.h, d_c.shape[0], _ptr(d_key_idx), _ptr(d_c), _ptr(d_k),
+                                         d_k.shape[1], _ptr(out), self.ctx.stream()), "mpe_paillier_mul")
+        return out
+
+    # ---- Python-int convenience wrappers ----
+    def _idx(self, key_idx):
+        return None if key_idx is None else torch.tensor(key_idx, dtype=torch.int32, device=self.ctx.device)
+
+    def encrypt(self, m, r, key_idx=None):
+        d = self.encrypt_device(_dev_u32(ints_to_words(m, 64), self.ctx.device),
+                                _dev_u32(ints_to_words(r, 64), self.ctx.device), self._idx(key_idx))
+        self.ctx.sync()
+        return words_to_ints(_to_np_u32(d))
+
+    def decrypt(self, c, key_idx=None):
+        d = self.decrypt_device(_dev_u32(ints_to_words(c, 128), self.ctx.device), self._idx(key_idx))
+        self.ctx.sync()
+        return words_to_ints(_to_np_u32(d))
+
+    def add(self, c1, c2, key_idx=None):
+        d = self.add_device(_dev_u32(ints_to_words(c1, 128), self.ctx.device),
+                            _dev_u32(ints_to_words(c2, 128), self.ctx.device), self._idx(key_idx))
+        self.ctx.sync()
+        return words_to_ints(_to_np_u32(d))
+
+    def mul(self, c, k, key_idx=None, k_words=8):
+        d = self.mul_device(_dev_u32(ints_to_words(c, 128), self.ctx.device),
+                            _dev_u32(ints_to_words(k, k_words), self.ctx.device), self._idx(key_idx))
+        self.ctx.sync()
+        return words_to_ints(_to_np_u32(d))

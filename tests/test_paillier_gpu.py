@@ -1,0 +1,116 @@
+"""GPU parity tests: batched Paillier encrypt / decrypt / add / mul through the C-ABI vs the GMP
+oracle and the golden vectors; BASELINE.json config 2 (65 536 ops, 16 keys) via round-trip and
+homomorphism properties."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fixtures as F
+import orc
+import pyref
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+H = lambda s: int(s, 16)
+
+
+@pytest.fixture(scope="module")
+def pk(gpu_ctx, keys):
+    from multi_party_ecdsa_amd import engine as E
+    return E.PaillierKeys(gpu_ctx, p=[k.p for k in keys], q=[k.q for k in keys])
+
+
+def test_private_keyset_derives_n(pk, keys, gpu_ctx):
+    from multi_party_ecdsa_amd import _native as N
+    import ctypes
+    ptr = N.lib.mpe_paillier_n(pk.h)
+    t = torch.empty((len(keys), 64), dtype=torch.int32, device=gpu_ctx.device)
+    # read the device table through torch: copy from raw pointer
+    buf = (ctypes.c_uint32 * (len(keys) * 64)).from_address  # noqa: F841 (documentation of the layout)
+    c = pk.encrypt([0] * len(keys), [1] * len(keys), list(range(len(keys))))      # Enc(0; r=1) = 1
+    assert c == [1] * len(keys)
+    c = pk.encrypt([1] * len(keys), [1] * len(keys), list(range(len(keys))))      # Enc(1; r=1) = 1 + N
+    assert c == [1 + k.N for k in keys]
+    assert ptr and t.shape[0] == pk.nkeys
+
+
+def test_paillier_golden(pk, keys):
+    with open(os.path.join(HERE, "golden", "golden_small.json")) as f:
+        gold = json.load(f)["paillier"]
+    kidx = [g["key"] for g in gold]
+    c = pk.encrypt([H(g["m"]) for g in gold], [H(g["r"]) for g in gold], kidx)
+    assert c == [H(g["c"]) for g in gold]
+    assert pk.decrypt(c, kidx) == [H(g["m"]) for g in gold]
+
+
+def test_encrypt_decrypt_vs_oracle_ragged(pk, keys):
+    r = F.Rng("gpu-paillier")
+    B = 203                                       # not a multiple of 8 or 16
+    kidx = [(3 * i) % len(keys) for i in range(B)]
+    m = [r.below(pyref.Q) if i % 2 == 0 else r.below(keys[kidx[i]].N) for i in range(B)]   # k_i-like / beta'-like
+    rr = [r.below(keys[kidx[i]].N) for i in range(B)]
+    m[0], m[1], rr[2] = 0, keys[kidx[1]].N - 1, 1                                         # edges
+    c = pk.encrypt(m, rr, kidx)
+    N = F.words([k.N for k in keys], 64)
+    want = F.ints(orc.paillier_encrypt(N, F.words(m, 64), F.words(rr, 64), kidx))
+    assert c == want
+    got_m = pk.decrypt(c, kidx)
+    want_m = F.ints(orc.paillier_decrypt(F.words([k.p for k in keys], 32), F.words([k.q for k in keys], 32),
+                                         F.words(c, 128), kidx))
+    assert got_m == want_m == m
+
+
+def test_add_mul_vs_oracle_and_mta_identity(pk, keys):
+    """Paillier::mul / add as used by MessageB::b (mta/mod.rs:140-145), then alpha + beta = a*b (mta/test.rs:16-18)"""
+    r = F.Rng("gpu-mta")
+    B = 37
+    kidx = [i % len(keys) for i in range(B)]
+    a = [r.below(pyref.Q) for _ in range(B)]
+    b = [r.below(pyref.Q) for _ in range(B)]
+    bt = [r.below(keys[k].N) for k in kidx]
+    c_a = pk.encrypt(a, [r.below(keys[k].N) for k in kidx], kidx)
+    c_bt = pk.encrypt(bt, [r.below(keys[k].N) for k in kidx], kidx)
+    b_c_a = pk.mul(c_a, b, kidx)
+    c_b = pk.add(b_c_a, c_bt, kidx)
+    N = F.words([k.N for k in keys], 64)
+    assert b_c_a == F.ints(orc.paillier_mul(N, F.words(c_a, 128), F.words(b, 64), kidx))
+    assert c_b == F.ints(orc.paillier_add(N, F.words(b_c_a, 128), F.words(c_bt, 128), kidx))
+    alpha = [x % pyref.Q for x in pk.decrypt(c_b, kidx)]
+    assert [(al + (-t) % pyref.Q) % pyref.Q for al, t in zip(alpha, bt)] == [x * y % pyref.Q for x, y in zip(a, b)]
+
+
+def test_public_keyset_and_errors(gpu_ctx, keys):
+    from multi_party_ecdsa_amd import engine as E, _native as N
+    pub = E.PaillierKeys(gpu_ctx, N=[k.N for k in keys[:3]])
+    r = F.Rng("gpu-pub")
+    m, rr = [r.below(pyref.Q) for _ in range(3)], [r.below(k.N) for k in keys[:3]]
+    assert pub.encrypt(m, rr) == [pyref.paillier_encrypt(k.N, x, y) for k, x, y in zip(keys, m, rr)]   # key_idx None -> key i
+    with pytest.raises(N.MpeError):
+        pub.decrypt([1, 2, 3])                    # no private part: rejected, not silently wrong
+
+
+def test_config2_full_size_roundtrip(pk, keys, gpu_ctx):
+    """BASELINE config 2: 65 536 encrypt + decrypt, 16 keys.  Decrypt(Encrypt(m, r)) == m for every item
+    (round trip), a strided 128-item sample of the ciphertexts is bit-exact against the oracle."""
+    B = 65536
+    dev = gpu_ctx.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    m = torch.zeros((B, 64), dtype=torch.int32, device=dev)
+    m[:, :8] = torch.randint(-2**31, 2**31 - 1, (B, 8), dtype=torch.int32, device=dev, generator=g)      # 256-bit (k_i case)
+    wide = torch.randint(-2**31, 2**31 - 1, (B // 2, 63), dtype=torch.int32, device=dev, generator=g)   # < 2^2016 < N
+    m[B // 2:, :63] = wide
+    rr = torch.zeros((B, 64), dtype=torch.int32, device=dev)
+    rr[:, :63] = torch.randint(-2**31, 2**31 - 1, (B, 63), dtype=torch.int32, device=dev, generator=g)
+    idx = (torch.arange(B, device=dev, dtype=torch.int32) % len(keys)).contiguous()
+    c = pk.encrypt_device(m, rr, idx)
+    back = pk.decrypt_device(c, idx)
+    gpu_ctx.sync()
+    assert torch.equal(back, m)
+    sel = torch.arange(0, B, 512, device=dev)
+    want = orc.paillier_encrypt(F.words([k.N for k in keys], 64), np.ascontiguousarray(m[sel].cpu().numpy().view(np.uint32)),
+                                np.ascontiguousarray(rr[sel].cpu().numpy().view(np.uint32)), [int(i) % len(keys) for i in sel.cpu()])
+    assert np.array_equal(np.ascontiguousarray(c[sel].cpu().numpy().view(np.uint32)), want)
