@@ -107,6 +107,68 @@ int mpe_paillier_add(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const int3
 int mpe_paillier_mul(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const int32_t* d_key_idx,
                      const uint32_t* d_c, const uint32_t* d_k, int k_words, uint32_t* d_out, void* stream);
 
+/* ---- BigInt::mod_inv ------------------------------------------------------------------------ */
+/* out[i] = a[i]^-1 mod modulus[idx(i)], ok[i] = 0 when gcd != 1 (curv `BigInt::mod_inv` -> Option;
+ * src/utilities/mta/range_proofs.rs:122,135,339,351,363; zk_pdl_with_slack/mod.rs:192).
+ * a must be reduced (a < modulus). */
+int mpe_modinv(mpe_ctx* ctx, const mpe_modset* ms, int batch, const int32_t* d_mod_idx, const uint32_t* d_a,
+               uint32_t* d_out, uint8_t* d_ok, void* stream);
+
+/* ---- secp256k1 (curv Point<Secp256k1> / Scalar<Secp256k1>) -------------------------------------- */
+/* Points: 16 words, affine x[8] | y[8], all-zero = point at infinity.  Scalars: k_words little-endian
+ * words, reduced mod q on entry exactly like `Scalar::from(&BigInt)` (k_words <= 89).
+ * out = k*G (`Point::generator() * k`), out = k*P (`P * k`), out = P + Q. */
+int mpe_ec_mul_base(mpe_ctx* ctx, int batch, const uint32_t* d_k, int k_words, uint32_t* d_out, void* stream);
+int mpe_ec_mul(mpe_ctx* ctx, int batch, const uint32_t* d_k, int k_words, const uint32_t* d_P, uint32_t* d_out,
+               void* stream);
+int mpe_ec_add(mpe_ctx* ctx, int batch, const uint32_t* d_P, const uint32_t* d_Q, uint32_t* d_out, void* stream);
+
+/* curv `DLogProof::prove(sk)` with the nonce as input / `DLogProof::verify`
+ * (src/utilities/mta/mod.rs:147-148,170-171).  pk, R: points; z: 8 words. */
+int mpe_dlog_prove(mpe_ctx* ctx, int batch, const uint32_t* d_sk, const uint32_t* d_nonce, uint32_t* d_pk,
+                   uint32_t* d_R, uint32_t* d_z, void* stream);
+int mpe_dlog_verify(mpe_ctx* ctx, int batch, const uint32_t* d_pk, const uint32_t* d_R, const uint32_t* d_z,
+                    uint8_t* d_ok, void* stream);
+
+/* ---- DLogStatement tables and the range / PDL proofs -------------------------------------------- */
+/* `zk_paillier::DLogStatement{N, g, ni}` as GG20 stores (N~, h1, h2)
+ * (src/protocols/multi_party_ecdsa/gg_2020/party_i.rs:225-229).  d_Nt, d_h1, d_h2: [count][64]. */
+typedef struct mpe_statements mpe_statements;
+int mpe_statements_create(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const uint32_t* d_h1,
+                          const uint32_t* d_h2, mpe_statements** out, void* stream);
+int mpe_statements_destroy(mpe_statements* s);
+
+/* Field widths (words): z,s 64 | e 8 | s1 25 (< 2^769) | s2,s3 89 (< 2^2817) | u2 128 | points 16.
+ * Nonces (the reference samples them inside the call; here they are inputs):
+ * alpha 24 (< q^3) | beta 64 | gamma 88 (< q^3 N~) | rho 72 (< q N~). */
+typedef struct { uint32_t *z, *e, *s, *s1, *s2; } mpe_alice_proof;
+typedef struct { const uint32_t *alpha, *beta, *gamma, *rho; } mpe_alice_nonces;
+/* `AliceProof::generate(a, cipher, alice_ek, dlog_statement, r)`  (src/utilities/mta/range_proofs.rs:160-193)
+ * a: [batch][8], cipher: [batch][128], r: [batch][64] (the Paillier randomness of cipher). */
+int mpe_alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch,
+                       const int32_t* d_key_idx, const int32_t* d_st_idx, const uint32_t* d_a,
+                       const uint32_t* d_cipher, const uint32_t* d_r, const mpe_alice_nonces* nonces,
+                       const mpe_alice_proof* out, void* stream);
+/* `AliceProof::verify(cipher, alice_ek, dlog_statement) -> bool`  (range_proofs.rs:105-156) */
+int mpe_alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch,
+                     const int32_t* d_key_idx, const int32_t* d_st_idx, const uint32_t* d_cipher,
+                     const mpe_alice_proof* proof, uint8_t* d_ok, void* stream);
+
+typedef struct { uint32_t *z, *u1, *u2, *u3, *s1, *s2, *s3; } mpe_pdl_proof;
+typedef struct { const uint32_t *alpha, *beta, *rho, *gamma; } mpe_pdl_nonces;
+/* `PDLwSlackProof::prove(witness{x, r}, statement{ciphertext, ek, Q, G, h1, h2, N_tilde})`
+ * (src/utilities/zk_pdl_with_slack/mod.rs:68-125).  Q, G: points; x: [batch][8]; r: [batch][64]. */
+int mpe_pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch,
+                  const int32_t* d_key_idx, const int32_t* d_st_idx, const uint32_t* d_cipher,
+                  const uint32_t* d_Q, const uint32_t* d_G, const uint32_t* d_x, const uint32_t* d_r,
+                  const mpe_pdl_nonces* nonces, const mpe_pdl_proof* out, void* stream);
+/* `PDLwSlackProof::verify(statement) -> Result<(), ZkPdlWithSlackError>`  (mod.rs:127-179); ok[i]=1 accepts.
+ * (Where the reference would panic on a non-invertible c or z, the item is rejected instead.) */
+int mpe_pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch,
+                   const int32_t* d_key_idx, const int32_t* d_st_idx, const uint32_t* d_cipher,
+                   const uint32_t* d_Q, const uint32_t* d_G, const mpe_pdl_proof* proof, uint8_t* d_ok,
+                   void* stream);
+
 /* Kernel geometry chosen for the last launch (for bench.py's roofline accounting). */
 typedef struct {
   int waves;              /* workgroups (= waves) launched */

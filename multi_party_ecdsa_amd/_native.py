@@ -25,6 +25,16 @@ class ProfRec(C.Structure):
     _fields_ = [("kind", C.c_int), ("bits", C.c_int), ("exp_words", C.c_int), ("batch", C.c_int), ("ms", C.c_float)]
 
 
+def _ptr_struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": [(f, C.c_void_p) for f in fields]})
+
+
+AliceProof = _ptr_struct("AliceProof", ["z", "e", "s", "s1", "s2"])
+AliceNonces = _ptr_struct("AliceNonces", ["alpha", "beta", "gamma", "rho"])
+PdlProof = _ptr_struct("PdlProof", ["z", "u1", "u2", "u3", "s1", "s2", "s3"])
+PdlNonces = _ptr_struct("PdlNonces", ["alpha", "beta", "rho", "gamma"])
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -45,6 +55,20 @@ def _load():
         "mpe_modexp": (ip, [vp, vp, ip, i32p, u32p, u32p, ip, u32p, vp]),
         "mpe_modmul": (ip, [vp, vp, ip, i32p, u32p, u32p, u32p, vp]),
         "mpe_last_launch_info": (ip, [vp, C.POINTER(LaunchInfo)]),
+        "mpe_modinv": (ip, [vp, vp, ip, i32p, u32p, u32p, vp, vp]),
+        "mpe_ec_mul_base": (ip, [vp, ip, u32p, ip, u32p, vp]),
+        "mpe_ec_mul": (ip, [vp, ip, u32p, ip, u32p, u32p, vp]),
+        "mpe_ec_add": (ip, [vp, ip, u32p, u32p, u32p, vp]),
+        "mpe_dlog_prove": (ip, [vp, ip, u32p, u32p, u32p, u32p, u32p, vp]),
+        "mpe_dlog_verify": (ip, [vp, ip, u32p, u32p, u32p, vp, vp]),
+        "mpe_statements_create": (ip, [vp, ip, u32p, u32p, u32p, C.POINTER(vp), vp]),
+        "mpe_statements_destroy": (ip, [vp]),
+        "mpe_alice_generate": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, u32p, C.POINTER(AliceNonces),
+                                    C.POINTER(AliceProof), vp]),
+        "mpe_alice_verify": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, C.POINTER(AliceProof), vp, vp]),
+        "mpe_pdl_prove": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, u32p, u32p, u32p, C.POINTER(PdlNonces),
+                               C.POINTER(PdlProof), vp]),
+        "mpe_pdl_verify": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, u32p, C.POINTER(PdlProof), vp, vp]),
         "mpe_prof_enable": (ip, [vp, ip]),
         "mpe_prof_collect": (ip, [vp, C.POINTER(ProfRec), ip, C.POINTER(C.c_int)]),
         "mpe_paillier_create_public": (ip, [vp, ip, u32p, C.POINTER(vp), vp]),
@@ -72,7 +96,9 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_modexp", "mpe_modmul", "mpe_last_launch_info", "mpe_paillier_create_public",
             "mpe_paillier_create_private", "mpe_paillier_destroy", "mpe_paillier_nkeys", "mpe_paillier_n",
             "mpe_paillier_encrypt", "mpe_paillier_decrypt", "mpe_paillier_add", "mpe_paillier_mul",
-            "mpe_prof_enable", "mpe_prof_collect"]
+            "mpe_prof_enable", "mpe_prof_collect", "mpe_modinv", "mpe_ec_mul_base", "mpe_ec_mul", "mpe_ec_add",
+            "mpe_dlog_prove", "mpe_dlog_verify", "mpe_statements_create", "mpe_statements_destroy",
+            "mpe_alice_generate", "mpe_alice_verify", "mpe_pdl_prove", "mpe_pdl_verify"]
 
 
 def check(rc, what):

@@ -35,6 +35,8 @@ struct mpe_modset {
   uint32_t* r2_limbs = nullptr;   // [count][K]   R^2 mod n
   uint32_t* r2h_limbs = nullptr;  // [count][K]   2^bits R^2 mod n
   uint32_t* n0inv = nullptr;      // [count]      -n^-1 mod 2^W
+  uint32_t* words = nullptr;      // [count][bits/32] the moduli as interface words (for modinv)
+  uint32_t* one_words = nullptr;  // [1]          the constant 1 (a 1-word operand: x * 1 mod n reduces x)
 };
 
 void mpe_set_error(const char* what, hipError_t e);

@@ -68,7 +68,8 @@ static int modset_create_impl(int count, const uint32_t* d_moduli, mpe_modset** 
   ms->count = count;
   ms->K = C::K;
   const size_t words = (size_t)count * C::K;
-  const size_t total = (4 * words + (size_t)count) * sizeof(uint32_t);
+  const size_t iw = (size_t)count * C::K32;
+  const size_t total = (4 * words + (size_t)count + iw + 4) * sizeof(uint32_t);
   hipError_t e = hipMalloc(&ms->blob, total);
   if (e != hipSuccess) { delete ms; mpe_set_error("hipMalloc(modset)", e); return MPE_E_NOMEM; }
   uint32_t* p = (uint32_t*)ms->blob;
@@ -77,6 +78,10 @@ static int modset_create_impl(int count, const uint32_t* d_moduli, mpe_modset** 
   ms->r2_limbs = p + 2 * words;
   ms->r2h_limbs = p + 3 * words;
   ms->n0inv = p + 4 * words;
+  ms->words = ms->n0inv + count;
+  ms->one_words = ms->words + iw;
+  (void)hipMemcpyAsync(ms->words, d_moduli, iw * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
+  (void)hipMemsetD32Async((hipDeviceptr_t)ms->one_words, 1, 1, st);
   const int blocks = (count + C::GROUPS - 1) / C::GROUPS;
   hipLaunchKernelGGL(modset_setup_kernel<C>, dim3(blocks), dim3(64), 0, st, count, d_moduli, ms->n_limbs,
                      ms->one_limbs, ms->r2_limbs, ms->r2h_limbs, ms->n0inv);
@@ -155,6 +160,7 @@ static Rows mod_selector(const mpe_modset* ms, const int32_t* d_mod_idx) {
 }  // namespace mpe
 
 #include "mpe_paillier.h"
+#include "mpe_proofs.h"
 
 extern "C" {
 

@@ -1,0 +1,565 @@
+// secp256k1 batch ops, modular inversion, and the zero-knowledge proofs of the GG20 hot path:
+//   AliceProof::{generate,verify}          src/utilities/mta/range_proofs.rs:39-193
+//   PDLwSlackProof::{prove,verify}         src/utilities/zk_pdl_with_slack/mod.rs:68-199
+//   DLogProof::{prove,verify}              curv, used at src/utilities/mta/mod.rs:147-148,170-171
+// Included by mpe_lib.hip.  Heavy arithmetic = launch_modexp / launch_modmul; everything else is
+// one-item-per-lane glue (mpe_small.h, mpe_ec.h).
+#pragma once
+#include "mpe_ec.h"
+#include "mpe_internal.h"
+#include "mpe_paillier.h"
+#include "mpe_small.h"
+
+struct mpe_statements {
+  int count = 0;
+  void* blob = nullptr;
+  uint32_t* Nt = nullptr;   // [count][64]
+  uint32_t* h1 = nullptr;
+  uint32_t* h2 = nullptr;
+  mpe_modset* ms = nullptr;  // 2048-bit, modulus k = N~_k
+};
+
+namespace mpe {
+
+// ---------------------------------------------------------------------------------------------
+// secp256k1 batch kernels
+// ---------------------------------------------------------------------------------------------
+// out = (k mod q) * P;  P == nullptr -> generator
+__global__ void ec_mul_kernel(int B, const uint32_t* __restrict__ k, int kw, const uint32_t* __restrict__ P,
+                              uint32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const ec::U256 s = ec::sc_reduce(k + (size_t)i * kw, kw);
+  const ec::Aff p = P ? ec::aff_load(P + (size_t)i * 16) : ec::aff_gen();
+  ec::aff_store(out + (size_t)i * 16, ec::jac_to_aff(ec::jac_mul(s, p)));
+}
+__global__ void ec_add_kernel(int B, const uint32_t* __restrict__ P, const uint32_t* __restrict__ Q,
+                              uint32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const ec::Jac r = ec::jac_add(ec::jac_from_aff(ec::aff_load(P + (size_t)i * 16)),
+                                ec::jac_from_aff(ec::aff_load(Q + (size_t)i * 16)));
+  ec::aff_store(out + (size_t)i * 16, ec::jac_to_aff(r));
+}
+
+// curv DLogProof: pk = sk G, R = rho G, c = H(R, G, pk) mod q, z = rho - c sk
+__device__ inline ec::U256 dlog_challenge(const ec::Aff& R, const ec::Aff& pk) {
+  ec::Sha256 s;
+  ec::sha_init(s);
+  ec::sha_point_uncompressed(s, R);
+  ec::sha_point_uncompressed(s, ec::aff_gen());
+  ec::sha_point_uncompressed(s, pk);
+  const ec::U256 d = ec::sha_final(s);
+  return ec::sc_reduce(d.w, 8);
+}
+__global__ void dlog_prove_kernel(int B, const uint32_t* __restrict__ sk, const uint32_t* __restrict__ nonce,
+                                  uint32_t* __restrict__ pk, uint32_t* __restrict__ R, uint32_t* __restrict__ z) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const ec::U256 s = ec::sc_reduce(sk + (size_t)i * 8, 8), k = ec::sc_reduce(nonce + (size_t)i * 8, 8);
+  const ec::Aff g = ec::aff_gen();
+  const ec::Aff Rp = ec::jac_to_aff(ec::jac_mul(k, g)), P = ec::jac_to_aff(ec::jac_mul(s, g));
+  const ec::U256 c = dlog_challenge(Rp, P);
+  ec::aff_store(pk + (size_t)i * 16, P);
+  ec::aff_store(R + (size_t)i * 16, Rp);
+  ec::u256_store(z + (size_t)i * 8, ec::sc_sub(k, ec::sc_mul(c, s)));
+}
+__global__ void dlog_verify_kernel(int B, const uint32_t* __restrict__ pk, const uint32_t* __restrict__ R,
+                                   const uint32_t* __restrict__ z, uint8_t* __restrict__ ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const ec::Aff P = ec::aff_load(pk + (size_t)i * 16), Rp = ec::aff_load(R + (size_t)i * 16);
+  const ec::U256 c = dlog_challenge(Rp, P), zz = ec::sc_reduce(z + (size_t)i * 8, 8);
+  const ec::Jac l = ec::jac_add(ec::jac_mul(zz, ec::aff_gen()), ec::jac_mul(c, P));
+  ok[i] = ec::aff_eq(ec::jac_to_aff(l), Rp) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// modular inversion (BigInt::mod_inv -> Option): binary extended gcd, one item per lane.
+// Inputs must be reduced (a < m), which every call site guarantees (outputs of modexp/modmul).
+// ---------------------------------------------------------------------------------------------
+template <int K32>
+__global__ void modinv_kernel(int B, const uint32_t* __restrict__ mod_words, Rows mod_sel, Rows A,
+                              uint32_t* __restrict__ out, uint8_t* __restrict__ ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  constexpr int W = K32 + 1;
+  uint32_t u[W], v[W], x1[W], x2[W], m[W];
+  const int mi = mod_sel.idx ? mod_sel.idx[i] : (mod_sel.stride ? i : 0);
+  const uint32_t* mp = mod_words + (size_t)mi * K32;
+  const uint32_t* ap = row_of(A, i);
+  const int aw = A.words ? A.words : K32;
+  for (int j = 0; j < W; ++j) {
+    m[j] = j < K32 ? mp[j] : 0;
+    v[j] = m[j];
+    u[j] = j < aw ? ap[j] : 0;
+    x1[j] = j == 0 ? 1u : 0u;
+    x2[j] = 0;
+  }
+  auto is_one = [&](const uint32_t* a) { uint32_t o = a[0] ^ 1u; for (int j = 1; j < W; ++j) o |= a[j]; return o == 0; };
+  auto halve_mod = [&](uint32_t* x) {      // x <- x/2 mod m
+    if (x[0] & 1u) sm::add(x, W, x, W, m, W);
+    for (int j = 0; j < W - 1; ++j) x[j] = (x[j] >> 1) | (x[j + 1] << 31);
+    x[W - 1] >>= 1;
+  };
+  auto shr1 = [&](uint32_t* x) {
+    for (int j = 0; j < W - 1; ++j) x[j] = (x[j] >> 1) | (x[j + 1] << 31);
+    x[W - 1] >>= 1;
+  };
+  bool good = !sm::is_zero(u, W);
+  int guard = 4 * 32 * K32 + 8;
+  while (good && !is_one(u) && !is_one(v) && guard-- > 0) {
+    while (!(u[0] & 1u)) { shr1(u); halve_mod(x1); }
+    while (!(v[0] & 1u)) { shr1(v); halve_mod(x2); }
+    if (sm::cmp(u, W, v, W) >= 0) {
+      sm::sub(u, W, u, W, v, W);
+      if (sm::sub(x1, W, x1, W, x2, W)) sm::add(x1, W, x1, W, m, W);
+      if (sm::is_zero(u, W)) good = false;            // gcd(a, m) = v != 1
+    } else {
+      sm::sub(v, W, v, W, u, W);
+      if (sm::sub(x2, W, x2, W, x1, W)) sm::add(x2, W, x2, W, m, W);
+    }
+  }
+  const uint32_t* res = is_one(u) ? x1 : x2;
+  if (!is_one(u) && !is_one(v)) good = false;
+  for (int j = 0; j < K32; ++j) out[(size_t)i * K32 + j] = good ? res[j] : 0u;
+  ok[i] = good ? 1 : 0;
+}
+
+static int launch_modinv(mpe_ctx* ctx, const mpe_modset* ms, int B, Rows mod_sel, Rows a, uint32_t* out, uint8_t* ok,
+                         hipStream_t st) {
+  (void)ctx;
+  if (B == 0) return MPE_OK;
+  if (ms->bits == 4096)
+    hipLaunchKernelGGL(modinv_kernel<128>, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ms->words, mod_sel, a, out, ok);
+  else
+    hipLaunchKernelGGL(modinv_kernel<64>, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ms->words, mod_sel, a, out, ok);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mpe_set_error("modinv_kernel", e); return MPE_E_HIP; }
+  return MPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// glue kernels
+// ---------------------------------------------------------------------------------------------
+// r[nr] = a[na] * b[nb] + c[nc]      (plain integers; nr >= na + nb)
+__global__ void muladd_kernel(int B, Rows a, int na, Rows b, int nb, Rows c, int nc, uint32_t* __restrict__ r, int nr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  uint32_t x[90], y[90], t[180];
+  sm::copy(x, row_of(a, i), na);
+  sm::copy(y, row_of(b, i), nb);
+  sm::mul(t, x, na, y, nb);
+  for (int j = na + nb; j < nr; ++j) t[j] = 0;
+  const uint32_t one[1] = {1};
+  const uint32_t* cp = c.p ? row_of(c, i) : one;     // c.p == nullptr means the constant 1
+  sm::add(t, nr, t, nr, cp, c.p ? nc : 1);           // callers size nr so that the sum fits
+  uint32_t* o = r + (size_t)i * nr;
+  for (int j = 0; j < nr; ++j) o[j] = t[j];
+}
+
+// Fiat-Shamir transcripts: SHA-256 over a list of fields, each hashed the way the reference hashes it
+enum { HF_BIGINT = 0, HF_BIGINT_PLUS1 = 1, HF_POINT_COMPRESSED = 2 };
+struct HashField { Rows r; int words; int kind; };
+struct HashDesc { HashField f[8]; int n; };
+__global__ void hash_kernel(int B, HashDesc d, uint32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  ec::Sha256 s;
+  ec::sha_init(s);
+  for (int k = 0; k < d.n; ++k) {
+    const uint32_t* p = row_of(d.f[k].r, i);
+    if (d.f[k].kind == HF_POINT_COMPRESSED) {
+      ec::sha_point_compressed(s, ec::aff_load(p));
+    } else if (d.f[k].kind == HF_BIGINT_PLUS1) {
+      uint32_t t[130];
+      const uint32_t one[1] = {1};
+      t[d.f[k].words] = sm::add(t, d.f[k].words, p, d.f[k].words, one, 1);
+      ec::sha_bigint(s, t, d.f[k].words + 1);
+    } else {
+      ec::sha_bigint(s, p, d.f[k].words);
+    }
+  }
+  ec::u256_store(out + (size_t)i * 8, ec::sha_final(s));
+}
+static HashField hf(Rows r, int words, int kind = HF_BIGINT) { return HashField{r, words, kind}; }
+
+// ok[i] = (a[i] <= q^3) for the s1 range check (range_proofs.rs:118 / :335)
+__global__ void s1_range_kernel(int B, const uint32_t* __restrict__ s1, int words, uint8_t* __restrict__ ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  uint32_t q[8], q2[16], q3[24];
+  for (int j = 0; j < 8; ++j) q[j] = ec::FQ[j];
+  sm::mul(q2, q, 8, q, 8);
+  sm::mul(q3, q2, 16, q, 8);
+  ok[i] = sm::cmp(s1 + (size_t)i * words, words, q3, 24) <= 0 ? 1 : 0;
+}
+// ok[i] &= all of: flags a, b (optional) and equality of the [words] rows x == y (optional)
+__global__ void and_flags_kernel(int B, uint8_t* __restrict__ ok, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                 const uint32_t* __restrict__ x, const uint32_t* __restrict__ y, int words) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  bool v = ok[i] != 0;
+  if (a) v = v && a[i];
+  if (b) v = v && b[i];
+  if (x) v = v && sm::cmp(x + (size_t)i * words, words, y + (size_t)i * words, words) == 0;
+  ok[i] = v ? 1 : 0;
+}
+__global__ void fill_u8_kernel(int B, uint8_t* p, uint8_t v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) p[i] = v;
+}
+// PDL verify: ok &= ( (s1 mod q) G + (q - e) Q == u1 )      (zk_pdl_with_slack/mod.rs:138-142,174)
+__global__ void pdl_u1_check_kernel(int B, const uint32_t* __restrict__ s1, const uint32_t* __restrict__ e,
+                                    const uint32_t* __restrict__ G, const uint32_t* __restrict__ Q,
+                                    const uint32_t* __restrict__ u1, uint8_t* __restrict__ ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const ec::U256 a = ec::sc_reduce(s1 + (size_t)i * 25, 25);
+  const ec::U256 ne = ec::sc_neg(ec::sc_reduce(e + (size_t)i * 8, 8));
+  const ec::Jac l = ec::jac_add(ec::jac_mul(a, ec::aff_load(G + (size_t)i * 16)), ec::jac_mul(ne, ec::aff_load(Q + (size_t)i * 16)));
+  if (!ec::aff_eq(ec::jac_to_aff(l), ec::aff_load(u1 + (size_t)i * 16))) ok[i] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side sequencing helper: every intermediate lives in the context workspace
+// ---------------------------------------------------------------------------------------------
+struct Seq {
+  mpe_ctx* ctx;
+  hipStream_t st;
+  int B;
+  int rc = MPE_OK;
+  uint32_t* words(size_t per_item) {
+    uint32_t* p = ws_array<uint32_t>(ctx, (size_t)B * per_item);
+    if (!p && rc == MPE_OK) { rc = MPE_E_NOMEM; mpe_set_error_msg("workspace under-reserved"); }
+    return p;
+  }
+  uint8_t* flags() {
+    uint8_t* p = ws_array<uint8_t>(ctx, (size_t)B);
+    if (!p && rc == MPE_OK) { rc = MPE_E_NOMEM; mpe_set_error_msg("workspace under-reserved"); }
+    return p;
+  }
+  uint32_t* modexp(const mpe_modset* ms, Rows sel, Rows base, Rows exps, int ew) {
+    uint32_t* o = words(ms->bits / 32);
+    if (rc == MPE_OK) rc = launch_modexp(ctx, ms, B, sel, base, no_rows(), exps, ew, o, st);
+    return o;
+  }
+  uint32_t* modmul(const mpe_modset* ms, Rows sel, Rows a, Rows b) {
+    uint32_t* o = words(ms->bits / 32);
+    if (rc == MPE_OK) rc = launch_modmul(ctx, ms, B, sel, a, b, o, st);
+    return o;
+  }
+  void modmul_to(const mpe_modset* ms, Rows sel, Rows a, Rows b, uint32_t* o) {
+    if (rc == MPE_OK) rc = launch_modmul(ctx, ms, B, sel, a, b, o, st);
+  }
+  uint32_t* modinv(const mpe_modset* ms, Rows sel, Rows a, uint8_t* ok) {
+    uint32_t* o = words(ms->bits / 32);
+    if (rc == MPE_OK) rc = launch_modinv(ctx, ms, B, sel, a, o, ok, st);
+    return o;
+  }
+  void muladd(Rows a, int na, Rows b, int nb, Rows c, int nc, uint32_t* r, int nr) {
+    if (rc != MPE_OK) return;
+    hipLaunchKernelGGL(muladd_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, a, na, b, nb, c, nc, r, nr);
+  }
+  void hash(const HashDesc& d, uint32_t* out) {
+    if (rc != MPE_OK) return;
+    hipLaunchKernelGGL(hash_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, d, out);
+  }
+  int finish(const char* what) {
+    if (rc != MPE_OK) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mpe_set_error(what, e); return MPE_E_HIP; }
+    return MPE_OK;
+  }
+};
+
+// per-item selectors of per-key / per-statement tables
+static Rows sel_of(const int32_t* idx, int count) { return Rows{nullptr, idx, (idx == nullptr && count != 1) ? 1 : 0, 0}; }
+static Rows tab_rows(const uint32_t* table, int stride, const int32_t* idx, int count, int words = 0) {
+  if (idx) return Rows{table, idx, stride, words};
+  return Rows{table, nullptr, count == 1 ? 0 : stride, words};
+}
+
+// ---------------------------------------------------------------------------------------------
+// AliceProof::generate   (range_proofs.rs:160-193; rounds :39-67 and :78-90)
+// ---------------------------------------------------------------------------------------------
+static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
+                          const int32_t* st_idx, const uint32_t* a, const uint32_t* cipher, const uint32_t* r,
+                          const mpe_alice_nonces* nn, const mpe_alice_proof* out, hipStream_t st) {
+  MPE_TRY(ws_reserve(ctx, (size_t)B * 1400 * 4 + 65536, st));
+  Seq q{ctx, st, B};
+  const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
+  const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
+  const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
+  // z = h1^a h2^rho mod N~                                                      :52
+  uint32_t* z1 = q.modexp(stm->ms, ssel, h1, rows(a, 8), 8);
+  uint32_t* z2 = q.modexp(stm->ms, ssel, h2, rows(nn->rho, 72), 72);
+  q.modmul_to(stm->ms, ssel, rows(z1, 64), rows(z2, 64), out->z);
+  // u = (alpha N + 1) beta^N mod N^2                                            :53-55
+  uint32_t* gu = q.words(128);
+  q.muladd(rows(nn->alpha, 24), 24, Nrow, 64, no_rows(), 0, gu, 128);
+  uint32_t* bn = q.modexp(pk->ms_nn, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64);
+  uint32_t* u = q.modmul(pk->ms_nn, ksel, rows(gu, 128), rows(bn, 128));
+  // w = h1^alpha h2^gamma mod N~                                                :56-57
+  uint32_t* w1 = q.modexp(stm->ms, ssel, h1, rows(nn->alpha, 24), 24);
+  uint32_t* w2 = q.modexp(stm->ms, ssel, h2, rows(nn->gamma, 88), 88);
+  uint32_t* w = q.modmul(stm->ms, ssel, rows(w1, 64), rows(w2, 64));
+  // e = H(N, N+1, c, z, u, w)                                                   :175-182
+  HashDesc d;
+  d.n = 6;
+  d.f[0] = hf(Nrow, 64); d.f[1] = hf(Nrow, 64, HF_BIGINT_PLUS1); d.f[2] = hf(rows(cipher, 128), 128);
+  d.f[3] = hf(rows(out->z, 64), 64); d.f[4] = hf(rows(u, 128), 128); d.f[5] = hf(rows(w, 64), 64);
+  q.hash(d, out->e);
+  // s = r^e beta mod N ; s1 = e a + alpha ; s2 = e rho + gamma                  :84-88
+  uint32_t* re = q.modexp(pk->ms_n, ksel, rows(r, 64), rows(out->e, 8), 8);
+  q.modmul_to(pk->ms_n, ksel, rows(re, 64), rows(nn->beta, 64), out->s);
+  q.muladd(rows(out->e, 8), 8, rows(a, 8), 8, rows(nn->alpha, 24), 24, out->s1, 25);
+  q.muladd(rows(out->e, 8), 8, rows(nn->rho, 72), 72, rows(nn->gamma, 88), 88, out->s2, 89);
+  return q.finish("alice_generate");
+}
+
+// ---------------------------------------------------------------------------------------------
+// AliceProof::verify   (range_proofs.rs:105-156)
+// ---------------------------------------------------------------------------------------------
+static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
+                        const int32_t* st_idx, const uint32_t* cipher, const mpe_alice_proof* pr, uint8_t* ok,
+                        hipStream_t st) {
+  MPE_TRY(ws_reserve(ctx, (size_t)B * 1800 * 4 + 65536, st));
+  Seq q{ctx, st, B};
+  const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
+  const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
+  const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
+  MPE_LAUNCH_1D(s1_range_kernel, B, st, B, pr->s1, 25, ok);                                        // :118
+  // w' = h1^s1 h2^s2 (z^e)^-1 mod N~                                                               :122-132
+  uint8_t *inv_ok1 = q.flags(), *inv_ok2 = q.flags();
+  uint32_t* ze = q.modexp(stm->ms, ssel, rows(pr->z, 64), rows(pr->e, 8), 8);
+  uint32_t* zei = q.modinv(stm->ms, ssel, rows(ze, 64), inv_ok1);
+  uint32_t* a1 = q.modexp(stm->ms, ssel, h1, rows(pr->s1, 25), 25);
+  uint32_t* a2 = q.modexp(stm->ms, ssel, h2, rows(pr->s2, 89), 89);
+  uint32_t* a12 = q.modmul(stm->ms, ssel, rows(a1, 64), rows(a2, 64));
+  uint32_t* w = q.modmul(stm->ms, ssel, rows(a12, 64), rows(zei, 64));
+  // u' = (s1 N + 1) s^N (c^e)^-1 mod N^2                                                           :134-141
+  uint32_t* gs1 = q.words(128);
+  q.muladd(rows(pr->s1, 25), 25, Nrow, 64, no_rows(), 0, gs1, 128);
+  uint32_t* ce = q.modexp(pk->ms_nn, ksel, rows(cipher, 128), rows(pr->e, 8), 8);
+  uint32_t* cei = q.modinv(pk->ms_nn, ksel, rows(ce, 128), inv_ok2);
+  uint32_t* sn = q.modexp(pk->ms_nn, ksel, rows(pr->s, 64, nullptr, 64), Nrow, 64);
+  uint32_t* b12 = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(sn, 128));
+  uint32_t* u = q.modmul(pk->ms_nn, ksel, rows(b12, 128), rows(cei, 128));
+  // e' = H(N, N+1, c, z, u', w') == e                                                              :143-153
+  uint32_t* e2 = q.words(8);
+  HashDesc d;
+  d.n = 6;
+  d.f[0] = hf(Nrow, 64); d.f[1] = hf(Nrow, 64, HF_BIGINT_PLUS1); d.f[2] = hf(rows(cipher, 128), 128);
+  d.f[3] = hf(rows(pr->z, 64), 64); d.f[4] = hf(rows(u, 128), 128); d.f[5] = hf(rows(w, 64), 64);
+  q.hash(d, e2);
+  if (q.rc == MPE_OK)
+    hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ok, inv_ok1, inv_ok2, e2, pr->e, 8);
+  return q.finish("alice_verify");
+}
+
+// ---------------------------------------------------------------------------------------------
+// PDLwSlackProof::prove   (zk_pdl_with_slack/mod.rs:68-125)
+// ---------------------------------------------------------------------------------------------
+static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
+                     const int32_t* st_idx, const uint32_t* cipher, const uint32_t* Qp, const uint32_t* Gp,
+                     const uint32_t* x, const uint32_t* r, const mpe_pdl_nonces* nn, const mpe_pdl_proof* out,
+                     hipStream_t st) {
+  MPE_TRY(ws_reserve(ctx, (size_t)B * 1400 * 4 + 65536, st));
+  Seq q{ctx, st, B};
+  const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
+  const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
+  const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
+  // z = h1^x h2^rho mod N~                                                      :79-85
+  uint32_t* z1 = q.modexp(stm->ms, ssel, h1, rows(x, 8), 8);
+  uint32_t* z2 = q.modexp(stm->ms, ssel, h2, rows(nn->rho, 72), 72);
+  q.modmul_to(stm->ms, ssel, rows(z1, 64), rows(z2, 64), out->z);
+  // u1 = (alpha mod q) G                                                        :86
+  MPE_LAUNCH_1D(ec_mul_kernel, B, st, B, nn->alpha, 24, Gp, out->u1);
+  // u2 = (N+1)^alpha beta^N mod N^2; (N+1)^alpha = 1 + alpha N (mod N^2), alpha N + 1 < N^2      :87-93
+  uint32_t* ga = q.words(128);
+  q.muladd(rows(nn->alpha, 24), 24, Nrow, 64, no_rows(), 0, ga, 128);
+  uint32_t* bn = q.modexp(pk->ms_nn, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64);
+  q.modmul_to(pk->ms_nn, ksel, rows(ga, 128), rows(bn, 128), out->u2);
+  // u3 = h1^alpha h2^gamma mod N~                                               :94-100
+  uint32_t* w1 = q.modexp(stm->ms, ssel, h1, rows(nn->alpha, 24), 24);
+  uint32_t* w2 = q.modexp(stm->ms, ssel, h2, rows(nn->gamma, 88), 88);
+  q.modmul_to(stm->ms, ssel, rows(w1, 64), rows(w2, 64), out->u3);
+  // e = H(G, Q, c, z, u1, u2, u3)                                               :102-110
+  uint32_t* e = q.words(8);
+  HashDesc d;
+  d.n = 7;
+  d.f[0] = hf(rows(Gp, 16), 16, HF_POINT_COMPRESSED); d.f[1] = hf(rows(Qp, 16), 16, HF_POINT_COMPRESSED);
+  d.f[2] = hf(rows(cipher, 128), 128); d.f[3] = hf(rows(out->z, 64), 64);
+  d.f[4] = hf(rows(out->u1, 16), 16, HF_POINT_COMPRESSED); d.f[5] = hf(rows(out->u2, 128), 128);
+  d.f[6] = hf(rows(out->u3, 64), 64);
+  q.hash(d, e);
+  // s1 = e x + alpha ; s2 = r^e beta mod N ; s3 = e rho + gamma                :112-114
+  q.muladd(rows(e, 8), 8, rows(x, 8), 8, rows(nn->alpha, 24), 24, out->s1, 25);
+  uint32_t* re = q.modexp(pk->ms_n, ksel, rows(r, 64), rows(e, 8), 8);
+  q.modmul_to(pk->ms_n, ksel, rows(re, 64), rows(nn->beta, 64), out->s2);
+  q.muladd(rows(e, 8), 8, rows(nn->rho, 72), 72, rows(nn->gamma, 88), 88, out->s3, 89);
+  return q.finish("pdl_prove");
+}
+
+// ---------------------------------------------------------------------------------------------
+// PDLwSlackProof::verify   (zk_pdl_with_slack/mod.rs:127-179)
+// ---------------------------------------------------------------------------------------------
+static int pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
+                      const int32_t* st_idx, const uint32_t* cipher, const uint32_t* Qp, const uint32_t* Gp,
+                      const mpe_pdl_proof* pr, uint8_t* ok, hipStream_t st) {
+  MPE_TRY(ws_reserve(ctx, (size_t)B * 2200 * 4 + 65536, st));
+  Seq q{ctx, st, B};
+  const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
+  const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
+  const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
+  uint32_t* e = q.words(8);
+  HashDesc d;
+  d.n = 7;
+  d.f[0] = hf(rows(Gp, 16), 16, HF_POINT_COMPRESSED); d.f[1] = hf(rows(Qp, 16), 16, HF_POINT_COMPRESSED);
+  d.f[2] = hf(rows(cipher, 128), 128); d.f[3] = hf(rows(pr->z, 64), 64);
+  d.f[4] = hf(rows(pr->u1, 16), 16, HF_POINT_COMPRESSED); d.f[5] = hf(rows(pr->u2, 128), 128);
+  d.f[6] = hf(rows(pr->u3, 64), 64);
+  q.hash(d, e);                                                                                     // :128-136
+  MPE_LAUNCH_1D(fill_u8_kernel, B, st, B, ok, (uint8_t)1);
+  MPE_LAUNCH_1D(pdl_u1_check_kernel, B, st, B, pr->s1, e, Gp, Qp, pr->u1, ok);                     // :138-142
+  uint8_t *inv_ok1 = q.flags(), *inv_ok2 = q.flags();
+  // u2' = (N+1)^s1 s2^N c^-e mod N^2; (N+1)^s1 = 1 + s1 N < N^2 because s1 < 2^800                 :144-157
+  uint32_t* g1 = q.words(128);
+  q.muladd(rows(pr->s1, 25), 25, Nrow, 64, no_rows(), 0, g1, 128);
+  uint32_t* s2n = q.modexp(pk->ms_nn, ksel, rows(pr->s2, 64, nullptr, 64), Nrow, 64);
+  uint32_t* t2 = q.modmul(pk->ms_nn, ksel, rows(g1, 128), rows(s2n, 128));
+  uint32_t* cred = q.modmul(pk->ms_nn, ksel, rows(cipher, 128), rows(pk->ms_nn->one_words, 0, nullptr, 1));  // c mod N^2
+  uint32_t* cinv = q.modinv(pk->ms_nn, ksel, rows(cred, 128), inv_ok1);
+  uint32_t* cie = q.modexp(pk->ms_nn, ksel, rows(cinv, 128), rows(e, 8), 8);
+  uint32_t* u2 = q.modmul(pk->ms_nn, ksel, rows(t2, 128), rows(cie, 128));
+  // u3' = h1^s1 h2^s3 z^-e mod N~                                                                  :159-172
+  uint32_t* a1 = q.modexp(stm->ms, ssel, h1, rows(pr->s1, 25), 25);
+  uint32_t* a2 = q.modexp(stm->ms, ssel, h2, rows(pr->s3, 89), 89);
+  uint32_t* a12 = q.modmul(stm->ms, ssel, rows(a1, 64), rows(a2, 64));
+  uint32_t* zred = q.modmul(stm->ms, ssel, rows(pr->z, 64), rows(stm->ms->one_words, 0, nullptr, 1));
+  uint32_t* zinv = q.modinv(stm->ms, ssel, rows(zred, 64), inv_ok2);
+  uint32_t* zie = q.modexp(stm->ms, ssel, rows(zinv, 64), rows(e, 8), 8);
+  uint32_t* u3 = q.modmul(stm->ms, ssel, rows(a12, 64), rows(zie, 64));
+  if (q.rc == MPE_OK) {                                                                             // :174
+    hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ok, inv_ok1, inv_ok2, u2, pr->u2, 128);
+    hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ok, (const uint8_t*)nullptr,
+                       (const uint8_t*)nullptr, u3, pr->u3, 64);
+  }
+  return q.finish("pdl_verify");
+}
+
+}  // namespace mpe
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+int mpe_statements_create(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const uint32_t* d_h1, const uint32_t* d_h2,
+                          mpe_statements** out, void* stream) {
+  if (!ctx || !d_Nt || !d_h1 || !d_h2 || !out || count <= 0) return MPE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  mpe_statements* s = new (std::nothrow) mpe_statements();
+  if (!s) return MPE_E_NOMEM;
+  s->count = count;
+  const size_t w = (size_t)count * 64;
+  hipError_t e = hipMalloc(&s->blob, 3 * w * 4);
+  if (e != hipSuccess) { delete s; mpe_set_error("hipMalloc(statements)", e); return MPE_E_NOMEM; }
+  s->Nt = (uint32_t*)s->blob; s->h1 = s->Nt + w; s->h2 = s->h1 + w;
+  (void)hipMemcpyAsync(s->Nt, d_Nt, w * 4, hipMemcpyDeviceToDevice, st);
+  (void)hipMemcpyAsync(s->h1, d_h1, w * 4, hipMemcpyDeviceToDevice, st);
+  (void)hipMemcpyAsync(s->h2, d_h2, w * 4, hipMemcpyDeviceToDevice, st);
+  int rc = mpe::modset_create_dev(ctx, 2048, count, s->Nt, &s->ms, st);
+  if (rc != MPE_OK) { (void)hipFree(s->blob); delete s; return rc; }
+  *out = s;
+  return MPE_OK;
+}
+int mpe_statements_destroy(mpe_statements* s) {
+  if (!s) return MPE_E_ARG;
+  if (s->ms) mpe_modset_destroy(s->ms);
+  if (s->blob) (void)hipFree(s->blob);
+  delete s;
+  return MPE_OK;
+}
+
+int mpe_ec_mul_base(mpe_ctx* ctx, int batch, const uint32_t* d_k, int k_words, uint32_t* d_out, void* stream) {
+  if (!ctx || !d_k || !d_out || batch < 0 || k_words <= 0 || k_words > 89) return MPE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  MPE_LAUNCH_1D(mpe::ec_mul_kernel, batch, st, batch, d_k, k_words, (const uint32_t*)nullptr, d_out);
+  return MPE_OK;
+}
+int mpe_ec_mul(mpe_ctx* ctx, int batch, const uint32_t* d_k, int k_words, const uint32_t* d_P, uint32_t* d_out,
+               void* stream) {
+  if (!ctx || !d_k || !d_P || !d_out || batch < 0 || k_words <= 0 || k_words > 89) return MPE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  MPE_LAUNCH_1D(mpe::ec_mul_kernel, batch, st, batch, d_k, k_words, d_P, d_out);
+  return MPE_OK;
+}
+int mpe_ec_add(mpe_ctx* ctx, int batch, const uint32_t* d_P, const uint32_t* d_Q, uint32_t* d_out, void* stream) {
+  if (!ctx || !d_P || !d_Q || !d_out || batch < 0) return MPE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  MPE_LAUNCH_1D(mpe::ec_add_kernel, batch, st, batch, d_P, d_Q, d_out);
+  return MPE_OK;
+}
+int mpe_dlog_prove(mpe_ctx* ctx, int batch, const uint32_t* d_sk, const uint32_t* d_nonce, uint32_t* d_pk,
+                   uint32_t* d_R, uint32_t* d_z, void* stream) {
+  if (!ctx || !d_sk || !d_nonce || !d_pk || !d_R || !d_z || batch < 0) return MPE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  MPE_LAUNCH_1D(mpe::dlog_prove_kernel, batch, st, batch, d_sk, d_nonce, d_pk, d_R, d_z);
+  return MPE_OK;
+}
+int mpe_dlog_verify(mpe_ctx* ctx, int batch, const uint32_t* d_pk, const uint32_t* d_R, const uint32_t* d_z,
+                    uint8_t* d_ok, void* stream) {
+  if (!ctx || !d_pk || !d_R || !d_z || !d_ok || batch < 0) return MPE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  MPE_LAUNCH_1D(mpe::dlog_verify_kernel, batch, st, batch, d_pk, d_R, d_z, d_ok);
+  return MPE_OK;
+}
+int mpe_modinv(mpe_ctx* ctx, const mpe_modset* ms, int batch, const int32_t* d_mod_idx, const uint32_t* d_a,
+               uint32_t* d_out, uint8_t* d_ok, void* stream) {
+  if (!ctx || !ms || !d_a || !d_out || !d_ok || batch < 0) return MPE_E_ARG;
+  if (!d_mod_idx && ms->count != 1 && ms->count < batch) return MPE_E_ARG;
+  return mpe::launch_modinv(ctx, ms, batch, mpe::sel_of(d_mod_idx, ms->count), mpe::rows(d_a, ms->bits / 32), d_out, d_ok,
+                            (hipStream_t)stream);
+}
+
+static bool proof_args_ok(const mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch,
+                          const int32_t* key_idx, const int32_t* st_idx) {
+  if (!ctx || !pk || !stm || batch < 0) return false;
+  if (!key_idx && pk->nkeys != 1 && pk->nkeys < batch) return false;
+  if (!st_idx && stm->count != 1 && stm->count < batch) return false;
+  return true;
+}
+int mpe_alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch,
+                       const int32_t* d_key_idx, const int32_t* d_st_idx, const uint32_t* d_a, const uint32_t* d_cipher,
+                       const uint32_t* d_r, const mpe_alice_nonces* nonces, const mpe_alice_proof* out, void* stream) {
+  if (!proof_args_ok(ctx, pk, stm, batch, d_key_idx, d_st_idx) || !d_a || !d_cipher || !d_r || !nonces || !out) return MPE_E_ARG;
+  if (batch == 0) return MPE_OK;
+  return mpe::alice_generate(ctx, pk, stm, batch, d_key_idx, d_st_idx, d_a, d_cipher, d_r, nonces, out, (hipStream_t)stream);
+}
+int mpe_alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch, const int32_t* d_key_idx,
+                     const int32_t* d_st_idx, const uint32_t* d_cipher, const mpe_alice_proof* proof, uint8_t* d_ok,
+                     void* stream) {
+  if (!proof_args_ok(ctx, pk, stm, batch, d_key_idx, d_st_idx) || !d_cipher || !proof || !d_ok) return MPE_E_ARG;
+  if (batch == 0) return MPE_OK;
+  return mpe::alice_verify(ctx, pk, stm, batch, d_key_idx, d_st_idx, d_cipher, proof, d_ok, (hipStream_t)stream);
+}
+int mpe_pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch, const int32_t* d_key_idx,
+                  const int32_t* d_st_idx, const uint32_t* d_cipher, const uint32_t* d_Q, const uint32_t* d_G,
+                  const uint32_t* d_x, const uint32_t* d_r, const mpe_pdl_nonces* nonces, const mpe_pdl_proof* out,
+                  void* stream) {
+  if (!proof_args_ok(ctx, pk, stm, batch, d_key_idx, d_st_idx) || !d_cipher || !d_Q || !d_G || !d_x || !d_r || !nonces || !out)
+    return MPE_E_ARG;
+  if (batch == 0) return MPE_OK;
+  return mpe::pdl_prove(ctx, pk, stm, batch, d_key_idx, d_st_idx, d_cipher, d_Q, d_G, d_x, d_r, nonces, out, (hipStream_t)stream);
+}
+int mpe_pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch, const int32_t* d_key_idx,
+                   const int32_t* d_st_idx, const uint32_t* d_cipher, const uint32_t* d_Q, const uint32_t* d_G,
+                   const mpe_pdl_proof* proof, uint8_t* d_ok, void* stream) {
+  if (!proof_args_ok(ctx, pk, stm, batch, d_key_idx, d_st_idx) || !d_cipher || !d_Q || !d_G || !proof || !d_ok) return MPE_E_ARG;
+  if (batch == 0) return MPE_OK;
+  return mpe::pdl_verify(ctx, pk, stm, batch, d_key_idx, d_st_idx, d_cipher, d_Q, d_G, proof, d_ok, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -226,3 +226,136 @@ class PaillierKeys:
                             _dev_u32(ints_to_words(k, k_words), self.ctx.device), self._idx(key_idx))
         self.ctx.sync()
         return words_to_ints(_to_np_u32(d))
+
+
+# ================================================================================================
+# secp256k1, modinv, DLogStatement tables and the proofs (device-tensor API; int32 tensors of u32 words)
+# ================================================================================================
+def _new(ctx, B, words):
+    return torch.empty((B, words), dtype=torch.int32, device=ctx.device)
+
+
+def _flags(ctx, B):
+    return torch.empty((B,), dtype=torch.uint8, device=ctx.device)
+
+
+def dev(ctx, vals, words):
+    """Python ints -> device word tensor"""
+    return _dev_u32(ints_to_words(vals, words), ctx.device)
+
+
+def host(t):
+    """device word tensor -> Python ints"""
+    return words_to_ints(_to_np_u32(t))
+
+
+def modinv_device(ctx, ms, d_a, d_mod_idx=None):
+    B = d_a.shape[0]
+    out, ok = torch.empty_like(d_a), _flags(ctx, B)
+    N_.check(N_.lib.mpe_modinv(ctx.h, ms.h, B, _ptr(d_mod_idx), _ptr(d_a), _ptr(out), _ptr(ok), ctx.stream()), "mpe_modinv")
+    return out, ok
+
+
+def ec_mul_base(ctx, d_k):
+    out = _new(ctx, d_k.shape[0], 16)
+    N_.check(N_.lib.mpe_ec_mul_base(ctx.h, d_k.shape[0], _ptr(d_k), d_k.shape[1], _ptr(out), ctx.stream()), "mpe_ec_mul_base")
+    return out
+
+
+def ec_mul(ctx, d_k, d_P):
+    out = _new(ctx, d_k.shape[0], 16)
+    N_.check(N_.lib.mpe_ec_mul(ctx.h, d_k.shape[0], _ptr(d_k), d_k.shape[1], _ptr(d_P), _ptr(out), ctx.stream()), "mpe_ec_mul")
+    return out
+
+
+def ec_add(ctx, d_P, d_Q):
+    out = _new(ctx, d_P.shape[0], 16)
+    N_.check(N_.lib.mpe_ec_add(ctx.h, d_P.shape[0], _ptr(d_P), _ptr(d_Q), _ptr(out), ctx.stream()), "mpe_ec_add")
+    return out
+
+
+def dlog_prove(ctx, d_sk, d_nonce):
+    B = d_sk.shape[0]
+    pk, R, z = _new(ctx, B, 16), _new(ctx, B, 16), _new(ctx, B, 8)
+    N_.check(N_.lib.mpe_dlog_prove(ctx.h, B, _ptr(d_sk), _ptr(d_nonce), _ptr(pk), _ptr(R), _ptr(z), ctx.stream()), "mpe_dlog_prove")
+    return pk, R, z
+
+
+def dlog_verify(ctx, d_pk, d_R, d_z):
+    ok = _flags(ctx, d_pk.shape[0])
+    N_.check(N_.lib.mpe_dlog_verify(ctx.h, d_pk.shape[0], _ptr(d_pk), _ptr(d_R), _ptr(d_z), _ptr(ok), ctx.stream()), "mpe_dlog_verify")
+    return ok
+
+
+class Statements:
+    """Table of `DLogStatement{N: N~, g: h1, ni: h2}` (party_i.rs:225-229) resident in HBM."""
+
+    def __init__(self, ctx, Nt, h1, h2):
+        self.ctx = ctx
+        self.d = [dev(ctx, v, 64) for v in (Nt, h1, h2)]
+        h = C.c_void_p()
+        N_.check(N_.lib.mpe_statements_create(ctx.h, len(Nt), _ptr(self.d[0]), _ptr(self.d[1]), _ptr(self.d[2]),
+                                              C.byref(h), ctx.stream()), "mpe_statements_create")
+        self.h, self.count = h, len(Nt)
+
+    def close(self):
+        if self.h:
+            N_.lib.mpe_statements_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+ALICE_PROOF_WORDS = dict(z=64, e=8, s=64, s1=25, s2=89)
+ALICE_NONCE_WORDS = dict(alpha=24, beta=64, gamma=88, rho=72)
+PDL_PROOF_WORDS = dict(z=64, u1=16, u2=128, u3=64, s1=25, s2=64, s3=89)
+PDL_NONCE_WORDS = dict(alpha=24, beta=64, rho=72, gamma=88)
+
+
+def _struct(cls, tensors):
+    s = cls()
+    for f, _ in cls._fields_:
+        setattr(s, f, tensors[f].data_ptr())
+    return s
+
+
+def alice_generate(ctx, pk, stm, d_a, d_cipher, d_r, nonces, d_key_idx=None, d_st_idx=None):
+    """`AliceProof::generate` batched.  nonces / result: dict of device tensors (widths: ALICE_*_WORDS)."""
+    B = d_a.shape[0]
+    out = {f: _new(ctx, B, w) for f, w in ALICE_PROOF_WORDS.items()}
+    nn, pr = _struct(N_.AliceNonces, nonces), _struct(N_.AliceProof, out)
+    N_.check(N_.lib.mpe_alice_generate(ctx.h, pk.h, stm.h, B, _ptr(d_key_idx), _ptr(d_st_idx), _ptr(d_a), _ptr(d_cipher),
+                                       _ptr(d_r), C.byref(nn), C.byref(pr), ctx.stream()), "mpe_alice_generate")
+    return out
+
+
+def alice_verify(ctx, pk, stm, d_cipher, proof, d_key_idx=None, d_st_idx=None):
+    B = d_cipher.shape[0]
+    ok = _flags(ctx, B)
+    pr = _struct(N_.AliceProof, proof)
+    N_.check(N_.lib.mpe_alice_verify(ctx.h, pk.h, stm.h, B, _ptr(d_key_idx), _ptr(d_st_idx), _ptr(d_cipher), C.byref(pr),
+                                     _ptr(ok), ctx.stream()), "mpe_alice_verify")
+    return ok
+
+
+def pdl_prove(ctx, pk, stm, d_cipher, d_Q, d_G, d_x, d_r, nonces, d_key_idx=None, d_st_idx=None):
+    """`PDLwSlackProof::prove` batched."""
+    B = d_x.shape[0]
+    out = {f: _new(ctx, B, w) for f, w in PDL_PROOF_WORDS.items()}
+    nn, pr = _struct(N_.PdlNonces, nonces), _struct(N_.PdlProof, out)
+    N_.check(N_.lib.mpe_pdl_prove(ctx.h, pk.h, stm.h, B, _ptr(d_key_idx), _ptr(d_st_idx), _ptr(d_cipher), _ptr(d_Q), _ptr(d_G),
+                                  _ptr(d_x), _ptr(d_r), C.byref(nn), C.byref(pr), ctx.stream()), "mpe_pdl_prove")
+    return out
+
+
+def pdl_verify(ctx, pk, stm, d_cipher, d_Q, d_G, proof, d_key_idx=None, d_st_idx=None):
+    B = d_cipher.shape[0]
+    ok = _flags(ctx, B)
+    pr = _struct(N_.PdlProof, proof)
+    N_.check(N_.lib.mpe_pdl_verify(ctx.h, pk.h, stm.h, B, _ptr(d_key_idx), _ptr(d_st_idx), _ptr(d_cipher), _ptr(d_Q), _ptr(d_G),
+                                   C.byref(pr), _ptr(ok), ctx.stream()), "mpe_pdl_verify")
+    return ok

@@ -1,0 +1,235 @@
+"""GPU parity tests: secp256k1 ops, modinv, DLogProof, AliceProof and PDLwSlackProof through the
+C-ABI vs the GMP oracle (byte-identical proofs for identical nonces; cross-verification both ways;
+the reference's negative tests)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fixtures as F
+import orc
+import pyref
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+H = lambda s: int(s, 16)
+
+
+def E():
+    from multi_party_ecdsa_amd import engine
+    return engine
+
+
+def npw(t):
+    return np.ascontiguousarray(t.cpu().numpy().view(np.uint32))
+
+
+def to_dev(ctx, arr):
+    return torch.from_numpy(np.ascontiguousarray(arr).view(np.int32)).to(ctx.device)
+
+
+@pytest.fixture(scope="module")
+def env(gpu_ctx, keys):
+    e = E()
+    pk = e.PaillierKeys(gpu_ctx, N=[k.N for k in keys[:4]])
+    stm = e.Statements(gpu_ctx, [k.Nt for k in keys[4:7]], [k.h1 for k in keys[4:7]], [k.h2 for k in keys[4:7]])
+    tabs = dict(N=F.words([k.N for k in keys[:4]], 64), Nt=F.words([k.Nt for k in keys[4:7]], 64),
+                h1=F.words([k.h1 for k in keys[4:7]], 64), h2=F.words([k.h2 for k in keys[4:7]], 64))
+    return pk, stm, tabs
+
+
+def test_ec_ops_vs_oracle(gpu_ctx):
+    e = E()
+    r = F.Rng("gpu-ec")
+    B = 70
+    ks = [r.below(pyref.Q) for _ in range(B)]
+    ks[0], ks[1], ks[2], ks[3] = 0, 1, pyref.Q - 1, pyref.Q + 7          # edges: infinity, G, -G, reduction mod q
+    kw = F.words(ks, 9)                                                     # 9 words: exercises the mod-q reduction
+    got = npw(e.ec_mul_base(gpu_ctx, to_dev(gpu_ctx, kw)))
+    kred = F.words([k % pyref.Q for k in ks], 8)
+    want = orc.ec_mul_base(kred)
+    assert np.array_equal(got, want)
+    P = want.copy()
+    P[0] = want[5]                                                          # avoid infinity as a base for item 0
+    k2 = F.words([r.below(pyref.Q) for _ in range(B)], 8)
+    got = npw(e.ec_mul(gpu_ctx, to_dev(gpu_ctx, k2), to_dev(gpu_ctx, P)))
+    assert np.array_equal(got, orc.ec_mul(k2, P))
+    Q = np.roll(P, 1, axis=0)
+    Q[4] = P[4]                                                             # doubling through the add path
+    Q[6] = F.point_words([pyref.ec_neg(F.points(P[6:7])[0])])[0]            # P + (-P) = infinity
+    Q[7] = 0                                                                # P + infinity
+    got = npw(e.ec_add(gpu_ctx, to_dev(gpu_ctx, P), to_dev(gpu_ctx, Q)))
+    assert np.array_equal(got, orc.ec_add(P, Q))
+    # wide scalars: alpha < q^3 (24 words) reduced like Scalar::from(&BigInt)
+    al = [r.below(pyref.Q ** 3) for _ in range(8)]
+    got = npw(e.ec_mul_base(gpu_ctx, to_dev(gpu_ctx, F.words(al, 24))))
+    assert np.array_equal(got, orc.ec_mul_base(F.words([a % pyref.Q for a in al], 8)))
+
+
+def test_modinv_vs_oracle(gpu_ctx, keys):
+    e = E()
+    r = F.Rng("gpu-modinv")
+    for bits in (2048, 4096):
+        k32 = bits // 32
+        mods = [keys[0].N ** (bits // 2048), r.bits(bits) | (1 << (bits - 1)) | 1, keys[1].p * 3 if bits == 2048 else keys[1].NN]
+        B = 24
+        idx = [i % 3 for i in range(B)]
+        a = [r.below(mods[i]) for i in idx]
+        a[0], a[1] = 1, mods[idx[1]] - 1
+        a[2] = 3 * 5 if bits == 2048 else keys[1].p                          # not invertible mod mods[2]
+        a[5] = 0
+        ms = e.ModSet(gpu_ctx, bits, mods)
+        out, ok = e.modinv_device(gpu_ctx, ms, e.dev(gpu_ctx, a, k32), torch.tensor(idx, dtype=torch.int32, device=gpu_ctx.device))
+        gpu_ctx.sync()
+        w_out, w_ok = orc.modinv(F.words(mods, k32), F.words(a, k32), idx)
+        assert list(ok.cpu().numpy()) == list(w_ok)
+        assert np.array_equal(npw(out), w_out)
+        assert w_ok[2] == 0 and w_ok[5] == 0 and w_ok[0] == 1
+
+
+def test_dlog_proof(gpu_ctx):
+    e = E()
+    r = F.Rng("gpu-dlog")
+    B = 33
+    sk, nonce = F.words([r.below(pyref.Q) for _ in range(B)], 8), F.words([r.below(pyref.Q) for _ in range(B)], 8)
+    pk, R, z = e.dlog_prove(gpu_ctx, to_dev(gpu_ctx, sk), to_dev(gpu_ctx, nonce))
+    wpk, wR, wz = orc.dlog_prove(sk, nonce)
+    assert np.array_equal(npw(pk), wpk) and np.array_equal(npw(R), wR) and np.array_equal(npw(z), wz)
+    zz = wz.copy()
+    zz[3, 0] ^= 1
+    ok = e.dlog_verify(gpu_ctx, pk, R, to_dev(gpu_ctx, zz))
+    want = [1] * B
+    want[3] = 0
+    assert list(ok.cpu().numpy()) == want == list(orc.dlog_verify(wpk, wR, zz))
+
+
+def _alice_inputs(keys, B, seed):
+    r = F.Rng(seed)
+    kidx, sidx = [i % 4 for i in range(B)], [(i // 2) % 3 for i in range(B)]
+    a = [r.below(pyref.Q) for _ in range(B)]
+    rr = [r.below(keys[k].N) for k in kidx]
+    c = [pyref.paillier_encrypt(keys[k].N, x, y) for k, x, y in zip(kidx, a, rr)]
+    nn = [F.alice_nonces(r, keys[k], keys[4 + s]) for k, s in zip(kidx, sidx)]
+    return kidx, sidx, a, rr, c, nn
+
+
+def test_alice_proof_golden_and_oracle(gpu_ctx, keys, env):
+    e = E()
+    pk, stm, tabs = env
+    B = 21
+    kidx, sidx, a, rr, c, nn = _alice_inputs(keys, B, "gpu-alice")
+    nw = {f: F.words([n[f] for n in nn], w) for f, w in e.ALICE_NONCE_WORDS.items()}
+    di = lambda v: torch.tensor(v, dtype=torch.int32, device=gpu_ctx.device)
+    pr = e.alice_generate(gpu_ctx, pk, stm, e.dev(gpu_ctx, a, 8), e.dev(gpu_ctx, c, 128), e.dev(gpu_ctx, rr, 64),
+                          {f: to_dev(gpu_ctx, v) for f, v in nw.items()}, di(kidx), di(sidx))
+    want = orc.alice_generate(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], kidx, sidx, F.words(a, 8), F.words(c, 128),
+                              F.words(rr, 64), nw["alpha"], nw["beta"], nw["gamma"], nw["rho"])
+    for f in want:
+        assert np.array_equal(npw(pr[f]), want[f]), f
+    # the GPU proof verifies under the oracle, and the GPU verifier accepts it
+    assert list(orc.alice_verify(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], kidx, sidx, F.words(c, 128),
+                                 {f: npw(v) for f, v in pr.items()})) == [1] * B
+    ok = e.alice_verify(gpu_ctx, pk, stm, e.dev(gpu_ctx, c, 128), pr, di(kidx), di(sidx))
+    assert list(ok.cpu().numpy()) == [1] * B
+    # negatives (mirrors the oracle's accept/reject pattern): tampered s / s2 / ciphertext, s1 > q^3, wrong statement
+    bad = {f: v.clone() for f, v in pr.items()}
+    bad["s"][0, 0] ^= 1
+    bad["s2"][1, 40] ^= 2
+    bad["s1"][2] = to_dev(gpu_ctx, F.words([pyref.Q ** 3 + 1], 25))[0]
+    bad["z"][3, 5] ^= 1
+    c2 = e.dev(gpu_ctx, c, 128)
+    c2[4, 7] ^= 16
+    sidx2 = list(sidx)
+    sidx2[5] = (sidx2[5] + 1) % 3
+    ok = e.alice_verify(gpu_ctx, pk, stm, c2, bad, di(kidx), di(sidx2))
+    want_ok = orc.alice_verify(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], kidx, sidx2, npw(c2), {f: npw(v) for f, v in bad.items()})
+    assert list(ok.cpu().numpy()) == list(want_ok)
+    assert list(want_ok[:6]) == [0] * 6 and list(want_ok[6:]) == [1] * (B - 6)
+    # committed golden vectors (pure-Python generated)
+    with open(os.path.join(HERE, "golden", "golden_small.json")) as f:
+        gold = json.load(f)["alice"]
+    pk2 = e.PaillierKeys(gpu_ctx, N=[keys[g["ek"]].N for g in gold])
+    stm2 = e.Statements(gpu_ctx, *[[getattr(keys[g["st"]], f) for g in gold] for f in ("Nt", "h1", "h2")])
+    pr = e.alice_generate(gpu_ctx, pk2, stm2, e.dev(gpu_ctx, [H(g["a"]) for g in gold], 8),
+                          e.dev(gpu_ctx, [H(g["c"]) for g in gold], 128), e.dev(gpu_ctx, [H(g["r"]) for g in gold], 64),
+                          {f: e.dev(gpu_ctx, [H(g["nonces"][f]) for g in gold], w) for f, w in e.ALICE_NONCE_WORDS.items()})
+    for f in e.ALICE_PROOF_WORDS:
+        assert e.host(pr[f]) == [H(g["proof"][f]) for g in gold], f
+
+
+def test_pdl_proof_oracle_and_soundness(gpu_ctx, keys, env):
+    """zk_pdl_with_slack/test.rs:11-68 (prove -> verify) and :70-129 (ciphertext of x+1 -> reject)"""
+    e = E()
+    pk, stm, tabs = env
+    r = F.Rng("gpu-pdl")
+    B = 19
+    kidx, sidx = [i % 4 for i in range(B)], [(i // 3) % 3 for i in range(B)]
+    x = [r.below(pyref.Q) for _ in range(B)]
+    rr = [r.below(keys[k].N) for k in kidx]
+    G = [pyref.ec_mul(r.below(pyref.Q), pyref.G) for _ in range(B)]
+    Qp = [pyref.ec_mul(xx, g) for xx, g in zip(x, G)]
+    c = [pyref.paillier_encrypt(keys[k].N, xx + (1 if i == 2 else 0), y) for i, (k, xx, y) in enumerate(zip(kidx, x, rr))]
+    nn = [F.pdl_nonces(r, keys[k], keys[4 + s]) for k, s in zip(kidx, sidx)]
+    nw = {f: F.words([n[f] for n in nn], w) for f, w in e.PDL_NONCE_WORDS.items()}
+    di = lambda v: torch.tensor(v, dtype=torch.int32, device=gpu_ctx.device)
+    dC, dQ, dG = e.dev(gpu_ctx, c, 128), to_dev(gpu_ctx, F.point_words(Qp)), to_dev(gpu_ctx, F.point_words(G))
+    pr = e.pdl_prove(gpu_ctx, pk, stm, dC, dQ, dG, e.dev(gpu_ctx, x, 8), e.dev(gpu_ctx, rr, 64),
+                     {f: to_dev(gpu_ctx, v) for f, v in nw.items()}, di(kidx), di(sidx))
+    want = orc.pdl_prove(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], kidx, sidx, F.words(c, 128), F.point_words(Qp),
+                         F.point_words(G), F.words(x, 8), F.words(rr, 64), nw["alpha"], nw["beta"], nw["rho"], nw["gamma"])
+    for f in want:
+        assert np.array_equal(npw(pr[f]), want[f]), f
+    ok = e.pdl_verify(gpu_ctx, pk, stm, dC, dQ, dG, pr, di(kidx), di(sidx))
+    exp = [1] * B
+    exp[2] = 0                                                            # soundness: x+1 was encrypted
+    assert list(ok.cpu().numpy()) == exp
+    assert list(orc.pdl_verify(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], kidx, sidx, F.words(c, 128), F.point_words(Qp),
+                               F.point_words(G), {f: npw(v) for f, v in pr.items()})) == exp
+    # tamper every field in turn
+    for j, f in enumerate(["z", "u1", "u2", "u3", "s1", "s2", "s3"]):
+        bad = {k: v.clone() for k, v in pr.items()}
+        bad[f][4 + j, 1] ^= 1
+        ok = e.pdl_verify(gpu_ctx, pk, stm, dC, dQ, dG, bad, di(kidx), di(sidx))
+        w = orc.pdl_verify(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], kidx, sidx, F.words(c, 128), F.point_words(Qp),
+                           F.point_words(G), {k: npw(v) for k, v in bad.items()})
+        assert list(ok.cpu().numpy()) == list(w), f
+        assert w[4 + j] == 0
+
+
+def test_config3_scale_proofs(gpu_ctx, keys, env):
+    """A larger batch of PDL prove + verify (config 3 shape, reduced count for test time): 100 % accept,
+    every corrupted item rejected, a prefix bit-exact vs the oracle."""
+    e = E()
+    pk, stm, tabs = env
+    B = 2048
+    dev_ = gpu_ctx.device
+    g = torch.Generator(device=dev_)
+    g.manual_seed(5)
+    rnd = lambda w, full: torch.cat([torch.randint(-2**31, 2**31 - 1, (B, full), dtype=torch.int32, device=dev_, generator=g),
+                                     torch.zeros((B, w - full), dtype=torch.int32, device=dev_)], dim=1)
+    x = rnd(8, 7)                              # < 2^224 < q
+    rr = rnd(64, 63)
+    nonces = dict(alpha=rnd(24, 23), beta=rnd(64, 63), rho=rnd(72, 71), gamma=rnd(88, 87))
+    kidx = (torch.arange(B, device=dev_, dtype=torch.int32) % 4).contiguous()
+    sidx = (torch.arange(B, device=dev_, dtype=torch.int32) % 3).contiguous()
+    Gp = e.ec_mul_base(gpu_ctx, rnd(8, 7))
+    Qp = e.ec_mul(gpu_ctx, x, Gp)
+    xm = torch.zeros((B, 64), dtype=torch.int32, device=dev_)
+    xm[:, :8] = x
+    c = pk.encrypt_device(xm, rr, kidx)
+    pr = e.pdl_prove(gpu_ctx, pk, stm, c, Qp, Gp, x, rr, nonces, kidx, sidx)
+    ok = e.pdl_verify(gpu_ctx, pk, stm, c, Qp, Gp, pr, kidx, sidx)
+    assert int(ok.sum()) == B
+    bad = {k: v.clone() for k, v in pr.items()}
+    bad["s2"][::100, 3] ^= 4
+    ok = e.pdl_verify(gpu_ctx, pk, stm, c, Qp, Gp, bad, kidx, sidx)
+    okh = ok.cpu().numpy()
+    assert okh[::100].sum() == 0 and okh.sum() == B - len(okh[::100])
+    n = 16
+    want = orc.pdl_prove(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], list(range(4)) * 4, [i % 3 for i in range(n)],
+                         npw(c[:n]), npw(Qp[:n]), npw(Gp[:n]), npw(x[:n]), npw(rr[:n]), npw(nonces["alpha"][:n]),
+                         npw(nonces["beta"][:n]), npw(nonces["rho"][:n]), npw(nonces["gamma"][:n]))
+    for f in want:
+        assert np.array_equal(npw(pr[f][:n]), want[f]), f
