@@ -740,3 +740,5 @@ void orc_nextprime(int k32, const uint32_t* start, uint32_t* out) {
   zout(out, k32, x);
   mpz_clear(x);
 }
+
+#include "gg20_oracle.c"

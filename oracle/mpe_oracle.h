@@ -127,6 +127,29 @@ void orc_pdl_verify(int batch, int nkeys, const uint32_t* N, int nst, const uint
 void orc_dlog_prove(int batch, const uint32_t* sk, const uint32_t* nonce, uint32_t* pk, uint32_t* R, uint32_t* z);
 void orc_dlog_verify(int batch, const uint32_t* pk, const uint32_t* R, const uint32_t* z, uint8_t* ok);
 
+/* ---- one complete GG20 signing session, all parties in lock-step (gg20_oracle.c) --------------- */
+/* keys: n parties (x: shares [n][8], p,q: Paillier primes [n][32], Nt,h1,h2: [n][64], y: public key [16],
+ * X: pk_vec [n][16]); signers: S ascending party indices.  Nonces: leading dimension = session, then
+ * signer i (S), statement st (n), pair pp = i*(S-1)+jj and MessageB variant v (0 = gamma_i, 1 = w_i). */
+typedef struct {
+  int t, n, S;
+  const int32_t* signers;
+  const uint32_t *x, *p, *q, *Nt, *h1, *h2, *y, *X;
+} orc_gg20_keys;
+
+typedef struct {
+  const uint32_t *k, *gamma, *blind, *r_a;
+  const uint32_t *al_alpha, *al_beta, *al_gamma, *al_rho;
+  const uint32_t *mb_beta_tag, *mb_r, *mb_nonce_b, *mb_nonce_bt;
+  const uint32_t *l, *ped_s1, *ped_s2;
+  const uint32_t *pdl_alpha, *pdl_beta, *pdl_rho, *pdl_gamma;
+  const uint32_t *heg_s1, *heg_s2;
+  const uint32_t* msg;
+} orc_gg20_nonces;
+
+void orc_gg20_sign(const orc_gg20_keys* K, const orc_gg20_nonces* Z, int first, int count, uint32_t* r_out,
+                   uint32_t* s_out, int32_t* recid_out, uint32_t* R_out, int32_t* status);
+
 /* fixture helper (test key material only): smallest prime > start */
 void orc_nextprime(int k32, const uint32_t* start, uint32_t* out);
 
