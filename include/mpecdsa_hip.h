@@ -169,6 +169,50 @@ int mpe_pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* s
                    const uint32_t* d_Q, const uint32_t* d_G, const mpe_pdl_proof* proof, uint8_t* d_ok,
                    void* stream);
 
+/* ---- GG20 signing, batched (Round0..Round7 of every party of every session in lock-step) ------------ */
+/* Key material as the reference's keygen leaves it in `LocalKey` (state_machine/keygen/rounds.rs:311-322),
+ * for all n parties, shared by every session of a batch: d_x [n][8] shares x_i, d_p/d_q [n][32] Paillier
+ * primes, d_Nt/d_h1/d_h2 [n][64] `h1_h2_n_tilde_vec`, d_y [16] `y_sum_s`, d_X [n][16] `pk_vec`.
+ * h_signers (HOST array): n_signers = t+1 ascending party indices (`s_l` minus one, sign.rs:78). */
+typedef struct mpe_gg20_keys mpe_gg20_keys;
+int mpe_gg20_keys_create(mpe_ctx* ctx, int t, int n, int n_signers, const int32_t* h_signers, const uint32_t* d_x,
+                         const uint32_t* d_p, const uint32_t* d_q, const uint32_t* d_Nt, const uint32_t* d_h1,
+                         const uint32_t* d_h2, const uint32_t* d_y, const uint32_t* d_X, mpe_gg20_keys** out,
+                         void* stream);
+int mpe_gg20_keys_destroy(mpe_gg20_keys* keys);
+
+/* Everything the reference samples while signing, as inputs.  S = signers, P = S(S-1) ordered pairs.
+ * Leading dimension = session; then signer i; pair pp = i*(S-1)+jj (peer ind = jj<i ? jj : jj+1, the
+ * `ind` of rounds.rs:149); statement st; MessageB variant v (0: gamma_i, 1: w_i).
+ *   k, gamma, blind, l, ped_s1, ped_s2, heg_s1, heg_s2 : [B][S][8]      r_a : [B][S][64]
+ *   al_alpha [B][S][n][24]  al_beta [..][64]  al_gamma [..][88]  al_rho [..][72]     (AliceProof nonces)
+ *   mb_beta_tag, mb_r : [B][P][2][64]   mb_nonce_b, mb_nonce_bt : [B][P][2][8]       (MessageB::b)
+ *   pdl_alpha [B][P][24]  pdl_beta [..][64]  pdl_rho [..][72]  pdl_gamma [..][88]    (PDLwSlackProof::prove)
+ *   msg : [B][8]  the message as BigInt (reduced mod q like `Scalar::from(message)`, party_i.rs:857) */
+typedef struct {
+  const uint32_t *k, *gamma, *blind, *r_a;
+  const uint32_t *al_alpha, *al_beta, *al_gamma, *al_rho;
+  const uint32_t *mb_beta_tag, *mb_r, *mb_nonce_b, *mb_nonce_bt;
+  const uint32_t *l, *ped_s1, *ped_s2;
+  const uint32_t *pdl_alpha, *pdl_beta, *pdl_rho, *pdl_gamma;
+  const uint32_t *heg_s1, *heg_s2;
+  const uint32_t *msg;
+} mpe_gg20_nonces;
+
+/* Runs OfflineStage Round0..Round6 and SignManual (Round7) for `batch` sessions, every party simulated on this
+ * GPU (what `round_based::dev::Simulation` does for one session in state_machine/sign.rs:667-763).
+ * Outputs per session: d_r, d_s [batch][8] and d_recid [batch] = `SignatureRecid{r,s,recid}` (party_i.rs:131-135,
+ * low-s normalised, 873-910), optionally d_R [batch][16], and d_status [batch]: 0 = signature produced and
+ * verified, otherwise 100*round + detail of the first failed check (101 range proof rejected -> the reference's
+ * Error::Round1/InvalidKey; 201 verify_proofs_get_alpha; 302 Pedersen; 401 phase4; 501 PDL/R_dash; 601 HEG/S_i
+ * sum; 701 final verify).  A failing session never aborts the batch.
+ * dedup_verify = 0: faithful work (each range proof verified for both MessageB::b calls, every party verifies
+ * every PDL proof, exactly as rounds.rs:151-175,546-558); 1: identical checks are evaluated once (same outputs).
+ * chunk: sessions per internal pass (0 = default 4096). */
+int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const mpe_gg20_nonces* nonces, uint32_t* d_r,
+                  uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, int dedup_verify, int chunk,
+                  void* stream);
+
 /* Kernel geometry chosen for the last launch (for bench.py's roofline accounting). */
 typedef struct {
   int waves;              /* workgroups (= waves) launched */

@@ -35,6 +35,12 @@ PdlProof = _ptr_struct("PdlProof", ["z", "u1", "u2", "u3", "s1", "s2", "s3"])
 PdlNonces = _ptr_struct("PdlNonces", ["alpha", "beta", "rho", "gamma"])
 
 
+GG20_NONCE_FIELDS = ["k", "gamma", "blind", "r_a", "al_alpha", "al_beta", "al_gamma", "al_rho", "mb_beta_tag", "mb_r",
+                     "mb_nonce_b", "mb_nonce_bt", "l", "ped_s1", "ped_s2", "pdl_alpha", "pdl_beta", "pdl_rho", "pdl_gamma",
+                     "heg_s1", "heg_s2", "msg"]
+Gg20Nonces = _ptr_struct("Gg20Nonces", GG20_NONCE_FIELDS)
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -69,6 +75,9 @@ def _load():
         "mpe_pdl_prove": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, u32p, u32p, u32p, C.POINTER(PdlNonces),
                                C.POINTER(PdlProof), vp]),
         "mpe_pdl_verify": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, u32p, C.POINTER(PdlProof), vp, vp]),
+        "mpe_gg20_keys_create": (ip, [vp, ip, ip, ip, C.POINTER(C.c_int32)] + [u32p] * 8 + [C.POINTER(vp), vp]),
+        "mpe_gg20_keys_destroy": (ip, [vp]),
+        "mpe_gg20_sign": (ip, [vp, vp, ip, C.POINTER(Gg20Nonces), u32p, u32p, vp, u32p, vp, ip, ip, vp]),
         "mpe_prof_enable": (ip, [vp, ip]),
         "mpe_prof_collect": (ip, [vp, C.POINTER(ProfRec), ip, C.POINTER(C.c_int)]),
         "mpe_paillier_create_public": (ip, [vp, ip, u32p, C.POINTER(vp), vp]),
@@ -98,7 +107,8 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_paillier_encrypt", "mpe_paillier_decrypt", "mpe_paillier_add", "mpe_paillier_mul",
             "mpe_prof_enable", "mpe_prof_collect", "mpe_modinv", "mpe_ec_mul_base", "mpe_ec_mul", "mpe_ec_add",
             "mpe_dlog_prove", "mpe_dlog_verify", "mpe_statements_create", "mpe_statements_destroy",
-            "mpe_alice_generate", "mpe_alice_verify", "mpe_pdl_prove", "mpe_pdl_verify"]
+            "mpe_alice_generate", "mpe_alice_verify", "mpe_pdl_prove", "mpe_pdl_verify", "mpe_gg20_keys_create",
+            "mpe_gg20_keys_destroy", "mpe_gg20_sign"]
 
 
 def check(rc, what):

@@ -185,24 +185,24 @@ __global__ void hash_kernel(int B, HashDesc d, uint32_t* __restrict__ out) {
 static HashField hf(Rows r, int words, int kind = HF_BIGINT) { return HashField{r, words, kind}; }
 
 // ok[i] = (a[i] <= q^3) for the s1 range check (range_proofs.rs:118 / :335)
-__global__ void s1_range_kernel(int B, const uint32_t* __restrict__ s1, int words, uint8_t* __restrict__ ok) {
+__global__ void s1_range_kernel(int B, Rows s1, int words, uint8_t* __restrict__ ok) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   uint32_t q[8], q2[16], q3[24];
   for (int j = 0; j < 8; ++j) q[j] = ec::FQ[j];
   sm::mul(q2, q, 8, q, 8);
   sm::mul(q3, q2, 16, q, 8);
-  ok[i] = sm::cmp(s1 + (size_t)i * words, words, q3, 24) <= 0 ? 1 : 0;
+  ok[i] = sm::cmp(row_of(s1, i), words, q3, 24) <= 0 ? 1 : 0;
 }
 // ok[i] &= all of: flags a, b (optional) and equality of the [words] rows x == y (optional)
 __global__ void and_flags_kernel(int B, uint8_t* __restrict__ ok, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
-                                 const uint32_t* __restrict__ x, const uint32_t* __restrict__ y, int words) {
+                                 const uint32_t* __restrict__ x, Rows y, int words) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   bool v = ok[i] != 0;
   if (a) v = v && a[i];
   if (b) v = v && b[i];
-  if (x) v = v && sm::cmp(x + (size_t)i * words, words, y + (size_t)i * words, words) == 0;
+  if (x) v = v && sm::cmp(x + (size_t)i * words, words, row_of(y, i), words) == 0;
   ok[i] = v ? 1 : 0;
 }
 __global__ void fill_u8_kernel(int B, uint8_t* p, uint8_t v) {
@@ -210,15 +210,22 @@ __global__ void fill_u8_kernel(int B, uint8_t* p, uint8_t v) {
   if (i < B) p[i] = v;
 }
 // PDL verify: ok &= ( (s1 mod q) G + (q - e) Q == u1 )      (zk_pdl_with_slack/mod.rs:138-142,174)
-__global__ void pdl_u1_check_kernel(int B, const uint32_t* __restrict__ s1, const uint32_t* __restrict__ e,
-                                    const uint32_t* __restrict__ G, const uint32_t* __restrict__ Q,
-                                    const uint32_t* __restrict__ u1, uint8_t* __restrict__ ok) {
+__global__ void pdl_u1_check_kernel(int B, Rows s1, const uint32_t* __restrict__ e, Rows G, Rows Q, Rows u1,
+                                    uint8_t* __restrict__ ok) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
-  const ec::U256 a = ec::sc_reduce(s1 + (size_t)i * 25, 25);
+  const ec::U256 a = ec::sc_reduce(row_of(s1, i), 25);
   const ec::U256 ne = ec::sc_neg(ec::sc_reduce(e + (size_t)i * 8, 8));
-  const ec::Jac l = ec::jac_add(ec::jac_mul(a, ec::aff_load(G + (size_t)i * 16)), ec::jac_mul(ne, ec::aff_load(Q + (size_t)i * 16)));
-  if (!ec::aff_eq(ec::jac_to_aff(l), ec::aff_load(u1 + (size_t)i * 16))) ok[i] = 0;
+  const ec::Jac l = ec::jac_add(ec::jac_mul(a, ec::aff_load(row_of(G, i))), ec::jac_mul(ne, ec::aff_load(row_of(Q, i))));
+  if (!ec::aff_eq(ec::jac_to_aff(l), ec::aff_load(row_of(u1, i)))) ok[i] = 0;
+}
+// out = (k mod q) * P with per-item rows (P.p == nullptr -> generator)
+__global__ void ec_mul_rows_kernel(int B, Rows k, int kw, Rows P, uint32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const ec::U256 s = ec::sc_reduce(row_of(k, i), kw);
+  const ec::Aff p = P.p ? ec::aff_load(row_of(P, i)) : ec::aff_gen();
+  ec::aff_store(out + (size_t)i * 16, ec::jac_to_aff(ec::jac_mul(s, p)));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -280,11 +287,23 @@ static Rows tab_rows(const uint32_t* table, int stride, const int32_t* idx, int 
   return Rows{table, nullptr, count == 1 ? 0 : stride, words};
 }
 
+// proofs read through Rows so that the round pipeline can verify a proof in place, without gathering
+struct AliceProofRows { Rows z, e, s, s1, s2; };
+struct PdlProofRows { Rows z, u1, u2, u3, s1, s2, s3; };
+static AliceProofRows dense(const mpe_alice_proof* p) {
+  return AliceProofRows{rows(p->z, 64), rows(p->e, 8), rows(p->s, 64), rows(p->s1, 25), rows(p->s2, 89)};
+}
+static PdlProofRows dense(const mpe_pdl_proof* p) {
+  return PdlProofRows{rows(p->z, 64), rows(p->u1, 16), rows(p->u2, 128), rows(p->u3, 64), rows(p->s1, 25), rows(p->s2, 64),
+                      rows(p->s3, 89)};
+}
+static Rows with_words(Rows r, int words) { r.words = words; return r; }
+
 // ---------------------------------------------------------------------------------------------
 // AliceProof::generate   (range_proofs.rs:160-193; rounds :39-67 and :78-90)
 // ---------------------------------------------------------------------------------------------
 static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
-                          const int32_t* st_idx, const uint32_t* a, const uint32_t* cipher, const uint32_t* r,
+                          const int32_t* st_idx, Rows a, Rows cipher, Rows r,
                           const mpe_alice_nonces* nn, const mpe_alice_proof* out, hipStream_t st) {
   MPE_TRY(ws_reserve(ctx, (size_t)B * 1400 * 4 + 65536, st));
   Seq q{ctx, st, B};
@@ -292,7 +311,7 @@ static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statem
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
   const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
   // z = h1^a h2^rho mod N~                                                      :52
-  uint32_t* z1 = q.modexp(stm->ms, ssel, h1, rows(a, 8), 8);
+  uint32_t* z1 = q.modexp(stm->ms, ssel, h1, a, 8);
   uint32_t* z2 = q.modexp(stm->ms, ssel, h2, rows(nn->rho, 72), 72);
   q.modmul_to(stm->ms, ssel, rows(z1, 64), rows(z2, 64), out->z);
   // u = (alpha N + 1) beta^N mod N^2                                            :53-55
@@ -307,13 +326,13 @@ static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statem
   // e = H(N, N+1, c, z, u, w)                                                   :175-182
   HashDesc d;
   d.n = 6;
-  d.f[0] = hf(Nrow, 64); d.f[1] = hf(Nrow, 64, HF_BIGINT_PLUS1); d.f[2] = hf(rows(cipher, 128), 128);
+  d.f[0] = hf(Nrow, 64); d.f[1] = hf(Nrow, 64, HF_BIGINT_PLUS1); d.f[2] = hf(cipher, 128);
   d.f[3] = hf(rows(out->z, 64), 64); d.f[4] = hf(rows(u, 128), 128); d.f[5] = hf(rows(w, 64), 64);
   q.hash(d, out->e);
   // s = r^e beta mod N ; s1 = e a + alpha ; s2 = e rho + gamma                  :84-88
-  uint32_t* re = q.modexp(pk->ms_n, ksel, rows(r, 64), rows(out->e, 8), 8);
+  uint32_t* re = q.modexp(pk->ms_n, ksel, r, rows(out->e, 8), 8);
   q.modmul_to(pk->ms_n, ksel, rows(re, 64), rows(nn->beta, 64), out->s);
-  q.muladd(rows(out->e, 8), 8, rows(a, 8), 8, rows(nn->alpha, 24), 24, out->s1, 25);
+  q.muladd(rows(out->e, 8), 8, a, 8, rows(nn->alpha, 24), 24, out->s1, 25);
   q.muladd(rows(out->e, 8), 8, rows(nn->rho, 72), 72, rows(nn->gamma, 88), 88, out->s2, 89);
   return q.finish("alice_generate");
 }
@@ -322,39 +341,38 @@ static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statem
 // AliceProof::verify   (range_proofs.rs:105-156)
 // ---------------------------------------------------------------------------------------------
 static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
-                        const int32_t* st_idx, const uint32_t* cipher, const mpe_alice_proof* pr, uint8_t* ok,
-                        hipStream_t st) {
+                        const int32_t* st_idx, Rows cipher, const AliceProofRows& pr, uint8_t* ok, hipStream_t st) {
   MPE_TRY(ws_reserve(ctx, (size_t)B * 1800 * 4 + 65536, st));
   Seq q{ctx, st, B};
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
   const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
-  MPE_LAUNCH_1D(s1_range_kernel, B, st, B, pr->s1, 25, ok);                                        // :118
+  MPE_LAUNCH_1D(s1_range_kernel, B, st, B, pr.s1, 25, ok);                                         // :118
   // w' = h1^s1 h2^s2 (z^e)^-1 mod N~                                                               :122-132
   uint8_t *inv_ok1 = q.flags(), *inv_ok2 = q.flags();
-  uint32_t* ze = q.modexp(stm->ms, ssel, rows(pr->z, 64), rows(pr->e, 8), 8);
+  uint32_t* ze = q.modexp(stm->ms, ssel, pr.z, pr.e, 8);
   uint32_t* zei = q.modinv(stm->ms, ssel, rows(ze, 64), inv_ok1);
-  uint32_t* a1 = q.modexp(stm->ms, ssel, h1, rows(pr->s1, 25), 25);
-  uint32_t* a2 = q.modexp(stm->ms, ssel, h2, rows(pr->s2, 89), 89);
+  uint32_t* a1 = q.modexp(stm->ms, ssel, h1, pr.s1, 25);
+  uint32_t* a2 = q.modexp(stm->ms, ssel, h2, pr.s2, 89);
   uint32_t* a12 = q.modmul(stm->ms, ssel, rows(a1, 64), rows(a2, 64));
   uint32_t* w = q.modmul(stm->ms, ssel, rows(a12, 64), rows(zei, 64));
   // u' = (s1 N + 1) s^N (c^e)^-1 mod N^2                                                           :134-141
   uint32_t* gs1 = q.words(128);
-  q.muladd(rows(pr->s1, 25), 25, Nrow, 64, no_rows(), 0, gs1, 128);
-  uint32_t* ce = q.modexp(pk->ms_nn, ksel, rows(cipher, 128), rows(pr->e, 8), 8);
+  q.muladd(pr.s1, 25, Nrow, 64, no_rows(), 0, gs1, 128);
+  uint32_t* ce = q.modexp(pk->ms_nn, ksel, cipher, pr.e, 8);
   uint32_t* cei = q.modinv(pk->ms_nn, ksel, rows(ce, 128), inv_ok2);
-  uint32_t* sn = q.modexp(pk->ms_nn, ksel, rows(pr->s, 64, nullptr, 64), Nrow, 64);
+  uint32_t* sn = q.modexp(pk->ms_nn, ksel, with_words(pr.s, 64), Nrow, 64);
   uint32_t* b12 = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(sn, 128));
   uint32_t* u = q.modmul(pk->ms_nn, ksel, rows(b12, 128), rows(cei, 128));
   // e' = H(N, N+1, c, z, u', w') == e                                                              :143-153
   uint32_t* e2 = q.words(8);
   HashDesc d;
   d.n = 6;
-  d.f[0] = hf(Nrow, 64); d.f[1] = hf(Nrow, 64, HF_BIGINT_PLUS1); d.f[2] = hf(rows(cipher, 128), 128);
-  d.f[3] = hf(rows(pr->z, 64), 64); d.f[4] = hf(rows(u, 128), 128); d.f[5] = hf(rows(w, 64), 64);
+  d.f[0] = hf(Nrow, 64); d.f[1] = hf(Nrow, 64, HF_BIGINT_PLUS1); d.f[2] = hf(cipher, 128);
+  d.f[3] = hf(pr.z, 64); d.f[4] = hf(rows(u, 128), 128); d.f[5] = hf(rows(w, 64), 64);
   q.hash(d, e2);
   if (q.rc == MPE_OK)
-    hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ok, inv_ok1, inv_ok2, e2, pr->e, 8);
+    hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ok, inv_ok1, inv_ok2, e2, pr.e, 8);
   return q.finish("alice_verify");
 }
 
@@ -362,20 +380,19 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
 // PDLwSlackProof::prove   (zk_pdl_with_slack/mod.rs:68-125)
 // ---------------------------------------------------------------------------------------------
 static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
-                     const int32_t* st_idx, const uint32_t* cipher, const uint32_t* Qp, const uint32_t* Gp,
-                     const uint32_t* x, const uint32_t* r, const mpe_pdl_nonces* nn, const mpe_pdl_proof* out,
-                     hipStream_t st) {
+                     const int32_t* st_idx, Rows cipher, Rows Qp, Rows Gp, Rows x, Rows r, const mpe_pdl_nonces* nn,
+                     const mpe_pdl_proof* out, hipStream_t st) {
   MPE_TRY(ws_reserve(ctx, (size_t)B * 1400 * 4 + 65536, st));
   Seq q{ctx, st, B};
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
   const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
   // z = h1^x h2^rho mod N~                                                      :79-85
-  uint32_t* z1 = q.modexp(stm->ms, ssel, h1, rows(x, 8), 8);
+  uint32_t* z1 = q.modexp(stm->ms, ssel, h1, x, 8);
   uint32_t* z2 = q.modexp(stm->ms, ssel, h2, rows(nn->rho, 72), 72);
   q.modmul_to(stm->ms, ssel, rows(z1, 64), rows(z2, 64), out->z);
   // u1 = (alpha mod q) G                                                        :86
-  MPE_LAUNCH_1D(ec_mul_kernel, B, st, B, nn->alpha, 24, Gp, out->u1);
+  MPE_LAUNCH_1D(ec_mul_rows_kernel, B, st, B, rows(nn->alpha, 24), 24, Gp, out->u1);
   // u2 = (N+1)^alpha beta^N mod N^2; (N+1)^alpha = 1 + alpha N (mod N^2), alpha N + 1 < N^2      :87-93
   uint32_t* ga = q.words(128);
   q.muladd(rows(nn->alpha, 24), 24, Nrow, 64, no_rows(), 0, ga, 128);
@@ -389,14 +406,14 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
   uint32_t* e = q.words(8);
   HashDesc d;
   d.n = 7;
-  d.f[0] = hf(rows(Gp, 16), 16, HF_POINT_COMPRESSED); d.f[1] = hf(rows(Qp, 16), 16, HF_POINT_COMPRESSED);
-  d.f[2] = hf(rows(cipher, 128), 128); d.f[3] = hf(rows(out->z, 64), 64);
+  d.f[0] = hf(Gp, 16, HF_POINT_COMPRESSED); d.f[1] = hf(Qp, 16, HF_POINT_COMPRESSED);
+  d.f[2] = hf(cipher, 128); d.f[3] = hf(rows(out->z, 64), 64);
   d.f[4] = hf(rows(out->u1, 16), 16, HF_POINT_COMPRESSED); d.f[5] = hf(rows(out->u2, 128), 128);
   d.f[6] = hf(rows(out->u3, 64), 64);
   q.hash(d, e);
   // s1 = e x + alpha ; s2 = r^e beta mod N ; s3 = e rho + gamma                :112-114
-  q.muladd(rows(e, 8), 8, rows(x, 8), 8, rows(nn->alpha, 24), 24, out->s1, 25);
-  uint32_t* re = q.modexp(pk->ms_n, ksel, rows(r, 64), rows(e, 8), 8);
+  q.muladd(rows(e, 8), 8, x, 8, rows(nn->alpha, 24), 24, out->s1, 25);
+  uint32_t* re = q.modexp(pk->ms_n, ksel, r, rows(e, 8), 8);
   q.modmul_to(pk->ms_n, ksel, rows(re, 64), rows(nn->beta, 64), out->s2);
   q.muladd(rows(e, 8), 8, rows(nn->rho, 72), 72, rows(nn->gamma, 88), 88, out->s3, 89);
   return q.finish("pdl_prove");
@@ -406,8 +423,8 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
 // PDLwSlackProof::verify   (zk_pdl_with_slack/mod.rs:127-179)
 // ---------------------------------------------------------------------------------------------
 static int pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
-                      const int32_t* st_idx, const uint32_t* cipher, const uint32_t* Qp, const uint32_t* Gp,
-                      const mpe_pdl_proof* pr, uint8_t* ok, hipStream_t st) {
+                      const int32_t* st_idx, Rows cipher, Rows Qp, Rows Gp, const PdlProofRows& pr, uint8_t* ok,
+                      hipStream_t st) {
   MPE_TRY(ws_reserve(ctx, (size_t)B * 2200 * 4 + 65536, st));
   Seq q{ctx, st, B};
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
@@ -416,35 +433,35 @@ static int pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   uint32_t* e = q.words(8);
   HashDesc d;
   d.n = 7;
-  d.f[0] = hf(rows(Gp, 16), 16, HF_POINT_COMPRESSED); d.f[1] = hf(rows(Qp, 16), 16, HF_POINT_COMPRESSED);
-  d.f[2] = hf(rows(cipher, 128), 128); d.f[3] = hf(rows(pr->z, 64), 64);
-  d.f[4] = hf(rows(pr->u1, 16), 16, HF_POINT_COMPRESSED); d.f[5] = hf(rows(pr->u2, 128), 128);
-  d.f[6] = hf(rows(pr->u3, 64), 64);
+  d.f[0] = hf(Gp, 16, HF_POINT_COMPRESSED); d.f[1] = hf(Qp, 16, HF_POINT_COMPRESSED);
+  d.f[2] = hf(cipher, 128); d.f[3] = hf(pr.z, 64);
+  d.f[4] = hf(pr.u1, 16, HF_POINT_COMPRESSED); d.f[5] = hf(pr.u2, 128);
+  d.f[6] = hf(pr.u3, 64);
   q.hash(d, e);                                                                                     // :128-136
   MPE_LAUNCH_1D(fill_u8_kernel, B, st, B, ok, (uint8_t)1);
-  MPE_LAUNCH_1D(pdl_u1_check_kernel, B, st, B, pr->s1, e, Gp, Qp, pr->u1, ok);                     // :138-142
+  MPE_LAUNCH_1D(pdl_u1_check_kernel, B, st, B, pr.s1, e, Gp, Qp, pr.u1, ok);                       // :138-142
   uint8_t *inv_ok1 = q.flags(), *inv_ok2 = q.flags();
   // u2' = (N+1)^s1 s2^N c^-e mod N^2; (N+1)^s1 = 1 + s1 N < N^2 because s1 < 2^800                 :144-157
   uint32_t* g1 = q.words(128);
-  q.muladd(rows(pr->s1, 25), 25, Nrow, 64, no_rows(), 0, g1, 128);
-  uint32_t* s2n = q.modexp(pk->ms_nn, ksel, rows(pr->s2, 64, nullptr, 64), Nrow, 64);
+  q.muladd(pr.s1, 25, Nrow, 64, no_rows(), 0, g1, 128);
+  uint32_t* s2n = q.modexp(pk->ms_nn, ksel, with_words(pr.s2, 64), Nrow, 64);
   uint32_t* t2 = q.modmul(pk->ms_nn, ksel, rows(g1, 128), rows(s2n, 128));
-  uint32_t* cred = q.modmul(pk->ms_nn, ksel, rows(cipher, 128), rows(pk->ms_nn->one_words, 0, nullptr, 1));  // c mod N^2
+  uint32_t* cred = q.modmul(pk->ms_nn, ksel, cipher, rows(pk->ms_nn->one_words, 0, nullptr, 1));  // c mod N^2
   uint32_t* cinv = q.modinv(pk->ms_nn, ksel, rows(cred, 128), inv_ok1);
   uint32_t* cie = q.modexp(pk->ms_nn, ksel, rows(cinv, 128), rows(e, 8), 8);
   uint32_t* u2 = q.modmul(pk->ms_nn, ksel, rows(t2, 128), rows(cie, 128));
   // u3' = h1^s1 h2^s3 z^-e mod N~                                                                  :159-172
-  uint32_t* a1 = q.modexp(stm->ms, ssel, h1, rows(pr->s1, 25), 25);
-  uint32_t* a2 = q.modexp(stm->ms, ssel, h2, rows(pr->s3, 89), 89);
+  uint32_t* a1 = q.modexp(stm->ms, ssel, h1, pr.s1, 25);
+  uint32_t* a2 = q.modexp(stm->ms, ssel, h2, pr.s3, 89);
   uint32_t* a12 = q.modmul(stm->ms, ssel, rows(a1, 64), rows(a2, 64));
-  uint32_t* zred = q.modmul(stm->ms, ssel, rows(pr->z, 64), rows(stm->ms->one_words, 0, nullptr, 1));
+  uint32_t* zred = q.modmul(stm->ms, ssel, pr.z, rows(stm->ms->one_words, 0, nullptr, 1));
   uint32_t* zinv = q.modinv(stm->ms, ssel, rows(zred, 64), inv_ok2);
   uint32_t* zie = q.modexp(stm->ms, ssel, rows(zinv, 64), rows(e, 8), 8);
   uint32_t* u3 = q.modmul(stm->ms, ssel, rows(a12, 64), rows(zie, 64));
   if (q.rc == MPE_OK) {                                                                             // :174
-    hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ok, inv_ok1, inv_ok2, u2, pr->u2, 128);
+    hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ok, inv_ok1, inv_ok2, u2, pr.u2, 128);
     hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ok, (const uint8_t*)nullptr,
-                       (const uint8_t*)nullptr, u3, pr->u3, 64);
+                       (const uint8_t*)nullptr, u3, pr.u3, 64);
   }
   return q.finish("pdl_verify");
 }
@@ -536,14 +553,16 @@ int mpe_alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statement
                        const uint32_t* d_r, const mpe_alice_nonces* nonces, const mpe_alice_proof* out, void* stream) {
   if (!proof_args_ok(ctx, pk, stm, batch, d_key_idx, d_st_idx) || !d_a || !d_cipher || !d_r || !nonces || !out) return MPE_E_ARG;
   if (batch == 0) return MPE_OK;
-  return mpe::alice_generate(ctx, pk, stm, batch, d_key_idx, d_st_idx, d_a, d_cipher, d_r, nonces, out, (hipStream_t)stream);
+  return mpe::alice_generate(ctx, pk, stm, batch, d_key_idx, d_st_idx, mpe::rows(d_a, 8), mpe::rows(d_cipher, 128),
+                             mpe::rows(d_r, 64), nonces, out, (hipStream_t)stream);
 }
 int mpe_alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch, const int32_t* d_key_idx,
                      const int32_t* d_st_idx, const uint32_t* d_cipher, const mpe_alice_proof* proof, uint8_t* d_ok,
                      void* stream) {
   if (!proof_args_ok(ctx, pk, stm, batch, d_key_idx, d_st_idx) || !d_cipher || !proof || !d_ok) return MPE_E_ARG;
   if (batch == 0) return MPE_OK;
-  return mpe::alice_verify(ctx, pk, stm, batch, d_key_idx, d_st_idx, d_cipher, proof, d_ok, (hipStream_t)stream);
+  return mpe::alice_verify(ctx, pk, stm, batch, d_key_idx, d_st_idx, mpe::rows(d_cipher, 128), mpe::dense(proof), d_ok,
+                           (hipStream_t)stream);
 }
 int mpe_pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch, const int32_t* d_key_idx,
                   const int32_t* d_st_idx, const uint32_t* d_cipher, const uint32_t* d_Q, const uint32_t* d_G,
@@ -552,14 +571,16 @@ int mpe_pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* st
   if (!proof_args_ok(ctx, pk, stm, batch, d_key_idx, d_st_idx) || !d_cipher || !d_Q || !d_G || !d_x || !d_r || !nonces || !out)
     return MPE_E_ARG;
   if (batch == 0) return MPE_OK;
-  return mpe::pdl_prove(ctx, pk, stm, batch, d_key_idx, d_st_idx, d_cipher, d_Q, d_G, d_x, d_r, nonces, out, (hipStream_t)stream);
+  return mpe::pdl_prove(ctx, pk, stm, batch, d_key_idx, d_st_idx, mpe::rows(d_cipher, 128), mpe::rows(d_Q, 16), mpe::rows(d_G, 16),
+                        mpe::rows(d_x, 8), mpe::rows(d_r, 64), nonces, out, (hipStream_t)stream);
 }
 int mpe_pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch, const int32_t* d_key_idx,
                    const int32_t* d_st_idx, const uint32_t* d_cipher, const uint32_t* d_Q, const uint32_t* d_G,
                    const mpe_pdl_proof* proof, uint8_t* d_ok, void* stream) {
   if (!proof_args_ok(ctx, pk, stm, batch, d_key_idx, d_st_idx) || !d_cipher || !d_Q || !d_G || !proof || !d_ok) return MPE_E_ARG;
   if (batch == 0) return MPE_OK;
-  return mpe::pdl_verify(ctx, pk, stm, batch, d_key_idx, d_st_idx, d_cipher, d_Q, d_G, proof, d_ok, (hipStream_t)stream);
+  return mpe::pdl_verify(ctx, pk, stm, batch, d_key_idx, d_st_idx, mpe::rows(d_cipher, 128), mpe::rows(d_Q, 16), mpe::rows(d_G, 16),
+                         mpe::dense(proof), d_ok, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -359,3 +359,46 @@ def pdl_verify(ctx, pk, stm, d_cipher, d_Q, d_G, proof, d_key_idx=None, d_st_idx
     N_.check(N_.lib.mpe_pdl_verify(ctx.h, pk.h, stm.h, B, _ptr(d_key_idx), _ptr(d_st_idx), _ptr(d_cipher), _ptr(d_Q), _ptr(d_G),
                                    C.byref(pr), _ptr(ok), ctx.stream()), "mpe_pdl_verify")
     return ok
+
+
+# ================================================================================================
+# GG20 signing (all parties of a batch of sessions in lock-step on one GPU)
+# ================================================================================================
+class Gg20Keys:
+    """`LocalKey` material of all n parties (keygen/rounds.rs:311-322) + the signer set, resident in HBM.
+    arrays: dict of numpy uint32 arrays x,p,q,Nt,h1,h2,y,X (layouts: include/mpecdsa_hip.h)."""
+
+    def __init__(self, ctx, t, n, signers, arrays):
+        self.ctx, self.t, self.n, self.S = ctx, t, n, len(signers)
+        self.d = {f: torch.from_numpy(np.ascontiguousarray(arrays[f]).view(np.int32)).to(ctx.device)
+                  for f in ("x", "p", "q", "Nt", "h1", "h2", "y", "X")}
+        sg = (C.c_int32 * len(signers))(*[int(s) for s in signers])
+        h = C.c_void_p()
+        N_.check(N_.lib.mpe_gg20_keys_create(ctx.h, t, n, len(signers), sg, *[_ptr(self.d[f]) for f in
+                                             ("x", "p", "q", "Nt", "h1", "h2", "y", "X")], C.byref(h), ctx.stream()),
+                 "mpe_gg20_keys_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            N_.lib.mpe_gg20_keys_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gg20_sign(ctx, keys, nonces, B, dedup_verify=False, chunk=0, want_R=False):
+    """nonces: dict of device int32 tensors (fields _native.GG20_NONCE_FIELDS).  Returns device tensors
+    r [B,8], s [B,8], recid [B], status [B] (0 = signed and verified) and optionally R [B,16]."""
+    r, s = _new(ctx, B, 8), _new(ctx, B, 8)
+    recid = torch.empty((B,), dtype=torch.int32, device=ctx.device)
+    status = torch.full((B,), -1, dtype=torch.int32, device=ctx.device)
+    R = _new(ctx, B, 16) if want_R else None
+    nn = _struct(N_.Gg20Nonces, nonces)
+    N_.check(N_.lib.mpe_gg20_sign(ctx.h, keys.h, B, C.byref(nn), _ptr(r), _ptr(s), _ptr(recid), _ptr(R), _ptr(status),
+                                  int(bool(dedup_verify)), int(chunk), ctx.stream()), "mpe_gg20_sign")
+    return (r, s, recid, status, R) if want_R else (r, s, recid, status)
