@@ -12,6 +12,9 @@
 //   pp = pi*(S-1) + jj                ordered pair (pi -> peer ordinal jj), ind = jj < i ? jj : jj+1 (rounds.rs:149)
 //   mb = pp*2 + v                     MessageB of pi for that peer, v = 0 (gamma_i) / 1 (w_i)
 #pragma once
+#include <cstdio>
+#include <cstdlib>
+
 #include "mpe_proofs.h"
 
 struct mpe_gg20_keys {
@@ -98,9 +101,13 @@ __device__ inline ec::U256 commit_point(const ec::Aff& P, const uint32_t* blind)
   ec::sha_bigint(s, blind, 8);
   return ec::sha_final(s);
 }
-__device__ inline ec::U256 hash_points(const ec::Aff* pts, int n) {
+// (the points are passed as an array reference and the function is force-inlined: handing a pointer to a
+//  lane-private array to an out-of-line function hung the kernel on gfx950 / ROCm 7.2)
+template <int N>
+__device__ __forceinline__ ec::U256 hash_points(const ec::Aff (&pts)[N]) {
   ec::Sha256 s; ec::sha_init(s);
-  for (int i = 0; i < n; ++i) ec::sha_point_uncompressed(s, pts[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) ec::sha_point_uncompressed(s, pts[i]);
   const ec::U256 d = ec::sha_final(s);
   return ec::sc_reduce(d.w, 8);
 }
@@ -199,7 +206,7 @@ __global__ void r2b_kernel(Dim d, const uint32_t* __restrict__ kq, const uint32_
   const ec::U256 s1 = ec::sc_reduce(s1_in + (size_t)pi * 8, 8), s2 = ec::sc_reduce(s2_in + (size_t)pi * 8, 8);
   const ec::Aff a1 = mul_aff(s1, G), a2 = mul_aff(s2, H);
   const ec::Aff hp[5] = {G, H, T, a1, a2};
-  const ec::U256 e = hash_points(hp, 5);
+  const ec::U256 e = hash_points(hp);
   ec::aff_store(p.T + (size_t)pi * 16, T);
   ec::aff_store(p.a1 + (size_t)pi * 16, a1);
   ec::aff_store(p.a2 + (size_t)pi * 16, a2);
@@ -220,7 +227,7 @@ __global__ void r3_kernel(Dim d, const uint32_t* __restrict__ delta_i, Ped p, ui
     sum = ec::sc_add(sum, ec::u256_load(delta_i + o * 8));
     const ec::Aff T = ec::aff_load(p.T + o * 16), a1 = ec::aff_load(p.a1 + o * 16), a2 = ec::aff_load(p.a2 + o * 16);
     const ec::Aff hp[5] = {G, H, T, a1, a2};
-    const ec::U256 e = hash_points(hp, 5);
+    const ec::U256 e = hash_points(hp);
     const ec::Jac lhs = ec::jac_add(ec::jac_mul(ec::u256_load(p.z1 + o * 8), G), ec::jac_mul(ec::u256_load(p.z2 + o * 8), H));
     const ec::Jac rhs = ec::jac_add(ec::jac_add(ec::jac_from_aff(a1), ec::jac_from_aff(a2)), ec::jac_mul(e, T));
     good = good && ec::aff_eq(ec::jac_to_aff(lhs), ec::jac_to_aff(rhs));
@@ -278,7 +285,7 @@ __global__ void r5_kernel(Dim d, const uint8_t* __restrict__ pdl_ok, const uint3
   const ec::U256 s1 = ec::sc_reduce(s1_in + (size_t)pi * 8, 8), s2 = ec::sc_reduce(s2_in + (size_t)pi * 8, 8);
   const ec::Aff A1 = mul_aff(s1, H), A2 = mul_aff(s2, G), A3 = mul_aff(s2, Rp), TT = add_aff(A1, A2);
   const ec::Aff hp[7] = {TT, A3, Rp, H, G, T, Sp};
-  const ec::U256 e = hash_points(hp, 7);
+  const ec::U256 e = hash_points(hp);
   ec::aff_store(h.S + (size_t)pi * 16, Sp);
   ec::aff_store(h.T + (size_t)pi * 16, TT);
   ec::aff_store(h.A3 + (size_t)pi * 16, A3);
@@ -301,7 +308,7 @@ __global__ void r6_kernel(Dim d, const uint32_t* __restrict__ R, const uint32_t*
     const ec::Aff TT = ec::aff_load(h.T + o * 16), A3 = ec::aff_load(h.A3 + o * 16), D = ec::aff_load(pedT + o * 16),
                   E = ec::aff_load(h.S + o * 16);
     const ec::Aff hp[7] = {TT, A3, Rp, H, G, D, E};
-    const ec::U256 e = hash_points(hp, 7), z1 = ec::u256_load(h.z1 + o * 8), z2 = ec::u256_load(h.z2 + o * 8);
+    const ec::U256 e = hash_points(hp), z1 = ec::u256_load(h.z1 + o * 8), z2 = ec::u256_load(h.z2 + o * 8);
     const ec::Jac l1 = ec::jac_add(ec::jac_mul(z1, H), ec::jac_mul(z2, G));
     const ec::Jac r1 = ec::jac_add(ec::jac_from_aff(TT), ec::jac_mul(e, D));
     const ec::Jac l2 = ec::jac_mul(z2, Rp);
@@ -366,10 +373,19 @@ static T* W(Seq& q, size_t count) {
   if (!p && q.rc == MPE_OK) { q.rc = MPE_E_NOMEM; mpe_set_error_msg("gg20: workspace under-reserved"); }
   return p;
 }
+// MPE_GG20_TRACE=1 in the environment: synchronise after every step and report it on stderr (debug aid)
+static void gg_trace(hipStream_t st, const char* what, int rc) {
+  static const bool on = getenv("MPE_GG20_TRACE") != nullptr;
+  if (!on) return;
+  const hipError_t e = hipStreamSynchronize(st);
+  fprintf(stderr, "[gg20] %-28s rc=%d sync=%s\n", what, rc, hipGetErrorString(e));
+  fflush(stderr);
+}
 #define GG_LAUNCH(kernel, nitems, ...)                                                                   \
   do {                                                                                                    \
     if (q.rc == MPE_OK && (nitems) > 0)                                                                   \
       hipLaunchKernelGGL(kernel, dim3(blocks_for((int)(nitems), 64)), dim3(64), 0, st, __VA_ARGS__);      \
+    gg_trace(st, #kernel, q.rc);                                                                          \
   } while (0)
 
 // one chunk of sessions [b0, b0+B)
@@ -423,10 +439,12 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
            *g_w = OW(nPI * 16), *com = OW(nPI * 8), *c_a = OW(nPI * 128);
   GG_LAUNCH(r0_kernel, nPI, d, K->d_signers, K->x, z_k, z_gamma, z_blind, kq, gq, w, k64, g_gamma, g_w, com);
   if (q.rc == MPE_OK) q.rc = paillier_encrypt(ctx, K->pk, (int)nPI, ix.key_pi, k64, z_ra, c_a, st);          // MessageA.c
+  gg_trace(st, "encrypt k", q.rc);
   mpe_alice_proof ap{OW(nAP * 64), OW(nAP * 8), OW(nAP * 64), OW(nAP * 25), OW(nAP * 89)};
   if (q.rc == MPE_OK)
     q.rc = alice_generate(ctx, K->pk, K->stm, (int)nAP, ix.key_ap, ix.st_ap, rows(kq, 8, ix.pi_ap), rows(c_a, 128, ix.pi_ap),
                           rows(z_ra, 64, ix.pi_ap), &an, &ap, st);
+  gg_trace(st, "alice_generate", q.rc);
 
   // ---- Round 1 ----
   uint8_t* ok_vi = OF(nVI);
@@ -435,6 +453,7 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
                       rows(ap.s2, 89, ix.ap_vi)};
     q.rc = alice_verify(ctx, K->pk, K->stm, (int)nVI, ix.key_vi, ix.st_vi, rows(c_a, 128, ix.pia_vi), pr, ok_vi, st);
   }
+  gg_trace(st, "alice_verify", q.rc);
   uint32_t *bsel = OW(nMB * 8), *btq = OW(nMB * 8), *beta = OW(nMB * 8), *c_bt = OW(nMB * 128), *bca = OW(nMB * 128),
            *c_b = OW(nMB * 128);
   uint32_t *Bpk = OW(nMB * 16), *BR = OW(nMB * 16), *Bz = OW(nMB * 8), *BTpk = OW(nMB * 16), *BTR = OW(nMB * 16), *BTz = OW(nMB * 8);
@@ -442,11 +461,14 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
                  *z_nbt = Z->mb_nonce_bt + oMB * 8;
   GG_LAUNCH(mb_prep_kernel, nMB, d, gq, w, z_bt, bsel, btq, beta);
   if (q.rc == MPE_OK) q.rc = paillier_encrypt(ctx, K->pk, (int)nMB, ix.key_mb, z_bt, z_mr, c_bt, st);          // :133-137
+  gg_trace(st, "encrypt beta_tag", q.rc);
   if (q.rc == MPE_OK)                                                                                          // Paillier::mul :140-144
     q.rc = launch_modexp(ctx, K->pk->ms_nn, (int)nMB, Rows{nullptr, ix.key_mb, 0, 0}, rows(c_a, 128, ix.pia_mb), no_rows(),
                          rows(bsel, 8), 8, bca, st);
+  gg_trace(st, "paillier mul", q.rc);
   if (q.rc == MPE_OK)                                                                                          // Paillier::add :145
     q.rc = launch_modmul(ctx, K->pk->ms_nn, (int)nMB, Rows{nullptr, ix.key_mb, 0, 0}, rows(bca, 128), rows(c_bt, 128), c_b, st);
+  gg_trace(st, "paillier add", q.rc);
   GG_LAUNCH(dlog_prove_kernel, nMB, (int)nMB, bsel, z_nb, Bpk, BR, Bz);                                       // :147
   GG_LAUNCH(dlog_prove_kernel, nMB, (int)nMB, btq, z_nbt, BTpk, BTR, BTz);                                    // :148
 
@@ -459,6 +481,7 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
     GG_LAUNCH(gather_rows_kernel, nMB * 128, (int)nMB, 128, c_b, ix.mbin_rv, cin);
     q.rc = paillier_decrypt(ctx, K->pk, (int)nMB, ix.key_rv, cin, alpha_full, st);
   }
+  gg_trace(st, "decrypt", q.rc);
   MsgB mbv{Bpk, BR, Bz, BTpk, BTR, BTz};
   GG_LAUNCH(r2a_kernel, nMB, d, ix.mbin_rv, alpha_full, kq, mbv, g_w, alpha, ok_rv);
   uint32_t *delta_i = OW(nPI * 8), *sigma_i = OW(nPI * 8), *lq = OW(nPI * 8);
@@ -475,6 +498,7 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
   if (q.rc == MPE_OK)                                                                                          // phase5_proof_pdl
     q.rc = pdl_prove(ctx, K->pk, K->stm, (int)nPP, ix.key_pp, ix.st_pp, rows(c_a, 128, ix.pi_pp), rows(Rbar, 16, ix.pi_pp),
                      rows(R, 16, ix.pi_pp), rows(kq, 8, ix.pi_pp), rows(z_ra, 64, ix.pi_pp), &pn, &pp, st);
+  gg_trace(st, "pdl_prove", q.rc);
 
   // ---- Round 5, 6, 7 ----
   uint8_t* ok_pv = OF(nPV);
@@ -484,6 +508,7 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
     q.rc = pdl_verify(ctx, K->pk, K->stm, (int)nPV, ix.key_pv, ix.st_pv, rows(c_a, 128, ix.pip_pv), rows(Rbar, 16, ix.pip_pv),
                       rows(R, 16, ix.pip_pv), pr, ok_pv, st);
   }
+  gg_trace(st, "pdl_verify", q.rc);
   Heg heg{OW(nPI * 16), OW(nPI * 16), OW(nPI * 16), OW(nPI * 8), OW(nPI * 8)};
   GG_LAUNCH(r5_kernel, nPI, d, ok_pv, R, Rbar, sigma_i, lq, ped.T, Z->heg_s1 + oPI * 8, Z->heg_s2 + oPI * 8, heg, ok_r5);
   GG_LAUNCH(r6_kernel, nPI, d, R, ped.T, heg, K->y, ok_r6);
