@@ -7,6 +7,7 @@
 #pragma once
 #include "mpe_ec.h"
 #include "mpe_internal.h"
+#include "mpe_modinv.h"
 #include "mpe_paillier.h"
 #include "mpe_small.h"
 
@@ -72,71 +73,6 @@ __global__ void dlog_verify_kernel(int B, const uint32_t* __restrict__ pk, const
   const ec::U256 c = dlog_challenge(Rp, P), zz = ec::sc_reduce(z + (size_t)i * 8, 8);
   const ec::Jac l = ec::jac_add(ec::jac_mul(zz, ec::aff_gen()), ec::jac_mul(c, P));
   ok[i] = ec::aff_eq(ec::jac_to_aff(l), Rp) ? 1 : 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// modular inversion (BigInt::mod_inv -> Option): binary extended gcd, one item per lane.
-// Inputs must be reduced (a < m), which every call site guarantees (outputs of modexp/modmul).
-// ---------------------------------------------------------------------------------------------
-template <int K32>
-__global__ void modinv_kernel(int B, const uint32_t* __restrict__ mod_words, Rows mod_sel, Rows A,
-                              uint32_t* __restrict__ out, uint8_t* __restrict__ ok) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B) return;
-  constexpr int W = K32 + 1;
-  uint32_t u[W], v[W], x1[W], x2[W], m[W];
-  const int mi = mod_sel.idx ? mod_sel.idx[i] : (mod_sel.stride ? i : 0);
-  const uint32_t* mp = mod_words + (size_t)mi * K32;
-  const uint32_t* ap = row_of(A, i);
-  const int aw = A.words ? A.words : K32;
-  for (int j = 0; j < W; ++j) {
-    m[j] = j < K32 ? mp[j] : 0;
-    v[j] = m[j];
-    u[j] = j < aw ? ap[j] : 0;
-    x1[j] = j == 0 ? 1u : 0u;
-    x2[j] = 0;
-  }
-  auto is_one = [&](const uint32_t* a) { uint32_t o = a[0] ^ 1u; for (int j = 1; j < W; ++j) o |= a[j]; return o == 0; };
-  auto halve_mod = [&](uint32_t* x) {      // x <- x/2 mod m
-    if (x[0] & 1u) sm::add(x, W, x, W, m, W);
-    for (int j = 0; j < W - 1; ++j) x[j] = (x[j] >> 1) | (x[j + 1] << 31);
-    x[W - 1] >>= 1;
-  };
-  auto shr1 = [&](uint32_t* x) {
-    for (int j = 0; j < W - 1; ++j) x[j] = (x[j] >> 1) | (x[j + 1] << 31);
-    x[W - 1] >>= 1;
-  };
-  bool good = !sm::is_zero(u, W);
-  int guard = 4 * 32 * K32 + 8;
-  while (good && !is_one(u) && !is_one(v) && guard-- > 0) {
-    while (!(u[0] & 1u)) { shr1(u); halve_mod(x1); }
-    while (!(v[0] & 1u)) { shr1(v); halve_mod(x2); }
-    if (sm::cmp(u, W, v, W) >= 0) {
-      sm::sub(u, W, u, W, v, W);
-      if (sm::sub(x1, W, x1, W, x2, W)) sm::add(x1, W, x1, W, m, W);
-      if (sm::is_zero(u, W)) good = false;            // gcd(a, m) = v != 1
-    } else {
-      sm::sub(v, W, v, W, u, W);
-      if (sm::sub(x2, W, x2, W, x1, W)) sm::add(x2, W, x2, W, m, W);
-    }
-  }
-  const uint32_t* res = is_one(u) ? x1 : x2;
-  if (!is_one(u) && !is_one(v)) good = false;
-  for (int j = 0; j < K32; ++j) out[(size_t)i * K32 + j] = good ? res[j] : 0u;
-  ok[i] = good ? 1 : 0;
-}
-
-static int launch_modinv(mpe_ctx* ctx, const mpe_modset* ms, int B, Rows mod_sel, Rows a, uint32_t* out, uint8_t* ok,
-                         hipStream_t st) {
-  (void)ctx;
-  if (B == 0) return MPE_OK;
-  if (ms->bits == 4096)
-    hipLaunchKernelGGL(modinv_kernel<128>, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ms->words, mod_sel, a, out, ok);
-  else
-    hipLaunchKernelGGL(modinv_kernel<64>, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ms->words, mod_sel, a, out, ok);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { mpe_set_error("modinv_kernel", e); return MPE_E_HIP; }
-  return MPE_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -537,6 +473,7 @@ int mpe_modinv(mpe_ctx* ctx, const mpe_modset* ms, int batch, const int32_t* d_m
                uint32_t* d_out, uint8_t* d_ok, void* stream) {
   if (!ctx || !ms || !d_a || !d_out || !d_ok || batch < 0) return MPE_E_ARG;
   if (!d_mod_idx && ms->count != 1 && ms->count < batch) return MPE_E_ARG;
+  MPE_TRY(mpe::ws_reserve(ctx, mpe::modinv_ws_words(ms, batch) * 4, (hipStream_t)stream));
   return mpe::launch_modinv(ctx, ms, batch, mpe::sel_of(d_mod_idx, ms->count), mpe::rows(d_a, ms->bits / 32), d_out, d_ok,
                             (hipStream_t)stream);
 }
