@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--sessions", type=int, default=4096, help="concurrent signing sessions per GPU per step")
+    ap.add_argument("--chunk", type=int, default=0, help="sessions per internal pass of mpe_gg20_sign (0 = library default)")
     ap.add_argument("--dedup", action="store_true", help="evaluate identical checks once (same outputs; not the faithful path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paillier", action="store_true")
@@ -169,7 +170,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        return E.gg20_sign(ctx, gk, nonces, B, dedup_verify=args.dedup)
+        return E.gg20_sign(ctx, gk, nonces, B, dedup_verify=args.dedup, chunk=args.chunk)
 
     for _ in range(args.warmup):
         out = step()

@@ -179,6 +179,7 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   if (!c) return MPE_E_NOMEM;
   c->device = device;
   c->cus = prop.multiProcessorCount;
+  if (getenv("MPE_NO_FIXED_BASE")) c->use_fixed_base = false;     // A/B switch for measurements
   *out = c;
   return MPE_OK;
 }

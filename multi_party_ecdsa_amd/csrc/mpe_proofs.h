@@ -18,9 +18,28 @@ struct mpe_statements {
   uint32_t* h1 = nullptr;
   uint32_t* h2 = nullptr;
   mpe_modset* ms = nullptr;  // 2048-bit, modulus k = N~_k
+  uint32_t* fb_tab = nullptr;  // [2*count][FB_MAX_WINDOWS][16][72] fixed-base tables of h1 (even) / h2 (odd)
 };
 
+#include "mpe_fixedbase.h"
+
 namespace mpe {
+
+static int launch_fb_modexp(mpe_ctx* ctx, const mpe_statements* stm, int B, Rows st_sel, int which, Rows exps, int ew,
+                            uint32_t* out, hipStream_t st) {
+  if (B == 0) return MPE_OK;
+  using C = Cfg2048;
+  const int need = (B + C::GROUPS - 1) / C::GROUPS, cap = ctx->cus * ctx->modexp_waves_per_cu;
+  int grid = need;
+  if (need > cap) { const int trips = (need + cap - 1) / cap; grid = (need + trips - 1) / trips; }
+  ModsetView v;
+  v.n_limbs = stm->ms->n_limbs; v.one_limbs = stm->ms->one_limbs; v.r2_limbs = stm->ms->r2_limbs;
+  v.r2h_limbs = stm->ms->r2h_limbs; v.n0inv = stm->ms->n0inv; v.count = stm->ms->count;
+  hipLaunchKernelGGL(fb_modexp_kernel<C>, dim3(grid), dim3(64), 0, st, B, v, st_sel, which, stm->fb_tab, exps, ew, out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mpe_set_error("fb_modexp_kernel", e); return MPE_E_HIP; }
+  return MPE_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // secp256k1 batch kernels
@@ -182,6 +201,13 @@ struct Seq {
     if (!p && rc == MPE_OK) { rc = MPE_E_NOMEM; mpe_set_error_msg("workspace under-reserved"); }
     return p;
   }
+  // h1^x / h2^x mod N~ of a statement: fixed-base tables when the statement set has them (mpe_fixedbase.h)
+  uint32_t* fb_modexp(const mpe_statements* stm, Rows sel, int which, Rows base, Rows exps, int ew) {
+    if (!stm->fb_tab || !ctx->use_fixed_base) return modexp(stm->ms, sel, base, exps, ew);
+    uint32_t* o = words(64);
+    if (rc == MPE_OK) rc = launch_fb_modexp(ctx, stm, B, sel, which, exps, ew, o, st);
+    return o;
+  }
   uint32_t* modexp(const mpe_modset* ms, Rows sel, Rows base, Rows exps, int ew) {
     uint32_t* o = words(ms->bits / 32);
     if (rc == MPE_OK) rc = launch_modexp(ctx, ms, B, sel, base, no_rows(), exps, ew, o, st);
@@ -247,8 +273,8 @@ static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statem
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
   const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
   // z = h1^a h2^rho mod N~                                                      :52
-  uint32_t* z1 = q.modexp(stm->ms, ssel, h1, a, 8);
-  uint32_t* z2 = q.modexp(stm->ms, ssel, h2, rows(nn->rho, 72), 72);
+  uint32_t* z1 = q.fb_modexp(stm, ssel, 0, h1,a, 8);
+  uint32_t* z2 = q.fb_modexp(stm, ssel, 1, h2,rows(nn->rho, 72), 72);
   q.modmul_to(stm->ms, ssel, rows(z1, 64), rows(z2, 64), out->z);
   // u = (alpha N + 1) beta^N mod N^2                                            :53-55
   uint32_t* gu = q.words(128);
@@ -256,8 +282,8 @@ static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statem
   uint32_t* bn = q.modexp(pk->ms_nn, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64);
   uint32_t* u = q.modmul(pk->ms_nn, ksel, rows(gu, 128), rows(bn, 128));
   // w = h1^alpha h2^gamma mod N~                                                :56-57
-  uint32_t* w1 = q.modexp(stm->ms, ssel, h1, rows(nn->alpha, 24), 24);
-  uint32_t* w2 = q.modexp(stm->ms, ssel, h2, rows(nn->gamma, 88), 88);
+  uint32_t* w1 = q.fb_modexp(stm, ssel, 0, h1,rows(nn->alpha, 24), 24);
+  uint32_t* w2 = q.fb_modexp(stm, ssel, 1, h2,rows(nn->gamma, 88), 88);
   uint32_t* w = q.modmul(stm->ms, ssel, rows(w1, 64), rows(w2, 64));
   // e = H(N, N+1, c, z, u, w)                                                   :175-182
   HashDesc d;
@@ -288,8 +314,8 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
   uint8_t *inv_ok1 = q.flags(), *inv_ok2 = q.flags();
   uint32_t* ze = q.modexp(stm->ms, ssel, pr.z, pr.e, 8);
   uint32_t* zei = q.modinv(stm->ms, ssel, rows(ze, 64), inv_ok1);
-  uint32_t* a1 = q.modexp(stm->ms, ssel, h1, pr.s1, 25);
-  uint32_t* a2 = q.modexp(stm->ms, ssel, h2, pr.s2, 89);
+  uint32_t* a1 = q.fb_modexp(stm, ssel, 0, h1,pr.s1, 25);
+  uint32_t* a2 = q.fb_modexp(stm, ssel, 1, h2,pr.s2, 89);
   uint32_t* a12 = q.modmul(stm->ms, ssel, rows(a1, 64), rows(a2, 64));
   uint32_t* w = q.modmul(stm->ms, ssel, rows(a12, 64), rows(zei, 64));
   // u' = (s1 N + 1) s^N (c^e)^-1 mod N^2                                                           :134-141
@@ -324,8 +350,8 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
   const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
   // z = h1^x h2^rho mod N~                                                      :79-85
-  uint32_t* z1 = q.modexp(stm->ms, ssel, h1, x, 8);
-  uint32_t* z2 = q.modexp(stm->ms, ssel, h2, rows(nn->rho, 72), 72);
+  uint32_t* z1 = q.fb_modexp(stm, ssel, 0, h1,x, 8);
+  uint32_t* z2 = q.fb_modexp(stm, ssel, 1, h2,rows(nn->rho, 72), 72);
   q.modmul_to(stm->ms, ssel, rows(z1, 64), rows(z2, 64), out->z);
   // u1 = (alpha mod q) G                                                        :86
   MPE_LAUNCH_1D(ec_mul_rows_kernel, B, st, B, rows(nn->alpha, 24), 24, Gp, out->u1);
@@ -335,8 +361,8 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
   uint32_t* bn = q.modexp(pk->ms_nn, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64);
   q.modmul_to(pk->ms_nn, ksel, rows(ga, 128), rows(bn, 128), out->u2);
   // u3 = h1^alpha h2^gamma mod N~                                               :94-100
-  uint32_t* w1 = q.modexp(stm->ms, ssel, h1, rows(nn->alpha, 24), 24);
-  uint32_t* w2 = q.modexp(stm->ms, ssel, h2, rows(nn->gamma, 88), 88);
+  uint32_t* w1 = q.fb_modexp(stm, ssel, 0, h1,rows(nn->alpha, 24), 24);
+  uint32_t* w2 = q.fb_modexp(stm, ssel, 1, h2,rows(nn->gamma, 88), 88);
   q.modmul_to(stm->ms, ssel, rows(w1, 64), rows(w2, 64), out->u3);
   // e = H(G, Q, c, z, u1, u2, u3)                                               :102-110
   uint32_t* e = q.words(8);
@@ -387,8 +413,8 @@ static int pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   uint32_t* cie = q.modexp(pk->ms_nn, ksel, rows(cinv, 128), rows(e, 8), 8);
   uint32_t* u2 = q.modmul(pk->ms_nn, ksel, rows(t2, 128), rows(cie, 128));
   // u3' = h1^s1 h2^s3 z^-e mod N~                                                                  :159-172
-  uint32_t* a1 = q.modexp(stm->ms, ssel, h1, pr.s1, 25);
-  uint32_t* a2 = q.modexp(stm->ms, ssel, h2, pr.s3, 89);
+  uint32_t* a1 = q.fb_modexp(stm, ssel, 0, h1,pr.s1, 25);
+  uint32_t* a2 = q.fb_modexp(stm, ssel, 1, h2,pr.s3, 89);
   uint32_t* a12 = q.modmul(stm->ms, ssel, rows(a1, 64), rows(a2, 64));
   uint32_t* zred = q.modmul(stm->ms, ssel, pr.z, rows(stm->ms->one_words, 0, nullptr, 1));
   uint32_t* zinv = q.modinv(stm->ms, ssel, rows(zred, 64), inv_ok2);
@@ -425,12 +451,28 @@ int mpe_statements_create(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const u
   (void)hipMemcpyAsync(s->h2, d_h2, w * 4, hipMemcpyDeviceToDevice, st);
   int rc = mpe::modset_create_dev(ctx, 2048, count, s->Nt, &s->ms, st);
   if (rc != MPE_OK) { (void)hipFree(s->blob); delete s; return rc; }
+  if (ctx->use_fixed_base) {
+    // fixed-base window tables of h1, h2 (3.3 MB per base), built on the GPU once per statement set
+    using C = mpe::Cfg2048;
+    const size_t bytes = (size_t)2 * count * mpe::FB_MAX_WINDOWS * 16 * C::K * sizeof(uint32_t);
+    e = hipMalloc((void**)&s->fb_tab, bytes);
+    if (e != hipSuccess) { mpe_set_error("hipMalloc(fixed-base tables)", e); mpe_statements_destroy(s); return MPE_E_NOMEM; }
+    mpe::ModsetView v;
+    v.n_limbs = s->ms->n_limbs; v.one_limbs = s->ms->one_limbs; v.r2_limbs = s->ms->r2_limbs; v.r2h_limbs = s->ms->r2h_limbs;
+    v.n0inv = s->ms->n0inv; v.count = s->ms->count;
+    const int npairs = 2 * count;
+    hipLaunchKernelGGL(mpe::fb_build_kernel<C>, dim3((npairs + C::GROUPS - 1) / C::GROUPS), dim3(64), 0, st, npairs, v, s->h1,
+                       s->h2, s->fb_tab);
+    e = hipGetLastError();
+    if (e != hipSuccess) { mpe_set_error("fb_build_kernel", e); mpe_statements_destroy(s); return MPE_E_HIP; }
+  }
   *out = s;
   return MPE_OK;
 }
 int mpe_statements_destroy(mpe_statements* s) {
   if (!s) return MPE_E_ARG;
   if (s->ms) mpe_modset_destroy(s->ms);
+  if (s->fb_tab) (void)hipFree(s->fb_tab);
   if (s->blob) (void)hipFree(s->blob);
   delete s;
   return MPE_OK;
