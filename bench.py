@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--sessions", type=int, default=4096, help="concurrent signing sessions per GPU per step")
+    ap.add_argument("--sessions", type=int, default=16384, help="concurrent signing sessions per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="sessions per internal pass of mpe_gg20_sign (0 = library default)")
     ap.add_argument("--dedup", action="store_true", help="evaluate identical checks once (same outputs; not the faithful path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -189,10 +189,8 @@ def main():
     elapsed = time.perf_counter() - t0
     recs = ctx.prof_collect(16384)
     ctx.prof_enable(False)
-    if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from multi_party_ecdsa_amd import dist as mpe_dist
+    elapsed = mpe_dist.max_over_ranks(elapsed, dev)          # the job ends when its slowest rank does
 
     if rank == 0:
         r, s, recid, status = [o.cpu().numpy() for o in out]

@@ -169,6 +169,23 @@ int mpe_pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* s
                    const uint32_t* d_Q, const uint32_t* d_G, const mpe_pdl_proof* proof, uint8_t* d_ok,
                    void* stream);
 
+/* Bob's MtA(wc) range proof: `BobProof::generate` / `BobProof::verify` / `BobProofExt::verify`
+ * (src/utilities/mta/range_proofs.rs:218-534).  Widths (words): t,z,s 64 | e 8 | s1 25 | s2,t2 89 | t1 81 (< 2^2561).
+ * Nonces: alpha 24 (< q^3) | beta 64 | gamma 80 (< q^2 N) | rho, sigma 72 (< q N~) | rho_prim, tau 88 (< q^3 N~).
+ * generate: a_enc, mta_enc [batch][128]; b [batch][8]; beta_prim, r [batch][64]; check != 0 also writes
+ * u = alpha*G to d_u [batch][16] and hashes X = b*G, u (the `check` flag of :414-424).
+ * verify: d_X, d_u both NULL -> BobProof::verify(.., None); both set -> BobProofExt::verify. */
+typedef struct { uint32_t *t, *z, *e, *s, *s1, *s2, *t1, *t2; } mpe_bob_proof;
+typedef struct { const uint32_t *alpha, *beta, *gamma, *rho, *rho_prim, *sigma, *tau; } mpe_bob_nonces;
+int mpe_bob_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch,
+                     const int32_t* d_key_idx, const int32_t* d_st_idx, const uint32_t* d_a_enc,
+                     const uint32_t* d_mta_enc, const uint32_t* d_b, const uint32_t* d_beta_prim, const uint32_t* d_r,
+                     const mpe_bob_nonces* nonces, int check, const mpe_bob_proof* out, uint32_t* d_u, void* stream);
+int mpe_bob_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch,
+                   const int32_t* d_key_idx, const int32_t* d_st_idx, const uint32_t* d_a_enc,
+                   const uint32_t* d_mta_enc, const mpe_bob_proof* proof, const uint32_t* d_X, const uint32_t* d_u,
+                   uint8_t* d_ok, void* stream);
+
 /* ---- GG20 signing, batched (Round0..Round7 of every party of every session in lock-step) ------------ */
 /* Key material as the reference's keygen leaves it in `LocalKey` (state_machine/keygen/rounds.rs:311-322),
  * for all n parties, shared by every session of a batch: d_x [n][8] shares x_i, d_p/d_q [n][32] Paillier

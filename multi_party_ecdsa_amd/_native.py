@@ -33,6 +33,8 @@ AliceProof = _ptr_struct("AliceProof", ["z", "e", "s", "s1", "s2"])
 AliceNonces = _ptr_struct("AliceNonces", ["alpha", "beta", "gamma", "rho"])
 PdlProof = _ptr_struct("PdlProof", ["z", "u1", "u2", "u3", "s1", "s2", "s3"])
 PdlNonces = _ptr_struct("PdlNonces", ["alpha", "beta", "rho", "gamma"])
+BobProof = _ptr_struct("BobProof", ["t", "z", "e", "s", "s1", "s2", "t1", "t2"])
+BobNonces = _ptr_struct("BobNonces", ["alpha", "beta", "gamma", "rho", "rho_prim", "sigma", "tau"])
 
 
 GG20_NONCE_FIELDS = ["k", "gamma", "blind", "r_a", "al_alpha", "al_beta", "al_gamma", "al_rho", "mb_beta_tag", "mb_r",
@@ -75,6 +77,9 @@ def _load():
         "mpe_pdl_prove": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, u32p, u32p, u32p, C.POINTER(PdlNonces),
                                C.POINTER(PdlProof), vp]),
         "mpe_pdl_verify": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, u32p, C.POINTER(PdlProof), vp, vp]),
+        "mpe_bob_generate": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, u32p, u32p, u32p, C.POINTER(BobNonces), ip,
+                                  C.POINTER(BobProof), u32p, vp]),
+        "mpe_bob_verify": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, C.POINTER(BobProof), u32p, u32p, vp, vp]),
         "mpe_gg20_keys_create": (ip, [vp, ip, ip, ip, C.POINTER(C.c_int32)] + [u32p] * 8 + [C.POINTER(vp), vp]),
         "mpe_gg20_keys_destroy": (ip, [vp]),
         "mpe_gg20_sign": (ip, [vp, vp, ip, C.POINTER(Gg20Nonces), u32p, u32p, vp, u32p, vp, ip, ip, vp]),
@@ -108,7 +113,7 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_prof_enable", "mpe_prof_collect", "mpe_modinv", "mpe_ec_mul_base", "mpe_ec_mul", "mpe_ec_add",
             "mpe_dlog_prove", "mpe_dlog_verify", "mpe_statements_create", "mpe_statements_destroy",
             "mpe_alice_generate", "mpe_alice_verify", "mpe_pdl_prove", "mpe_pdl_verify", "mpe_gg20_keys_create",
-            "mpe_gg20_keys_destroy", "mpe_gg20_sign"]
+            "mpe_gg20_keys_destroy", "mpe_gg20_sign", "mpe_bob_generate", "mpe_bob_verify"]
 
 
 def check(rc, what):

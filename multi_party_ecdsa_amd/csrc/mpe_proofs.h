@@ -116,7 +116,7 @@ __global__ void muladd_kernel(int B, Rows a, int na, Rows b, int nb, Rows c, int
 // Fiat-Shamir transcripts: SHA-256 over a list of fields, each hashed the way the reference hashes it
 enum { HF_BIGINT = 0, HF_BIGINT_PLUS1 = 1, HF_POINT_COMPRESSED = 2 };
 struct HashField { Rows r; int words; int kind; };
-struct HashDesc { HashField f[8]; int n; };
+struct HashDesc { HashField f[14]; int n; };
 __global__ void hash_kernel(int B, HashDesc d, uint32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;

@@ -402,3 +402,30 @@ def gg20_sign(ctx, keys, nonces, B, dedup_verify=False, chunk=0, want_R=False):
     N_.check(N_.lib.mpe_gg20_sign(ctx.h, keys.h, B, C.byref(nn), _ptr(r), _ptr(s), _ptr(recid), _ptr(R), _ptr(status),
                                   int(bool(dedup_verify)), int(chunk), ctx.stream()), "mpe_gg20_sign")
     return (r, s, recid, status, R) if want_R else (r, s, recid, status)
+
+
+BOB_PROOF_WORDS = dict(t=64, z=64, e=8, s=64, s1=25, s2=89, t1=81, t2=89)
+BOB_NONCE_WORDS = dict(alpha=24, beta=64, gamma=80, rho=72, rho_prim=88, sigma=72, tau=88)
+
+
+def bob_generate(ctx, pk, stm, d_a_enc, d_mta_enc, d_b, d_beta_prim, d_r, nonces, check, d_key_idx=None, d_st_idx=None):
+    """`BobProof::generate(a_encrypted, mta_encrypted, b, beta_prim, alice_ek, dlog_statement, r, check)` batched.
+    Returns (proof dict, u or None)."""
+    B = d_b.shape[0]
+    out = {f: _new(ctx, B, w) for f, w in BOB_PROOF_WORDS.items()}
+    u = _new(ctx, B, 16) if check else None
+    nn, pr = _struct(N_.BobNonces, nonces), _struct(N_.BobProof, out)
+    N_.check(N_.lib.mpe_bob_generate(ctx.h, pk.h, stm.h, B, _ptr(d_key_idx), _ptr(d_st_idx), _ptr(d_a_enc), _ptr(d_mta_enc),
+                                     _ptr(d_b), _ptr(d_beta_prim), _ptr(d_r), C.byref(nn), int(bool(check)), C.byref(pr),
+                                     _ptr(u), ctx.stream()), "mpe_bob_generate")
+    return out, u
+
+
+def bob_verify(ctx, pk, stm, d_a_enc, d_mta_enc, proof, d_X=None, d_u=None, d_key_idx=None, d_st_idx=None):
+    """`BobProof::verify` (d_X, d_u None) / `BobProofExt::verify` batched -> ok flags"""
+    B = d_a_enc.shape[0]
+    ok = _flags(ctx, B)
+    pr = _struct(N_.BobProof, proof)
+    N_.check(N_.lib.mpe_bob_verify(ctx.h, pk.h, stm.h, B, _ptr(d_key_idx), _ptr(d_st_idx), _ptr(d_a_enc), _ptr(d_mta_enc),
+                                   C.byref(pr), _ptr(d_X), _ptr(d_u), _ptr(ok), ctx.stream()), "mpe_bob_verify")
+    return ok

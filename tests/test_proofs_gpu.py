@@ -233,3 +233,46 @@ def test_config3_scale_proofs(gpu_ctx, keys, env):
                          npw(nonces["beta"][:n]), npw(nonces["rho"][:n]), npw(nonces["gamma"][:n]))
     for f in want:
         assert np.array_equal(npw(pr[f][:n]), want[f]), f
+
+
+@pytest.mark.parametrize("check", [False, True])
+def test_bob_proof_vs_oracle(gpu_ctx, keys, env, check):
+    """range_proofs.rs:636-709: generate(check=false) -> verify(None); generate(check=true) -> BobProofExt::verify"""
+    e = E()
+    pk, stm, tabs = env
+    r = F.Rng(f"gpu-bob-{check}")
+    B = 11
+    kidx, sidx = [i % 4 for i in range(B)], [(i // 2) % 3 for i in range(B)]
+    a_enc, mta, bs, bps, rs, nns = [], [], [], [], [], []
+    for k, s in zip(kidx, sidx):
+        ek, st = keys[k], keys[4 + s]
+        a, b, bp, rr = r.below(pyref.Q), r.below(pyref.Q), r.below(ek.N), r.below(ek.N)
+        ae = pyref.paillier_encrypt(ek.N, a, r.below(ek.N))
+        a_enc.append(ae); bs.append(b); bps.append(bp); rs.append(rr)
+        mta.append(pow(ae, b, ek.NN) * pyref.paillier_encrypt(ek.N, bp, rr) % ek.NN)
+        nns.append(F.bob_nonces(r, ek, st))
+    nw = {f: F.words([n[f] for n in nns], w) for f, w in e.BOB_NONCE_WORDS.items()}
+    di = lambda v: torch.tensor(v, dtype=torch.int32, device=gpu_ctx.device)
+    dA, dM = e.dev(gpu_ctx, a_enc, 128), e.dev(gpu_ctx, mta, 128)
+    pr, u = e.bob_generate(gpu_ctx, pk, stm, dA, dM, e.dev(gpu_ctx, bs, 8), e.dev(gpu_ctx, bps, 64), e.dev(gpu_ctx, rs, 64),
+                           {f: to_dev(gpu_ctx, v) for f, v in nw.items()}, check, di(kidx), di(sidx))
+    want, wu = orc.bob_generate(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], kidx, sidx, F.words(a_enc, 128), F.words(mta, 128),
+                                F.words(bs, 8), F.words(bps, 64), F.words(rs, 64), nw["alpha"], nw["beta"], nw["gamma"], nw["rho"],
+                                nw["rho_prim"], nw["sigma"], nw["tau"], check)
+    for f in want:
+        assert np.array_equal(npw(pr[f]), want[f]), f
+    X = None
+    if check:
+        assert np.array_equal(npw(u), wu)
+        X = to_dev(gpu_ctx, orc.ec_mul_base(F.words(bs, 8)))
+    ok = e.bob_verify(gpu_ctx, pk, stm, dA, dM, pr, X, u, di(kidx), di(sidx))
+    assert list(ok.cpu().numpy()) == [1] * B
+    # tamper one field per item; GPU verdicts must equal the oracle's
+    bad = {k: v.clone() for k, v in pr.items()}
+    for j, f in enumerate(["t", "z", "e", "s", "s1", "s2", "t1", "t2"]):
+        bad[f][j, 0] ^= 2
+    ok = e.bob_verify(gpu_ctx, pk, stm, dA, dM, bad, X, u, di(kidx), di(sidx))
+    w_ok = orc.bob_verify(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], kidx, sidx, F.words(a_enc, 128), F.words(mta, 128),
+                          {k: npw(v) for k, v in bad.items()}, npw(X) if check else None, npw(u) if check else None)
+    assert list(ok.cpu().numpy()) == list(w_ok)
+    assert list(w_ok[:8]) == [0] * 8 and list(w_ok[8:]) == [1] * (B - 8)
