@@ -30,6 +30,12 @@ def montmul(a, b, n, n0inv, W, L, TPI, stats):
                 c[t][i] += m * n[t * L + i]
                 stats['maxcol'] = max(stats['maxcol'], c[t][i])
         assert c[0][0] & MASK == 0
+        # long lanes (L > 18 at W = 29): also split the column half-way down the lane
+        if 2 * L * (1 << (2 * W)) * 1.02 >= (1 << 64):
+            h = L // 2
+            for t in range(TPI):
+                c[t][h + 1] += c[t][h] >> W
+                c[t][h] &= MASK
         # fold + shift: every lane keeps the high part of its lowest column, the low W bits
         # move to the lower neighbour lane as its new top column
         for t in range(TPI):
@@ -87,3 +93,5 @@ if __name__ == '__main__':
     run(2048, 27, 19, 4, iters=6)
     run(4096, 29, 18, 8, iters=4)
     run(2048, 29, 18, 4, iters=6)
+    run(4096, 29, 36, 4, iters=4)
+    run(2048, 29, 36, 2, iters=6)
