@@ -20,7 +20,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <utility>
 
 namespace mpe {
 
@@ -37,9 +36,6 @@ struct Cfg {
   static constexpr int K = L_ * TPI_;       // internal limbs per integer
   static constexpr int GROUPS = 64 / TPI_;  // integers per wave
   static constexpr uint32_t MASK = (1u << W_) - 1u;
-  // a column absorbs 2 products of < 2^(2W+0.01) per step; it must be split before 2^64: every L steps is
-  // enough up to L = 18 at W = 29, longer lanes split it a second time half-way (montmul)
-  static constexpr bool MIDFOLD = (2.0 * L_ * (double)(1ull << (2 * W_ - 40)) * 1.02) >= (double)(1ull << 24);
   static_assert(W_ * L_ * TPI_ >= BITS_ + 2, "R must exceed 4N");
   static_assert(K >= K32 + 2, "staging region reuse");
   // LDS words per group: K limbs + padding, chosen so the groups of one 32-lane half hit
@@ -69,13 +65,8 @@ struct Cfg {
 #ifndef MPE_L
 #define MPE_L 18
 #endif
-// lanes per integer: K = 144 (72) limbs / L.  L = 18 -> 8 (4) lanes; L = 36 -> 4 (2) lanes: twice the MACs per
-// step for the same per-step overhead (one DPP broadcast instead of two), at ~2x the registers; columns then
-// need one extra split half-way down the lane (MIDFOLD) to keep the 64-bit accumulators from overflowing.
-#define MPE_TPI4096 (144 / MPE_L)
-#define MPE_TPI2048 (72 / MPE_L)
-using Cfg4096 = Cfg<4096, MPE_W, MPE_L, MPE_TPI4096>;
-using Cfg2048 = Cfg<2048, MPE_W, MPE_L, MPE_TPI2048>;
+using Cfg4096 = Cfg<4096, MPE_W, MPE_L, 8>;
+using Cfg2048 = Cfg<2048, MPE_W, MPE_L, 4>;
 
 // ---------------------------------------------------------------------------------------------
 // cross-lane primitives (DPP; VALU only, no LDS traffic)
@@ -145,36 +136,6 @@ __device__ __forceinline__ Lane make_lane() {
 //   bl  : the group's K multiplier limbs in LDS (limbs < 2^W + 2^12)
 //   n   : this lane's L limbs of the modulus (exactly normalised), n0inv = -n^-1 mod 2^W
 // ---------------------------------------------------------------------------------------------
-// one outer CIOS step with a compile-time column rotation R
-template <class C, int R>
-__device__ __forceinline__ void montmul_step(uint64_t (&c)[C::L], const uint32_t (&a)[C::L], const uint32_t* __restrict__ bp,
-                                             const uint32_t (&n)[C::L], uint32_t n0inv) {
-  constexpr int L = C::L, W = C::W;
-  const uint32_t bj = bp[R];
-  c[R] += (uint64_t)a[0] * bj;
-  const uint32_t m = bcast0<C::TPI>((uint32_t)c[R] * n0inv) & C::MASK;
-#pragma unroll
-  for (int i = 1; i < L; ++i) c[(R + i) % L] += (uint64_t)a[i] * bj;
-#pragma unroll
-  for (int i = 0; i < L; ++i) c[(R + i) % L] += (uint64_t)m * n[i];
-  // One-limb shift.  Every lane splits its lowest column: the part above 2^W stays with the lane (it has
-  // the weight of the next column), the low W bits move to the lower neighbour as its new top column.
-  // For lane 0 of the group the low part is 0 by construction of m, so the previous group's top lane
-  // (and lane 15 of a row, via bound_ctrl) pulls in a zero.
-  if constexpr (C::MIDFOLD) {   // long lanes: also split the column that is half-way down
-    constexpr int h = L / 2;
-    c[(R + h + 1) % L] += c[(R + h) % L] >> W;
-    c[(R + h) % L] &= (uint64_t)C::MASK;
-  }
-  c[(R + 1) % L] += c[R] >> W;
-  c[R] = (uint64_t)pull_next((uint32_t)c[R] & C::MASK);
-}
-template <class C, int... Rs>
-__device__ __forceinline__ void montmul_steps(uint64_t (&c)[C::L], const uint32_t (&a)[C::L], const uint32_t* __restrict__ bp,
-                                              const uint32_t (&n)[C::L], uint32_t n0inv, std::integer_sequence<int, Rs...>) {
-  (montmul_step<C, Rs>(c, a, bp, n, n0inv), ...);
-}
-
 template <class C>
 __device__ __forceinline__ void montmul(uint32_t (&res)[C::L], const uint32_t (&a)[C::L],
                                         const uint32_t* __restrict__ bl, const uint32_t (&n)[C::L],
@@ -187,9 +148,24 @@ __device__ __forceinline__ void montmul(uint32_t (&res)[C::L], const uint32_t (&
 #pragma unroll 1
   for (int jj = 0; jj < C::TPI; ++jj) {
     const uint32_t* bp = bl + jj * L;
-    // L outer steps, unrolled by construction (template parameter R): step R keeps logical column i in
-    // physical c[(R+i)%L], so the one-limb shift per step is a renaming and only the incoming top column moves.
-    montmul_steps<C>(c, a, bp, n, n0inv, std::make_integer_sequence<int, L>{});
+    // L outer steps, fully unrolled: step r keeps logical column i in physical c[(r+i)%L],
+    // so the one-limb shift per step is a renaming and only the incoming top column moves.
+#pragma unroll
+    for (int r = 0; r < L; ++r) {
+      const uint32_t bj = bp[r];
+      c[r] += (uint64_t)a[0] * bj;
+      const uint32_t m = bcast0<C::TPI>((uint32_t)c[r] * n0inv) & C::MASK;
+#pragma unroll
+      for (int i = 1; i < L; ++i) c[(r + i) % L] += (uint64_t)a[i] * bj;
+#pragma unroll
+      for (int i = 0; i < L; ++i) c[(r + i) % L] += (uint64_t)m * n[i];
+      // One-limb shift.  Every lane splits its lowest column: the part above 2^W stays with the
+      // lane (it has the weight of the next column), the low W bits move to the lower neighbour
+      // as its new top column.  For lane 0 of the group the low part is 0 by construction of m,
+      // so the previous group's top lane (and lane 15 of a row, via bound_ctrl) pulls in a zero.
+      c[(r + 1) % L] += c[r] >> W;
+      c[r] = (uint64_t)pull_next((uint32_t)c[r] & C::MASK);
+    }
   }
   // local ripple, then hand the lane's carry-out (< 2^38) to the next lane without rippling on
   uint64_t carry = 0;
