@@ -205,6 +205,16 @@ def main():
         heavy_s = sum(x["ms"] for x in recs) * 1e-3
         achieved = dom_macs / dom_s
         value = B * world * args.steps / elapsed
+        # HBM traffic of the dominant kernel: measured in separate rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied) and committed under profiles/ — not re-measured here
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if B == 16384 and not args.dedup:
+                traffic = pmc["hbm_bytes_per_launch"]
+        except OSError:
+            pass
         res = {
             "metric": "GG20 signatures/sec (t=1, n=3; all parties of each session on the GPU) + Paillier-2048 modexp/s per GPU",
             "value": value, "unit": "signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -217,7 +227,8 @@ def main():
             "roofline": {"bound": "valu-int (v_mad_u64_u32 issue rate; HBM traffic is negligible)",
                          "achieved": achieved / 1e12, "peak": PEAK_MAC_PER_S / 1e12,
                          "unit": "TMAC/s (algorithmic 32x32+64 MACs, SURVEY.md 8d)", "frac": achieved / PEAK_MAC_PER_S,
-                         "traffic": None, "kernel": "mpe::modexp_kernel<Cfg<4096,29,18,8>> (all launches of the timed region)",
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_traffic.json)",
+                         "kernel": "mpe::modexp_kernel<Cfg<4096,29,18,8>> (all launches of the timed region)",
                          "launches": len(dom), "avg_kernel_ms": dom_s / max(1, len(dom)) * 1e3,
                          "alg_mac_per_launch": dom_macs / max(1, len(dom)), "kernel_time_share_of_step": dom_s / elapsed},
             "breakdown": {"modexp4096_s_per_step": dom_s / args.steps, "modexp2048_s_per_step": sec_s / args.steps,
