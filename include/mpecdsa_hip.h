@@ -169,6 +169,29 @@ int mpe_pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* s
                    const uint32_t* d_Q, const uint32_t* d_G, const mpe_pdl_proof* proof, uint8_t* d_ok,
                    void* stream);
 
+/* ---- MtA share conversion (src/utilities/mta/mod.rs) ---------------------------------------------------- */
+/* `dlog_statements` = all statements of `stm` (rounds.rs:87,154 pass the whole h1_h2_n_tilde_vec); per-exchange
+ * arrays of range proofs / nonces are item-major [batch][count_statements]. */
+typedef struct { uint32_t *pk, *R, *z; } mpe_dlog_proof;     /* DLogProof{pk, pk_t_rand_commitment, challenge_response} */
+/* `MessageA::a_with_predefined_randomness(a, alice_ek, randomness, dlog_statements)`  (:62-87)
+ * a [batch][8], r [batch][64] -> c [batch][128] + one AliceProof per statement. */
+int mpe_mta_message_a(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch,
+                      const int32_t* d_key_idx, const uint32_t* d_a, const uint32_t* d_r,
+                      const mpe_alice_nonces* nonces, uint32_t* d_c, const mpe_alice_proof* proofs, void* stream);
+/* `MessageB::b_with_predefined_randomness(b, alice_ek, m_a, randomness, beta_tag, dlog_statements)`  (:111-158)
+ * key_idx selects ALICE's key.  ok[i] = 0 is the reference's Err(InvalidKey) (a range proof failed); the
+ * outputs of such an item are still written.  beta = -beta_tag mod q [batch][8]. */
+int mpe_mta_message_b(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int batch,
+                      const int32_t* d_key_idx, const uint32_t* d_b, const uint32_t* d_ca,
+                      const mpe_alice_proof* range_proofs, const uint32_t* d_r, const uint32_t* d_beta_tag,
+                      const uint32_t* d_nonce_b, const uint32_t* d_nonce_bt, uint32_t* d_cb, uint32_t* d_beta,
+                      const mpe_dlog_proof* b_proof, const mpe_dlog_proof* beta_tag_proof, uint8_t* d_ok, void* stream);
+/* `MessageB::verify_proofs_get_alpha(dk, a)`  (:160-179): alpha [batch][8] = Dec(c_b) mod q, alice_share [batch][64]
+ * the full plaintext; ok[i] = 0 is Err(InvalidKey). */
+int mpe_mta_verify_get_alpha(mpe_ctx* ctx, const mpe_paillier* sk, int batch, const int32_t* d_key_idx,
+                             const uint32_t* d_cb, const mpe_dlog_proof* b_proof, const mpe_dlog_proof* beta_tag_proof,
+                             const uint32_t* d_a, uint32_t* d_alpha, uint32_t* d_alice_share, uint8_t* d_ok, void* stream);
+
 /* Bob's MtA(wc) range proof: `BobProof::generate` / `BobProof::verify` / `BobProofExt::verify`
  * (src/utilities/mta/range_proofs.rs:218-534).  Widths (words): t,z,s 64 | e 8 | s1 25 | s2,t2 89 | t1 81 (< 2^2561).
  * Nonces: alpha 24 (< q^3) | beta 64 | gamma 80 (< q^2 N) | rho, sigma 72 (< q N~) | rho_prim, tau 88 (< q^3 N~).

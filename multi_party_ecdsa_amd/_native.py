@@ -33,6 +33,7 @@ AliceProof = _ptr_struct("AliceProof", ["z", "e", "s", "s1", "s2"])
 AliceNonces = _ptr_struct("AliceNonces", ["alpha", "beta", "gamma", "rho"])
 PdlProof = _ptr_struct("PdlProof", ["z", "u1", "u2", "u3", "s1", "s2", "s3"])
 PdlNonces = _ptr_struct("PdlNonces", ["alpha", "beta", "rho", "gamma"])
+DlogProof = _ptr_struct("DlogProof", ["pk", "R", "z"])
 BobProof = _ptr_struct("BobProof", ["t", "z", "e", "s", "s1", "s2", "t1", "t2"])
 BobNonces = _ptr_struct("BobNonces", ["alpha", "beta", "gamma", "rho", "rho_prim", "sigma", "tau"])
 
@@ -77,6 +78,11 @@ def _load():
         "mpe_pdl_prove": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, u32p, u32p, u32p, C.POINTER(PdlNonces),
                                C.POINTER(PdlProof), vp]),
         "mpe_pdl_verify": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, u32p, C.POINTER(PdlProof), vp, vp]),
+        "mpe_mta_message_a": (ip, [vp, vp, vp, ip, i32p, u32p, u32p, C.POINTER(AliceNonces), u32p, C.POINTER(AliceProof), vp]),
+        "mpe_mta_message_b": (ip, [vp, vp, vp, ip, i32p, u32p, u32p, C.POINTER(AliceProof), u32p, u32p, u32p, u32p, u32p, u32p,
+                                   C.POINTER(DlogProof), C.POINTER(DlogProof), vp, vp]),
+        "mpe_mta_verify_get_alpha": (ip, [vp, vp, ip, i32p, u32p, C.POINTER(DlogProof), C.POINTER(DlogProof), u32p, u32p, u32p,
+                                          vp, vp]),
         "mpe_bob_generate": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, u32p, u32p, u32p, C.POINTER(BobNonces), ip,
                                   C.POINTER(BobProof), u32p, vp]),
         "mpe_bob_verify": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, C.POINTER(BobProof), u32p, u32p, vp, vp]),
@@ -113,7 +119,8 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_prof_enable", "mpe_prof_collect", "mpe_modinv", "mpe_ec_mul_base", "mpe_ec_mul", "mpe_ec_add",
             "mpe_dlog_prove", "mpe_dlog_verify", "mpe_statements_create", "mpe_statements_destroy",
             "mpe_alice_generate", "mpe_alice_verify", "mpe_pdl_prove", "mpe_pdl_verify", "mpe_gg20_keys_create",
-            "mpe_gg20_keys_destroy", "mpe_gg20_sign", "mpe_bob_generate", "mpe_bob_verify"]
+            "mpe_gg20_keys_destroy", "mpe_gg20_sign", "mpe_bob_generate", "mpe_bob_verify", "mpe_mta_message_a",
+            "mpe_mta_message_b", "mpe_mta_verify_get_alpha"]
 
 
 def check(rc, what):

@@ -161,6 +161,7 @@ static Rows mod_selector(const mpe_modset* ms, const int32_t* d_mod_idx) {
 
 #include "mpe_paillier.h"
 #include "mpe_proofs.h"
+#include "mpe_mta.h"
 #include "mpe_bob.h"
 #include "mpe_gg20.h"
 

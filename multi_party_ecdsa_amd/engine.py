@@ -429,3 +429,41 @@ def bob_verify(ctx, pk, stm, d_a_enc, d_mta_enc, proof, d_X=None, d_u=None, d_ke
     N_.check(N_.lib.mpe_bob_verify(ctx.h, pk.h, stm.h, B, _ptr(d_key_idx), _ptr(d_st_idx), _ptr(d_a_enc), _ptr(d_mta_enc),
                                    C.byref(pr), _ptr(d_X), _ptr(d_u), _ptr(ok), ctx.stream()), "mpe_bob_verify")
     return ok
+
+
+# ================================================================================================
+# MtA (src/utilities/mta/mod.rs): MessageA / MessageB / verify_proofs_get_alpha, batched
+# ================================================================================================
+def mta_message_a(ctx, pk, stm, d_a, d_r, nonces, d_key_idx=None):
+    """`MessageA::a_with_predefined_randomness`: returns (c [B,128], range proofs dict [B*nst, ...])"""
+    B, total = d_a.shape[0], d_a.shape[0] * stm.count
+    c = _new(ctx, B, 128)
+    proofs = {f: _new(ctx, total, w) for f, w in ALICE_PROOF_WORDS.items()}
+    nn, pr = _struct(N_.AliceNonces, nonces), _struct(N_.AliceProof, proofs)
+    N_.check(N_.lib.mpe_mta_message_a(ctx.h, pk.h, stm.h, B, _ptr(d_key_idx), _ptr(d_a), _ptr(d_r), C.byref(nn), _ptr(c),
+                                      C.byref(pr), ctx.stream()), "mpe_mta_message_a")
+    return c, proofs
+
+
+def mta_message_b(ctx, pk, stm, d_b, d_ca, range_proofs, d_r, d_beta_tag, d_nonce_b, d_nonce_bt, d_key_idx=None):
+    """`MessageB::b_with_predefined_randomness`: returns dict(c, beta, b_proof, beta_tag_proof, ok)"""
+    B = d_b.shape[0]
+    out = dict(c=_new(ctx, B, 128), beta=_new(ctx, B, 8), ok=_flags(ctx, B),
+               b_proof=dict(pk=_new(ctx, B, 16), R=_new(ctx, B, 16), z=_new(ctx, B, 8)),
+               beta_tag_proof=dict(pk=_new(ctx, B, 16), R=_new(ctx, B, 16), z=_new(ctx, B, 8)))
+    rp = _struct(N_.AliceProof, range_proofs)
+    p1, p2 = _struct(N_.DlogProof, out["b_proof"]), _struct(N_.DlogProof, out["beta_tag_proof"])
+    N_.check(N_.lib.mpe_mta_message_b(ctx.h, pk.h, stm.h, B, _ptr(d_key_idx), _ptr(d_b), _ptr(d_ca), C.byref(rp), _ptr(d_r),
+                                      _ptr(d_beta_tag), _ptr(d_nonce_b), _ptr(d_nonce_bt), _ptr(out["c"]), _ptr(out["beta"]),
+                                      C.byref(p1), C.byref(p2), _ptr(out["ok"]), ctx.stream()), "mpe_mta_message_b")
+    return out
+
+
+def mta_verify_get_alpha(ctx, sk, d_cb, b_proof, beta_tag_proof, d_a, d_key_idx=None):
+    """`MessageB::verify_proofs_get_alpha(dk, a)`: returns (alpha [B,8], alice_share [B,64], ok)"""
+    B = d_cb.shape[0]
+    alpha, share, ok = _new(ctx, B, 8), _new(ctx, B, 64), _flags(ctx, B)
+    p1, p2 = _struct(N_.DlogProof, b_proof), _struct(N_.DlogProof, beta_tag_proof)
+    N_.check(N_.lib.mpe_mta_verify_get_alpha(ctx.h, sk.h, B, _ptr(d_key_idx), _ptr(d_cb), C.byref(p1), C.byref(p2), _ptr(d_a),
+                                             _ptr(alpha), _ptr(share), _ptr(ok), ctx.stream()), "mpe_mta_verify_get_alpha")
+    return alpha, share, ok
