@@ -193,32 +193,41 @@ __device__ __forceinline__ void store_limbs_as_words(uint32_t* __restrict__ dst,
   wave_lds_sync();
 }
 
+// window wi (wb bits) of a little-endian exponent; windows may straddle words, the top one may be partial
+__device__ __forceinline__ uint32_t exp_window(const uint32_t* __restrict__ ex, int exp_words, int wi, int wb) {
+  const int bitpos = wi * wb, word = bitpos >> 5, sh = bitpos & 31;
+  uint32_t v = ex[word] >> sh;
+  if (sh + wb > 32 && word + 1 < exp_words) v |= ex[word + 1] << (32 - sh);
+  return v & ((1u << wb) - 1u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // modexp kernel: persistent waves, each group walks the batch with a grid stride.
 //   out[i] = (base_lo[i] + 2^BITS * base_hi[i]) ^ exp[i]  mod  modulus[mod(i)]
-// base_hi.p == nullptr -> single-width base.  Fixed 4-bit windows, constant operation sequence.
+// base_hi.p == nullptr -> single-width base.  Fixed wb-bit windows, constant operation sequence.
 // ---------------------------------------------------------------------------------------------
 template <class C>
 __global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Rows mod_sel, Rows base_lo, Rows base_hi,
-                                                    Rows exps, int exp_words, uint32_t* __restrict__ out,
+                                                    Rows exps, int exp_words, int wb, uint32_t* __restrict__ out,
                                                     uint32_t* __restrict__ tables) {
   __shared__ uint32_t lds[C::LDS_WORDS];
   const Lane ln = make_lane<C>();
   uint32_t* gl = lds + ln.g * C::STRIDE;
   const int slot = blockIdx.x * C::GROUPS + ln.g;
   const int nslots = gridDim.x * C::GROUPS;
-  uint32_t* tab = tables + (size_t)slot * 16 * C::K;     // this group's 16-entry window table
+  const int TE = 1 << wb;                                // window width wb in {4,5,6}: 2^wb table entries
+  uint32_t* tab = tables + (size_t)slot * TE * C::K;     // this group's window table
   const int trips = (batch + nslots - 1) / nslots;
-  const int nwin = exp_words * 8;
+  const int nwin = (exp_words * 32 + wb - 1) / wb;
   const bool wide = base_hi.p != nullptr;
   // One Montgomery multiplication per step; the step index alone (wave-uniform) decides where the
   // multiplier comes from and where the product goes, so montmul is instantiated exactly once:
   //   step -1 (wide)    : hi * (2^BITS R^2)           -> Mont(2^BITS hi), kept aside
   //   step 0            : cur = base * R^2 (+ aside)  -> Mont(base) = tab[1]
-  //   step 1..14        : cur = cur * Mont(base)      -> tab[2..15]
-  //   then per window   : 4 squarings, 1 multiplication by tab[window]
+  //   step 1..TE-2      : cur = cur * Mont(base)      -> tab[2..TE-1]
+  //   then per window   : wb squarings, 1 multiplication by tab[window]
   //   last step         : cur = cur * 1               -> leaves the Montgomery domain
-  const int nsteps = 15 + 5 * (nwin - 1) + 1;
+  const int nsteps = (TE - 1) + (wb + 1) * (nwin - 1) + 1;
 
 #pragma unroll 1
   for (int trip = 0; trip < trips; ++trip) {
@@ -252,11 +261,11 @@ __global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Ro
         copy_to_lds<C>(gl, ms.r2_limbs + (size_t)mi * C::K, ln);
       } else if (step == 1) {
         put_limbs<C>(gl, cur, ln);                          // Mont(base) stays in LDS for steps 1..14
-      } else if (step >= 15 && step < nsteps - 1) {
-        const int k = step - 15;
-        const int wi = nwin - 2 - k / 5;
-        if (k % 5 == 4) {
-          const uint32_t w = (ex[wi >> 3] >> ((wi & 7) * 4)) & 15u;
+      } else if (step >= TE - 1 && step < nsteps - 1) {
+        const int k = step - (TE - 1);
+        const int wi = nwin - 2 - k / (wb + 1);
+        if (k % (wb + 1) == wb) {
+          const uint32_t w = exp_window(ex, exp_words, wi, wb);
           copy_to_lds<C>(gl, tab + (size_t)w * C::K, ln);
         } else {
           put_limbs<C>(gl, cur, ln);                        // squaring
@@ -285,12 +294,12 @@ __global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Ro
         for (int i = 0; i < C::L; ++i) cur[i] = (uint32_t)z[i];
       }
       // ---- product -> window table ----
-      if (step >= 0 && step < 15) {
+      if (step >= 0 && step < TE - 1) {
         store_owner<C>(tab + (size_t)(step + 1) * C::K, cur, ln);
-        if (step == 14) {
+        if (step == TE - 2) {
           // table complete: start the ladder from the top window
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          const uint32_t w = (ex[(nwin - 1) >> 3] >> (((nwin - 1) & 7) * 4)) & 15u;
+          const uint32_t w = exp_window(ex, exp_words, nwin - 1, wb);
           load_owner<C>(cur, tab + (size_t)w * C::K, ln);
         }
       }

@@ -102,7 +102,10 @@ template <class C>
 static int modexp_impl(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows base_lo, Rows base_hi, Rows exps,
                        int exp_words, uint32_t* d_out, hipStream_t st) {
   const int grid = grid_for<C>(ctx, batch, ctx->modexp_waves_per_cu);
-  const size_t need = (size_t)grid * C::GROUPS * 16 * C::K * sizeof(uint32_t);
+  // window width: multiplications = E + E/wb + 2^wb; 4 bits up to 256-bit exponents, 5 up to ~1500, 6 beyond
+  int wb = exp_words <= 8 ? 4 : (exp_words < 48 ? 5 : 6);
+  if (ctx->window_bits) wb = ctx->window_bits;
+  const size_t need = (size_t)grid * C::GROUPS * ((size_t)1 << wb) * C::K * sizeof(uint32_t);
   if (need > ctx->tables_bytes) {
     if (ctx->tables) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->tables); ctx->tables = nullptr; ctx->tables_bytes = 0; }
     hipError_t e = hipMalloc(&ctx->tables, need);
@@ -111,7 +114,7 @@ static int modexp_impl(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_s
   }
   prof_begin(ctx, st, 0, C::BITS, exp_words, batch);
   hipLaunchKernelGGL(modexp_kernel<C>, dim3(grid), dim3(64), 0, st, batch, view_of(ms), mod_sel, base_lo, base_hi, exps,
-                     exp_words, d_out, (uint32_t*)ctx->tables);
+                     exp_words, wb, d_out, (uint32_t*)ctx->tables);
   prof_end(ctx, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("modexp_kernel", e); return MPE_E_HIP; }
@@ -181,7 +184,8 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   if (!c) return MPE_E_NOMEM;
   c->device = device;
   c->cus = prop.multiProcessorCount;
-  if (getenv("MPE_NO_FIXED_BASE")) c->use_fixed_base = false;     // A/B switch for measurements
+  if (getenv("MPE_NO_FIXED_BASE")) c->use_fixed_base = false;     // A/B switches for measurements
+  if (getenv("MPE_WINDOW_BITS")) { const int w = atoi(getenv("MPE_WINDOW_BITS")); if (w >= 4 && w <= 6) c->window_bits = w; }
   *out = c;
   return MPE_OK;
 }
