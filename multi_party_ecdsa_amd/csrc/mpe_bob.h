@@ -104,7 +104,7 @@ static int bob_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
 static int bob_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
                       const int32_t* st_idx, const uint32_t* a_enc, const uint32_t* mta_enc, const BobProofRows& pr,
                       const uint32_t* X, const uint32_t* u, uint8_t* ok, hipStream_t st) {
-  MPE_TRY(ws_reserve(ctx, (size_t)B * 3600 * 4 + 65536, st));
+  MPE_TRY(ws_reserve(ctx, (size_t)B * (3600 + 3 * CRT_WS_WORDS) * 4 + 65536, st));
   Seq q{ctx, st, B};
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
@@ -122,10 +122,11 @@ static int bob_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   uint32_t* zp = open(pr.s1, 25, pr.s2, 89, pr.z, ok1);                                               // z'  :339-349
   uint32_t* w = open(pr.t1, 81, pr.t2, 89, pr.t, ok3);                                                // w   :363-372
   // v = a_enc^s1 s^N (t1 N + 1) (mta^e)^-1 mod N^2                                                     :351-361
-  uint32_t* me = q.modexp(pk->ms_nn, ksel, rows(mta_enc, 128), pr.e, 8);
+  // the verifier of a Bob proof is Alice, the owner of the key: her exponentiations may go through p^2 | q^2
+  uint32_t* me = q.modexp_nn(pk, ksel, rows(mta_enc, 128), pr.e, 8, true);
   uint32_t* mei = q.modinv(pk->ms_nn, ksel, rows(me, 128), ok2);
-  uint32_t* as1 = q.modexp(pk->ms_nn, ksel, rows(a_enc, 128), pr.s1, 25);
-  uint32_t* sn = q.modexp(pk->ms_nn, ksel, with_words(pr.s, 64), Nrow, 64);
+  uint32_t* as1 = q.modexp_nn(pk, ksel, rows(a_enc, 128), pr.s1, 25, true);
+  uint32_t* sn = q.modexp_nn(pk, ksel, with_words(pr.s, 64), Nrow, 64, true);
   uint32_t* tN = q.modmul(pk->ms_nn, ksel, with_words(pr.t1, 81), with_words(Nrow, 64));
   uint32_t* g1 = q.words(128);
   if (q.rc == MPE_OK)

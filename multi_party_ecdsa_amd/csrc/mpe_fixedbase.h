@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(64) fb_modexp_kernel(int batch, ModsetView ms,
     const int inst = trip * nslots + slot;
     const bool active = inst < batch;
     const int idx = active ? inst : batch - 1;
-    const int st = st_sel.idx ? st_sel.idx[idx] : (st_sel.stride ? idx : 0);
+    const int st = sel_index(st_sel, idx);
     const uint32_t* ex = row_of(exps, idx);
     const uint32_t* T = tab + (size_t)(2 * st + which) * FB_MAX_WINDOWS * 16 * C::K;
     uint32_t n[C::L];

@@ -397,7 +397,7 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
                nPV = (size_t)B * d.PV * P;
   // workspace: own arrays + the largest inner composite (alice_verify over nVI items / pdl_verify over nPV items)
   const size_t own = nPI * 700 + nAP * 260 + nVI * 8 + nMB * 720 + nPP * 470 + nPV * 8 + 64 * 64;
-  const size_t inner = (nVI > nPV ? nVI : nPV) * 2300 + nAP * 1500 + nMB * 300;
+  const size_t inner = (nVI > nPV ? nVI : nPV) * 2300 + nAP * 2100 + nMB * 300;
   // the inner composites call ws_reserve themselves (it resets the bump pointer), so this function keeps
   // its own arrays in a second arena carved from the tail of one reservation: reserve everything once here
   // and let the inner calls see a workspace that is already large enough (ws_reserve then only resets ws_off).
@@ -438,7 +438,7 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
   uint32_t *kq = OW(nPI * 8), *gq = OW(nPI * 8), *w = OW(nPI * 8), *k64 = OW(nPI * 64), *g_gamma = OW(nPI * 16),
            *g_w = OW(nPI * 16), *com = OW(nPI * 8), *c_a = OW(nPI * 128);
   GG_LAUNCH(r0_kernel, nPI, d, K->d_signers, K->x, z_k, z_gamma, z_blind, kq, gq, w, k64, g_gamma, g_w, com);
-  if (q.rc == MPE_OK) q.rc = paillier_encrypt(ctx, K->pk, (int)nPI, ix.key_pi, k64, z_ra, c_a, st);          // MessageA.c
+  if (q.rc == MPE_OK) q.rc = paillier_encrypt(ctx, K->pk, (int)nPI, ix.key_pi, k64, z_ra, c_a, true, st);          // MessageA.c
   gg_trace(st, "encrypt k", q.rc);
   mpe_alice_proof ap{OW(nAP * 64), OW(nAP * 8), OW(nAP * 64), OW(nAP * 25), OW(nAP * 89)};
   if (q.rc == MPE_OK)
@@ -460,7 +460,7 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
   const uint32_t *z_bt = Z->mb_beta_tag + oMB * 64, *z_mr = Z->mb_r + oMB * 64, *z_nb = Z->mb_nonce_b + oMB * 8,
                  *z_nbt = Z->mb_nonce_bt + oMB * 8;
   GG_LAUNCH(mb_prep_kernel, nMB, d, gq, w, z_bt, bsel, btq, beta);
-  if (q.rc == MPE_OK) q.rc = paillier_encrypt(ctx, K->pk, (int)nMB, ix.key_mb, z_bt, z_mr, c_bt, st);          // :133-137
+  if (q.rc == MPE_OK) q.rc = paillier_encrypt(ctx, K->pk, (int)nMB, ix.key_mb, z_bt, z_mr, c_bt, false, st);          // :133-137
   gg_trace(st, "encrypt beta_tag", q.rc);
   if (q.rc == MPE_OK)                                                                                          // Paillier::mul :140-144
     q.rc = launch_modexp(ctx, K->pk->ms_nn, (int)nMB, Rows{nullptr, ix.key_mb, 0, 0}, rows(c_a, 128, ix.pia_mb), no_rows(),

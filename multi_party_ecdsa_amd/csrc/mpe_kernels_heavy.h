@@ -5,16 +5,24 @@
 
 namespace mpe {
 
-// A batch operand: row(i) = p + (idx ? idx[i] : i) * stride words.  stride = 0 broadcasts row 0.
-// words = number of valid words in a row (the rest of the integer is zero); 0 means "full width".
+// A batch operand: row(i) = p + (idx ? idx[j] : j) * stride words with j = i >> shift.  stride = 0 broadcasts
+// row 0.  words = number of valid words in a row (the rest of the integer is zero); 0 means "full width".
+// shift = 1 lets the two CRT halves 2i, 2i+1 of item i read the same operand row.
 struct Rows {
   const uint32_t* p;
   const int32_t* idx;
   int stride;
   int words;
+  int shift;
 };
 __device__ __forceinline__ const uint32_t* row_of(const Rows& r, int i) {
-  return r.p + (size_t)(r.idx ? r.idx[i] : i) * (size_t)r.stride;
+  const int j = i >> r.shift;
+  return r.p + (size_t)(r.idx ? r.idx[j] : j) * (size_t)r.stride;
+}
+// a selector (p unused): idx != null -> idx[j];  stride != 0 -> j;  else 0
+__device__ __forceinline__ int sel_index(const Rows& sel, int i) {
+  const int j = i >> sel.shift;
+  return sel.idx ? sel.idx[j] : (sel.stride ? j : 0);
 }
 
 struct ModsetView {
@@ -234,7 +242,7 @@ __global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Ro
     const int inst = trip * nslots + slot;
     const bool active = inst < batch;
     const int idx = active ? inst : batch - 1;
-    const int mi = mod_sel.idx ? mod_sel.idx[idx] : (mod_sel.stride ? idx : 0);
+    const int mi = sel_index(mod_sel, idx);
     const uint32_t* ex = row_of(exps, idx);
 
     uint32_t n[C::L];
@@ -327,7 +335,7 @@ __global__ void __launch_bounds__(64) modmul_kernel(int batch, ModsetView ms, Ro
     const int inst = trip * nslots + slot;
     const bool active = inst < batch;
     const int idx = active ? inst : batch - 1;
-    const int mi = mod_sel.idx ? mod_sel.idx[idx] : (mod_sel.stride ? idx : 0);
+    const int mi = sel_index(mod_sel, idx);
     uint32_t n[C::L];
     load_owner<C>(n, ms.n_limbs + (size_t)mi * C::K, ln);
     const uint32_t n0inv = ms.n0inv[mi];

@@ -185,6 +185,7 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   c->device = device;
   c->cus = prop.multiProcessorCount;
   if (getenv("MPE_NO_FIXED_BASE")) c->use_fixed_base = false;     // A/B switches for measurements
+  if (getenv("MPE_NO_CRT")) c->use_crt = false;
   if (getenv("MPE_WINDOW_BITS")) { const int w = atoi(getenv("MPE_WINDOW_BITS")); if (w >= 4 && w <= 6) c->window_bits = w; }
   *out = c;
   return MPE_OK;

@@ -29,7 +29,7 @@ __global__ void modinv_lane_kernel(int B, const uint32_t* __restrict__ mod_words
   if (only_if && !only_if[i]) return;
   constexpr int W = K32 + 1;
   uint32_t u[W], v[W], x1[W], x2[W], m[W];
-  const int mi = mod_sel.idx ? mod_sel.idx[i] : (mod_sel.stride ? i : 0);
+  const int mi = sel_index(mod_sel, i);
   const uint32_t* mp = mod_words + (size_t)mi * K32;
   const uint32_t* ap = row_of(A, i);
   const int aw = A.words ? A.words : K32;
@@ -183,7 +183,7 @@ struct InvPlan {
   int32_t* ch_mod;     // [maxch]
   int32_t* nch;        // [1]
 };
-__device__ __forceinline__ int mod_index(const Rows& sel, int i) { return sel.idx ? sel.idx[i] : (sel.stride ? i : 0); }
+__device__ __forceinline__ int mod_index(const Rows& sel, int i) { return sel_index(sel, i); }
 
 __global__ void inv_count_kernel(int B, Rows mod_sel, InvPlan p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -70,7 +70,7 @@ int mpe_mta_message_a(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   hipStream_t st = (hipStream_t)stream;
   const int nst = stm->count, total = batch * nst;
   // own arrays at the top of the workspace, composites below (same scheme as the GG20 pipeline)
-  MPE_TRY(mpe::ws_reserve(ctx, ((size_t)total * 1500 + (size_t)batch * 400) * 4 + (1u << 20), st));
+  MPE_TRY(mpe::ws_reserve(ctx, ((size_t)total * 2100 + (size_t)batch * 1000) * 4 + (1u << 20), st));
   char* top = (char*)ctx->ws + ctx->ws_bytes;
   int32_t* b_of = (int32_t*)(top -= ((size_t)total * 4 + 255) & ~(size_t)255);
   int32_t* st_of = (int32_t*)(top -= ((size_t)total * 4 + 255) & ~(size_t)255);
@@ -80,7 +80,7 @@ int mpe_mta_message_a(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   // c = Enc(a; r)   (:68-75)   a zero-extended to the plaintext width
   (void)hipMemsetAsync(a64, 0, (size_t)batch * 64 * 4, st);
   (void)hipMemcpy2DAsync(a64, 64 * 4, d_a, 8 * 4, 8 * 4, batch, hipMemcpyDeviceToDevice, st);
-  MPE_TRY(mpe::paillier_encrypt(ctx, pk, batch, d_key_idx, a64, d_r, d_c, st));
+  MPE_TRY(mpe::paillier_encrypt(ctx, pk, batch, d_key_idx, a64, d_r, d_c, true, st));      // Alice's own key
   // one AliceProof per statement   (:76-81)
   return mpe::alice_generate(ctx, pk, stm, total, key_it, st_of, mpe::rows(d_a, 8, b_of), mpe::rows(d_c, 128, b_of),
                              mpe::rows(d_r, 64, b_of), nonces, proofs, st);
@@ -113,7 +113,7 @@ int mpe_mta_message_b(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   MPE_TRY(mpe::alice_verify(ctx, pk, stm, total, key_it, st_of, mpe::rows(d_ca, 128, b_of), mpe::dense(range_proofs), ok_items, st));
   MPE_LAUNCH_1D(mpe::mta_all_kernel, batch, st, batch, nst, ok_items, d_ok);
   // c_b = (b * c_a) + Enc(beta_tag; r)   (:133-145);  beta = -beta_tag mod q   (:146)
-  MPE_TRY(mpe::paillier_encrypt(ctx, pk, batch, d_key_idx, d_beta_tag, d_r, c_bt, st));
+  MPE_TRY(mpe::paillier_encrypt(ctx, pk, batch, d_key_idx, d_beta_tag, d_r, c_bt, false, st));   // Alice's key, Bob computes
   MPE_TRY(mpe::launch_modexp(ctx, pk->ms_nn, batch, mpe::key_selector(pk, d_key_idx), mpe::rows(d_ca, 128), mpe::no_rows(),
                              mpe::rows(d_b, 8), 8, bca, st));
   MPE_TRY(mpe::launch_modmul(ctx, pk->ms_nn, batch, mpe::key_selector(pk, d_key_idx), mpe::rows(bca, 128), mpe::rows(c_bt, 128),

@@ -6,6 +6,8 @@
 //   mul                            : c^k mod N^2                    1 modexp(4096,|k|)
 //   decrypt (CRT)                  : m_p = L_p(c^(p-1) mod p^2) h_p mod p, same for q, recombine
 //                                    2 modexp(2048,1024) + 4 modmul(2048) + two light kernels
+//   x^e mod N^2 by the key holder  : x^e mod p^2 and mod q^2 (a quarter of the work each), recombined with the CRT
+//                                    idempotents mod N^2 (modexp_nn_crt below) -- the same residue, half the work
 // All arithmetic runs on the GPU, including the per-key constants (h_p, h_q, CRT idempotents),
 // which the reference recomputes inside every decrypt call; per-key reuse is output-identical.
 #pragma once
@@ -29,6 +31,8 @@ struct mpe_paillier {
   uint32_t* inv2 = nullptr;   // [2nk][32]  p^-1 | q^-1 mod 2^1024
   uint32_t* h64 = nullptr;    // [2nk][64]  h_p | h_q
   uint32_t* ab64 = nullptr;   // [2nk][64]  q (q^-1 mod p) | p (p^-1 mod q): the CRT idempotents mod N
+  uint32_t* ecrt = nullptr;   // [2nk][64]  p(p-1)-1 | q(q-1)-1: the inverting exponent mod p^2 | q^2
+  uint32_t* e128 = nullptr;   // [2nk][128] q^2 (q^-2 mod p^2) | p^2 (p^-2 mod q^2): the CRT idempotents mod N^2
   int32_t* swap_idx = nullptr;  // [2nk]    j ^ 1
   mpe_modset* ms_pp = nullptr;  // 2048-bit, moduli p^2 | q^2
   mpe_modset* ms_p = nullptr;   // 2048-bit, moduli p | q
@@ -53,7 +57,8 @@ __global__ void pk_square_kernel(int nk, const uint32_t* __restrict__ N, uint32_
 __global__ void sk_setup_a_kernel(int nk, const uint32_t* __restrict__ p, const uint32_t* __restrict__ q,
                                   uint32_t* __restrict__ N, uint32_t* __restrict__ pq32, uint32_t* __restrict__ pq64,
                                   uint32_t* __restrict__ sq64, uint32_t* __restrict__ em1, uint32_t* __restrict__ em2,
-                                  uint32_t* __restrict__ inv2, int32_t* __restrict__ swap_idx) {
+                                  uint32_t* __restrict__ inv2, uint32_t* __restrict__ ecrt,
+                                  int32_t* __restrict__ swap_idx) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= 2 * nk) return;
   const int k = j >> 1;
@@ -67,6 +72,9 @@ __global__ void sk_setup_a_kernel(int nk, const uint32_t* __restrict__ p, const 
   sm::copy(sq64 + (size_t)j * 64, r, 64);
   sm::sub(t1, 32, x, 32, one, 1);
   sm::copy(em1 + (size_t)j * 32, t1, 32);
+  sm::mul(r, x, 32, t1, 32);                       // phi(x^2) = x (x - 1)
+  sm::sub(r, 64, r, 64, one, 1);
+  sm::copy(ecrt + (size_t)j * 64, r, 64);
   sm::sub(t1, 32, x, 32, two, 1);
   sm::copy(em2 + (size_t)j * 32, t1, 32);
   uint32_t iv[32];
@@ -93,6 +101,38 @@ __global__ void sk_setup_b_kernel(int nk2, const uint32_t* __restrict__ pq32, co
   sm::zero(h64 + (size_t)j * 64 + 32, 32);
   sm::mul(r, y, 32, iv, 32);
   sm::copy(ab64 + (size_t)j * 64, r, 64);
+}
+
+// e128[j] = other^2 * inv_sq[j],  inv_sq[j] = (other^2)^-1 mod own^2
+__global__ void sk_setup_c_kernel(int nk2, const uint32_t* __restrict__ sq64, const uint32_t* __restrict__ inv_sq,
+                                  uint32_t* __restrict__ e128) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nk2) return;
+  uint32_t a[64], b[64], r[128];
+  sm::copy(a, sq64 + (size_t)(j ^ 1) * 64, 64);
+  sm::copy(b, inv_sq + (size_t)j * 64, 64);
+  sm::mul(r, a, 64, b, 64);
+  sm::copy(e128 + (size_t)j * 128, r, 128);
+}
+
+// CRT plumbing for x^e mod N^2: half item j = 2i + side uses modulus 2 key(i) + side of ms_pp
+__global__ void crt_half_kernel(int B2, Rows ksel, int32_t* __restrict__ half_of) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= B2) return;
+  half_of[j] = 2 * sel_index(ksel, j >> 1) + (j & 1);
+}
+// out = y[2i] + y[2i+1] mod N^2
+__global__ void crt_add_kernel(int B, Rows ksel, const uint32_t* __restrict__ NN, const uint32_t* __restrict__ y,
+                               uint32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  uint32_t a[129], b[128];
+  sm::copy(a, y + (size_t)(2 * i) * 128, 128);
+  sm::copy(b, y + (size_t)(2 * i + 1) * 128, 128);
+  a[128] = sm::add(a, 128, a, 128, b, 128);
+  sm::copy(b, NN + (size_t)sel_index(ksel, i) * 128, 128);
+  if (sm::cmp(a, 129, b, 128) >= 0) sm::sub(a, 129, a, 129, b, 128);
+  sm::copy(out + (size_t)i * 128, a, 128);
 }
 
 // gm = 1 + m N   (128 words; m < N so gm < N^2)
@@ -172,7 +212,7 @@ static int paillier_create(mpe_ctx* ctx, int nk, const uint32_t* d_N, const uint
   pk->has_private = d_p != nullptr;
   const size_t nk2 = 2 * (size_t)nk;
   size_t words = (size_t)nk * (64 + 128);
-  if (pk->has_private) words += nk2 * (32 + 64 + 64 + 32 + 32 + 32 + 64 + 64 + 1);
+  if (pk->has_private) words += nk2 * (32 + 64 + 64 + 32 + 32 + 32 + 64 + 64 + 64 + 128 + 1);
   hipError_t e = hipMalloc(&pk->blob, words * 4);
   if (e != hipSuccess) { delete pk; mpe_set_error("hipMalloc(paillier keys)", e); return MPE_E_NOMEM; }
   uint32_t* w = (uint32_t*)pk->blob;
@@ -189,19 +229,27 @@ static int paillier_create(mpe_ctx* ctx, int nk, const uint32_t* d_N, const uint
     pk->inv2 = w; w += nk2 * 32;
     pk->h64 = w; w += nk2 * 64;
     pk->ab64 = w; w += nk2 * 64;
+    pk->ecrt = w; w += nk2 * 64;
+    pk->e128 = w; w += nk2 * 128;
     pk->swap_idx = (int32_t*)w; w += nk2;
     hipLaunchKernelGGL(sk_setup_a_kernel, dim3(blocks_for((int)nk2, 64)), dim3(64), 0, st, nk, d_p, d_q, pk->N, pk->pq32,
-                       pk->pq64, pk->sq64, pk->em1, pk->em2, pk->inv2, pk->swap_idx);
+                       pk->pq64, pk->sq64, pk->em1, pk->em2, pk->inv2, pk->ecrt, pk->swap_idx);
     if ((rc = modset_create_dev(ctx, 2048, (int)nk2, pk->sq64, &pk->ms_pp, st)) != MPE_OK) return fail(rc);
     if ((rc = modset_create_dev(ctx, 2048, (int)nk2, pk->pq64, &pk->ms_p, st)) != MPE_OK) return fail(rc);
     // (other prime)^(own-2) mod own = (other prime)^-1 mod own   (Fermat; own is prime)
-    if ((rc = ws_reserve(ctx, nk2 * 64 * 4 + 4096, st)) != MPE_OK) return fail(rc);
+    if ((rc = ws_reserve(ctx, nk2 * 128 * 4 + 4096, st)) != MPE_OK) return fail(rc);
     uint32_t* inv_other = ws_array<uint32_t>(ctx, nk2 * 64);
+    uint32_t* inv_sq = ws_array<uint32_t>(ctx, nk2 * 64);
     rc = launch_modexp(ctx, pk->ms_p, (int)nk2, rows(nullptr, 1), rows(pk->pq32, 32, pk->swap_idx, 32), no_rows(),
                        rows(pk->em2, 32), 32, inv_other, st);
     if (rc != MPE_OK) return fail(rc);
     hipLaunchKernelGGL(sk_setup_b_kernel, dim3(blocks_for((int)nk2, 64)), dim3(64), 0, st, (int)nk2, pk->pq32, inv_other,
                        pk->h64, pk->ab64);
+    // (other^2)^(phi(own^2)-1) mod own^2 = (other^2)^-1 mod own^2
+    rc = launch_modexp(ctx, pk->ms_pp, (int)nk2, rows(nullptr, 1), rows(pk->sq64, 64, pk->swap_idx, 64), no_rows(),
+                       rows(pk->ecrt, 64), 64, inv_sq, st);
+    if (rc != MPE_OK) return fail(rc);
+    hipLaunchKernelGGL(sk_setup_c_kernel, dim3(blocks_for((int)nk2, 64)), dim3(64), 0, st, (int)nk2, pk->sq64, inv_sq, pk->e128);
   } else {
     e = hipMemcpyAsync(pk->N, d_N, (size_t)nk * 64 * 4, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) { mpe_set_error("hipMemcpyAsync(N)", e); return fail(MPE_E_HIP); }
@@ -224,14 +272,39 @@ static Rows key_rows(const mpe_paillier* pk, const uint32_t* table, int stride, 
   return Rows{table, nullptr, pk->nkeys == 1 ? 0 : stride, words};
 }
 
+// words of workspace per item that modexp_nn takes when it goes through the CRT
+constexpr size_t CRT_WS_WORDS = 2 + 2 * 64 + 2 * 128 + 192;
+
+// base^exps mod N_k^2.  holder = the caller is the owner of the key (it may use p and q): the two halves
+// mod p^2 | q^2 on the 2048-bit engine, then  x = x_p E_p + x_q E_q mod N^2.  Same residue as the direct form.
+static int modexp_nn(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Rows base, Rows exps, int ew, bool holder,
+                     uint32_t* out, hipStream_t st) {
+  if (!(holder && pk->has_private && ctx->use_crt)) return launch_modexp(ctx, pk->ms_nn, B, ksel, base, no_rows(), exps, ew, out, st);
+  const int B2 = 2 * B;
+  int32_t* half_of = ws_array<int32_t>(ctx, B2);
+  uint32_t* u = ws_array<uint32_t>(ctx, (size_t)B2 * 64);
+  uint32_t* y = ws_array<uint32_t>(ctx, (size_t)B2 * 128);
+  if (!half_of || !u || !y) { mpe_set_error_msg("workspace under-reserved (modexp_nn)"); return MPE_E_NOMEM; }
+  MPE_LAUNCH_1D(crt_half_kernel, B2, st, B2, ksel, half_of);
+  const int bw = base.words ? base.words : 128;
+  Rows lo{base.p, base.idx, base.stride, bw < 64 ? bw : 64, 1};
+  Rows hi = bw > 64 ? Rows{base.p + 64, base.idx, base.stride, bw - 64, 1} : no_rows();
+  Rows ex{exps.p, exps.idx, exps.stride, exps.words, 1};
+  MPE_TRY(launch_modexp(ctx, pk->ms_pp, B2, Rows{nullptr, half_of, 0, 0}, lo, hi, ex, ew, u, st));
+  MPE_TRY(launch_modmul(ctx, pk->ms_nn, B2, Rows{nullptr, ksel.idx, ksel.stride, 0, 1}, rows(u, 64, nullptr, 64),
+                        rows(pk->e128, 128, half_of), y, st));
+  MPE_LAUNCH_1D(crt_add_kernel, B, st, B, ksel, pk->NN, y, out);
+  return MPE_OK;
+}
+
 static int paillier_encrypt(mpe_ctx* ctx, const mpe_paillier* pk, int B, const int32_t* key_idx, const uint32_t* d_m,
-                            const uint32_t* d_r, uint32_t* d_c, hipStream_t st) {
-  MPE_TRY(ws_reserve(ctx, (size_t)B * 128 * 4 * 2 + 8192, st));
+                            const uint32_t* d_r, uint32_t* d_c, bool holder, hipStream_t st) {
+  MPE_TRY(ws_reserve(ctx, (size_t)B * (256 + CRT_WS_WORDS) * 4 + 8192, st));
   uint32_t* x = ws_array<uint32_t>(ctx, (size_t)B * 128);
   uint32_t* gm = ws_array<uint32_t>(ctx, (size_t)B * 128);
   // r^N mod N^2
-  MPE_TRY(launch_modexp(ctx, pk->ms_nn, B, key_selector(pk, key_idx), rows(d_r, 64, nullptr, 64), no_rows(),
-                        key_rows(pk, pk->N, 64, key_idx), 64, x, st));
+  MPE_TRY(modexp_nn(ctx, pk, B, key_selector(pk, key_idx), rows(d_r, 64, nullptr, 64), key_rows(pk, pk->N, 64, key_idx), 64,
+                    holder, x, st));
   MPE_LAUNCH_1D(enc_gm_kernel, B, st, B, pk->nkeys, d_m, key_idx, pk->N, gm);
   return launch_modmul(ctx, pk->ms_nn, B, key_selector(pk, key_idx), rows(x, 128), rows(gm, 128), d_c, st);
 }
@@ -287,7 +360,8 @@ int mpe_paillier_encrypt(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const 
   if (!ctx || !pk || !d_m || !d_r || !d_c || batch < 0) return MPE_E_ARG;
   if (!d_key_idx && pk->nkeys != 1 && pk->nkeys < batch) return MPE_E_ARG;
   if (batch == 0) return MPE_OK;
-  return mpe::paillier_encrypt(ctx, pk, batch, d_key_idx, d_m, d_r, d_c, (hipStream_t)stream);
+  // a key set created with its primes belongs to the caller: encrypt through the CRT
+  return mpe::paillier_encrypt(ctx, pk, batch, d_key_idx, d_m, d_r, d_c, pk->has_private, (hipStream_t)stream);
 }
 int mpe_paillier_decrypt(mpe_ctx* ctx, const mpe_paillier* sk, int batch, const int32_t* d_key_idx, const uint32_t* d_c,
                          uint32_t* d_m, void* stream) {

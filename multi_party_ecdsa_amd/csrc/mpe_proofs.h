@@ -213,6 +213,12 @@ struct Seq {
     if (rc == MPE_OK) rc = launch_modexp(ctx, ms, B, sel, base, no_rows(), exps, ew, o, st);
     return o;
   }
+  // x^e mod N^2; holder = this party owns the key and may go through p^2 | q^2
+  uint32_t* modexp_nn(const mpe_paillier* pk, Rows sel, Rows base, Rows exps, int ew, bool holder) {
+    uint32_t* o = words(128);
+    if (rc == MPE_OK) rc = mpe::modexp_nn(ctx, pk, B, sel, base, exps, ew, holder, o, st);
+    return o;
+  }
   uint32_t* modmul(const mpe_modset* ms, Rows sel, Rows a, Rows b) {
     uint32_t* o = words(ms->bits / 32);
     if (rc == MPE_OK) rc = launch_modmul(ctx, ms, B, sel, a, b, o, st);
@@ -267,7 +273,7 @@ static Rows with_words(Rows r, int words) { r.words = words; return r; }
 static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
                           const int32_t* st_idx, Rows a, Rows cipher, Rows r,
                           const mpe_alice_nonces* nn, const mpe_alice_proof* out, hipStream_t st) {
-  MPE_TRY(ws_reserve(ctx, (size_t)B * 1400 * 4 + 65536, st));
+  MPE_TRY(ws_reserve(ctx, (size_t)B * (1400 + CRT_WS_WORDS) * 4 + 65536, st));
   Seq q{ctx, st, B};
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
@@ -279,7 +285,7 @@ static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statem
   // u = (alpha N + 1) beta^N mod N^2                                            :53-55
   uint32_t* gu = q.words(128);
   q.muladd(rows(nn->alpha, 24), 24, Nrow, 64, no_rows(), 0, gu, 128);
-  uint32_t* bn = q.modexp(pk->ms_nn, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64);
+  uint32_t* bn = q.modexp_nn(pk, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64, true);   // the prover owns the key
   uint32_t* u = q.modmul(pk->ms_nn, ksel, rows(gu, 128), rows(bn, 128));
   // w = h1^alpha h2^gamma mod N~                                                :56-57
   uint32_t* w1 = q.fb_modexp(stm, ssel, 0, h1,rows(nn->alpha, 24), 24);
@@ -344,7 +350,7 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
 static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
                      const int32_t* st_idx, Rows cipher, Rows Qp, Rows Gp, Rows x, Rows r, const mpe_pdl_nonces* nn,
                      const mpe_pdl_proof* out, hipStream_t st) {
-  MPE_TRY(ws_reserve(ctx, (size_t)B * 1400 * 4 + 65536, st));
+  MPE_TRY(ws_reserve(ctx, (size_t)B * (1400 + CRT_WS_WORDS) * 4 + 65536, st));
   Seq q{ctx, st, B};
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
@@ -358,7 +364,7 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
   // u2 = (N+1)^alpha beta^N mod N^2; (N+1)^alpha = 1 + alpha N (mod N^2), alpha N + 1 < N^2      :87-93
   uint32_t* ga = q.words(128);
   q.muladd(rows(nn->alpha, 24), 24, Nrow, 64, no_rows(), 0, ga, 128);
-  uint32_t* bn = q.modexp(pk->ms_nn, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64);
+  uint32_t* bn = q.modexp_nn(pk, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64, true);   // the prover owns the key
   q.modmul_to(pk->ms_nn, ksel, rows(ga, 128), rows(bn, 128), out->u2);
   // u3 = h1^alpha h2^gamma mod N~                                               :94-100
   uint32_t* w1 = q.fb_modexp(stm, ssel, 0, h1,rows(nn->alpha, 24), 24);
