@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--sessions", type=int, default=16384, help="concurrent signing sessions per GPU per step")
+    ap.add_argument("--sessions", type=int, default=65536, help="concurrent signing sessions per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="sessions per internal pass of mpe_gg20_sign (0 = library default)")
     ap.add_argument("--dedup", action="store_true", help="evaluate identical checks once (same outputs; not the faithful path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -211,7 +211,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            if B == 16384 and not args.dedup:
+            if pmc.get("sessions") == B and not args.dedup:
                 traffic = pmc["hbm_bytes_per_launch"]
         except OSError:
             pass

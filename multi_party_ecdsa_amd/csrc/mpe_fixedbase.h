@@ -2,20 +2,33 @@
 //
 // Almost every mod-N~ exponentiation on the GG20 path has base h1 or h2 of a statement
 // (src/utilities/mta/range_proofs.rs:52,56-57,129-131; src/utilities/zk_pdl_with_slack/mod.rs:79-100,159-165),
-// and those bases are fixed per key.  With a table T[i][d] = h^(d * 16^i) in HBM (712 windows x 16 entries x
-// 288 B = 3.3 MB per base — nothing next to 288 GB) an exponentiation is just one Montgomery multiplication
-// per 4-bit window: E/4 multiplications and no squarings, instead of E squarings + E/4 multiplications.
+// and those bases are fixed per key.  With a table T[i][d] = h^(d * 2^(wb i)) in HBM an exponentiation is just
+// one Montgomery multiplication per wb-bit window: E/wb multiplications and no squarings, instead of E
+// squarings + E/4 multiplications.  wb = 8: 356 windows x 256 entries x 288 B = 26 MB per base — nothing next
+// to 288 GB; each multiplication reads one 288-byte row (prefetched one step ahead).
 // The value is the same residue mpz_powm returns.  The operation sequence depends only on exp_words.
 #pragma once
 #include "mpe_internal.h"
 
 namespace mpe {
 
-constexpr int FB_MAX_WINDOWS = 89 * 8;     // exponents up to 89 words (s2, s3 < 2^2817)
+#ifndef MPE_FB_WB
+#define MPE_FB_WB 8
+#endif
+constexpr int FB_WB = MPE_FB_WB;                               // window bits (4 or 8: windows do not straddle words)
+constexpr int FB_TE = 1 << FB_WB;                              // table entries per window
+constexpr int FB_PER_WORD = 32 / FB_WB;
+constexpr int FB_MAX_WINDOWS = 89 * FB_PER_WORD;               // exponents up to 89 words (s2, s3 < 2^2817)
+static_assert(FB_WB == 4 || FB_WB == 8, "fixed-base windows must divide a word");
 
-// one lane group per (statement, base): tab[(pair * FB_MAX_WINDOWS + i) * 16 + d][K] = Mont(h^(d 16^i))
+__device__ __forceinline__ uint32_t fb_digit(const uint32_t* __restrict__ ex, int i) {
+  return (ex[i / FB_PER_WORD] >> ((i % FB_PER_WORD) * FB_WB)) & (uint32_t)(FB_TE - 1);
+}
+
+// Stage 1, one lane group per (statement, base): the window bases.
+//   tab[pair][i][0] = Mont(1), tab[pair][i][1] = Mont(h^(2^(wb i)))       (canonical residues)
 template <class C>
-__global__ void __launch_bounds__(64) fb_build_kernel(int npairs, ModsetView ms, const uint32_t* __restrict__ h1,
+__global__ void __launch_bounds__(64) fb_bases_kernel(int npairs, ModsetView ms, const uint32_t* __restrict__ h1,
                                                       const uint32_t* __restrict__ h2, uint32_t* __restrict__ tab) {
   __shared__ uint32_t lds[C::LDS_WORDS];
   const Lane ln = make_lane<C>();
@@ -28,30 +41,20 @@ __global__ void __launch_bounds__(64) fb_build_kernel(int npairs, ModsetView ms,
   uint32_t n[C::L];
   load_owner<C>(n, ms.n_limbs + (size_t)st * C::K, ln);
   const uint32_t n0inv = ms.n0inv[st];
-  uint32_t one[C::L], base[C::L], cur[C::L];
+  uint32_t one[C::L], cur[C::L];
   load_owner<C>(one, ms.one_limbs + (size_t)st * C::K, ln);
   load_words_as_limbs<C>(cur, gl, hw, 0, ln);
-  // step -1: base = Mont(h).  Then per window: 14 products e_d = e_{d-1} * base (d = 2..15), 4 squarings of base.
-  const int nsteps = FB_MAX_WINDOWS * 18;
+  // step -1: cur = Mont(h); then FB_WB squarings per window
+  const int nsteps = (FB_MAX_WINDOWS - 1) * FB_WB;
 #pragma unroll 1
   for (int s = -1; s < nsteps; ++s) {
-    const int i = s < 0 ? 0 : s / 18, ph = s < 0 ? -1 : s % 18;
-    uint32_t* row = tab + ((size_t)pair * FB_MAX_WINDOWS + i) * 16 * C::K;
-    if (s < 0) {
-      copy_to_lds<C>(gl, ms.r2_limbs + (size_t)st * C::K, ln);
-    } else if (ph == 0) {
-      // new window: entries 0 and 1, multiplier = base, running product starts at base
-      if (active) { store_owner<C>(row, one, ln); store_owner<C>(row + C::K, base, ln); }
-      put_limbs<C>(gl, base, ln);
-#pragma unroll
-      for (int k = 0; k < C::L; ++k) cur[k] = base[k];
-    } else if (ph == 14) {
-      put_limbs<C>(gl, base, ln);                    // squarings: base <- base^2, four times
-#pragma unroll
-      for (int k = 0; k < C::L; ++k) cur[k] = base[k];
-    } else if (ph > 14) {
-      put_limbs<C>(gl, cur, ln);
+    if (s >= 0 && s % FB_WB == 0 && active) {
+      uint32_t* row = tab + ((size_t)pair * FB_MAX_WINDOWS + s / FB_WB) * FB_TE * C::K;
+      store_owner<C>(row, one, ln);
+      store_owner<C>(row + C::K, cur, ln);
     }
+    if (s < 0) copy_to_lds<C>(gl, ms.r2_limbs + (size_t)st * C::K, ln);
+    else put_limbs<C>(gl, cur, ln);
     wave_lds_sync();
     uint32_t r[C::L];
     montmul<C>(r, cur, gl, n, n0inv, ln);
@@ -59,15 +62,40 @@ __global__ void __launch_bounds__(64) fb_build_kernel(int npairs, ModsetView ms,
     reduce_once<C>(r, n, ln);                        // keep table entries canonical
 #pragma unroll
     for (int k = 0; k < C::L; ++k) cur[k] = r[k];
-    if (s < 0) {
+  }
+  if (active) {
+    uint32_t* row = tab + ((size_t)pair * FB_MAX_WINDOWS + (FB_MAX_WINDOWS - 1)) * FB_TE * C::K;
+    store_owner<C>(row, one, ln);
+    store_owner<C>(row + C::K, cur, ln);
+  }
+}
+
+// Stage 2, one lane group per (statement, base, window): tab[..][d] = tab[..][d-1] * tab[..][1], d = 2..TE-1
+template <class C>
+__global__ void __launch_bounds__(64) fb_fill_kernel(int nrows, ModsetView ms, uint32_t* __restrict__ tab) {
+  __shared__ uint32_t lds[C::LDS_WORDS];
+  const Lane ln = make_lane<C>();
+  uint32_t* gl = lds + ln.g * C::STRIDE;
+  const int slot = blockIdx.x * C::GROUPS + ln.g;
+  const bool active = slot < nrows;
+  const int rowi = active ? slot : nrows - 1;                 // = pair * FB_MAX_WINDOWS + window
+  const int st = (rowi / FB_MAX_WINDOWS) >> 1;
+  uint32_t* row = tab + (size_t)rowi * FB_TE * C::K;
+  uint32_t n[C::L];
+  load_owner<C>(n, ms.n_limbs + (size_t)st * C::K, ln);
+  const uint32_t n0inv = ms.n0inv[st];
+  uint32_t cur[C::L];
+  load_owner<C>(cur, row + C::K, ln);
+  put_limbs<C>(gl, cur, ln);                                   // the window base stays in LDS
+  wave_lds_sync();
+#pragma unroll 1
+  for (int d = 2; d < FB_TE; ++d) {
+    uint32_t r[C::L];
+    montmul<C>(r, cur, gl, n, n0inv, ln);
+    reduce_once<C>(r, n, ln);
 #pragma unroll
-      for (int k = 0; k < C::L; ++k) base[k] = cur[k];
-    } else if (ph < 14) {
-      if (active) store_owner<C>(row + (size_t)(ph + 2) * C::K, cur, ln);
-    } else if (ph == 17) {
-#pragma unroll
-      for (int k = 0; k < C::L; ++k) base[k] = cur[k];
-    }
+    for (int k = 0; k < C::L; ++k) cur[k] = r[k];
+    if (active) store_owner<C>(row + (size_t)d * C::K, cur, ln);
   }
 }
 
@@ -82,7 +110,7 @@ __global__ void __launch_bounds__(64) fb_modexp_kernel(int batch, ModsetView ms,
   const int slot = blockIdx.x * C::GROUPS + ln.g;
   const int nslots = gridDim.x * C::GROUPS;
   const int trips = (batch + nslots - 1) / nslots;
-  const int nwin = exp_words * 8;
+  const int nwin = exp_words * FB_PER_WORD;
 #pragma unroll 1
   for (int trip = 0; trip < trips; ++trip) {
     const int inst = trip * nslots + slot;
@@ -90,20 +118,16 @@ __global__ void __launch_bounds__(64) fb_modexp_kernel(int batch, ModsetView ms,
     const int idx = active ? inst : batch - 1;
     const int st = sel_index(st_sel, idx);
     const uint32_t* ex = row_of(exps, idx);
-    const uint32_t* T = tab + (size_t)(2 * st + which) * FB_MAX_WINDOWS * 16 * C::K;
+    const uint32_t* T = tab + (size_t)(2 * st + which) * FB_MAX_WINDOWS * FB_TE * C::K;
     uint32_t n[C::L];
     load_owner<C>(n, ms.n_limbs + (size_t)st * C::K, ln);
     const uint32_t n0inv = ms.n0inv[st];
     uint32_t cur[C::L], nx[C::L];
-    {
-      const uint32_t d0 = ex[0] & 15u;
-      load_owner<C>(cur, T + (size_t)d0 * C::K, ln);
-    }
+    load_owner<C>(cur, T + (size_t)fb_digit(ex, 0) * C::K, ln);
     // steps 1..nwin-1: cur <- cur * T[i][digit_i]; step nwin: cur <- cur * 1.  The next table row is fetched
     // (coalesced within the group) before the multiplication that hides its latency.
     auto fetch = [&](int i) {
-      const uint32_t d = (ex[i >> 3] >> ((i & 7) * 4)) & 15u;
-      const uint32_t* src = T + ((size_t)i * 16 + d) * C::K;
+      const uint32_t* src = T + ((size_t)i * FB_TE + fb_digit(ex, i)) * C::K;
 #pragma unroll
       for (int k = 0; k < C::L; ++k) nx[k] = src[ln.t + C::TPI * k];
     };

@@ -568,7 +568,7 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const mpe_
                   uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, int dedup_verify, int chunk,
                   void* stream) {
   if (!ctx || !keys || !nonces || !d_r || !d_s || !d_recid || !d_status || batch < 0) return MPE_E_ARG;
-  if (chunk <= 0) chunk = 16384;
+  if (chunk <= 0) chunk = 65536;      // ~13 GB of workspace at t=1, n=3; the EC kernels want >= 2 waves per SIMD
   for (int b0 = 0; b0 < batch; b0 += chunk) {
     const int B = batch - b0 < chunk ? batch - b0 : chunk;
     int rc = mpe::gg::sign_chunk(ctx, keys, B, b0, nonces, d_r, d_s, d_recid, d_R, d_status, dedup_verify, (hipStream_t)stream);

@@ -18,7 +18,7 @@ struct mpe_statements {
   uint32_t* h1 = nullptr;
   uint32_t* h2 = nullptr;
   mpe_modset* ms = nullptr;  // 2048-bit, modulus k = N~_k
-  uint32_t* fb_tab = nullptr;  // [2*count][FB_MAX_WINDOWS][16][72] fixed-base tables of h1 (even) / h2 (odd)
+  uint32_t* fb_tab = nullptr;  // [2*count][FB_MAX_WINDOWS][FB_TE][72] fixed-base tables of h1 (even) / h2 (odd)
 };
 
 #include "mpe_fixedbase.h"
@@ -458,19 +458,21 @@ int mpe_statements_create(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const u
   int rc = mpe::modset_create_dev(ctx, 2048, count, s->Nt, &s->ms, st);
   if (rc != MPE_OK) { (void)hipFree(s->blob); delete s; return rc; }
   if (ctx->use_fixed_base) {
-    // fixed-base window tables of h1, h2 (3.3 MB per base), built on the GPU once per statement set
+    // fixed-base window tables of h1, h2 (26 MB per base at 8-bit windows), built on the GPU once per statement set:
+    // the window bases one after the other (squarings), then every window's multiples in parallel
     using C = mpe::Cfg2048;
-    const size_t bytes = (size_t)2 * count * mpe::FB_MAX_WINDOWS * 16 * C::K * sizeof(uint32_t);
+    const size_t bytes = (size_t)2 * count * mpe::FB_MAX_WINDOWS * mpe::FB_TE * C::K * sizeof(uint32_t);
     e = hipMalloc((void**)&s->fb_tab, bytes);
     if (e != hipSuccess) { mpe_set_error("hipMalloc(fixed-base tables)", e); mpe_statements_destroy(s); return MPE_E_NOMEM; }
     mpe::ModsetView v;
     v.n_limbs = s->ms->n_limbs; v.one_limbs = s->ms->one_limbs; v.r2_limbs = s->ms->r2_limbs; v.r2h_limbs = s->ms->r2h_limbs;
     v.n0inv = s->ms->n0inv; v.count = s->ms->count;
-    const int npairs = 2 * count;
-    hipLaunchKernelGGL(mpe::fb_build_kernel<C>, dim3((npairs + C::GROUPS - 1) / C::GROUPS), dim3(64), 0, st, npairs, v, s->h1,
+    const int npairs = 2 * count, nrows = npairs * mpe::FB_MAX_WINDOWS;
+    hipLaunchKernelGGL(mpe::fb_bases_kernel<C>, dim3((npairs + C::GROUPS - 1) / C::GROUPS), dim3(64), 0, st, npairs, v, s->h1,
                        s->h2, s->fb_tab);
+    hipLaunchKernelGGL(mpe::fb_fill_kernel<C>, dim3((nrows + C::GROUPS - 1) / C::GROUPS), dim3(64), 0, st, nrows, v, s->fb_tab);
     e = hipGetLastError();
-    if (e != hipSuccess) { mpe_set_error("fb_build_kernel", e); mpe_statements_destroy(s); return MPE_E_HIP; }
+    if (e != hipSuccess) { mpe_set_error("fixed-base table build", e); mpe_statements_destroy(s); return MPE_E_HIP; }
   }
   *out = s;
   return MPE_OK;
