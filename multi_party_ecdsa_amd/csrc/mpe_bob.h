@@ -26,9 +26,9 @@ __global__ void bob_ext_check_kernel(int B, Rows s1, Rows e, const uint32_t* __r
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::U256 a = ec::sc_reduce(row_of(s1, i), 25), ee = ec::sc_reduce(row_of(e, i), 8);
-  const ec::Jac l = ec::jac_mul(a, ec::aff_gen());
-  const ec::Jac r = ec::jac_add(ec::jac_mul(ee, ec::aff_load(X + (size_t)i * 16)), ec::jac_from_aff(ec::aff_load(u + (size_t)i * 16)));
-  if (!ec::aff_eq(ec::jac_to_aff(l), ec::jac_to_aff(r))) ok[i] = 0;
+  const ec::Jac l = ec::jac_mul_gen(a);
+  const ec::Jac r = ec::jac_add_aff(ec::jac_mul(ee, ec::aff_load(X + (size_t)i * 16)), ec::aff_load(u + (size_t)i * 16));
+  if (!ec::jac_eq(l, r)) ok[i] = 0;
 }
 
 struct BobProofRows { Rows t, z, e, s, s1, s2, t1, t2; };

@@ -73,6 +73,32 @@ __device__ __forceinline__ void mul_wide(uint32_t (&t)[16], const U256& a, const
   }
 }
 
+// a^2 -> 16 words: 28 cross products doubled + 8 squares (36 multiplies instead of 64)
+__device__ __forceinline__ void sqr_wide(uint32_t (&t)[16], const U256& a) {
+  for (int i = 0; i < 16; ++i) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = i + 1; j < 8; ++j) {
+      const uint64_t v = (uint64_t)a.w[i] * a.w[j] + t[i + j] + c;
+      t[i + j] = (uint32_t)v;
+      c = v >> 32;
+    }
+    t[i + 8] = (uint32_t)c;
+  }
+  uint32_t top = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const uint32_t nt = t[i] >> 31; t[i] = (t[i] << 1) | top; top = nt; }
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t sq = (uint64_t)a.w[i] * a.w[i];
+    c += (uint64_t)t[2 * i] + (uint32_t)sq; t[2 * i] = (uint32_t)c; c >>= 32;
+    c += (uint64_t)t[2 * i + 1] + (sq >> 32); t[2 * i + 1] = (uint32_t)c; c >>= 32;
+  }
+}
+
 // ---- field: mod p = 2^256 - 2^32 - 977 ------------------------------------------------------
 __device__ __forceinline__ U256 fe_reduce_wide(const uint32_t (&t)[16]) {
   // t = lo + hi 2^256,  2^256 = 2^32 + 977 (mod p):  r = lo + hi*977 + (hi << 32), twice
@@ -112,7 +138,7 @@ __device__ __forceinline__ U256 fe_reduce_wide(const uint32_t (&t)[16]) {
   return o;
 }
 __device__ __forceinline__ U256 fe_mul(const U256& a, const U256& b) { uint32_t t[16]; mul_wide(t, a, b); return fe_reduce_wide(t); }
-__device__ __forceinline__ U256 fe_sqr(const U256& a) { return fe_mul(a, a); }
+__device__ __forceinline__ U256 fe_sqr(const U256& a) { uint32_t t[16]; sqr_wide(t, a); return fe_reduce_wide(t); }
 __device__ __forceinline__ U256 fe_add(const U256& a, const U256& b) {
   U256 r; const uint32_t c = u256_add(r, a, b);
   if (c || u256_ge(r, FP)) u256_sub_m(r, r, FP);
@@ -131,11 +157,18 @@ __device__ inline U256 fe_pow(const U256& a, const uint32_t* e) {   // a^e, e: 8
   }
   return r;
 }
+__device__ inline U256 fe_sqrn(U256 x, int n) { for (int i = 0; i < n; ++i) x = fe_sqr(x); return x; }
+// a^(p-2): p - 2 = 1^223 0 1^22 0000 101101 in binary; addition chain with 255 squarings + 15 multiplications
 __device__ inline U256 fe_inv(const U256& a) {
-  uint32_t e[8];
-  for (int i = 0; i < 8; ++i) e[i] = FP[i];
-  e[0] -= 2;                                    // p - 2
-  return fe_pow(a, e);
+  const U256 x2 = fe_mul(fe_sqr(a), a), x3 = fe_mul(fe_sqr(x2), a);
+  const U256 x6 = fe_mul(fe_sqrn(x3, 3), x3), x9 = fe_mul(fe_sqrn(x6, 3), x3), x11 = fe_mul(fe_sqrn(x9, 2), x2);
+  const U256 x22 = fe_mul(fe_sqrn(x11, 11), x11), x44 = fe_mul(fe_sqrn(x22, 22), x22);
+  const U256 x88 = fe_mul(fe_sqrn(x44, 44), x44), x176 = fe_mul(fe_sqrn(x88, 88), x88);
+  const U256 x220 = fe_mul(fe_sqrn(x176, 44), x44), x223 = fe_mul(fe_sqrn(x220, 3), x3);
+  U256 t = fe_mul(fe_sqrn(x223, 23), x22);
+  t = fe_mul(fe_sqrn(t, 5), a);
+  t = fe_mul(fe_sqrn(t, 3), x2);
+  return fe_mul(fe_sqrn(t, 2), a);
 }
 
 // ---- scalars: mod q ---------------------------------------------------------------------------
@@ -227,6 +260,33 @@ __device__ inline Jac jac_add(const Jac& p, const Jac& q) {
   r.z = fe_mul(fe_mul(p.z, q.z), h);
   return r;
 }
+// p + q with q affine (z = 1): 8 multiplications + 3 squarings
+__device__ inline Jac jac_add_aff(const Jac& p, const Aff& q) {
+  if (q.inf) return p;
+  if (jac_is_inf(p)) { Jac r; r.x = q.x; r.y = q.y; r.z = u256_one(); return r; }
+  const U256 z1z1 = fe_sqr(p.z);
+  const U256 u2 = fe_mul(q.x, z1z1), s2 = fe_mul(fe_mul(q.y, p.z), z1z1);
+  const U256 h = fe_sub(u2, p.x), rr = fe_sub(s2, p.y);
+  if (u256_is_zero(h)) return u256_is_zero(rr) ? jac_dbl(p) : jac_inf();
+  const U256 hh = fe_sqr(h), hhh = fe_mul(h, hh), v = fe_mul(p.x, hh);
+  Jac r;
+  r.x = fe_sub(fe_sub(fe_sqr(rr), hhh), fe_add(v, v));
+  r.y = fe_sub(fe_mul(rr, fe_sub(v, r.x)), fe_mul(p.y, hhh));
+  r.z = fe_mul(p.z, h);
+  return r;
+}
+// equality without leaving projective coordinates (no inversion)
+__device__ inline bool jac_eq_aff(const Jac& p, const Aff& a) {
+  if (a.inf || jac_is_inf(p)) return a.inf && jac_is_inf(p);
+  const U256 zz = fe_sqr(p.z);
+  return u256_eq(p.x, fe_mul(a.x, zz)) && u256_eq(p.y, fe_mul(a.y, fe_mul(zz, p.z)));
+}
+__device__ inline bool jac_eq(const Jac& p, const Jac& q) {
+  if (jac_is_inf(p) || jac_is_inf(q)) return jac_is_inf(p) && jac_is_inf(q);
+  const U256 z1z1 = fe_sqr(p.z), z2z2 = fe_sqr(q.z);
+  return u256_eq(fe_mul(p.x, z2z2), fe_mul(q.x, z1z1)) &&
+         u256_eq(fe_mul(p.y, fe_mul(z2z2, q.z)), fe_mul(q.y, fe_mul(z1z1, p.z)));
+}
 __device__ inline Aff jac_to_aff(const Jac& p) {
   Aff a;
   if (jac_is_inf(p)) { a.inf = true; a.x = u256_zero(); a.y = u256_zero(); return a; }
@@ -253,6 +313,40 @@ __device__ inline Jac jac_mul(const U256& k, const Aff& P) {
 }
 __device__ __forceinline__ Aff aff_gen() { Aff g; g.x = u256_load(GX); g.y = u256_load(GY); g.inf = false; return g; }
 __device__ __forceinline__ Aff aff_h2() { Aff g; g.x = u256_load(H2X); g.y = u256_load(H2Y); g.inf = false; return g; }
+// Comb tables of the two fixed generators: COMB[g][w][d-1] = d * 16^w * (g == 0 ? G : base_point2), affine x|y,
+// d = 1..15, w = 0..63 (123 KB, filled once per device by ec_comb_build_kernel when a context is created).
+// k*G is then 64 mixed additions and no doublings; the additions always run (digit 0 adds a dummy and
+// keeps the old accumulator), so the operation sequence does not depend on the scalar.
+__device__ uint32_t COMB[2][64][15][16];
+__global__ void ec_comb_build_kernel() {
+  const int w = threadIdx.x & 63, g = blockIdx.x;
+  if (g > 1) return;
+  Jac b = jac_from_aff(g ? aff_h2() : aff_gen());
+  for (int i = 0; i < 4 * w; ++i) b = jac_dbl(b);
+  const Aff ba = jac_to_aff(b);
+  Jac acc = jac_from_aff(ba);
+  for (int d = 1; d <= 15; ++d) {
+    const Aff a = jac_to_aff(acc);
+    for (int j = 0; j < 8; ++j) { COMB[g][w][d - 1][j] = a.x.w[j]; COMB[g][w][d - 1][8 + j] = a.y.w[j]; }
+    acc = jac_add_aff(acc, ba);
+  }
+}
+// k*G (g = 0) or k*base_point2 (g = 1), k already reduced mod q
+__device__ inline Jac jac_mul_fixed(const U256& k, int g) {
+  Jac acc = jac_inf();
+  for (int w = 0; w < 64; ++w) {
+    const uint32_t d = (k.w[w >> 3] >> ((w & 7) * 4)) & 15u;
+    const uint32_t* e = COMB[g][w][d ? d - 1 : 0];
+    Aff a; a.inf = false;
+    for (int j = 0; j < 8; ++j) { a.x.w[j] = e[j]; a.y.w[j] = e[8 + j]; }
+    const Jac sum = jac_add_aff(acc, a);
+    if (d) acc = sum;
+  }
+  return acc;
+}
+__device__ __forceinline__ Jac jac_mul_gen(const U256& k) { return jac_mul_fixed(k, 0); }
+__device__ __forceinline__ Jac jac_mul_h2(const U256& k) { return jac_mul_fixed(k, 1); }
+
 // interface layout: x[8] | y[8], all-zero = infinity
 __device__ __forceinline__ Aff aff_load(const uint32_t* p) {
   Aff a; a.x = u256_load(p); a.y = u256_load(p + 8); a.inf = u256_is_zero(a.x) && u256_is_zero(a.y); return a;

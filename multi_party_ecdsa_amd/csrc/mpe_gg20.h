@@ -131,10 +131,9 @@ __global__ void r0_kernel(Dim d, const int32_t* __restrict__ signers, const uint
   ec::u256_store(gq + (size_t)pi * 8, g);
   ec::u256_store(w + (size_t)pi * 8, wi);
   for (int j = 0; j < 64; ++j) k64[(size_t)pi * 64 + j] = j < 8 ? k.w[j] : 0u;
-  const ec::Aff G = ec::aff_gen();
-  const ec::Aff gg = mul_aff(g, G);
+  const ec::Aff gg = ec::jac_to_aff(ec::jac_mul_gen(g));
   ec::aff_store(g_gamma + (size_t)pi * 16, gg);
-  ec::aff_store(g_w + (size_t)pi * 16, mul_aff(wi, G));
+  ec::aff_store(g_w + (size_t)pi * 16, ec::jac_to_aff(ec::jac_mul_gen(wi)));
   ec::u256_store(com + (size_t)pi * 8, commit_point(gg, blind + (size_t)pi * 8));
 }
 
@@ -164,17 +163,16 @@ __global__ void r2a_kernel(Dim d, const int32_t* __restrict__ mbin_rv, const uin
   const int in = mbin_rv[rv];
   const ec::U256 al = ec::sc_reduce(alpha_full + (size_t)rv * 64, 64);
   ec::u256_store(alpha + (size_t)rv * 8, al);
-  const ec::Aff G = ec::aff_gen();
   const ec::Aff Bpk = ec::aff_load(m.pk + (size_t)in * 16), BTpk = ec::aff_load(m.tpk + (size_t)in * 16);
-  const ec::Aff g_alpha = mul_aff(al, G);
-  const ec::Aff ba_btag = add_aff(mul_aff(ec::u256_load(kq + (size_t)pi * 8), Bpk), BTpk);
-  bool good = ec::aff_eq(g_alpha, ba_btag);
+  const ec::Jac g_alpha = ec::jac_mul_gen(al);
+  const ec::Jac ba_btag = ec::jac_add_aff(ec::jac_mul(ec::u256_load(kq + (size_t)pi * 8), Bpk), BTpk);
+  bool good = ec::jac_eq(g_alpha, ba_btag);
   {  // DLogProof::verify x2
     const ec::Aff R1 = ec::aff_load(m.R + (size_t)in * 16), R2 = ec::aff_load(m.tR + (size_t)in * 16);
     const ec::U256 c1 = dlog_challenge(R1, Bpk), c2 = dlog_challenge(R2, BTpk);
-    const ec::Jac l1 = ec::jac_add(ec::jac_mul(ec::sc_reduce(m.z + (size_t)in * 8, 8), G), ec::jac_mul(c1, Bpk));
-    const ec::Jac l2 = ec::jac_add(ec::jac_mul(ec::sc_reduce(m.tz + (size_t)in * 8, 8), G), ec::jac_mul(c2, BTpk));
-    good = good && ec::aff_eq(ec::jac_to_aff(l1), R1) && ec::aff_eq(ec::jac_to_aff(l2), R2);
+    const ec::Jac l1 = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(m.z + (size_t)in * 8, 8)), ec::jac_mul(c1, Bpk));
+    const ec::Jac l2 = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(m.tz + (size_t)in * 8, 8)), ec::jac_mul(c2, BTpk));
+    good = good && ec::jac_eq_aff(l1, R1) && ec::jac_eq_aff(l2, R2);
   }
   if (v == 1) good = good && ec::aff_eq(Bpk, ec::aff_load(g_w + (size_t)(b * d.S + ind) * 16));   // rounds.rs:281
   ok[rv] = good ? 1 : 0;
@@ -202,9 +200,9 @@ __global__ void r2b_kernel(Dim d, const uint32_t* __restrict__ kq, const uint32_
   const ec::U256 l = ec::sc_reduce(l_in + (size_t)pi * 8, 8);
   ec::u256_store(lq + (size_t)pi * 8, l);
   const ec::Aff G = ec::aff_gen(), H = ec::aff_h2();
-  const ec::Aff T = add_aff(mul_aff(si, G), mul_aff(l, H));
+  const ec::Aff T = ec::jac_to_aff(ec::jac_add(ec::jac_mul_gen(si), ec::jac_mul_h2(l)));
   const ec::U256 s1 = ec::sc_reduce(s1_in + (size_t)pi * 8, 8), s2 = ec::sc_reduce(s2_in + (size_t)pi * 8, 8);
-  const ec::Aff a1 = mul_aff(s1, G), a2 = mul_aff(s2, H);
+  const ec::Aff a1 = ec::jac_to_aff(ec::jac_mul_gen(s1)), a2 = ec::jac_to_aff(ec::jac_mul_h2(s2));
   const ec::Aff hp[5] = {G, H, T, a1, a2};
   const ec::U256 e = hash_points(hp);
   ec::aff_store(p.T + (size_t)pi * 16, T);
@@ -228,9 +226,9 @@ __global__ void r3_kernel(Dim d, const uint32_t* __restrict__ delta_i, Ped p, ui
     const ec::Aff T = ec::aff_load(p.T + o * 16), a1 = ec::aff_load(p.a1 + o * 16), a2 = ec::aff_load(p.a2 + o * 16);
     const ec::Aff hp[5] = {G, H, T, a1, a2};
     const ec::U256 e = hash_points(hp);
-    const ec::Jac lhs = ec::jac_add(ec::jac_mul(ec::u256_load(p.z1 + o * 8), G), ec::jac_mul(ec::u256_load(p.z2 + o * 8), H));
-    const ec::Jac rhs = ec::jac_add(ec::jac_add(ec::jac_from_aff(a1), ec::jac_from_aff(a2)), ec::jac_mul(e, T));
-    good = good && ec::aff_eq(ec::jac_to_aff(lhs), ec::jac_to_aff(rhs));
+    const ec::Jac lhs = ec::jac_add(ec::jac_mul_gen(ec::u256_load(p.z1 + o * 8)), ec::jac_mul_h2(ec::u256_load(p.z2 + o * 8)));
+    const ec::Jac rhs = ec::jac_add_aff(ec::jac_add_aff(ec::jac_mul(e, T), a1), a2);
+    good = good && ec::jac_eq(lhs, rhs);
   }
   good = good && !ec::u256_is_zero(sum);
   ec::u256_store(dinv + (size_t)pi * 8, ec::sc_inv(sum));
@@ -278,12 +276,12 @@ __global__ void r5_kernel(Dim d, const uint8_t* __restrict__ pdl_ok, const uint3
   const ec::Aff G = ec::aff_gen(), H = ec::aff_h2();
   ec::Jac acc = ec::jac_inf();
   for (int j = 0; j < d.S; ++j) acc = ec::jac_add(acc, ec::jac_from_aff(ec::aff_load(Rbar + ((size_t)b * d.S + j) * 16)));
-  good = good && ec::aff_eq(ec::jac_to_aff(acc), G);                                     // phase5_check_R_dash_sum
+  good = good && ec::jac_eq_aff(acc, G);                                                 // phase5_check_R_dash_sum
   const ec::Aff Rp = ec::aff_load(R + (size_t)pi * 16), T = ec::aff_load(pedT + (size_t)pi * 16);
   const ec::U256 si = ec::u256_load(sigma_i + (size_t)pi * 8), l = ec::u256_load(lq + (size_t)pi * 8);
   const ec::Aff Sp = mul_aff(si, Rp);
   const ec::U256 s1 = ec::sc_reduce(s1_in + (size_t)pi * 8, 8), s2 = ec::sc_reduce(s2_in + (size_t)pi * 8, 8);
-  const ec::Aff A1 = mul_aff(s1, H), A2 = mul_aff(s2, G), A3 = mul_aff(s2, Rp), TT = add_aff(A1, A2);
+  const ec::Aff A3 = mul_aff(s2, Rp), TT = ec::jac_to_aff(ec::jac_add(ec::jac_mul_h2(s1), ec::jac_mul_gen(s2)));
   const ec::Aff hp[7] = {TT, A3, Rp, H, G, T, Sp};
   const ec::U256 e = hash_points(hp);
   ec::aff_store(h.S + (size_t)pi * 16, Sp);
@@ -309,14 +307,14 @@ __global__ void r6_kernel(Dim d, const uint32_t* __restrict__ R, const uint32_t*
                   E = ec::aff_load(h.S + o * 16);
     const ec::Aff hp[7] = {TT, A3, Rp, H, G, D, E};
     const ec::U256 e = hash_points(hp), z1 = ec::u256_load(h.z1 + o * 8), z2 = ec::u256_load(h.z2 + o * 8);
-    const ec::Jac l1 = ec::jac_add(ec::jac_mul(z1, H), ec::jac_mul(z2, G));
-    const ec::Jac r1 = ec::jac_add(ec::jac_from_aff(TT), ec::jac_mul(e, D));
+    const ec::Jac l1 = ec::jac_add(ec::jac_mul_h2(z1), ec::jac_mul_gen(z2));
+    const ec::Jac r1 = ec::jac_add_aff(ec::jac_mul(e, D), TT);
     const ec::Jac l2 = ec::jac_mul(z2, Rp);
-    const ec::Jac r2 = ec::jac_add(ec::jac_from_aff(A3), ec::jac_mul(e, E));
-    good = good && ec::aff_eq(ec::jac_to_aff(l1), ec::jac_to_aff(r1)) && ec::aff_eq(ec::jac_to_aff(l2), ec::jac_to_aff(r2));
-    acc = ec::jac_add(acc, ec::jac_from_aff(E));
+    const ec::Jac r2 = ec::jac_add_aff(ec::jac_mul(e, E), A3);
+    good = good && ec::jac_eq(l1, r1) && ec::jac_eq(l2, r2);
+    acc = ec::jac_add_aff(acc, E);
   }
-  good = good && ec::aff_eq(ec::jac_to_aff(acc), ec::aff_load(y));
+  good = good && ec::jac_eq_aff(acc, ec::aff_load(y));
   ok[pi] = good ? 1 : 0;
 }
 
@@ -356,7 +354,7 @@ __global__ void r7_kernel(Dim d, Flags f, const uint32_t* __restrict__ msg, cons
   bool okv = !ec::u256_is_zero(s);
   if (okv) {
     const ec::U256 bi = ec::sc_inv(s), u1 = ec::sc_mul(m, bi), u2 = ec::sc_mul(r, bi);
-    const ec::Aff V = ec::jac_to_aff(ec::jac_add(ec::jac_mul(u1, ec::aff_gen()), ec::jac_mul(u2, ec::aff_load(y))));
+    const ec::Aff V = ec::jac_to_aff(ec::jac_add(ec::jac_mul_gen(u1), ec::jac_mul(u2, ec::aff_load(y))));
     okv = !V.inf && ec::u256_eq(ec::sc_reduce(V.x.w, 8), r);
   }
   if (!okv && !st) st = 701;

@@ -1,5 +1,6 @@
 // libmpecdsa_hip.so — C-ABI (include/mpecdsa_hip.h) over the gfx950 kernels.  Single translation unit.
 #include "mpe_internal.h"
+#include "mpe_ec.h"
 
 using namespace mpe;
 
@@ -187,6 +188,10 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   if (getenv("MPE_NO_FIXED_BASE")) c->use_fixed_base = false;     // A/B switches for measurements
   if (getenv("MPE_NO_CRT")) c->use_crt = false;
   if (getenv("MPE_WINDOW_BITS")) { const int w = atoi(getenv("MPE_WINDOW_BITS")); if (w >= 4 && w <= 6) c->window_bits = w; }
+  // comb tables of the two fixed secp256k1 generators (module globals of this device; identical on every call)
+  hipLaunchKernelGGL(mpe::ec::ec_comb_build_kernel, dim3(2), dim3(64), 0, 0);
+  e = hipDeviceSynchronize();
+  if (e != hipSuccess) { mpe_set_error("ec_comb_build_kernel", e); delete c; return MPE_E_HIP; }
   *out = c;
   return MPE_OK;
 }

@@ -44,16 +44,15 @@ __global__ void mta_alpha_kernel(int B, const uint32_t* __restrict__ share, cons
   if (i >= B) return;
   const ec::U256 al = ec::sc_reduce(share + (size_t)i * 64, 64);
   ec::u256_store(alpha + (size_t)i * 8, al);
-  const ec::Aff G = ec::aff_gen();
   const ec::Aff Bpk = ec::aff_load(pk + (size_t)i * 16), BTpk = ec::aff_load(tpk + (size_t)i * 16);
   const ec::Aff R1 = ec::aff_load(R + (size_t)i * 16), R2 = ec::aff_load(tR + (size_t)i * 16);
-  const ec::Aff g_alpha = ec::jac_to_aff(ec::jac_mul(al, G));
-  const ec::Jac bb = ec::jac_add(ec::jac_mul(ec::sc_reduce(a + (size_t)i * 8, 8), Bpk), ec::jac_from_aff(BTpk));
-  bool good = ec::aff_eq(g_alpha, ec::jac_to_aff(bb));
+  const ec::Jac g_alpha = ec::jac_mul_gen(al);
+  const ec::Jac bb = ec::jac_add_aff(ec::jac_mul(ec::sc_reduce(a + (size_t)i * 8, 8), Bpk), BTpk);
+  bool good = ec::jac_eq(g_alpha, bb);
   const ec::U256 c1 = dlog_challenge(R1, Bpk), c2 = dlog_challenge(R2, BTpk);
-  const ec::Jac l1 = ec::jac_add(ec::jac_mul(ec::sc_reduce(z + (size_t)i * 8, 8), G), ec::jac_mul(c1, Bpk));
-  const ec::Jac l2 = ec::jac_add(ec::jac_mul(ec::sc_reduce(tz + (size_t)i * 8, 8), G), ec::jac_mul(c2, BTpk));
-  good = good && ec::aff_eq(ec::jac_to_aff(l1), R1) && ec::aff_eq(ec::jac_to_aff(l2), R2);
+  const ec::Jac l1 = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(z + (size_t)i * 8, 8)), ec::jac_mul(c1, Bpk));
+  const ec::Jac l2 = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(tz + (size_t)i * 8, 8)), ec::jac_mul(c2, BTpk));
+  good = good && ec::jac_eq_aff(l1, R1) && ec::jac_eq_aff(l2, R2);
   ok[i] = good ? 1 : 0;
 }
 

@@ -50,8 +50,8 @@ __global__ void ec_mul_kernel(int B, const uint32_t* __restrict__ k, int kw, con
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::U256 s = ec::sc_reduce(k + (size_t)i * kw, kw);
-  const ec::Aff p = P ? ec::aff_load(P + (size_t)i * 16) : ec::aff_gen();
-  ec::aff_store(out + (size_t)i * 16, ec::jac_to_aff(ec::jac_mul(s, p)));
+  const ec::Jac r = P ? ec::jac_mul(s, ec::aff_load(P + (size_t)i * 16)) : ec::jac_mul_gen(s);
+  ec::aff_store(out + (size_t)i * 16, ec::jac_to_aff(r));
 }
 __global__ void ec_add_kernel(int B, const uint32_t* __restrict__ P, const uint32_t* __restrict__ Q,
                               uint32_t* __restrict__ out) {
@@ -77,8 +77,7 @@ __global__ void dlog_prove_kernel(int B, const uint32_t* __restrict__ sk, const 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::U256 s = ec::sc_reduce(sk + (size_t)i * 8, 8), k = ec::sc_reduce(nonce + (size_t)i * 8, 8);
-  const ec::Aff g = ec::aff_gen();
-  const ec::Aff Rp = ec::jac_to_aff(ec::jac_mul(k, g)), P = ec::jac_to_aff(ec::jac_mul(s, g));
+  const ec::Aff Rp = ec::jac_to_aff(ec::jac_mul_gen(k)), P = ec::jac_to_aff(ec::jac_mul_gen(s));
   const ec::U256 c = dlog_challenge(Rp, P);
   ec::aff_store(pk + (size_t)i * 16, P);
   ec::aff_store(R + (size_t)i * 16, Rp);
@@ -90,8 +89,8 @@ __global__ void dlog_verify_kernel(int B, const uint32_t* __restrict__ pk, const
   if (i >= B) return;
   const ec::Aff P = ec::aff_load(pk + (size_t)i * 16), Rp = ec::aff_load(R + (size_t)i * 16);
   const ec::U256 c = dlog_challenge(Rp, P), zz = ec::sc_reduce(z + (size_t)i * 8, 8);
-  const ec::Jac l = ec::jac_add(ec::jac_mul(zz, ec::aff_gen()), ec::jac_mul(c, P));
-  ok[i] = ec::aff_eq(ec::jac_to_aff(l), Rp) ? 1 : 0;
+  const ec::Jac l = ec::jac_add(ec::jac_mul_gen(zz), ec::jac_mul(c, P));
+  ok[i] = ec::jac_eq_aff(l, Rp) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -172,15 +171,15 @@ __global__ void pdl_u1_check_kernel(int B, Rows s1, const uint32_t* __restrict__
   const ec::U256 a = ec::sc_reduce(row_of(s1, i), 25);
   const ec::U256 ne = ec::sc_neg(ec::sc_reduce(e + (size_t)i * 8, 8));
   const ec::Jac l = ec::jac_add(ec::jac_mul(a, ec::aff_load(row_of(G, i))), ec::jac_mul(ne, ec::aff_load(row_of(Q, i))));
-  if (!ec::aff_eq(ec::jac_to_aff(l), ec::aff_load(row_of(u1, i)))) ok[i] = 0;
+  if (!ec::jac_eq_aff(l, ec::aff_load(row_of(u1, i)))) ok[i] = 0;
 }
 // out = (k mod q) * P with per-item rows (P.p == nullptr -> generator)
 __global__ void ec_mul_rows_kernel(int B, Rows k, int kw, Rows P, uint32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::U256 s = ec::sc_reduce(row_of(k, i), kw);
-  const ec::Aff p = P.p ? ec::aff_load(row_of(P, i)) : ec::aff_gen();
-  ec::aff_store(out + (size_t)i * 16, ec::jac_to_aff(ec::jac_mul(s, p)));
+  const ec::Jac r = P.p ? ec::jac_mul(s, ec::aff_load(row_of(P, i))) : ec::jac_mul_gen(s);
+  ec::aff_store(out + (size_t)i * 16, ec::jac_to_aff(r));
 }
 
 // ---------------------------------------------------------------------------------------------
