@@ -64,11 +64,17 @@ int mpe_modset_bits(const mpe_modset* ms);
  *  d_base    : [batch][bits/32], any value < 2^bits (need not be reduced).
  *  d_exp     : [batch][exp_words] little-endian words, exponent >= 0.
  *  d_out     : [batch][bits/32], canonical residue in [0, n).
- * Fixed 4-bit windows, constant sequence of operations for a given exp_words (exponents on this
- * path are secret nonces). */
+ * Fixed windows (4/5/6 bits by exponent length), constant sequence of operations for a given exp_words
+ * (exponents on this path are secret nonces). */
 int mpe_modexp(mpe_ctx* ctx, const mpe_modset* ms, int batch, const int32_t* d_mod_idx,
                const uint32_t* d_base, const uint32_t* d_exp, int exp_words, uint32_t* d_out,
                void* stream);
+/* out[i] = base[i]^exp[i] * base2[i]^exp2[i] mod modulus[idx(i)]: the `mod_pow(..) * mod_pow(..) % n` pattern of
+ * the verifiers (range_proofs.rs:134-141, zk_pdl_with_slack/mod.rs:144-157) on ONE ladder — the squarings are
+ * shared, the residue is the same.  exp2 must be the short one: 32*exp2_words < 32*exp_words - 6. */
+int mpe_modexp2(mpe_ctx* ctx, const mpe_modset* ms, int batch, const int32_t* d_mod_idx,
+                const uint32_t* d_base, const uint32_t* d_exp, int exp_words,
+                const uint32_t* d_base2, const uint32_t* d_exp2, int exp2_words, uint32_t* d_out, void* stream);
 
 /* out[i] = a[i] * b[i] mod modulus[idx(i)]   (curv `BigInt::mod_mul`,
  * src/utilities/zk_pdl_with_slack/mod.rs:198; also Paillier::add = mulmod N^2, mta/mod.rs:145) */
@@ -266,7 +272,7 @@ int mpe_last_launch_info(const mpe_ctx* ctx, mpe_launch_info* out);
 
 /* Per-launch timing of the heavy kernels with HIP events recorded on the launch stream (used by
  * bench.py for the roofline line).  kind: 0 = modexp kernel, 1 = modmul kernel. */
-typedef struct { int kind; int bits; int exp_words; int batch; float ms; } mpe_prof_rec;
+typedef struct { int kind; int bits; int exp_words; int batch; float ms; int exp2_words; } mpe_prof_rec;  /* exp2_words != 0: mpe_modexp2-style launch */
 int mpe_prof_enable(mpe_ctx* ctx, int on);       /* clears earlier records */
 int mpe_prof_collect(mpe_ctx* ctx, mpe_prof_rec* out, int max_records, int* n_out);  /* waits for the events */
 

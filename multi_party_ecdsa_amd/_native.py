@@ -22,7 +22,7 @@ class LaunchInfo(C.Structure):
 
 
 class ProfRec(C.Structure):
-    _fields_ = [("kind", C.c_int), ("bits", C.c_int), ("exp_words", C.c_int), ("batch", C.c_int), ("ms", C.c_float)]
+    _fields_ = [("kind", C.c_int), ("bits", C.c_int), ("exp_words", C.c_int), ("batch", C.c_int), ("ms", C.c_float), ("exp2_words", C.c_int)]
 
 
 def _ptr_struct(name, fields):
@@ -62,6 +62,7 @@ def _load():
         "mpe_modset_count": (ip, [vp]),
         "mpe_modset_bits": (ip, [vp]),
         "mpe_modexp": (ip, [vp, vp, ip, i32p, u32p, u32p, ip, u32p, vp]),
+        "mpe_modexp2": (ip, [vp, vp, ip, i32p, u32p, u32p, ip, u32p, u32p, ip, u32p, vp]),
         "mpe_modmul": (ip, [vp, vp, ip, i32p, u32p, u32p, u32p, vp]),
         "mpe_last_launch_info": (ip, [vp, C.POINTER(LaunchInfo)]),
         "mpe_modinv": (ip, [vp, vp, ip, i32p, u32p, u32p, vp, vp]),
@@ -113,7 +114,7 @@ lib = _load()
 # every symbol include/mpecdsa_hip.h declares; tests check the library exports all of them
 EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy", "mpe_sync",
             "mpe_modset_create", "mpe_modset_destroy", "mpe_modset_count", "mpe_modset_bits",
-            "mpe_modexp", "mpe_modmul", "mpe_last_launch_info", "mpe_paillier_create_public",
+            "mpe_modexp", "mpe_modexp2", "mpe_modmul", "mpe_last_launch_info", "mpe_paillier_create_public",
             "mpe_paillier_create_private", "mpe_paillier_destroy", "mpe_paillier_nkeys", "mpe_paillier_n",
             "mpe_paillier_encrypt", "mpe_paillier_decrypt", "mpe_paillier_add", "mpe_paillier_mul",
             "mpe_prof_enable", "mpe_prof_collect", "mpe_modinv", "mpe_ec_mul_base", "mpe_ec_mul", "mpe_ec_add",

@@ -452,21 +452,15 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
     q.rc = alice_verify(ctx, K->pk, K->stm, (int)nVI, ix.key_vi, ix.st_vi, rows(c_a, 128, ix.pia_vi), pr, ok_vi, st);
   }
   gg_trace(st, "alice_verify", q.rc);
-  uint32_t *bsel = OW(nMB * 8), *btq = OW(nMB * 8), *beta = OW(nMB * 8), *c_bt = OW(nMB * 128), *bca = OW(nMB * 128),
+  uint32_t *bsel = OW(nMB * 8), *btq = OW(nMB * 8), *beta = OW(nMB * 8),
            *c_b = OW(nMB * 128);
   uint32_t *Bpk = OW(nMB * 16), *BR = OW(nMB * 16), *Bz = OW(nMB * 8), *BTpk = OW(nMB * 16), *BTR = OW(nMB * 16), *BTz = OW(nMB * 8);
   const uint32_t *z_bt = Z->mb_beta_tag + oMB * 64, *z_mr = Z->mb_r + oMB * 64, *z_nb = Z->mb_nonce_b + oMB * 8,
                  *z_nbt = Z->mb_nonce_bt + oMB * 8;
   GG_LAUNCH(mb_prep_kernel, nMB, d, gq, w, z_bt, bsel, btq, beta);
-  if (q.rc == MPE_OK) q.rc = paillier_encrypt(ctx, K->pk, (int)nMB, ix.key_mb, z_bt, z_mr, c_bt, false, st);          // :133-137
-  gg_trace(st, "encrypt beta_tag", q.rc);
-  if (q.rc == MPE_OK)                                                                                          // Paillier::mul :140-144
-    q.rc = launch_modexp(ctx, K->pk->ms_nn, (int)nMB, Rows{nullptr, ix.key_mb, 0, 0}, rows(c_a, 128, ix.pia_mb), no_rows(),
-                         rows(bsel, 8), 8, bca, st);
-  gg_trace(st, "paillier mul", q.rc);
-  if (q.rc == MPE_OK)                                                                                          // Paillier::add :145
-    q.rc = launch_modmul(ctx, K->pk->ms_nn, (int)nMB, Rows{nullptr, ix.key_mb, 0, 0}, rows(bca, 128), rows(c_bt, 128), c_b, st);
-  gg_trace(st, "paillier add", q.rc);
+  if (q.rc == MPE_OK)                                                           // encrypt, Paillier::mul, Paillier::add :133-145
+    q.rc = paillier_mul_add_enc(ctx, K->pk, (int)nMB, ix.key_mb, rows(c_a, 128, ix.pia_mb), rows(bsel, 8), 8, z_bt, z_mr, c_b, st);
+  gg_trace(st, "MessageB ciphertext", q.rc);
   GG_LAUNCH(dlog_prove_kernel, nMB, (int)nMB, bsel, z_nb, Bpk, BR, Bz);                                       // :147
   GG_LAUNCH(dlog_prove_kernel, nMB, (int)nMB, btq, z_nbt, BTpk, BTR, BTz);                                    // :148
 

@@ -13,6 +13,7 @@ struct mpe_ctx {
   int device = 0;
   int cus = 256;
   int window_bits = 0;            // 0 = choose per exponent length (4/5/6); 4..6 = force (A/B runs)
+  bool use_multiexp = true;       // verifiers: s^N * (c^-1)^e on one ladder instead of two exponentiations (same residue)
   bool use_crt = true;            // key holders compute x^e mod N^2 through p^2 | q^2 (mpe_paillier.h modexp_nn)
   bool use_fixed_base = true;     // h1/h2 exponentiations through per-statement window tables (mpe_fixedbase.h)
   int modexp_waves_per_cu = 8;    // 2 waves/SIMD: the montmul loop holds ~230 VGPRs and already issues back-to-back
@@ -24,7 +25,7 @@ struct mpe_ctx {
   mpe_launch_info last = {};
   // optional per-launch timing of the heavy kernels (HIP events on the launch stream)
   bool prof_on = false;
-  struct ProfEvt { hipEvent_t a, b; int kind, bits, exp_words, batch; };
+  struct ProfEvt { hipEvent_t a, b; int kind, bits, exp_words, batch, exp2_words; };
   std::vector<ProfEvt> prof;
 };
 
@@ -55,6 +56,9 @@ inline Rows no_rows() { return Rows{nullptr, nullptr, 0, 0}; }
 // mod_sel: idx != null -> idx[i];  stride != 0 -> i;  else modulus 0
 int launch_modexp(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows base_lo, Rows base_hi, Rows exps,
                   int exp_words, uint32_t* out, hipStream_t st);
+// base^exps * base2^exps2 on one ladder (shared squarings); exps2 short (32 exp2_words < 32 exp_words)
+int launch_modexp2(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
+                   Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st);
 int launch_modmul(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows a, Rows b, uint32_t* out,
                   hipStream_t st);
 int modset_create_dev(mpe_ctx* ctx, int bits, int count, const uint32_t* d_moduli, mpe_modset** out, hipStream_t st);

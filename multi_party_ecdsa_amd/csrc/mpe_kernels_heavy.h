@@ -211,31 +211,41 @@ __device__ __forceinline__ uint32_t exp_window(const uint32_t* __restrict__ ex, 
 
 // ---------------------------------------------------------------------------------------------
 // modexp kernel: persistent waves, each group walks the batch with a grid stride.
-//   out[i] = (base_lo[i] + 2^BITS * base_hi[i]) ^ exp[i]  mod  modulus[mod(i)]
-// base_hi.p == nullptr -> single-width base.  Fixed wb-bit windows, constant operation sequence.
+//   out[i] = (base_lo[i] + 2^BITS * base_hi[i]) ^ exp[i]  [ * base2[i] ^ exp2[i] ]   mod  modulus[mod(i)]
+// base_hi.p == nullptr -> single-width base.  base2.p != nullptr -> the product of two powers on one ladder
+// (the squarings are shared; exp2 is short: 4-bit windows, 32 exp2_words <= (nwin-1) wb).
+// Fixed windows, constant operation sequence: it depends on the exponent LENGTHS only.
 // ---------------------------------------------------------------------------------------------
+enum ModexpPhase { PH_WIDE, PH_MONT1, PH_TAB1, PH_MONT2, PH_TAB2, PH_SQ, PH_MUL1, PH_MUL2, PH_FINAL, PH_DONE };
+
 template <class C>
 __global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Rows mod_sel, Rows base_lo, Rows base_hi,
-                                                    Rows exps, int exp_words, int wb, uint32_t* __restrict__ out,
+                                                    Rows exps, int exp_words, int wb, Rows base2, Rows exps2,
+                                                    int exp2_words, uint32_t* __restrict__ out,
                                                     uint32_t* __restrict__ tables) {
   __shared__ uint32_t lds[C::LDS_WORDS];
   const Lane ln = make_lane<C>();
   uint32_t* gl = lds + ln.g * C::STRIDE;
   const int slot = blockIdx.x * C::GROUPS + ln.g;
   const int nslots = gridDim.x * C::GROUPS;
+  const bool wide = base_hi.p != nullptr, dual = base2.p != nullptr;
   const int TE = 1 << wb;                                // window width wb in {4,5,6}: 2^wb table entries
-  uint32_t* tab = tables + (size_t)slot * TE * C::K;     // this group's window table
+  // this group's window tables: tab[0..TE-1] = Mont(base^d); tab2[1..15] = Mont(base2^d) (digit 0 uses tab[0] = Mont(1))
+  uint32_t* tab = tables + (size_t)slot * (TE + (dual ? 16 : 0)) * C::K;
+  uint32_t* tab2 = tab + (size_t)TE * C::K;
   const int trips = (batch + nslots - 1) / nslots;
   const int nwin = (exp_words * 32 + wb - 1) / wb;
-  const bool wide = base_hi.p != nullptr;
-  // One Montgomery multiplication per step; the step index alone (wave-uniform) decides where the
-  // multiplier comes from and where the product goes, so montmul is instantiated exactly once:
-  //   step -1 (wide)    : hi * (2^BITS R^2)           -> Mont(2^BITS hi), kept aside
-  //   step 0            : cur = base * R^2 (+ aside)  -> Mont(base) = tab[1]
-  //   step 1..TE-2      : cur = cur * Mont(base)      -> tab[2..TE-1]
-  //   then per window   : wb squarings, 1 multiplication by tab[window]
-  //   last step         : cur = cur * 1               -> leaves the Montgomery domain
-  const int nsteps = (TE - 1) + (wb + 1) * (nwin - 1) + 1;
+  const int nwin2 = dual ? exp2_words * 8 : 0;
+  const int top_bit = (nwin - 1) * wb;                   // the ladder squares top_bit times
+  // One Montgomery multiplication per step; the phase (wave-uniform) decides where the multiplier comes from
+  // and where the product goes, so montmul is instantiated exactly once:
+  //   PH_WIDE            : hi * (2^BITS R^2)           -> Mont(2^BITS hi), kept aside (in the table slab)
+  //   PH_MONT1           : cur = base * R^2 (+ aside)  -> Mont(base) = tab[1]
+  //   PH_TAB1 k=1..TE-2  : cur = cur * Mont(base)      -> tab[k+1]
+  //   PH_MONT2 / PH_TAB2 : the same for base2          -> tab2[1..15]
+  //   ladder             : PH_SQ per bit; PH_MUL1 by tab[window] where a window of exp starts, PH_MUL2 by
+  //                        tab2[window] where a 4-bit window of exp2 starts
+  //   PH_FINAL           : cur = cur * 1               -> leaves the Montgomery domain
 
 #pragma unroll 1
   for (int trip = 0; trip < trips; ++trip) {
@@ -244,14 +254,13 @@ __global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Ro
     const int idx = active ? inst : batch - 1;
     const int mi = sel_index(mod_sel, idx);
     const uint32_t* ex = row_of(exps, idx);
+    const uint32_t* ex2 = dual ? row_of(exps2, idx) : ex;
 
     uint32_t n[C::L];
     load_owner<C>(n, ms.n_limbs + (size_t)mi * C::K, ln);
     const uint32_t n0inv = ms.n0inv[mi];
 
-    uint32_t cur[C::L], aside[C::L];
-#pragma unroll
-    for (int i = 0; i < C::L; ++i) aside[i] = 0;
+    uint32_t cur[C::L];
     load_words_as_limbs<C>(cur, gl, wide ? row_of(base_hi, idx) : row_of(base_lo, idx),
                            wide ? base_hi.words : base_lo.words, ln);
     {
@@ -260,25 +269,28 @@ __global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Ro
       store_owner<C>(tab, one, ln);                         // tab[0] = Mont(1)
     }
 
+    int ph = wide ? PH_WIDE : PH_MONT1;
+    int k = 0;                                              // position inside a table phase
+    int b = top_bit;                                        // the ladder has consumed the exponent bits >= b
 #pragma unroll 1
-    for (int step = wide ? -1 : 0; step < nsteps; ++step) {
+    while (ph != PH_DONE) {
       // ---- multiplier -> LDS ----
-      if (step == -1) {
+      if (ph == PH_WIDE) {
         copy_to_lds<C>(gl, ms.r2h_limbs + (size_t)mi * C::K, ln);
-      } else if (step == 0) {
+      } else if (ph == PH_MONT1 || ph == PH_MONT2) {
         copy_to_lds<C>(gl, ms.r2_limbs + (size_t)mi * C::K, ln);
-      } else if (step == 1) {
-        put_limbs<C>(gl, cur, ln);                          // Mont(base) stays in LDS for steps 1..14
-      } else if (step >= TE - 1 && step < nsteps - 1) {
-        const int k = step - (TE - 1);
-        const int wi = nwin - 2 - k / (wb + 1);
-        if (k % (wb + 1) == wb) {
-          const uint32_t w = exp_window(ex, exp_words, wi, wb);
-          copy_to_lds<C>(gl, tab + (size_t)w * C::K, ln);
-        } else {
-          put_limbs<C>(gl, cur, ln);                        // squaring
-        }
-      } else if (step == nsteps - 1) {
+      } else if (ph == PH_TAB1 || ph == PH_TAB2) {
+        if (k == 1) put_limbs<C>(gl, cur, ln);              // Mont(base) stays in LDS for the whole table phase
+      } else if (ph == PH_SQ) {
+        put_limbs<C>(gl, cur, ln);
+      } else if (ph == PH_MUL1) {
+        const uint32_t w = exp_window(ex, exp_words, b / wb, wb);
+        copy_to_lds<C>(gl, tab + (size_t)w * C::K, ln);
+      } else if (ph == PH_MUL2) {
+        const int wi = b >> 2;
+        const uint32_t w = (ex2[wi >> 3] >> ((wi & 7) * 4)) & 15u;
+        copy_to_lds<C>(gl, w ? tab2 + (size_t)w * C::K : tab, ln);
+      } else {                                              // PH_FINAL
 #pragma unroll
         for (int i = 0; i < C::L; ++i) gl[ln.t * C::L + i] = (ln.t == 0 && i == 0) ? 1u : 0u;
       }
@@ -288,28 +300,62 @@ __global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Ro
       wave_lds_sync();
 #pragma unroll
       for (int i = 0; i < C::L; ++i) cur[i] = r[i];
-      if (step == -1) {
-#pragma unroll
-        for (int i = 0; i < C::L; ++i) aside[i] = cur[i];
+
+      // ---- product -> its place; next phase ----
+      bool tables_done = false;
+      if (ph == PH_WIDE) {
+        store_owner<C>(tab + 2 * C::K, cur, ln);            // kept aside in the (still empty) table slab, not in registers
         load_words_as_limbs<C>(cur, gl, row_of(base_lo, idx), base_lo.words, ln);
-      } else if (step == 0 && wide) {
-        // Mont(lo) + Mont(2^BITS hi): value < 4n, settle the limbs exactly before it is squared
-        int64_t z[C::L];
-#pragma unroll
-        for (int i = 0; i < C::L; ++i) z[i] = (int64_t)cur[i] + (int64_t)aside[i];
-        full_normalize<C>(z, ln);
-#pragma unroll
-        for (int i = 0; i < C::L; ++i) cur[i] = (uint32_t)z[i];
-      }
-      // ---- product -> window table ----
-      if (step >= 0 && step < TE - 1) {
-        store_owner<C>(tab + (size_t)(step + 1) * C::K, cur, ln);
-        if (step == TE - 2) {
-          // table complete: start the ladder from the top window
+        ph = PH_MONT1;
+      } else if (ph == PH_MONT1) {
+        if (wide) {
+          // Mont(lo) + Mont(2^BITS hi): value < 4n, settle the limbs exactly before it is squared
+          uint32_t aside[C::L];
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          const uint32_t w = exp_window(ex, exp_words, nwin - 1, wb);
-          load_owner<C>(cur, tab + (size_t)w * C::K, ln);
+          load_owner<C>(aside, tab + 2 * C::K, ln);
+          int64_t z[C::L];
+#pragma unroll
+          for (int i = 0; i < C::L; ++i) z[i] = (int64_t)cur[i] + (int64_t)aside[i];
+          full_normalize<C>(z, ln);
+#pragma unroll
+          for (int i = 0; i < C::L; ++i) cur[i] = (uint32_t)z[i];
         }
+        store_owner<C>(tab + C::K, cur, ln);
+        k = 1;
+        ph = PH_TAB1;                                       // TE >= 16: at least tab[2..] to fill
+      } else if (ph == PH_TAB1) {
+        store_owner<C>(tab + (size_t)(k + 1) * C::K, cur, ln);
+        if (++k > TE - 2) {
+          if (dual) {
+            load_words_as_limbs<C>(cur, gl, row_of(base2, idx), base2.words, ln);
+            ph = PH_MONT2;
+          } else {
+            tables_done = true;
+          }
+        }
+      } else if (ph == PH_MONT2) {
+        store_owner<C>(tab2 + C::K, cur, ln);
+        k = 1;
+        ph = PH_TAB2;
+      } else if (ph == PH_TAB2) {
+        store_owner<C>(tab2 + (size_t)(k + 1) * C::K, cur, ln);
+        if (++k > 14) tables_done = true;
+      } else if (ph == PH_FINAL) {
+        ph = PH_DONE;
+      } else {
+        // ladder: after a squaring the position moves down one bit; multiplications leave it in place
+        if (ph == PH_SQ) --b;
+        const bool m1 = ph == PH_SQ && (b % wb) == 0;
+        const bool m2 = ph != PH_MUL2 && dual && (b & 3) == 0 && (b >> 2) < nwin2;
+        ph = m1 ? PH_MUL1 : (m2 ? PH_MUL2 : (b == 0 ? PH_FINAL : PH_SQ));
+      }
+      if (tables_done) {
+        // tables complete: start the ladder from the top window of the long exponent
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const uint32_t w = exp_window(ex, exp_words, nwin - 1, wb);
+        load_owner<C>(cur, tab + (size_t)w * C::K, ln);
+        b = top_bit;
+        ph = b == 0 ? PH_FINAL : PH_SQ;
       }
     }
     // canonical residue -> interface words

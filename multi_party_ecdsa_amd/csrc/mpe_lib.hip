@@ -30,10 +30,10 @@ void* ws_alloc(mpe_ctx* ctx, size_t bytes) {
   return (char*)ctx->ws + off;
 }
 
-static void prof_begin(mpe_ctx* ctx, hipStream_t st, int kind, int bits, int exp_words, int batch) {
+static void prof_begin(mpe_ctx* ctx, hipStream_t st, int kind, int bits, int exp_words, int batch, int exp2_words = 0) {
   if (!ctx->prof_on) return;
   mpe_ctx::ProfEvt ev;
-  ev.kind = kind; ev.bits = bits; ev.exp_words = exp_words; ev.batch = batch;
+  ev.kind = kind; ev.bits = bits; ev.exp_words = exp_words; ev.batch = batch; ev.exp2_words = exp2_words;
   (void)hipEventCreate(&ev.a);
   (void)hipEventCreate(&ev.b);
   (void)hipEventRecord(ev.a, st);
@@ -101,21 +101,26 @@ int modset_create_dev(mpe_ctx* ctx, int bits, int count, const uint32_t* d_modul
 
 template <class C>
 static int modexp_impl(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows base_lo, Rows base_hi, Rows exps,
-                       int exp_words, uint32_t* d_out, hipStream_t st) {
+                       int exp_words, Rows base2, Rows exps2, int exp2_words, uint32_t* d_out, hipStream_t st) {
   const int grid = grid_for<C>(ctx, batch, ctx->modexp_waves_per_cu);
   // window width: multiplications = E + E/wb + 2^wb; 4 bits up to 256-bit exponents, 5 up to ~1500, 6 beyond
   int wb = exp_words <= 8 ? 4 : (exp_words < 48 ? 5 : 6);
   if (ctx->window_bits) wb = ctx->window_bits;
-  const size_t need = (size_t)grid * C::GROUPS * ((size_t)1 << wb) * C::K * sizeof(uint32_t);
+  const bool dual = base2.p != nullptr;
+  if (dual && (base_hi.p != nullptr || exp2_words <= 0 || 32 * exp2_words > ((exp_words * 32 + wb - 1) / wb - 1) * wb)) {
+    mpe_set_error_msg("modexp: the second exponent must be shorter than the first");
+    return MPE_E_ARG;
+  }
+  const size_t need = (size_t)grid * C::GROUPS * (((size_t)1 << wb) + (dual ? 16 : 0)) * C::K * sizeof(uint32_t);
   if (need > ctx->tables_bytes) {
     if (ctx->tables) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->tables); ctx->tables = nullptr; ctx->tables_bytes = 0; }
     hipError_t e = hipMalloc(&ctx->tables, need);
     if (e != hipSuccess) { mpe_set_error("hipMalloc(window tables)", e); return MPE_E_NOMEM; }
     ctx->tables_bytes = need;
   }
-  prof_begin(ctx, st, 0, C::BITS, exp_words, batch);
+  prof_begin(ctx, st, 0, C::BITS, exp_words, batch, dual ? exp2_words : 0);
   hipLaunchKernelGGL(modexp_kernel<C>, dim3(grid), dim3(64), 0, st, batch, view_of(ms), mod_sel, base_lo, base_hi, exps,
-                     exp_words, wb, d_out, (uint32_t*)ctx->tables);
+                     exp_words, wb, base2, exps2, exp2_words, d_out, (uint32_t*)ctx->tables);
   prof_end(ctx, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("modexp_kernel", e); return MPE_E_HIP; }
@@ -128,11 +133,22 @@ static int modexp_impl(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_s
   return MPE_OK;
 }
 
+int launch_modexp2(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
+                   Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st) {
+  if (batch == 0) return MPE_OK;
+  if (ms->bits == 4096)
+    return modexp_impl<Cfg4096>(ctx, ms, batch, mod_sel, base, no_rows(), exps, exp_words, base2, exps2, exp2_words, out, st);
+  if (ms->bits == 2048)
+    return modexp_impl<Cfg2048>(ctx, ms, batch, mod_sel, base, no_rows(), exps, exp_words, base2, exps2, exp2_words, out, st);
+  return MPE_E_ARG;
+}
 int launch_modexp(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows base_lo, Rows base_hi, Rows exps,
                   int exp_words, uint32_t* out, hipStream_t st) {
   if (batch == 0) return MPE_OK;
-  if (ms->bits == 4096) return modexp_impl<Cfg4096>(ctx, ms, batch, mod_sel, base_lo, base_hi, exps, exp_words, out, st);
-  if (ms->bits == 2048) return modexp_impl<Cfg2048>(ctx, ms, batch, mod_sel, base_lo, base_hi, exps, exp_words, out, st);
+  if (ms->bits == 4096)
+    return modexp_impl<Cfg4096>(ctx, ms, batch, mod_sel, base_lo, base_hi, exps, exp_words, no_rows(), no_rows(), 0, out, st);
+  if (ms->bits == 2048)
+    return modexp_impl<Cfg2048>(ctx, ms, batch, mod_sel, base_lo, base_hi, exps, exp_words, no_rows(), no_rows(), 0, out, st);
   return MPE_E_ARG;
 }
 
@@ -187,6 +203,7 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   c->cus = prop.multiProcessorCount;
   if (getenv("MPE_NO_FIXED_BASE")) c->use_fixed_base = false;     // A/B switches for measurements
   if (getenv("MPE_NO_CRT")) c->use_crt = false;
+  if (getenv("MPE_NO_MULTIEXP")) c->use_multiexp = false;
   if (getenv("MPE_WINDOW_BITS")) { const int w = atoi(getenv("MPE_WINDOW_BITS")); if (w >= 4 && w <= 6) c->window_bits = w; }
   // comb tables of the two fixed secp256k1 generators (module globals of this device; identical on every call)
   hipLaunchKernelGGL(mpe::ec::ec_comb_build_kernel, dim3(2), dim3(64), 0, 0);
@@ -235,6 +252,7 @@ int mpe_prof_collect(mpe_ctx* ctx, mpe_prof_rec* out, int max_records, int* n_ou
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ev.a, ev.b) != hipSuccess) continue;
     out[n].kind = ev.kind; out[n].bits = ev.bits; out[n].exp_words = ev.exp_words; out[n].batch = ev.batch; out[n].ms = ms;
+    out[n].exp2_words = ev.exp2_words;
     ++n;
   }
   *n_out = n;
@@ -263,6 +281,17 @@ int mpe_modexp(mpe_ctx* ctx, const mpe_modset* ms, int batch, const int32_t* d_m
   const int k32 = ms->bits / 32;
   return launch_modexp(ctx, ms, batch, mod_selector(ms, d_mod_idx), rows(d_base, k32), no_rows(), rows(d_exp, exp_words),
                        exp_words, d_out, (hipStream_t)stream);
+}
+
+int mpe_modexp2(mpe_ctx* ctx, const mpe_modset* ms, int batch, const int32_t* d_mod_idx, const uint32_t* d_base,
+                const uint32_t* d_exp, int exp_words, const uint32_t* d_base2, const uint32_t* d_exp2, int exp2_words,
+                uint32_t* d_out, void* stream) {
+  if (!ctx || !ms || !d_base || !d_exp || !d_base2 || !d_exp2 || !d_out || batch < 0 || exp_words <= 0 || exp2_words <= 0)
+    return MPE_E_ARG;
+  if (!d_mod_idx && ms->count != 1 && ms->count < batch) return MPE_E_ARG;
+  const int k32 = ms->bits / 32;
+  return launch_modexp2(ctx, ms, batch, mod_selector(ms, d_mod_idx), rows(d_base, k32), rows(d_exp, exp_words), exp_words,
+                        rows(d_base2, k32), rows(d_exp2, exp2_words), exp2_words, d_out, (hipStream_t)stream);
 }
 
 int mpe_modmul(mpe_ctx* ctx, const mpe_modset* ms, int batch, const int32_t* d_mod_idx, const uint32_t* d_a,

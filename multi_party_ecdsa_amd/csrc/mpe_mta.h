@@ -104,19 +104,14 @@ int mpe_mta_message_b(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   int32_t* st_of = (int32_t*)take((size_t)total * 4);
   int32_t* key_it = (int32_t*)take((size_t)total * 4);
   uint8_t* ok_items = (uint8_t*)take((size_t)total);
-  uint32_t* c_bt = (uint32_t*)take((size_t)batch * 128 * 4);
-  uint32_t* bca = (uint32_t*)take((size_t)batch * 128 * 4);
   uint32_t* btq = (uint32_t*)take((size_t)batch * 8 * 4);
   MPE_LAUNCH_1D(mpe::mta_idx_kernel, total, st, total, nst, pk->nkeys, d_key_idx, b_of, st_of, key_it);
   // verify Alice's range proofs against every statement   (:119-131); any failure -> Err(InvalidKey) -> ok = 0
   MPE_TRY(mpe::alice_verify(ctx, pk, stm, total, key_it, st_of, mpe::rows(d_ca, 128, b_of), mpe::dense(range_proofs), ok_items, st));
   MPE_LAUNCH_1D(mpe::mta_all_kernel, batch, st, batch, nst, ok_items, d_ok);
   // c_b = (b * c_a) + Enc(beta_tag; r)   (:133-145);  beta = -beta_tag mod q   (:146)
-  MPE_TRY(mpe::paillier_encrypt(ctx, pk, batch, d_key_idx, d_beta_tag, d_r, c_bt, false, st));   // Alice's key, Bob computes
-  MPE_TRY(mpe::launch_modexp(ctx, pk->ms_nn, batch, mpe::key_selector(pk, d_key_idx), mpe::rows(d_ca, 128), mpe::no_rows(),
-                             mpe::rows(d_b, 8), 8, bca, st));
-  MPE_TRY(mpe::launch_modmul(ctx, pk->ms_nn, batch, mpe::key_selector(pk, d_key_idx), mpe::rows(bca, 128), mpe::rows(c_bt, 128),
-                             d_cb, st));
+  MPE_TRY(mpe::paillier_mul_add_enc(ctx, pk, batch, d_key_idx, mpe::rows(d_ca, 128), mpe::rows(d_b, 8), 8, d_beta_tag, d_r, d_cb,
+                                    st));                                                      // Alice's key, Bob computes
   MPE_LAUNCH_1D(mpe::mta_beta_kernel, batch, st, batch, d_beta_tag, btq, d_beta);
   // DLogProof::prove(b), DLogProof::prove(beta_tag_fe)   (:147-148)
   MPE_LAUNCH_1D(mpe::dlog_prove_kernel, batch, st, batch, d_b, d_nonce_b, b_proof->pk, b_proof->R, b_proof->z);

@@ -309,6 +309,27 @@ static int paillier_encrypt(mpe_ctx* ctx, const mpe_paillier* pk, int B, const i
   return launch_modmul(ctx, pk->ms_nn, B, key_selector(pk, key_idx), rows(x, 128), rows(gm, 128), d_c, st);
 }
 
+// MessageB's ciphertext in one go: out = c_a^k * Enc(m; r) = c_a^k (1 + m N) r^N mod N^2   (mta/mod.rs:133-145:
+// Paillier::encrypt_with_chosen_randomness, Paillier::mul, Paillier::add).  The peer computes this under a key
+// it does not own; r^N and c_a^k share one ladder.
+static int paillier_mul_add_enc(mpe_ctx* ctx, const mpe_paillier* pk, int B, const int32_t* key_idx, Rows c_a, Rows k, int kw,
+                                const uint32_t* d_m, const uint32_t* d_r, uint32_t* d_out, hipStream_t st) {
+  MPE_TRY(ws_reserve(ctx, (size_t)B * 128 * 4 * 3 + 8192, st));
+  uint32_t* x = ws_array<uint32_t>(ctx, (size_t)B * 128);
+  uint32_t* gm = ws_array<uint32_t>(ctx, (size_t)B * 128);
+  const Rows ksel = key_selector(pk, key_idx), Nrow = key_rows(pk, pk->N, 64, key_idx);
+  MPE_LAUNCH_1D(enc_gm_kernel, B, st, B, pk->nkeys, d_m, key_idx, pk->N, gm);
+  if (ctx->use_multiexp) {
+    MPE_TRY(launch_modexp2(ctx, pk->ms_nn, B, ksel, rows(d_r, 64, nullptr, 64), Nrow, 64, c_a, k, kw, x, st));
+  } else {
+    uint32_t* y = ws_array<uint32_t>(ctx, (size_t)B * 128);
+    MPE_TRY(launch_modexp(ctx, pk->ms_nn, B, ksel, rows(d_r, 64, nullptr, 64), no_rows(), Nrow, 64, x, st));
+    MPE_TRY(launch_modexp(ctx, pk->ms_nn, B, ksel, c_a, no_rows(), k, kw, y, st));
+    MPE_TRY(launch_modmul(ctx, pk->ms_nn, B, ksel, rows(x, 128), rows(y, 128), x, st));
+  }
+  return launch_modmul(ctx, pk->ms_nn, B, ksel, rows(x, 128), rows(gm, 128), d_out, st);
+}
+
 static int paillier_decrypt(mpe_ctx* ctx, const mpe_paillier* pk, int B, const int32_t* key_idx, const uint32_t* d_c,
                             uint32_t* d_m, hipStream_t st) {
   const int B2 = 2 * B;

@@ -218,6 +218,11 @@ struct Seq {
     if (rc == MPE_OK) rc = mpe::modexp_nn(ctx, pk, B, sel, base, exps, ew, holder, o, st);
     return o;
   }
+  uint32_t* modexp2(const mpe_modset* ms, Rows sel, Rows base, Rows exps, int ew, Rows base2, Rows exps2, int ew2) {
+    uint32_t* o = words(ms->bits / 32);
+    if (rc == MPE_OK) rc = launch_modexp2(ctx, ms, B, sel, base, exps, ew, base2, exps2, ew2, o, st);
+    return o;
+  }
   uint32_t* modmul(const mpe_modset* ms, Rows sel, Rows a, Rows b) {
     uint32_t* o = words(ms->bits / 32);
     if (rc == MPE_OK) rc = launch_modmul(ctx, ms, B, sel, a, b, o, st);
@@ -326,11 +331,20 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
   // u' = (s1 N + 1) s^N (c^e)^-1 mod N^2                                                           :134-141
   uint32_t* gs1 = q.words(128);
   q.muladd(pr.s1, 25, Nrow, 64, no_rows(), 0, gs1, 128);
-  uint32_t* ce = q.modexp(pk->ms_nn, ksel, cipher, pr.e, 8);
-  uint32_t* cei = q.modinv(pk->ms_nn, ksel, rows(ce, 128), inv_ok2);
-  uint32_t* sn = q.modexp(pk->ms_nn, ksel, with_words(pr.s, 64), Nrow, 64);
-  uint32_t* b12 = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(sn, 128));
-  uint32_t* u = q.modmul(pk->ms_nn, ksel, rows(b12, 128), rows(cei, 128));
+  uint32_t* u;
+  if (ctx->use_multiexp) {
+    // (c^e)^-1 = (c^-1)^e: invert first, then s^N (c^-1)^e on one ladder (the 256 squarings of c^e are shared)
+    uint32_t* cred = q.modmul(pk->ms_nn, ksel, cipher, rows(pk->ms_nn->one_words, 0, nullptr, 1));   // c mod N^2
+    uint32_t* cinv = q.modinv(pk->ms_nn, ksel, rows(cred, 128), inv_ok2);
+    uint32_t* m = q.modexp2(pk->ms_nn, ksel, with_words(pr.s, 64), Nrow, 64, rows(cinv, 128), pr.e, 8);
+    u = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(m, 128));
+  } else {
+    uint32_t* ce = q.modexp(pk->ms_nn, ksel, cipher, pr.e, 8);
+    uint32_t* cei = q.modinv(pk->ms_nn, ksel, rows(ce, 128), inv_ok2);
+    uint32_t* sn = q.modexp(pk->ms_nn, ksel, with_words(pr.s, 64), Nrow, 64);
+    uint32_t* b12 = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(sn, 128));
+    u = q.modmul(pk->ms_nn, ksel, rows(b12, 128), rows(cei, 128));
+  }
   // e' = H(N, N+1, c, z, u', w') == e                                                              :143-153
   uint32_t* e2 = q.words(8);
   HashDesc d;
@@ -411,12 +425,18 @@ static int pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   // u2' = (N+1)^s1 s2^N c^-e mod N^2; (N+1)^s1 = 1 + s1 N < N^2 because s1 < 2^800                 :144-157
   uint32_t* g1 = q.words(128);
   q.muladd(pr.s1, 25, Nrow, 64, no_rows(), 0, g1, 128);
-  uint32_t* s2n = q.modexp(pk->ms_nn, ksel, with_words(pr.s2, 64), Nrow, 64);
-  uint32_t* t2 = q.modmul(pk->ms_nn, ksel, rows(g1, 128), rows(s2n, 128));
   uint32_t* cred = q.modmul(pk->ms_nn, ksel, cipher, rows(pk->ms_nn->one_words, 0, nullptr, 1));  // c mod N^2
   uint32_t* cinv = q.modinv(pk->ms_nn, ksel, rows(cred, 128), inv_ok1);
-  uint32_t* cie = q.modexp(pk->ms_nn, ksel, rows(cinv, 128), rows(e, 8), 8);
-  uint32_t* u2 = q.modmul(pk->ms_nn, ksel, rows(t2, 128), rows(cie, 128));
+  uint32_t* u2;
+  if (ctx->use_multiexp) {
+    uint32_t* m = q.modexp2(pk->ms_nn, ksel, with_words(pr.s2, 64), Nrow, 64, rows(cinv, 128), rows(e, 8), 8);
+    u2 = q.modmul(pk->ms_nn, ksel, rows(g1, 128), rows(m, 128));
+  } else {
+    uint32_t* s2n = q.modexp(pk->ms_nn, ksel, with_words(pr.s2, 64), Nrow, 64);
+    uint32_t* t2 = q.modmul(pk->ms_nn, ksel, rows(g1, 128), rows(s2n, 128));
+    uint32_t* cie = q.modexp(pk->ms_nn, ksel, rows(cinv, 128), rows(e, 8), 8);
+    u2 = q.modmul(pk->ms_nn, ksel, rows(t2, 128), rows(cie, 128));
+  }
   // u3' = h1^s1 h2^s3 z^-e mod N~                                                                  :159-172
   uint32_t* a1 = q.fb_modexp(stm, ssel, 0, h1,pr.s1, 25);
   uint32_t* a2 = q.fb_modexp(stm, ssel, 1, h2,pr.s3, 89);

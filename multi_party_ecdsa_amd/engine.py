@@ -47,7 +47,7 @@ class Context:
         arr = (N.ProfRec * max_records)()
         n = C.c_int(0)
         N.check(N.lib.mpe_prof_collect(self.h, arr, max_records, C.byref(n)), "mpe_prof_collect")
-        return [dict(kind=r.kind, bits=r.bits, exp_words=r.exp_words, batch=r.batch, ms=r.ms) for r in arr[:n.value]]
+        return [dict(kind=r.kind, bits=r.bits, exp_words=r.exp_words, batch=r.batch, ms=r.ms, exp2_words=r.exp2_words) for r in arr[:n.value]]
 
     def close(self):
         if self.h:
@@ -109,6 +109,21 @@ def modmul_device(ctx, ms, d_a, d_b, d_out=None, d_mod_idx=None):
     N.check(N.lib.mpe_modmul(ctx.h, ms.h, B, idx_ptr, C.c_void_p(d_a.data_ptr()), C.c_void_p(d_b.data_ptr()),
                              C.c_void_p(d_out.data_ptr()), ctx.stream()), "mpe_modmul")
     return d_out
+
+
+def mod_pow2(ctx, ms, bases, exps, bases2, exps2, mod_idx=None, exp_bits=None, exp2_bits=None):
+    """Batched `mod_pow(b, e, n) * mod_pow(b2, e2, n) % n` on one ladder (`mpe_modexp2`); e2 is the short exponent."""
+    ew = ((exp_bits or max(1, max(int(e).bit_length() for e in exps))) + 31) // 32
+    ew2 = ((exp2_bits or max(1, max(int(e).bit_length() for e in exps2))) + 31) // 32
+    dv = lambda xs, w: _dev_u32(ints_to_words(xs, w), ctx.device)
+    d_idx = torch.tensor(mod_idx, dtype=torch.int32, device=ctx.device) if mod_idx is not None else None
+    d_b, d_e, d_b2, d_e2 = dv(bases, ms.k32), dv(exps, ew), dv(bases2, ms.k32), dv(exps2, ew2)
+    d_out = torch.empty_like(d_b)
+    N.check(N.lib.mpe_modexp2(ctx.h, ms.h, len(bases), C.c_void_p(d_idx.data_ptr()) if d_idx is not None else None,
+                              C.c_void_p(d_b.data_ptr()), C.c_void_p(d_e.data_ptr()), ew, C.c_void_p(d_b2.data_ptr()),
+                              C.c_void_p(d_e2.data_ptr()), ew2, C.c_void_p(d_out.data_ptr()), ctx.stream()), "mpe_modexp2")
+    ctx.sync()
+    return words_to_ints(_to_np_u32(d_out))
 
 
 def mod_pow(ctx, ms, bases, exps, mod_idx=None, exp_bits=None):

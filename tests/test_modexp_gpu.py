@@ -64,6 +64,35 @@ def test_modexp_vs_oracle(gpu_ctx, keys, bits, ebits, B, nmod):
     assert not bad, f"{len(bad)} mismatches, first {bad[:5]}"
 
 
+@pytest.mark.parametrize("bits,ebits,e2bits,B,nmod", [(4096, 2048, 256, 150, 3), (2048, 2048, 256, 70, 5), (4096, 800, 256, 33, 33),
+                                                       (2048, 320, 32, 40, 1)])
+def test_modexp2_is_the_product_of_the_two_powers(gpu_ctx, keys, bits, ebits, e2bits, B, nmod):
+    """mpe_modexp2 (one ladder, shared squarings) == mod_pow * mod_pow % n of the oracle, incl. zero windows and edge exponents"""
+    E = _engine()
+    r = F.Rng(f"gpu-modexp2-{bits}-{ebits}-{e2bits}")
+    k32 = bits // 32
+    mods = [r.bits(bits) | (1 << (bits - 1)) | 1 for _ in range(nmod)]
+    if nmod >= 3:
+        mods[0] = keys[0].N ** (bits // 2048)
+    idx = [(i * 5) % nmod for i in range(B)]
+    b1, b2 = [r.bits(bits) for _ in range(B)], [r.bits(bits) for _ in range(B)]
+    e1, e2 = [r.bits(ebits) for _ in range(B)], [r.bits(e2bits) for _ in range(B)]
+    e1[0], e2[0] = 0, 0
+    e1[1], e2[1] = (1 << ebits) - 1, (1 << e2bits) - 1
+    e2[2] = 0
+    e1[3] = 0
+    e2[4] = 0xF0F0F0F0 & ((1 << e2bits) - 1)
+    b2[5] = 1
+    ms = E.ModSet(gpu_ctx, bits, mods)
+    got = E.mod_pow2(gpu_ctx, ms, b1, e1, b2, e2, mod_idx=idx, exp_bits=ebits, exp2_bits=e2bits)
+    mw = F.words(mods, k32)
+    p1 = orc.modexp(mw, F.words(b1, k32), F.words(e1, (ebits + 31) // 32), idx)
+    p2 = orc.modexp(mw, F.words(b2, k32), F.words(e2, (e2bits + 31) // 32), idx)
+    want = F.ints(orc.modmul(mw, p1, p2, idx))
+    bad = [i for i in range(B) if got[i] != want[i]]
+    assert not bad, f"{len(bad)} mismatches, first {bad[:5]}"
+
+
 @pytest.mark.parametrize("bits", [2048, 4096])
 def test_modmul_vs_oracle(gpu_ctx, bits):
     E = _engine()
