@@ -103,10 +103,13 @@ def cpu_baseline_gg20(lk, host_nonces, sample, threads):
 
 
 def paillier_config2(ctx, E, keys, F, steps=1):
-    """BASELINE config 2: 65 536 encrypt + 65 536 decrypt, 16 keys; returns ops/s and per-kernel times."""
+    """BASELINE config 2: 65 536 encrypt + 65 536 decrypt, 16 keys.  Encryption is timed twice: by the key holder
+    (p, q known: the p^2 | q^2 path) and by a peer that only has N (the plain 4096-bit modexp r^N mod N^2 — the
+    'Paillier-2048 modexp/s' of the metric, with its kernel time from the HIP-event records)."""
     B = 65536
     dev = ctx.device
-    pk = E.PaillierKeys(ctx, p=[k.p for k in keys], q=[k.q for k in keys])
+    sk = E.PaillierKeys(ctx, p=[k.p for k in keys], q=[k.q for k in keys])
+    pk = E.PaillierKeys(ctx, N=[k.N for k in keys])
     g = torch.Generator(device=dev)
     g.manual_seed(99)
     m = rand_words(g, dev, B, 64, 8)
@@ -114,24 +117,31 @@ def paillier_config2(ctx, E, keys, F, steps=1):
     rr = rand_words(g, dev, B, 64, 63)
     idx = (torch.arange(B, device=dev, dtype=torch.int32) % len(keys)).contiguous()
     c = torch.empty((B, 128), dtype=torch.int32, device=dev)
+    c2 = torch.empty((B, 128), dtype=torch.int32, device=dev)
     back = torch.empty((B, 64), dtype=torch.int32, device=dev)
-    pk.encrypt_device(m, rr, idx, c); pk.decrypt_device(c, idx, back)          # warm-up
-    torch.cuda.synchronize()
+    sk.encrypt_device(m, rr, idx, c); pk.encrypt_device(m, rr, idx, c2); sk.decrypt_device(c, idx, back)   # warm-up
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    t_enc = timed(lambda: sk.encrypt_device(m, rr, idx, c))
+    t_dec = timed(lambda: sk.decrypt_device(c, idx, back))
     ctx.prof_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        pk.encrypt_device(m, rr, idx, c)
-        pk.decrypt_device(c, idx, back)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    t_pub = timed(lambda: pk.encrypt_device(m, rr, idx, c2))
     recs = ctx.prof_collect()
     ctx.prof_enable(False)
-    enc = float(np.mean([r["ms"] for r in recs if r["kind"] == 0 and r["bits"] == 4096]))
-    dec = float(np.mean([r["ms"] for r in recs if r["kind"] == 0 and r["bits"] == 2048]))
-    return {"ops_per_s": 2 * B * steps / dt, "batch": B, "roundtrip_ok": bool(torch.equal(back, m)),
-            "encrypt_per_s": B / (enc * 1e-3), "decrypt_per_s": B / (dec * 1e-3), "modexp4096_2048_per_s": B / (enc * 1e-3),
-            "modexp4096_alg_TMAC_per_s": B * modexp_macs(128, 2048) / (enc * 1e-3) / 1e12,
-            "modexp4096_frac_of_peak": B * modexp_macs(128, 2048) / (enc * 1e-3) / PEAK_MAC_PER_S}
+    kern = float(np.mean([r["ms"] for r in recs if r["kind"] == 0 and r["bits"] == 4096])) * 1e-3
+    return {"ops_per_s": 2 * B / (t_enc + t_dec), "batch": B,
+            "roundtrip_ok": bool(torch.equal(back, m)), "holder_equals_public_ciphertext": bool(torch.equal(c, c2)),
+            "encrypt_per_s": B / t_enc, "decrypt_per_s": B / t_dec, "encrypt_public_key_per_s": B / t_pub,
+            "modexp4096_2048_per_s": B / kern,
+            "modexp4096_alg_TMAC_per_s": B * modexp_macs(128, 2048) / kern / 1e12,
+            "modexp4096_frac_of_peak": B * modexp_macs(128, 2048) / kern / PEAK_MAC_PER_S}
 
 
 def main():

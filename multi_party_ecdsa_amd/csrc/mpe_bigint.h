@@ -104,6 +104,21 @@ __device__ __forceinline__ uint32_t bcast0(uint32_t x) {
     return (uint32_t)y;
   }
 }
+// bcast0(x) & MASK with the mask applied between the two DPP stages, so that the first stage and the mask fold
+// into one v_and_b32_dpp (the VALU issue slot is what the modexp kernel is bound by)
+// (maskv holds the mask in a VGPR: DPP encodings take no literal operand)
+template <int TPI>
+__device__ __forceinline__ uint32_t bcast0_masked(uint32_t x, uint32_t maskv) {
+  if constexpr (TPI == 8) {
+    int y = __builtin_amdgcn_update_dpp(0, (int)x, 0x00, 0xf, 0xf, true) & (int)maskv;  // quad_perm [0,0,0,0]
+    y = __builtin_amdgcn_update_dpp(y, y, 0x114, 0xf, 0xA, false);                      // 4-7 <- 0-3 of each half row
+    return (uint32_t)y;
+  } else if constexpr (TPI == 4) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x00, 0xf, 0xf, true) & maskv;
+  } else {
+    return bcast0<TPI>(x) & maskv;
+  }
+}
 // Order LDS traffic between the lanes of one wave (lanes exchange operands through LDS; the
 // hardware executes one wave's DS ops in order, this only stops the compiler reordering them).
 __device__ __forceinline__ void wave_lds_sync() {
@@ -144,6 +159,8 @@ __device__ __forceinline__ void montmul(uint32_t (&res)[C::L], const uint32_t (&
   uint64_t c[L];
 #pragma unroll
   for (int i = 0; i < L; ++i) c[i] = 0;
+  uint32_t maskv = C::MASK;
+  asm volatile("" : "+v"(maskv));                  // keep the mask in a register (see bcast0_masked)
 
 #pragma unroll 1
   for (int jj = 0; jj < C::TPI; ++jj) {
@@ -154,7 +171,7 @@ __device__ __forceinline__ void montmul(uint32_t (&res)[C::L], const uint32_t (&
     for (int r = 0; r < L; ++r) {
       const uint32_t bj = bp[r];
       c[r] += (uint64_t)a[0] * bj;
-      const uint32_t m = bcast0<C::TPI>((uint32_t)c[r] * n0inv) & C::MASK;
+      const uint32_t m = bcast0_masked<C::TPI>((uint32_t)c[r] * n0inv, maskv);
 #pragma unroll
       for (int i = 1; i < L; ++i) c[(r + i) % L] += (uint64_t)a[i] * bj;
 #pragma unroll
@@ -164,7 +181,7 @@ __device__ __forceinline__ void montmul(uint32_t (&res)[C::L], const uint32_t (&
       // as its new top column.  For lane 0 of the group the low part is 0 by construction of m,
       // so the previous group's top lane (and lane 15 of a row, via bound_ctrl) pulls in a zero.
       c[(r + 1) % L] += c[r] >> W;
-      c[r] = (uint64_t)pull_next((uint32_t)c[r] & C::MASK);
+      c[r] = (uint64_t)(pull_next((uint32_t)c[r]) & maskv);      // mask after the move: folds into one v_and_b32_dpp
     }
   }
   // local ripple, then hand the lane's carry-out (< 2^38) to the next lane without rippling on

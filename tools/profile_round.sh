@@ -1,0 +1,39 @@
+#!/bin/bash
+# Collects the evidence bench.py's roofline line refers to, on a GPU box:
+#   1. the default bench line (with cpu_baseline and the Paillier config-2 numbers)
+#   2. the same bench under torch.distributed.run with one rank (the N>1 code path: RCCL init, barriers, max-reduce)
+#   3. rocprofv3 --kernel-trace --stats of the bench command (per-kernel durations)
+#   4. separate rocprofv3 --pmc passes (kernel-trace only): FETCH_SIZE | WRITE_SIZE | SQ/GRBM activity
+# Usage (from the repo root):  tools/profile_round.sh <tag>      -> gpurun_out/<tag>/...
+# tools/pmc_summary.py turns the counter CSVs into profiles/<round>/pmc_*.json.
+set -u
+TAG=${1:-prof}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py"
+LIGHT="--no-cpu-baseline --no-paillier --steps 1"
+
+timeout 900 $BENCH > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+tail -c 300 "$OUT/bench_default.json"; echo
+
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
+  $ROOT/bench.py --gpus 1 $LIGHT --warmup 1 > "$OUT/bench_torchrun1.json" 2> "$OUT/bench_torchrun1.err"
+tail -c 200 "$OUT/bench_torchrun1.json"; echo
+
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o s -- $BENCH $LIGHT --warmup 1 \
+  > "$OUT/stats_bench.json" 2> /dev/null
+cp /tmp/p_stats/s_kernel_stats.csv "$OUT/kernel_stats.csv" 2> /dev/null
+
+pmc_pass() {  # name, counters...
+  local name=$1; shift
+  timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/p_$name -o c -- $BENCH $LIGHT --warmup 0 \
+    > "$OUT/pmc_${name}_bench.json" 2> "$OUT/pmc_${name}.err"
+  python "$ROOT/tools/pmc_summary.py" /tmp/p_$name/c_counter_collection.csv /tmp/p_$name/c_kernel_trace.csv > "$OUT/pmc_$name.json" 2>> "$OUT/pmc_${name}.err"
+  tail -c 400 "$OUT/pmc_$name.json"; echo
+}
+pmc_pass fetch FETCH_SIZE
+pmc_pass write WRITE_SIZE
+pmc_pass sq GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES
+ls -la "$OUT"
