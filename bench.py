@@ -32,7 +32,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-T, N_PARTIES, SIGNERS = 1, 3, [0, 1]
 PEAK_MAC_PER_S = 16 * 4 * 256 * 2.4e9     # gfx950 v_mad_u64_u32: 16 lanes/clk/SIMD (profiles/r01_valu_rate.json)
 EXP_BITS = {8: 256, 24: 768, 25: 769, 32: 1024, 64: 2048, 72: 2304, 80: 2560, 81: 2561, 88: 2816, 89: 2817}
 
@@ -150,6 +149,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--sessions", type=int, default=65536, help="concurrent signing sessions per GPU per step")
+    ap.add_argument("--t", type=int, default=1, help="threshold (t+1 signers); BASELINE config 5 is --t 2 --n 5")
+    ap.add_argument("--n", type=int, default=3, help="parties of the key")
     ap.add_argument("--chunk", type=int, default=0, help="sessions per internal pass of mpe_gg20_sign (0 = library default)")
     ap.add_argument("--dedup", action="store_true", help="evaluate identical checks once (same outputs; not the faithful path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,6 +172,8 @@ def main():
     keys = F.load_keys()
     ctx = E.Context(local_rank)
     dev = ctx.device
+    T, N_PARTIES = args.t, args.n
+    SIGNERS = list(range(T + 1))                               # parties 1..t+1 sign
     B, S, n = args.sessions, len(SIGNERS), N_PARTIES
     lk = G.make_local_keys(keys, T, N_PARTIES, SIGNERS)
     gk = E.Gg20Keys(ctx, T, N_PARTIES, SIGNERS, lk["arrays"])
@@ -232,12 +235,12 @@ def main():
         except OSError:
             pass
         res = {
-            "metric": "GG20 signatures/sec (t=1, n=3; all parties of each session on the GPU) + Paillier-2048 modexp/s per GPU",
+            "metric": f"GG20 signatures/sec (t={T}, n={N_PARTIES}; all parties of each session on the GPU) + Paillier-2048 modexp/s per GPU",
             "value": value, "unit": "signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (radix 2^29) / u64 accumulators", "data": "synthetic",
-            "config": {"workload": f"{B} concurrent GG20 t=1 n=3 signing sessions per GPU, full MtA path (BASELINE config 4 shape), "
-                                   f"{'deduplicated checks' if args.dedup else 'faithful work'}, one LocalKey fixture, signers {{1,2}}",
+            "config": {"workload": f"{B} concurrent GG20 t={T} n={N_PARTIES} signing sessions per GPU, full MtA path (BASELINE config 4 shape), "
+                                   f"{'deduplicated checks' if args.dedup else 'faithful work'}, one LocalKey fixture, signers {{1..{T + 1}}}",
                        "sessions_per_gpu": B, "t": T, "n": N_PARTIES, "signers": S,
                        "parallelism": f"session-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "valu-int (v_mad_u64_u32 issue rate; HBM traffic is negligible)",
