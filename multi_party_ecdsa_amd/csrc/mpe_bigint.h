@@ -67,6 +67,7 @@ struct Cfg {
 #endif
 using Cfg4096 = Cfg<4096, MPE_W, MPE_L, 8>;
 using Cfg2048 = Cfg<2048, MPE_W, MPE_L, 4>;
+using Cfg1024 = Cfg<1024, MPE_W, MPE_L, 2>;     // the halves of the N-adic arithmetic modulo p^2 | q^2 (mpe_pairexp.h)
 
 // ---------------------------------------------------------------------------------------------
 // cross-lane primitives (DPP; VALU only, no LDS traffic)
@@ -115,6 +116,8 @@ __device__ __forceinline__ uint32_t bcast0_masked(uint32_t x, uint32_t maskv) {
     return (uint32_t)y;
   } else if constexpr (TPI == 4) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x00, 0xf, 0xf, true) & maskv;
+  } else if constexpr (TPI == 2) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xA0, 0xf, 0xf, true) & maskv;   // quad_perm [0,0,2,2]
   } else {
     return bcast0<TPI>(x) & maskv;
   }
@@ -256,9 +259,13 @@ __device__ __forceinline__ void reduce_once(uint32_t (&v)[C::L], const uint32_t 
 // Interface words (little-endian u32, K32 of them, zero-padded up to bit W*K + 32, in LDS) -> limbs.
 template <class C>
 __device__ __forceinline__ void limbs_from_words(uint32_t (&v)[C::L], const uint32_t* w32, const Lane& ln) {
+  // The per-limb word indices and shifts depend on the lane only; laundering t keeps the compiler from hoisting
+  // those ~36 values out of the exponentiation loop and holding them in VGPRs for the whole kernel.
+  int t = ln.t;
+  asm volatile("" : "+v"(t));
 #pragma unroll
   for (int i = 0; i < C::L; ++i) {
-    const int bitpos = (ln.t * C::L + i) * C::W;
+    const int bitpos = (t * C::L + i) * C::W;
     const int q = bitpos >> 5, s = bitpos & 31;
     const uint64_t two = (uint64_t)w32[q] | ((uint64_t)w32[q + 1] << 32);
     v[i] = (uint32_t)(two >> s) & C::MASK;

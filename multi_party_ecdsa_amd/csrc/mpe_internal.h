@@ -13,6 +13,7 @@ struct mpe_ctx {
   int device = 0;
   int cus = 256;
   int window_bits = 0;            // 0 = choose per exponent length (4/5/6); 4..6 = force (A/B runs)
+  bool use_pair = true;           // arithmetic modulo N^2 / p^2 in N-adic pair form (mpe_pairexp.h): half the multiplies
   bool use_multiexp = true;       // verifiers: s^N * (c^-1)^e on one ladder instead of two exponentiations (same residue)
   bool use_crt = true;            // key holders compute x^e mod N^2 through p^2 | q^2 (mpe_paillier.h modexp_nn)
   bool use_fixed_base = true;     // h1/h2 exponentiations through per-statement window tables (mpe_fixedbase.h)

@@ -179,6 +179,8 @@ static Rows mod_selector(const mpe_modset* ms, const int32_t* d_mod_idx) {
 
 }  // namespace mpe
 
+#include "mpe_small.h"
+#include "mpe_pairexp.h"
 #include "mpe_paillier.h"
 #include "mpe_proofs.h"
 #include "mpe_mta.h"
@@ -204,6 +206,7 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   if (getenv("MPE_NO_FIXED_BASE")) c->use_fixed_base = false;     // A/B switches for measurements
   if (getenv("MPE_NO_CRT")) c->use_crt = false;
   if (getenv("MPE_NO_MULTIEXP")) c->use_multiexp = false;
+  if (getenv("MPE_NO_PAIR")) c->use_pair = false;
   if (getenv("MPE_WINDOW_BITS")) { const int w = atoi(getenv("MPE_WINDOW_BITS")); if (w >= 4 && w <= 6) c->window_bits = w; }
   // comb tables of the two fixed secp256k1 generators (module globals of this device; identical on every call)
   hipLaunchKernelGGL(mpe::ec::ec_comb_build_kernel, dim3(2), dim3(64), 0, 0);

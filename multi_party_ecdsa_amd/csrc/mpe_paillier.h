@@ -36,6 +36,8 @@ struct mpe_paillier {
   int32_t* swap_idx = nullptr;  // [2nk]    j ^ 1
   mpe_modset* ms_pp = nullptr;  // 2048-bit, moduli p^2 | q^2
   mpe_modset* ms_p = nullptr;   // 2048-bit, moduli p | q
+  mpe_pairset* ps_nn = nullptr; // N-adic pair arithmetic modulo N_k^2   (mpe_pairexp.h)
+  mpe_pairset* ps_pp = nullptr; // p-adic pair arithmetic modulo p^2 | q^2 (private key sets)
 };
 
 namespace mpe {
@@ -200,6 +202,8 @@ static void paillier_free(mpe_paillier* pk) {
   if (pk->ms_n) mpe_modset_destroy(pk->ms_n);
   if (pk->ms_pp) mpe_modset_destroy(pk->ms_pp);
   if (pk->ms_p) mpe_modset_destroy(pk->ms_p);
+  pairset_free(pk->ps_nn);
+  pairset_free(pk->ps_pp);
   if (pk->blob) (void)hipFree(pk->blob);
   delete pk;
 }
@@ -257,6 +261,8 @@ static int paillier_create(mpe_ctx* ctx, int nk, const uint32_t* d_N, const uint
   hipLaunchKernelGGL(pk_square_kernel, dim3(blocks_for(nk, 64)), dim3(64), 0, st, nk, pk->N, pk->NN);
   if ((rc = modset_create_dev(ctx, 4096, nk, pk->NN, &pk->ms_nn, st)) != MPE_OK) return fail(rc);
   if ((rc = modset_create_dev(ctx, 2048, nk, pk->N, &pk->ms_n, st)) != MPE_OK) return fail(rc);
+  if ((rc = pairset_create(2048, nk, pk->N, &pk->ps_nn, st)) != MPE_OK) return fail(rc);
+  if (pk->has_private && (rc = pairset_create(1024, (int)nk2, pk->pq32, &pk->ps_pp, st)) != MPE_OK) return fail(rc);
   e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("paillier key set-up", e); return fail(MPE_E_HIP); }
   *out = pk;
@@ -279,7 +285,10 @@ constexpr size_t CRT_WS_WORDS = 2 + 2 * 64 + 2 * 128 + 192;
 // mod p^2 | q^2 on the 2048-bit engine, then  x = x_p E_p + x_q E_q mod N^2.  Same residue as the direct form.
 static int modexp_nn(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Rows base, Rows exps, int ew, bool holder,
                      uint32_t* out, hipStream_t st) {
-  if (!(holder && pk->has_private && ctx->use_crt)) return launch_modexp(ctx, pk->ms_nn, B, ksel, base, no_rows(), exps, ew, out, st);
+  if (!(holder && pk->has_private && ctx->use_crt)) {
+    if (ctx->use_pair) return launch_pair_modexp(ctx, pk->ps_nn, B, ksel, base, exps, ew, no_rows(), no_rows(), 0, out, st);
+    return launch_modexp(ctx, pk->ms_nn, B, ksel, base, no_rows(), exps, ew, out, st);
+  }
   const int B2 = 2 * B;
   int32_t* half_of = ws_array<int32_t>(ctx, B2);
   uint32_t* u = ws_array<uint32_t>(ctx, (size_t)B2 * 64);
@@ -290,11 +299,23 @@ static int modexp_nn(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Row
   Rows lo{base.p, base.idx, base.stride, bw < 64 ? bw : 64, 1};
   Rows hi = bw > 64 ? Rows{base.p + 64, base.idx, base.stride, bw - 64, 1} : no_rows();
   Rows ex{exps.p, exps.idx, exps.stride, exps.words, 1};
-  MPE_TRY(launch_modexp(ctx, pk->ms_pp, B2, Rows{nullptr, half_of, 0, 0}, lo, hi, ex, ew, u, st));
+  if (ctx->use_pair) {
+    MPE_TRY(launch_pair_modexp(ctx, pk->ps_pp, B2, Rows{nullptr, half_of, 0, 0}, Rows{base.p, base.idx, base.stride, bw, 1}, ex, ew,
+                               no_rows(), no_rows(), 0, u, st));
+  } else {
+    MPE_TRY(launch_modexp(ctx, pk->ms_pp, B2, Rows{nullptr, half_of, 0, 0}, lo, hi, ex, ew, u, st));
+  }
   MPE_TRY(launch_modmul(ctx, pk->ms_nn, B2, Rows{nullptr, ksel.idx, ksel.stride, 0, 1}, rows(u, 64, nullptr, 64),
                         rows(pk->e128, 128, half_of), y, st));
   MPE_LAUNCH_1D(crt_add_kernel, B, st, B, ksel, pk->NN, y, out);
   return MPE_OK;
+}
+
+// base^exps * base2^exps2 mod N_k^2 on one ladder, for a party that does NOT own the key (the verifiers, MessageB)
+static int modexp_nn2(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Rows base, Rows exps, int ew, Rows base2,
+                      Rows exps2, int ew2, uint32_t* out, hipStream_t st) {
+  if (ctx->use_pair) return launch_pair_modexp(ctx, pk->ps_nn, B, ksel, base, exps, ew, base2, exps2, ew2, out, st);
+  return launch_modexp2(ctx, pk->ms_nn, B, ksel, base, exps, ew, base2, exps2, ew2, out, st);
 }
 
 static int paillier_encrypt(mpe_ctx* ctx, const mpe_paillier* pk, int B, const int32_t* key_idx, const uint32_t* d_m,
@@ -320,7 +341,7 @@ static int paillier_mul_add_enc(mpe_ctx* ctx, const mpe_paillier* pk, int B, con
   const Rows ksel = key_selector(pk, key_idx), Nrow = key_rows(pk, pk->N, 64, key_idx);
   MPE_LAUNCH_1D(enc_gm_kernel, B, st, B, pk->nkeys, d_m, key_idx, pk->N, gm);
   if (ctx->use_multiexp) {
-    MPE_TRY(launch_modexp2(ctx, pk->ms_nn, B, ksel, rows(d_r, 64, nullptr, 64), Nrow, 64, c_a, k, kw, x, st));
+    MPE_TRY(modexp_nn2(ctx, pk, B, ksel, rows(d_r, 64, nullptr, 64), Nrow, 64, c_a, k, kw, x, st));
   } else {
     uint32_t* y = ws_array<uint32_t>(ctx, (size_t)B * 128);
     MPE_TRY(launch_modexp(ctx, pk->ms_nn, B, ksel, rows(d_r, 64, nullptr, 64), no_rows(), Nrow, 64, x, st));
@@ -343,8 +364,13 @@ static int paillier_decrypt(mpe_ctx* ctx, const mpe_paillier* pk, int B, const i
   uint32_t* y = ws_array<uint32_t>(ctx, (size_t)B2 * 64);
   MPE_LAUNCH_1D(dec_index_kernel, B2, st, B2, pk->nkeys, key_idx, item_of, half_of, keyj);
   // u = c^(p-1) mod p^2 | c^(q-1) mod q^2   (c is double-width for the 2048-bit engine)
-  MPE_TRY(launch_modexp(ctx, pk->ms_pp, B2, Rows{nullptr, half_of, 0, 0}, rows(d_c, 128, item_of, 64),
-                        rows(d_c + 64, 128, item_of, 64), rows(pk->em1, 32, half_of), 32, u, st));
+  if (ctx->use_pair) {
+    MPE_TRY(launch_pair_modexp(ctx, pk->ps_pp, B2, Rows{nullptr, half_of, 0, 0}, rows(d_c, 128, item_of, 128),
+                               rows(pk->em1, 32, half_of), 32, no_rows(), no_rows(), 0, u, st));
+  } else {
+    MPE_TRY(launch_modexp(ctx, pk->ms_pp, B2, Rows{nullptr, half_of, 0, 0}, rows(d_c, 128, item_of, 64),
+                          rows(d_c + 64, 128, item_of, 64), rows(pk->em1, 32, half_of), 32, u, st));
+  }
   MPE_LAUNCH_1D(dec_lfunc_kernel, B2, st, B2, u, half_of, pk->inv2, t);
   // m_p = L_p(u) h_p mod p | m_q
   MPE_TRY(launch_modmul(ctx, pk->ms_p, B2, Rows{nullptr, half_of, 0, 0}, rows(t, 32, nullptr, 32),

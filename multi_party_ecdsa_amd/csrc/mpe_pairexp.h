@@ -1,0 +1,518 @@
+// Exponentiation modulo a SQUARE (N^2 for Paillier, p^2 | q^2 for the key holder's CRT halves) in N-adic form.
+//
+// Every 4096-bit exponentiation on the GG20 path is modulo N^2 (src/utilities/mta/range_proofs.rs:53-55,134-141,
+// zk_pdl_with_slack/mod.rs:87-93,144-157, mta/mod.rs:68-75,133-145).  An element of Z/N^2 is kept as a pair
+// (x0, x1) of residues mod N with   x0 + x1 N = v R  (mod N^2),   R = 2^(W K) the Montgomery radix of N.  Then
+//
+//     (x0 + x1 N)(y0 + y1 N) R^-1 = u + ((x0 y1 + x1 y0 - m) R^-1 mod N) N      (mod N^2)
+//
+// where x0 y0 + m N = u R is the ordinary Montgomery step mod N (u = its result, m = its quotient digits) —
+// the x1 y1 N^2 term vanishes and every reduction is HALF-size.  A multiplication mod N^2 is therefore
+//   pass A : u  = CIOS(x0, y0)  mod N, remembering the K quotient digits m_j
+//   pass B : z1 = CIOS-reduce( x0 y1 + x1 y0 + [K_c + (R-1-m)] ),   K_c = -(R-1) mod N  (so the bracket = -m mod N,
+//            limb-wise non-negative: it just pre-loads the accumulator columns)
+// i.e. 5 K^2 multiply-accumulates, and a squaring (x0 x1 counted twice: one stream with 2 x1) 4 K^2 — against
+// 8 K^2 for the Montgomery multiplication of the 2K-limb integers.  The residues produced are the same numbers
+// mpz_powm returns: the pair is converted back (multiply by (1, 0), normalise, z0 + z1 N) at the end.
+#pragma once
+#include "mpe_internal.h"
+
+namespace mpe {
+
+template <class C>
+struct PairLds {
+  static constexpr int B0 = 0;            // multiplier y0: K limbs
+  static constexpr int B1 = C::K;         // multiplier y1: K limbs
+  static constexpr int M = 2 * C::K;      // quotient digits of pass A: K limbs
+  static constexpr int KC = 3 * C::K;     // K_c + (R - 1) of this item's modulus, limb-wise: K limbs
+  // words per group: even (64-bit LDS reads stay aligned) and such that the groups of a 32-lane half hit distinct banks
+  static constexpr int pick_stride() {
+    constexpr int per_half = (C::GROUPS >= 2) ? C::GROUPS / 2 : 1;
+    for (int s = 4 * C::K + 2;; s += 2) {
+      bool ok = true;
+      for (int a = 0; a < per_half && ok; ++a)
+        for (int b = a + 1; b < per_half; ++b)
+          if (((a * s) & 31) == ((b * s) & 31)) { ok = false; break; }
+      if (ok) return s;
+    }
+  }
+  static constexpr int STRIDE = pick_stride();
+  static constexpr int WORDS = STRIDE * C::GROUPS;
+};
+
+// per-modulus constants of the pair arithmetic (limb arrays, modulus-major)
+struct PairsetView {
+  const uint32_t* n_limbs;   // [count][K]
+  const uint32_t* n0inv;     // [count]
+  const uint32_t* one;       // [count][2K]  pair = R      (the form of 1)
+  const uint32_t* r2;        // [count][2K]  pair = R^2    (multiplying a plain pair by it gives its form)
+  const uint32_t* tp;        // [count][2K]  pair = 2^BITS R (the form of 2^BITS: Horner step over BITS-bit chunks)
+  const uint32_t* kc;        // [count][K]   -(R-1) mod N
+  int count;
+};
+
+// the shared tail of a CIOS pass: local ripple, then hand the lane's carry-out to the next lane without rippling on
+template <class C>
+__device__ __forceinline__ void cios_tail(uint32_t (&res)[C::L], const uint64_t (&c)[C::L], const Lane& ln) {
+  constexpr int L = C::L, W = C::W;
+  uint64_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    const uint64_t v = c[i] + carry;
+    res[i] = (uint32_t)v & C::MASK;
+    carry = v >> W;
+  }
+  uint64_t cin = pull_prev64(carry);
+  if (ln.t0) cin = 0;
+  const uint32_t v0 = res[0] + ((uint32_t)cin & C::MASK);
+  res[0] = v0 & C::MASK;                       // one extra ripple step: every limb < 2^W + 2^12
+  res[1] += (uint32_t)(cin >> W) + (v0 >> W);
+}
+
+// One CIOS pass with ONE product stream:  res = (c_in + a * b + m n) / R,  quotient digits m_j stored to ml[j].
+// (montmul of mpe_bigint.h with pre-loaded columns and the digits kept.)
+template <class C, bool STORE_M>
+__device__ __forceinline__ void cios1(uint32_t (&res)[C::L], uint64_t (&c)[C::L], const uint32_t (&a)[C::L],
+                                      const uint32_t* __restrict__ bl, uint32_t* __restrict__ ml,
+                                      const uint32_t (&n)[C::L], uint32_t n0inv, const Lane& ln) {
+  constexpr int L = C::L, W = C::W;
+  uint32_t maskv = C::MASK;
+  asm volatile("" : "+v"(maskv));
+#pragma unroll 1
+  for (int jj = 0; jj < C::TPI; ++jj) {
+    const uint32_t* bp = bl + jj * L;
+    uint32_t* mp = ml + jj * L;
+#pragma unroll
+    for (int r = 0; r < L; ++r) {
+      const uint32_t bj = bp[r];
+      c[r] += (uint64_t)a[0] * bj;
+      const uint32_t m = bcast0_masked<C::TPI>((uint32_t)c[r] * n0inv, maskv);
+      if (STORE_M) mp[r] = m;                    // every lane of the group writes the same word
+#pragma unroll
+      for (int i = 1; i < L; ++i) c[(r + i) % L] += (uint64_t)a[i] * bj;
+#pragma unroll
+      for (int i = 0; i < L; ++i) c[(r + i) % L] += (uint64_t)m * n[i];
+      c[(r + 1) % L] += c[r] >> W;
+      c[r] = (uint64_t)(pull_next((uint32_t)c[r]) & maskv);
+    }
+  }
+  cios_tail<C>(res, c, ln);
+}
+
+// (r0, r1) = (a0, a1) * (y0, y1) R^-1 in Z/N^2.  The group's LDS region holds y0 in B0 and y1 in B1; for a squaring
+// (sq: y == a) B1 holds 2 y0 instead, so that pass B is the single stream a1 * (2 a0).
+// Column bound: a pass-B column absorbs per lane block 18 x (2^59.01 + 2^58.01) (squaring: the doubled stream) or
+// 18 x 3 x 2^58.01 (two streams) plus the 2^30 pre-load and the fold carries: < 2^63.8.
+template <class C>
+__device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::L], const uint32_t (&a0)[C::L],
+                                        const uint32_t (&a1)[C::L], uint32_t* gl, const uint32_t (&n)[C::L],
+                                        uint32_t n0inv, bool sq, const Lane& ln) {
+  using PL = PairLds<C>;
+  constexpr int L = C::L;
+  uint64_t c[L];
+#pragma unroll
+  for (int i = 0; i < L; ++i) c[i] = 0;
+  cios1<C, true>(r0, c, a0, gl + PL::B0, gl + PL::M, n, n0inv, ln);           // pass A: u, digits -> M
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < L; ++i) c[i] = (uint64_t)(gl[PL::KC + ln.t * L + i] - gl[PL::M + ln.t * L + i]);
+  wave_lds_sync();
+  // u waits in the M region (its digits are consumed) so that pass B does not carry 18 more live registers
+#pragma unroll
+  for (int i = 0; i < L; ++i) gl[PL::M + ln.t * L + i] = r0[i];
+  if (sq) {
+    cios1<C, false>(r1, c, a1, gl + PL::B1, gl + PL::M, n, n0inv, ln);        // pass B: a1 * (2 a0) - m
+  } else {
+    // pass B as two single-stream passes (a two-stream loop body needs ~80 more VGPRs than the kernel has):
+    //   t = redc(a0 y1 - m),  r1 = redc(a1 y0) + t   (lazily normalised again by one local ripple)
+    uint32_t t[L];
+    cios1<C, false>(t, c, a0, gl + PL::B1, gl + PL::M, n, n0inv, ln);
+#pragma unroll
+    for (int i = 0; i < L; ++i) c[i] = 0;
+    cios1<C, false>(r1, c, a1, gl + PL::B0, gl + PL::M, n, n0inv, ln);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      const uint32_t v = r1[i] + t[i] + carry;
+      r1[i] = v & C::MASK;
+      carry = v >> C::W;
+    }
+    uint32_t cin = pull_prev(carry);                 // the value is < 4N << R: the top lane's carry-out is 0
+    if (ln.t0) cin = 0;
+    const uint32_t v0 = r1[0] + cin;
+    r1[0] = v0 & C::MASK;
+    r1[1] += v0 >> C::W;
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < L; ++i) r0[i] = gl[PL::M + ln.t * L + i];
+}
+
+template <class C>
+__device__ __forceinline__ void copy_pair_to_lds(uint32_t* gl, const uint32_t* __restrict__ src, const Lane& ln) {
+  using PL = PairLds<C>;
+#pragma unroll
+  for (int i = 0; i < C::L; ++i) {
+    gl[PL::B0 + ln.t + C::TPI * i] = src[ln.t + C::TPI * i];
+    gl[PL::B1 + ln.t + C::TPI * i] = src[C::K + ln.t + C::TPI * i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// constants: one group per modulus.  Everything comes from exact doublings of the pair (1, 0):
+//   after W K doublings the pair is R (= `one`), after W K + BITS it is 2^BITS R (= `tp`), after 2 W K it is R^2.
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(64) pairset_setup_kernel(int count, const uint32_t* __restrict__ moduli,
+                                                           uint32_t* __restrict__ n_limbs, uint32_t* __restrict__ n0inv_out,
+                                                           uint32_t* __restrict__ one, uint32_t* __restrict__ r2,
+                                                           uint32_t* __restrict__ tp, uint32_t* __restrict__ kc) {
+  __shared__ uint32_t lds[C::LDS_WORDS];
+  const Lane ln = make_lane<C>();
+  uint32_t* gl = lds + ln.g * C::STRIDE;
+  const int slot = blockIdx.x * C::GROUPS + ln.g;
+  const bool active = slot < count;
+  const int idx = active ? slot : count - 1;
+  stage_words<C>(gl, moduli + (size_t)idx * C::K32, ln);
+  wave_lds_sync();
+  uint32_t n[C::L];
+  limbs_from_words<C>(n, gl, ln);
+  const uint32_t w0 = gl[0];
+  uint32_t inv = w0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) inv *= 2u - w0 * inv;
+  const uint32_t n0inv = (0u - inv) & C::MASK;
+  wave_lds_sync();
+
+  int64_t x0[C::L], x1[C::L];
+#pragma unroll
+  for (int i = 0; i < C::L; ++i) { x0[i] = (ln.t == 0 && i == 0) ? 1 : 0; x1[i] = 0; }
+  auto store_pair = [&](uint32_t* dst) {
+    if (!active) return;
+#pragma unroll
+    for (int i = 0; i < C::L; ++i) {
+      dst[(size_t)idx * 2 * C::K + ln.t * C::L + i] = (uint32_t)x0[i];
+      dst[(size_t)idx * 2 * C::K + C::K + ln.t * C::L + i] = (uint32_t)x1[i];
+    }
+  };
+  constexpr int WK = C::W * C::K;
+#pragma unroll 1
+  for (int d = 1; d <= 2 * WK; ++d) {
+    // (x0, x1) <- 2 (x0, x1):  x0 = 2 x0 [- N, carry 1];  x1 = 2 x1 + carry [- N]
+#pragma unroll
+    for (int i = 0; i < C::L; ++i) x0[i] *= 2;
+    full_normalize<C>(x0, ln);
+    const bool cy = cmp_ge<C>(x0, n, ln);
+    if (cy) {
+#pragma unroll
+      for (int i = 0; i < C::L; ++i) x0[i] -= (int64_t)n[i];
+      full_normalize<C>(x0, ln);
+    }
+#pragma unroll
+    for (int i = 0; i < C::L; ++i) x1[i] *= 2;
+    if (cy && ln.t == 0) x1[0] += 1;
+    full_normalize<C>(x1, ln);
+    if (cmp_ge<C>(x1, n, ln)) {
+#pragma unroll
+      for (int i = 0; i < C::L; ++i) x1[i] -= (int64_t)n[i];
+      full_normalize<C>(x1, ln);
+    }
+    if (d == WK) {
+      store_pair(one);
+      // kc = -(R - 1) mod N = N + 1 - (R mod N), reduced
+      int64_t z[C::L];
+#pragma unroll
+      for (int i = 0; i < C::L; ++i) z[i] = (int64_t)n[i] - x0[i] + ((ln.t == 0 && i == 0) ? 1 : 0);
+      full_normalize<C>(z, ln);
+      if (cmp_ge<C>(z, n, ln)) {
+#pragma unroll
+        for (int i = 0; i < C::L; ++i) z[i] -= (int64_t)n[i];
+        full_normalize<C>(z, ln);
+      }
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < C::L; ++i) kc[(size_t)idx * C::K + ln.t * C::L + i] = (uint32_t)z[i];
+      }
+    }
+    if (d == WK + C::BITS) store_pair(tp);
+  }
+  store_pair(r2);
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < C::L; ++i) n_limbs[(size_t)idx * C::K + ln.t * C::L + i] = n[i];
+    if (ln.t0) n0inv_out[idx] = n0inv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exponentiation modulo modulus[mod(i)]^2:   out pair (z0 | z1, each K32 words, both in [0, N)) with
+//   z0 + z1 N = base^exp [* base2^exp2]  mod N^2        (pair_finish_kernel then forms that integer in place)
+// base rows may be any number of words (chunks of K32 words, Horner); phases as in modexp_kernel.
+// ---------------------------------------------------------------------------------------------
+enum PairPhase { PP_IN, PP_MONT, PP_TAB, PP_SQ, PP_MUL1, PP_MUL2, PP_FINAL, PP_DONE };
+
+template <class C>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) pair_modexp_kernel(int batch, PairsetView ps, Rows mod_sel, Rows base, Rows exps,
+                                                         int exp_words, int wb, Rows base2, Rows exps2, int exp2_words,
+                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ tables) {
+  using PL = PairLds<C>;
+  __shared__ uint32_t lds[PL::WORDS];
+  const Lane ln = make_lane<C>();
+  uint32_t* gl = lds + ln.g * PL::STRIDE;
+  constexpr int K2 = 2 * C::K;
+  const int slot = blockIdx.x * C::GROUPS + ln.g;
+  const int nslots = gridDim.x * C::GROUPS;
+  const bool dual = base2.p != nullptr;
+  const int TE = 1 << wb;
+  uint32_t* tab = tables + (size_t)slot * (TE + (dual ? 16 : 0)) * K2;
+  uint32_t* tab2 = tab + (size_t)TE * K2;
+  const int trips = (batch + nslots - 1) / nslots;
+  const int nwin = (exp_words * 32 + wb - 1) / wb;
+  const int nwin2 = dual ? exp2_words * 8 : 0;
+  const int top_bit = (nwin - 1) * wb;
+  const int words1 = base.words ? base.words : 2 * C::K32, words2 = base2.words ? base2.words : 2 * C::K32;
+
+#pragma unroll 1
+  for (int trip = 0; trip < trips; ++trip) {
+    const int inst = trip * nslots + slot;
+    const bool active = inst < batch;
+    const int idx = active ? inst : batch - 1;
+    const int mi = sel_index(mod_sel, idx);
+    const uint32_t* ex = row_of(exps, idx);
+    const uint32_t* ex2 = dual ? row_of(exps2, idx) : ex;
+
+    uint32_t n[C::L];
+    load_owner<C>(n, ps.n_limbs + (size_t)mi * C::K, ln);
+    const uint32_t n0inv = ps.n0inv[mi];
+    {
+      const uint32_t* kc = ps.kc + (size_t)mi * C::K;         // K_c + (R - 1), limb-wise, stays in LDS for the item
+#pragma unroll
+      for (int i = 0; i < C::L; ++i) gl[PL::KC + ln.t + C::TPI * i] = kc[ln.t + C::TPI * i] + C::MASK;
+      uint32_t t0[C::L], t1[C::L];                            // tab[0] = the form of 1
+      load_owner<C>(t0, ps.one + (size_t)mi * K2, ln);
+      load_owner<C>(t1, ps.one + (size_t)mi * K2 + C::K, ln);
+      store_owner<C>(tab, t0, ln);
+      store_owner<C>(tab + C::K, t1, ln);
+    }
+
+    uint32_t cur0[C::L], cur1[C::L];
+    int which = 0;                                            // 0: base / tab, 1: base2 / tab2
+    const uint32_t* bw = row_of(base, idx);
+    int kin = (words1 + C::K32 - 1) / C::K32 - 1;             // chunk being absorbed (Horner from the top)
+    load_words_as_limbs<C>(cur0, gl, bw + kin * C::K32, words1 - kin * C::K32, ln);
+#pragma unroll
+    for (int i = 0; i < C::L; ++i) cur1[i] = 0;
+    int ph = kin > 0 ? PP_IN : PP_MONT;
+    --kin;
+    int k = 0, b = top_bit;
+#pragma unroll 1
+    while (ph != PP_DONE) {
+      bool sq = false;
+      // ---- multiplier pair -> LDS ----
+      if (ph == PP_IN) {
+        copy_pair_to_lds<C>(gl, ps.tp + (size_t)mi * K2, ln);
+      } else if (ph == PP_MONT) {
+        copy_pair_to_lds<C>(gl, ps.r2 + (size_t)mi * K2, ln);
+      } else if (ph == PP_TAB) {
+        if (k == 1) { put_limbs<C>(gl + PL::B0, cur0, ln); put_limbs<C>(gl + PL::B1, cur1, ln); }
+      } else if (ph == PP_SQ) {
+        put_limbs<C>(gl + PL::B0, cur0, ln);
+#pragma unroll
+        for (int i = 0; i < C::L; ++i) gl[PL::B1 + ln.t * C::L + i] = cur0[i] << 1;
+        sq = true;
+      } else if (ph == PP_MUL1) {
+        const uint32_t w = exp_window(ex, exp_words, b / wb, wb);
+        copy_pair_to_lds<C>(gl, tab + (size_t)w * K2, ln);
+      } else if (ph == PP_MUL2) {
+        const int wi = b >> 2;
+        const uint32_t w = (ex2[wi >> 3] >> ((wi & 7) * 4)) & 15u;
+        copy_pair_to_lds<C>(gl, w ? tab2 + (size_t)w * K2 : tab, ln);
+      } else {                                                // PP_FINAL: times the plain pair (1, 0)
+#pragma unroll
+        for (int i = 0; i < C::L; ++i) {
+          gl[PL::B0 + ln.t * C::L + i] = (ln.t == 0 && i == 0) ? 1u : 0u;
+          gl[PL::B1 + ln.t * C::L + i] = 0u;
+        }
+      }
+      wave_lds_sync();
+      uint32_t r0[C::L], r1[C::L];
+      pairmul<C>(r0, r1, cur0, cur1, gl, n, n0inv, sq, ln);
+      wave_lds_sync();
+#pragma unroll
+      for (int i = 0; i < C::L; ++i) { cur0[i] = r0[i]; cur1[i] = r1[i]; }
+
+      // ---- product -> its place; next phase ----
+      bool tables_done = false;
+      if (ph == PP_IN) {
+        // x0 += chunk kin, exactly normalised (the value stays a small multiple of N)
+        uint32_t ch[C::L];
+        load_words_as_limbs<C>(ch, gl, bw + kin * C::K32, C::K32, ln);
+        int64_t z[C::L];
+#pragma unroll
+        for (int i = 0; i < C::L; ++i) z[i] = (int64_t)cur0[i] + (int64_t)ch[i];
+        full_normalize<C>(z, ln);
+#pragma unroll
+        for (int i = 0; i < C::L; ++i) cur0[i] = (uint32_t)z[i];
+        if (--kin < 0) ph = PP_MONT;
+      } else if (ph == PP_MONT) {
+        uint32_t* T = which ? tab2 : tab;
+        store_owner<C>(T + K2, cur0, ln);
+        store_owner<C>(T + K2 + C::K, cur1, ln);
+        k = 1;
+        ph = PP_TAB;
+      } else if (ph == PP_TAB) {
+        uint32_t* T = which ? tab2 : tab;
+        store_owner<C>(T + (size_t)(k + 1) * K2, cur0, ln);
+        store_owner<C>(T + (size_t)(k + 1) * K2 + C::K, cur1, ln);
+        if (++k > (which ? 14 : TE - 2)) {
+          if (!which && dual) {
+            which = 1;
+            bw = row_of(base2, idx);
+            kin = (words2 + C::K32 - 1) / C::K32 - 1;
+            load_words_as_limbs<C>(cur0, gl, bw + kin * C::K32, words2 - kin * C::K32, ln);
+#pragma unroll
+            for (int i = 0; i < C::L; ++i) cur1[i] = 0;
+            ph = kin > 0 ? PP_IN : PP_MONT;
+            --kin;
+          } else {
+            tables_done = true;
+          }
+        }
+      } else if (ph == PP_FINAL) {
+        ph = PP_DONE;
+      } else {
+        if (ph == PP_SQ) --b;
+        const bool m1 = ph == PP_SQ && (b % wb) == 0;
+        const bool m2 = ph != PP_MUL2 && dual && (b & 3) == 0 && (b >> 2) < nwin2;
+        ph = m1 ? PP_MUL1 : (m2 ? PP_MUL2 : (b == 0 ? PP_FINAL : PP_SQ));
+      }
+      if (tables_done) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const uint32_t w = exp_window(ex, exp_words, nwin - 1, wb);
+        load_owner<C>(cur0, tab + (size_t)w * K2, ln);
+        load_owner<C>(cur1, tab + (size_t)w * K2 + C::K, ln);
+        b = top_bit;
+        ph = b == 0 ? PP_FINAL : PP_SQ;
+      }
+    }
+    // canonical digits -> interface words z0 | z1
+    reduce_once<C>(cur0, n, ln);
+    reduce_once<C>(cur1, n, ln);
+    store_limbs_as_words<C>(out + (size_t)idx * 2 * C::K32, gl, cur0, active, ln);
+    store_limbs_as_words<C>(out + (size_t)idx * 2 * C::K32 + C::K32, gl, cur1, active, ln);
+  }
+}
+
+// out[i] (2H words) = z0 + z1 * N   (z0 | z1 as left by pair_modexp_kernel; one item per lane)
+template <int H>
+__global__ void pair_finish_kernel(int B, Rows mod_sel, const uint32_t* __restrict__ mod_words, uint32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  uint32_t z0[H], z1[H], nn[H], r[2 * H];
+  sm::copy(z0, out + (size_t)i * 2 * H, H);
+  sm::copy(z1, out + (size_t)i * 2 * H + H, H);
+  sm::copy(nn, mod_words + (size_t)sel_index(mod_sel, i) * H, H);
+  sm::mul(r, z1, H, nn, H);
+  sm::add(r, 2 * H, r, 2 * H, z0, H);
+  sm::copy(out + (size_t)i * 2 * H, r, 2 * H);
+}
+
+}  // namespace mpe
+
+// host side -------------------------------------------------------------------------------------
+struct mpe_pairset {
+  int half_bits = 0;     // bits of the modulus N (the arithmetic is modulo N^2)
+  int count = 0;
+  void* blob = nullptr;
+  uint32_t *n_limbs = nullptr, *n0inv = nullptr, *one = nullptr, *r2 = nullptr, *tp = nullptr, *kc = nullptr;
+  const uint32_t* mod_words = nullptr;   // [count][half_bits/32], owned by the caller (the key set)
+};
+
+namespace mpe {
+
+static void pairset_free(mpe_pairset* ps) {
+  if (!ps) return;
+  if (ps->blob) (void)hipFree(ps->blob);
+  delete ps;
+}
+
+template <class C>
+static int pairset_create_impl(int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st) {
+  mpe_pairset* ps = new (std::nothrow) mpe_pairset();
+  if (!ps) return MPE_E_NOMEM;
+  ps->half_bits = C::BITS;
+  ps->count = count;
+  ps->mod_words = d_moduli;
+  const size_t K = C::K, words = (size_t)count * (K + 1 + 3 * 2 * K + K);
+  hipError_t e = hipMalloc(&ps->blob, words * 4);
+  if (e != hipSuccess) { delete ps; mpe_set_error("hipMalloc(pairset)", e); return MPE_E_NOMEM; }
+  uint32_t* p = (uint32_t*)ps->blob;
+  ps->n_limbs = p; p += count * K;
+  ps->n0inv = p; p += count;
+  ps->one = p; p += count * 2 * K;
+  ps->r2 = p; p += count * 2 * K;
+  ps->tp = p; p += count * 2 * K;
+  ps->kc = p;
+  hipLaunchKernelGGL(pairset_setup_kernel<C>, dim3((count + C::GROUPS - 1) / C::GROUPS), dim3(64), 0, st, count, d_moduli,
+                     ps->n_limbs, ps->n0inv, ps->one, ps->r2, ps->tp, ps->kc);
+  e = hipGetLastError();
+  if (e != hipSuccess) { pairset_free(ps); mpe_set_error("pairset_setup_kernel", e); return MPE_E_HIP; }
+  *out = ps;
+  return MPE_OK;
+}
+
+static int pairset_create(int half_bits, int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st) {
+  if (half_bits == 2048) return pairset_create_impl<Cfg2048>(count, d_moduli, out, st);
+  if (half_bits == 1024) return pairset_create_impl<Cfg1024>(count, d_moduli, out, st);
+  return MPE_E_ARG;
+}
+
+template <class C>
+static int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
+                            Rows base2, Rows exps2, int exp2_words, uint32_t* d_out, hipStream_t st) {
+  const int need_w = (batch + C::GROUPS - 1) / C::GROUPS, cap = ctx->cus * ctx->modexp_waves_per_cu;
+  int grid = need_w;
+  if (need_w > cap) { const int trips = (need_w + cap - 1) / cap; grid = (need_w + trips - 1) / trips; }
+  int wb = exp_words <= 8 ? 4 : (exp_words < 48 ? 5 : 6);
+  if (ctx->window_bits) wb = ctx->window_bits;
+  const bool dual = base2.p != nullptr;
+  if (dual && (exp2_words <= 0 || 32 * exp2_words > ((exp_words * 32 + wb - 1) / wb - 1) * wb)) {
+    mpe_set_error_msg("pair modexp: the second exponent must be shorter than the first");
+    return MPE_E_ARG;
+  }
+  const size_t need = (size_t)grid * C::GROUPS * (((size_t)1 << wb) + (dual ? 16 : 0)) * 2 * C::K * sizeof(uint32_t);
+  if (need > ctx->tables_bytes) {
+    if (ctx->tables) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->tables); ctx->tables = nullptr; ctx->tables_bytes = 0; }
+    hipError_t e = hipMalloc(&ctx->tables, need);
+    if (e != hipSuccess) { mpe_set_error("hipMalloc(window tables)", e); return MPE_E_NOMEM; }
+    ctx->tables_bytes = need;
+  }
+  PairsetView v{ps->n_limbs, ps->n0inv, ps->one, ps->r2, ps->tp, ps->kc, ps->count};
+  prof_begin(ctx, st, 3, 2 * C::BITS, exp_words, batch, dual ? exp2_words : 0);
+  hipLaunchKernelGGL(pair_modexp_kernel<C>, dim3(grid), dim3(64), 0, st, batch, v, mod_sel, base, exps, exp_words, wb, base2,
+                     exps2, exp2_words, d_out, (uint32_t*)ctx->tables);
+  prof_end(ctx, st);
+  hipLaunchKernelGGL(pair_finish_kernel<C::K32>, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, mod_sel, ps->mod_words, d_out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mpe_set_error("pair_modexp_kernel", e); return MPE_E_HIP; }
+  ctx->last.waves = grid;
+  ctx->last.ints_per_wave = C::GROUPS;
+  ctx->last.limbs = 2 * C::K;
+  ctx->last.limb_bits = C::W;
+  ctx->last.lds_bytes_per_wave = PairLds<C>::WORDS * 4;
+  ctx->last.table_scratch_bytes = need;
+  return MPE_OK;
+}
+
+// base^exps [* base2^exps2] modulo the SQUARE of modulus mod_sel(i) of `ps`; out rows are 2 * half_bits/32 words
+static int launch_pair_modexp(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
+                              Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st) {
+  if (batch == 0) return MPE_OK;
+  if (ps->half_bits == 2048)
+    return pair_modexp_impl<Cfg2048>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, out, st);
+  if (ps->half_bits == 1024)
+    return pair_modexp_impl<Cfg1024>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, out, st);
+  return MPE_E_ARG;
+}
+
+}  // namespace mpe

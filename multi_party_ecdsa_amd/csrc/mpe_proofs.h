@@ -218,9 +218,9 @@ struct Seq {
     if (rc == MPE_OK) rc = mpe::modexp_nn(ctx, pk, B, sel, base, exps, ew, holder, o, st);
     return o;
   }
-  uint32_t* modexp2(const mpe_modset* ms, Rows sel, Rows base, Rows exps, int ew, Rows base2, Rows exps2, int ew2) {
-    uint32_t* o = words(ms->bits / 32);
-    if (rc == MPE_OK) rc = launch_modexp2(ctx, ms, B, sel, base, exps, ew, base2, exps2, ew2, o, st);
+  uint32_t* modexp_nn2(const mpe_paillier* pk, Rows sel, Rows base, Rows exps, int ew, Rows base2, Rows exps2, int ew2) {
+    uint32_t* o = words(128);
+    if (rc == MPE_OK) rc = mpe::modexp_nn2(ctx, pk, B, sel, base, exps, ew, base2, exps2, ew2, o, st);
     return o;
   }
   uint32_t* modmul(const mpe_modset* ms, Rows sel, Rows a, Rows b) {
@@ -336,7 +336,7 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
     // (c^e)^-1 = (c^-1)^e: invert first, then s^N (c^-1)^e on one ladder (the 256 squarings of c^e are shared)
     uint32_t* cred = q.modmul(pk->ms_nn, ksel, cipher, rows(pk->ms_nn->one_words, 0, nullptr, 1));   // c mod N^2
     uint32_t* cinv = q.modinv(pk->ms_nn, ksel, rows(cred, 128), inv_ok2);
-    uint32_t* m = q.modexp2(pk->ms_nn, ksel, with_words(pr.s, 64), Nrow, 64, rows(cinv, 128), pr.e, 8);
+    uint32_t* m = q.modexp_nn2(pk, ksel, with_words(pr.s, 64), Nrow, 64, rows(cinv, 128), pr.e, 8);
     u = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(m, 128));
   } else {
     uint32_t* ce = q.modexp(pk->ms_nn, ksel, cipher, pr.e, 8);
@@ -429,7 +429,7 @@ static int pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   uint32_t* cinv = q.modinv(pk->ms_nn, ksel, rows(cred, 128), inv_ok1);
   uint32_t* u2;
   if (ctx->use_multiexp) {
-    uint32_t* m = q.modexp2(pk->ms_nn, ksel, with_words(pr.s2, 64), Nrow, 64, rows(cinv, 128), rows(e, 8), 8);
+    uint32_t* m = q.modexp_nn2(pk, ksel, with_words(pr.s2, 64), Nrow, 64, rows(cinv, 128), rows(e, 8), 8);
     u2 = q.modmul(pk->ms_nn, ksel, rows(g1, 128), rows(m, 128));
   } else {
     uint32_t* s2n = q.modexp(pk->ms_nn, ksel, with_words(pr.s2, 64), Nrow, 64);
