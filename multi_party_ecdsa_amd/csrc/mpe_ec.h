@@ -157,7 +157,11 @@ __device__ inline U256 fe_pow(const U256& a, const uint32_t* e) {   // a^e, e: 8
   }
   return r;
 }
-__device__ inline U256 fe_sqrn(U256 x, int n) { for (int i = 0; i < n; ++i) x = fe_sqr(x); return x; }
+__device__ inline U256 fe_sqrn(U256 x, int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) x = fe_sqr(x);
+  return x;
+}
 // a^(p-2): p - 2 = 1^223 0 1^22 0000 101101 in binary; addition chain with 255 squarings + 15 multiplications
 __device__ inline U256 fe_inv(const U256& a) {
   const U256 x2 = fe_mul(fe_sqr(a), a), x3 = fe_mul(fe_sqr(x2), a);
@@ -304,6 +308,7 @@ __device__ inline Jac jac_mul(const U256& k, const Aff& P) {
   tab[1] = jac_from_aff(P);
   for (int i = 2; i < 16; ++i) tab[i] = (i & 1) ? jac_add(tab[i - 1], tab[1]) : jac_dbl(tab[i >> 1]);
   Jac acc = jac_inf();
+#pragma unroll 1
   for (int wi = 63; wi >= 0; --wi) {
     acc = jac_dbl(jac_dbl(jac_dbl(jac_dbl(acc))));
     const uint32_t d = (k.w[wi >> 3] >> ((wi & 7) * 4)) & 15u;
@@ -318,7 +323,7 @@ __device__ __forceinline__ Aff aff_h2() { Aff g; g.x = u256_load(H2X); g.y = u25
 // k*G is then 64 mixed additions and no doublings; the additions always run (digit 0 adds a dummy and
 // keeps the old accumulator), so the operation sequence does not depend on the scalar.
 __device__ uint32_t COMB[2][64][15][16];
-__global__ void ec_comb_build_kernel() {
+__global__ void __launch_bounds__(64) ec_comb_build_kernel() {
   const int w = threadIdx.x & 63, g = blockIdx.x;
   if (g > 1) return;
   Jac b = jac_from_aff(g ? aff_h2() : aff_gen());
@@ -332,8 +337,9 @@ __global__ void ec_comb_build_kernel() {
   }
 }
 // k*G (g = 0) or k*base_point2 (g = 1), k already reduced mod q
-__device__ inline Jac jac_mul_fixed(const U256& k, int g) {
+__device__ __noinline__ Jac jac_mul_fixed(const U256& k, int g) {
   Jac acc = jac_inf();
+#pragma unroll 1
   for (int w = 0; w < 64; ++w) {
     const uint32_t d = (k.w[w >> 3] >> ((w & 7) * 4)) & 15u;
     const uint32_t* e = COMB[g][w][d ? d - 1 : 0];
@@ -381,7 +387,7 @@ __device__ inline void sha_init(Sha256& s) {
   for (int i = 0; i < 16; ++i) s.buf[i] = 0;
   s.len = 0;
 }
-__device__ inline void sha_block(Sha256& s) {
+__device__ __noinline__ void sha_block(Sha256& s) {     // out of line: every sha_byte site would otherwise carry a copy
   uint32_t w[64];
   for (int i = 0; i < 16; ++i) w[i] = s.buf[i];
   for (int i = 16; i < 64; ++i) {

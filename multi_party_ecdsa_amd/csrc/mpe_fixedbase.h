@@ -19,7 +19,7 @@ constexpr int FB_WB = MPE_FB_WB;                               // window bits (4
 constexpr int FB_TE = 1 << FB_WB;                              // table entries per window
 constexpr int FB_PER_WORD = 32 / FB_WB;
 constexpr int FB_MAX_WINDOWS = 89 * FB_PER_WORD;               // exponents up to 89 words (s2, s3 < 2^2817)
-static_assert(FB_WB == 4 || FB_WB == 8, "fixed-base windows must divide a word");
+static_assert(FB_WB == 4 || FB_WB == 8 || FB_WB == 16, "fixed-base windows must divide a word");
 
 __device__ __forceinline__ uint32_t fb_digit(const uint32_t* __restrict__ ex, int i) {
   return (ex[i / FB_PER_WORD] >> ((i % FB_PER_WORD) * FB_WB)) & (uint32_t)(FB_TE - 1);

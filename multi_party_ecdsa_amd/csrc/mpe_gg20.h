@@ -117,7 +117,7 @@ __device__ __forceinline__ ec::Aff add_aff(const ec::Aff& a, const ec::Aff& b) {
 }
 
 // ---- Round 0: SignKeys::create + phase1_broadcast (party_i.rs:546-589) ----------------------------
-__global__ void r0_kernel(Dim d, const int32_t* __restrict__ signers, const uint32_t* __restrict__ xs,
+__global__ void __launch_bounds__(64) r0_kernel(Dim d, const int32_t* __restrict__ signers, const uint32_t* __restrict__ xs,
                           const uint32_t* __restrict__ k_in, const uint32_t* __restrict__ gamma_in,
                           const uint32_t* __restrict__ blind, uint32_t* __restrict__ kq, uint32_t* __restrict__ gq,
                           uint32_t* __restrict__ w, uint32_t* __restrict__ k64, uint32_t* __restrict__ g_gamma,
@@ -153,7 +153,7 @@ __global__ void mb_prep_kernel(Dim d, const uint32_t* __restrict__ gq, const uin
 
 // ---- Round 2a: MessageB::verify_proofs_get_alpha after the decryption (mta/mod.rs:166-178, rounds.rs:281) ----
 struct MsgB { const uint32_t *pk, *R, *z, *tpk, *tR, *tz; };   // [mb] b_proof / beta_tag_proof
-__global__ void r2a_kernel(Dim d, const int32_t* __restrict__ mbin_rv, const uint32_t* __restrict__ alpha_full,
+__global__ void __launch_bounds__(64) r2a_kernel(Dim d, const int32_t* __restrict__ mbin_rv, const uint32_t* __restrict__ alpha_full,
                            const uint32_t* __restrict__ kq, MsgB m, const uint32_t* __restrict__ g_w,
                            uint32_t* __restrict__ alpha, uint8_t* __restrict__ ok) {
   const int rv = blockIdx.x * blockDim.x + threadIdx.x;
@@ -180,7 +180,7 @@ __global__ void r2a_kernel(Dim d, const int32_t* __restrict__ mbin_rv, const uin
 
 // ---- Round 2b: delta_i, sigma_i, T_i + PedersenProof::prove (party_i.rs:591-634) -------------------
 struct Ped { uint32_t *T, *a1, *a2, *z1, *z2; };       // [pi]
-__global__ void r2b_kernel(Dim d, const uint32_t* __restrict__ kq, const uint32_t* __restrict__ gq,
+__global__ void __launch_bounds__(64) r2b_kernel(Dim d, const uint32_t* __restrict__ kq, const uint32_t* __restrict__ gq,
                            const uint32_t* __restrict__ w, const uint32_t* __restrict__ alpha,
                            const uint32_t* __restrict__ beta, const uint32_t* __restrict__ l_in,
                            const uint32_t* __restrict__ s1_in, const uint32_t* __restrict__ s2_in,
@@ -213,7 +213,7 @@ __global__ void r2b_kernel(Dim d, const uint32_t* __restrict__ kq, const uint32_
 }
 
 // ---- Round 3: every party verifies every PedersenProof, reconstructs delta^-1 (rounds.rs:347-402) ---
-__global__ void r3_kernel(Dim d, const uint32_t* __restrict__ delta_i, Ped p, uint32_t* __restrict__ dinv, uint8_t* __restrict__ ok) {
+__global__ void __launch_bounds__(64) r3_kernel(Dim d, const uint32_t* __restrict__ delta_i, Ped p, uint32_t* __restrict__ dinv, uint8_t* __restrict__ ok) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.S) return;
   const int b = pi / d.S;
@@ -236,7 +236,7 @@ __global__ void r3_kernel(Dim d, const uint32_t* __restrict__ delta_i, Ped p, ui
 }
 
 // ---- Round 4: phase4 -> R, R_dash (party_i.rs:642-687, rounds.rs:452) --------------------------------
-__global__ void r4_kernel(Dim d, const uint32_t* __restrict__ dinv, const uint32_t* __restrict__ g_gamma,
+__global__ void __launch_bounds__(64) r4_kernel(Dim d, const uint32_t* __restrict__ dinv, const uint32_t* __restrict__ g_gamma,
                           const uint32_t* __restrict__ com, const uint32_t* __restrict__ blind, const uint32_t* __restrict__ Bpk,
                           const uint32_t* __restrict__ kq, uint32_t* __restrict__ R, uint32_t* __restrict__ Rbar,
                           uint8_t* __restrict__ ok) {
@@ -262,7 +262,7 @@ __global__ void r4_kernel(Dim d, const uint32_t* __restrict__ dinv, const uint32
 
 // ---- Round 5: R_dash sum, S_i and HomoELGamalProof::prove (party_i.rs:768-799) ------------------------
 struct Heg { uint32_t *S, *T, *A3, *z1, *z2; };      // [pi]
-__global__ void r5_kernel(Dim d, const uint8_t* __restrict__ pdl_ok, const uint32_t* __restrict__ R,
+__global__ void __launch_bounds__(64) r5_kernel(Dim d, const uint8_t* __restrict__ pdl_ok, const uint32_t* __restrict__ R,
                           const uint32_t* __restrict__ Rbar, const uint32_t* __restrict__ sigma_i, const uint32_t* __restrict__ lq,
                           const uint32_t* __restrict__ pedT, const uint32_t* __restrict__ s1_in, const uint32_t* __restrict__ s2_in,
                           Heg h, uint8_t* __restrict__ ok) {
@@ -293,7 +293,7 @@ __global__ void r5_kernel(Dim d, const uint8_t* __restrict__ pdl_ok, const uint3
 }
 
 // ---- Round 6: every party verifies every HomoELGamalProof; sum S_i == y (party_i.rs:801-848) --------------
-__global__ void r6_kernel(Dim d, const uint32_t* __restrict__ R, const uint32_t* __restrict__ pedT, Heg h,
+__global__ void __launch_bounds__(64) r6_kernel(Dim d, const uint32_t* __restrict__ R, const uint32_t* __restrict__ pedT, Heg h,
                           const uint32_t* __restrict__ y, uint8_t* __restrict__ ok) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.S) return;
@@ -320,7 +320,7 @@ __global__ void r6_kernel(Dim d, const uint32_t* __restrict__ R, const uint32_t*
 
 // ---- Round 7: local signatures, output_signature, verify (party_i.rs:850-936) -------------------------------
 struct Flags { const uint8_t *vi, *rv, *r3, *r4, *r5, *r6; };
-__global__ void r7_kernel(Dim d, Flags f, const uint32_t* __restrict__ msg, const uint32_t* __restrict__ R,
+__global__ void __launch_bounds__(64) r7_kernel(Dim d, Flags f, const uint32_t* __restrict__ msg, const uint32_t* __restrict__ R,
                           const uint32_t* __restrict__ kq, const uint32_t* __restrict__ sigma_i, const uint32_t* __restrict__ y,
                           uint32_t* __restrict__ r_out, uint32_t* __restrict__ s_out, int32_t* __restrict__ recid_out,
                           uint32_t* __restrict__ R_out, int32_t* __restrict__ status) {

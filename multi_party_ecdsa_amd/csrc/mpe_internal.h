@@ -44,6 +44,15 @@ struct mpe_modset {
   uint32_t* one_words = nullptr;  // [1]          the constant 1 (a 1-word operand: x * 1 mod n reduces x)
 };
 
+// per-modulus constants of the N-adic pair arithmetic modulo N^2 (mpe_pairexp.h)
+struct mpe_pairset {
+  int half_bits = 0;     // bits of the modulus N (the arithmetic is modulo N^2)
+  int count = 0;
+  void* blob = nullptr;
+  uint32_t *n_limbs = nullptr, *n0inv = nullptr, *one = nullptr, *r2 = nullptr, *tp = nullptr, *kc = nullptr;
+  const uint32_t* mod_words = nullptr;   // [count][half_bits/32], owned by the caller (the key set)
+};
+
 void mpe_set_error(const char* what, hipError_t e);
 void mpe_set_error_msg(const char* what);
 
@@ -63,6 +72,18 @@ int launch_modexp2(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, 
 int launch_modmul(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows a, Rows b, uint32_t* out,
                   hipStream_t st);
 int modset_create_dev(mpe_ctx* ctx, int bits, int count, const uint32_t* d_moduli, mpe_modset** out, hipStream_t st);
+
+// per-launch timing records (mpe_prof_*), defined in mpe_lib.hip
+void prof_begin(mpe_ctx* ctx, hipStream_t st, int kind, int bits, int exp_words, int batch, int exp2_words = 0);
+void prof_end(mpe_ctx* ctx, hipStream_t st);
+
+// N-adic pair engine (mpe_pair2048.hip / mpe_pair1024.hip)
+int pairset_create_2048(int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st);
+int pairset_create_1024(int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st);
+int pair_modexp_2048(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
+                     Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st);
+int pair_modexp_1024(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
+                     Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st);
 
 // workspace: reserve once per composite call (may reallocate -> synchronises the stream), then bump-allocate
 int ws_reserve(mpe_ctx* ctx, size_t bytes, hipStream_t st);

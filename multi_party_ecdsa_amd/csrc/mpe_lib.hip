@@ -30,7 +30,7 @@ void* ws_alloc(mpe_ctx* ctx, size_t bytes) {
   return (char*)ctx->ws + off;
 }
 
-static void prof_begin(mpe_ctx* ctx, hipStream_t st, int kind, int bits, int exp_words, int batch, int exp2_words = 0) {
+void prof_begin(mpe_ctx* ctx, hipStream_t st, int kind, int bits, int exp_words, int batch, int exp2_words) {
   if (!ctx->prof_on) return;
   mpe_ctx::ProfEvt ev;
   ev.kind = kind; ev.bits = bits; ev.exp_words = exp_words; ev.batch = batch; ev.exp2_words = exp2_words;
@@ -39,7 +39,7 @@ static void prof_begin(mpe_ctx* ctx, hipStream_t st, int kind, int bits, int exp
   (void)hipEventRecord(ev.a, st);
   ctx->prof.push_back(ev);
 }
-static void prof_end(mpe_ctx* ctx, hipStream_t st) {
+void prof_end(mpe_ctx* ctx, hipStream_t st) {
   if (ctx->prof_on && !ctx->prof.empty()) (void)hipEventRecord(ctx->prof.back().b, st);
 }
 
@@ -180,7 +180,28 @@ static Rows mod_selector(const mpe_modset* ms, const int32_t* d_mod_idx) {
 }  // namespace mpe
 
 #include "mpe_small.h"
-#include "mpe_pairexp.h"
+
+namespace mpe {
+// N-adic pair engine: dispatch on the width of the modulus (the kernels live in their own translation units)
+static void pairset_free(mpe_pairset* ps) {
+  if (!ps) return;
+  if (ps->blob) (void)hipFree(ps->blob);
+  delete ps;
+}
+static int pairset_create(int half_bits, int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st) {
+  if (half_bits == 2048) return pairset_create_2048(count, d_moduli, out, st);
+  if (half_bits == 1024) return pairset_create_1024(count, d_moduli, out, st);
+  return MPE_E_ARG;
+}
+// base^exps [* base2^exps2] modulo the SQUARE of modulus mod_sel(i) of `ps`; out rows are 2 * half_bits/32 words
+static int launch_pair_modexp(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
+                              Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st) {
+  if (batch == 0) return MPE_OK;
+  if (ps->half_bits == 2048) return pair_modexp_2048(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, out, st);
+  if (ps->half_bits == 1024) return pair_modexp_1024(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, out, st);
+  return MPE_E_ARG;
+}
+}  // namespace mpe
 #include "mpe_paillier.h"
 #include "mpe_proofs.h"
 #include "mpe_mta.h"

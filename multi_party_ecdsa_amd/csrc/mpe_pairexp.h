@@ -16,6 +16,7 @@
 // mpz_powm returns: the pair is converted back (multiply by (1, 0), normalise, z0 + z1 N) at the end.
 #pragma once
 #include "mpe_internal.h"
+#include "mpe_small.h"
 
 namespace mpe {
 
@@ -419,25 +420,11 @@ __global__ void pair_finish_kernel(int B, Rows mod_sel, const uint32_t* __restri
 
 }  // namespace mpe
 
-// host side -------------------------------------------------------------------------------------
-struct mpe_pairset {
-  int half_bits = 0;     // bits of the modulus N (the arithmetic is modulo N^2)
-  int count = 0;
-  void* blob = nullptr;
-  uint32_t *n_limbs = nullptr, *n0inv = nullptr, *one = nullptr, *r2 = nullptr, *tp = nullptr, *kc = nullptr;
-  const uint32_t* mod_words = nullptr;   // [count][half_bits/32], owned by the caller (the key set)
-};
-
+// host side: template implementations, instantiated by mpe_pair2048.hip / mpe_pair1024.hip ----------------
 namespace mpe {
 
-static void pairset_free(mpe_pairset* ps) {
-  if (!ps) return;
-  if (ps->blob) (void)hipFree(ps->blob);
-  delete ps;
-}
-
 template <class C>
-static int pairset_create_impl(int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st) {
+int pairset_create_impl(int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st) {
   mpe_pairset* ps = new (std::nothrow) mpe_pairset();
   if (!ps) return MPE_E_NOMEM;
   ps->half_bits = C::BITS;
@@ -456,19 +443,13 @@ static int pairset_create_impl(int count, const uint32_t* d_moduli, mpe_pairset*
   hipLaunchKernelGGL(pairset_setup_kernel<C>, dim3((count + C::GROUPS - 1) / C::GROUPS), dim3(64), 0, st, count, d_moduli,
                      ps->n_limbs, ps->n0inv, ps->one, ps->r2, ps->tp, ps->kc);
   e = hipGetLastError();
-  if (e != hipSuccess) { pairset_free(ps); mpe_set_error("pairset_setup_kernel", e); return MPE_E_HIP; }
+  if (e != hipSuccess) { (void)hipFree(ps->blob); delete ps; mpe_set_error("pairset_setup_kernel", e); return MPE_E_HIP; }
   *out = ps;
   return MPE_OK;
 }
 
-static int pairset_create(int half_bits, int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st) {
-  if (half_bits == 2048) return pairset_create_impl<Cfg2048>(count, d_moduli, out, st);
-  if (half_bits == 1024) return pairset_create_impl<Cfg1024>(count, d_moduli, out, st);
-  return MPE_E_ARG;
-}
-
 template <class C>
-static int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
+int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
                             Rows base2, Rows exps2, int exp2_words, uint32_t* d_out, hipStream_t st) {
   const int need_w = (batch + C::GROUPS - 1) / C::GROUPS, cap = ctx->cus * ctx->modexp_waves_per_cu;
   int grid = need_w;
@@ -502,17 +483,6 @@ static int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows
   ctx->last.lds_bytes_per_wave = PairLds<C>::WORDS * 4;
   ctx->last.table_scratch_bytes = need;
   return MPE_OK;
-}
-
-// base^exps [* base2^exps2] modulo the SQUARE of modulus mod_sel(i) of `ps`; out rows are 2 * half_bits/32 words
-static int launch_pair_modexp(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
-                              Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st) {
-  if (batch == 0) return MPE_OK;
-  if (ps->half_bits == 2048)
-    return pair_modexp_impl<Cfg2048>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, out, st);
-  if (ps->half_bits == 1024)
-    return pair_modexp_impl<Cfg1024>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, out, st);
-  return MPE_E_ARG;
 }
 
 }  // namespace mpe
