@@ -126,7 +126,7 @@ static int bob_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   uint32_t* me = q.modexp_nn(pk, ksel, rows(mta_enc, 128), pr.e, 8, true);
   uint32_t* mei = q.modinv(pk->ms_nn, ksel, rows(me, 128), ok2);
   uint32_t* as1 = q.modexp_nn(pk, ksel, rows(a_enc, 128), pr.s1, 25, true);
-  uint32_t* sn = q.modexp_nn(pk, ksel, with_words(pr.s, 64), Nrow, 64, true);
+  uint32_t* sn = q.modexp_nn(pk, ksel, with_words(pr.s, 64), Nrow, 64, true, true);
   uint32_t* tN = q.modmul(pk->ms_nn, ksel, with_words(pr.t1, 81), with_words(Nrow, 64));
   uint32_t* g1 = q.words(128);
   if (q.rc == MPE_OK)

@@ -13,6 +13,7 @@ struct mpe_ctx {
   int device = 0;
   int cus = 256;
   int window_bits = 0;            // 0 = choose per exponent length (4/5/6); 4..6 = force (A/B runs)
+  bool use_pown = true;           // key holders: x^N mod p^2 as (x^(q mod (p-1)) mod p)^p (mpe_paillier.h modexp_nn)
   bool use_pair = true;           // arithmetic modulo N^2 / p^2 in N-adic pair form (mpe_pairexp.h): half the multiplies
   bool use_multiexp = true;       // verifiers: s^N * (c^-1)^e on one ladder instead of two exponentiations (same residue)
   bool use_crt = true;            // key holders compute x^e mod N^2 through p^2 | q^2 (mpe_paillier.h modexp_nn)
@@ -81,9 +82,9 @@ void prof_end(mpe_ctx* ctx, hipStream_t st);
 int pairset_create_2048(int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st);
 int pairset_create_1024(int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st);
 int pair_modexp_2048(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
-                     Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st);
+                     Rows base2, Rows exps2, int exp2_words, int half, uint32_t* out, hipStream_t st);
 int pair_modexp_1024(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
-                     Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st);
+                     Rows base2, Rows exps2, int exp2_words, int half, uint32_t* out, hipStream_t st);
 
 // workspace: reserve once per composite call (may reallocate -> synchronises the stream), then bump-allocate
 int ws_reserve(mpe_ctx* ctx, size_t bytes, hipStream_t st);

@@ -194,11 +194,14 @@ static int pairset_create(int half_bits, int count, const uint32_t* d_moduli, mp
   return MPE_E_ARG;
 }
 // base^exps [* base2^exps2] modulo the SQUARE of modulus mod_sel(i) of `ps`; out rows are 2 * half_bits/32 words
+// half != 0: plain exponentiation modulo the modulus itself (out rows keep the 2 * half_bits/32 layout, value < N)
 static int launch_pair_modexp(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
-                              Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st) {
+                              Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st, int half = 0) {
   if (batch == 0) return MPE_OK;
-  if (ps->half_bits == 2048) return pair_modexp_2048(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, out, st);
-  if (ps->half_bits == 1024) return pair_modexp_1024(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, out, st);
+  if (ps->half_bits == 2048)
+    return pair_modexp_2048(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st);
+  if (ps->half_bits == 1024)
+    return pair_modexp_1024(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st);
   return MPE_E_ARG;
 }
 }  // namespace mpe
@@ -228,6 +231,7 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   if (getenv("MPE_NO_CRT")) c->use_crt = false;
   if (getenv("MPE_NO_MULTIEXP")) c->use_multiexp = false;
   if (getenv("MPE_NO_PAIR")) c->use_pair = false;
+  if (getenv("MPE_NO_POWN")) c->use_pown = false;
   if (getenv("MPE_WINDOW_BITS")) { const int w = atoi(getenv("MPE_WINDOW_BITS")); if (w >= 4 && w <= 6) c->window_bits = w; }
   // comb tables of the two fixed secp256k1 generators (module globals of this device; identical on every call)
   hipLaunchKernelGGL(mpe::ec::ec_comb_build_kernel, dim3(2), dim3(64), 0, 0);

@@ -31,6 +31,7 @@ struct mpe_paillier {
   uint32_t* inv2 = nullptr;   // [2nk][32]  p^-1 | q^-1 mod 2^1024
   uint32_t* h64 = nullptr;    // [2nk][64]  h_p | h_q
   uint32_t* ab64 = nullptr;   // [2nk][64]  q (q^-1 mod p) | p (p^-1 mod q): the CRT idempotents mod N
+  uint32_t* eq1 = nullptr;    // [2nk][32]  q mod (p-1) | p mod (q-1): x^N = (x^eq1 mod p)^p  (mod p^2)
   uint32_t* ecrt = nullptr;   // [2nk][64]  p(p-1)-1 | q(q-1)-1: the inverting exponent mod p^2 | q^2
   uint32_t* e128 = nullptr;   // [2nk][128] q^2 (q^-2 mod p^2) | p^2 (p^-2 mod q^2): the CRT idempotents mod N^2
   int32_t* swap_idx = nullptr;  // [2nk]    j ^ 1
@@ -59,7 +60,7 @@ __global__ void pk_square_kernel(int nk, const uint32_t* __restrict__ N, uint32_
 __global__ void sk_setup_a_kernel(int nk, const uint32_t* __restrict__ p, const uint32_t* __restrict__ q,
                                   uint32_t* __restrict__ N, uint32_t* __restrict__ pq32, uint32_t* __restrict__ pq64,
                                   uint32_t* __restrict__ sq64, uint32_t* __restrict__ em1, uint32_t* __restrict__ em2,
-                                  uint32_t* __restrict__ inv2, uint32_t* __restrict__ ecrt,
+                                  uint32_t* __restrict__ inv2, uint32_t* __restrict__ ecrt, uint32_t* __restrict__ eq1,
                                   int32_t* __restrict__ swap_idx) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= 2 * nk) return;
@@ -74,6 +75,13 @@ __global__ void sk_setup_a_kernel(int nk, const uint32_t* __restrict__ p, const 
   sm::copy(sq64 + (size_t)j * 64, r, 64);
   sm::sub(t1, 32, x, 32, one, 1);
   sm::copy(em1 + (size_t)j * 32, t1, 32);
+  {                                                // other prime mod (own - 1): at most two subtractions
+    uint32_t e[32];
+    sm::copy(e, y, 32);
+    for (int it = 0; it < 3; ++it)
+      if (sm::cmp(e, 32, t1, 32) >= 0) sm::sub(e, 32, e, 32, t1, 32);
+    sm::copy(eq1 + (size_t)j * 32, e, 32);
+  }
   sm::mul(r, x, 32, t1, 32);                       // phi(x^2) = x (x - 1)
   sm::sub(r, 64, r, 64, one, 1);
   sm::copy(ecrt + (size_t)j * 64, r, 64);
@@ -216,7 +224,7 @@ static int paillier_create(mpe_ctx* ctx, int nk, const uint32_t* d_N, const uint
   pk->has_private = d_p != nullptr;
   const size_t nk2 = 2 * (size_t)nk;
   size_t words = (size_t)nk * (64 + 128);
-  if (pk->has_private) words += nk2 * (32 + 64 + 64 + 32 + 32 + 32 + 64 + 64 + 64 + 128 + 1);
+  if (pk->has_private) words += nk2 * (32 + 64 + 64 + 32 + 32 + 32 + 64 + 64 + 64 + 128 + 32 + 1);
   hipError_t e = hipMalloc(&pk->blob, words * 4);
   if (e != hipSuccess) { delete pk; mpe_set_error("hipMalloc(paillier keys)", e); return MPE_E_NOMEM; }
   uint32_t* w = (uint32_t*)pk->blob;
@@ -234,10 +242,11 @@ static int paillier_create(mpe_ctx* ctx, int nk, const uint32_t* d_N, const uint
     pk->h64 = w; w += nk2 * 64;
     pk->ab64 = w; w += nk2 * 64;
     pk->ecrt = w; w += nk2 * 64;
+    pk->eq1 = w; w += nk2 * 32;
     pk->e128 = w; w += nk2 * 128;
     pk->swap_idx = (int32_t*)w; w += nk2;
     hipLaunchKernelGGL(sk_setup_a_kernel, dim3(blocks_for((int)nk2, 64)), dim3(64), 0, st, nk, d_p, d_q, pk->N, pk->pq32,
-                       pk->pq64, pk->sq64, pk->em1, pk->em2, pk->inv2, pk->ecrt, pk->swap_idx);
+                       pk->pq64, pk->sq64, pk->em1, pk->em2, pk->inv2, pk->ecrt, pk->eq1, pk->swap_idx);
     if ((rc = modset_create_dev(ctx, 2048, (int)nk2, pk->sq64, &pk->ms_pp, st)) != MPE_OK) return fail(rc);
     if ((rc = modset_create_dev(ctx, 2048, (int)nk2, pk->pq64, &pk->ms_p, st)) != MPE_OK) return fail(rc);
     // (other prime)^(own-2) mod own = (other prime)^-1 mod own   (Fermat; own is prime)
@@ -283,8 +292,11 @@ constexpr size_t CRT_WS_WORDS = 2 + 2 * 64 + 2 * 128 + 192;
 
 // base^exps mod N_k^2.  holder = the caller is the owner of the key (it may use p and q): the two halves
 // mod p^2 | q^2 on the 2048-bit engine, then  x = x_p E_p + x_q E_q mod N^2.  Same residue as the direct form.
+// pow_n: the exponent is N itself.  Then x^N = (x^q)^p and x^q = a (mod p) with a = x^(q mod (p-1)) mod p gives
+// x^N = a^p (mod p^2): a 1024-bit exponentiation modulo p (one pass per squaring) and one modulo p^2 (two passes)
+// instead of a 2048-bit one modulo p^2 — a quarter less work, the same residue.
 static int modexp_nn(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Rows base, Rows exps, int ew, bool holder,
-                     uint32_t* out, hipStream_t st) {
+                     uint32_t* out, hipStream_t st, bool pow_n = false) {
   if (!(holder && pk->has_private && ctx->use_crt)) {
     if (ctx->use_pair) return launch_pair_modexp(ctx, pk->ps_nn, B, ksel, base, exps, ew, no_rows(), no_rows(), 0, out, st);
     return launch_modexp(ctx, pk->ms_nn, B, ksel, base, no_rows(), exps, ew, out, st);
@@ -299,7 +311,13 @@ static int modexp_nn(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Row
   Rows lo{base.p, base.idx, base.stride, bw < 64 ? bw : 64, 1};
   Rows hi = bw > 64 ? Rows{base.p + 64, base.idx, base.stride, bw - 64, 1} : no_rows();
   Rows ex{exps.p, exps.idx, exps.stride, exps.words, 1};
-  if (ctx->use_pair) {
+  if (ctx->use_pair && pow_n && ctx->use_pown) {
+    const Rows hsel{nullptr, half_of, 0, 0};
+    MPE_TRY(launch_pair_modexp(ctx, pk->ps_pp, B2, hsel, Rows{base.p, base.idx, base.stride, bw, 1}, rows(pk->eq1, 32, half_of), 32,
+                               no_rows(), no_rows(), 0, y, st, 1));                        // a = x^(q mod (p-1)) mod p
+    MPE_TRY(launch_pair_modexp(ctx, pk->ps_pp, B2, hsel, rows(y, 64, nullptr, 32), rows(pk->pq32, 32, half_of), 32,
+                               no_rows(), no_rows(), 0, u, st));                           // a^p mod p^2
+  } else if (ctx->use_pair) {
     MPE_TRY(launch_pair_modexp(ctx, pk->ps_pp, B2, Rows{nullptr, half_of, 0, 0}, Rows{base.p, base.idx, base.stride, bw, 1}, ex, ew,
                                no_rows(), no_rows(), 0, u, st));
   } else {
@@ -325,7 +343,7 @@ static int paillier_encrypt(mpe_ctx* ctx, const mpe_paillier* pk, int B, const i
   uint32_t* gm = ws_array<uint32_t>(ctx, (size_t)B * 128);
   // r^N mod N^2
   MPE_TRY(modexp_nn(ctx, pk, B, key_selector(pk, key_idx), rows(d_r, 64, nullptr, 64), key_rows(pk, pk->N, 64, key_idx), 64,
-                    holder, x, st));
+                    holder, x, st, true));
   MPE_LAUNCH_1D(enc_gm_kernel, B, st, B, pk->nkeys, d_m, key_idx, pk->N, gm);
   return launch_modmul(ctx, pk->ms_nn, B, key_selector(pk, key_idx), rows(x, 128), rows(gm, 128), d_c, st);
 }

@@ -8,8 +8,8 @@ int pairset_create_2048(int count, const uint32_t* d_moduli, mpe_pairset** out, 
   return pairset_create_impl<Cfg2048>(count, d_moduli, out, st);
 }
 int pair_modexp_2048(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
-                     Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st) {
-  return pair_modexp_impl<Cfg2048>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, out, st);
+                     Rows base2, Rows exps2, int exp2_words, int half, uint32_t* out, hipStream_t st) {
+  return pair_modexp_impl<Cfg2048>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st);
 }
 
 }  // namespace mpe

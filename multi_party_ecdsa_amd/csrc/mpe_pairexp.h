@@ -100,6 +100,39 @@ __device__ __forceinline__ void cios1(uint32_t (&res)[C::L], uint64_t (&c)[C::L]
   cios_tail<C>(res, c, ln);
 }
 
+// One CIOS pass with TWO product streams:  res = (c_in + a0 * b1 + a1 * b0 + m n) / R
+template <class C>
+__device__ __forceinline__ void cios2(uint32_t (&res)[C::L], uint64_t (&c)[C::L], const uint32_t (&a0)[C::L],
+                                      const uint32_t (&a1)[C::L], const uint32_t* __restrict__ bl0,
+                                      const uint32_t* __restrict__ bl1, const uint32_t (&n)[C::L], uint32_t n0inv,
+                                      const Lane& ln) {
+  constexpr int L = C::L, W = C::W;
+  uint32_t maskv = C::MASK;
+  asm volatile("" : "+v"(maskv));
+#pragma unroll 1
+  for (int jj = 0; jj < C::TPI; ++jj) {
+    const uint32_t* bp0 = bl0 + jj * L;
+    const uint32_t* bp1 = bl1 + jj * L;
+#pragma unroll
+    for (int r = 0; r < L; ++r) {
+      const uint32_t b0j = bp0[r], b1j = bp1[r];
+      c[r] += (uint64_t)a0[0] * b1j;
+      c[r] += (uint64_t)a1[0] * b0j;
+      const uint32_t m = bcast0_masked<C::TPI>((uint32_t)c[r] * n0inv, maskv);
+#pragma unroll
+      for (int i = 1; i < L; ++i) {
+        c[(r + i) % L] += (uint64_t)a0[i] * b1j;
+        c[(r + i) % L] += (uint64_t)a1[i] * b0j;
+      }
+#pragma unroll
+      for (int i = 0; i < L; ++i) c[(r + i) % L] += (uint64_t)m * n[i];
+      c[(r + 1) % L] += c[r] >> W;
+      c[r] = (uint64_t)(pull_next((uint32_t)c[r]) & maskv);
+    }
+  }
+  cios_tail<C>(res, c, ln);
+}
+
 // (r0, r1) = (a0, a1) * (y0, y1) R^-1 in Z/N^2.  The group's LDS region holds y0 in B0 and y1 in B1; for a squaring
 // (sq: y == a) B1 holds 2 y0 instead, so that pass B is the single stream a1 * (2 a0).
 // Column bound: a pass-B column absorbs per lane block 18 x (2^59.01 + 2^58.01) (squaring: the doubled stream) or
@@ -107,7 +140,7 @@ __device__ __forceinline__ void cios1(uint32_t (&res)[C::L], uint64_t (&c)[C::L]
 template <class C>
 __device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::L], const uint32_t (&a0)[C::L],
                                         const uint32_t (&a1)[C::L], uint32_t* gl, const uint32_t (&n)[C::L],
-                                        uint32_t n0inv, bool sq, const Lane& ln) {
+                                        uint32_t n0inv, bool sq, bool half, const Lane& ln) {
   using PL = PairLds<C>;
   constexpr int L = C::L;
   uint64_t c[L];
@@ -115,6 +148,11 @@ __device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::
   for (int i = 0; i < L; ++i) c[i] = 0;
   cios1<C, true>(r0, c, a0, gl + PL::B0, gl + PL::M, n, n0inv, ln);           // pass A: u, digits -> M
   wave_lds_sync();
+  if (half) {                                      // arithmetic modulo N only: the x1 components stay 0
+#pragma unroll
+    for (int i = 0; i < L; ++i) r1[i] = 0;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < L; ++i) c[i] = (uint64_t)(gl[PL::KC + ln.t * L + i] - gl[PL::M + ln.t * L + i]);
   wave_lds_sync();
@@ -126,6 +164,10 @@ __device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::
   } else {
     // pass B as two single-stream passes (a two-stream loop body needs ~80 more VGPRs than the kernel has):
     //   t = redc(a0 y1 - m),  r1 = redc(a1 y0) + t   (lazily normalised again by one local ripple)
+#ifndef MPE_PAIR_THREE_PASSES
+    cios2<C>(r1, c, a0, a1, gl + PL::B0, gl + PL::B1, n, n0inv, ln);          // pass B: a0 * y1 + a1 * y0 - m
+#else
+    // (build-time alternative: two single-stream passes, t = redc(a0 y1 - m), r1 = redc(a1 y0) + t)
     uint32_t t[L];
     cios1<C, false>(t, c, a0, gl + PL::B1, gl + PL::M, n, n0inv, ln);
 #pragma unroll
@@ -143,6 +185,7 @@ __device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::
     const uint32_t v0 = r1[0] + cin;
     r1[0] = v0 & C::MASK;
     r1[1] += v0 >> C::W;
+#endif
   }
   wave_lds_sync();
 #pragma unroll
@@ -246,6 +289,7 @@ __global__ void __launch_bounds__(64) pairset_setup_kernel(int count, const uint
 }
 
 // ---------------------------------------------------------------------------------------------
+// (half != 0: the same machine on the x0 components alone = plain Montgomery exponentiation modulo N; out = value < N)
 // exponentiation modulo modulus[mod(i)]^2:   out pair (z0 | z1, each K32 words, both in [0, N)) with
 //   z0 + z1 N = base^exp [* base2^exp2]  mod N^2        (pair_finish_kernel then forms that integer in place)
 // base rows may be any number of words (chunks of K32 words, Horner); phases as in modexp_kernel.
@@ -255,7 +299,7 @@ enum PairPhase { PP_IN, PP_MONT, PP_TAB, PP_SQ, PP_MUL1, PP_MUL2, PP_FINAL, PP_D
 template <class C>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) pair_modexp_kernel(int batch, PairsetView ps, Rows mod_sel, Rows base, Rows exps,
                                                          int exp_words, int wb, Rows base2, Rows exps2, int exp2_words,
-                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ tables) {
+                                                         int half, uint32_t* __restrict__ out, uint32_t* __restrict__ tables) {
   using PL = PairLds<C>;
   __shared__ uint32_t lds[PL::WORDS];
   const Lane ln = make_lane<C>();
@@ -337,7 +381,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
       wave_lds_sync();
       uint32_t r0[C::L], r1[C::L];
-      pairmul<C>(r0, r1, cur0, cur1, gl, n, n0inv, sq, ln);
+      pairmul<C>(r0, r1, cur0, cur1, gl, n, n0inv, sq, half != 0, ln);
       wave_lds_sync();
 #pragma unroll
       for (int i = 0; i < C::L; ++i) { cur0[i] = r0[i]; cur1[i] = r1[i]; }
@@ -450,7 +494,7 @@ int pairset_create_impl(int count, const uint32_t* d_moduli, mpe_pairset** out, 
 
 template <class C>
 int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
-                            Rows base2, Rows exps2, int exp2_words, uint32_t* d_out, hipStream_t st) {
+                     Rows base2, Rows exps2, int exp2_words, int half, uint32_t* d_out, hipStream_t st) {
   const int need_w = (batch + C::GROUPS - 1) / C::GROUPS, cap = ctx->cus * ctx->modexp_waves_per_cu;
   int grid = need_w;
   if (need_w > cap) { const int trips = (need_w + cap - 1) / cap; grid = (need_w + trips - 1) / trips; }
@@ -469,9 +513,9 @@ int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
     ctx->tables_bytes = need;
   }
   PairsetView v{ps->n_limbs, ps->n0inv, ps->one, ps->r2, ps->tp, ps->kc, ps->count};
-  prof_begin(ctx, st, 3, 2 * C::BITS, exp_words, batch, dual ? exp2_words : 0);
+  prof_begin(ctx, st, half ? 4 : 3, half ? C::BITS : 2 * C::BITS, exp_words, batch, dual ? exp2_words : 0);
   hipLaunchKernelGGL(pair_modexp_kernel<C>, dim3(grid), dim3(64), 0, st, batch, v, mod_sel, base, exps, exp_words, wb, base2,
-                     exps2, exp2_words, d_out, (uint32_t*)ctx->tables);
+                     exps2, exp2_words, half, d_out, (uint32_t*)ctx->tables);
   prof_end(ctx, st);
   hipLaunchKernelGGL(pair_finish_kernel<C::K32>, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, mod_sel, ps->mod_words, d_out);
   hipError_t e = hipGetLastError();

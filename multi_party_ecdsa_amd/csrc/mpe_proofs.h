@@ -213,9 +213,9 @@ struct Seq {
     return o;
   }
   // x^e mod N^2; holder = this party owns the key and may go through p^2 | q^2
-  uint32_t* modexp_nn(const mpe_paillier* pk, Rows sel, Rows base, Rows exps, int ew, bool holder) {
+  uint32_t* modexp_nn(const mpe_paillier* pk, Rows sel, Rows base, Rows exps, int ew, bool holder, bool pow_n = false) {
     uint32_t* o = words(128);
-    if (rc == MPE_OK) rc = mpe::modexp_nn(ctx, pk, B, sel, base, exps, ew, holder, o, st);
+    if (rc == MPE_OK) rc = mpe::modexp_nn(ctx, pk, B, sel, base, exps, ew, holder, o, st, pow_n);
     return o;
   }
   uint32_t* modexp_nn2(const mpe_paillier* pk, Rows sel, Rows base, Rows exps, int ew, Rows base2, Rows exps2, int ew2) {
@@ -289,7 +289,7 @@ static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statem
   // u = (alpha N + 1) beta^N mod N^2                                            :53-55
   uint32_t* gu = q.words(128);
   q.muladd(rows(nn->alpha, 24), 24, Nrow, 64, no_rows(), 0, gu, 128);
-  uint32_t* bn = q.modexp_nn(pk, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64, true);   // the prover owns the key
+  uint32_t* bn = q.modexp_nn(pk, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64, true, true);   // the prover owns the key
   uint32_t* u = q.modmul(pk->ms_nn, ksel, rows(gu, 128), rows(bn, 128));
   // w = h1^alpha h2^gamma mod N~                                                :56-57
   uint32_t* w1 = q.fb_modexp(stm, ssel, 0, h1,rows(nn->alpha, 24), 24);
@@ -377,7 +377,7 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
   // u2 = (N+1)^alpha beta^N mod N^2; (N+1)^alpha = 1 + alpha N (mod N^2), alpha N + 1 < N^2      :87-93
   uint32_t* ga = q.words(128);
   q.muladd(rows(nn->alpha, 24), 24, Nrow, 64, no_rows(), 0, ga, 128);
-  uint32_t* bn = q.modexp_nn(pk, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64, true);   // the prover owns the key
+  uint32_t* bn = q.modexp_nn(pk, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64, true, true);   // the prover owns the key
   q.modmul_to(pk->ms_nn, ksel, rows(ga, 128), rows(bn, 128), out->u2);
   // u3 = h1^alpha h2^gamma mod N~                                               :94-100
   uint32_t* w1 = q.fb_modexp(stm, ssel, 0, h1,rows(nn->alpha, 24), 24);
