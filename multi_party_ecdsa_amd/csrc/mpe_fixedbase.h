@@ -4,32 +4,33 @@
 // (src/utilities/mta/range_proofs.rs:52,56-57,129-131; src/utilities/zk_pdl_with_slack/mod.rs:79-100,159-165),
 // and those bases are fixed per key.  With a table T[i][d] = h^(d * 2^(wb i)) in HBM an exponentiation is just
 // one Montgomery multiplication per wb-bit window: E/wb multiplications and no squarings, instead of E
-// squarings + E/4 multiplications.  wb = 8: 356 windows x 256 entries x 288 B = 26 MB per base — nothing next
-// to 288 GB; each multiplication reads one 288-byte row (prefetched one step ahead).
+// squarings + E/4 multiplications.  wb = 13 (the default): 220 windows x 8192 entries x 288 B = 0.5 GB per base —
+// nothing next to 288 GB; each multiplication reads one 288-byte row (prefetched one step ahead).  Measured on
+// one box, signatures/s at wb = 8 / 10 / 12 / 13 / 14: 16 151 / 16 408 / 16 555 / 16 590 / 16 669; wb = 16 (3.3 GB
+// per base, 20 GB of randomly read rows) is slower than 8: the TLBs thrash.
 // The value is the same residue mpz_powm returns.  The operation sequence depends only on exp_words.
 #pragma once
 #include "mpe_internal.h"
 
 namespace mpe {
 
-#ifndef MPE_FB_WB
-#define MPE_FB_WB 8
-#endif
-constexpr int FB_WB = MPE_FB_WB;                               // window bits (4 or 8: windows do not straddle words)
-constexpr int FB_TE = 1 << FB_WB;                              // table entries per window
-constexpr int FB_PER_WORD = 32 / FB_WB;
-constexpr int FB_MAX_WINDOWS = 89 * FB_PER_WORD;               // exponents up to 89 words (s2, s3 < 2^2817)
-static_assert(FB_WB == 4 || FB_WB == 8 || FB_WB == 16, "fixed-base windows must divide a word");
+// window width wb: a property of a statement set (chosen when its tables are built; windows may straddle words)
+constexpr int FB_EXP_BITS = 89 * 32;                            // exponents up to 89 words (s2, s3 < 2^2817)
+__host__ __device__ inline int fb_windows(int wb) { return (FB_EXP_BITS + wb - 1) / wb; }
 
-__device__ __forceinline__ uint32_t fb_digit(const uint32_t* __restrict__ ex, int i) {
-  return (ex[i / FB_PER_WORD] >> ((i % FB_PER_WORD) * FB_WB)) & (uint32_t)(FB_TE - 1);
+__device__ __forceinline__ uint32_t fb_digit(const uint32_t* __restrict__ ex, int exp_words, int i, int wb) {
+  const int bitpos = i * wb, word = bitpos >> 5, sh = bitpos & 31;
+  uint32_t v = ex[word] >> sh;
+  if (sh + wb > 32 && word + 1 < exp_words) v |= ex[word + 1] << (32 - sh);
+  return v & ((1u << wb) - 1u);
 }
 
 // Stage 1, one lane group per (statement, base): the window bases.
 //   tab[pair][i][0] = Mont(1), tab[pair][i][1] = Mont(h^(2^(wb i)))       (canonical residues)
 template <class C>
 __global__ void __launch_bounds__(64) fb_bases_kernel(int npairs, ModsetView ms, const uint32_t* __restrict__ h1,
-                                                      const uint32_t* __restrict__ h2, uint32_t* __restrict__ tab) {
+                                                      const uint32_t* __restrict__ h2, int wb, uint32_t* __restrict__ tab) {
+  const int FB_WB = wb, FB_TE = 1 << wb, FB_MAX_WINDOWS = fb_windows(wb);
   __shared__ uint32_t lds[C::LDS_WORDS];
   const Lane ln = make_lane<C>();
   uint32_t* gl = lds + ln.g * C::STRIDE;
@@ -72,7 +73,8 @@ __global__ void __launch_bounds__(64) fb_bases_kernel(int npairs, ModsetView ms,
 
 // Stage 2, one lane group per (statement, base, window): tab[..][d] = tab[..][d-1] * tab[..][1], d = 2..TE-1
 template <class C>
-__global__ void __launch_bounds__(64) fb_fill_kernel(int nrows, ModsetView ms, uint32_t* __restrict__ tab) {
+__global__ void __launch_bounds__(64) fb_fill_kernel(int nrows, ModsetView ms, int wb, uint32_t* __restrict__ tab) {
+  const int FB_TE = 1 << wb, FB_MAX_WINDOWS = fb_windows(wb);
   __shared__ uint32_t lds[C::LDS_WORDS];
   const Lane ln = make_lane<C>();
   uint32_t* gl = lds + ln.g * C::STRIDE;
@@ -102,15 +104,16 @@ __global__ void __launch_bounds__(64) fb_fill_kernel(int nrows, ModsetView ms, u
 // out[i] = h^exp[i] mod N~ for h = h1 (which = 0) or h2 (which = 1) of statement st(i)
 template <class C>
 __global__ void __launch_bounds__(64) fb_modexp_kernel(int batch, ModsetView ms, Rows st_sel, int which,
-                                                       const uint32_t* __restrict__ tab, Rows exps, int exp_words,
+                                                       const uint32_t* __restrict__ tab, int wb, Rows exps, int exp_words,
                                                        uint32_t* __restrict__ out) {
+  const int FB_WB = wb, FB_TE = 1 << wb, FB_MAX_WINDOWS = fb_windows(wb);
   __shared__ uint32_t lds[C::LDS_WORDS];
   const Lane ln = make_lane<C>();
   uint32_t* gl = lds + ln.g * C::STRIDE;
   const int slot = blockIdx.x * C::GROUPS + ln.g;
   const int nslots = gridDim.x * C::GROUPS;
   const int trips = (batch + nslots - 1) / nslots;
-  const int nwin = exp_words * FB_PER_WORD;
+  const int nwin = (exp_words * 32 + FB_WB - 1) / FB_WB;
 #pragma unroll 1
   for (int trip = 0; trip < trips; ++trip) {
     const int inst = trip * nslots + slot;
@@ -123,11 +126,11 @@ __global__ void __launch_bounds__(64) fb_modexp_kernel(int batch, ModsetView ms,
     load_owner<C>(n, ms.n_limbs + (size_t)st * C::K, ln);
     const uint32_t n0inv = ms.n0inv[st];
     uint32_t cur[C::L], nx[C::L];
-    load_owner<C>(cur, T + (size_t)fb_digit(ex, 0) * C::K, ln);
+    load_owner<C>(cur, T + (size_t)fb_digit(ex, exp_words, 0, wb) * C::K, ln);
     // steps 1..nwin-1: cur <- cur * T[i][digit_i]; step nwin: cur <- cur * 1.  The next table row is fetched
     // (coalesced within the group) before the multiplication that hides its latency.
     auto fetch = [&](int i) {
-      const uint32_t* src = T + ((size_t)i * FB_TE + fb_digit(ex, i)) * C::K;
+      const uint32_t* src = T + ((size_t)i * FB_TE + fb_digit(ex, exp_words, i, wb)) * C::K;
 #pragma unroll
       for (int k = 0; k < C::L; ++k) nx[k] = src[ln.t + C::TPI * k];
     };

@@ -18,7 +18,8 @@ struct mpe_statements {
   uint32_t* h1 = nullptr;
   uint32_t* h2 = nullptr;
   mpe_modset* ms = nullptr;  // 2048-bit, modulus k = N~_k
-  uint32_t* fb_tab = nullptr;  // [2*count][FB_MAX_WINDOWS][FB_TE][72] fixed-base tables of h1 (even) / h2 (odd)
+  int fb_wb = 8;               // window width of the fixed-base tables
+  uint32_t* fb_tab = nullptr;  // [2*count][windows][2^fb_wb][72] fixed-base tables of h1 (even) / h2 (odd)
 };
 
 #include "mpe_fixedbase.h"
@@ -35,7 +36,7 @@ static int launch_fb_modexp(mpe_ctx* ctx, const mpe_statements* stm, int B, Rows
   ModsetView v;
   v.n_limbs = stm->ms->n_limbs; v.one_limbs = stm->ms->one_limbs; v.r2_limbs = stm->ms->r2_limbs;
   v.r2h_limbs = stm->ms->r2h_limbs; v.n0inv = stm->ms->n0inv; v.count = stm->ms->count;
-  hipLaunchKernelGGL(fb_modexp_kernel<C>, dim3(grid), dim3(64), 0, st, B, v, st_sel, which, stm->fb_tab, exps, ew, out);
+  hipLaunchKernelGGL(fb_modexp_kernel<C>, dim3(grid), dim3(64), 0, st, B, v, st_sel, which, stm->fb_tab, stm->fb_wb, exps, ew, out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("fb_modexp_kernel", e); return MPE_E_HIP; }
   return MPE_OK;
@@ -480,16 +481,19 @@ int mpe_statements_create(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const u
     // fixed-base window tables of h1, h2 (26 MB per base at 8-bit windows), built on the GPU once per statement set:
     // the window bases one after the other (squarings), then every window's multiples in parallel
     using C = mpe::Cfg2048;
-    const size_t bytes = (size_t)2 * count * mpe::FB_MAX_WINDOWS * mpe::FB_TE * C::K * sizeof(uint32_t);
+    s->fb_wb = ctx->fb_window_bits;
+    const int nwindows = mpe::fb_windows(s->fb_wb);
+    const size_t bytes = (size_t)2 * count * nwindows * ((size_t)1 << s->fb_wb) * C::K * sizeof(uint32_t);
     e = hipMalloc((void**)&s->fb_tab, bytes);
     if (e != hipSuccess) { mpe_set_error("hipMalloc(fixed-base tables)", e); mpe_statements_destroy(s); return MPE_E_NOMEM; }
     mpe::ModsetView v;
     v.n_limbs = s->ms->n_limbs; v.one_limbs = s->ms->one_limbs; v.r2_limbs = s->ms->r2_limbs; v.r2h_limbs = s->ms->r2h_limbs;
     v.n0inv = s->ms->n0inv; v.count = s->ms->count;
-    const int npairs = 2 * count, nrows = npairs * mpe::FB_MAX_WINDOWS;
+    const int npairs = 2 * count, nrows = npairs * nwindows;
     hipLaunchKernelGGL(mpe::fb_bases_kernel<C>, dim3((npairs + C::GROUPS - 1) / C::GROUPS), dim3(64), 0, st, npairs, v, s->h1,
-                       s->h2, s->fb_tab);
-    hipLaunchKernelGGL(mpe::fb_fill_kernel<C>, dim3((nrows + C::GROUPS - 1) / C::GROUPS), dim3(64), 0, st, nrows, v, s->fb_tab);
+                       s->h2, s->fb_wb, s->fb_tab);
+    hipLaunchKernelGGL(mpe::fb_fill_kernel<C>, dim3((nrows + C::GROUPS - 1) / C::GROUPS), dim3(64), 0, st, nrows, v, s->fb_wb,
+                       s->fb_tab);
     e = hipGetLastError();
     if (e != hipSuccess) { mpe_set_error("fixed-base table build", e); mpe_statements_destroy(s); return MPE_E_HIP; }
   }
