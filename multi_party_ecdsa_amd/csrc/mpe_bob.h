@@ -69,12 +69,12 @@ static int bob_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
   commit(rows(beta_prim, 64), 64, rows(nn->sigma, 72), 72, out->t);                      // t       :242-243
   commit(rows(nn->gamma, 80), 80, rows(nn->tau, 88), 88, w);                             // w       :244-245
   // v = a_enc^alpha (gamma N + 1) beta^N mod N^2                                          :246-249
-  uint32_t* ca = q.modexp(pk->ms_nn, ksel, rows(a_enc, 128), rows(nn->alpha, 24), 24);
+  uint32_t* ca = q.modexp_nn(pk, ksel, rows(a_enc, 128), rows(nn->alpha, 24), 24, false);      // Bob works under Alice's key
   uint32_t* gN = q.modmul(pk->ms_nn, ksel, rows(nn->gamma, 80, nullptr, 80), with_words(Nrow, 64));
   uint32_t* g1 = q.words(128);
   if (q.rc == MPE_OK)
     hipLaunchKernelGGL(add_one_mod_kernel<128>, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, gN, pk->ms_nn->words, ksel, g1);
-  uint32_t* bn = q.modexp(pk->ms_nn, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64);
+  uint32_t* bn = q.modexp_nn(pk, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64, false);
   uint32_t* v1 = q.modmul(pk->ms_nn, ksel, rows(ca, 128), rows(g1, 128));
   uint32_t* v = q.modmul(pk->ms_nn, ksel, rows(v1, 128), rows(bn, 128));
   // e = H(N, N+1, a_enc, mta, z, z', t, v, w [, X.x, X.y, u.x, u.y])                       :433-470

@@ -362,8 +362,8 @@ static int paillier_mul_add_enc(mpe_ctx* ctx, const mpe_paillier* pk, int B, con
     MPE_TRY(modexp_nn2(ctx, pk, B, ksel, rows(d_r, 64, nullptr, 64), Nrow, 64, c_a, k, kw, x, st));
   } else {
     uint32_t* y = ws_array<uint32_t>(ctx, (size_t)B * 128);
-    MPE_TRY(launch_modexp(ctx, pk->ms_nn, B, ksel, rows(d_r, 64, nullptr, 64), no_rows(), Nrow, 64, x, st));
-    MPE_TRY(launch_modexp(ctx, pk->ms_nn, B, ksel, c_a, no_rows(), k, kw, y, st));
+    MPE_TRY(modexp_nn(ctx, pk, B, ksel, rows(d_r, 64, nullptr, 64), Nrow, 64, false, x, st));
+    MPE_TRY(modexp_nn(ctx, pk, B, ksel, c_a, k, kw, false, y, st));
     MPE_TRY(launch_modmul(ctx, pk->ms_nn, B, ksel, rows(x, 128), rows(y, 128), x, st));
   }
   return launch_modmul(ctx, pk->ms_nn, B, ksel, rows(x, 128), rows(gm, 128), d_out, st);
@@ -447,8 +447,8 @@ int mpe_paillier_mul(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const int3
                      const uint32_t* d_k, int k_words, uint32_t* d_out, void* stream) {
   if (!ctx || !pk || !d_c || !d_k || !d_out || batch < 0 || k_words <= 0) return MPE_E_ARG;
   if (!d_key_idx && pk->nkeys != 1 && pk->nkeys < batch) return MPE_E_ARG;
-  return mpe::launch_modexp(ctx, pk->ms_nn, batch, mpe::key_selector(pk, d_key_idx), mpe::rows(d_c, 128), mpe::no_rows(),
-                            mpe::rows(d_k, k_words), k_words, d_out, (hipStream_t)stream);
+  return mpe::modexp_nn(ctx, pk, batch, mpe::key_selector(pk, d_key_idx), mpe::rows(d_c, 128), mpe::rows(d_k, k_words), k_words,
+                        false, d_out, (hipStream_t)stream);
 }
 
 }  // extern "C"

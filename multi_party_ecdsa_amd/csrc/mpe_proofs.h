@@ -340,9 +340,9 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
     uint32_t* m = q.modexp_nn2(pk, ksel, with_words(pr.s, 64), Nrow, 64, rows(cinv, 128), pr.e, 8);
     u = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(m, 128));
   } else {
-    uint32_t* ce = q.modexp(pk->ms_nn, ksel, cipher, pr.e, 8);
+    uint32_t* ce = q.modexp_nn(pk, ksel, cipher, pr.e, 8, false);
     uint32_t* cei = q.modinv(pk->ms_nn, ksel, rows(ce, 128), inv_ok2);
-    uint32_t* sn = q.modexp(pk->ms_nn, ksel, with_words(pr.s, 64), Nrow, 64);
+    uint32_t* sn = q.modexp_nn(pk, ksel, with_words(pr.s, 64), Nrow, 64, false);
     uint32_t* b12 = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(sn, 128));
     u = q.modmul(pk->ms_nn, ksel, rows(b12, 128), rows(cei, 128));
   }
@@ -433,9 +433,9 @@ static int pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
     uint32_t* m = q.modexp_nn2(pk, ksel, with_words(pr.s2, 64), Nrow, 64, rows(cinv, 128), rows(e, 8), 8);
     u2 = q.modmul(pk->ms_nn, ksel, rows(g1, 128), rows(m, 128));
   } else {
-    uint32_t* s2n = q.modexp(pk->ms_nn, ksel, with_words(pr.s2, 64), Nrow, 64);
+    uint32_t* s2n = q.modexp_nn(pk, ksel, with_words(pr.s2, 64), Nrow, 64, false);
     uint32_t* t2 = q.modmul(pk->ms_nn, ksel, rows(g1, 128), rows(s2n, 128));
-    uint32_t* cie = q.modexp(pk->ms_nn, ksel, rows(cinv, 128), rows(e, 8), 8);
+    uint32_t* cie = q.modexp_nn(pk, ksel, rows(cinv, 128), rows(e, 8), 8, false);
     u2 = q.modmul(pk->ms_nn, ksel, rows(t2, 128), rows(cie, 128));
   }
   // u3' = h1^s1 h2^s3 z^-e mod N~                                                                  :159-172

@@ -114,3 +114,33 @@ def test_config2_full_size_roundtrip(pk, keys, gpu_ctx):
     want = orc.paillier_encrypt(F.words([k.N for k in keys], 64), np.ascontiguousarray(m[sel].cpu().numpy().view(np.uint32)),
                                 np.ascontiguousarray(rr[sel].cpu().numpy().view(np.uint32)), [int(i) % len(keys) for i in sel.cpu()])
     assert np.array_equal(np.ascontiguousarray(c[sel].cpu().numpy().view(np.uint32)), want)
+
+
+@pytest.mark.parametrize("env", [{"MPE_NO_PAIR": "1"}, {"MPE_NO_CRT": "1"}, {"MPE_NO_POWN": "1"}, {"MPE_NO_PAIR": "1", "MPE_NO_CRT": "1"},
+                                 {"MPE_WINDOW_BITS": "4"}, {"MPE_WINDOW_BITS": "5"}])
+def test_every_arithmetic_route_gives_the_same_ciphertexts(pk, keys, env):
+    """The A/B switches select different algorithms for the same residues (N-adic pairs vs the 4096-bit kernel, the
+    holder's p^2|q^2 halves, x^N through a^p, window widths): all of them must agree with the default route, which
+    the other tests pin to the oracle."""
+    from multi_party_ecdsa_amd import engine as E
+    r = F.Rng("gpu-routes")
+    B = 37
+    kidx = [(5 * i) % len(keys) for i in range(B)]
+    m = [r.below(keys[kidx[i]].N) for i in range(B)]
+    rr = [r.below(keys[kidx[i]].N) for i in range(B)]
+    want = pk.encrypt(m, rr, kidx)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx2 = E.Context(0)                                  # the switches are read when a context is created
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    sk2 = E.PaillierKeys(ctx2, p=[k.p for k in keys], q=[k.q for k in keys])
+    pk2 = E.PaillierKeys(ctx2, N=[k.N for k in keys])
+    assert sk2.encrypt(m, rr, kidx) == want                  # key holder
+    assert pk2.encrypt(m, rr, kidx) == want                  # public key only
+    assert sk2.decrypt(want, kidx) == m
