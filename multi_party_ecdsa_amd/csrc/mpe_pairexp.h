@@ -162,30 +162,7 @@ __device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::
   if (sq) {
     cios1<C, false>(r1, c, a1, gl + PL::B1, gl + PL::M, n, n0inv, ln);        // pass B: a1 * (2 a0) - m
   } else {
-    // pass B as two single-stream passes (a two-stream loop body needs ~80 more VGPRs than the kernel has):
-    //   t = redc(a0 y1 - m),  r1 = redc(a1 y0) + t   (lazily normalised again by one local ripple)
-#ifndef MPE_PAIR_THREE_PASSES
     cios2<C>(r1, c, a0, a1, gl + PL::B0, gl + PL::B1, n, n0inv, ln);          // pass B: a0 * y1 + a1 * y0 - m
-#else
-    // (build-time alternative: two single-stream passes, t = redc(a0 y1 - m), r1 = redc(a1 y0) + t)
-    uint32_t t[L];
-    cios1<C, false>(t, c, a0, gl + PL::B1, gl + PL::M, n, n0inv, ln);
-#pragma unroll
-    for (int i = 0; i < L; ++i) c[i] = 0;
-    cios1<C, false>(r1, c, a1, gl + PL::B0, gl + PL::M, n, n0inv, ln);
-    uint32_t carry = 0;
-#pragma unroll
-    for (int i = 0; i < L; ++i) {
-      const uint32_t v = r1[i] + t[i] + carry;
-      r1[i] = v & C::MASK;
-      carry = v >> C::W;
-    }
-    uint32_t cin = pull_prev(carry);                 // the value is < 4N << R: the top lane's carry-out is 0
-    if (ln.t0) cin = 0;
-    const uint32_t v0 = r1[0] + cin;
-    r1[0] = v0 & C::MASK;
-    r1[1] += v0 >> C::W;
-#endif
   }
   wave_lds_sync();
 #pragma unroll
