@@ -87,6 +87,7 @@ def run(bits, W, L, TPI, iters=20, seed=1):
     print(f"bits={bits} W={W} L={L} TPI={TPI} K={K}: maxcol=2^{stats['maxcol'].bit_length()} "
           f"maxlimb=2^{stats['maxlimb'].bit_length()}  OK")
     assert stats['maxcol'] < 1 << 64
+    return stats
 
 if __name__ == '__main__':
     run(4096, 27, 19, 8, iters=4)
