@@ -185,10 +185,25 @@ struct InvPlan {
 };
 __device__ __forceinline__ int mod_index(const Rows& sel, int i) { return sel_index(sel, i); }
 
+// rank[i] = position of item i among the items of its modulus.  A launch has a handful of moduli, so the lanes of a
+// wave are grouped by modulus with ballots and ONE lane per (wave, modulus) does the atomic: 64x fewer colliding
+// atomics than one per item.
 __global__ void inv_count_kernel(int B, Rows mod_sel, InvPlan p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B) return;
-  p.rank[i] = atomicAdd(&p.cnt[mod_index(mod_sel, i)], 1);
+  const bool live = i < B;
+  const int m = live ? mod_index(mod_sel, i) : -1;
+  const int lane = threadIdx.x & 63;
+  uint64_t todo = __ballot(live);
+  while (todo) {
+    const int leader = __builtin_ctzll(todo);
+    const int lm = __shfl(m, leader);                    // the modulus this round serves
+    const uint64_t same = __ballot(live && m == lm);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&p.cnt[lm], (int)__builtin_popcountll(same));
+    base = __shfl(base, leader);
+    if (live && m == lm) p.rank[i] = base + (int)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
 }
 // single lane: bucket offsets (in place of the counts) and the chunk table
 __global__ void inv_plan_kernel(int nmod, int chunk, InvPlan p) {
