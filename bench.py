@@ -178,7 +178,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or "RANK" in os.environ          # under torch.distributed.run even one rank goes through RCCL
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist

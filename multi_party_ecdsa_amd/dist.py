@@ -15,7 +15,7 @@ def shard_range(total, rank, world):
 
 def max_over_ranks(value, device="cpu"):
     """Largest `value` (e.g. elapsed seconds) over all ranks: the job finishes when its slowest rank does."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -24,7 +24,7 @@ def max_over_ranks(value, device="cpu"):
 
 def gather_counts(count, device="cpu"):
     """Per-rank unit counts gathered on every rank (used to report whole-job throughput)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [int(count)]
     t = torch.tensor([int(count)], dtype=torch.int64, device=device)
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
