@@ -58,3 +58,26 @@ def test_wrong_public_key_fails_only_that_check(gpu_ctx, keys):
     gpu_ctx.sync()
     assert list(status.cpu().numpy()) == [601, 601]
     assert list(G.oracle_sign(lk, nonces, 2)[4]) == [602, 602]
+
+
+def test_config4_sessions_byte_identical_to_the_threaded_oracle(gpu_ctx, keys):
+    """BASELINE config 4's shape (t=1, n=3, signers {1,2}, one LocalKey, distinct nonces and messages per session) at
+    a size the oracle finishes in seconds on the host cores: 192 sessions, every (r, s, recid, R) byte-identical."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    B = 192
+    lk, nonces, (r, s, recid, status, R) = _run(gpu_ctx, keys, 1, 3, [0, 1], B, "gpu-config4")
+    assert list(status) == [0] * B
+    threads = max(1, min(os.cpu_count() or 1, 32))
+    chunks = [c for c in np.array_split(np.arange(B), threads) if len(c)]
+    outs = {}
+
+    def run(ix):
+        outs[int(ix[0])] = (len(ix), G.oracle_sign(lk, nonces, B, first=int(ix[0]), count=len(ix)))
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(run, chunks))
+    for first, (cnt, (wr, ws, wrecid, wR, wstatus)) in outs.items():
+        sl = slice(first, first + cnt)
+        assert list(wstatus[sl]) == [0] * cnt
+        assert np.array_equal(r.view(np.uint32)[sl], wr[sl]) and np.array_equal(s.view(np.uint32)[sl], ws[sl])
+        assert list(recid[sl]) == list(wrecid[sl]) and np.array_equal(R.view(np.uint32)[sl], wR[sl])
