@@ -1,14 +1,15 @@
 // Batched Paillier-2048 (kzen-paillier 0.4.2 call surface used by the reference:
 // src/utilities/mta/mod.rs:22-24,68-75,133-145,165).  Included by mpe_lib.hip.
 //
-//   encrypt_with_chosen_randomness : c = (1 + m N) r^N mod N^2     1 modexp(4096,2048) + 1 modmul
+//   encrypt_with_chosen_randomness : c = (1 + m N) r^N mod N^2     1 exponentiation mod N^2 + 1 modmul
 //   add                            : c1 c2 mod N^2                  1 modmul
-//   mul                            : c^k mod N^2                    1 modexp(4096,|k|)
+//   mul                            : c^k mod N^2                    1 exponentiation mod N^2
 //   decrypt (CRT)                  : m_p = L_p(c^(p-1) mod p^2) h_p mod p, same for q, recombine
-//                                    2 modexp(2048,1024) + 4 modmul(2048) + two light kernels
-//   x^e mod N^2 by the key holder  : x^e mod p^2 and mod q^2 (a quarter of the work each), recombined with the CRT
-//                                    idempotents mod N^2 (modexp_nn_crt below) -- the same residue, half the work
-// All arithmetic runs on the GPU, including the per-key constants (h_p, h_q, CRT idempotents),
+//                                    2 exponentiations mod p^2 | q^2 + 4 modmul(2048) + two light kernels
+// Every exponentiation modulo N^2 (public key only) or p^2 | q^2 (the key holder: modexp_nn) runs on the N-adic
+// pair kernel of mpe_pairexp.h; the holder's x^N goes through (x^(q mod (p-1)) mod p)^p.  MPE_NO_PAIR / MPE_NO_CRT /
+// MPE_NO_POWN switch back to the plain 4096- / 2048-bit kernels for A/B runs (tests check that every route agrees).
+// All arithmetic runs on the GPU, including the per-key constants (h_p, h_q, CRT idempotents, pair constants),
 // which the reference recomputes inside every decrypt call; per-key reuse is output-identical.
 #pragma once
 #include "mpe_internal.h"
