@@ -117,7 +117,7 @@ def test_config2_full_size_roundtrip(pk, keys, gpu_ctx):
 
 
 @pytest.mark.parametrize("env", [{"MPE_NO_PAIR": "1"}, {"MPE_NO_CRT": "1"}, {"MPE_NO_POWN": "1"}, {"MPE_NO_PAIR": "1", "MPE_NO_CRT": "1"},
-                                 {"MPE_WINDOW_BITS": "4"}, {"MPE_WINDOW_BITS": "5"}])
+                                 {"MPE_WINDOW_BITS": "4"}, {"MPE_WINDOW_BITS": "5"}, {"MPE_NO_ADAPTIVE_LANES": "1"}])
 def test_every_arithmetic_route_gives_the_same_ciphertexts(pk, keys, env):
     """The A/B switches select different algorithms for the same residues (N-adic pairs vs the 4096-bit kernel, the
     holder's p^2|q^2 halves, x^N through a^p, window widths): all of them must agree with the default route, which
