@@ -289,9 +289,11 @@ def main():
                           "whole_step_frac_of_peak": value / world * sig_macs(S, n) / PEAK_MAC_PER_S},
             "all_sessions_signed": all_signed, "launch": ctx.launch_info(),
         }
-        if not args.no_paillier:
+        # the Paillier section and the CPU baseline belong to the single-GPU line (rank 0 at N=1 only): at N>1 the
+        # other ranks would just wait for them
+        if not args.no_paillier and world == 1:
             res["paillier"] = paillier_config2(ctx, E, keys, F)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             threads = min(os.cpu_count() or 1, 64)
             sample = min(B, 2 * threads)
             host_nonces = {f: np.ascontiguousarray(v.cpu().numpy().view(np.uint32)) for f, v in nonces.items()}
