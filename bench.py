@@ -162,6 +162,39 @@ def paillier_config2(ctx, E, keys, F, steps=1):
             "modexp4096_executed_frac": B * pair_modexp_macs(64, 64) / kern / PEAK_MAC_PER_S}
 
 
+def lindell_section(ctx, E, keys, F, cpu=True):
+    """SURVEY.md 8f row 4: Lindell'17 two-party signing (PartialSig::compute + Signature::compute_with_recid), 65 536
+    independent sessions over 16 Paillier keys; the first sessions are checked against the oracle bit for bit."""
+    import lindell_fixture as L
+    B, dev = 65536, ctx.device
+    small = 128
+    fx = L.make(keys, small, seed="bench-lindell")
+    rep_ = lambda a: torch.from_numpy(np.ascontiguousarray(np.tile(a, (B // small, 1))).view(np.int32)).to(dev)
+    d = {k: rep_(fx[k]) for k in ("c_key", "x2", "k1", "k2", "R1", "R2", "msg", "rho", "r")}
+    kidx = torch.tensor(fx["kidx"] * (B // small), dtype=torch.int32, device=dev)
+    sk = E.PaillierKeys(ctx, p=[k.p for k in keys], q=[k.q for k in keys])
+    pk = E.PaillierKeys(ctx, N=[k.N for k in keys])
+
+    def run():
+        c3 = E.lindell_partial_sig(ctx, pk, d["c_key"], d["x2"], d["k2"], d["R1"], d["msg"], d["rho"], d["r"], kidx)
+        return E.lindell_sign(ctx, sk, c3, d["k1"], d["R2"], kidx)
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r, s_, recid = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"signatures_per_s": B / dt, "batch": B}
+    if cpu:
+        t0 = time.perf_counter()
+        _, wr, ws, wrec = L.oracle_run(fx)
+        out["cpu_oracle_signatures_per_s_1_thread"] = small / (time.perf_counter() - t0)
+        out["parity_vs_oracle_on_sample"] = bool(np.array_equal(r[:small].cpu().numpy().view(np.uint32), wr) and
+                                                 np.array_equal(s_[:small].cpu().numpy().view(np.uint32), ws) and
+                                                 list(recid[:small].cpu().numpy()) == list(wrec))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -293,6 +326,7 @@ def main():
         # other ranks would just wait for them
         if not args.no_paillier and world == 1:
             res["paillier"] = paillier_config2(ctx, E, keys, F)
+            res["lindell17"] = lindell_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline and world == 1:
             threads = min(os.cpu_count() or 1, 64)
             sample = min(B, 2 * threads)

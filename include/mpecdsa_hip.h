@@ -259,6 +259,22 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const mpe_
                   uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, int dedup_verify, int chunk,
                   void* stream);
 
+/* ---- Lindell'17 two-party ECDSA, signing ---------------------------------------------- */
+/* Party two, `PartialSig::compute(ek, encrypted_secret_share, local_share, ephemeral_local_share,
+ * ephemeral_other_public_share, message)` (src/protocols/two_party_ecdsa/lindell_2017/party_two.rs:390-423).
+ * pk = party ONE's Paillier key (public part is enough); c_key [batch][128] = Enc(x1); x2, k2, msg [batch][8];
+ * R1 [batch][16] = party one's ephemeral public share; rho [batch][16] (< q^2, `BigInt::sample_below(&q.pow(2))`)
+ * and r [batch][64] (the randomness `Paillier::encrypt` draws) are inputs.  c3 [batch][128]. */
+int mpe_lindell_partial_sig(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const int32_t* d_key_idx,
+                            const uint32_t* d_c_key, const uint32_t* d_x2, const uint32_t* d_k2, const uint32_t* d_R1,
+                            const uint32_t* d_msg, const uint32_t* d_rho, const uint32_t* d_r, uint32_t* d_c3, void* stream);
+/* Party one, `Signature::compute_with_recid(party_one_private, partial_sig_c3, ephemeral_local_share,
+ * ephemeral_other_public_share)` (lindell_2017/party_one.rs:519-565).  sk holds p, q; k1 [batch][8]; R2 [batch][16];
+ * outputs r, s [batch][8] (s low: min(s, q - s)) and recid [batch]. */
+int mpe_lindell_sign(mpe_ctx* ctx, const mpe_paillier* sk, int batch, const int32_t* d_key_idx, const uint32_t* d_c3,
+                     const uint32_t* d_k1, const uint32_t* d_R2, uint32_t* d_r, uint32_t* d_s, int32_t* d_recid,
+                     void* stream);
+
 /* Kernel geometry chosen for the last launch (for bench.py's roofline accounting). */
 typedef struct {
   int waves;              /* workgroups (= waves) launched */

@@ -1,0 +1,92 @@
+// Lindell'17 two-party ECDSA, the signing half, batched over independent sessions:
+//   party two  PartialSig::compute            src/protocols/two_party_ecdsa/lindell_2017/party_two.rs:390-423
+//   party one  Signature::compute_with_recid  src/protocols/two_party_ecdsa/lindell_2017/party_one.rs:519-565
+// Both are the Paillier kernels of the GG20 path plus two per-lane EC / scalar kernels: the partial signature
+// c3 = Enc(rho q + k2^-1 m; r) * c_key^(k2^-1 rx x2) is ONE two-base ladder modulo N^2 (the peer's key: no p, q),
+// party one's s = Dec(c3) k1^-1 is the CRT decryption on the pair kernel modulo p^2 | q^2.
+// Included by mpe_lib.hip.
+#pragma once
+#include "mpe_paillier.h"
+#include "mpe_ec.h"
+
+namespace mpe {
+
+// per session: plaintext ps = rho q + (k2^-1 m mod q)  [64 words]  and multiplier v = k2^-1 (rx x2) mod q  [8 words]
+__global__ void __launch_bounds__(64) lindell_p2_prep_kernel(int B, const uint32_t* __restrict__ k2, const uint32_t* __restrict__ x2,
+                                                             const uint32_t* __restrict__ R1, const uint32_t* __restrict__ msg,
+                                                             const uint32_t* __restrict__ rho, uint32_t* __restrict__ ps,
+                                                             uint32_t* __restrict__ v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const ec::U256 k = ec::sc_reduce(k2 + (size_t)i * 8, 8);
+  const ec::Aff Rp = ec::jac_to_aff(ec::jac_mul(k, ec::aff_load(R1 + (size_t)i * 16)));   // r = R1 * k2        :401
+  const ec::U256 rx = ec::sc_reduce(Rp.x.w, 8);                                            // rx = r.x mod q     :403
+  const ec::U256 kinv = ec::sc_inv(k);                                                     // k2_inv             :405
+  const ec::U256 t = ec::sc_mul(kinv, ec::sc_reduce(msg + (size_t)i * 8, 8));
+  uint32_t prod[24], q8[8], r16[16];
+  for (int j = 0; j < 8; ++j) q8[j] = ec::FQ[j];
+  sm::copy(r16, rho + (size_t)i * 16, 16);
+  sm::mul(prod, r16, 16, q8, 8);                                                           // rho q
+  sm::add(prod, 24, prod, 24, t.w, 8);                                                     // + k2_inv m         :406
+  for (int j = 0; j < 64; ++j) ps[(size_t)i * 64 + j] = j < 24 ? prod[j] : 0u;
+  const ec::U256 vv = ec::sc_mul(kinv, ec::sc_mul(rx, ec::sc_reduce(x2 + (size_t)i * 8, 8)));   // :409-413
+  ec::u256_store(v + (size_t)i * 8, vv);
+}
+
+// per session: r = (k1 R2).x mod q, s = min(s'', q - s'') with s'' = (s_tag mod q) k1^-1, recid   (:526-561)
+__global__ void __launch_bounds__(64) lindell_p1_finish_kernel(int B, const uint32_t* __restrict__ s_tag, const uint32_t* __restrict__ k1,
+                                                               const uint32_t* __restrict__ R2, uint32_t* __restrict__ r_out,
+                                                               uint32_t* __restrict__ s_out, int32_t* __restrict__ recid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const ec::U256 k = ec::sc_reduce(k1 + (size_t)i * 8, 8);
+  const ec::Aff Rp = ec::jac_to_aff(ec::jac_mul(k, ec::aff_load(R2 + (size_t)i * 16)));
+  const ec::U256 rx = ec::sc_reduce(Rp.x.w, 8), ry = ec::sc_reduce(Rp.y.w, 8);
+  ec::U256 s = ec::sc_mul(ec::sc_reduce(s_tag + (size_t)i * 64, 64), ec::sc_inv(k));
+  const ec::U256 neg = ec::sc_neg(s);
+  bool gt = false;
+  for (int j = 7; j >= 0; --j) { if (s.w[j] != neg.w[j]) { gt = s.w[j] > neg.w[j]; break; } }
+  int rec = (int)(ry.w[0] & 1u);
+  if (gt) { s = neg; rec ^= 1; }
+  ec::u256_store(r_out + (size_t)i * 8, rx);
+  ec::u256_store(s_out + (size_t)i * 8, s);
+  recid[i] = rec;
+}
+
+}  // namespace mpe
+
+extern "C" {
+
+int mpe_lindell_partial_sig(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const int32_t* d_key_idx, const uint32_t* d_c_key,
+                            const uint32_t* d_x2, const uint32_t* d_k2, const uint32_t* d_R1, const uint32_t* d_msg,
+                            const uint32_t* d_rho, const uint32_t* d_r, uint32_t* d_c3, void* stream) {
+  if (!ctx || !pk || !d_c_key || !d_x2 || !d_k2 || !d_R1 || !d_msg || !d_rho || !d_r || !d_c3 || batch < 0) return MPE_E_ARG;
+  if (!d_key_idx && pk->nkeys != 1 && pk->nkeys < batch) return MPE_E_ARG;
+  if (batch == 0) return MPE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  // own arrays at the top of the workspace, the composite below (the scheme of mpe_mta.h)
+  MPE_TRY(mpe::ws_reserve(ctx, (size_t)batch * (128 * 3 + 64 + 8 + 64) * 4 + (1u << 20), st));
+  char* top = (char*)ctx->ws + ctx->ws_bytes;
+  uint32_t* ps = (uint32_t*)(top -= ((size_t)batch * 64 * 4 + 255) & ~(size_t)255);
+  uint32_t* v = (uint32_t*)(top -= ((size_t)batch * 8 * 4 + 255) & ~(size_t)255);
+  MPE_LAUNCH_1D(mpe::lindell_p2_prep_kernel, batch, st, batch, d_k2, d_x2, d_R1, d_msg, d_rho, ps, v);
+  // c3 = c_key^v * Enc(ps; r): Paillier::encrypt, Paillier::mul, Paillier::add   :408-421
+  return mpe::paillier_mul_add_enc(ctx, pk, batch, d_key_idx, mpe::rows(d_c_key, 128), mpe::rows(v, 8), 8, ps, d_r, d_c3, st);
+}
+
+int mpe_lindell_sign(mpe_ctx* ctx, const mpe_paillier* sk, int batch, const int32_t* d_key_idx, const uint32_t* d_c3,
+                     const uint32_t* d_k1, const uint32_t* d_R2, uint32_t* d_r, uint32_t* d_s, int32_t* d_recid, void* stream) {
+  if (!ctx || !sk || !d_c3 || !d_k1 || !d_R2 || !d_r || !d_s || !d_recid || batch < 0) return MPE_E_ARG;
+  if (!sk->has_private) { mpe_set_error_msg("mpe_lindell_sign: key set has no private part"); return MPE_E_ARG; }
+  if (!d_key_idx && sk->nkeys != 1 && sk->nkeys < batch) return MPE_E_ARG;
+  if (batch == 0) return MPE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  MPE_TRY(mpe::ws_reserve(ctx, (size_t)batch * (2 * (3 + 64 + 32 + 64 + 64) + 64) * 4 + (1u << 20), st));
+  char* top = (char*)ctx->ws + ctx->ws_bytes;
+  uint32_t* s_tag = (uint32_t*)(top -= ((size_t)batch * 64 * 4 + 255) & ~(size_t)255);
+  MPE_TRY(mpe::paillier_decrypt(ctx, sk, batch, d_key_idx, d_c3, s_tag, st));               // :538-542
+  MPE_LAUNCH_1D(mpe::lindell_p1_finish_kernel, batch, st, batch, s_tag, d_k1, d_R2, d_r, d_s, d_recid);
+  return MPE_OK;
+}
+
+}  // extern "C"

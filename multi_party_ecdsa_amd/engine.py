@@ -482,3 +482,23 @@ def mta_verify_get_alpha(ctx, sk, d_cb, b_proof, beta_tag_proof, d_a, d_key_idx=
     N_.check(N_.lib.mpe_mta_verify_get_alpha(ctx.h, sk.h, B, _ptr(d_key_idx), _ptr(d_cb), C.byref(p1), C.byref(p2), _ptr(d_a),
                                              _ptr(alpha), _ptr(share), _ptr(ok), ctx.stream()), "mpe_mta_verify_get_alpha")
     return alpha, share, ok
+
+
+# ---- Lindell'17 two-party ECDSA, signing (lindell_2017/party_two.rs:390-423, party_one.rs:519-565) ----
+def lindell_partial_sig(ctx, pk, d_c_key, d_x2, d_k2, d_R1, d_msg, d_rho, d_r, d_key_idx=None):
+    """`PartialSig::compute` batched: returns c3 [B,128] (device)."""
+    B = d_c_key.shape[0]
+    c3 = _new(ctx, B, 128)
+    N_.check(N_.lib.mpe_lindell_partial_sig(ctx.h, pk.h, B, _ptr(d_key_idx), _ptr(d_c_key), _ptr(d_x2), _ptr(d_k2), _ptr(d_R1),
+                                            _ptr(d_msg), _ptr(d_rho), _ptr(d_r), _ptr(c3), ctx.stream()), "mpe_lindell_partial_sig")
+    return c3
+
+
+def lindell_sign(ctx, sk, d_c3, d_k1, d_R2, d_key_idx=None):
+    """`Signature::compute_with_recid` batched: returns (r [B,8], s [B,8], recid [B]) on the device."""
+    B = d_c3.shape[0]
+    r, s = _new(ctx, B, 8), _new(ctx, B, 8)
+    recid = torch.empty((B,), dtype=torch.int32, device=ctx.device)
+    N_.check(N_.lib.mpe_lindell_sign(ctx.h, sk.h, B, _ptr(d_key_idx), _ptr(d_c3), _ptr(d_k1), _ptr(d_R2), _ptr(r), _ptr(s),
+                                     _ptr(recid), ctx.stream()), "mpe_lindell_sign")
+    return r, s, recid

@@ -742,3 +742,4 @@ void orc_nextprime(int k32, const uint32_t* start, uint32_t* out) {
 }
 
 #include "gg20_oracle.c"
+#include "lindell_oracle.c"

@@ -153,6 +153,14 @@ void orc_gg20_sign(const orc_gg20_keys* K, const orc_gg20_nonces* Z, int first, 
 /* fixture helper (test key material only): smallest prime > start */
 void orc_nextprime(int k32, const uint32_t* start, uint32_t* out);
 
+/* Lindell'17 two-party signing (lindell_oracle.c): PartialSig::compute and Signature::compute_with_recid.
+ * c_key, c3 [batch][128]; x2, k2, k1, msg [batch][8]; R1, R2 [batch][16]; rho [batch][16] (< q^2); r [batch][64]. */
+void orc_lindell_partial_sig(int batch, int nkeys, const uint32_t* N, const int32_t* key_idx, const uint32_t* c_key,
+                             const uint32_t* x2, const uint32_t* k2, const uint32_t* R1, const uint32_t* msg,
+                             const uint32_t* rho, const uint32_t* r, uint32_t* c3);
+void orc_lindell_sign(int batch, int nkeys, const uint32_t* p, const uint32_t* q, const int32_t* key_idx, const uint32_t* c3,
+                      const uint32_t* k1, const uint32_t* R2, uint32_t* r_out, uint32_t* s_out, int32_t* recid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,3 +200,20 @@ def dlog_verify(pk, R, z):
     ok = np.zeros(pk.shape[0], dtype=np.uint8)
     lib.orc_dlog_verify(pk.shape[0], _p(pk), _p(R), _p(z), _p(ok))
     return ok
+
+
+def lindell_partial_sig(N, c_key, x2, k2, R1, msg, rho, r, key_idx=None):
+    """PartialSig::compute (lindell_2017/party_two.rs:390-423): c3 [B][128]"""
+    B = c_key.shape[0]
+    c3 = u32((B, W4096))
+    lib.orc_lindell_partial_sig(B, N.shape[0], _p(N), _p(_idx(key_idx)), _p(c_key), _p(x2), _p(k2), _p(R1), _p(msg), _p(rho),
+                                _p(r), _p(c3))
+    return c3
+
+
+def lindell_sign(p, q, c3, k1, R2, key_idx=None):
+    """Signature::compute_with_recid (lindell_2017/party_one.rs:519-565): r, s [B][8], recid [B]"""
+    B = c3.shape[0]
+    r, s, recid = u32((B, 8)), u32((B, 8)), np.zeros(B, dtype=np.int32)
+    lib.orc_lindell_sign(B, p.shape[0], _p(p), _p(q), _p(_idx(key_idx)), _p(c3), _p(k1), _p(R2), _p(r), _p(s), _p(recid))
+    return r, s, recid
