@@ -318,6 +318,126 @@ __global__ void __launch_bounds__(64) r6_kernel(Dim d, const uint32_t* __restric
   ok[pi] = good ? 1 : 0;
 }
 
+// ---- small batches: the same checks with a group of adjacent lanes per item ---------------------------
+// One party per lane runs an item's scalar multiplications back to back; with few sessions that leaves most SIMDs
+// idle for the whole latency of the chain.  The *_group kernels give every item G lanes: the independent
+// multiplications run one per lane (all lanes of a phase execute the same routine on different data), the Jacobian
+// results meet in LDS and lane 0 of the group does the additions, comparisons and stores.  With many sessions the
+// idle lanes of the groups cost more than the latency they hide (measured at 65 536 sessions: r2a 42 -> 57 ms,
+// r3 22 -> 52 ms), so sign_chunk picks them only when the grouped launch still fits the chip.
+struct JacSlots { ec::Jac v[64]; };
+
+__global__ void __launch_bounds__(64) r2a_group_kernel(Dim d, const int32_t* __restrict__ mbin_rv, const uint32_t* __restrict__ alpha_full,
+                           const uint32_t* __restrict__ kq, MsgB m, const uint32_t* __restrict__ g_w,
+                           uint32_t* __restrict__ alpha, uint8_t* __restrict__ ok) {
+  // 4 lanes per incoming MessageB: lanes 0..2 do  k_i B | c1 B | c2 B'  (variable base), then  alpha G | z G | z' G
+  __shared__ JacSlots vs, fs;
+  const int gid = blockIdx.x * 64 + threadIdx.x, rv = gid >> 2, sub = gid & 3, base = (int)threadIdx.x - sub;
+  const int P1 = d.S - 1;
+  const bool live = rv < d.B * d.S * P1 * 2;
+  const int rvc = live ? rv : 0;
+  const int v = rvc & 1, pp = rvc >> 1, jj = pp % P1, pi = pp / P1, i = pi % d.S, b = pi / d.S, ind = ind_of(i, jj);
+  const int in = mbin_rv[rvc];
+  const ec::U256 al = ec::sc_reduce(alpha_full + (size_t)rvc * 64, 64);
+  const ec::Aff Bpk = ec::aff_load(m.pk + (size_t)in * 16), BTpk = ec::aff_load(m.tpk + (size_t)in * 16);
+  const ec::Aff R1 = ec::aff_load(m.R + (size_t)in * 16), R2 = ec::aff_load(m.tR + (size_t)in * 16);
+  ec::Jac res = ec::jac_inf(), fr = ec::jac_inf();
+  if (live && sub < 3) {
+    const ec::U256 sc = sub == 0 ? ec::u256_load(kq + (size_t)pi * 8) : (sub == 1 ? dlog_challenge(R1, Bpk) : dlog_challenge(R2, BTpk));
+    res = ec::jac_mul(sc, sub == 2 ? BTpk : Bpk);
+    const ec::U256 fk = sub == 0 ? al : ec::sc_reduce((sub == 1 ? m.z : m.tz) + (size_t)in * 8, 8);
+    fr = ec::jac_mul_gen(fk);
+  }
+  vs.v[threadIdx.x] = res;
+  fs.v[threadIdx.x] = fr;
+  __syncthreads();
+  if (!live || sub) return;
+  ec::u256_store(alpha + (size_t)rv * 8, al);
+  bool good = ec::jac_eq(fs.v[base], ec::jac_add_aff(vs.v[base], BTpk));                     // g^alpha == k_i B + B'
+  good = good && ec::jac_eq_aff(ec::jac_add(fs.v[base + 1], vs.v[base + 1]), R1)             // DLogProof::verify x2
+              && ec::jac_eq_aff(ec::jac_add(fs.v[base + 2], vs.v[base + 2]), R2);
+  if (v == 1) good = good && ec::aff_eq(Bpk, ec::aff_load(g_w + (size_t)(b * d.S + ind) * 16));   // rounds.rs:281
+  ok[rv] = good ? 1 : 0;
+}
+
+// G lanes per party (a power of two >= 2 S): lane 2j | 2j+1 does z1_j G | z2_j H, lane j also e_j T_j
+__global__ void __launch_bounds__(64) r3_group_kernel(Dim d, int G, const uint32_t* __restrict__ delta_i, Ped p, uint32_t* __restrict__ dinv, uint8_t* __restrict__ ok) {
+  __shared__ JacSlots vs, fs;
+  const int gid = blockIdx.x * 64 + threadIdx.x, pi = gid / G, sub = gid % G, base = (int)threadIdx.x - sub;
+  const bool live = pi < d.B * d.S;
+  const int b = live ? pi / d.S : 0;
+  const ec::Aff Gp = ec::aff_gen(), H = ec::aff_h2();
+  ec::Jac res = ec::jac_inf(), fr = ec::jac_inf();
+  if (live && sub < d.S) {
+    const size_t o = (size_t)b * d.S + sub;
+    const ec::Aff T = ec::aff_load(p.T + o * 16), a1 = ec::aff_load(p.a1 + o * 16), a2 = ec::aff_load(p.a2 + o * 16);
+    const ec::Aff hp[5] = {Gp, H, T, a1, a2};
+    res = ec::jac_mul(hash_points(hp), T);
+  }
+  if (live && sub < 2 * d.S) {
+    const size_t o = (size_t)b * d.S + (sub >> 1);
+    fr = ec::jac_mul_fixed(ec::u256_load(((sub & 1) ? p.z2 : p.z1) + o * 8), sub & 1);
+  }
+  vs.v[threadIdx.x] = res;
+  fs.v[threadIdx.x] = fr;
+  __syncthreads();
+  if (!live || sub) return;
+  ec::U256 sum = ec::u256_zero();
+  bool good = true;
+  for (int j = 0; j < d.S; ++j) {
+    const size_t o = (size_t)b * d.S + j;
+    sum = ec::sc_add(sum, ec::u256_load(delta_i + o * 8));
+    const ec::Aff a1 = ec::aff_load(p.a1 + o * 16), a2 = ec::aff_load(p.a2 + o * 16);
+    const ec::Jac lhs = ec::jac_add(fs.v[base + 2 * j], fs.v[base + 2 * j + 1]);
+    const ec::Jac rhs = ec::jac_add_aff(ec::jac_add_aff(vs.v[base + j], a1), a2);
+    good = good && ec::jac_eq(lhs, rhs);
+  }
+  good = good && !ec::u256_is_zero(sum);
+  ec::u256_store(dinv + (size_t)pi * 8, ec::sc_inv(sum));
+  ok[pi] = good ? 1 : 0;
+}
+
+// G lanes per party (a power of two >= 3 S): lane 3j+k does e D_j | z2_j R | e E_j; lane 2j+k does z1_j H | z2_j G
+__global__ void __launch_bounds__(64) r6_group_kernel(Dim d, int G, const uint32_t* __restrict__ R, const uint32_t* __restrict__ pedT, Heg h,
+                          const uint32_t* __restrict__ y, uint8_t* __restrict__ ok) {
+  __shared__ JacSlots vs, fs;
+  const int gid = blockIdx.x * 64 + threadIdx.x, pi = gid / G, sub = gid % G, base = (int)threadIdx.x - sub;
+  const bool live = pi < d.B * d.S;
+  const int pic = live ? pi : 0, b = pic / d.S;
+  const ec::Aff Gp = ec::aff_gen(), H = ec::aff_h2(), Rp = ec::aff_load(R + (size_t)pic * 16);
+  ec::Jac res = ec::jac_inf(), fr = ec::jac_inf();
+  if (live && sub < 3 * d.S) {
+    const int j = sub / 3, kind = sub % 3;
+    const size_t o = (size_t)b * d.S + j;
+    const ec::Aff TT = ec::aff_load(h.T + o * 16), A3 = ec::aff_load(h.A3 + o * 16), D = ec::aff_load(pedT + o * 16),
+                  E = ec::aff_load(h.S + o * 16);
+    const ec::Aff hp[7] = {TT, A3, Rp, H, Gp, D, E};
+    const ec::U256 e = hash_points(hp);
+    res = ec::jac_mul(kind == 1 ? ec::u256_load(h.z2 + o * 8) : e, kind == 0 ? D : (kind == 1 ? Rp : E));
+  }
+  if (live && sub < 2 * d.S) {
+    const size_t o = (size_t)b * d.S + (sub >> 1);
+    fr = ec::jac_mul_fixed(ec::u256_load(((sub & 1) ? h.z2 : h.z1) + o * 8), (sub & 1) ? 0 : 1);
+  }
+  vs.v[threadIdx.x] = res;
+  fs.v[threadIdx.x] = fr;
+  __syncthreads();
+  if (!live || sub) return;
+  bool good = true;
+  ec::Jac acc = ec::jac_inf();
+  for (int j = 0; j < d.S; ++j) {
+    const size_t o = (size_t)b * d.S + j;
+    const ec::Aff TT = ec::aff_load(h.T + o * 16), A3 = ec::aff_load(h.A3 + o * 16), E = ec::aff_load(h.S + o * 16);
+    const ec::Jac l1 = ec::jac_add(fs.v[base + 2 * j], fs.v[base + 2 * j + 1]);
+    const ec::Jac r1 = ec::jac_add_aff(vs.v[base + 3 * j], TT);
+    const ec::Jac r2 = ec::jac_add_aff(vs.v[base + 3 * j + 2], A3);
+    good = good && ec::jac_eq(l1, r1) && ec::jac_eq(vs.v[base + 3 * j + 1], r2);
+    acc = ec::jac_add_aff(acc, E);
+  }
+  good = good && ec::jac_eq_aff(acc, ec::aff_load(y));
+  ok[pi] = good ? 1 : 0;
+}
+
 // ---- Round 7: local signatures, output_signature, verify (party_i.rs:850-936) -------------------------------
 struct Flags { const uint8_t *vi, *rv, *r3, *r4, *r5, *r6; };
 __global__ void __launch_bounds__(64) r7_kernel(Dim d, Flags f, const uint32_t* __restrict__ msg, const uint32_t* __restrict__ R,
@@ -475,7 +595,9 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
   }
   gg_trace(st, "decrypt", q.rc);
   MsgB mbv{Bpk, BR, Bz, BTpk, BTR, BTz};
-  GG_LAUNCH(r2a_kernel, nMB, d, ix.mbin_rv, alpha_full, kq, mbv, g_w, alpha, ok_rv);
+  const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 : 0;      // two waves per SIMD
+  if (nMB * 4 <= lanes_fit) GG_LAUNCH(r2a_group_kernel, nMB * 4, d, ix.mbin_rv, alpha_full, kq, mbv, g_w, alpha, ok_rv);
+  else GG_LAUNCH(r2a_kernel, nMB, d, ix.mbin_rv, alpha_full, kq, mbv, g_w, alpha, ok_rv);
   uint32_t *delta_i = OW(nPI * 8), *sigma_i = OW(nPI * 8), *lq = OW(nPI * 8);
   Ped ped{OW(nPI * 16), OW(nPI * 16), OW(nPI * 16), OW(nPI * 8), OW(nPI * 8)};
   GG_LAUNCH(r2b_kernel, nPI, d, kq, gq, w, alpha, beta, Z->l + oPI * 8, Z->ped_s1 + oPI * 8, Z->ped_s2 + oPI * 8, delta_i,
@@ -484,7 +606,9 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
   // ---- Round 3, 4 ----
   uint32_t *dinv = OW(nPI * 8), *R = OW(nPI * 16), *Rbar = OW(nPI * 16);
   uint8_t *ok_r3 = OF(nPI), *ok_r4 = OF(nPI), *ok_r5 = OF(nPI), *ok_r6 = OF(nPI);
-  GG_LAUNCH(r3_kernel, nPI, d, delta_i, ped, dinv, ok_r3);
+  const int g3 = 2 * S <= 4 ? 4 : (2 * S <= 8 ? 8 : 16), g6 = 3 * S <= 8 ? 8 : (3 * S <= 16 ? 16 : 32);
+  if (nPI * g3 <= lanes_fit) GG_LAUNCH(r3_group_kernel, nPI * g3, d, g3, delta_i, ped, dinv, ok_r3);
+  else GG_LAUNCH(r3_kernel, nPI, d, delta_i, ped, dinv, ok_r3);
   GG_LAUNCH(r4_kernel, nPI, d, dinv, g_gamma, com, z_blind, Bpk, kq, R, Rbar, ok_r4);
   mpe_pdl_proof pp{OW(nPP * 64), OW(nPP * 16), OW(nPP * 128), OW(nPP * 64), OW(nPP * 25), OW(nPP * 64), OW(nPP * 89)};
   if (q.rc == MPE_OK)                                                                                          // phase5_proof_pdl
@@ -503,7 +627,8 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
   gg_trace(st, "pdl_verify", q.rc);
   Heg heg{OW(nPI * 16), OW(nPI * 16), OW(nPI * 16), OW(nPI * 8), OW(nPI * 8)};
   GG_LAUNCH(r5_kernel, nPI, d, ok_pv, R, Rbar, sigma_i, lq, ped.T, Z->heg_s1 + oPI * 8, Z->heg_s2 + oPI * 8, heg, ok_r5);
-  GG_LAUNCH(r6_kernel, nPI, d, R, ped.T, heg, K->y, ok_r6);
+  if (nPI * g6 <= lanes_fit) GG_LAUNCH(r6_group_kernel, nPI * g6, d, g6, R, ped.T, heg, K->y, ok_r6);
+  else GG_LAUNCH(r6_kernel, nPI, d, R, ped.T, heg, K->y, ok_r6);
   Flags fl{ok_vi, ok_rv, ok_r3, ok_r4, ok_r5, ok_r6};
   GG_LAUNCH(r7_kernel, B, d, fl, Z->msg + (size_t)b0 * 8, R, kq, sigma_i, K->y, d_r + (size_t)b0 * 8, d_s + (size_t)b0 * 8,
             d_recid + b0, d_R ? d_R + (size_t)b0 * 16 : nullptr, d_status + b0);

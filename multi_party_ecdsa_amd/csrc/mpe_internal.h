@@ -14,6 +14,7 @@ struct mpe_ctx {
   int cus = 256;
   int fb_window_bits = 13;        // window width of the fixed-base tables of h1, h2 (mpe_fixedbase.h); 0.5 GB per base at 13
   int window_bits = 0;            // 0 = choose per exponent length (4/5/6); 4..6 = force (A/B runs)
+  bool ec_lane_groups = true;     // small batches: a group of lanes per party in the EC round kernels (mpe_gg20.h)
   bool adaptive_lanes = true;     // small batches: twice the lanes per exponentiation (mpe_pair*.hip)
   bool use_pown = true;           // key holders: x^N mod p^2 as (x^(q mod (p-1)) mod p)^p (mpe_paillier.h modexp_nn)
   bool use_pair = true;           // arithmetic modulo N^2 / p^2 in N-adic pair form (mpe_pairexp.h): half the multiplies

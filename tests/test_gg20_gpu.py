@@ -47,6 +47,27 @@ def test_sign_matches_oracle(gpu_ctx, keys, t, n, signers, B, kw):
         assert pyref.ecdsa_verify(lk["y"], m, F.ints(wr[b:b + 1])[0], F.ints(ws[b:b + 1])[0])
 
 
+def test_large_batch_kernels_on_a_small_batch(keys):
+    """Small batches take the latency-oriented variants (twice the lanes per exponentiation, lane groups in the EC
+    round kernels); MPE_NO_ADAPTIVE_LANES forces the throughput variants the big batches use: same signatures."""
+    import os
+    from multi_party_ecdsa_amd import engine as E
+    old = os.environ.get("MPE_NO_ADAPTIVE_LANES")
+    os.environ["MPE_NO_ADAPTIVE_LANES"] = "1"
+    try:
+        ctx2 = E.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop("MPE_NO_ADAPTIVE_LANES", None)
+        else:
+            os.environ["MPE_NO_ADAPTIVE_LANES"] = old
+    B = 4
+    lk, nonces, (r, s, recid, status, R) = _run(ctx2, keys, 2, 5, [0, 1, 3], B, "gpu-throughput-variants")
+    wr, ws, wrecid, wR, wstatus = G.oracle_sign(lk, nonces, B)
+    assert list(status) == [0] * B == list(wstatus)
+    assert np.array_equal(r.view(np.uint32), wr) and np.array_equal(s.view(np.uint32), ws) and list(recid) == list(wrecid)
+
+
 def test_wrong_public_key_fails_only_that_check(gpu_ctx, keys):
     """phase6_check_S_i_sum: with an inconsistent y every session reports 601, like the oracle's 602 family"""
     from multi_party_ecdsa_amd import engine as E
