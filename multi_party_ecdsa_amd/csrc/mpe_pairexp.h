@@ -417,9 +417,35 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         ph = b == 0 ? PP_FINAL : PP_SQ;
       }
     }
-    // canonical digits -> interface words z0 | z1
-    reduce_once<C>(cur0, n, ln);
-    reduce_once<C>(cur1, n, ln);
+    // canonical digits -> interface words z0 | z1.  The pair means the INTEGER z0 + z1 N with z0 < 2N lazily, so a
+    // subtraction of N from z0 carries 1 into z1 (z0 >= N is a 2^-38 event for random operands, but e.g. the base N
+    // itself lands exactly there); z1 is then reduced modulo N (multiples of N^2 drop out).
+    {
+      int64_t z[C::L];
+#pragma unroll
+      for (int i = 0; i < C::L; ++i) z[i] = (int64_t)cur0[i];
+      full_normalize<C>(z, ln);
+      const bool ge = cmp_ge<C>(z, n, ln);
+      if (ge) {
+#pragma unroll
+        for (int i = 0; i < C::L; ++i) z[i] -= (int64_t)n[i];
+        full_normalize<C>(z, ln);
+      }
+#pragma unroll
+      for (int i = 0; i < C::L; ++i) { cur0[i] = (uint32_t)z[i]; z[i] = (int64_t)cur1[i]; }
+      if (ge && !half && ln.t == 0) z[0] += 1;
+      full_normalize<C>(z, ln);
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {                 // z1 + 1 <= 2N: at most two subtractions
+        if (cmp_ge<C>(z, n, ln)) {
+#pragma unroll
+          for (int i = 0; i < C::L; ++i) z[i] -= (int64_t)n[i];
+          full_normalize<C>(z, ln);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < C::L; ++i) cur1[i] = (uint32_t)z[i];
+    }
     store_limbs_as_words<C>(out + (size_t)idx * 2 * C::K32, gl, cur0, active, ln);
     store_limbs_as_words<C>(out + (size_t)idx * 2 * C::K32 + C::K32, gl, cur1, active, ln);
   }

@@ -144,3 +144,33 @@ def test_every_arithmetic_route_gives_the_same_ciphertexts(pk, keys, env):
     assert sk2.encrypt(m, rr, kidx) == want                  # key holder
     assert pk2.encrypt(m, rr, kidx) == want                  # public key only
     assert sk2.decrypt(want, kidx) == m
+
+
+@pytest.mark.parametrize("kw", [8, 25, 64])
+def test_pair_engine_edge_operands(pk, keys, kw):
+    """c^k mod N^2 through the N-adic pair kernel at the corners: bases 0, 1, N, N^2 - 1, 2^4096 - 1 (unreduced), a
+    multiple of p; exponents 0, 1, all-ones; every exponent width class (4-, 5- and 6-bit windows)."""
+    r = F.Rng(f"gpu-pair-edges-{kw}")
+    nk = len(keys)
+    bases, exps, kidx = [], [], []
+    for i in range(24):
+        k = keys[i % nk]
+        kidx.append(i % nk)
+        bases.append([0, 1, k.N, k.N * k.N - 1, (1 << 4096) - 1, k.p * 12345, r.below(k.N * k.N), r.bits(4096)][i % 8])
+        exps.append([0, 1, (1 << (32 * kw)) - 1, r.bits(32 * kw)][(i // 8 + i) % 4])
+    got = pk.mul(bases, exps, kidx, k_words=kw)
+    assert got == [pow(b, e, keys[j].N ** 2) for b, e, j in zip(bases, exps, kidx)]
+
+
+def test_decrypt_edge_ciphertexts(pk, keys):
+    """ciphertexts 1, 1 + N, N^2 - 1 and an unreduced one (c + N^2 < 2^4096) decrypt like the oracle says"""
+    nk = len(keys)
+    cs, kidx = [], []
+    for i in range(4 * nk):
+        k = keys[i % nk]
+        kidx.append(i % nk)
+        cs.append([1, 1 + k.N, k.N * k.N - 1, 1 + 5 * k.N + (k.N * k.N if (k.N * k.N).bit_length() < 4096 else 0)][i // nk])
+    got = pk.decrypt(cs, kidx)
+    want = F.ints(orc.paillier_decrypt(F.words([k.p for k in keys], 32), F.words([k.q for k in keys], 32), F.words(cs, 128), kidx))
+    assert got == want
+    assert got[:nk] == [0] * nk and got[nk:2 * nk] == [1] * nk and got[2 * nk:3 * nk] == [0] * nk and got[3 * nk:] == [5] * nk
