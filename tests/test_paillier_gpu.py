@@ -174,3 +174,20 @@ def test_decrypt_edge_ciphertexts(pk, keys):
     want = F.ints(orc.paillier_decrypt(F.words([k.p for k in keys], 32), F.words([k.q for k in keys], 32), F.words(cs, 128), kidx))
     assert got == want
     assert got[:nk] == [0] * nk and got[nk:2 * nk] == [1] * nk and got[2 * nk:3 * nk] == [0] * nk and got[3 * nk:] == [5] * nk
+
+
+def test_holder_paths_on_degenerate_randomness(pk, keys, gpu_ctx):
+    """r = 1, N - 1, multiples of p and of q (not units: the a^p shortcut must not rely on Fermat there), r just below
+    N: the key holder's p^2 | q^2 route and the public route give the oracle's ciphertext."""
+    from multi_party_ecdsa_amd import engine as E
+    pub = E.PaillierKeys(gpu_ctx, N=[k.N for k in keys])
+    nk = len(keys)
+    m, rr, kidx = [], [], []
+    for i in range(5 * nk):
+        k = keys[i % nk]
+        kidx.append(i % nk)
+        m.append((i * 0x9E3779B97F4A7C15) % k.N)
+        rr.append([1, k.N - 1, k.p * 3, k.q * (k.p - 1), k.p * k.p % k.N][i // nk])
+    want = F.ints(orc.paillier_encrypt(F.words([k.N for k in keys], 64), F.words(m, 64), F.words(rr, 64), kidx))
+    assert pk.encrypt(m, rr, kidx) == want
+    assert pub.encrypt(m, rr, kidx) == want
