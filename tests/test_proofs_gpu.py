@@ -159,6 +159,38 @@ def test_alice_proof_golden_and_oracle(gpu_ctx, keys, env):
         assert e.host(pr[f]) == [H(g["proof"][f]) for g in gold], f
 
 
+def test_alice_verify_on_hostile_proof_values(gpu_ctx, keys, env):
+    """A prover may send anything: s = N, 0, N - 1, 2^2048 - 1 (>= N), z = N~ or 0, a ciphertext that is a multiple of
+    N, of p, or not reduced.  The GPU verifier must return exactly the oracle's verdicts (all rejections here)."""
+    e = E()
+    pk, stm, tabs = env
+    B = 12
+    kidx, sidx, a, rr, c, nn = _alice_inputs(keys, B, "gpu-alice-hostile")
+    nw = {f: F.words([n[f] for n in nn], w) for f, w in e.ALICE_NONCE_WORDS.items()}
+    di = lambda v: torch.tensor(v, dtype=torch.int32, device=gpu_ctx.device)
+    pr = e.alice_generate(gpu_ctx, pk, stm, e.dev(gpu_ctx, a, 8), e.dev(gpu_ctx, c, 128), e.dev(gpu_ctx, rr, 64),
+                          {f: to_dev(gpu_ctx, v) for f, v in nw.items()}, di(kidx), di(sidx))
+    bad = {f: v.clone() for f, v in pr.items()}
+    N = [keys[k].N for k in kidx]
+    Nt = [keys[4 + s_].Nt for s_ in sidx]
+    row = lambda v, w: to_dev(gpu_ctx, F.words([v], w))[0]
+    bad["s"][0] = row(N[0], 64)
+    bad["s"][1] = row(0, 64)
+    bad["s"][2] = row(N[2] - 1, 64)
+    bad["s"][3] = row((1 << 2048) - 1, 64)
+    bad["z"][4] = row(Nt[4], 64)
+    bad["z"][5] = row(0, 64)
+    c2 = e.dev(gpu_ctx, c, 128)
+    c2[6] = row(N[6] * 7, 128)
+    c2[7] = row(keys[kidx[7]].p * 11, 128)
+    c2[8] = row((c[8] + N[8] * N[8]) if (c[8] + N[8] * N[8]).bit_length() <= 4096 else c[8], 128)
+    c2[9] = row(0, 128)
+    ok = e.alice_verify(gpu_ctx, pk, stm, c2, bad, di(kidx), di(sidx))
+    want_ok = orc.alice_verify(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], kidx, sidx, npw(c2), {f: npw(v) for f, v in bad.items()})
+    assert list(ok.cpu().numpy()) == list(want_ok)
+    assert list(want_ok[10:]) == [1, 1] and sum(want_ok[:8]) == 0
+
+
 def test_pdl_proof_oracle_and_soundness(gpu_ctx, keys, env):
     """zk_pdl_with_slack/test.rs:11-68 (prove -> verify) and :70-129 (ciphertext of x+1 -> reject)"""
     e = E()
