@@ -185,10 +185,12 @@ def test_alice_verify_on_hostile_proof_values(gpu_ctx, keys, env):
     c2[7] = row(keys[kidx[7]].p * 11, 128)
     c2[8] = row((c[8] + N[8] * N[8]) if (c[8] + N[8] * N[8]).bit_length() <= 4096 else c[8], 128)
     c2[9] = row(0, 128)
+    bad["s2"][10] = row((1 << (89 * 32)) - 1, 89)           # every 13-bit fixed-base window at its maximum, top one partial
+    bad["s1"][11] = row(pyref.Q ** 3, 25)                    # the boundary of the range check (s1 > q^3 rejects)
     ok = e.alice_verify(gpu_ctx, pk, stm, c2, bad, di(kidx), di(sidx))
     want_ok = orc.alice_verify(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], kidx, sidx, npw(c2), {f: npw(v) for f, v in bad.items()})
     assert list(ok.cpu().numpy()) == list(want_ok)
-    assert list(want_ok[10:]) == [1, 1] and sum(want_ok[:8]) == 0
+    assert sum(want_ok[:8]) == 0 and sum(want_ok[10:]) == 0
 
 
 def test_pdl_proof_oracle_and_soundness(gpu_ctx, keys, env):
