@@ -81,6 +81,19 @@ def pairmul(X, Y, n, n0inv, kc, TPI, stats, sq):
     return u, z1
 
 
+def finish(Z, N):
+    """The kernel's output step: the pair means the INTEGER z0 + z1 N with z0 < 2N lazily, so reducing z0 by N carries 1
+    into z1; z1 is then reduced modulo N.  Returns the canonical residue z0 + z1 N in [0, N^2)."""
+    z0, z1 = from_limbs(Z[0]), from_limbs(Z[1])
+    assert z0 < 2 * N + 2 and z1 < 2 * N + 2
+    if z0 >= N:
+        z0 -= N
+        z1 += 1
+    while z1 >= N:
+        z1 -= N
+    return z0 + z1 * N
+
+
 def run(bits, TPI, iters, seed, stress):
     rnd = random.Random(seed)
     K = L * TPI
@@ -117,6 +130,14 @@ def run(bits, TPI, iters, seed, stress):
             Z = pairmul(X, Yp, n, n0inv, kc, TPI, stats, sq)
             assert val(Z) == val(X) * val(Yp) * Rinv % NN, "wrong residue"
             assert from_limbs(Z[0]) < 2 * N + (1 << (bits - 30)) and from_limbs(Z[1]) < 2 * N + (1 << (bits - 30)), "value bound"
+    # the corner the final normalisation has to get right: the base N itself (x0 = N is the lazy form of 0)
+    one = (to_limbs(1, K), to_limbs(0, K))
+    XN = (to_limbs(N, K), to_limbs(0, K))                                    # the plain pair of the value N
+    r2 = (R * R) % NN
+    F_N = pairmul(XN, (to_limbs(r2 % N, K), to_limbs(r2 // N, K)), n, n0inv, kc, TPI, stats, False)   # its form
+    back = pairmul(F_N, one, n, n0inv, kc, TPI, stats, False)
+    assert finish(back, N) == N, "z0 >= N must carry into z1"
+    assert finish(pairmul(pairmul(F_N, F_N, n, n0inv, kc, TPI, stats, True), one, n, n0inv, kc, TPI, stats, False), N) == 0
     assert stats['maxcol'] < (1 << 64), "column overflow"
     assert stats['maxlimb'] <= lazy, "lazy limb bound"
     return stats
