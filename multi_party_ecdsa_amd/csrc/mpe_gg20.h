@@ -118,7 +118,7 @@ __device__ __forceinline__ ec::Aff add_aff(const ec::Aff& a, const ec::Aff& b) {
 
 // ---- Round 0: SignKeys::create + phase1_broadcast (party_i.rs:546-589) ----------------------------
 __global__ void __launch_bounds__(64) r0_kernel(Dim d, const int32_t* __restrict__ signers, const uint32_t* __restrict__ xs,
-                          const uint32_t* __restrict__ k_in, const uint32_t* __restrict__ gamma_in,
+                          const uint32_t* __restrict__ Xs, const uint32_t* __restrict__ k_in, const uint32_t* __restrict__ gamma_in,
                           const uint32_t* __restrict__ blind, uint32_t* __restrict__ kq, uint32_t* __restrict__ gq,
                           uint32_t* __restrict__ w, uint32_t* __restrict__ k64, uint32_t* __restrict__ g_gamma,
                           uint32_t* __restrict__ g_w, uint32_t* __restrict__ com) {
@@ -126,14 +126,17 @@ __global__ void __launch_bounds__(64) r0_kernel(Dim d, const int32_t* __restrict
   if (pi >= d.B * d.S) return;
   const int i = pi % d.S;
   const ec::U256 k = ec::sc_reduce(k_in + (size_t)pi * 8, 8), g = ec::sc_reduce(gamma_in + (size_t)pi * 8, 8);
-  const ec::U256 wi = ec::sc_mul(lagrange0(signers, d.S, i), ec::sc_reduce(xs + (size_t)signers[i] * 8, 8));
+  const ec::U256 lam = lagrange0(signers, d.S, i);
+  const ec::U256 wi = ec::sc_mul(lam, ec::sc_reduce(xs + (size_t)signers[i] * 8, 8));
   ec::u256_store(kq + (size_t)pi * 8, k);
   ec::u256_store(gq + (size_t)pi * 8, g);
   ec::u256_store(w + (size_t)pi * 8, wi);
   for (int j = 0; j < 64; ++j) k64[(size_t)pi * 64 + j] = j < 8 ? k.w[j] : 0u;
   const ec::Aff gg = ec::jac_to_aff(ec::jac_mul_gen(g));
   ec::aff_store(g_gamma + (size_t)pi * 16, gg);
-  ec::aff_store(g_w + (size_t)pi * 16, ec::jac_to_aff(ec::jac_mul_gen(wi)));
+  // g_w_vec[i] as the PEERS compute it, from pk_vec (SignKeys::g_w_vec, party_i.rs:527-544): lambda_i X_i — not from
+  // the secret share, so that a share inconsistent with the public key is caught by the check of rounds.rs:281
+  ec::aff_store(g_w + (size_t)pi * 16, ec::jac_to_aff(ec::jac_mul(lam, ec::aff_load(Xs + (size_t)signers[i] * 16))));
   ec::u256_store(com + (size_t)pi * 8, commit_point(gg, blind + (size_t)pi * 8));
 }
 
@@ -555,7 +558,7 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
   // ---- Round 0 ----
   uint32_t *kq = OW(nPI * 8), *gq = OW(nPI * 8), *w = OW(nPI * 8), *k64 = OW(nPI * 64), *g_gamma = OW(nPI * 16),
            *g_w = OW(nPI * 16), *com = OW(nPI * 8), *c_a = OW(nPI * 128);
-  GG_LAUNCH(r0_kernel, nPI, d, K->d_signers, K->x, z_k, z_gamma, z_blind, kq, gq, w, k64, g_gamma, g_w, com);
+  GG_LAUNCH(r0_kernel, nPI, d, K->d_signers, K->x, K->X, z_k, z_gamma, z_blind, kq, gq, w, k64, g_gamma, g_w, com);
   if (q.rc == MPE_OK) q.rc = paillier_encrypt(ctx, K->pk, (int)nPI, ix.key_pi, k64, z_ra, c_a, true, st);          // MessageA.c
   gg_trace(st, "encrypt k", q.rc);
   mpe_alice_proof ap{OW(nAP * 64), OW(nAP * 8), OW(nAP * 64), OW(nAP * 25), OW(nAP * 89)};

@@ -114,7 +114,6 @@ static int gg20_sign_one(const orc_gg20_keys* K, const orc_gg20_nonces* Z, int s
     lagrange_at_zero(lam, K->signers, S, i);                          /* party_i.rs:553-557 */
     zin(t, K->x + (size_t)me * 8, 8);
     mpz_mul(w[i], lam, t); sc_mod(w[i]);                               /* w_i = li * x_i :558 */
-    pt_mul(&g_w[i], w[i], &G);
     pt_mul(&g_gamma[i], gam[i], &G);                                   /* :562 */
     hash_commit_point(com[i], &g_gamma[i], blind[i]);                  /* phase1_broadcast :573-589 */
     paillier_enc(ca[i], N[me], NN[me], k[i], ra[i]);                   /* MessageA::a_with_predefined_randomness mta/mod.rs:68-75 */
@@ -130,8 +129,7 @@ static int gg20_sign_one(const orc_gg20_keys* K, const orc_gg20_nonces* Z, int s
   for (int i = 0; i < S; ++i) {
     lagrange_at_zero(lam, K->signers, S, i);
     pt_in(&tmp, K->X + (size_t)K->signers[i] * 16);
-    pt_mul(&tmp2, lam, &tmp);
-    if (!pt_eq(&tmp2, &g_w[i])) { rc = 2; goto done; }                 /* fixture consistency */
+    pt_mul(&g_w[i], lam, &tmp);          /* what the peers hold for signer i: from pk_vec, NOT from its secret share */
   }
 
   /* ---------------- Round 1 (rounds.rs:122-206): MessageB::b for gamma_i and w_i towards every peer ---------------- */

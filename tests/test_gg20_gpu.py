@@ -102,3 +102,20 @@ def test_config4_sessions_byte_identical_to_the_threaded_oracle(gpu_ctx, keys):
         assert list(wstatus[sl]) == [0] * cnt
         assert np.array_equal(r.view(np.uint32)[sl], wr[sl]) and np.array_equal(s.view(np.uint32)[sl], ws[sl])
         assert list(recid[sl]) == list(wrecid[sl]) and np.array_equal(R.view(np.uint32)[sl], wR[sl])
+
+
+def test_inconsistent_key_share_is_caught_in_the_same_round(gpu_ctx, keys):
+    """A signer whose share x_i does not match its public X_i: Bob's g^{w} check in verify_proofs_get_alpha (rounds.rs:281)
+    fails for every session.  GPU and oracle must stop in the same round (hundreds digit of the status)."""
+    from multi_party_ecdsa_amd import engine as E
+    lk = G.make_local_keys(keys, 1, 3, [0, 2])
+    lk["arrays"]["x"][0, 0] ^= 1                                   # party 1's share off by a bit; X, y untouched
+    B = 3
+    nonces = G.make_nonces(lk, B, seed="gpu-bad-share")
+    gk = E.Gg20Keys(gpu_ctx, 1, 3, [0, 2], lk["arrays"])
+    r, s, recid, status = E.gg20_sign(gpu_ctx, gk, {f: _dev(gpu_ctx, v) for f, v in nonces.items()}, B)
+    gpu_ctx.sync()
+    want = G.oracle_sign(lk, nonces, B)[4]
+    got = status.cpu().numpy()
+    assert all(int(x) != 0 for x in got) and all(int(x) != 0 for x in want)
+    assert [int(x) // 100 for x in got] == [int(x) // 100 for x in want]

@@ -230,6 +230,23 @@ def test_pdl_proof_oracle_and_soundness(gpu_ctx, keys, env):
                            F.point_words(G), {k: npw(v) for k, v in bad.items()})
         assert list(ok.cpu().numpy()) == list(w), f
         assert w[4 + j] == 0
+    # hostile values: s2 = N, 0, 2^2048 - 1; u2 = 0 / N^2 - 1; z = N~; a ciphertext that is a multiple of N (not a unit)
+    bad = {k: v.clone() for k, v in pr.items()}
+    row = lambda v, w: to_dev(gpu_ctx, F.words([v], w))[0]
+    N = [keys[k].N for k in kidx]
+    bad["s2"][0] = row(N[0], 64)
+    bad["s2"][1] = row(0, 64)
+    bad["s2"][3] = row((1 << 2048) - 1, 64)
+    bad["u2"][5] = row(0, 128)
+    bad["u2"][6] = row(N[6] * N[6] - 1, 128)
+    bad["z"][7] = row(keys[4 + sidx[7]].Nt, 64)
+    dC2 = dC.clone()
+    dC2[8] = row(N[8] * 3, 128)
+    ok = e.pdl_verify(gpu_ctx, pk, stm, dC2, dQ, dG, bad, di(kidx), di(sidx))
+    w = orc.pdl_verify(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], kidx, sidx, npw(dC2), F.point_words(Qp),
+                       F.point_words(G), {k: npw(v) for k, v in bad.items()})
+    assert list(ok.cpu().numpy()) == list(w)
+    assert sum(w[i] for i in (0, 1, 3, 5, 6, 7, 8)) == 0
 
 
 def test_config3_scale_proofs(gpu_ctx, keys, env):
