@@ -2,9 +2,10 @@
  * The signing half of Lindell'17 two-party ECDSA, restated over libgmp with every sampled value as an input:
  *   party two  PartialSig::compute            src/protocols/two_party_ecdsa/lindell_2017/party_two.rs:390-423
  *   party one  Signature::compute_with_recid  src/protocols/two_party_ecdsa/lindell_2017/party_one.rs:519-565
- * PARITY UNPINNED like the rest of the oracle (the reference has no vectors for this path); pinned by the independent
- * ECDSA verification of the signatures it produces (tests/test_lindell_cpu.py, the reference's own check:
- * lindell_2017/test.rs verifies party_one::verify on the result). */
+ * PARITY UNPINNED like the rest of the oracle (the reference has no vectors for this path); pinned by an independent
+ * pure-Python restatement (tests/pyref.py: other big-integer engine, textbook decryption) and by the independent
+ * ECDSA verification of the signatures it produces (tests/test_lindell_cpu.py; the reference's own test asserts
+ * party_one::verify on the result, lindell_2017/test.rs). */
 
 /* c3 = Enc(rho q + k2^-1 m; r) * c_key^(k2^-1 rx x2)  mod N^2 */
 void orc_lindell_partial_sig(int batch, int nkeys, const uint32_t* N, const int32_t* key_idx, const uint32_t* c_key,

@@ -199,3 +199,26 @@ def ecdsa_verify(pub, msg_int, r, s):
     w = pow(s, -1, Q)
     pt = ec_add(ec_mul(msg_int * w % Q, G), ec_mul(r * w % Q, pub))
     return pt is not None and pt[0] % Q == r
+
+
+# ---- Lindell'17 signing (two_party_ecdsa/lindell_2017/party_two.rs:390-423, party_one.rs:519-565) ------------
+def lindell_partial_sig(n, c_key, x2, k2, R1, msg, rho, r):
+    """PartialSig::compute with the sampled values (rho, the encryption randomness r) as inputs -> c3"""
+    nn = n * n
+    rx = ec_mul(k2, R1)[0] % Q
+    k2_inv = pow(k2, -1, Q)
+    partial = rho * Q + k2_inv * msg % Q
+    c1 = paillier_encrypt(n, partial, r)
+    v = k2_inv * (rx * x2 % Q) % Q
+    return pow(c_key, v, nn) * c1 % nn
+
+
+def lindell_sign(p, q, c3, k1, R2):
+    """Signature::compute_with_recid -> (r, s, recid); the plaintext through the textbook (non-CRT) decryption"""
+    Rp = ec_mul(k1, R2)
+    rx, ry = Rp[0] % Q, Rp[1] % Q
+    s2 = paillier_decrypt_textbook(p, q, c3) % Q * pow(k1, -1, Q) % Q
+    recid = ry & 1
+    if s2 > Q - s2:
+        s2, recid = Q - s2, recid ^ 1
+    return rx, s2, recid
