@@ -254,7 +254,7 @@ typedef struct {
  * sum; 701 final verify).  A failing session never aborts the batch.
  * dedup_verify = 0: faithful work (each range proof verified for both MessageB::b calls, every party verifies
  * every PDL proof, exactly as rounds.rs:151-175,546-558); 1: identical checks are evaluated once (same outputs).
- * chunk: sessions per internal pass (0 = default 65536). */
+ * chunk: sessions per internal pass (0 = 65536, fewer for wide shapes so that a pass stays under ~64 GB of workspace). */
 int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const mpe_gg20_nonces* nonces, uint32_t* d_r,
                   uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, int dedup_verify, int chunk,
                   void* stream);

@@ -688,7 +688,17 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const mpe_
                   uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, int dedup_verify, int chunk,
                   void* stream) {
   if (!ctx || !keys || !nonces || !d_r || !d_s || !d_recid || !d_status || batch < 0) return MPE_E_ARG;
-  if (chunk <= 0) chunk = 65536;      // ~13 GB of workspace at t=1, n=3; the EC kernels want >= 2 waves per SIMD
+  if (chunk <= 0) {
+    // 65 536 sessions per pass (~13 GB of workspace at t=1, n=3; the EC kernels want >= 2 waves per SIMD), fewer
+    // when the shape is wide: the workspace per session grows like S (S-1) n, keep a pass under ~64 GB
+    const size_t S = keys->S, n = keys->n, P = S * (S - 1), V = dedup_verify ? 1 : 2, PV = dedup_verify ? 1 : S;
+    const size_t nVI = P * V * n, nPV = PV * P;
+    const size_t words = S * 700 + S * n * 260 + nVI * 8 + P * 2 * 720 + P * 470 + nPV * 8 +
+                         (nVI > nPV ? nVI : nPV) * 2300 + S * n * 2100 + P * 2 * 300;          // per session, as sign_chunk sizes it
+    size_t fit = ((size_t)64 << 30) / (words * 4);
+    fit = fit >= 1024 ? (fit / 1024) * 1024 : (fit ? fit : 1);
+    chunk = (int)(fit < 65536 ? fit : 65536);
+  }
   for (int b0 = 0; b0 < batch; b0 += chunk) {
     const int B = batch - b0 < chunk ? batch - b0 : chunk;
     int rc = mpe::gg::sign_chunk(ctx, keys, B, b0, nonces, d_r, d_s, d_recid, d_R, d_status, dedup_verify, (hipStream_t)stream);
