@@ -1,21 +1,68 @@
-/* gg20_oracle.c — CPU ORACLE (test infrastructure, NOT product code): one party-complete GG20
- * signing session, all parties simulated in lock-step the way `round_based::dev::Simulation` does in
- * the reference's own test (src/protocols/multi_party_ecdsa/gg_2020/state_machine/sign.rs:667-763),
- * with every sampled value passed in.  Follows
- *   src/protocols/multi_party_ecdsa/gg_2020/state_machine/sign/rounds.rs:67-692  (Round0..Round7)
- *   src/protocols/multi_party_ecdsa/gg_2020/party_i.rs:526-936                   (SignKeys, LocalSignature)
- *   src/utilities/mta/mod.rs:52-179                                              (MessageA / MessageB)
- * and, for the un-vendored curv sigma proofs, SURVEY.md App. A.3 (PedersenProof, HomoELGamalProof,
- * HashCommitment, VerifiableSS::map_share_to_new_params).  PARITY UNPINNED — see mpe_oracle.h.
+/* gg20_oracle.c — CPU ORACLE (test infrastructure, NOT product code): GG20 signing as the reference structures it,
+ * ONE PARTY AT A TIME.  Each `gg_roundN` below is the restatement of `RoundN::proceed`
+ *   src/protocols/multi_party_ecdsa/gg_2020/state_machine/sign/rounds.rs:68,122,234,347,431,525,612,672
+ * a pure function of (this party's state, the messages of the previous round) -> (next state, outgoing message),
+ * over SignKeys / LocalSignature (src/protocols/multi_party_ecdsa/gg_2020/party_i.rs:526-936) and
+ * MessageA / MessageB (src/utilities/mta/mod.rs:52-179); for the un-vendored curv sigma proofs see SURVEY.md
+ * App. A.3 (PedersenProof, HomoELGamalProof, HashCommitment, VerifiableSS::map_share_to_new_params).
+ * Every value the reference samples is an input.  PARITY UNPINNED — see mpe_oracle.h.
+ *
+ * Messages are fixed-size records of 32-bit words, one per (sender, session); the layouts are those of
+ * include/mpecdsa_hip.h ("GG20 round messages"), so a test can compare whole message slabs byte for byte:
+ *   M0 Round0 out  (MessageA, SignBroadcastPhase1)     (n+1) sub-records of 256: AliceProof st | {c, com}
+ *   M1 Round1 out  (GammaI, WI) for every peer          2(S-1) sub-records of 208: MessageB (jj, v)
+ *   M2 Round2 out  (DeltaI, TI, TIProof)                96
+ *   M3 Round3 out  SignDecommitPhase1                   24
+ *   M4 Round4 out  (RDash, Vec<PDLwSlackProof>)         S sub-records of 450: proof for peer jj | R_dash
+ *   M5 Round5 out  (SI, HEGProof)                       64
+ *   M6 Round7 out  PartialSignature                     8
+ * P2P messages travel like broadcast ones and are filtered by the receiver, as in the reference's relay
+ * (examples/gg20_sm_client.rs:35-40).
+ *
+ * Status of a party in a session: 0, or 100*round + detail of its FIRST failed check, in the order the reference
+ * evaluates them (sticky):
+ *   101 MessageB::b -> InvalidKey (a peer's range proof)              rounds.rs:151-175  (Error::Round1)
+ *   201 verify_proofs_get_alpha                                        rounds.rs:264-279  (Error::Round3 [sic])
+ *   202 assert_eq!(m_b.b_proof.pk, g_w_vec[ind])                       rounds.rs:281      (panic)
+ *   303 assert_eq!(t_vec[i], t_proof_vec[i].com)                       rounds.rs:365-367  (panic)
+ *   301 phase3_reconstruct_delta: sum not invertible                   party_i.rs:635-640 (unwrap panic)
+ *   302 PedersenProof::verify                                          rounds.rs:371-378  (Error::Round3)
+ *   401 phase4 "bad gamma_i decommit", bad_actors = the peers          party_i.rs:642-687 (Error::Round5 [sic])
+ *   501 "Bad PDLwSlack proof", bad_actors = the first failing prover   party_i.rs:719-766, rounds.rs:546-558
+ *   502 phase5_check_R_dash_sum                                        party_i.rs:768-776
+ *   601 phase6_verify_proof, bad_actors = every failing prover         party_i.rs:801-833 (Error::Round6VerifyProof)
+ *   602 phase6_check_S_i_sum                                           party_i.rs:835-848 (Error::Round6CheckSig)
+ *   701 output_signature: verify failed                                party_i.rs:873-910 (Error::Round7)
+ * bad_actors is a bit mask over signer ordinals (positions in s_l), as the reference's Vec<usize>.
  *
  * Compiled into libmpe_oracle.so by #include from mpe_oracle.c (shares its static helpers). */
 
-/* ---- layouts ------------------------------------------------------------------------------ */
-/* keys: n parties; signers: S ascending indices into 0..n-1 */
-/* pair index pp = i*(S-1) + jj  (i = sender/owner signer ordinal, jj = peer ordinal, ind = jj<i ? jj : jj+1)
- * (the `ind` convention of rounds.rs:149,261,464) */
+#define GG_MAXS 8
+#define GG_MAXN 8
+#define GG_SUB0 256
+#define GG_SUB1 208
+#define GG_W2 96
+#define GG_W3 24
+#define GG_SUB4 450
+#define GG_W5 64
+#define GG_W6 8
+
+int orc_gg20_msg_words(int S, int n, int round) {
+  switch (round) {
+    case 0: return GG_SUB0 * (n + 1);
+    case 1: return GG_SUB1 * 2 * (S - 1);
+    case 2: return GG_W2;
+    case 3: return GG_W3;
+    case 4: return GG_SUB4 * S;
+    case 5: return GG_W5;
+    case 7: return GG_W6;
+    default: return 0;
+  }
+}
 
 static void sc_mod(mpz_t r) { mpz_mod(r, r, EC_Q); }
+static int ind_of(int i, int jj) { return jj < i ? jj : jj + 1; }          /* rounds.rs:149,261,464 */
+static int jme_of(int i, int ind) { return i < ind ? i : i - 1; }          /* my slot in the P2P messages of `ind` */
 
 /* HashCommitment::create_commitment_with_user_defined_randomness(m, r) = SHA256(bytes(m) || bytes(r)) as BigInt
  * with m = BigInt::from_bytes(point.to_bytes(true))   (party_i.rs:577-580,654-659) */
@@ -54,304 +101,572 @@ static void lagrange_at_zero(mpz_t out, const int32_t* signers, int S, int i) {
   mpz_clears(num, den, t, NULL);
 }
 
-#define MAXS 8
-#define MAXN 8
-
-/* returns 0 on success, otherwise 100*round + detail */
-static int gg20_sign_one(const orc_gg20_keys* K, const orc_gg20_nonces* Z, int sess, uint32_t* r_out, uint32_t* s_out,
-                         int32_t* recid_out, uint32_t* R_out) {
-  const int S = K->S, n = K->n, P = S * (S - 1);
-  if (S > MAXS || n > MAXN) return 1;
-  int rc = 0;
-  ec_setup();
-  /* per-session slices */
-  const uint32_t* k_w = Z->k + (size_t)sess * S * 8;
-  const uint32_t* gam_w = Z->gamma + (size_t)sess * S * 8;
-  const uint32_t* blind_w = Z->blind + (size_t)sess * S * 8;
-  const uint32_t* ra_w = Z->r_a + (size_t)sess * S * 64;
-  const size_t an = (size_t)sess * S * n;
-  const size_t pb = (size_t)sess * P * 2, pp0 = (size_t)sess * P;
-
-  mpz_t N[MAXN], NN[MAXN], pw[MAXN], qw[MAXN];
-  for (int a = 0; a < n; ++a) {
-    mpz_inits(N[a], NN[a], pw[a], qw[a], NULL);
-    zin(pw[a], K->p + (size_t)a * 32, 32); zin(qw[a], K->q + (size_t)a * 32, 32);
-    mpz_mul(N[a], pw[a], qw[a]); mpz_mul(NN[a], N[a], N[a]);
-  }
-  /* tables as words for the batch helpers of mpe_oracle.c */
-  uint32_t Nw[MAXN][64];
-  for (int a = 0; a < n; ++a) zout(Nw[a], 64, N[a]);
-
-  mpz_t k[MAXS], gam[MAXS], w[MAXS], blind[MAXS], com[MAXS], ca[MAXS], ra[MAXS], delta_i[MAXS], sigma_i[MAXS], l[MAXS], lam, t, t2, e;
-  pt_t G, H2, g_gamma[MAXS], g_w[MAXS], Tpt[MAXS], Rbar[MAXS], Spt[MAXS], R, tmp, tmp2, tmp3;
-  mpz_inits(lam, t, t2, e, NULL);
-  pt_init(&G); pt_init(&H2); pt_init(&R); pt_init(&tmp); pt_init(&tmp2); pt_init(&tmp3);
-  pt_gen(&G); pt_h2(&H2);
-  for (int i = 0; i < S; ++i) {
-    mpz_inits(k[i], gam[i], w[i], blind[i], com[i], ca[i], ra[i], delta_i[i], sigma_i[i], l[i], NULL);
-    pt_init(&g_gamma[i]); pt_init(&g_w[i]); pt_init(&Tpt[i]); pt_init(&Rbar[i]); pt_init(&Spt[i]);
-  }
-  /* MessageB state: [i][jj][v] */
-  static __thread uint32_t cb[MAXS][MAXS][2][128];
-  mpz_t beta[MAXS][MAXS][2];
-  pt_t Bpk[MAXS][MAXS][2], BR[MAXS][MAXS][2], BTpk[MAXS][MAXS][2], BTR[MAXS][MAXS][2];
-  mpz_t Bz[MAXS][MAXS][2], BTz[MAXS][MAXS][2];
-  for (int i = 0; i < S; ++i) for (int j = 0; j < S; ++j) for (int v = 0; v < 2; ++v) {
-    mpz_inits(beta[i][j][v], Bz[i][j][v], BTz[i][j][v], NULL);
-    pt_init(&Bpk[i][j][v]); pt_init(&BR[i][j][v]); pt_init(&BTpk[i][j][v]); pt_init(&BTR[i][j][v]);
-  }
-  /* Alice proofs [i][st] */
-  static __thread uint32_t az[MAXS][MAXN][64], ae[MAXS][MAXN][8], as_[MAXS][MAXN][64], as1[MAXS][MAXN][25], as2[MAXS][MAXN][89];
-  static __thread uint32_t caw[MAXS][128];
-
-  /* ---------------- Round 0 (rounds.rs:68-104): SignKeys::create, phase1_broadcast, MessageA::a ---------------- */
-  for (int i = 0; i < S; ++i) {
-    const int me = K->signers[i];
-    zin(k[i], k_w + i * 8, 8); sc_mod(k[i]);
-    zin(gam[i], gam_w + i * 8, 8); sc_mod(gam[i]);
-    zin(blind[i], blind_w + i * 8, 8);
-    zin(ra[i], ra_w + i * 64, 64);
-    lagrange_at_zero(lam, K->signers, S, i);                          /* party_i.rs:553-557 */
-    zin(t, K->x + (size_t)me * 8, 8);
-    mpz_mul(w[i], lam, t); sc_mod(w[i]);                               /* w_i = li * x_i :558 */
-    pt_mul(&g_gamma[i], gam[i], &G);                                   /* :562 */
-    hash_commit_point(com[i], &g_gamma[i], blind[i]);                  /* phase1_broadcast :573-589 */
-    paillier_enc(ca[i], N[me], NN[me], k[i], ra[i]);                   /* MessageA::a_with_predefined_randomness mta/mod.rs:68-75 */
-    zout(caw[i], 128, ca[i]);
-    for (int st = 0; st < n; ++st) {                                   /* :76-81, all n statements (rounds.rs:87) */
-      const size_t ix = an + (size_t)i * n + st;
-      orc_alice_generate(1, 1, Nw[me], 1, K->Nt + (size_t)st * 64, K->h1 + (size_t)st * 64, K->h2 + (size_t)st * 64, NULL, NULL,
-                         k_w + i * 8, caw[i], ra_w + i * 64, Z->al_alpha + ix * 24, Z->al_beta + ix * 64, Z->al_gamma + ix * 88,
-                         Z->al_rho + ix * 72, az[i][st], ae[i][st], as_[i][st], as1[i][st], as2[i][st]);
-    }
-  }
-  /* g_w_vec as every party recomputes it in Round2 (party_i.rs:527-544): lambda_j * X_j */
-  for (int i = 0; i < S; ++i) {
-    lagrange_at_zero(lam, K->signers, S, i);
-    pt_in(&tmp, K->X + (size_t)K->signers[i] * 16);
-    pt_mul(&g_w[i], lam, &tmp);          /* what the peers hold for signer i: from pk_vec, NOT from its secret share */
-  }
-
-  /* ---------------- Round 1 (rounds.rs:122-206): MessageB::b for gamma_i and w_i towards every peer ---------------- */
-  for (int i = 0; i < S; ++i) {
-    for (int jj = 0; jj < S - 1; ++jj) {
-      const int ind = jj < i ? jj : jj + 1, alice = K->signers[ind];
-      for (int v = 0; v < 2; ++v) {
-        /* verify Alice's n range proofs (mta/mod.rs:119-131); executed for both calls as the reference does */
-        for (int st = 0; st < n; ++st) {
-          uint8_t ok = 0;
-          orc_alice_verify(1, 1, Nw[alice], 1, K->Nt + (size_t)st * 64, K->h1 + (size_t)st * 64, K->h2 + (size_t)st * 64, NULL, NULL,
-                           caw[ind], az[ind][st], ae[ind][st], as_[ind][st], as1[ind][st], as2[ind][st], &ok);
-          if (!ok) { rc = 101; goto done; }
-        }
-        const size_t ix = pb + ((size_t)i * (S - 1) + jj) * 2 + v;
-        mpz_t bt, rr, cbt, bca; mpz_inits(bt, rr, cbt, bca, NULL);
-        zin(bt, Z->mb_beta_tag + ix * 64, 64);
-        zin(rr, Z->mb_r + ix * 64, 64);
-        paillier_enc(cbt, N[alice], NN[alice], bt, rr);                 /* :133-137 */
-        mpz_powm(bca, ca[ind], v == 0 ? gam[i] : w[i], NN[alice]);      /* Paillier::mul :140-144 */
-        mpz_mul(bca, bca, cbt); mpz_mod(bca, bca, NN[alice]);           /* Paillier::add :145 */
-        zout(cb[i][jj][v], 128, bca);
-        mpz_mod(t, bt, EC_Q);                                           /* beta_tag_fe :132 */
-        mpz_neg(beta[i][jj][v], t); sc_mod(beta[i][jj][v]);             /* beta = -beta_tag :146 */
-        /* DLogProof::prove(b), DLogProof::prove(beta_tag_fe) :147-148 */
-        uint32_t skw[8], pkw[16], Rw[16], zw[8];
-        zout(skw, 8, v == 0 ? gam[i] : w[i]);
-        orc_dlog_prove(1, skw, Z->mb_nonce_b + ix * 8, pkw, Rw, zw);
-        pt_in(&Bpk[i][jj][v], pkw); pt_in(&BR[i][jj][v], Rw); zin(Bz[i][jj][v], zw, 8);
-        zout(skw, 8, t);
-        orc_dlog_prove(1, skw, Z->mb_nonce_bt + ix * 8, pkw, Rw, zw);
-        pt_in(&BTpk[i][jj][v], pkw); pt_in(&BTR[i][jj][v], Rw); zin(BTz[i][jj][v], zw, 8);
-        mpz_clears(bt, rr, cbt, bca, NULL);
-      }
-    }
-  }
-
-  /* ---------------- Round 2 (rounds.rs:234-317): verify_proofs_get_alpha, delta_i, sigma_i, T_i ---------------- */
-  for (int i = 0; i < S; ++i) {
-    const int me = K->signers[i];
-    mpz_mul(delta_i[i], k[i], gam[i]); sc_mod(delta_i[i]);             /* phase2_delta_i :591-604 */
-    mpz_mul(sigma_i[i], k[i], w[i]); sc_mod(sigma_i[i]);               /* phase2_sigma_i :606-618 */
-    for (int jj = 0; jj < S - 1; ++jj) {
-      const int ind = jj < i ? jj : jj + 1;
-      /* the message peer `ind` sent to me: its pair ordinal for me */
-      const int jme = i < ind ? i : i - 1;
-      for (int v = 0; v < 2; ++v) {
-        mpz_t c, m; mpz_inits(c, m, NULL);
-        zin(c, cb[ind][jme][v], 128);
-        paillier_dec(m, pw[me], qw[me], c);                             /* mta/mod.rs:165 */
-        mpz_mod(t, m, EC_Q);                                            /* alpha :167 */
-        pt_mul(&tmp, t, &G);                                            /* g_alpha :168 */
-        pt_mul(&tmp2, k[i], &Bpk[ind][jme][v]); pt_add(&tmp2, &tmp2, &BTpk[ind][jme][v]);   /* ba_btag :169 */
-        uint32_t pkw[16], Rw[16], zw[8]; uint8_t ok1, ok2;
-        pt_out(pkw, &Bpk[ind][jme][v]); pt_out(Rw, &BR[ind][jme][v]); zout(zw, 8, Bz[ind][jme][v]);
-        orc_dlog_verify(1, pkw, Rw, zw, &ok1);
-        pt_out(pkw, &BTpk[ind][jme][v]); pt_out(Rw, &BTR[ind][jme][v]); zout(zw, 8, BTz[ind][jme][v]);
-        orc_dlog_verify(1, pkw, Rw, zw, &ok2);
-        if (!ok1 || !ok2 || !pt_eq(&tmp, &tmp2)) { mpz_clears(c, m, NULL); rc = 201; goto done; }   /* :170-177 */
-        if (v == 1 && !pt_eq(&Bpk[ind][jme][1], &g_w[ind])) { mpz_clears(c, m, NULL); rc = 202; goto done; }  /* rounds.rs:281 */
-        /* alpha_ij + beta_ij (my own beta from the MessageB I built for this peer) */
-        mpz_add(t, t, beta[i][jj][v]);
-        if (v == 0) { mpz_add(delta_i[i], delta_i[i], t); sc_mod(delta_i[i]); }
-        else { mpz_add(sigma_i[i], sigma_i[i], t); sc_mod(sigma_i[i]); }
-        mpz_clears(c, m, NULL);
-      }
-    }
-    /* phase3_compute_t_i :620-634 */
-    zin(l[i], Z->l + ((size_t)sess * S + i) * 8, 8); sc_mod(l[i]);
-    pt_mul(&tmp, sigma_i[i], &G); pt_mul(&tmp2, l[i], &H2); pt_add(&Tpt[i], &tmp, &tmp2);
-  }
-
-  /* ---------------- Round 3 (rounds.rs:347-402): PedersenProof prove/verify, delta^-1 ---------------- */
-  mpz_t dinv; mpz_init(dinv);
-  mpz_set_ui(dinv, 0);
-  for (int i = 0; i < S; ++i) { mpz_add(dinv, dinv, delta_i[i]); sc_mod(dinv); }
-  if (!mpz_invert(dinv, dinv, EC_Q)) { rc = 301; goto done2; }         /* phase3_reconstruct_delta :635-640 */
-  for (int i = 0; i < S; ++i) {
-    /* prove (App. A.3): a1 = s1 g, a2 = s2 h, com = m g + r h, e = H(g,h,com,a1,a2), z1 = s1 + e m, z2 = s2 + e r */
-    mpz_t s1, s2, z1, z2; mpz_inits(s1, s2, z1, z2, NULL);
-    zin(s1, Z->ped_s1 + ((size_t)sess * S + i) * 8, 8); sc_mod(s1);
-    zin(s2, Z->ped_s2 + ((size_t)sess * S + i) * 8, 8); sc_mod(s2);
-    pt_t a1, a2; pt_init(&a1); pt_init(&a2);
-    pt_mul(&a1, s1, &G); pt_mul(&a2, s2, &H2);
-    const pt_t* hp[5] = {&G, &H2, &Tpt[i], &a1, &a2};                  /* com == T_i (rounds.rs:366) */
+/* ---- curv PedersenProof / HomoELGamalProof, word interface --------------------------- */
+/* PedersenProof::prove(m, r) with the nonces s1, s2 as inputs: com = m G + r H, a1 = s1 G, a2 = s2 H,
+ * e = H(G, H, com, a1, a2), z1 = s1 + e m, z2 = s2 + e r */
+void orc_pedersen_prove(int batch, const uint32_t* m, const uint32_t* r, const uint32_t* s1, const uint32_t* s2, uint32_t* com,
+                        uint32_t* e_out, uint32_t* a1_out, uint32_t* a2_out, uint32_t* z1_out, uint32_t* z2_out) {
+  mpz_t M, R, S1, S2, e, z; mpz_inits(M, R, S1, S2, e, z, NULL);
+  pt_t G, H, C, A1, A2, t; pt_init(&G); pt_init(&H); pt_init(&C); pt_init(&A1); pt_init(&A2); pt_init(&t);
+  pt_gen(&G); pt_h2(&H);
+  for (int i = 0; i < batch; ++i) {
+    zin(M, m + (size_t)i * 8, 8); sc_mod(M); zin(R, r + (size_t)i * 8, 8); sc_mod(R);
+    zin(S1, s1 + (size_t)i * 8, 8); sc_mod(S1); zin(S2, s2 + (size_t)i * 8, 8); sc_mod(S2);
+    pt_mul(&C, M, &G); pt_mul(&t, R, &H); pt_add(&C, &C, &t);
+    pt_mul(&A1, S1, &G); pt_mul(&A2, S2, &H);
+    const pt_t* hp[5] = {&G, &H, &C, &A1, &A2};
     hash_points_scalar(e, hp, 5);
-    mpz_mul(z1, e, sigma_i[i]); mpz_add(z1, z1, s1); sc_mod(z1);
-    mpz_mul(z2, e, l[i]); mpz_add(z2, z2, s2); sc_mod(z2);
-    /* verify: z1 g + z2 h == a1 + a2 + e com  (every party verifies every proof; identical outcome) */
-    pt_mul(&tmp, z1, &G); pt_mul(&tmp2, z2, &H2); pt_add(&tmp, &tmp, &tmp2);
-    pt_mul(&tmp2, e, &Tpt[i]); pt_add(&tmp3, &a1, &a2); pt_add(&tmp3, &tmp3, &tmp2);
-    const int okp = pt_eq(&tmp, &tmp3);
-    pt_clear(&a1); pt_clear(&a2); mpz_clears(s1, s2, z1, z2, NULL);
-    if (!okp) { rc = 302; goto done2; }
+    pt_out(com + (size_t)i * 16, &C); pt_out(a1_out + (size_t)i * 16, &A1); pt_out(a2_out + (size_t)i * 16, &A2);
+    zout(e_out + (size_t)i * 8, 8, e);
+    mpz_mul(z, e, M); mpz_add(z, z, S1); sc_mod(z); zout(z1_out + (size_t)i * 8, 8, z);
+    mpz_mul(z, e, R); mpz_add(z, z, S2); sc_mod(z); zout(z2_out + (size_t)i * 8, 8, z);
   }
-
-  /* ---------------- Round 4 (rounds.rs:431-498): phase4 -> R, R_dash, PDL proofs ---------------- */
-  for (int i = 0; i < S; ++i) {                                          /* phase4 :642-687, as run by party i */
-    for (int jj = 0; jj < S - 1; ++jj) {
-      const int ind = jj < i ? jj : jj + 1, jme = i < ind ? i : i - 1;
-      hash_commit_point(t, &g_gamma[ind], blind[ind]);
-      if (!pt_eq(&Bpk[ind][jme][0], &g_gamma[ind]) || mpz_cmp(t, com[ind]) != 0) { rc = 401; goto done2; }
-    }
+  pt_clear(&G); pt_clear(&H); pt_clear(&C); pt_clear(&A1); pt_clear(&A2); pt_clear(&t);
+  mpz_clears(M, R, S1, S2, e, z, NULL);
+}
+/* PedersenProof::verify: e recomputed; z1 G + z2 H == a1 + a2 + e com */
+void orc_pedersen_verify(int batch, const uint32_t* com, const uint32_t* a1, const uint32_t* a2, const uint32_t* z1,
+                         const uint32_t* z2, uint8_t* ok) {
+  mpz_t e, Z1, Z2; mpz_inits(e, Z1, Z2, NULL);
+  pt_t G, H, C, A1, A2, l, r, t; pt_init(&G); pt_init(&H); pt_init(&C); pt_init(&A1); pt_init(&A2); pt_init(&l); pt_init(&r); pt_init(&t);
+  pt_gen(&G); pt_h2(&H);
+  for (int i = 0; i < batch; ++i) {
+    pt_in(&C, com + (size_t)i * 16); pt_in(&A1, a1 + (size_t)i * 16); pt_in(&A2, a2 + (size_t)i * 16);
+    zin(Z1, z1 + (size_t)i * 8, 8); zin(Z2, z2 + (size_t)i * 8, 8);
+    const pt_t* hp[5] = {&G, &H, &C, &A1, &A2};
+    hash_points_scalar(e, hp, 5);
+    pt_mul(&l, Z1, &G); pt_mul(&t, Z2, &H); pt_add(&l, &l, &t);
+    pt_add(&r, &A1, &A2); pt_mul(&t, e, &C); pt_add(&r, &r, &t);
+    ok[i] = (uint8_t)pt_eq(&l, &r);
   }
-  pt_set(&tmp, &g_gamma[0]);
-  for (int i = 1; i < S; ++i) pt_add(&tmp, &tmp, &g_gamma[i]);
-  pt_mul(&R, dinv, &tmp);                                                 /* R = (sum Gamma_i) * delta^-1 */
-  /* PDL proofs [i][jj] */
-  static __thread uint32_t pz[MAXS][MAXS][64], pu1[MAXS][MAXS][16], pu2[MAXS][MAXS][128], pu3[MAXS][MAXS][64], ps1[MAXS][MAXS][25],
-      ps2[MAXS][MAXS][64], ps3[MAXS][MAXS][89];
-  uint32_t Rw16[16], Rbw[MAXS][16];
-  pt_out(Rw16, &R);
-  for (int i = 0; i < S; ++i) {
-    const int me = K->signers[i];
-    pt_mul(&Rbar[i], k[i], &R);                                           /* R_dash = R * k_i  rounds.rs:452 */
-    pt_out(Rbw[i], &Rbar[i]);
-    for (int jj = 0; jj < S - 1; ++jj) {
-      const int ind = jj < i ? jj : jj + 1, st = K->signers[ind];
-      const size_t ix = pp0 + (size_t)i * (S - 1) + jj;
-      uint32_t kw8[8]; zout(kw8, 8, k[i]);
-      orc_pdl_prove(1, 1, Nw[me], 1, K->Nt + (size_t)st * 64, K->h1 + (size_t)st * 64, K->h2 + (size_t)st * 64, NULL, NULL, caw[i],
-                    Rbw[i], Rw16, kw8, ra_w + i * 64, Z->pdl_alpha + ix * 24, Z->pdl_beta + ix * 64, Z->pdl_rho + ix * 72,
-                    Z->pdl_gamma + ix * 88, pz[i][jj], pu1[i][jj], pu2[i][jj], pu3[i][jj], ps1[i][jj], ps2[i][jj], ps3[i][jj]);
-    }
-  }
-
-  /* ---------------- Round 5 (rounds.rs:525-601): verify all PDL proofs, sum R_dash, S_i + HEG proof ---------------- */
-  for (int verifier = 0; verifier < S; ++verifier) {                      /* every party verifies all S(S-1) proofs */
-    for (int i = 0; i < S; ++i) {
-      const int me = K->signers[i];
-      for (int jj = 0; jj < S - 1; ++jj) {
-        const int ind = jj < i ? jj : jj + 1, st = K->signers[ind];
-        uint8_t ok = 0;
-        orc_pdl_verify(1, 1, Nw[me], 1, K->Nt + (size_t)st * 64, K->h1 + (size_t)st * 64, K->h2 + (size_t)st * 64, NULL, NULL, caw[i],
-                       Rbw[i], Rw16, pz[i][jj], pu1[i][jj], pu2[i][jj], pu3[i][jj], ps1[i][jj], ps2[i][jj], ps3[i][jj], &ok);
-        if (!ok) { rc = 501; goto done2; }
-      }
-    }
-  }
-  pt_set(&tmp, &Rbar[0]);
-  for (int i = 1; i < S; ++i) pt_add(&tmp, &tmp, &Rbar[i]);
-  if (!pt_eq(&tmp, &G)) { rc = 502; goto done2; }                          /* phase5_check_R_dash_sum :768-776 */
-  pt_t ysum; pt_init(&ysum);
-  for (int i = 0; i < S; ++i) {
-    pt_mul(&Spt[i], sigma_i[i], &R);                                       /* phase6_compute_S_i :784 */
-    /* HomoELGamalProof (App. A.3) with G=R, H=base_point2, Y=generator, D=T_i, E=S_i, x=l_i, r=sigma_i */
-    mpz_t s1, s2, z1, z2; mpz_inits(s1, s2, z1, z2, NULL);
-    zin(s1, Z->heg_s1 + ((size_t)sess * S + i) * 8, 8); sc_mod(s1);
-    zin(s2, Z->heg_s2 + ((size_t)sess * S + i) * 8, 8); sc_mod(s2);
-    pt_t A1, A2, A3, TT; pt_init(&A1); pt_init(&A2); pt_init(&A3); pt_init(&TT);
-    pt_mul(&A1, s1, &H2); pt_mul(&A2, s2, &G); pt_mul(&A3, s2, &R); pt_add(&TT, &A1, &A2);
-    const pt_t* hp[7] = {&TT, &A3, &R, &H2, &G, &Tpt[i], &Spt[i]};
+  pt_clear(&G); pt_clear(&H); pt_clear(&C); pt_clear(&A1); pt_clear(&A2); pt_clear(&l); pt_clear(&r); pt_clear(&t);
+  mpz_clears(e, Z1, Z2, NULL);
+}
+/* HomoELGamalProof::prove(w{x, r}, delta{G, H, Y, D, E}) with the nonces s1, s2 as inputs:
+ * A1 = s1 H, A2 = s2 Y, A3 = s2 G, T = A1 + A2, e = H(T, A3, G, H, Y, D, E), z1 = s1 + e x (s1 if x = 0), z2 = s2 + e r */
+void orc_heg_prove(int batch, const uint32_t* x, const uint32_t* r, const uint32_t* s1, const uint32_t* s2, const uint32_t* Gp,
+                   const uint32_t* Hp, const uint32_t* Yp, const uint32_t* Dp, const uint32_t* Ep, uint32_t* T_out, uint32_t* A3_out,
+                   uint32_t* z1_out, uint32_t* z2_out) {
+  mpz_t X, R, S1, S2, e, z; mpz_inits(X, R, S1, S2, e, z, NULL);
+  pt_t G, H, Y, D, E, A1, A2, A3, T; pt_init(&G); pt_init(&H); pt_init(&Y); pt_init(&D); pt_init(&E); pt_init(&A1); pt_init(&A2); pt_init(&A3); pt_init(&T);
+  for (int i = 0; i < batch; ++i) {
+    zin(X, x + (size_t)i * 8, 8); sc_mod(X); zin(R, r + (size_t)i * 8, 8); sc_mod(R);
+    zin(S1, s1 + (size_t)i * 8, 8); sc_mod(S1); zin(S2, s2 + (size_t)i * 8, 8); sc_mod(S2);
+    pt_in(&G, Gp + (size_t)i * 16); pt_in(&H, Hp + (size_t)i * 16); pt_in(&Y, Yp + (size_t)i * 16); pt_in(&D, Dp + (size_t)i * 16); pt_in(&E, Ep + (size_t)i * 16);
+    pt_mul(&A1, S1, &H); pt_mul(&A2, S2, &Y); pt_mul(&A3, S2, &G); pt_add(&T, &A1, &A2);
+    const pt_t* hp[7] = {&T, &A3, &G, &H, &Y, &D, &E};
     hash_points_scalar(e, hp, 7);
-    if (mpz_sgn(l[i]) != 0) { mpz_mul(z1, e, l[i]); mpz_add(z1, z1, s1); sc_mod(z1); } else mpz_set(z1, s1);
-    mpz_mul(z2, e, sigma_i[i]); mpz_add(z2, z2, s2); sc_mod(z2);
-    /* Round 6 verify (party_i.rs:801-833): z1 H + z2 Y == T + e D  and  z2 G == A3 + e E */
-    pt_mul(&tmp, z1, &H2); pt_mul(&tmp2, z2, &G); pt_add(&tmp, &tmp, &tmp2);
-    pt_mul(&tmp2, e, &Tpt[i]); pt_add(&tmp2, &TT, &tmp2);
-    int okh = pt_eq(&tmp, &tmp2);
-    pt_mul(&tmp, z2, &R); pt_mul(&tmp2, e, &Spt[i]); pt_add(&tmp2, &A3, &tmp2);
-    okh = okh && pt_eq(&tmp, &tmp2);
-    pt_clear(&A1); pt_clear(&A2); pt_clear(&A3); pt_clear(&TT); mpz_clears(s1, s2, z1, z2, NULL);
-    if (!okh) { pt_clear(&ysum); rc = 601; goto done2; }
-    pt_add(&ysum, &ysum, &Spt[i]);
+    if (mpz_sgn(X) != 0) { mpz_mul(z, e, X); mpz_add(z, z, S1); sc_mod(z); } else mpz_set(z, S1);
+    zout(z1_out + (size_t)i * 8, 8, z);
+    mpz_mul(z, e, R); mpz_add(z, z, S2); sc_mod(z); zout(z2_out + (size_t)i * 8, 8, z);
+    pt_out(T_out + (size_t)i * 16, &T); pt_out(A3_out + (size_t)i * 16, &A3);
   }
-  pt_in(&tmp, K->y);
-  if (!pt_eq(&ysum, &tmp)) { pt_clear(&ysum); rc = 602; goto done2; }      /* phase6_check_S_i_sum :835-848 */
-  pt_clear(&ysum);
-
-  /* ---------------- Round 7 (party_i.rs:850-936): local sigs, output_signature, verify ---------------- */
-  {
-    mpz_t m, r, s, half; mpz_inits(m, r, s, half, NULL);
-    zin(m, Z->msg + (size_t)sess * 8, 8);
-    mpz_mod(r, R.x, EC_Q);
-    mpz_set_ui(s, 0);
-    for (int i = 0; i < S; ++i) {
-      mpz_mod(t, m, EC_Q); mpz_mul(t, t, k[i]);
-      mpz_mul(t2, r, sigma_i[i]); mpz_add(t, t, t2); sc_mod(t);            /* s_i = m k_i + r sigma_i :864 */
-      mpz_add(s, s, t); sc_mod(s);
-    }
-    int recid = mpz_tstbit(R.y, 0) ? 1 : 0;        /* ry = R.y mod q parity: y < p; the reference reduces mod q first (:890-895) */
-    { mpz_t ry; mpz_init(ry); mpz_mod(ry, R.y, EC_Q); recid = mpz_tstbit(ry, 0) ? 1 : 0; mpz_clear(ry); }
-    mpz_sub(half, EC_Q, s);
-    if (mpz_cmp(s, half) > 0) { mpz_set(s, half); recid ^= 1; }             /* :896-900 */
-    /* verify :913-936 */
-    mpz_t b, u1, u2; mpz_inits(b, u1, u2, NULL);
-    int okv = mpz_invert(b, s, EC_Q) != 0;
-    if (okv) {
-      mpz_mod(u1, m, EC_Q); mpz_mul(u1, u1, b); sc_mod(u1);
-      mpz_mul(u2, r, b); sc_mod(u2);
-      pt_in(&tmp3, K->y);
-      pt_mul(&tmp, u1, &G); pt_mul(&tmp2, u2, &tmp3); pt_add(&tmp, &tmp, &tmp2);
-      mpz_mod(t, tmp.x, EC_Q);
-      okv = !tmp.inf && mpz_cmp(t, r) == 0;
-    }
-    mpz_clears(b, u1, u2, NULL);
-    zout(r_out, 8, r); zout(s_out, 8, s); *recid_out = recid;
-    if (R_out) pt_out(R_out, &R);
-    mpz_clears(m, r, s, half, NULL);
-    if (!okv) rc = 701;
+  pt_clear(&G); pt_clear(&H); pt_clear(&Y); pt_clear(&D); pt_clear(&E); pt_clear(&A1); pt_clear(&A2); pt_clear(&A3); pt_clear(&T);
+  mpz_clears(X, R, S1, S2, e, z, NULL);
+}
+/* HomoELGamalProof::verify: z1 H + z2 Y == T + e D  and  z2 G == A3 + e E */
+void orc_heg_verify(int batch, const uint32_t* Gp, const uint32_t* Hp, const uint32_t* Yp, const uint32_t* Dp, const uint32_t* Ep,
+                    const uint32_t* Tp, const uint32_t* A3p, const uint32_t* z1, const uint32_t* z2, uint8_t* ok) {
+  mpz_t e, Z1, Z2; mpz_inits(e, Z1, Z2, NULL);
+  pt_t G, H, Y, D, E, A3, T, l, r, t; pt_init(&G); pt_init(&H); pt_init(&Y); pt_init(&D); pt_init(&E); pt_init(&A3); pt_init(&T); pt_init(&l); pt_init(&r); pt_init(&t);
+  for (int i = 0; i < batch; ++i) {
+    pt_in(&G, Gp + (size_t)i * 16); pt_in(&H, Hp + (size_t)i * 16); pt_in(&Y, Yp + (size_t)i * 16); pt_in(&D, Dp + (size_t)i * 16); pt_in(&E, Ep + (size_t)i * 16);
+    pt_in(&T, Tp + (size_t)i * 16); pt_in(&A3, A3p + (size_t)i * 16);
+    zin(Z1, z1 + (size_t)i * 8, 8); zin(Z2, z2 + (size_t)i * 8, 8);
+    const pt_t* hp[7] = {&T, &A3, &G, &H, &Y, &D, &E};
+    hash_points_scalar(e, hp, 7);
+    pt_mul(&l, Z1, &H); pt_mul(&t, Z2, &Y); pt_add(&l, &l, &t);
+    pt_mul(&t, e, &D); pt_add(&r, &T, &t);
+    int good = pt_eq(&l, &r);
+    pt_mul(&l, Z2, &G); pt_mul(&t, e, &E); pt_add(&r, &A3, &t);
+    good = good && pt_eq(&l, &r);
+    ok[i] = (uint8_t)good;
   }
-done2:
-  mpz_clear(dinv);
-done:
-  for (int a = 0; a < n; ++a) mpz_clears(N[a], NN[a], pw[a], qw[a], NULL);
-  for (int i = 0; i < S; ++i) {
-    mpz_clears(k[i], gam[i], w[i], blind[i], com[i], ca[i], ra[i], delta_i[i], sigma_i[i], l[i], NULL);
-    pt_clear(&g_gamma[i]); pt_clear(&g_w[i]); pt_clear(&Tpt[i]); pt_clear(&Rbar[i]); pt_clear(&Spt[i]);
+  pt_clear(&G); pt_clear(&H); pt_clear(&Y); pt_clear(&D); pt_clear(&E); pt_clear(&A3); pt_clear(&T); pt_clear(&l); pt_clear(&r); pt_clear(&t);
+  mpz_clears(e, Z1, Z2, NULL);
+}
+/* HashCommitment::create_commitment_with_user_defined_randomness(BigInt::from_bytes(P.to_bytes(true)), blind) */
+void orc_hash_commit_point(int batch, const uint32_t* P, const uint32_t* blind, uint32_t* com) {
+  mpz_t b, c; mpz_inits(b, c, NULL);
+  pt_t p; pt_init(&p);
+  for (int i = 0; i < batch; ++i) {
+    pt_in(&p, P + (size_t)i * 16); zin(b, blind + (size_t)i * 8, 8);
+    hash_commit_point(c, &p, b);
+    zout(com + (size_t)i * 8, 8, c);
   }
-  for (int i = 0; i < S; ++i) for (int j = 0; j < S; ++j) for (int v = 0; v < 2; ++v) {
-    mpz_clears(beta[i][j][v], Bz[i][j][v], BTz[i][j][v], NULL);
-    pt_clear(&Bpk[i][j][v]); pt_clear(&BR[i][j][v]); pt_clear(&BTpk[i][j][v]); pt_clear(&BTR[i][j][v]);
-  }
-  mpz_clears(lam, t, t2, e, NULL);
-  pt_clear(&G); pt_clear(&H2); pt_clear(&R); pt_clear(&tmp); pt_clear(&tmp2); pt_clear(&tmp3);
-  return rc;
+  pt_clear(&p); mpz_clears(b, c, NULL);
 }
 
-/* batch driver: sessions [first, first+count) ; status[i] = 0 on success */
+/* ---- one party's state in one session (what the reference carries from RoundN to RoundN+1) ------------------ */
+typedef struct {
+  uint32_t k[8], gamma[8], w[8], blind[8], ra[64];                 /* sign_keys, phase1_decom, m_a.1 */
+  uint32_t g_gamma[16], com[8], ca[128];
+  uint32_t beta[GG_MAXS][2][8];                                    /* beta_vec / ni_vec: [jj][v] */
+  uint32_t ca_all[GG_MAXS][128], com_all[GG_MAXS][8];              /* m_a_vec[..].c, bc_vec */
+  uint32_t bpk_in[GG_MAXS][16];                                    /* mb_gamma_s[jj].b_proof.pk */
+  uint32_t delta_i[8], sigma_i[8], l[8], T[16];
+  uint32_t ped[5][16];                                             /* TIProof: e, a1, a2, z1, z2 (8- or 16-word fields) */
+  uint32_t tvec[GG_MAXS][16];
+  uint32_t dinv[8], R[16], Rbar[16];
+  uint32_t S_i[16], heg[4][16];                                    /* HEGProof: T, A3, z1, z2 */
+  uint32_t r[8], s_i[8], m[8], sig_s[8];
+  int32_t recid;
+  int32_t status;
+  uint32_t bad;
+} gg_sess;
+
+struct orc_gg20_party {
+  orc_gg20_keys K;
+  int ord, B, L, li;
+  const int32_t* keyset;
+  orc_gg20_nonces Z;
+  gg_sess* s;
+};
+
+static void gg_fail(gg_sess* s, int code, uint32_t bad) {
+  if (s->status == 0) { s->status = code; s->bad = bad; }
+}
+
+/* key material of party `a` of the key set of session b */
+typedef struct { const uint32_t *x, *p, *q, *N, *Nt, *h1, *h2, *y, *X; } gg_kv;
+static gg_kv gg_keys_of(const orc_gg20_party* P, int b) {
+  const orc_gg20_keys* K = &P->K;
+  const size_t ks = P->keyset ? (size_t)P->keyset[b] : 0, n = (size_t)K->n;
+  gg_kv v;
+  v.x = K->x + ks * n * 8; v.p = K->p + ks * n * 32; v.q = K->q + ks * n * 32; v.N = K->N ? K->N + ks * n * 64 : NULL;
+  v.Nt = K->Nt + ks * n * 64; v.h1 = K->h1 + ks * n * 64; v.h2 = K->h2 + ks * n * 64; v.y = K->y + ks * 16; v.X = K->X + ks * n * 16;
+  return v;
+}
+/* N of party a: paillier_key_vec[a] (public), or p*q when the fixture holds every party's primes */
+static void gg_N_words(const gg_kv* kv, int a, uint32_t* Nw) {
+  if (kv->N) { memcpy(Nw, kv->N + (size_t)a * 64, 256); return; }
+  mpz_t p, q; mpz_inits(p, q, NULL);
+  zin(p, kv->p + (size_t)a * 32, 32); zin(q, kv->q + (size_t)a * 32, 32);
+  mpz_mul(p, p, q); zout(Nw, 64, p);
+  mpz_clears(p, q, NULL);
+}
+static const uint32_t* gg_rec(const uint32_t* in, const int64_t* off, int B, int W, int j, int b) {
+  const int64_t o = off ? off[j] : (int64_t)j * B;
+  return in + (size_t)(o + b) * (size_t)W;
+}
+static int words_eq(const uint32_t* a, const uint32_t* b, int n) { return memcmp(a, b, (size_t)n * 4) == 0; }
+
+/* ---- Round 0 (rounds.rs:68-104): SignKeys::create, phase1_broadcast, MessageA::a ----------------------------- */
+static void gg_round0(orc_gg20_party* P, int b, uint32_t* out) {
+  const orc_gg20_keys* K = &P->K;
+  const int S = K->S, n = K->n, i = P->ord, me = K->signers[i];
+  gg_sess* s = &P->s[b];
+  const gg_kv kv = gg_keys_of(P, b);
+  const size_t pi = (size_t)b * P->L + P->li;
+  mpz_t k, g, lam, x, w, blind, com; mpz_inits(k, g, lam, x, w, blind, com, NULL);
+  pt_t G, gg; pt_init(&G); pt_init(&gg); pt_gen(&G);
+  zin(k, P->Z.k + pi * 8, 8); sc_mod(k); zout(s->k, 8, k);
+  zin(g, P->Z.gamma + pi * 8, 8); sc_mod(g); zout(s->gamma, 8, g);
+  memcpy(s->blind, P->Z.blind + pi * 8, 32);
+  memcpy(s->ra, P->Z.r_a + pi * 64, 256);
+  lagrange_at_zero(lam, K->signers, S, i);                              /* party_i.rs:553-557 */
+  zin(x, kv.x + (size_t)me * 8, 8);
+  mpz_mul(w, lam, x); sc_mod(w); zout(s->w, 8, w);                       /* w_i = li * x_i :558 */
+  pt_mul(&gg, g, &G); pt_out(s->g_gamma, &gg);                           /* :562 */
+  zin(blind, s->blind, 8);
+  hash_commit_point(com, &gg, blind); zout(s->com, 8, com);              /* phase1_broadcast :573-589 */
+  uint32_t Nw[64], k64[64] = {0};
+  gg_N_words(&kv, me, Nw);
+  memcpy(k64, s->k, 32);
+  orc_paillier_encrypt(1, 1, Nw, NULL, k64, s->ra, s->ca);               /* MessageA::a mta/mod.rs:68-75 */
+  memset(out, 0, (size_t)GG_SUB0 * (n + 1) * 4);
+  for (int st = 0; st < n; ++st) {                                       /* :76-81, all n statements (rounds.rs:87) */
+    const size_t ix = pi * n + st;
+    uint32_t* o = out + (size_t)st * GG_SUB0;
+    orc_alice_generate(1, 1, Nw, 1, kv.Nt + (size_t)st * 64, kv.h1 + (size_t)st * 64, kv.h2 + (size_t)st * 64, NULL, NULL, s->k, s->ca,
+                       s->ra, P->Z.al_alpha + ix * 24, P->Z.al_beta + ix * 64, P->Z.al_gamma + ix * 88, P->Z.al_rho + ix * 72,
+                       o, o + 64, o + 72, o + 136, o + 161);
+  }
+  memcpy(out + (size_t)n * GG_SUB0, s->ca, 512);
+  memcpy(out + (size_t)n * GG_SUB0 + 128, s->com, 32);
+  pt_clear(&G); pt_clear(&gg); mpz_clears(k, g, lam, x, w, blind, com, NULL);
+}
+
+/* ---- Round 1 (rounds.rs:122-206): MessageB::b for gamma_i and w_i towards every peer ------------------------- */
+static void gg_round1(orc_gg20_party* P, int b, const uint32_t* in, const int64_t* off, uint32_t* out) {
+  const orc_gg20_keys* K = &P->K;
+  const int S = K->S, n = K->n, i = P->ord, W0 = GG_SUB0 * (n + 1);
+  gg_sess* s = &P->s[b];
+  const gg_kv kv = gg_keys_of(P, b);
+  const size_t pi = (size_t)b * P->L + P->li;
+  for (int j = 0; j < S; ++j) {                                          /* into_vec_including_me: m_a_vec, bc_vec */
+    const uint32_t* rec = gg_rec(in, off, P->B, W0, j, b) + (size_t)n * GG_SUB0;
+    memcpy(s->ca_all[j], rec, 512); memcpy(s->com_all[j], rec + 128, 32);
+  }
+  mpz_t bt, t; mpz_inits(bt, t, NULL);
+  memset(out, 0, (size_t)GG_SUB1 * 2 * (S - 1) * 4);
+  for (int jj = 0; jj < S - 1; ++jj) {
+    const int ind = ind_of(i, jj), alice = K->signers[ind];
+    uint32_t Nw[64];
+    gg_N_words(&kv, alice, Nw);
+    const uint32_t* arec = gg_rec(in, off, P->B, W0, ind, b);
+    for (int v = 0; v < 2; ++v) {
+      /* verify Alice's n range proofs (mta/mod.rs:119-131); executed for both calls as the reference does */
+      for (int st = 0; st < n; ++st) {
+        const uint32_t* pr = arec + (size_t)st * GG_SUB0;
+        uint8_t ok = 0;
+        orc_alice_verify(1, 1, Nw, 1, kv.Nt + (size_t)st * 64, kv.h1 + (size_t)st * 64, kv.h2 + (size_t)st * 64, NULL, NULL,
+                         s->ca_all[ind], pr, pr + 64, pr + 72, pr + 136, pr + 161, &ok);
+        if (!ok) gg_fail(s, 101, 0);
+      }
+      const size_t ix = (pi * (S - 1) + jj) * 2 + v;
+      uint32_t* o = out + (size_t)(jj * 2 + v) * GG_SUB1;
+      const uint32_t* bsel = v == 0 ? s->gamma : s->w;
+      uint32_t cbt[128], bca[128], b64[64] = {0};
+      orc_paillier_encrypt(1, 1, Nw, NULL, P->Z.mb_beta_tag + ix * 64, P->Z.mb_r + ix * 64, cbt);       /* :133-137 */
+      memcpy(b64, bsel, 32);
+      orc_paillier_mul(1, 1, Nw, NULL, s->ca_all[ind], b64, bca);                                        /* :140-144 */
+      orc_paillier_add(1, 1, Nw, NULL, bca, cbt, o);                                                     /* :145 */
+      zin(bt, P->Z.mb_beta_tag + ix * 64, 64); sc_mod(bt);                                               /* beta_tag_fe :132 */
+      mpz_neg(t, bt); sc_mod(t); zout(s->beta[jj][v], 8, t);                                             /* beta = -beta_tag :146 */
+      orc_dlog_prove(1, bsel, P->Z.mb_nonce_b + ix * 8, o + 128, o + 144, o + 160);                      /* :147 */
+      uint32_t btw[8]; zout(btw, 8, bt);
+      orc_dlog_prove(1, btw, P->Z.mb_nonce_bt + ix * 8, o + 168, o + 184, o + 200);                      /* :148 */
+    }
+  }
+  mpz_clears(bt, t, NULL);
+}
+
+/* ---- Round 2 (rounds.rs:234-317): verify_proofs_get_alpha, delta_i, sigma_i, T_i + PedersenProof -------------- */
+static void gg_round2(orc_gg20_party* P, int b, const uint32_t* in, const int64_t* off, uint32_t* out) {
+  const orc_gg20_keys* K = &P->K;
+  const int S = K->S, i = P->ord, me = K->signers[i], W1 = GG_SUB1 * 2 * (S - 1);
+  gg_sess* s = &P->s[b];
+  const gg_kv kv = gg_keys_of(P, b);
+  const size_t pi = (size_t)b * P->L + P->li;
+  mpz_t k, de, si, t, lam, al; mpz_inits(k, de, si, t, lam, al, NULL);
+  pt_t G, Bp, BTp, gw, a, c, Xp; pt_init(&G); pt_init(&Bp); pt_init(&BTp); pt_init(&gw); pt_init(&a); pt_init(&c); pt_init(&Xp); pt_gen(&G);
+  zin(k, s->k, 8);
+  zin(t, s->gamma, 8); mpz_mul(de, k, t); sc_mod(de);                     /* phase2_delta_i :591-604 */
+  zin(t, s->w, 8); mpz_mul(si, k, t); sc_mod(si);                         /* phase2_sigma_i :606-618 */
+  for (int jj = 0; jj < S - 1; ++jj) {
+    const int ind = ind_of(i, jj), jme = jme_of(i, ind);
+    const uint32_t* rec = gg_rec(in, off, P->B, W1, ind, b);
+    for (int v = 0; v < 2; ++v) {
+      const uint32_t* mb = rec + (size_t)(jme * 2 + v) * GG_SUB1;
+      uint32_t mw[64];
+      orc_paillier_decrypt(1, 1, kv.p + (size_t)me * 32, kv.q + (size_t)me * 32, NULL, mb, mw);   /* mta/mod.rs:165 */
+      zin(al, mw, 64); sc_mod(al);                                         /* alpha :167 */
+      pt_mul(&a, al, &G);                                                  /* g_alpha :168 */
+      pt_in(&Bp, mb + 128); pt_in(&BTp, mb + 168);
+      pt_mul(&c, k, &Bp); pt_add(&c, &c, &BTp);                            /* ba_btag :169 */
+      uint8_t ok1 = 0, ok2 = 0;
+      orc_dlog_verify(1, mb + 128, mb + 144, mb + 160, &ok1);              /* :170 */
+      orc_dlog_verify(1, mb + 168, mb + 184, mb + 200, &ok2);              /* :171 */
+      if (!ok1 || !ok2 || !pt_eq(&a, &c)) gg_fail(s, 201, 0);              /* :173-177 */
+      if (v == 1) {                                                        /* rounds.rs:281: g_w_vec[ind] = lambda_ind X_ind (party_i.rs:527-544) */
+        lagrange_at_zero(lam, K->signers, S, ind);
+        pt_in(&Xp, kv.X + (size_t)K->signers[ind] * 16);
+        pt_mul(&gw, lam, &Xp);
+        if (!pt_eq(&Bp, &gw)) gg_fail(s, 202, 0);
+      } else {
+        memcpy(s->bpk_in[jj], mb + 128, 64);                               /* mb_gamma_s[jj].b_proof.pk, used by phase4 */
+      }
+      zin(t, s->beta[jj][v], 8); mpz_add(t, t, al);
+      if (v == 0) { mpz_add(de, de, t); sc_mod(de); } else { mpz_add(si, si, t); sc_mod(si); }
+    }
+  }
+  zout(s->delta_i, 8, de); zout(s->sigma_i, 8, si);
+  /* phase3_compute_t_i :620-634: T = sigma G + l H and PedersenProof::prove(sigma_i, l) */
+  zin(t, P->Z.l + pi * 8, 8); sc_mod(t); zout(s->l, 8, t);
+  memset(s->ped, 0, sizeof s->ped);
+  orc_pedersen_prove(1, s->sigma_i, s->l, P->Z.ped_s1 + pi * 8, P->Z.ped_s2 + pi * 8, s->T, s->ped[0], s->ped[1], s->ped[2], s->ped[3], s->ped[4]);
+  memset(out, 0, GG_W2 * 4);
+  memcpy(out, s->delta_i, 32); memcpy(out + 8, s->T, 64);
+  memcpy(out + 24, s->ped[0], 32); memcpy(out + 32, s->ped[1], 64); memcpy(out + 48, s->ped[2], 64); memcpy(out + 64, s->T, 64);
+  memcpy(out + 80, s->ped[3], 32); memcpy(out + 88, s->ped[4], 32);
+  pt_clear(&G); pt_clear(&Bp); pt_clear(&BTp); pt_clear(&gw); pt_clear(&a); pt_clear(&c); pt_clear(&Xp);
+  mpz_clears(k, de, si, t, lam, al, NULL);
+}
+
+/* ---- Round 3 (rounds.rs:347-402): T_i == proof.com, delta^-1, PedersenProof::verify; decommit ------------------ */
+static void gg_round3(orc_gg20_party* P, int b, const uint32_t* in, const int64_t* off, uint32_t* out) {
+  const int S = P->K.S;
+  gg_sess* s = &P->s[b];
+  mpz_t sum, t; mpz_inits(sum, t, NULL);
+  int com_ok = 1, ped_ok = 1;
+  for (int j = 0; j < S; ++j) {
+    const uint32_t* rec = gg_rec(in, off, P->B, GG_W2, j, b);
+    memcpy(s->tvec[j], rec + 8, 64);
+    if (!words_eq(rec + 8, rec + 64, 16)) com_ok = 0;                     /* rounds.rs:365-367 */
+    zin(t, rec, 8); mpz_add(sum, sum, t); sc_mod(sum);
+    uint8_t ok = 0;
+    orc_pedersen_verify(1, rec + 64, rec + 32, rec + 48, rec + 80, rec + 88, &ok);
+    if (!ok) ped_ok = 0;
+  }
+  if (!com_ok) gg_fail(s, 303, 0);
+  if (!mpz_invert(t, sum, EC_Q)) { gg_fail(s, 301, 0); mpz_set_ui(t, 0); }   /* phase3_reconstruct_delta :635-640 */
+  zout(s->dinv, 8, t);
+  if (!ped_ok) gg_fail(s, 302, 0);
+  memset(out, 0, GG_W3 * 4);
+  memcpy(out, s->blind, 32); memcpy(out + 8, s->g_gamma, 64);
+  mpz_clears(sum, t, NULL);
+}
+
+/* ---- Round 4 (rounds.rs:431-498): phase4 -> R, R_dash = k_i R, one PDLwSlackProof per peer ------------------- */
+static void gg_round4(orc_gg20_party* P, int b, const uint32_t* in, const int64_t* off, uint32_t* out) {
+  const orc_gg20_keys* K = &P->K;
+  const int S = K->S, i = P->ord, me = K->signers[i];
+  gg_sess* s = &P->s[b];
+  const gg_kv kv = gg_keys_of(P, b);
+  const size_t pi = (size_t)b * P->L + P->li;
+  mpz_t t, blind, com; mpz_inits(t, blind, com, NULL);
+  pt_t gg, acc, R, Rb; pt_init(&gg); pt_init(&acc); pt_init(&R); pt_init(&Rb);
+  uint32_t bad = 0;
+  for (int jj = 0; jj < S - 1; ++jj) {                                    /* phase4 :642-687 */
+    const int ind = ind_of(i, jj);
+    const uint32_t* rec = gg_rec(in, off, P->B, GG_W3, ind, b);
+    pt_in(&gg, rec + 8); zin(blind, rec, 8);
+    hash_commit_point(com, &gg, blind);
+    zin(t, s->com_all[ind], 8);
+    if (!words_eq(s->bpk_in[jj], rec + 8, 16) || mpz_cmp(com, t) != 0) bad |= 1u << ind;
+  }
+  if (bad) gg_fail(s, 401, bad);
+  for (int j = 0; j < S; ++j) {                                           /* gamma_sum over the decommitments, mine included */
+    pt_in(&gg, gg_rec(in, off, P->B, GG_W3, j, b) + 8);
+    pt_add(&acc, &acc, &gg);
+  }
+  zin(t, s->dinv, 8); pt_mul(&R, t, &acc); pt_out(s->R, &R);              /* R = gamma_sum * delta_inv */
+  zin(t, s->k, 8); pt_mul(&Rb, t, &R); pt_out(s->Rbar, &Rb);              /* R_dash = R * k_i  rounds.rs:452 */
+  uint32_t Nw[64];
+  gg_N_words(&kv, me, Nw);
+  memset(out, 0, (size_t)GG_SUB4 * S * 4);
+  for (int jj = 0; jj < S - 1; ++jj) {                                    /* phase5_proof_pdl :691-717 */
+    const int st = K->signers[ind_of(i, jj)];
+    const size_t ix = pi * (S - 1) + jj;
+    uint32_t* o = out + (size_t)jj * GG_SUB4;
+    orc_pdl_prove(1, 1, Nw, 1, kv.Nt + (size_t)st * 64, kv.h1 + (size_t)st * 64, kv.h2 + (size_t)st * 64, NULL, NULL, s->ca, s->Rbar,
+                  s->R, s->k, s->ra, P->Z.pdl_alpha + ix * 24, P->Z.pdl_beta + ix * 64, P->Z.pdl_rho + ix * 72, P->Z.pdl_gamma + ix * 88,
+                  o, o + 64, o + 80, o + 208, o + 272, o + 297, o + 361);
+  }
+  memcpy(out + (size_t)(S - 1) * GG_SUB4, s->Rbar, 64);
+  pt_clear(&gg); pt_clear(&acc); pt_clear(&R); pt_clear(&Rb); mpz_clears(t, blind, com, NULL);
+}
+
+/* ---- Round 5 (rounds.rs:525-601): all PDL proofs, sum R_dash, S_i + HomoELGamalProof ------------------------- */
+static void gg_round5(orc_gg20_party* P, int b, const uint32_t* in, const int64_t* off, uint32_t* out) {
+  const orc_gg20_keys* K = &P->K;
+  const int S = K->S, W4 = GG_SUB4 * S;
+  gg_sess* s = &P->s[b];
+  const gg_kv kv = gg_keys_of(P, b);
+  const size_t pi = (size_t)b * P->L + P->li;
+  pt_t acc, G, t; pt_init(&acc); pt_init(&G); pt_init(&t); pt_gen(&G);
+  uint32_t bad = 0;
+  for (int i = 0; i < S && !bad; ++i) {                                    /* `?` stops at the first failing prover */
+    const uint32_t* rec = gg_rec(in, off, P->B, W4, i, b);
+    const uint32_t* rdash = rec + (size_t)(S - 1) * GG_SUB4;
+    uint32_t Nw[64];
+    gg_N_words(&kv, K->signers[i], Nw);
+    for (int jj = 0; jj < S - 1; ++jj) {                                   /* phase5_verify_pdl :719-766, G = MY R */
+      const int st = K->signers[ind_of(i, jj)];
+      const uint32_t* o = rec + (size_t)jj * GG_SUB4;
+      uint8_t ok = 0;
+      orc_pdl_verify(1, 1, Nw, 1, kv.Nt + (size_t)st * 64, kv.h1 + (size_t)st * 64, kv.h2 + (size_t)st * 64, NULL, NULL, s->ca_all[i],
+                     rdash, s->R, o, o + 64, o + 80, o + 208, o + 272, o + 297, o + 361, &ok);
+      if (!ok) bad |= 1u << i;
+    }
+  }
+  if (bad) gg_fail(s, 501, bad);
+  for (int j = 0; j < S; ++j) {                                            /* phase5_check_R_dash_sum :768-776 */
+    pt_in(&t, gg_rec(in, off, P->B, W4, j, b) + (size_t)(S - 1) * GG_SUB4);
+    pt_add(&acc, &acc, &t);
+  }
+  if (!pt_eq(&acc, &G)) gg_fail(s, 502, 0);
+  /* phase6_compute_S_i_and_proof_of_consistency :778-799: G = R, H = base_point2, Y = generator, D = T_i, E = S_i, x = l_i, r = sigma_i */
+  mpz_t si; mpz_init(si);
+  pt_t R, Sp, H; pt_init(&R); pt_init(&Sp); pt_init(&H); pt_h2(&H);
+  pt_in(&R, s->R); zin(si, s->sigma_i, 8);
+  pt_mul(&Sp, si, &R); pt_out(s->S_i, &Sp);
+  uint32_t Gw[16], Hw[16];
+  pt_out(Gw, &G); pt_out(Hw, &H);
+  memset(s->heg, 0, sizeof s->heg);
+  orc_heg_prove(1, s->l, s->sigma_i, P->Z.heg_s1 + pi * 8, P->Z.heg_s2 + pi * 8, s->R, Hw, Gw, s->T, s->S_i, s->heg[0], s->heg[1], s->heg[2], s->heg[3]);
+  memset(out, 0, GG_W5 * 4);
+  memcpy(out, s->S_i, 64); memcpy(out + 16, s->heg[0], 64); memcpy(out + 32, s->heg[1], 64);
+  memcpy(out + 48, s->heg[2], 32); memcpy(out + 56, s->heg[3], 32);
+  pt_clear(&acc); pt_clear(&G); pt_clear(&t); pt_clear(&R); pt_clear(&Sp); pt_clear(&H); mpz_clear(si);
+}
+
+/* ---- Round 6 (rounds.rs:612-636): every HomoELGamalProof, sum S_i == y ------------------------------------------- */
+static void gg_round6(orc_gg20_party* P, int b, const uint32_t* in, const int64_t* off) {
+  const int S = P->K.S;
+  gg_sess* s = &P->s[b];
+  const gg_kv kv = gg_keys_of(P, b);
+  pt_t acc, G, H, t, y; pt_init(&acc); pt_init(&G); pt_init(&H); pt_init(&t); pt_init(&y); pt_gen(&G); pt_h2(&H);
+  uint32_t Gw[16], Hw[16], bad = 0;
+  pt_out(Gw, &G); pt_out(Hw, &H);
+  for (int j = 0; j < S; ++j) {                                            /* phase6_verify_proof :801-833: collects every failure */
+    const uint32_t* rec = gg_rec(in, off, P->B, GG_W5, j, b);
+    uint8_t ok = 0;
+    orc_heg_verify(1, s->R, Hw, Gw, s->tvec[j], rec, rec + 16, rec + 32, rec + 48, rec + 56, &ok);
+    if (!ok) bad |= 1u << j;
+    pt_in(&t, rec); pt_add(&acc, &acc, &t);
+  }
+  if (bad) gg_fail(s, 601, bad);
+  pt_in(&y, kv.y);
+  if (!pt_eq(&acc, &y)) gg_fail(s, 602, 0);                                /* phase6_check_S_i_sum :835-848 */
+  pt_clear(&acc); pt_clear(&G); pt_clear(&H); pt_clear(&t); pt_clear(&y);
+}
+
+/* ---- Round 7 (rounds.rs:672-692, party_i.rs:850-871): phase7_local_sig -> PartialSignature ----------------------- */
+static void gg_round7(orc_gg20_party* P, int b, uint32_t* out) {
+  gg_sess* s = &P->s[b];
+  mpz_t m, r, t, t2; mpz_inits(m, r, t, t2, NULL);
+  memcpy(s->m, P->Z.msg + (size_t)b * 8, 32);
+  zin(m, s->m, 8); sc_mod(m);
+  zin(r, s->R, 8); sc_mod(r); zout(s->r, 8, r);                            /* r = R.x mod q */
+  zin(t, s->k, 8); mpz_mul(t, t, m);
+  zin(t2, s->sigma_i, 8); mpz_mul(t2, t2, r); mpz_add(t, t, t2); sc_mod(t);   /* s_i = m k_i + r sigma_i :864 */
+  zout(s->s_i, 8, t);
+  memcpy(out, s->s_i, 32);
+  mpz_clears(m, r, t, t2, NULL);
+}
+/* SignManual::complete -> output_signature (party_i.rs:873-910) + verify (:913-936) */
+static void gg_complete(orc_gg20_party* P, int b, const uint32_t* in, const int64_t* off) {
+  const int S = P->K.S, i = P->ord;
+  gg_sess* s = &P->s[b];
+  const gg_kv kv = gg_keys_of(P, b);
+  mpz_t sg, t, r, m, half, ry; mpz_inits(sg, t, r, m, half, ry, NULL);
+  zin(sg, s->s_i, 8);
+  for (int j = 0; j < S; ++j) {
+    if (j == i) continue;
+    zin(t, gg_rec(in, off, P->B, GG_W6, j, b), 8); mpz_add(sg, sg, t); sc_mod(sg);
+  }
+  zin(r, s->r, 8);
+  zin(ry, s->R + 8, 8); mpz_mod(ry, ry, EC_Q);
+  int recid = mpz_tstbit(ry, 0) ? 1 : 0;
+  mpz_sub(half, EC_Q, sg);
+  if (mpz_cmp(sg, half) > 0) { mpz_set(sg, half); recid ^= 1; }             /* :896-900 */
+  pt_t G, y, a, c; pt_init(&G); pt_init(&y); pt_init(&a); pt_init(&c); pt_gen(&G);
+  int okv = mpz_invert(t, sg, EC_Q) != 0;
+  if (okv) {
+    mpz_t u1, u2; mpz_inits(u1, u2, NULL);
+    zin(m, s->m, 8); sc_mod(m);
+    mpz_mul(u1, m, t); sc_mod(u1); mpz_mul(u2, r, t); sc_mod(u2);
+    pt_in(&y, kv.y);
+    pt_mul(&a, u1, &G); pt_mul(&c, u2, &y); pt_add(&a, &a, &c);
+    mpz_mod(t, a.x, EC_Q);
+    okv = !a.inf && mpz_cmp(t, r) == 0;
+    mpz_clears(u1, u2, NULL);
+  }
+  if (!okv) gg_fail(s, 701, 0);
+  zout(s->sig_s, 8, sg); s->recid = recid;
+  pt_clear(&G); pt_clear(&y); pt_clear(&a); pt_clear(&c);
+  mpz_clears(sg, t, r, m, half, ry, NULL);
+}
+
+/* ---- the per-party object ------------------------------------------------------------------------------------------ */
+/* K: tables [nkeysets][n][..]; this party reads x, p, q of its OWN index only (signers[ord]) and N of everybody (NULL: p*q).
+ * Z: nonces with leading dimensions [B][L], this party at position li (L = 1, li = 0 when the arrays hold one party).
+ * keyset: [B] key-set index per session, or NULL. */
+orc_gg20_party* orc_gg20_party_new(const orc_gg20_keys* K, int ord, int B, const orc_gg20_nonces* Z, int L, int li, const int32_t* keyset) {
+  if (K->S > GG_MAXS || K->n > GG_MAXN || ord < 0 || ord >= K->S) return NULL;
+  ec_setup();
+  orc_gg20_party* P = (orc_gg20_party*)calloc(1, sizeof *P);
+  P->K = *K; P->ord = ord; P->B = B; P->L = L; P->li = li; P->keyset = keyset; P->Z = *Z;
+  P->s = (gg_sess*)calloc((size_t)B, sizeof(gg_sess));
+  return P;
+}
+void orc_gg20_party_free(orc_gg20_party* P) {
+  if (!P) return;
+  if (P->s) { memset(P->s, 0, (size_t)P->B * sizeof(gg_sess)); free(P->s); }      /* secrets do not outlive the object */
+  free(P);
+}
+/* round 0..7 = RoundN::proceed / Round7::new; round 8 = SignManual::complete.  in: the previous round's records of all S senders
+ * (sender j's [B][W] block at record offset in_off[j]; NULL: j*B); out: this party's [B][W] block.  Sessions [first, first+count). */
+void orc_gg20_party_round(orc_gg20_party* P, int round, const uint32_t* in, const int64_t* in_off, uint32_t* out, int first, int count) {
+  const int S = P->K.S, n = P->K.n;
+  const size_t W = (size_t)orc_gg20_msg_words(S, n, round);
+  for (int b = first; b < first + count; ++b) {
+    uint32_t* o = out ? out + (size_t)b * W : NULL;
+    switch (round) {
+      case 0: gg_round0(P, b, o); break;
+      case 1: gg_round1(P, b, in, in_off, o); break;
+      case 2: gg_round2(P, b, in, in_off, o); break;
+      case 3: gg_round3(P, b, in, in_off, o); break;
+      case 4: gg_round4(P, b, in, in_off, o); break;
+      case 5: gg_round5(P, b, in, in_off, o); break;
+      case 6: gg_round6(P, b, in, in_off); break;
+      case 7: gg_round7(P, b, o); break;
+      case 8: gg_complete(P, b, in, in_off); break;
+      default: break;
+    }
+  }
+}
+/* per-session results of this party: status, bad_actors, SignatureRecid (zero when status != 0), R */
+void orc_gg20_party_result(const orc_gg20_party* P, int32_t* status, uint32_t* bad, uint32_t* r, uint32_t* s, int32_t* recid, uint32_t* R) {
+  for (int b = 0; b < P->B; ++b) {
+    const gg_sess* x = &P->s[b];
+    if (status) status[b] = x->status;
+    if (bad) bad[b] = x->bad;
+    const int good = x->status == 0;
+    if (r) { if (good) memcpy(r + (size_t)b * 8, x->r, 32); else memset(r + (size_t)b * 8, 0, 32); }
+    if (s) { if (good) memcpy(s + (size_t)b * 8, x->sig_s, 32); else memset(s + (size_t)b * 8, 0, 32); }
+    if (recid) recid[b] = good ? x->recid : 0;
+    if (R) memcpy(R + (size_t)b * 16, x->R, 64);
+  }
+}
+/* test hook (the reference's corrupt_step of gg_2020/test.rs:282-289,458-465,679-686): doubles delta_i (step 5, before it is
+ * broadcast), sigma_i (step 6) or s_i (step 7) of this party in every session; call between the rounds as the test does. */
+void orc_gg20_party_corrupt(orc_gg20_party* P, int step) {
+  mpz_t t; mpz_init(t);
+  for (int b = 0; b < P->B; ++b) {
+    uint32_t* w = step == 5 ? P->s[b].delta_i : (step == 6 ? P->s[b].sigma_i : P->s[b].s_i);
+    zin(t, w, 8); mpz_add(t, t, t); sc_mod(t); zout(w, 8, t);
+  }
+  mpz_clear(t);
+}
+
+/* ---- all parties of sessions [first, first+count) in lock-step: round_based::dev::Simulation (sign.rs:667-763) ----------
+ * Z: [B][S] layout (every party's nonces).  slabs: NULL, or 7 pointers (M0..M6) to [S][B][W] arrays that receive every
+ * message.  party_status / party_bad: NULL or [S][B].  status[b] = the smallest non-zero party status (0 = all parties signed);
+ * r, s, recid, R: party 0's output. */
+void orc_gg20_sign_ex(const orc_gg20_keys* K, const orc_gg20_nonces* Z, const int32_t* keyset, int B, int first, int count,
+                      uint32_t* const* slabs, uint32_t* r_out, uint32_t* s_out, int32_t* recid_out, uint32_t* R_out, int32_t* status,
+                      int32_t* party_status, uint32_t* party_bad) {
+  const int S = K->S, n = K->n;
+  static const int rounds[7] = {0, 1, 2, 3, 4, 5, 7};
+  uint32_t* own[7] = {0};
+  uint32_t* m[7];
+  for (int q = 0; q < 7; ++q) {
+    if (slabs && slabs[q]) m[q] = slabs[q];
+    else m[q] = own[q] = (uint32_t*)calloc((size_t)S * B * orc_gg20_msg_words(S, n, rounds[q]), 4);
+  }
+  orc_gg20_party* P[GG_MAXS];
+  for (int i = 0; i < S; ++i) P[i] = orc_gg20_party_new(K, i, B, Z, S, i, keyset);
+  for (int q = 0; q < 7; ++q) {
+    const int round = rounds[q];
+    const size_t W = (size_t)orc_gg20_msg_words(S, n, round);
+    for (int i = 0; i < S; ++i) {
+      if (round == 7) orc_gg20_party_round(P[i], 6, m[5], NULL, NULL, first, count);
+      orc_gg20_party_round(P[i], round, q ? m[q - 1] : NULL, NULL, m[q] + (size_t)i * B * W, first, count);
+    }
+  }
+  for (int i = 0; i < S; ++i) orc_gg20_party_round(P[i], 8, m[6], NULL, NULL, first, count);
+  for (int b = first; b < first + count; ++b) {
+    int st = 0;
+    for (int i = 0; i < S; ++i) {
+      const gg_sess* x = &P[i]->s[b];
+      if (x->status && (!st || x->status < st)) st = x->status;
+      if (party_status) party_status[(size_t)i * B + b] = x->status;
+      if (party_bad) party_bad[(size_t)i * B + b] = x->bad;
+    }
+    const gg_sess* x = &P[0]->s[b];
+    if (status) status[b] = st;
+    if (st == 0) { memcpy(r_out + (size_t)b * 8, x->r, 32); memcpy(s_out + (size_t)b * 8, x->sig_s, 32); recid_out[b] = x->recid; }
+    else { memset(r_out + (size_t)b * 8, 0, 32); memset(s_out + (size_t)b * 8, 0, 32); recid_out[b] = 0; }
+    if (R_out) memcpy(R_out + (size_t)b * 16, x->R, 64);
+  }
+  for (int i = 0; i < S; ++i) orc_gg20_party_free(P[i]);
+  for (int q = 0; q < 7; ++q) free(own[q]);
+}
 void orc_gg20_sign(const orc_gg20_keys* K, const orc_gg20_nonces* Z, int first, int count, uint32_t* r_out, uint32_t* s_out,
                    int32_t* recid_out, uint32_t* R_out, int32_t* status) {
-  for (int sidx = first; sidx < first + count; ++sidx)
-    status[sidx] = gg20_sign_one(K, Z, sidx, r_out + (size_t)sidx * 8, s_out + (size_t)sidx * 8, recid_out + sidx,
-                                 R_out ? R_out + (size_t)sidx * 16 : NULL);
+  /* the arrays are indexed by absolute session number: B = first + count covers them */
+  orc_gg20_sign_ex(K, Z, NULL, first + count, first, count, NULL, r_out, s_out, recid_out, R_out, status, NULL, NULL);
 }

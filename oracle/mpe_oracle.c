@@ -301,18 +301,76 @@ static void pt_neg(pt_t* r, const pt_t* a) {
   pt_set(r, a);
   if (!r->inf && mpz_sgn(r->y) != 0) mpz_sub(r->y, EC_P, r->y);
 }
-/* r = k*P with k reduced mod q (Scalar::from(&BigInt) reduces; Point * Scalar) */
+/* Jacobian helpers for the scalar multiplication (a = 0 curve): the result is converted back to affine, so the
+ * points every caller sees are the unique affine ones whatever the ladder */
+typedef struct { mpz_t X, Y, Z; int inf; } jac_t;
+static void jac_init(jac_t* j) { mpz_inits(j->X, j->Y, j->Z, NULL); j->inf = 1; }
+static void jac_clear(jac_t* j) { mpz_clears(j->X, j->Y, j->Z, NULL); }
+static void jac_dbl(jac_t* r, const jac_t* a, mpz_t* t) {           /* t: 4 scratch values */
+  if (a->inf || mpz_sgn(a->Y) == 0) { r->inf = 1; return; }
+  mpz_mul(t[0], a->Y, a->Y); mpz_mod(t[0], t[0], EC_P);              /* Y^2 */
+  mpz_mul(t[1], a->X, t[0]); mpz_mul_ui(t[1], t[1], 4); mpz_mod(t[1], t[1], EC_P);   /* S = 4 X Y^2 */
+  mpz_mul(t[2], a->X, a->X); mpz_mul_ui(t[2], t[2], 3); mpz_mod(t[2], t[2], EC_P);   /* M = 3 X^2 */
+  mpz_mul(t[3], a->Y, a->Z); mpz_mul_ui(t[3], t[3], 2); mpz_mod(t[3], t[3], EC_P);   /* Z' = 2 Y Z */
+  mpz_mul(r->X, t[2], t[2]); mpz_submul_ui(r->X, t[1], 2); mpz_mod(r->X, r->X, EC_P);
+  mpz_mul(t[0], t[0], t[0]); mpz_mul_ui(t[0], t[0], 8);             /* 8 Y^4 */
+  mpz_sub(t[1], t[1], r->X); mpz_mul(t[1], t[1], t[2]); mpz_sub(t[1], t[1], t[0]); mpz_mod(r->Y, t[1], EC_P);
+  mpz_set(r->Z, t[3]); r->inf = 0;
+}
+/* r = a + (x, y) affine; r may alias a */
+static void jac_add_aff(jac_t* r, const jac_t* a, const pt_t* b, mpz_t* t) {       /* t: 6 scratch values */
+  if (b->inf) { if (r != a) { mpz_set(r->X, a->X); mpz_set(r->Y, a->Y); mpz_set(r->Z, a->Z); r->inf = a->inf; } return; }
+  if (a->inf) { mpz_set(r->X, b->x); mpz_set(r->Y, b->y); mpz_set_ui(r->Z, 1); r->inf = 0; return; }
+  mpz_mul(t[0], a->Z, a->Z); mpz_mod(t[0], t[0], EC_P);                              /* Z^2 */
+  mpz_mul(t[1], b->x, t[0]); mpz_mod(t[1], t[1], EC_P);                              /* U2 */
+  mpz_mul(t[2], t[0], a->Z); mpz_mul(t[2], t[2], b->y); mpz_mod(t[2], t[2], EC_P);   /* S2 */
+  mpz_sub(t[1], t[1], a->X); mpz_mod(t[1], t[1], EC_P);                              /* H */
+  mpz_sub(t[2], t[2], a->Y); mpz_mod(t[2], t[2], EC_P);                              /* r */
+  if (mpz_sgn(t[1]) == 0) {
+    if (mpz_sgn(t[2]) == 0) { jac_t c; jac_init(&c); mpz_set(c.X, a->X); mpz_set(c.Y, a->Y); mpz_set(c.Z, a->Z); c.inf = 0; jac_dbl(r, &c, t); jac_clear(&c); }
+    else r->inf = 1;
+    return;
+  }
+  mpz_mul(t[3], t[1], t[1]); mpz_mod(t[3], t[3], EC_P);                              /* H^2 */
+  mpz_mul(t[4], t[3], t[1]); mpz_mod(t[4], t[4], EC_P);                              /* H^3 */
+  mpz_mul(t[3], t[3], a->X); mpz_mod(t[3], t[3], EC_P);                              /* X1 H^2 */
+  mpz_mul(t[5], a->Z, t[1]); mpz_mod(t[5], t[5], EC_P);                              /* Z3 */
+  mpz_mul(t[0], t[2], t[2]); mpz_sub(t[0], t[0], t[4]); mpz_submul_ui(t[0], t[3], 2); mpz_mod(t[0], t[0], EC_P);   /* X3 */
+  mpz_sub(t[3], t[3], t[0]); mpz_mul(t[3], t[3], t[2]); mpz_mul(t[4], t[4], a->Y); mpz_sub(t[3], t[3], t[4]); mpz_mod(t[3], t[3], EC_P);
+  mpz_set(r->X, t[0]); mpz_set(r->Y, t[3]); mpz_set(r->Z, t[5]); r->inf = 0;
+}
+/* r = k*P with k reduced mod q (Scalar::from(&BigInt) reduces; Point * Scalar): 4-bit windows over affine multiples */
 static void pt_mul(pt_t* r, const mpz_t k, const pt_t* p) {
   ec_setup();
-  mpz_t kk; mpz_init(kk); mpz_mod(kk, k, EC_Q);
-  pt_t acc, base; pt_init(&acc); pt_init(&base); pt_set(&base, p);
-  const size_t nb = mpz_sizeinbase(kk, 2);
-  for (size_t i = 0; i < nb; ++i) {
-    if (mpz_tstbit(kk, i)) pt_add(&acc, &acc, &base);
-    pt_add(&base, &base, &base);
+  mpz_t kk, t[6]; mpz_init(kk); mpz_mod(kk, k, EC_Q);
+  for (int i = 0; i < 6; ++i) mpz_init(t[i]);
+  if (p->inf || mpz_sgn(kk) == 0) { r->inf = 1; mpz_set_ui(r->x, 0); mpz_set_ui(r->y, 0); goto out; }
+  {
+    pt_t tab[16];
+    for (int i = 0; i < 16; ++i) pt_init(&tab[i]);
+    pt_set(&tab[1], p);
+    for (int i = 2; i < 16; ++i) pt_add(&tab[i], &tab[i - 1], p);
+    jac_t acc, tmp; jac_init(&acc); jac_init(&tmp);
+    const int nb = (int)mpz_sizeinbase(kk, 2);
+    for (int w = (nb + 3) / 4 - 1; w >= 0; --w) {
+      for (int d = 0; d < 4; ++d) { jac_dbl(&tmp, &acc, t); mpz_swap(acc.X, tmp.X); mpz_swap(acc.Y, tmp.Y); mpz_swap(acc.Z, tmp.Z); acc.inf = tmp.inf; }
+      const int dig = (int)(mpz_tstbit(kk, 4 * w) | mpz_tstbit(kk, 4 * w + 1) << 1 | mpz_tstbit(kk, 4 * w + 2) << 2 | mpz_tstbit(kk, 4 * w + 3) << 3);
+      if (dig) jac_add_aff(&acc, &acc, &tab[dig], t);
+    }
+    if (acc.inf) { r->inf = 1; mpz_set_ui(r->x, 0); mpz_set_ui(r->y, 0); }
+    else {
+      mpz_invert(t[0], acc.Z, EC_P);
+      mpz_mul(t[1], t[0], t[0]); mpz_mod(t[1], t[1], EC_P);
+      mpz_mul(t[2], acc.X, t[1]); mpz_mod(t[2], t[2], EC_P);
+      mpz_mul(t[1], t[1], t[0]); mpz_mul(t[1], t[1], acc.Y); mpz_mod(t[1], t[1], EC_P);
+      mpz_set(r->x, t[2]); mpz_set(r->y, t[1]); r->inf = 0;
+    }
+    jac_clear(&acc); jac_clear(&tmp);
+    for (int i = 0; i < 16; ++i) pt_clear(&tab[i]);
   }
-  pt_set(r, &acc);
-  pt_clear(&acc); pt_clear(&base); mpz_clear(kk);
+out:
+  for (int i = 0; i < 6; ++i) mpz_clear(t[i]);
+  mpz_clear(kk);
 }
 static int pt_eq(const pt_t* a, const pt_t* b) {
   if (a->inf || b->inf) return a->inf && b->inf;

@@ -127,14 +127,31 @@ void orc_pdl_verify(int batch, int nkeys, const uint32_t* N, int nst, const uint
 void orc_dlog_prove(int batch, const uint32_t* sk, const uint32_t* nonce, uint32_t* pk, uint32_t* R, uint32_t* z);
 void orc_dlog_verify(int batch, const uint32_t* pk, const uint32_t* R, const uint32_t* z, uint8_t* ok);
 
-/* ---- one complete GG20 signing session, all parties in lock-step (gg20_oracle.c) --------------- */
-/* keys: n parties (x: shares [n][8], p,q: Paillier primes [n][32], Nt,h1,h2: [n][64], y: public key [16],
- * X: pk_vec [n][16]); signers: S ascending party indices.  Nonces: leading dimension = session, then
- * signer i (S), statement st (n), pair pp = i*(S-1)+jj and MessageB variant v (0 = gamma_i, 1 = w_i). */
+/* ---- curv sigma proofs used by GG20 phase 3 / phase 6 and the hash commitment (A.3), nonces as inputs ------ */
+/* PedersenProof::prove(m, r): com = m G + r H (H = base_point2), a1 = s1 G, a2 = s2 H, e = H(G,H,com,a1,a2), z = s + e w */
+void orc_pedersen_prove(int batch, const uint32_t* m, const uint32_t* r, const uint32_t* s1, const uint32_t* s2, uint32_t* com,
+                        uint32_t* e, uint32_t* a1, uint32_t* a2, uint32_t* z1, uint32_t* z2);
+void orc_pedersen_verify(int batch, const uint32_t* com, const uint32_t* a1, const uint32_t* a2, const uint32_t* z1,
+                         const uint32_t* z2, uint8_t* ok);
+/* HomoELGamalProof::prove(w{x,r}, delta{G,H,Y,D,E}): T = s1 H + s2 Y, A3 = s2 G, e = H(T,A3,G,H,Y,D,E) */
+void orc_heg_prove(int batch, const uint32_t* x, const uint32_t* r, const uint32_t* s1, const uint32_t* s2, const uint32_t* G,
+                   const uint32_t* H, const uint32_t* Y, const uint32_t* D, const uint32_t* E, uint32_t* T, uint32_t* A3,
+                   uint32_t* z1, uint32_t* z2);
+void orc_heg_verify(int batch, const uint32_t* G, const uint32_t* H, const uint32_t* Y, const uint32_t* D, const uint32_t* E,
+                    const uint32_t* T, const uint32_t* A3, const uint32_t* z1, const uint32_t* z2, uint8_t* ok);
+/* HashCommitment::create_commitment_with_user_defined_randomness(BigInt::from_bytes(P.to_bytes(true)), blind) -> [B][8] */
+void orc_hash_commit_point(int batch, const uint32_t* P, const uint32_t* blind, uint32_t* com);
+
+/* ---- GG20 signing, one party at a time (gg20_oracle.c): RoundN::proceed as functions of (state, messages) ------- */
+/* keys: tables [nkeysets][n][..] (x: shares [8], p,q: Paillier primes [32], N: Paillier moduli [64] or NULL = p*q,
+ * Nt,h1,h2 [64], X: pk_vec [16]) and y [nkeysets][16]; signers: S ascending party indices (t < S <= n).
+ * A party object reads x, p, q of its own index only.
+ * Nonces: leading dimensions [B][L] (L = parties whose nonces the arrays hold), then statement st (n), peer slot
+ * jj (S-1; peer ordinal ind = jj < i ? jj : jj+1) and MessageB variant v (0 = gamma_i, 1 = w_i); msg [B][8]. */
 typedef struct {
-  int t, n, S;
+  int t, n, S, nkeysets;
   const int32_t* signers;
-  const uint32_t *x, *p, *q, *Nt, *h1, *h2, *y, *X;
+  const uint32_t *x, *p, *q, *N, *Nt, *h1, *h2, *y, *X;
 } orc_gg20_keys;
 
 typedef struct {
@@ -147,6 +164,26 @@ typedef struct {
   const uint32_t* msg;
 } orc_gg20_nonces;
 
+/* words of one (sender, session) record of the message Round `round` emits (0..5; 7 = PartialSignature) */
+int orc_gg20_msg_words(int S, int n, int round);
+typedef struct orc_gg20_party orc_gg20_party;
+orc_gg20_party* orc_gg20_party_new(const orc_gg20_keys* K, int ord, int B, const orc_gg20_nonces* Z, int L, int li,
+                                   const int32_t* keyset);
+void orc_gg20_party_free(orc_gg20_party* P);
+/* round 0..7 = RoundN::proceed / Round7::new, 8 = SignManual::complete, for sessions [first, first+count).
+ * in: previous round's records of all S senders, sender j's [B][W] block at record offset in_off[j] (NULL: j*B);
+ * out: this party's [B][W] block (NULL for rounds 6 and 8). */
+void orc_gg20_party_round(orc_gg20_party* P, int round, const uint32_t* in, const int64_t* in_off, uint32_t* out, int first,
+                          int count);
+void orc_gg20_party_result(const orc_gg20_party* P, int32_t* status, uint32_t* bad_actors, uint32_t* r, uint32_t* s,
+                           int32_t* recid, uint32_t* R);
+void orc_gg20_party_corrupt(orc_gg20_party* P, int step);      /* the reference tests' corrupt_step 5 / 6 / 7 */
+
+/* all parties in lock-step (round_based::dev::Simulation).  slabs: NULL or 7 pointers (M0..M6) to [S][B][W];
+ * party_status / party_bad: NULL or [S][B]; status[b] = smallest non-zero party status. */
+void orc_gg20_sign_ex(const orc_gg20_keys* K, const orc_gg20_nonces* Z, const int32_t* keyset, int B, int first, int count,
+                      uint32_t* const* slabs, uint32_t* r_out, uint32_t* s_out, int32_t* recid_out, uint32_t* R_out,
+                      int32_t* status, int32_t* party_status, uint32_t* party_bad);
 void orc_gg20_sign(const orc_gg20_keys* K, const orc_gg20_nonces* Z, int first, int count, uint32_t* r_out,
                    uint32_t* s_out, int32_t* recid_out, uint32_t* R_out, int32_t* status);
 

@@ -12,8 +12,8 @@ Q = pyref.Q
 
 
 class KeysStruct(C.Structure):
-    _fields_ = [("t", C.c_int), ("n", C.c_int), ("S", C.c_int), ("signers", C.c_void_p)] + \
-               [(f, C.c_void_p) for f in ("x", "p", "q", "Nt", "h1", "h2", "y", "X")]
+    _fields_ = [("t", C.c_int), ("n", C.c_int), ("S", C.c_int), ("nkeysets", C.c_int), ("signers", C.c_void_p)] + \
+               [(f, C.c_void_p) for f in ("x", "p", "q", "N", "Nt", "h1", "h2", "y", "X")]
 
 
 NONCE_FIELDS = ["k", "gamma", "blind", "r_a", "al_alpha", "al_beta", "al_gamma", "al_rho", "mb_beta_tag", "mb_r",
@@ -42,7 +42,7 @@ def make_local_keys(keys, t, n, signers, seed="keygen"):
 
 def keys_struct(lk):
     s = KeysStruct()
-    s.t, s.n, s.S = lk["t"], lk["n"], lk["S"]
+    s.t, s.n, s.S, s.nkeysets = lk["t"], lk["n"], lk["S"], lk.get("nkeysets", 1)
     for f, a in lk["arrays"].items():
         setattr(s, f, a.ctypes.data)
     return s
@@ -99,3 +99,62 @@ def oracle_sign(lk, nonces, B, first=0, count=None):
     ks, ns = keys_struct(lk), nonces_struct(nonces)
     orc.lib.orc_gg20_sign(C.byref(ks), C.byref(ns), first, count, orc._p(r), orc._p(s), orc._p(recid), orc._p(R), orc._p(status))
     return r, s, recid, R, status
+
+
+ROUNDS = [0, 1, 2, 3, 4, 5, 7]                     # rounds that emit a message (M0..M6)
+
+
+def msg_words(S, n, rnd):
+    return {0: 256 * (n + 1), 1: 208 * 2 * (S - 1), 2: 96, 3: 24, 4: 450 * S, 5: 64, 7: 8}[rnd]
+
+
+def oracle_sign_ex(lk, nonces, B, keyset=None):
+    """All parties in lock-step on the oracle, every round message kept.
+    Returns dict(slabs={round: [S][B][W] uint32}, r, s, recid, R, status [B], party_status [S][B], party_bad [S][B])."""
+    import orc
+    S, n = lk["S"], lk["n"]
+    slabs = {rnd: np.zeros((S, B, msg_words(S, n, rnd)), dtype=np.uint32) for rnd in ROUNDS}
+    ptrs = (C.c_void_p * 7)(*[slabs[rnd].ctypes.data for rnd in ROUNDS])
+    r, s = np.zeros((B, 8), dtype=np.uint32), np.zeros((B, 8), dtype=np.uint32)
+    recid, status = np.zeros(B, dtype=np.int32), np.full(B, -1, dtype=np.int32)
+    R = np.zeros((B, 16), dtype=np.uint32)
+    pst, pbad = np.zeros((S, B), dtype=np.int32), np.zeros((S, B), dtype=np.uint32)
+    ks, ns = keys_struct(lk), nonces_struct(nonces)
+    kset = None if keyset is None else np.ascontiguousarray(keyset, dtype=np.int32)
+    orc.lib.orc_gg20_sign_ex(C.byref(ks), C.byref(ns), orc._p(kset), B, 0, B, ptrs, orc._p(r), orc._p(s), orc._p(recid), orc._p(R),
+                             orc._p(status), orc._p(pst), orc._p(pbad))
+    return dict(slabs=slabs, r=r, s=s, recid=recid, R=R, status=status, party_status=pst, party_bad=pbad)
+
+
+def py_parties(lk, nonces, b):
+    """pyref_gg20.Party objects of session b (every party only gets its own secrets)."""
+    import pyref_gg20 as PG
+    S, n, keys = lk["S"], lk["n"], lk["keys"]
+    signers = [int(x) for x in lk["arrays"]["signers"]]
+    xs = F.ints(lk["arrays"]["x"])
+    pub = dict(n=n, signers=signers, N=[k.N for k in keys], Nt=[k.Nt for k in keys], h1=[k.h1 for k in keys], h2=[k.h2 for k in keys],
+               X=F.points(lk["arrays"]["X"]), y=F.points(lk["arrays"]["y"])[0])
+    g = lambda f, ix: F.ints(nonces[f][ix:ix + 1])[0]
+    out = []
+    for i in range(S):
+        me = signers[i]
+        pi = b * S + i
+        z = dict(k=g("k", pi), gamma=g("gamma", pi), blind=g("blind", pi), r_a=g("r_a", pi), l=g("l", pi), ped_s1=g("ped_s1", pi),
+                 ped_s2=g("ped_s2", pi), heg_s1=g("heg_s1", pi), heg_s2=g("heg_s2", pi))
+        z["al"] = [{f: g("al_" + f, pi * n + st) for f in ("alpha", "beta", "gamma", "rho")} for st in range(n)]
+        z["mb"] = [[dict(beta_tag=g("mb_beta_tag", (pi * (S - 1) + jj) * 2 + v), r=g("mb_r", (pi * (S - 1) + jj) * 2 + v),
+                         nonce_b=g("mb_nonce_b", (pi * (S - 1) + jj) * 2 + v), nonce_bt=g("mb_nonce_bt", (pi * (S - 1) + jj) * 2 + v))
+                    for v in range(2)] for jj in range(S - 1)]
+        z["pdl"] = [{f: g("pdl_" + f, pi * (S - 1) + jj) for f in ("alpha", "beta", "rho", "gamma")} for jj in range(S - 1)]
+        out.append(PG.Party(i, dict(pub, x_i=xs[me], p=keys[me].p, q=keys[me].q), z))
+    return out
+
+
+def py_session(lk, nonces, b):
+    """(slab bytes per round: {round: [S] bytes}, per-party (r, s, recid), per-party status) of session b by the Python restatement"""
+    import pyref_gg20 as PG
+    parties = py_parties(lk, nonces, b)
+    msgs, sigs = PG.simulate(parties, F.ints(nonces["msg"][b:b + 1])[0])
+    S, n = lk["S"], lk["n"]
+    packed = {rnd: [PG.pack(rnd, m, S, n) for m in msgs[q]] for q, rnd in enumerate(ROUNDS)}
+    return packed, sigs, [(p.status, p.bad) for p in parties]
