@@ -42,6 +42,12 @@ const char* mpe_last_error(void);
 
 int mpe_ctx_create(mpe_ctx** out, int device);
 int mpe_ctx_destroy(mpe_ctx* ctx);
+/* Zeroes the scratch the context owns (window tables of secret bases, nonce-derived intermediates of composite calls);
+ * the reference zeroizes its round-1 secrets (src/utilities/mta/range_proofs.rs:26-36,197-212).  Also done by destroy. */
+int mpe_ctx_wipe(mpe_ctx* ctx, void* stream);
+/* Audit of the wiping: the number of non-zero 32-bit words in every scratch region the context owns (window tables,
+ * composite workspace, cached GG20 session arena and message slabs) and their total size.  Synchronises the stream. */
+int mpe_ctx_scratch_audit(mpe_ctx* ctx, uint64_t* nonzero_words, uint64_t* total_bytes, void* stream);
 /* Blocks the host until everything queued on `stream` has finished (hipStreamSynchronize). */
 int mpe_sync(mpe_ctx* ctx, void* stream);
 
@@ -142,6 +148,10 @@ int mpe_dlog_verify(mpe_ctx* ctx, int batch, const uint32_t* d_pk, const uint32_
 typedef struct mpe_statements mpe_statements;
 int mpe_statements_create(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const uint32_t* d_h1,
                           const uint32_t* d_h2, mpe_statements** out, void* stream);
+/* the same with an explicit window width (bits, 2..16) of the fixed-base tables of h1, h2: 2 * count tables of
+ * ceil(2848 / wb) * 2^wb rows of 288 bytes (mpe_statements_create uses 13: 0.5 GB per base) */
+int mpe_statements_create_wb(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const uint32_t* d_h1, const uint32_t* d_h2,
+                             int wb, mpe_statements** out, void* stream);
 int mpe_statements_destroy(mpe_statements* s);
 
 /* Field widths (words): z,s 64 | e 8 | s1 25 (< 2^769) | s2,s3 89 (< 2^2817) | u2 128 | points 16.
@@ -215,26 +225,55 @@ int mpe_bob_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* s
                    const uint32_t* d_mta_enc, const mpe_bob_proof* proof, const uint32_t* d_X, const uint32_t* d_u,
                    uint8_t* d_ok, void* stream);
 
-/* ---- GG20 signing, batched (Round0..Round7 of every party of every session in lock-step) ------------ */
-/* Key material as the reference's keygen leaves it in `LocalKey` (state_machine/keygen/rounds.rs:311-322),
- * for all n parties, shared by every session of a batch: d_x [n][8] shares x_i, d_p/d_q [n][32] Paillier
- * primes, d_Nt/d_h1/d_h2 [n][64] `h1_h2_n_tilde_vec`, d_y [16] `y_sum_s`, d_X [n][16] `pk_vec`.
- * h_signers (HOST array): n_signers = t+1 ascending party indices (`s_l` minus one, sign.rs:78). */
-typedef struct mpe_gg20_keys mpe_gg20_keys;
-int mpe_gg20_keys_create(mpe_ctx* ctx, int t, int n, int n_signers, const int32_t* h_signers, const uint32_t* d_x,
-                         const uint32_t* d_p, const uint32_t* d_q, const uint32_t* d_Nt, const uint32_t* d_h1,
-                         const uint32_t* d_h2, const uint32_t* d_y, const uint32_t* d_X, mpe_gg20_keys** out,
-                         void* stream);
-int mpe_gg20_keys_destroy(mpe_gg20_keys* keys);
+/* ---- curv sigma proofs of GG20 phases 3 / 6 and the phase-1 hash commitment (curv-kzen 0.9, un-vendored) ------ */
+/* `PedersenProof::prove(m, r)` with the nonces s1, s2 as inputs (src/protocols/multi_party_ecdsa/gg_2020/party_i.rs:620-634):
+ * com = m G + r H (H = `Point::base_point2()`), a1 = s1 G, a2 = s2 H, e = H(G, H, com, a1, a2), z1 = s1 + e m, z2 = s2 + e r.
+ * Points 16 words, scalars 8.  `PedersenProof::verify` (state_machine/sign/rounds.rs:371-378) recomputes e. */
+typedef struct { uint32_t *com, *e, *a1, *a2, *z1, *z2; } mpe_pedersen_proof;
+int mpe_pedersen_prove(mpe_ctx* ctx, int batch, const uint32_t* d_m, const uint32_t* d_r, const uint32_t* d_s1,
+                       const uint32_t* d_s2, const mpe_pedersen_proof* out, void* stream);
+int mpe_pedersen_verify(mpe_ctx* ctx, int batch, const mpe_pedersen_proof* proof, uint8_t* d_ok, void* stream);
+/* `HomoELGamalProof::prove(witness{x, r}, statement{G, H, Y, D, E})` / `verify` (party_i.rs:778-833): T = s1 H + s2 Y,
+ * A3 = s2 G, e = H(T, A3, G, H, Y, D, E), z1 = s1 + e x (s1 when x = 0), z2 = s2 + e r;
+ * verify: z1 H + z2 Y == T + e D and z2 G == A3 + e E.  Every point per item, [batch][16]. */
+typedef struct { const uint32_t *G, *H, *Y, *D, *E; } mpe_heg_statement;
+typedef struct { uint32_t *T, *A3, *z1, *z2; } mpe_heg_proof;
+int mpe_heg_prove(mpe_ctx* ctx, int batch, const uint32_t* d_x, const uint32_t* d_r, const uint32_t* d_s1, const uint32_t* d_s2,
+                  const mpe_heg_statement* statement, const mpe_heg_proof* out, void* stream);
+int mpe_heg_verify(mpe_ctx* ctx, int batch, const mpe_heg_statement* statement, const mpe_heg_proof* proof, uint8_t* d_ok,
+                   void* stream);
+/* `HashCommitment::create_commitment_with_user_defined_randomness(BigInt::from_bytes(P.to_bytes(true)), blind)`
+ * (party_i.rs:577-580,654-659): com [batch][8] = SHA-256(33 bytes of P || minimal bytes of blind). */
+int mpe_hash_commit_point(mpe_ctx* ctx, int batch, const uint32_t* d_P, const uint32_t* d_blind, uint32_t* d_com, void* stream);
 
-/* Everything the reference samples while signing, as inputs.  S = signers, P = S(S-1) ordered pairs.
- * Leading dimension = session; then signer i; pair pp = i*(S-1)+jj (peer ind = jj<i ? jj : jj+1, the
- * `ind` of rounds.rs:149); statement st; MessageB variant v (0: gamma_i, 1: w_i).
- *   k, gamma, blind, l, ped_s1, ped_s2, heg_s1, heg_s2 : [B][S][8]      r_a : [B][S][64]
- *   al_alpha [B][S][n][24]  al_beta [..][64]  al_gamma [..][88]  al_rho [..][72]     (AliceProof nonces)
- *   mb_beta_tag, mb_r : [B][P][2][64]   mb_nonce_b, mb_nonce_bt : [B][P][2][8]       (MessageB::b)
- *   pdl_alpha [B][P][24]  pdl_beta [..][64]  pdl_rho [..][72]  pdl_gamma [..][88]    (PDLwSlackProof::prove)
- *   msg : [B][8]  the message as BigInt (reduced mod q like `Scalar::from(message)`, party_i.rs:857) */
+/* ---- GG20 signing ------------------------------------------------------------------------------------------------ */
+/* Key material as the reference's keygen leaves it in `LocalKey` (state_machine/keygen/rounds.rs:311-322), for
+ * `nkeysets` wallets of the same (t, n) shape (a batch may mix wallets: every session names its key set).
+ * PUBLIC part, all n parties:  d_N [K][n][64] `paillier_key_vec`, d_Nt/d_h1/d_h2 [K][n][64] `h1_h2_n_tilde_vec`,
+ * d_y [K][16] `y_sum_s`, d_X [K][n][16] `pk_vec`.
+ * SECRET part, only of the n_own parties h_own[] (ascending party indices) this process acts for:
+ * d_x [K][n_own][8] `keys_linear.x_i`, d_p / d_q [K][n_own][32] `paillier_dk`.  One party per process is the
+ * reference's deployment; all of them in one object is its `Simulation` test harness (state_machine/sign.rs:667-763).
+ * h_signers (HOST array): n_signers ascending party indices (`s_l` minus one, sign.rs:78), t < n_signers <= n.
+ * The window width of the fixed-base tables of h1, h2 is chosen from the table memory 2 K n bases need
+ * (13 bits = 0.5 GB per base when that fits a quarter of the free HBM, narrower for many wallets). */
+typedef struct mpe_gg20_keys mpe_gg20_keys;
+int mpe_gg20_keys_create(mpe_ctx* ctx, int t, int n, int n_signers, const int32_t* h_signers, int nkeysets, int n_own,
+                         const int32_t* h_own, const uint32_t* d_x, const uint32_t* d_p, const uint32_t* d_q,
+                         const uint32_t* d_N, const uint32_t* d_Nt, const uint32_t* d_h1, const uint32_t* d_h2,
+                         const uint32_t* d_y, const uint32_t* d_X, mpe_gg20_keys** out, void* stream);
+int mpe_gg20_keys_destroy(mpe_gg20_keys* keys);
+int mpe_gg20_keys_fb_window_bits(const mpe_gg20_keys* keys);
+
+/* Everything the reference samples while signing, as inputs.  L = the local parties of a session object (their
+ * nonces only), S = signers.  Leading dimensions [B][L]; then statement st (n); peer slot jj (S-1; the peer's signer
+ * ordinal is ind = jj < i ? jj : jj+1, the `ind` of rounds.rs:149); MessageB variant v (0: gamma_i, 1: w_i).
+ *   k, gamma, blind, l, ped_s1, ped_s2, heg_s1, heg_s2 : [B][L][8]      r_a : [B][L][64]
+ *   al_alpha [B][L][n][24]  al_beta [..][64]  al_gamma [..][88]  al_rho [..][72]       (AliceProof nonces)
+ *   mb_beta_tag, mb_r : [B][L][S-1][2][64]   mb_nonce_b, mb_nonce_bt : [B][L][S-1][2][8] (MessageB::b)
+ *   pdl_alpha [B][L][S-1][24]  pdl_beta [..][64]  pdl_rho [..][72]  pdl_gamma [..][88]   (PDLwSlackProof::prove)
+ *   msg : [B][8]  the message as BigInt (reduced mod q like `Scalar::from(message)`, party_i.rs:857); read by
+ *         mpe_gg20_sign only (the round view takes the message in round 7). */
 typedef struct {
   const uint32_t *k, *gamma, *blind, *r_a;
   const uint32_t *al_alpha, *al_beta, *al_gamma, *al_rho;
@@ -245,18 +284,70 @@ typedef struct {
   const uint32_t *msg;
 } mpe_gg20_nonces;
 
-/* Runs OfflineStage Round0..Round6 and SignManual (Round7) for `batch` sessions, every party simulated on this
- * GPU (what `round_based::dev::Simulation` does for one session in state_machine/sign.rs:667-763).
- * Outputs per session: d_r, d_s [batch][8] and d_recid [batch] = `SignatureRecid{r,s,recid}` (party_i.rs:131-135,
- * low-s normalised, 873-910), optionally d_R [batch][16], and d_status [batch]: 0 = signature produced and
- * verified, otherwise 100*round + detail of the first failed check (101 range proof rejected -> the reference's
- * Error::Round1/InvalidKey; 201 verify_proofs_get_alpha; 302 Pedersen; 401 phase4; 501 PDL/R_dash; 601 HEG/S_i
- * sum; 701 final verify).  A failing session never aborts the batch.
- * dedup_verify = 0: faithful work (each range proof verified for both MessageB::b calls, every party verifies
- * every PDL proof, exactly as rounds.rs:151-175,546-558); 1: identical checks are evaluated once (same outputs).
- * chunk: sessions per internal pass (0 = 65536, fewer for wide shapes so that a pass stays under ~64 GB of workspace). */
-int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const mpe_gg20_nonces* nonces, uint32_t* d_r,
-                  uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, int dedup_verify, int chunk,
+/* GG20 round messages.  One fixed-size record of 32-bit words per (sender, session); a slab holds, for every sender,
+ * a [B][W] block of records.  P2P messages travel like broadcast ones and are filtered by the receiver, exactly as the
+ * reference's relay does (examples/gg20_sm_client.rs:35-40).  Points: x[8] | y[8]; all other fields little-endian words.
+ *   round 0  (MessageA, SignBroadcastPhase1)       W = 256 (n+1): sub-record st < n = AliceProof for statement st
+ *                                                   {z 0, e 64, s 72, s1 136, s2 161}; sub-record n = {c 0, com 128}
+ *   round 1  (GammaI, WI) to every peer            W = 208 * 2 (S-1): sub-record 2 jj + v = MessageB for peer slot jj
+ *                                                   {c 0, b_proof {pk 128, R 144, z 160}, beta_tag_proof {pk 168, R 184, z 200}}
+ *   round 2  (DeltaI, TI, TIProof)                 W = 96: {delta 0, T 8, proof {e 24, a1 32, a2 48, com 64, z1 80, z2 88}}
+ *   round 3  SignDecommitPhase1                    W = 24: {blind_factor 0, g_gamma_i 8}
+ *   round 4  (RDash, Vec<PDLwSlackProof>)          W = 450 S: sub-record jj < S-1 = the proof for peer slot jj
+ *                                                   {z 0, u1 64, u2 80, u3 208, s1 272, s2 297, s3 361}; sub-record S-1 = {R_dash 0}
+ *   round 5  (SI, HEGProof)                        W = 64: {S_i 0, T 16, A3 32, z1 48, z2 56}
+ *   round 7  PartialSignature                      W = 8:  {s_i}
+ * mpe_gg20_msg_words returns W (0 for rounds that emit nothing). */
+int mpe_gg20_msg_words(int n_signers, int n, int round);
+
+/* The per-party ROUND VIEW: `RoundN::proceed` (state_machine/sign/rounds.rs:68,122,234,347,431,525,612,672) batched over
+ * `batch` sessions and over the n_local parties h_local[] (ascending signer ORDINALS, positions in s_l) this object acts
+ * for; their secrets must be in `keys`.  d_keyset [batch]: key set of every session (NULL when nkeysets == 1).
+ * `nonces`: the local parties' sampled values (layout above); the arrays must stay valid until round 5 is queued.
+ * dedup_verify = 0: faithful work (each range proof verified for both MessageB::b calls, every local party verifies
+ * every PDL proof, rounds.rs:151-175,546-558); 1: identical checks are evaluated once (same results).
+ *
+ * mpe_gg20_roundN(sess, d_in, h_in_off, d_out): d_in = the previous round's records of ALL S senders ("including me"):
+ * sender ordinal j's [batch][W] block starts at record h_in_off[j] of d_in (HOST array; NULL = j*batch); d_out = this
+ * object's outgoing records [n_local][batch][W].  Round 6 emits nothing; round 7 takes the messages to sign
+ * (d_msg [batch][8]) and emits the partial signatures; mpe_gg20_complete = `SignManual::complete` (sign.rs:625-646).
+ * Rounds must be called in order.  A failing check never aborts the batch: the party's status in that session becomes
+ * 100*round + detail of its FIRST failed check, in the order the reference evaluates them, and sticks:
+ *   101 MessageB::b -> InvalidKey (Error::Round1) | 201 verify_proofs_get_alpha | 202 b_proof.pk != g_w_vec[ind] (rounds.rs:281)
+ *   303 T_i != proof.com (rounds.rs:366) | 301 delta not invertible | 302 PedersenProof::verify
+ *   401 phase4 "bad gamma_i decommit" | 501 "Bad PDLwSlack proof" | 502 phase5_check_R_dash_sum
+ *   601 phase6_verify_proof | 602 phase6_check_S_i_sum | 701 output_signature: verify failed
+ * with `bad_actors` (a bit mask over signer ordinals, the reference's `ErrorType::bad_actors`, gg_2020/mod.rs:23-27) set
+ * for 401 (the peers whose decommitment is bad), 501 (the first failing prover) and 601 (every failing prover).
+ * mpe_gg20_session_result: d_status, d_bad_actors, d_recid [n_local][batch]; d_r, d_s [n_local][batch][8] (after
+ * mpe_gg20_complete; zero unless status == 0); d_R [n_local][batch][16] (after round 4).  Any pointer may be NULL.
+ * Destroying a session zeroes its state (k_i, gamma_i, w_i, sigma_i, ...). */
+typedef struct mpe_gg20_session mpe_gg20_session;
+int mpe_gg20_session_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, int n_local, const int32_t* h_local,
+                            const int32_t* d_keyset, const mpe_gg20_nonces* nonces, int dedup_verify, mpe_gg20_session** out,
+                            void* stream);
+int mpe_gg20_session_destroy(mpe_gg20_session* sess, void* stream);
+int mpe_gg20_round0(mpe_gg20_session* sess, uint32_t* d_out, void* stream);
+int mpe_gg20_round1(mpe_gg20_session* sess, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream);
+int mpe_gg20_round2(mpe_gg20_session* sess, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream);
+int mpe_gg20_round3(mpe_gg20_session* sess, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream);
+int mpe_gg20_round4(mpe_gg20_session* sess, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream);
+int mpe_gg20_round5(mpe_gg20_session* sess, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream);
+int mpe_gg20_round6(mpe_gg20_session* sess, const uint32_t* d_in, const int64_t* h_in_off, void* stream);
+int mpe_gg20_round7(mpe_gg20_session* sess, const uint32_t* d_msg, uint32_t* d_out, void* stream);
+int mpe_gg20_complete(mpe_gg20_session* sess, const uint32_t* d_in, const int64_t* h_in_off, void* stream);
+int mpe_gg20_session_result(const mpe_gg20_session* sess, int32_t* d_status, uint32_t* d_bad_actors, uint32_t* d_r,
+                            uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, void* stream);
+
+/* The lock-step composition of the rounds above with every signer local (needs every signer's secrets in `keys`):
+ * OfflineStage Round0..Round6 and SignManual for `batch` sessions on this GPU — what `round_based::dev::Simulation`
+ * does for one session (state_machine/sign.rs:667-763).  nonces: [batch][S] layout.  Outputs per session: d_r, d_s
+ * [batch][8] and d_recid [batch] = `SignatureRecid{r,s,recid}` (party_i.rs:131-135, low-s normalised, 873-910; zero
+ * unless status == 0), optionally d_R [batch][16], and d_status [batch] = the smallest non-zero party status (0 = every
+ * party produced and verified the signature).  chunk: sessions per internal pass (0 = 65536, fewer for wide shapes so
+ * that a pass stays under ~64 GB).  Scratch that held nonce-derived values is zeroed before the call returns. */
+int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int32_t* d_keyset, const mpe_gg20_nonces* nonces,
+                  uint32_t* d_r, uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, int dedup_verify, int chunk,
                   void* stream);
 
 /* ---- Lindell'17 two-party ECDSA, signing ---------------------------------------------- */

@@ -42,6 +42,9 @@ GG20_NONCE_FIELDS = ["k", "gamma", "blind", "r_a", "al_alpha", "al_beta", "al_ga
                      "mb_nonce_b", "mb_nonce_bt", "l", "ped_s1", "ped_s2", "pdl_alpha", "pdl_beta", "pdl_rho", "pdl_gamma",
                      "heg_s1", "heg_s2", "msg"]
 Gg20Nonces = _ptr_struct("Gg20Nonces", GG20_NONCE_FIELDS)
+PedersenProof = _ptr_struct("PedersenProof", ["com", "e", "a1", "a2", "z1", "z2"])
+HegStatement = _ptr_struct("HegStatement", ["G", "H", "Y", "D", "E"])
+HegProof = _ptr_struct("HegProof", ["T", "A3", "z1", "z2"])
 
 
 def _load():
@@ -89,9 +92,31 @@ def _load():
         "mpe_bob_generate": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, u32p, u32p, u32p, C.POINTER(BobNonces), ip,
                                   C.POINTER(BobProof), u32p, vp]),
         "mpe_bob_verify": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, C.POINTER(BobProof), u32p, u32p, vp, vp]),
-        "mpe_gg20_keys_create": (ip, [vp, ip, ip, ip, C.POINTER(C.c_int32)] + [u32p] * 8 + [C.POINTER(vp), vp]),
+        "mpe_gg20_keys_create": (ip, [vp, ip, ip, ip, C.POINTER(C.c_int32), ip, ip, C.POINTER(C.c_int32)] + [u32p] * 9 + [C.POINTER(vp), vp]),
         "mpe_gg20_keys_destroy": (ip, [vp]),
-        "mpe_gg20_sign": (ip, [vp, vp, ip, C.POINTER(Gg20Nonces), u32p, u32p, vp, u32p, vp, ip, ip, vp]),
+        "mpe_gg20_keys_fb_window_bits": (ip, [vp]),
+        "mpe_gg20_msg_words": (ip, [ip, ip, ip]),
+        "mpe_gg20_session_create": (ip, [vp, vp, ip, ip, C.POINTER(C.c_int32), i32p, C.POINTER(Gg20Nonces), ip, C.POINTER(vp), vp]),
+        "mpe_gg20_session_destroy": (ip, [vp, vp]),
+        "mpe_gg20_round0": (ip, [vp, u32p, vp]),
+        "mpe_gg20_round1": (ip, [vp, u32p, C.POINTER(C.c_int64), u32p, vp]),
+        "mpe_gg20_round2": (ip, [vp, u32p, C.POINTER(C.c_int64), u32p, vp]),
+        "mpe_gg20_round3": (ip, [vp, u32p, C.POINTER(C.c_int64), u32p, vp]),
+        "mpe_gg20_round4": (ip, [vp, u32p, C.POINTER(C.c_int64), u32p, vp]),
+        "mpe_gg20_round5": (ip, [vp, u32p, C.POINTER(C.c_int64), u32p, vp]),
+        "mpe_gg20_round6": (ip, [vp, u32p, C.POINTER(C.c_int64), vp]),
+        "mpe_gg20_round7": (ip, [vp, u32p, u32p, vp]),
+        "mpe_gg20_complete": (ip, [vp, u32p, C.POINTER(C.c_int64), vp]),
+        "mpe_gg20_session_result": (ip, [vp, vp, vp, u32p, u32p, vp, u32p, vp]),
+        "mpe_gg20_sign": (ip, [vp, vp, ip, i32p, C.POINTER(Gg20Nonces), u32p, u32p, vp, u32p, vp, ip, ip, vp]),
+        "mpe_pedersen_prove": (ip, [vp, ip, u32p, u32p, u32p, u32p, C.POINTER(PedersenProof), vp]),
+        "mpe_pedersen_verify": (ip, [vp, ip, C.POINTER(PedersenProof), vp, vp]),
+        "mpe_heg_prove": (ip, [vp, ip, u32p, u32p, u32p, u32p, C.POINTER(HegStatement), C.POINTER(HegProof), vp]),
+        "mpe_heg_verify": (ip, [vp, ip, C.POINTER(HegStatement), C.POINTER(HegProof), vp, vp]),
+        "mpe_hash_commit_point": (ip, [vp, ip, u32p, u32p, u32p, vp]),
+        "mpe_ctx_wipe": (ip, [vp, vp]),
+        "mpe_ctx_scratch_audit": (ip, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]),
+        "mpe_statements_create_wb": (ip, [vp, ip, u32p, u32p, u32p, ip, C.POINTER(vp), vp]),
         "mpe_prof_enable": (ip, [vp, ip]),
         "mpe_prof_collect": (ip, [vp, C.POINTER(ProfRec), ip, C.POINTER(C.c_int)]),
         "mpe_paillier_create_public": (ip, [vp, ip, u32p, C.POINTER(vp), vp]),
@@ -123,7 +148,12 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_dlog_prove", "mpe_dlog_verify", "mpe_statements_create", "mpe_statements_destroy",
             "mpe_alice_generate", "mpe_alice_verify", "mpe_pdl_prove", "mpe_pdl_verify", "mpe_gg20_keys_create",
             "mpe_gg20_keys_destroy", "mpe_gg20_sign", "mpe_bob_generate", "mpe_bob_verify", "mpe_mta_message_a",
-            "mpe_mta_message_b", "mpe_mta_verify_get_alpha", "mpe_lindell_partial_sig", "mpe_lindell_sign"]
+            "mpe_mta_message_b", "mpe_mta_verify_get_alpha", "mpe_lindell_partial_sig", "mpe_lindell_sign",
+            "mpe_gg20_keys_fb_window_bits", "mpe_gg20_msg_words", "mpe_gg20_session_create", "mpe_gg20_session_destroy",
+            "mpe_gg20_round0", "mpe_gg20_round1", "mpe_gg20_round2", "mpe_gg20_round3", "mpe_gg20_round4", "mpe_gg20_round5",
+            "mpe_gg20_round6", "mpe_gg20_round7", "mpe_gg20_complete", "mpe_gg20_session_result", "mpe_pedersen_prove",
+            "mpe_pedersen_verify", "mpe_heg_prove", "mpe_heg_verify", "mpe_hash_commit_point", "mpe_ctx_wipe", "mpe_ctx_scratch_audit",
+            "mpe_statements_create_wb"]
 
 
 def check(rc, what):

@@ -1,15 +1,21 @@
-// GG20 signing, all parties of a batch of sessions in lock-step on one GPU — the batched form of
-// Round0..Round7 (src/protocols/multi_party_ecdsa/gg_2020/state_machine/sign/rounds.rs:67-692) over
-// SignKeys / LocalSignature (src/protocols/multi_party_ecdsa/gg_2020/party_i.rs:526-936) and
-// MessageA / MessageB (src/utilities/mta/mod.rs:52-179).  This is what `round_based::dev::Simulation`
-// does for one session in the reference's own test (state_machine/sign.rs:667-763), for B sessions at once:
-// every round is a handful of batched launches over (session, party[, peer[, statement]]) items.
+// GG20 signing as the reference structures it — Round0..Round7 of
+// src/protocols/multi_party_ecdsa/gg_2020/state_machine/sign/rounds.rs:68,122,234,347,431,525,612,672, each a function
+// of (the party's state, the messages of the previous round) -> (next state, outgoing message) — batched over B
+// sessions and over the LOCAL parties of those sessions:
+//   * local = every signer: the whole session runs on this GPU in lock-step (what `round_based::dev::Simulation` does
+//     for one session in the reference's own test, state_machine/sign.rs:667-763); mpe_gg20_sign is this composition;
+//   * local = one signer: the per-party view a real deployment (or the party-sharded multi-GPU mode) uses — the
+//     object only ever sees that party's secrets (x_i, p_i, q_i) and the broadcast messages.
+// Party math: SignKeys / LocalSignature (src/protocols/multi_party_ecdsa/gg_2020/party_i.rs:526-936), MessageA /
+// MessageB (src/utilities/mta/mod.rs:52-179).  Every round is a handful of batched launches over
+// (session, local party[, peer[, statement]]) items; messages are fixed-size records (include/mpecdsa_hip.h), read IN
+// PLACE from the incoming slab through Rows views and packed into the outgoing one.
 // Included by mpe_lib.hip.
 //
 // Index conventions (identical to oracle/gg20_oracle.c):
-//   pi = b*S + i                      party instance (session b, signer ordinal i)
+//   pi = b*L + li                     party instance (session b, local slot li; signer ordinal i = local[li])
 //   ap = pi*n + st                    Alice range proof of pi for statement st
-//   pp = pi*(S-1) + jj                ordered pair (pi -> peer ordinal jj), ind = jj < i ? jj : jj+1 (rounds.rs:149)
+//   pp = pi*(S-1) + jj                ordered pair (pi -> peer slot jj), ind = jj < i ? jj : jj+1 (rounds.rs:149)
 //   mb = pp*2 + v                     MessageB of pi for that peer, v = 0 (gamma_i) / 1 (w_i)
 #pragma once
 #include <cstdio>
@@ -18,77 +24,123 @@
 #include "mpe_proofs.h"
 
 struct mpe_gg20_keys {
-  int t = 0, n = 0, S = 0;
+  int t = 0, n = 0, S = 0, K = 1, n_own = 0;
   int signers[8] = {0};
-  mpe_paillier* pk = nullptr;       // n private Paillier keys (party a = key a)
-  mpe_statements* stm = nullptr;    // n statements (party a = statement a)
+  int own[8] = {0};                 // party indices whose secrets this object holds
+  int own_slot[8] = {0};            // party index -> slot in own, or -1
+  mpe_paillier* pub = nullptr;      // K*n public Paillier keys (key set kk, party a = key kk*n + a)
+  mpe_paillier* prv = nullptr;      // K*n_own private keys (kk*n_own + slot)
+  mpe_statements* stm = nullptr;    // K*n statements
   void* blob = nullptr;
-  uint32_t* x = nullptr;            // [n][8]  key shares
-  uint32_t* X = nullptr;            // [n][16] pk_vec
-  uint32_t* y = nullptr;            // [16]    group public key
-  int32_t* d_signers = nullptr;     // [S]
+  size_t blob_bytes = 0;
+  uint32_t* x = nullptr;            // [K][n_own][8]  key shares of the own parties
+  uint32_t* X = nullptr;            // [K][n][16]     pk_vec
+  uint32_t* y = nullptr;            // [K][16]        group public key
+  uint32_t* gw = nullptr;           // [K][S][16]     g_w_vec = lambda_j X_j (SignKeys::g_w_vec, party_i.rs:527-544)
 };
 
 namespace mpe {
 namespace gg {
 
-struct Dim { int B, S, n, V, PV; };   // V: range-proof verifications per MessageB pair (2 faithful / 1 dedup); PV: PDL verifiers (S / 1)
-__device__ __forceinline__ int ind_of(int i, int jj) { return jj < i ? jj : jj + 1; }
-__device__ __forceinline__ int jme_of(int i, int ind) { return i < ind ? i : i - 1; }
-
-// ---- index tables for the batched launches -------------------------------------------------------
-struct Idx {
-  int32_t *key_pi;                                  // [B*S]
-  int32_t *pi_ap, *key_ap, *st_ap;                  // [B*S*n]
-  int32_t *ap_vi, *pia_vi, *key_vi, *st_vi;         // [B*S*(S-1)*V*n]  verifier-side range-proof checks
-  int32_t *pia_mb, *key_mb;                         // [B*P*2]
-  int32_t *mbin_rv, *key_rv;                        // [B*P*2] receiver-ordered incoming MessageB
-  int32_t *pi_pp, *key_pp, *st_pp;                  // [B*P]
-  int32_t *pp_pv, *pip_pv, *key_pv, *st_pv;         // [B*PV*P] PDL verifications
-};
-__global__ void idx_kernel(Dim d, const int32_t* __restrict__ signers, Idx x, int total) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= total) return;
-  const int S = d.S, n = d.n, P1 = S - 1;
-  if (g < d.B * S) { x.key_pi[g] = signers[g % S]; }
-  if (g < d.B * S * n) { const int pi = g / n; x.pi_ap[g] = pi; x.key_ap[g] = signers[pi % S]; x.st_ap[g] = g % n; }
-  if (g < d.B * S * P1 * d.V * n) {
-    const int st = g % n, r1 = g / n, r2 = r1 / d.V, jj = r2 % P1, pi = r2 / P1, i = pi % S, b = pi / S;
-    const int ind = ind_of(i, jj), pia = b * S + ind;
-    x.ap_vi[g] = pia * n + st; x.pia_vi[g] = pia; x.key_vi[g] = signers[ind]; x.st_vi[g] = st;
-  }
-  if (g < d.B * S * P1 * 2) {
-    const int pp = g >> 1, v = g & 1, jj = pp % P1, pi = pp / P1, i = pi % S, b = pi / S, ind = ind_of(i, jj);
-    x.pia_mb[g] = b * S + ind; x.key_mb[g] = signers[ind];
-    // as receiver pi, peer ordinal jj: the message that peer `ind` built for me
-    x.mbin_rv[g] = (((b * S + ind) * P1) + jme_of(i, ind)) * 2 + v; x.key_rv[g] = signers[i];
-  }
-  if (g < d.B * S * P1) {
-    const int jj = g % P1, pi = g / P1, i = pi % S;
-    x.pi_pp[g] = pi; x.key_pp[g] = signers[i]; x.st_pp[g] = signers[ind_of(i, jj)];
-  }
-  if (g < d.B * d.PV * S * P1) {
-    const int per_sess = S * P1, q = g % per_sess, r1 = g / per_sess, b = r1 / d.PV;   // verifier ordinal = r1 % PV (unused)
-    const int pp = b * per_sess + q, jj = pp % P1, pi = pp / P1, i = pi % S;
-    x.pp_pv[g] = pp; x.pip_pv[g] = pi; x.key_pv[g] = signers[i]; x.st_pv[g] = signers[ind_of(i, jj)];
+constexpr int SUB0 = 256, SUB1 = 208, W2 = 96, W3 = 24, SUB4 = 450, W5 = 64, W6 = 8;
+inline int msg_words(int S, int n, int round) {
+  switch (round) {
+    case 0: return SUB0 * (n + 1);
+    case 1: return SUB1 * 2 * (S - 1);
+    case 2: return W2;
+    case 3: return W3;
+    case 4: return SUB4 * S;
+    case 5: return W5;
+    case 7: return W6;
+    default: return 0;
   }
 }
 
-__global__ void gather_rows_kernel(int n, int words, const uint32_t* __restrict__ src, const int32_t* __restrict__ idx,
-                                   uint32_t* __restrict__ out) {
+// V: range-proof verifications per MessageB pair (2 faithful / 1 dedup); PV: verifiers of the PDL proofs (L / 1)
+struct Dim {
+  int B, S, n, L, V, PV, K, n_own;
+  int loc[8];        // local slot -> signer ordinal
+  int sg[8];         // signer ordinal -> party index
+  int oslot[8];      // party index -> slot among the own parties
+  const int32_t* ks; // [B] key set of a session, or null
+};
+__device__ __forceinline__ int ind_of(int i, int jj) { return jj < i ? jj : jj + 1; }
+__device__ __forceinline__ int jme_of(int i, int ind) { return i < ind ? i : i - 1; }
+__device__ __forceinline__ int ks_of(const Dim& d, int b) { return d.ks ? d.ks[b] : 0; }
+__device__ __forceinline__ int kpub(const Dim& d, int b, int i) { return ks_of(d, b) * d.n + d.sg[i]; }
+__device__ __forceinline__ int kown(const Dim& d, int b, int i) { return ks_of(d, b) * d.n_own + d.oslot[d.sg[i]]; }
+
+// incoming message slab: sender j's [B][W] block starts at record off[j]
+struct Slab { const uint32_t* p; long long off[8]; int W; };
+__device__ __forceinline__ long long rec_index(const Slab& s, int j, int b) { return s.off[j] + b; }
+__device__ __forceinline__ const uint32_t* rec_of(const Slab& s, int j, int b) { return s.p + (size_t)(s.off[j] + b) * (size_t)s.W; }
+
+// ---- index tables that do not depend on the message slabs (built once per session object) ------------------------
+struct Idx {
+  int32_t *kown_pi;                                  // [B*L]
+  int32_t *pi_ap, *kown_ap, *st_ap;                  // [B*L*n]
+  int32_t *ca_vi, *kpub_vi, *st_vi;                  // [B*L*(S-1)*V*n]  verifier-side range-proof checks
+  int32_t *ca_mb, *kpub_mb, *kown_mb;                // [B*L*(S-1)*2]
+  int32_t *pi_pp, *kown_pp, *st_pp;                  // [B*L*(S-1)]
+  int32_t *ca_pv, *pi_pv, *kpub_pv, *st_pv;          // [B*PV*S*(S-1)]   PDL verifications
+};
+__global__ void idx_kernel(Dim d, Idx x, int total) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const int S = d.S, n = d.n, L = d.L, P1 = S - 1;
+  if (g < d.B * L) { const int b = g / L; x.kown_pi[g] = kown(d, b, d.loc[g % L]); }
+  if (g < d.B * L * n) {
+    const int pi = g / n, b = pi / L;
+    x.pi_ap[g] = pi; x.kown_ap[g] = kown(d, b, d.loc[pi % L]); x.st_ap[g] = ks_of(d, b) * n + g % n;
+  }
+  if (g < d.B * L * P1 * d.V * n) {
+    const int st = g % n, r1 = g / n, r2 = r1 / d.V, jj = r2 % P1, pi = r2 / P1, i = d.loc[pi % L], b = pi / L;
+    const int ind = ind_of(i, jj);
+    x.ca_vi[g] = ind * d.B + b; x.kpub_vi[g] = kpub(d, b, ind); x.st_vi[g] = ks_of(d, b) * n + st;
+  }
+  if (g < d.B * L * P1 * 2) {
+    const int pp = g >> 1, jj = pp % P1, pi = pp / P1, i = d.loc[pi % L], b = pi / L, ind = ind_of(i, jj);
+    x.ca_mb[g] = ind * d.B + b; x.kpub_mb[g] = kpub(d, b, ind); x.kown_mb[g] = kown(d, b, i);
+  }
+  if (g < d.B * L * P1) {
+    const int jj = g % P1, pi = g / P1, i = d.loc[pi % L], b = pi / L;
+    x.pi_pp[g] = pi; x.kown_pp[g] = kown(d, b, i); x.st_pp[g] = ks_of(d, b) * n + d.sg[ind_of(i, jj)];
+  }
+  if (g < d.B * d.PV * S * P1) {
+    const int jj = g % P1, r1 = g / P1, i = r1 % S, r2 = r1 / S, vl = r2 % d.PV, b = r2 / d.PV;
+    x.ca_pv[g] = i * d.B + b; x.pi_pv[g] = b * L + vl; x.kpub_pv[g] = kpub(d, b, i);
+    x.st_pv[g] = ks_of(d, b) * n + d.sg[ind_of(i, jj)];
+  }
+}
+
+// dst[(j*B + b)*words + w] = record(j, b)[src_off + w]: keeps a field of every sender's message (m_a_vec, bc_vec, t_vec)
+__global__ void gather_field_kernel(Slab s, int S, int B, int src_off, int words, uint32_t* __restrict__ dst) {
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (size_t)n * words) return;
-  const size_t j = g / words;
-  out[g] = src[(size_t)idx[j] * words + (g - j * words)];
+  if (g >= (size_t)S * B * words) return;
+  const int w = (int)(g % words);
+  const size_t jb = g / words;
+  dst[g] = rec_of(s, (int)(jb / B), (int)(jb % B))[src_off + w];
+}
+// out record of (li, b), sub-record sub0 + (item % per):  [dst_off .. dst_off+words) = src[item]
+__global__ void pack_field_kernel(int nitems, int per, int L, int B, int nsub, int sub0, int subw, int dst_off,
+                                  const uint32_t* __restrict__ src, int words, uint32_t* __restrict__ out) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)nitems * words) return;
+  const int w = (int)(g % words), item = (int)(g / words), pi = item / per, li = pi % L, b = pi / L;
+  out[((size_t)(li * B + b) * nsub + sub0 + item % per) * subw + dst_off + w] = src[g];
+}
+// status / bad_actors of a party instance: the FIRST failed check sticks
+__device__ __forceinline__ void fail(int32_t* status, uint32_t* bad, int pi, int code, uint32_t mask) {
+  if (status[pi] == 0) { status[pi] = code; bad[pi] = mask; }
 }
 
 // ---- helpers -------------------------------------------------------------------------------------
-__device__ inline ec::U256 lagrange0(const int32_t* signers, int S, int i) {
+__device__ inline ec::U256 lagrange0(const int* sg, int S, int i) {
   ec::U256 num = ec::u256_one(), den = ec::u256_one();
   for (int j = 0; j < S; ++j) {
     if (j == i) continue;
-    ec::U256 xj = ec::u256_zero(); xj.w[0] = (uint32_t)(signers[j] + 1);
-    ec::U256 xi = ec::u256_zero(); xi.w[0] = (uint32_t)(signers[i] + 1);
+    ec::U256 xj = ec::u256_zero(); xj.w[0] = (uint32_t)(sg[j] + 1);
+    ec::U256 xi = ec::u256_zero(); xi.w[0] = (uint32_t)(sg[i] + 1);
     num = ec::sc_mul(num, xj);
     den = ec::sc_mul(den, ec::sc_sub(xj, xi));
   }
@@ -112,40 +164,49 @@ __device__ __forceinline__ ec::U256 hash_points(const ec::Aff (&pts)[N]) {
   return ec::sc_reduce(d.w, 8);
 }
 __device__ __forceinline__ ec::Aff mul_aff(const ec::U256& k, const ec::Aff& P) { return ec::jac_to_aff(ec::jac_mul(k, P)); }
-__device__ __forceinline__ ec::Aff add_aff(const ec::Aff& a, const ec::Aff& b) {
-  return ec::jac_to_aff(ec::jac_add(ec::jac_from_aff(a), ec::jac_from_aff(b)));
+
+// g_w_vec of a key set: lambda_j X_j for every signer (once per key object)
+__global__ void __launch_bounds__(64) gw_kernel(Dim d, const uint32_t* __restrict__ Xs, uint32_t* __restrict__ gw) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= d.K * d.S) return;
+  const int kk = g / d.S, j = g % d.S;
+  ec::aff_store(gw + (size_t)g * 16, mul_aff(lagrange0(d.sg, d.S, j), ec::aff_load(Xs + ((size_t)kk * d.n + d.sg[j]) * 16)));
 }
 
 // ---- Round 0: SignKeys::create + phase1_broadcast (party_i.rs:546-589) ----------------------------
-__global__ void __launch_bounds__(64) r0_kernel(Dim d, const int32_t* __restrict__ signers, const uint32_t* __restrict__ xs,
-                          const uint32_t* __restrict__ Xs, const uint32_t* __restrict__ k_in, const uint32_t* __restrict__ gamma_in,
-                          const uint32_t* __restrict__ blind, uint32_t* __restrict__ kq, uint32_t* __restrict__ gq,
-                          uint32_t* __restrict__ w, uint32_t* __restrict__ k64, uint32_t* __restrict__ g_gamma,
-                          uint32_t* __restrict__ g_w, uint32_t* __restrict__ com) {
+__global__ void __launch_bounds__(64) r0_kernel(Dim d, const uint32_t* __restrict__ xs, const uint32_t* __restrict__ k_in,
+                          const uint32_t* __restrict__ gamma_in, const uint32_t* __restrict__ blind, uint32_t* __restrict__ kq,
+                          uint32_t* __restrict__ gq, uint32_t* __restrict__ w, uint32_t* __restrict__ k64, uint32_t* __restrict__ g_gamma,
+                          uint32_t* __restrict__ com) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= d.B * d.S) return;
-  const int i = pi % d.S;
+  if (pi >= d.B * d.L) return;
+  const int i = d.loc[pi % d.L], b = pi / d.L;
   const ec::U256 k = ec::sc_reduce(k_in + (size_t)pi * 8, 8), g = ec::sc_reduce(gamma_in + (size_t)pi * 8, 8);
-  const ec::U256 lam = lagrange0(signers, d.S, i);
-  const ec::U256 wi = ec::sc_mul(lam, ec::sc_reduce(xs + (size_t)signers[i] * 8, 8));
+  const ec::U256 wi = ec::sc_mul(lagrange0(d.sg, d.S, i), ec::sc_reduce(xs + (size_t)kown(d, b, i) * 8, 8));
   ec::u256_store(kq + (size_t)pi * 8, k);
   ec::u256_store(gq + (size_t)pi * 8, g);
   ec::u256_store(w + (size_t)pi * 8, wi);
   for (int j = 0; j < 64; ++j) k64[(size_t)pi * 64 + j] = j < 8 ? k.w[j] : 0u;
   const ec::Aff gg = ec::jac_to_aff(ec::jac_mul_gen(g));
   ec::aff_store(g_gamma + (size_t)pi * 16, gg);
-  // g_w_vec[i] as the PEERS compute it, from pk_vec (SignKeys::g_w_vec, party_i.rs:527-544): lambda_i X_i — not from
-  // the secret share, so that a share inconsistent with the public key is caught by the check of rounds.rs:281
-  ec::aff_store(g_w + (size_t)pi * 16, ec::jac_to_aff(ec::jac_mul(lam, ec::aff_load(Xs + (size_t)signers[i] * 16))));
   ec::u256_store(com + (size_t)pi * 8, commit_point(gg, blind + (size_t)pi * 8));
 }
 
-// ---- Round 1 glue: per MessageB the multiplier b, beta_tag mod q, beta = -beta_tag (mta/mod.rs:132,146) ----
+// ---- Round 1 -------------------------------------------------------------------------------------------------------
+// sub-record index (in the incoming M0 slab) of the range proof every verification item reads
+__global__ void idx1_kernel(Dim d, Slab in0, int32_t* __restrict__ sub0_vi) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int P1 = d.S - 1;
+  if (g >= d.B * d.L * P1 * d.V * d.n) return;
+  const int st = g % d.n, r1 = g / d.n, r2 = r1 / d.V, jj = r2 % P1, pi = r2 / P1, i = d.loc[pi % d.L], b = pi / d.L;
+  sub0_vi[g] = (int32_t)(rec_index(in0, ind_of(i, jj), b) * (d.n + 1) + st);
+}
+// per MessageB the multiplier b, beta_tag mod q, beta = -beta_tag (mta/mod.rs:132,146)
 __global__ void mb_prep_kernel(Dim d, const uint32_t* __restrict__ gq, const uint32_t* __restrict__ w,
                                const uint32_t* __restrict__ beta_tag, uint32_t* __restrict__ bsel,
                                uint32_t* __restrict__ btq, uint32_t* __restrict__ beta) {
   const int mb = blockIdx.x * blockDim.x + threadIdx.x;
-  if (mb >= d.B * d.S * (d.S - 1) * 2) return;
+  if (mb >= d.B * d.L * (d.S - 1) * 2) return;
   const int pi = (mb >> 1) / (d.S - 1);
   const uint32_t* src = (mb & 1) ? w + (size_t)pi * 8 : gq + (size_t)pi * 8;
   for (int j = 0; j < 8; ++j) bsel[(size_t)mb * 8 + j] = src[j];
@@ -153,51 +214,79 @@ __global__ void mb_prep_kernel(Dim d, const uint32_t* __restrict__ gq, const uin
   ec::u256_store(btq + (size_t)mb * 8, t);
   ec::u256_store(beta + (size_t)mb * 8, ec::sc_neg(t));
 }
+// MessageB::b -> Err(InvalidKey) when a range proof of the peer fails (rounds.rs:151-175 -> Error::Round1)
+__global__ void status1_kernel(Dim d, const uint8_t* __restrict__ ok_vi, int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= d.B * d.L) return;
+  const int per = (d.S - 1) * d.V * d.n;
+  bool good = true;
+  for (int q = 0; q < per; ++q) good = good && ok_vi[(size_t)pi * per + q];
+  if (!good) fail(status, bad, pi, 101, 0);
+}
 
-// ---- Round 2a: MessageB::verify_proofs_get_alpha after the decryption (mta/mod.rs:166-178, rounds.rs:281) ----
-struct MsgB { const uint32_t *pk, *R, *z, *tpk, *tR, *tz; };   // [mb] b_proof / beta_tag_proof
-__global__ void __launch_bounds__(64) r2a_kernel(Dim d, const int32_t* __restrict__ mbin_rv, const uint32_t* __restrict__ alpha_full,
-                           const uint32_t* __restrict__ kq, MsgB m, const uint32_t* __restrict__ g_w,
-                           uint32_t* __restrict__ alpha, uint8_t* __restrict__ ok) {
+// ---- Round 2 -------------------------------------------------------------------------------------------------------
+// receiver view: sub-record (in the incoming M1 slab) of the MessageB that peer `ind` built for me
+__global__ void idx2_kernel(Dim d, Slab in1, int32_t* __restrict__ sub1_rv) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int P1 = d.S - 1;
+  if (g >= d.B * d.L * P1 * 2) return;
+  const int v = g & 1, pp = g >> 1, jj = pp % P1, pi = pp / P1, i = d.loc[pi % d.L], b = pi / d.L, ind = ind_of(i, jj);
+  sub1_rv[g] = (int32_t)(rec_index(in1, ind, b) * (2 * P1) + jme_of(i, ind) * 2 + v);
+}
+// MessageB::verify_proofs_get_alpha after the decryption (mta/mod.rs:166-178) and the check of rounds.rs:281
+// code[rv]: 0 ok, 1 -> 201, 2 -> 202
+__device__ __forceinline__ void r2a_finish(const Dim& d, int rv, int v, int pp, int b, int ind, const ec::Aff& Bpk, bool good,
+                                           const uint32_t* gw, uint32_t* bpk_in, uint8_t* code) {
+  uint8_t c = good ? 0 : 1;
+  if (v == 1) { if (!c && !ec::aff_eq(Bpk, ec::aff_load(gw + ((size_t)ks_of(d, b) * d.S + ind) * 16))) c = 2; }   // rounds.rs:281
+  else ec::aff_store(bpk_in + (size_t)pp * 16, Bpk);                                          // mb_gamma_s[jj].b_proof.pk, for phase4
+  code[rv] = c;
+}
+__global__ void __launch_bounds__(64) r2a_kernel(Dim d, const int32_t* __restrict__ sub1_rv, const uint32_t* __restrict__ in1,
+                           const uint32_t* __restrict__ alpha_full, const uint32_t* __restrict__ kq, const uint32_t* __restrict__ gw,
+                           uint32_t* __restrict__ alpha, uint32_t* __restrict__ bpk_in, uint8_t* __restrict__ code) {
   const int rv = blockIdx.x * blockDim.x + threadIdx.x;
   const int P1 = d.S - 1;
-  if (rv >= d.B * d.S * P1 * 2) return;
-  const int v = rv & 1, pp = rv >> 1, jj = pp % P1, pi = pp / P1, i = pi % d.S, b = pi / d.S, ind = ind_of(i, jj);
-  const int in = mbin_rv[rv];
+  if (rv >= d.B * d.L * P1 * 2) return;
+  const int v = rv & 1, pp = rv >> 1, jj = pp % P1, pi = pp / P1, i = d.loc[pi % d.L], b = pi / d.L, ind = ind_of(i, jj);
+  const uint32_t* m = in1 + (size_t)sub1_rv[rv] * SUB1;
   const ec::U256 al = ec::sc_reduce(alpha_full + (size_t)rv * 64, 64);
   ec::u256_store(alpha + (size_t)rv * 8, al);
-  const ec::Aff Bpk = ec::aff_load(m.pk + (size_t)in * 16), BTpk = ec::aff_load(m.tpk + (size_t)in * 16);
+  const ec::Aff Bpk = ec::aff_load(m + 128), BTpk = ec::aff_load(m + 168);
   const ec::Jac g_alpha = ec::jac_mul_gen(al);
   const ec::Jac ba_btag = ec::jac_add_aff(ec::jac_mul(ec::u256_load(kq + (size_t)pi * 8), Bpk), BTpk);
   bool good = ec::jac_eq(g_alpha, ba_btag);
   {  // DLogProof::verify x2
-    const ec::Aff R1 = ec::aff_load(m.R + (size_t)in * 16), R2 = ec::aff_load(m.tR + (size_t)in * 16);
+    const ec::Aff R1 = ec::aff_load(m + 144), R2 = ec::aff_load(m + 184);
     const ec::U256 c1 = dlog_challenge(R1, Bpk), c2 = dlog_challenge(R2, BTpk);
-    const ec::Jac l1 = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(m.z + (size_t)in * 8, 8)), ec::jac_mul(c1, Bpk));
-    const ec::Jac l2 = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(m.tz + (size_t)in * 8, 8)), ec::jac_mul(c2, BTpk));
+    const ec::Jac l1 = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(m + 160, 8)), ec::jac_mul(c1, Bpk));
+    const ec::Jac l2 = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(m + 200, 8)), ec::jac_mul(c2, BTpk));
     good = good && ec::jac_eq_aff(l1, R1) && ec::jac_eq_aff(l2, R2);
   }
-  if (v == 1) good = good && ec::aff_eq(Bpk, ec::aff_load(g_w + (size_t)(b * d.S + ind) * 16));   // rounds.rs:281
-  ok[rv] = good ? 1 : 0;
+  r2a_finish(d, rv, v, pp, b, ind, Bpk, good, gw, bpk_in, code);
 }
 
-// ---- Round 2b: delta_i, sigma_i, T_i + PedersenProof::prove (party_i.rs:591-634) -------------------
-struct Ped { uint32_t *T, *a1, *a2, *z1, *z2; };       // [pi]
+// delta_i, sigma_i, T_i + PedersenProof::prove (party_i.rs:591-634); the party's status of this round
+struct Ped { uint32_t *T, *e, *a1, *a2, *z1, *z2; };       // [pi]
 __global__ void __launch_bounds__(64) r2b_kernel(Dim d, const uint32_t* __restrict__ kq, const uint32_t* __restrict__ gq,
                            const uint32_t* __restrict__ w, const uint32_t* __restrict__ alpha,
-                           const uint32_t* __restrict__ beta, const uint32_t* __restrict__ l_in,
+                           const uint32_t* __restrict__ beta, const uint8_t* __restrict__ code, const uint32_t* __restrict__ l_in,
                            const uint32_t* __restrict__ s1_in, const uint32_t* __restrict__ s2_in,
-                           uint32_t* __restrict__ delta_i, uint32_t* __restrict__ sigma_i, uint32_t* __restrict__ lq, Ped p) {
+                           uint32_t* __restrict__ delta_i, uint32_t* __restrict__ sigma_i, uint32_t* __restrict__ lq, Ped p,
+                           int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= d.B * d.S) return;
+  if (pi >= d.B * d.L) return;
   const int P1 = d.S - 1;
   const ec::U256 k = ec::u256_load(kq + (size_t)pi * 8);
   ec::U256 de = ec::sc_mul(k, ec::u256_load(gq + (size_t)pi * 8)), si = ec::sc_mul(k, ec::u256_load(w + (size_t)pi * 8));
+  int st = 0;
   for (int jj = 0; jj < P1; ++jj) {
     const size_t m0 = ((size_t)pi * P1 + jj) * 2;
     de = ec::sc_add(de, ec::sc_add(ec::u256_load(alpha + m0 * 8), ec::u256_load(beta + m0 * 8)));
     si = ec::sc_add(si, ec::sc_add(ec::u256_load(alpha + (m0 + 1) * 8), ec::u256_load(beta + (m0 + 1) * 8)));
+    for (int v = 0; v < 2 && !st; ++v) if (code[m0 + v]) st = 200 + code[m0 + v];          // the loop order of rounds.rs:260-286
   }
+  if (st) fail(status, bad, pi, st, 0);
   ec::u256_store(delta_i + (size_t)pi * 8, de);
   ec::u256_store(sigma_i + (size_t)pi * 8, si);
   const ec::U256 l = ec::sc_reduce(l_in + (size_t)pi * 8, 8);
@@ -209,77 +298,104 @@ __global__ void __launch_bounds__(64) r2b_kernel(Dim d, const uint32_t* __restri
   const ec::Aff hp[5] = {G, H, T, a1, a2};
   const ec::U256 e = hash_points(hp);
   ec::aff_store(p.T + (size_t)pi * 16, T);
+  ec::u256_store(p.e + (size_t)pi * 8, e);
   ec::aff_store(p.a1 + (size_t)pi * 16, a1);
   ec::aff_store(p.a2 + (size_t)pi * 16, a2);
   ec::u256_store(p.z1 + (size_t)pi * 8, ec::sc_add(s1, ec::sc_mul(e, si)));
   ec::u256_store(p.z2 + (size_t)pi * 8, ec::sc_add(s2, ec::sc_mul(e, l)));
 }
 
-// ---- Round 3: every party verifies every PedersenProof, reconstructs delta^-1 (rounds.rs:347-402) ---
-__global__ void __launch_bounds__(64) r3_kernel(Dim d, const uint32_t* __restrict__ delta_i, Ped p, uint32_t* __restrict__ dinv, uint8_t* __restrict__ ok) {
+// ---- Round 3: T_i == proof.com, delta^-1, every PedersenProof (rounds.rs:347-402) -----------------------------------
+// M2 record: delta 0 | T 8 | e 24 | a1 32 | a2 48 | com 64 | z1 80 | z2 88
+__device__ __forceinline__ bool words_eq(const uint32_t* a, const uint32_t* b, int n) {
+  uint32_t o = 0;
+  for (int i = 0; i < n; ++i) o |= a[i] ^ b[i];
+  return o == 0;
+}
+__device__ __forceinline__ void r3_finish(int pi, bool com_ok, bool ped_ok, const ec::U256& sum, uint32_t* dinv, int32_t* status,
+                                          uint32_t* bad) {
+  if (!com_ok) fail(status, bad, pi, 303, 0);
+  const bool inv_ok = !ec::u256_is_zero(sum);
+  if (!inv_ok) fail(status, bad, pi, 301, 0);
+  ec::u256_store(dinv + (size_t)pi * 8, inv_ok ? ec::sc_inv(sum) : ec::u256_zero());
+  if (!ped_ok) fail(status, bad, pi, 302, 0);
+}
+__global__ void __launch_bounds__(64) r3_kernel(Dim d, Slab in2, uint32_t* __restrict__ dinv, int32_t* __restrict__ status,
+                                                uint32_t* __restrict__ bad) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= d.B * d.S) return;
-  const int b = pi / d.S;
+  if (pi >= d.B * d.L) return;
+  const int b = pi / d.L;
   const ec::Aff G = ec::aff_gen(), H = ec::aff_h2();
   ec::U256 sum = ec::u256_zero();
-  bool good = true;
+  bool com_ok = true, ped_ok = true;
   for (int j = 0; j < d.S; ++j) {
-    const size_t o = (size_t)b * d.S + j;
-    sum = ec::sc_add(sum, ec::u256_load(delta_i + o * 8));
-    const ec::Aff T = ec::aff_load(p.T + o * 16), a1 = ec::aff_load(p.a1 + o * 16), a2 = ec::aff_load(p.a2 + o * 16);
-    const ec::Aff hp[5] = {G, H, T, a1, a2};
+    const uint32_t* m = rec_of(in2, j, b);
+    sum = ec::sc_add(sum, ec::sc_reduce(m, 8));
+    com_ok = com_ok && words_eq(m + 8, m + 64, 16);
+    const ec::Aff C = ec::aff_load(m + 64), a1 = ec::aff_load(m + 32), a2 = ec::aff_load(m + 48);
+    const ec::Aff hp[5] = {G, H, C, a1, a2};
     const ec::U256 e = hash_points(hp);
-    const ec::Jac lhs = ec::jac_add(ec::jac_mul_gen(ec::u256_load(p.z1 + o * 8)), ec::jac_mul_h2(ec::u256_load(p.z2 + o * 8)));
-    const ec::Jac rhs = ec::jac_add_aff(ec::jac_add_aff(ec::jac_mul(e, T), a1), a2);
-    good = good && ec::jac_eq(lhs, rhs);
+    const ec::Jac lhs = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(m + 80, 8)), ec::jac_mul_h2(ec::sc_reduce(m + 88, 8)));
+    const ec::Jac rhs = ec::jac_add_aff(ec::jac_add_aff(ec::jac_mul(e, C), a1), a2);
+    ped_ok = ped_ok && ec::jac_eq(lhs, rhs);
   }
-  good = good && !ec::u256_is_zero(sum);
-  ec::u256_store(dinv + (size_t)pi * 8, ec::sc_inv(sum));
-  ok[pi] = good ? 1 : 0;
+  r3_finish(pi, com_ok, ped_ok, sum, dinv, status, bad);
 }
 
 // ---- Round 4: phase4 -> R, R_dash (party_i.rs:642-687, rounds.rs:452) --------------------------------
-__global__ void __launch_bounds__(64) r4_kernel(Dim d, const uint32_t* __restrict__ dinv, const uint32_t* __restrict__ g_gamma,
-                          const uint32_t* __restrict__ com, const uint32_t* __restrict__ blind, const uint32_t* __restrict__ Bpk,
-                          const uint32_t* __restrict__ kq, uint32_t* __restrict__ R, uint32_t* __restrict__ Rbar,
-                          uint8_t* __restrict__ ok) {
+// M3 record: blind 0 | g_gamma 8
+__global__ void __launch_bounds__(64) r4_kernel(Dim d, Slab in3, const uint32_t* __restrict__ dinv, const uint32_t* __restrict__ com_all,
+                          const uint32_t* __restrict__ bpk_in, const uint32_t* __restrict__ kq, uint32_t* __restrict__ R,
+                          uint32_t* __restrict__ Rbar, int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= d.B * d.S) return;
-  const int P1 = d.S - 1, i = pi % d.S, b = pi / d.S;
-  bool good = true;
+  if (pi >= d.B * d.L) return;
+  const int P1 = d.S - 1, i = d.loc[pi % d.L], b = pi / d.L;
+  uint32_t mask = 0;
   for (int jj = 0; jj < P1; ++jj) {
     const int ind = ind_of(i, jj);
-    const size_t o = (size_t)b * d.S + ind;
-    const ec::Aff gg = ec::aff_load(g_gamma + o * 16);
-    const size_t in = ((o * P1) + jme_of(i, ind)) * 2;          // the gamma MessageB that `ind` sent me
-    good = good && ec::aff_eq(ec::aff_load(Bpk + in * 16), gg);
-    good = good && ec::u256_eq(commit_point(gg, blind + o * 8), ec::u256_load(com + o * 8));
+    const uint32_t* m = rec_of(in3, ind, b);
+    const ec::Aff gg = ec::aff_load(m + 8);
+    bool good = ec::aff_eq(ec::aff_load(bpk_in + ((size_t)pi * P1 + jj) * 16), gg);
+    good = good && ec::u256_eq(commit_point(gg, m), ec::u256_load(com_all + ((size_t)ind * d.B + b) * 8));
+    if (!good) mask |= 1u << ind;
   }
+  if (mask) fail(status, bad, pi, 401, mask);
   ec::Jac acc = ec::jac_inf();
-  for (int j = 0; j < d.S; ++j) acc = ec::jac_add(acc, ec::jac_from_aff(ec::aff_load(g_gamma + ((size_t)b * d.S + j) * 16)));
+  for (int j = 0; j < d.S; ++j) acc = ec::jac_add(acc, ec::jac_from_aff(ec::aff_load(rec_of(in3, j, b) + 8)));
   const ec::Aff Rp = mul_aff(ec::u256_load(dinv + (size_t)pi * 8), ec::jac_to_aff(acc));
   ec::aff_store(R + (size_t)pi * 16, Rp);
   ec::aff_store(Rbar + (size_t)pi * 16, mul_aff(ec::u256_load(kq + (size_t)pi * 8), Rp));
-  ok[pi] = good ? 1 : 0;
 }
 
-// ---- Round 5: R_dash sum, S_i and HomoELGamalProof::prove (party_i.rs:768-799) ------------------------
+// ---- Round 5 -------------------------------------------------------------------------------------------------------
+// M4 record: S sub-records of 450: proof for peer slot jj (z 0 | u1 64 | u2 80 | u3 208 | s1 272 | s2 297 | s3 361); the last: R_dash
+__global__ void idx5_kernel(Dim d, Slab in4, int32_t* __restrict__ sub4_pv, int32_t* __restrict__ rdash_pv) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int P1 = d.S - 1;
+  if (g >= d.B * d.PV * d.S * P1) return;
+  const int jj = g % P1, r1 = g / P1, i = r1 % d.S, b = r1 / d.S / d.PV;
+  const long long r = rec_index(in4, i, b) * d.S;
+  sub4_pv[g] = (int32_t)(r + jj); rdash_pv[g] = (int32_t)(r + P1);
+}
+// my PDL verifications (rounds.rs:546-558), the R_dash sum, S_i and HomoELGamalProof::prove (party_i.rs:768-799)
 struct Heg { uint32_t *S, *T, *A3, *z1, *z2; };      // [pi]
-__global__ void __launch_bounds__(64) r5_kernel(Dim d, const uint8_t* __restrict__ pdl_ok, const uint32_t* __restrict__ R,
-                          const uint32_t* __restrict__ Rbar, const uint32_t* __restrict__ sigma_i, const uint32_t* __restrict__ lq,
-                          const uint32_t* __restrict__ pedT, const uint32_t* __restrict__ s1_in, const uint32_t* __restrict__ s2_in,
-                          Heg h, uint8_t* __restrict__ ok) {
+__global__ void __launch_bounds__(64) r5_kernel(Dim d, Slab in4, const uint8_t* __restrict__ pdl_ok, const uint32_t* __restrict__ R,
+                          const uint32_t* __restrict__ sigma_i, const uint32_t* __restrict__ lq, const uint32_t* __restrict__ pedT,
+                          const uint32_t* __restrict__ s1_in, const uint32_t* __restrict__ s2_in, Heg h, int32_t* __restrict__ status,
+                          uint32_t* __restrict__ bad) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= d.B * d.S) return;
-  const int P1 = d.S - 1, i = pi % d.S, b = pi / d.S, per = d.S * P1;
-  bool good = true;
-  // my PDL verifications: all S(S-1) proofs of the session (rounds.rs:546-558)
-  const int vo = d.PV == 1 ? 0 : i;
-  for (int q = 0; q < per; ++q) good = good && pdl_ok[((size_t)b * d.PV + vo) * per + q];
+  if (pi >= d.B * d.L) return;
+  const int P1 = d.S - 1, li = pi % d.L, b = pi / d.L;
+  const int vo = d.PV == 1 ? 0 : li;
+  uint32_t mask = 0;
+  for (int i = 0; i < d.S && !mask; ++i)                                                  // `?` stops at the first failing prover
+    for (int jj = 0; jj < P1; ++jj)
+      if (!pdl_ok[(((size_t)b * d.PV + vo) * d.S + i) * P1 + jj]) mask = 1u << i;
+  if (mask) fail(status, bad, pi, 501, mask);
   const ec::Aff G = ec::aff_gen(), H = ec::aff_h2();
   ec::Jac acc = ec::jac_inf();
-  for (int j = 0; j < d.S; ++j) acc = ec::jac_add(acc, ec::jac_from_aff(ec::aff_load(Rbar + ((size_t)b * d.S + j) * 16)));
-  good = good && ec::jac_eq_aff(acc, G);                                                 // phase5_check_R_dash_sum
+  for (int j = 0; j < d.S; ++j) acc = ec::jac_add(acc, ec::jac_from_aff(ec::aff_load(rec_of(in4, j, b) + (size_t)P1 * SUB4)));
+  if (!ec::jac_eq_aff(acc, G)) fail(status, bad, pi, 502, 0);                              // phase5_check_R_dash_sum
   const ec::Aff Rp = ec::aff_load(R + (size_t)pi * 16), T = ec::aff_load(pedT + (size_t)pi * 16);
   const ec::U256 si = ec::u256_load(sigma_i + (size_t)pi * 8), l = ec::u256_load(lq + (size_t)pi * 8);
   const ec::Aff Sp = mul_aff(si, Rp);
@@ -292,33 +408,33 @@ __global__ void __launch_bounds__(64) r5_kernel(Dim d, const uint8_t* __restrict
   ec::aff_store(h.A3 + (size_t)pi * 16, A3);
   ec::u256_store(h.z1 + (size_t)pi * 8, ec::u256_is_zero(l) ? s1 : ec::sc_add(s1, ec::sc_mul(l, e)));
   ec::u256_store(h.z2 + (size_t)pi * 8, ec::sc_add(s2, ec::sc_mul(si, e)));
-  ok[pi] = good ? 1 : 0;
 }
 
-// ---- Round 6: every party verifies every HomoELGamalProof; sum S_i == y (party_i.rs:801-848) --------------
-__global__ void __launch_bounds__(64) r6_kernel(Dim d, const uint32_t* __restrict__ R, const uint32_t* __restrict__ pedT, Heg h,
-                          const uint32_t* __restrict__ y, uint8_t* __restrict__ ok) {
+// ---- Round 6: every HomoELGamalProof; sum S_i == y (party_i.rs:801-848) --------------------------------------------
+// M5 record: S_i 0 | T 16 | A3 32 | z1 48 | z2 56
+__global__ void __launch_bounds__(64) r6_kernel(Dim d, Slab in5, const uint32_t* __restrict__ R, const uint32_t* __restrict__ tvec,
+                          const uint32_t* __restrict__ y, int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= d.B * d.S) return;
-  const int b = pi / d.S;
+  if (pi >= d.B * d.L) return;
+  const int b = pi / d.L;
   const ec::Aff G = ec::aff_gen(), H = ec::aff_h2(), Rp = ec::aff_load(R + (size_t)pi * 16);
-  bool good = true;
+  uint32_t mask = 0;
   ec::Jac acc = ec::jac_inf();
   for (int j = 0; j < d.S; ++j) {
-    const size_t o = (size_t)b * d.S + j;
-    const ec::Aff TT = ec::aff_load(h.T + o * 16), A3 = ec::aff_load(h.A3 + o * 16), D = ec::aff_load(pedT + o * 16),
-                  E = ec::aff_load(h.S + o * 16);
+    const uint32_t* m = rec_of(in5, j, b);
+    const ec::Aff E = ec::aff_load(m), TT = ec::aff_load(m + 16), A3 = ec::aff_load(m + 32),
+                  D = ec::aff_load(tvec + ((size_t)j * d.B + b) * 16);
     const ec::Aff hp[7] = {TT, A3, Rp, H, G, D, E};
-    const ec::U256 e = hash_points(hp), z1 = ec::u256_load(h.z1 + o * 8), z2 = ec::u256_load(h.z2 + o * 8);
+    const ec::U256 e = hash_points(hp), z1 = ec::sc_reduce(m + 48, 8), z2 = ec::sc_reduce(m + 56, 8);
     const ec::Jac l1 = ec::jac_add(ec::jac_mul_h2(z1), ec::jac_mul_gen(z2));
     const ec::Jac r1 = ec::jac_add_aff(ec::jac_mul(e, D), TT);
     const ec::Jac l2 = ec::jac_mul(z2, Rp);
     const ec::Jac r2 = ec::jac_add_aff(ec::jac_mul(e, E), A3);
-    good = good && ec::jac_eq(l1, r1) && ec::jac_eq(l2, r2);
+    if (!(ec::jac_eq(l1, r1) && ec::jac_eq(l2, r2))) mask |= 1u << j;
     acc = ec::jac_add_aff(acc, E);
   }
-  good = good && ec::jac_eq_aff(acc, ec::aff_load(y));
-  ok[pi] = good ? 1 : 0;
+  if (mask) fail(status, bad, pi, 601, mask);
+  if (!ec::jac_eq_aff(acc, ec::aff_load(y + (size_t)ks_of(d, b) * 16))) fail(status, bad, pi, 602, 0);
 }
 
 // ---- small batches: the same checks with a group of adjacent lanes per item ---------------------------
@@ -327,28 +443,28 @@ __global__ void __launch_bounds__(64) r6_kernel(Dim d, const uint32_t* __restric
 // multiplications run one per lane (all lanes of a phase execute the same routine on different data), the Jacobian
 // results meet in LDS and lane 0 of the group does the additions, comparisons and stores.  With many sessions the
 // idle lanes of the groups cost more than the latency they hide (measured at 65 536 sessions: r2a 42 -> 57 ms,
-// r3 22 -> 52 ms), so sign_chunk picks them only when the grouped launch still fits the chip.
+// r3 22 -> 52 ms), so the rounds pick them only when the grouped launch still fits the chip.
 struct JacSlots { ec::Jac v[64]; };
 
-__global__ void __launch_bounds__(64) r2a_group_kernel(Dim d, const int32_t* __restrict__ mbin_rv, const uint32_t* __restrict__ alpha_full,
-                           const uint32_t* __restrict__ kq, MsgB m, const uint32_t* __restrict__ g_w,
-                           uint32_t* __restrict__ alpha, uint8_t* __restrict__ ok) {
+__global__ void __launch_bounds__(64) r2a_group_kernel(Dim d, const int32_t* __restrict__ sub1_rv, const uint32_t* __restrict__ in1,
+                           const uint32_t* __restrict__ alpha_full, const uint32_t* __restrict__ kq, const uint32_t* __restrict__ gw,
+                           uint32_t* __restrict__ alpha, uint32_t* __restrict__ bpk_in, uint8_t* __restrict__ code) {
   // 4 lanes per incoming MessageB: lanes 0..2 do  k_i B | c1 B | c2 B'  (variable base), then  alpha G | z G | z' G
   __shared__ JacSlots vs, fs;
   const int gid = blockIdx.x * 64 + threadIdx.x, rv = gid >> 2, sub = gid & 3, base = (int)threadIdx.x - sub;
   const int P1 = d.S - 1;
-  const bool live = rv < d.B * d.S * P1 * 2;
+  const bool live = rv < d.B * d.L * P1 * 2;
   const int rvc = live ? rv : 0;
-  const int v = rvc & 1, pp = rvc >> 1, jj = pp % P1, pi = pp / P1, i = pi % d.S, b = pi / d.S, ind = ind_of(i, jj);
-  const int in = mbin_rv[rvc];
+  const int v = rvc & 1, pp = rvc >> 1, jj = pp % P1, pi = pp / P1, i = d.loc[pi % d.L], b = pi / d.L, ind = ind_of(i, jj);
+  const uint32_t* m = in1 + (size_t)sub1_rv[rvc] * SUB1;
   const ec::U256 al = ec::sc_reduce(alpha_full + (size_t)rvc * 64, 64);
-  const ec::Aff Bpk = ec::aff_load(m.pk + (size_t)in * 16), BTpk = ec::aff_load(m.tpk + (size_t)in * 16);
-  const ec::Aff R1 = ec::aff_load(m.R + (size_t)in * 16), R2 = ec::aff_load(m.tR + (size_t)in * 16);
+  const ec::Aff Bpk = ec::aff_load(m + 128), BTpk = ec::aff_load(m + 168);
+  const ec::Aff R1 = ec::aff_load(m + 144), R2 = ec::aff_load(m + 184);
   ec::Jac res = ec::jac_inf(), fr = ec::jac_inf();
   if (live && sub < 3) {
     const ec::U256 sc = sub == 0 ? ec::u256_load(kq + (size_t)pi * 8) : (sub == 1 ? dlog_challenge(R1, Bpk) : dlog_challenge(R2, BTpk));
     res = ec::jac_mul(sc, sub == 2 ? BTpk : Bpk);
-    const ec::U256 fk = sub == 0 ? al : ec::sc_reduce((sub == 1 ? m.z : m.tz) + (size_t)in * 8, 8);
+    const ec::U256 fk = sub == 0 ? al : ec::sc_reduce(m + (sub == 1 ? 160 : 200), 8);
     fr = ec::jac_mul_gen(fk);
   }
   vs.v[threadIdx.x] = res;
@@ -359,113 +475,112 @@ __global__ void __launch_bounds__(64) r2a_group_kernel(Dim d, const int32_t* __r
   bool good = ec::jac_eq(fs.v[base], ec::jac_add_aff(vs.v[base], BTpk));                     // g^alpha == k_i B + B'
   good = good && ec::jac_eq_aff(ec::jac_add(fs.v[base + 1], vs.v[base + 1]), R1)             // DLogProof::verify x2
               && ec::jac_eq_aff(ec::jac_add(fs.v[base + 2], vs.v[base + 2]), R2);
-  if (v == 1) good = good && ec::aff_eq(Bpk, ec::aff_load(g_w + (size_t)(b * d.S + ind) * 16));   // rounds.rs:281
-  ok[rv] = good ? 1 : 0;
+  r2a_finish(d, rv, v, pp, b, ind, Bpk, good, gw, bpk_in, code);
 }
 
-// G lanes per party (a power of two >= 2 S): lane 2j | 2j+1 does z1_j G | z2_j H, lane j also e_j T_j
-__global__ void __launch_bounds__(64) r3_group_kernel(Dim d, int G, const uint32_t* __restrict__ delta_i, Ped p, uint32_t* __restrict__ dinv, uint8_t* __restrict__ ok) {
+// G lanes per party (a power of two >= 2 S): lane 2j | 2j+1 does z1_j G | z2_j H, lane j also e_j com_j
+__global__ void __launch_bounds__(64) r3_group_kernel(Dim d, int G, Slab in2, uint32_t* __restrict__ dinv, int32_t* __restrict__ status,
+                                                      uint32_t* __restrict__ bad) {
   __shared__ JacSlots vs, fs;
   const int gid = blockIdx.x * 64 + threadIdx.x, pi = gid / G, sub = gid % G, base = (int)threadIdx.x - sub;
-  const bool live = pi < d.B * d.S;
-  const int b = live ? pi / d.S : 0;
+  const bool live = pi < d.B * d.L;
+  const int b = live ? pi / d.L : 0;
   const ec::Aff Gp = ec::aff_gen(), H = ec::aff_h2();
   ec::Jac res = ec::jac_inf(), fr = ec::jac_inf();
   if (live && sub < d.S) {
-    const size_t o = (size_t)b * d.S + sub;
-    const ec::Aff T = ec::aff_load(p.T + o * 16), a1 = ec::aff_load(p.a1 + o * 16), a2 = ec::aff_load(p.a2 + o * 16);
-    const ec::Aff hp[5] = {Gp, H, T, a1, a2};
-    res = ec::jac_mul(hash_points(hp), T);
+    const uint32_t* m = rec_of(in2, sub, b);
+    const ec::Aff C = ec::aff_load(m + 64), a1 = ec::aff_load(m + 32), a2 = ec::aff_load(m + 48);
+    const ec::Aff hp[5] = {Gp, H, C, a1, a2};
+    res = ec::jac_mul(hash_points(hp), C);
   }
   if (live && sub < 2 * d.S) {
-    const size_t o = (size_t)b * d.S + (sub >> 1);
-    fr = ec::jac_mul_fixed(ec::u256_load(((sub & 1) ? p.z2 : p.z1) + o * 8), sub & 1);
+    const uint32_t* m = rec_of(in2, sub >> 1, b);
+    fr = ec::jac_mul_fixed(ec::sc_reduce(m + ((sub & 1) ? 88 : 80), 8), sub & 1);
   }
   vs.v[threadIdx.x] = res;
   fs.v[threadIdx.x] = fr;
   __syncthreads();
   if (!live || sub) return;
   ec::U256 sum = ec::u256_zero();
-  bool good = true;
+  bool com_ok = true, ped_ok = true;
   for (int j = 0; j < d.S; ++j) {
-    const size_t o = (size_t)b * d.S + j;
-    sum = ec::sc_add(sum, ec::u256_load(delta_i + o * 8));
-    const ec::Aff a1 = ec::aff_load(p.a1 + o * 16), a2 = ec::aff_load(p.a2 + o * 16);
+    const uint32_t* m = rec_of(in2, j, b);
+    sum = ec::sc_add(sum, ec::sc_reduce(m, 8));
+    com_ok = com_ok && words_eq(m + 8, m + 64, 16);
+    const ec::Aff a1 = ec::aff_load(m + 32), a2 = ec::aff_load(m + 48);
     const ec::Jac lhs = ec::jac_add(fs.v[base + 2 * j], fs.v[base + 2 * j + 1]);
     const ec::Jac rhs = ec::jac_add_aff(ec::jac_add_aff(vs.v[base + j], a1), a2);
-    good = good && ec::jac_eq(lhs, rhs);
+    ped_ok = ped_ok && ec::jac_eq(lhs, rhs);
   }
-  good = good && !ec::u256_is_zero(sum);
-  ec::u256_store(dinv + (size_t)pi * 8, ec::sc_inv(sum));
-  ok[pi] = good ? 1 : 0;
+  r3_finish(pi, com_ok, ped_ok, sum, dinv, status, bad);
 }
 
 // G lanes per party (a power of two >= 3 S): lane 3j+k does e D_j | z2_j R | e E_j; lane 2j+k does z1_j H | z2_j G
-__global__ void __launch_bounds__(64) r6_group_kernel(Dim d, int G, const uint32_t* __restrict__ R, const uint32_t* __restrict__ pedT, Heg h,
-                          const uint32_t* __restrict__ y, uint8_t* __restrict__ ok) {
+__global__ void __launch_bounds__(64) r6_group_kernel(Dim d, int G, Slab in5, const uint32_t* __restrict__ R, const uint32_t* __restrict__ tvec,
+                          const uint32_t* __restrict__ y, int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
   __shared__ JacSlots vs, fs;
   const int gid = blockIdx.x * 64 + threadIdx.x, pi = gid / G, sub = gid % G, base = (int)threadIdx.x - sub;
-  const bool live = pi < d.B * d.S;
-  const int pic = live ? pi : 0, b = pic / d.S;
+  const bool live = pi < d.B * d.L;
+  const int pic = live ? pi : 0, b = pic / d.L;
   const ec::Aff Gp = ec::aff_gen(), H = ec::aff_h2(), Rp = ec::aff_load(R + (size_t)pic * 16);
   ec::Jac res = ec::jac_inf(), fr = ec::jac_inf();
   if (live && sub < 3 * d.S) {
     const int j = sub / 3, kind = sub % 3;
-    const size_t o = (size_t)b * d.S + j;
-    const ec::Aff TT = ec::aff_load(h.T + o * 16), A3 = ec::aff_load(h.A3 + o * 16), D = ec::aff_load(pedT + o * 16),
-                  E = ec::aff_load(h.S + o * 16);
+    const uint32_t* m = rec_of(in5, j, b);
+    const ec::Aff E = ec::aff_load(m), TT = ec::aff_load(m + 16), A3 = ec::aff_load(m + 32),
+                  D = ec::aff_load(tvec + ((size_t)j * d.B + b) * 16);
     const ec::Aff hp[7] = {TT, A3, Rp, H, Gp, D, E};
     const ec::U256 e = hash_points(hp);
-    res = ec::jac_mul(kind == 1 ? ec::u256_load(h.z2 + o * 8) : e, kind == 0 ? D : (kind == 1 ? Rp : E));
+    res = ec::jac_mul(kind == 1 ? ec::sc_reduce(m + 56, 8) : e, kind == 0 ? D : (kind == 1 ? Rp : E));
   }
   if (live && sub < 2 * d.S) {
-    const size_t o = (size_t)b * d.S + (sub >> 1);
-    fr = ec::jac_mul_fixed(ec::u256_load(((sub & 1) ? h.z2 : h.z1) + o * 8), (sub & 1) ? 0 : 1);
+    const uint32_t* m = rec_of(in5, sub >> 1, b);
+    fr = ec::jac_mul_fixed(ec::sc_reduce(m + ((sub & 1) ? 56 : 48), 8), (sub & 1) ? 0 : 1);
   }
   vs.v[threadIdx.x] = res;
   fs.v[threadIdx.x] = fr;
   __syncthreads();
   if (!live || sub) return;
-  bool good = true;
+  uint32_t mask = 0;
   ec::Jac acc = ec::jac_inf();
   for (int j = 0; j < d.S; ++j) {
-    const size_t o = (size_t)b * d.S + j;
-    const ec::Aff TT = ec::aff_load(h.T + o * 16), A3 = ec::aff_load(h.A3 + o * 16), E = ec::aff_load(h.S + o * 16);
+    const uint32_t* m = rec_of(in5, j, b);
+    const ec::Aff E = ec::aff_load(m), TT = ec::aff_load(m + 16), A3 = ec::aff_load(m + 32);
     const ec::Jac l1 = ec::jac_add(fs.v[base + 2 * j], fs.v[base + 2 * j + 1]);
     const ec::Jac r1 = ec::jac_add_aff(vs.v[base + 3 * j], TT);
     const ec::Jac r2 = ec::jac_add_aff(vs.v[base + 3 * j + 2], A3);
-    good = good && ec::jac_eq(l1, r1) && ec::jac_eq(vs.v[base + 3 * j + 1], r2);
+    if (!(ec::jac_eq(l1, r1) && ec::jac_eq(vs.v[base + 3 * j + 1], r2))) mask |= 1u << j;
     acc = ec::jac_add_aff(acc, E);
   }
-  good = good && ec::jac_eq_aff(acc, ec::aff_load(y));
-  ok[pi] = good ? 1 : 0;
+  if (mask) fail(status, bad, pi, 601, mask);
+  if (!ec::jac_eq_aff(acc, ec::aff_load(y + (size_t)ks_of(d, b) * 16))) fail(status, bad, pi, 602, 0);
 }
 
-// ---- Round 7: local signatures, output_signature, verify (party_i.rs:850-936) -------------------------------
-struct Flags { const uint8_t *vi, *rv, *r3, *r4, *r5, *r6; };
-__global__ void __launch_bounds__(64) r7_kernel(Dim d, Flags f, const uint32_t* __restrict__ msg, const uint32_t* __restrict__ R,
-                          const uint32_t* __restrict__ kq, const uint32_t* __restrict__ sigma_i, const uint32_t* __restrict__ y,
-                          uint32_t* __restrict__ r_out, uint32_t* __restrict__ s_out, int32_t* __restrict__ recid_out,
-                          uint32_t* __restrict__ R_out, int32_t* __restrict__ status) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= d.B) return;
-  const int S = d.S, P1 = S - 1;
-  int st = 0;
-  const int nvi = S * P1 * d.V * d.n, nrv = S * P1 * 2;
-  for (int q = 0; q < nvi && !st; ++q) if (!f.vi[(size_t)b * nvi + q]) st = 101;          // MessageB::b -> InvalidKey
-  for (int q = 0; q < nrv && !st; ++q) if (!f.rv[(size_t)b * nrv + q]) st = 201;          // verify_proofs_get_alpha
-  for (int j = 0; j < S && !st; ++j) if (!f.r3[(size_t)b * S + j]) st = 302;
-  for (int j = 0; j < S && !st; ++j) if (!f.r4[(size_t)b * S + j]) st = 401;
-  for (int j = 0; j < S && !st; ++j) if (!f.r5[(size_t)b * S + j]) st = 501;
-  for (int j = 0; j < S && !st; ++j) if (!f.r6[(size_t)b * S + j]) st = 601;
-  const ec::Aff Rp = ec::aff_load(R + (size_t)b * S * 16);
-  const ec::U256 m = ec::sc_reduce(msg + (size_t)b * 8, 8), r = ec::sc_reduce(Rp.x.w, 8);
-  ec::U256 s = ec::u256_zero();
-  for (int j = 0; j < S; ++j) {
-    const size_t o = (size_t)b * S + j;
-    s = ec::sc_add(s, ec::sc_add(ec::sc_mul(m, ec::u256_load(kq + o * 8)), ec::sc_mul(r, ec::u256_load(sigma_i + o * 8))));
-  }
-  const ec::U256 ry = ec::sc_reduce(Rp.y.w, 8);
+// ---- Round 7: phase7_local_sig -> PartialSignature (party_i.rs:850-871) -------------------------------------------------
+__global__ void __launch_bounds__(64) r7_kernel(Dim d, const uint32_t* __restrict__ msg, const uint32_t* __restrict__ R,
+                          const uint32_t* __restrict__ kq, const uint32_t* __restrict__ sigma_i, uint32_t* __restrict__ mq,
+                          uint32_t* __restrict__ rq, uint32_t* __restrict__ s_i) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= d.B * d.L) return;
+  const int b = pi / d.L;
+  const ec::U256 m = ec::sc_reduce(msg + (size_t)b * 8, 8), r = ec::sc_reduce(R + (size_t)pi * 16, 8);
+  ec::u256_store(mq + (size_t)pi * 8, m);
+  ec::u256_store(rq + (size_t)pi * 8, r);
+  ec::u256_store(s_i + (size_t)pi * 8, ec::sc_add(ec::sc_mul(m, ec::u256_load(kq + (size_t)pi * 8)),
+                                                  ec::sc_mul(r, ec::u256_load(sigma_i + (size_t)pi * 8))));
+}
+// SignManual::complete -> output_signature + verify (party_i.rs:873-936); outputs are [L][B], zero unless status == 0
+__global__ void __launch_bounds__(64) complete_kernel(Dim d, Slab in6, const uint32_t* __restrict__ R, const uint32_t* __restrict__ mq,
+                          const uint32_t* __restrict__ rq, const uint32_t* __restrict__ s_i, const uint32_t* __restrict__ y,
+                          int32_t* __restrict__ status, uint32_t* __restrict__ bad, uint32_t* __restrict__ r_out,
+                          uint32_t* __restrict__ s_out, int32_t* __restrict__ recid_out) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= d.B * d.L) return;
+  const int li = pi % d.L, i = d.loc[li], b = pi / d.L;
+  ec::U256 s = ec::u256_load(s_i + (size_t)pi * 8);
+  for (int j = 0; j < d.S; ++j) if (j != i) s = ec::sc_add(s, ec::sc_reduce(rec_of(in6, j, b), 8));
+  const ec::U256 m = ec::u256_load(mq + (size_t)pi * 8), r = ec::u256_load(rq + (size_t)pi * 8);
+  const ec::U256 ry = ec::sc_reduce(R + (size_t)pi * 16 + 8, 8);
   int recid = (int)(ry.w[0] & 1u);
   const ec::U256 neg = ec::sc_neg(s);
   {  // if s > q - s: s = q - s, recid ^= 1
@@ -473,27 +588,74 @@ __global__ void __launch_bounds__(64) r7_kernel(Dim d, Flags f, const uint32_t* 
     for (int j = 7; j >= 0; --j) { if (s.w[j] != neg.w[j]) { gt = s.w[j] > neg.w[j]; break; } }
     if (gt) { s = neg; recid ^= 1; }
   }
-  // verify (party_i.rs:913-936)
   bool okv = !ec::u256_is_zero(s);
   if (okv) {
     const ec::U256 bi = ec::sc_inv(s), u1 = ec::sc_mul(m, bi), u2 = ec::sc_mul(r, bi);
-    const ec::Aff V = ec::jac_to_aff(ec::jac_add(ec::jac_mul_gen(u1), ec::jac_mul(u2, ec::aff_load(y))));
+    const ec::Aff V = ec::jac_to_aff(ec::jac_add(ec::jac_mul_gen(u1), ec::jac_mul(u2, ec::aff_load(y + (size_t)ks_of(d, b) * 16))));
     okv = !V.inf && ec::u256_eq(ec::sc_reduce(V.x.w, 8), r);
   }
-  if (!okv && !st) st = 701;
-  ec::u256_store(r_out + (size_t)b * 8, r);
-  ec::u256_store(s_out + (size_t)b * 8, s);
-  recid_out[b] = recid;
-  if (R_out) ec::aff_store(R_out + (size_t)b * 16, Rp);
-  status[b] = st;
+  if (!okv) fail(status, bad, pi, 701, 0);
+  const bool good = status[pi] == 0;
+  const size_t o = (size_t)li * d.B + b;
+  ec::u256_store(r_out + o * 8, good ? r : ec::u256_zero());
+  ec::u256_store(s_out + o * 8, good ? s : ec::u256_zero());
+  recid_out[o] = good ? recid : 0;
+}
+// [L][B] views of the per-party state
+__global__ void result_kernel(Dim d, const int32_t* __restrict__ status, const uint32_t* __restrict__ bad, const uint32_t* __restrict__ R,
+                              int32_t* __restrict__ st_out, uint32_t* __restrict__ bad_out, uint32_t* __restrict__ R_out) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= d.B * d.L) return;
+  const size_t o = (size_t)(pi % d.L) * d.B + pi / d.L;
+  if (st_out) st_out[o] = status[pi];
+  if (bad_out) bad_out[o] = bad[pi];
+  if (R_out) for (int j = 0; j < 16; ++j) R_out[o * 16 + j] = R[(size_t)pi * 16 + j];
+}
+// the lock-step composition: a session's status = the smallest non-zero party status; the signature is party 0's
+__global__ void sign_finish_kernel(int B, int L, int b0, const int32_t* __restrict__ pst, const uint32_t* __restrict__ pr,
+                                   const uint32_t* __restrict__ ps, const int32_t* __restrict__ prec, const uint32_t* __restrict__ pR,
+                                   uint32_t* __restrict__ r_out, uint32_t* __restrict__ s_out, int32_t* __restrict__ recid_out,
+                                   uint32_t* __restrict__ R_out, int32_t* __restrict__ status) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int st = 0;
+  for (int li = 0; li < L; ++li) { const int s = pst[(size_t)li * B + b]; if (s && (!st || s < st)) st = s; }
+  const size_t o = (size_t)b0 + b;
+  for (int j = 0; j < 8; ++j) { r_out[o * 8 + j] = st ? 0u : pr[(size_t)b * 8 + j]; s_out[o * 8 + j] = st ? 0u : ps[(size_t)b * 8 + j]; }
+  recid_out[o] = st ? 0 : prec[b];
+  if (R_out) for (int j = 0; j < 16; ++j) R_out[o * 16 + j] = pR[(size_t)b * 16 + j];
+  status[o] = st;
 }
 
-template <class T>
-static T* W(Seq& q, size_t count) {
-  T* p = ws_array<T>(q.ctx, count);
-  if (!p && q.rc == MPE_OK) { q.rc = MPE_E_NOMEM; mpe_set_error_msg("gg20: workspace under-reserved"); }
-  return p;
-}
+}  // namespace gg
+}  // namespace mpe
+
+// ======================================================================================================================
+// the session object: one batch of B sessions x L local parties, carried from round to round
+// ======================================================================================================================
+struct mpe_gg20_session {
+  mpe_ctx* ctx = nullptr;
+  const mpe_gg20_keys* K = nullptr;
+  int B = 0, L = 0, dedup = 0, next_round = 0;
+  mpe::gg::Dim d{};
+  mpe_gg20_nonces Z{};
+  void* mem = nullptr;
+  size_t mem_bytes = 0;
+  bool from_cache = false;
+  mpe::gg::Idx ix{};
+  // state that lives across rounds (what the reference's RoundN structs carry)
+  uint32_t *kq = nullptr, *gq = nullptr, *w = nullptr, *k64 = nullptr, *g_gamma = nullptr, *com = nullptr, *c_a = nullptr, *beta = nullptr;
+  uint32_t *ca_all = nullptr, *com_all = nullptr, *bpk_in = nullptr, *delta_i = nullptr, *sigma_i = nullptr, *lq = nullptr, *pedT = nullptr;
+  uint32_t *tvec = nullptr, *dinv = nullptr, *R = nullptr, *Rbar = nullptr, *mq = nullptr, *rq = nullptr, *s_i = nullptr, *bad = nullptr;
+  uint32_t *sig_r = nullptr, *sig_s = nullptr;
+  int32_t *status = nullptr, *sig_recid = nullptr;
+  char* tmp = nullptr;             // per-round scratch (dense outputs of the composites before they are packed)
+  size_t tmp_bytes = 0;
+};
+
+namespace mpe {
+namespace gg {
+
 // MPE_GG20_TRACE=1 in the environment: synchronise after every step and report it on stderr (debug aid)
 static void gg_trace(hipStream_t st, const char* what, int rc) {
   static const bool on = getenv("MPE_GG20_TRACE") != nullptr;
@@ -504,142 +666,279 @@ static void gg_trace(hipStream_t st, const char* what, int rc) {
 }
 #define GG_LAUNCH(kernel, nitems, ...)                                                                   \
   do {                                                                                                    \
-    if (q.rc == MPE_OK && (nitems) > 0)                                                                   \
+    if (rc == MPE_OK && (nitems) > 0)                                                                     \
       hipLaunchKernelGGL(kernel, dim3(blocks_for((int)(nitems), 64)), dim3(64), 0, st, __VA_ARGS__);      \
-    gg_trace(st, #kernel, q.rc);                                                                          \
+    gg_trace(st, #kernel, rc);                                                                            \
   } while (0)
 
-// one chunk of sessions [b0, b0+B)
-static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const mpe_gg20_nonces* Z, uint32_t* d_r,
-                      uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, int dedup, hipStream_t st) {
-  const int S = K->S, n = K->n, P1 = S - 1, P = S * P1;
-  Dim d{B, S, n, dedup ? 1 : 2, dedup ? 1 : S};
-  const size_t nPI = (size_t)B * S, nAP = nPI * n, nVI = (size_t)B * P * d.V * n, nMB = (size_t)B * P * 2, nPP = (size_t)B * P,
-               nPV = (size_t)B * d.PV * P;
-  // workspace: own arrays + the largest inner composite (alice_verify over nVI items / pdl_verify over nPV items)
-  const size_t own = nPI * 700 + nAP * 260 + nVI * 8 + nMB * 720 + nPP * 470 + nPV * 8 + 64 * 64;
-  const size_t inner = (nVI > nPV ? nVI : nPV) * 2300 + nAP * 2100 + nMB * 300;
-  // the inner composites call ws_reserve themselves (it resets the bump pointer), so this function keeps
-  // its own arrays in a second arena carved from the tail of one reservation: reserve everything once here
-  // and let the inner calls see a workspace that is already large enough (ws_reserve then only resets ws_off).
-  MPE_TRY(ws_reserve(ctx, (own + inner) * 4 + (1u << 20), st));
-  // carve the "own" region at the top of the workspace so that inner resets do not touch it
-  char* top = (char*)ctx->ws + ctx->ws_bytes;
-  size_t top_off = 0;
-  auto own_alloc = [&](size_t bytes) -> void* {
-    top_off = (top_off + bytes + 255) & ~(size_t)255;
-    return top - top_off;
-  };
-  auto OW = [&](size_t words) { return (uint32_t*)own_alloc(words * 4); };
-  auto OI = [&](size_t count) { return (int32_t*)own_alloc(count * 4); };
-  auto OF = [&](size_t count) { return (uint8_t*)own_alloc(count); };
-  Seq q{ctx, st, B};
+struct Bump {
+  char* base; size_t off = 0;
+  explicit Bump(char* b) : base(b) {}
+  void* take(size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return base ? base + o : nullptr; }
+  uint32_t* w(size_t words) { return (uint32_t*)take(words * 4); }
+  int32_t* i(size_t count) { return (int32_t*)take(count * 4); }
+  uint8_t* f(size_t count) { return (uint8_t*)take(count); }
+};
+struct Counts { size_t nPI, nAP, nVI, nMB, nPP, nPV, SB; };
+static Counts counts_of(const Dim& d) {
+  const size_t P1 = d.S - 1;
+  Counts c;
+  c.nPI = (size_t)d.B * d.L; c.nAP = c.nPI * d.n; c.nPP = c.nPI * P1; c.nMB = c.nPP * 2; c.nVI = c.nPP * d.V * d.n;
+  c.nPV = (size_t)d.B * d.PV * d.S * P1; c.SB = (size_t)d.S * d.B;
+  return c;
+}
+static size_t tmp_bytes_of(const Counts& c) {
+  const size_t r0 = c.nAP * 250 * 4 + 4096;
+  const size_t r1 = c.nVI * 5 + c.nMB * (8 + 8 + 128 + 16 + 16 + 8 + 16 + 16 + 8) * 4 + 8192;
+  const size_t r2 = c.nMB * (1 + 64 + 8) * 4 + c.nMB + c.nPI * 72 * 4 + 8192;
+  const size_t r4 = c.nPP * 450 * 4 + 4096;
+  const size_t r5 = c.nPV * 9 + c.nPI * 64 * 4 + 8192;
+  size_t m = r0;
+  if (r1 > m) m = r1;
+  if (r2 > m) m = r2;
+  if (r4 > m) m = r4;
+  if (r5 > m) m = r5;
+  return m + 64 * 256;                 // alignment slack of the bump allocator
+}
+// assigns every state array (base == nullptr: only sizes)
+static size_t layout(mpe_gg20_session* s, char* base) {
+  const Dim& d = s->d;
+  const Counts c = counts_of(d);
+  Bump m(base);
+  Idx& x = s->ix;
+  x.kown_pi = m.i(c.nPI);
+  x.pi_ap = m.i(c.nAP); x.kown_ap = m.i(c.nAP); x.st_ap = m.i(c.nAP);
+  x.ca_vi = m.i(c.nVI); x.kpub_vi = m.i(c.nVI); x.st_vi = m.i(c.nVI);
+  x.ca_mb = m.i(c.nMB); x.kpub_mb = m.i(c.nMB); x.kown_mb = m.i(c.nMB);
+  x.pi_pp = m.i(c.nPP); x.kown_pp = m.i(c.nPP); x.st_pp = m.i(c.nPP);
+  x.ca_pv = m.i(c.nPV); x.pi_pv = m.i(c.nPV); x.kpub_pv = m.i(c.nPV); x.st_pv = m.i(c.nPV);
+  s->kq = m.w(c.nPI * 8); s->gq = m.w(c.nPI * 8); s->w = m.w(c.nPI * 8); s->k64 = m.w(c.nPI * 64);
+  s->g_gamma = m.w(c.nPI * 16); s->com = m.w(c.nPI * 8); s->c_a = m.w(c.nPI * 128); s->beta = m.w(c.nMB * 8);
+  s->ca_all = m.w(c.SB * 128); s->com_all = m.w(c.SB * 8); s->bpk_in = m.w(c.nPP * 16);
+  s->delta_i = m.w(c.nPI * 8); s->sigma_i = m.w(c.nPI * 8); s->lq = m.w(c.nPI * 8); s->pedT = m.w(c.nPI * 16);
+  s->tvec = m.w(c.SB * 16); s->dinv = m.w(c.nPI * 8); s->R = m.w(c.nPI * 16); s->Rbar = m.w(c.nPI * 16);
+  s->mq = m.w(c.nPI * 8); s->rq = m.w(c.nPI * 8); s->s_i = m.w(c.nPI * 8); s->bad = m.w(c.nPI);
+  s->sig_r = m.w(c.nPI * 8); s->sig_s = m.w(c.nPI * 8);
+  s->status = m.i(c.nPI); s->sig_recid = m.i(c.nPI);
+  s->tmp_bytes = tmp_bytes_of(c);
+  s->tmp = (char*)m.take(s->tmp_bytes);
+  return m.off;
+}
+static Slab slab_of(const mpe_gg20_session* s, const uint32_t* p, const int64_t* h_off, int round) {
+  Slab sl;
+  sl.p = p; sl.W = msg_words(s->d.S, s->d.n, round);
+  for (int j = 0; j < 8; ++j) sl.off[j] = j < s->d.S ? (h_off ? (long long)h_off[j] : (long long)j * s->B) : 0;
+  return sl;
+}
+static int round_enter(mpe_gg20_session* s, int round, const void* in, const void* out, bool need_in, bool need_out) {
+  if (!s || (need_in && !in) || (need_out && !out)) return MPE_E_ARG;
+  if (s->next_round != round) { mpe_set_error_msg("gg20: rounds must be run in order"); return MPE_E_ARG; }
+  return MPE_OK;
+}
+static int round_exit(mpe_gg20_session* s, int rc, const char* what) {
+  if (rc != MPE_OK) return rc;
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mpe_set_error(what, e); return MPE_E_HIP; }
+  s->next_round++;
+  return MPE_OK;
+}
+#define PACK(nitems, per, nsub, sub0, subw, dst_off, src, words)                                                              \
+  GG_LAUNCH(pack_field_kernel, (size_t)(nitems) * (words), (int)(nitems), (int)(per), d.L, d.B, (int)(nsub), (int)(sub0), (int)(subw),  \
+            (int)(dst_off), (const uint32_t*)(src), (int)(words), d_out)
 
-  // nonce slices of this chunk
-  const size_t oPI = (size_t)b0 * S, oAP = oPI * n, oMB = (size_t)b0 * P * 2, oPP = (size_t)b0 * P;
-  const uint32_t *z_k = Z->k + oPI * 8, *z_gamma = Z->gamma + oPI * 8, *z_blind = Z->blind + oPI * 8, *z_ra = Z->r_a + oPI * 64;
-  mpe_alice_nonces an{Z->al_alpha + oAP * 24, Z->al_beta + oAP * 64, Z->al_gamma + oAP * 88, Z->al_rho + oAP * 72};
-  mpe_pdl_nonces pn{Z->pdl_alpha + oPP * 24, Z->pdl_beta + oPP * 64, Z->pdl_rho + oPP * 72, Z->pdl_gamma + oPP * 88};
+// ---- Round0::proceed (rounds.rs:68-104) ------------------------------------------------------------------------------
+static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
+  int rc = round_enter(s, 0, nullptr, d_out, false, true);
+  if (rc != MPE_OK) return rc;
+  mpe_ctx* ctx = s->ctx; const mpe_gg20_keys* K = s->K; const Dim& d = s->d; const Counts c = counts_of(d); const mpe_gg20_nonces& Z = s->Z;
+  const int n = d.n;
+  (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)msg_words(d.S, n, 0) * 4, st);
+  GG_LAUNCH(r0_kernel, c.nPI, d, K->x, Z.k, Z.gamma, Z.blind, s->kq, s->gq, s->w, s->k64, s->g_gamma, s->com);
+  if (rc == MPE_OK) rc = paillier_encrypt(ctx, K->prv, (int)c.nPI, s->ix.kown_pi, s->k64, Z.r_a, s->c_a, true, st);      // MessageA.c
+  gg_trace(st, "encrypt k", rc);
+  Bump t(s->tmp);
+  mpe_alice_proof ap{t.w(c.nAP * 64), t.w(c.nAP * 8), t.w(c.nAP * 64), t.w(c.nAP * 25), t.w(c.nAP * 89)};
+  mpe_alice_nonces an{Z.al_alpha, Z.al_beta, Z.al_gamma, Z.al_rho};
+  if (rc == MPE_OK)
+    rc = alice_generate(ctx, K->prv, K->stm, (int)c.nAP, s->ix.kown_ap, s->ix.st_ap, rows(s->kq, 8, s->ix.pi_ap),
+                        rows(s->c_a, 128, s->ix.pi_ap), rows(Z.r_a, 64, s->ix.pi_ap), &an, &ap, st);
+  gg_trace(st, "alice_generate", rc);
+  PACK(c.nAP, n, n + 1, 0, SUB0, 0, ap.z, 64); PACK(c.nAP, n, n + 1, 0, SUB0, 64, ap.e, 8); PACK(c.nAP, n, n + 1, 0, SUB0, 72, ap.s, 64);
+  PACK(c.nAP, n, n + 1, 0, SUB0, 136, ap.s1, 25); PACK(c.nAP, n, n + 1, 0, SUB0, 161, ap.s2, 89);
+  PACK(c.nPI, 1, n + 1, n, SUB0, 0, s->c_a, 128); PACK(c.nPI, 1, n + 1, n, SUB0, 128, s->com, 8);
+  return round_exit(s, rc, "gg20 round0");
+}
 
-  Idx ix;
-  ix.key_pi = OI(nPI);
-  ix.pi_ap = OI(nAP); ix.key_ap = OI(nAP); ix.st_ap = OI(nAP);
-  ix.ap_vi = OI(nVI); ix.pia_vi = OI(nVI); ix.key_vi = OI(nVI); ix.st_vi = OI(nVI);
-  ix.pia_mb = OI(nMB); ix.key_mb = OI(nMB); ix.mbin_rv = OI(nMB); ix.key_rv = OI(nMB);
-  ix.pi_pp = OI(nPP); ix.key_pp = OI(nPP); ix.st_pp = OI(nPP);
-  ix.pp_pv = OI(nPV); ix.pip_pv = OI(nPV); ix.key_pv = OI(nPV); ix.st_pv = OI(nPV);
-  size_t total = nVI;
-  if (nMB > total) total = nMB;
-  if (nAP > total) total = nAP;
-  if (nPV > total) total = nPV;
-  if (nPI > total) total = nPI;
-  GG_LAUNCH(idx_kernel, total, d, K->d_signers, ix, (int)total);
-
-  // ---- Round 0 ----
-  uint32_t *kq = OW(nPI * 8), *gq = OW(nPI * 8), *w = OW(nPI * 8), *k64 = OW(nPI * 64), *g_gamma = OW(nPI * 16),
-           *g_w = OW(nPI * 16), *com = OW(nPI * 8), *c_a = OW(nPI * 128);
-  GG_LAUNCH(r0_kernel, nPI, d, K->d_signers, K->x, K->X, z_k, z_gamma, z_blind, kq, gq, w, k64, g_gamma, g_w, com);
-  if (q.rc == MPE_OK) q.rc = paillier_encrypt(ctx, K->pk, (int)nPI, ix.key_pi, k64, z_ra, c_a, true, st);          // MessageA.c
-  gg_trace(st, "encrypt k", q.rc);
-  mpe_alice_proof ap{OW(nAP * 64), OW(nAP * 8), OW(nAP * 64), OW(nAP * 25), OW(nAP * 89)};
-  if (q.rc == MPE_OK)
-    q.rc = alice_generate(ctx, K->pk, K->stm, (int)nAP, ix.key_ap, ix.st_ap, rows(kq, 8, ix.pi_ap), rows(c_a, 128, ix.pi_ap),
-                          rows(z_ra, 64, ix.pi_ap), &an, &ap, st);
-  gg_trace(st, "alice_generate", q.rc);
-
-  // ---- Round 1 ----
-  uint8_t* ok_vi = OF(nVI);
-  if (q.rc == MPE_OK) {
-    AliceProofRows pr{rows(ap.z, 64, ix.ap_vi), rows(ap.e, 8, ix.ap_vi), rows(ap.s, 64, ix.ap_vi), rows(ap.s1, 25, ix.ap_vi),
-                      rows(ap.s2, 89, ix.ap_vi)};
-    q.rc = alice_verify(ctx, K->pk, K->stm, (int)nVI, ix.key_vi, ix.st_vi, rows(c_a, 128, ix.pia_vi), pr, ok_vi, st);
+// ---- Round1::proceed (rounds.rs:122-206) -----------------------------------------------------------------------------
+static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_off, uint32_t* d_out, hipStream_t st) {
+  int rc = round_enter(s, 1, d_in, d_out, true, true);
+  if (rc != MPE_OK) return rc;
+  mpe_ctx* ctx = s->ctx; const mpe_gg20_keys* K = s->K; const Dim& d = s->d; const Counts c = counts_of(d); const mpe_gg20_nonces& Z = s->Z;
+  const int n = d.n, P1 = d.S - 1;
+  const Slab in0 = slab_of(s, d_in, h_off, 0);
+  (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)msg_words(d.S, n, 1) * 4, st);
+  // m_a_vec[..].c and bc_vec of every party (into_vec_including_me)
+  GG_LAUNCH(gather_field_kernel, c.SB * 128, in0, d.S, d.B, n * SUB0, 128, s->ca_all);
+  GG_LAUNCH(gather_field_kernel, c.SB * 8, in0, d.S, d.B, n * SUB0 + 128, 8, s->com_all);
+  Bump t(s->tmp);
+  int32_t* sub0_vi = t.i(c.nVI);
+  uint8_t* ok_vi = t.f(c.nVI);
+  uint32_t *bsel = t.w(c.nMB * 8), *btq = t.w(c.nMB * 8), *c_b = t.w(c.nMB * 128);
+  uint32_t *Bpk = t.w(c.nMB * 16), *BR = t.w(c.nMB * 16), *Bz = t.w(c.nMB * 8), *BTpk = t.w(c.nMB * 16), *BTR = t.w(c.nMB * 16), *BTz = t.w(c.nMB * 8);
+  GG_LAUNCH(idx1_kernel, c.nVI, d, in0, sub0_vi);
+  if (rc == MPE_OK) {      // every range proof of every peer, for both MessageB::b calls (mta/mod.rs:119-131), read in place
+    AliceProofRows pr{rows(d_in, SUB0, sub0_vi), rows(d_in + 64, SUB0, sub0_vi), rows(d_in + 72, SUB0, sub0_vi),
+                      rows(d_in + 136, SUB0, sub0_vi), rows(d_in + 161, SUB0, sub0_vi)};
+    rc = alice_verify(ctx, K->pub, K->stm, (int)c.nVI, s->ix.kpub_vi, s->ix.st_vi, rows(s->ca_all, 128, s->ix.ca_vi), pr, ok_vi, st);
   }
-  gg_trace(st, "alice_verify", q.rc);
-  uint32_t *bsel = OW(nMB * 8), *btq = OW(nMB * 8), *beta = OW(nMB * 8),
-           *c_b = OW(nMB * 128);
-  uint32_t *Bpk = OW(nMB * 16), *BR = OW(nMB * 16), *Bz = OW(nMB * 8), *BTpk = OW(nMB * 16), *BTR = OW(nMB * 16), *BTz = OW(nMB * 8);
-  const uint32_t *z_bt = Z->mb_beta_tag + oMB * 64, *z_mr = Z->mb_r + oMB * 64, *z_nb = Z->mb_nonce_b + oMB * 8,
-                 *z_nbt = Z->mb_nonce_bt + oMB * 8;
-  GG_LAUNCH(mb_prep_kernel, nMB, d, gq, w, z_bt, bsel, btq, beta);
-  if (q.rc == MPE_OK)                                                           // encrypt, Paillier::mul, Paillier::add :133-145
-    q.rc = paillier_mul_add_enc(ctx, K->pk, (int)nMB, ix.key_mb, rows(c_a, 128, ix.pia_mb), rows(bsel, 8), 8, z_bt, z_mr, c_b, st);
-  gg_trace(st, "MessageB ciphertext", q.rc);
-  GG_LAUNCH(dlog_prove_kernel, nMB, (int)nMB, bsel, z_nb, Bpk, BR, Bz);                                       // :147
-  GG_LAUNCH(dlog_prove_kernel, nMB, (int)nMB, btq, z_nbt, BTpk, BTR, BTz);                                    // :148
+  gg_trace(st, "alice_verify", rc);
+  GG_LAUNCH(status1_kernel, c.nPI, d, ok_vi, s->status, s->bad);
+  GG_LAUNCH(mb_prep_kernel, c.nMB, d, s->gq, s->w, Z.mb_beta_tag, bsel, btq, s->beta);
+  if (rc == MPE_OK)                                                             // encrypt, Paillier::mul, Paillier::add :133-145
+    rc = paillier_mul_add_enc(ctx, K->pub, (int)c.nMB, s->ix.kpub_mb, rows(s->ca_all, 128, s->ix.ca_mb), rows(bsel, 8), 8, Z.mb_beta_tag,
+                              Z.mb_r, c_b, st);
+  gg_trace(st, "MessageB ciphertext", rc);
+  GG_LAUNCH(dlog_prove_kernel, c.nMB, (int)c.nMB, bsel, Z.mb_nonce_b, Bpk, BR, Bz);                                     // :147
+  GG_LAUNCH(dlog_prove_kernel, c.nMB, (int)c.nMB, btq, Z.mb_nonce_bt, BTpk, BTR, BTz);                                  // :148
+  const int per = 2 * P1;
+  PACK(c.nMB, per, per, 0, SUB1, 0, c_b, 128); PACK(c.nMB, per, per, 0, SUB1, 128, Bpk, 16); PACK(c.nMB, per, per, 0, SUB1, 144, BR, 16);
+  PACK(c.nMB, per, per, 0, SUB1, 160, Bz, 8); PACK(c.nMB, per, per, 0, SUB1, 168, BTpk, 16); PACK(c.nMB, per, per, 0, SUB1, 184, BTR, 16);
+  PACK(c.nMB, per, per, 0, SUB1, 200, BTz, 8);
+  return round_exit(s, rc, "gg20 round1");
+}
 
-  // ---- Round 2 ----
-  uint32_t *alpha_full = OW(nMB * 64), *alpha = OW(nMB * 8);
-  uint8_t* ok_rv = OF(nMB);
-  if (q.rc == MPE_OK) {
-    // Paillier::decrypt of the incoming c_b with my key (mta/mod.rs:165); rows gathered receiver-ordered
-    uint32_t* cin = OW(nMB * 128);
-    GG_LAUNCH(gather_rows_kernel, nMB * 128, (int)nMB, 128, c_b, ix.mbin_rv, cin);
-    q.rc = paillier_decrypt(ctx, K->pk, (int)nMB, ix.key_rv, cin, alpha_full, st);
-  }
-  gg_trace(st, "decrypt", q.rc);
-  MsgB mbv{Bpk, BR, Bz, BTpk, BTR, BTz};
+// ---- Round2::proceed (rounds.rs:234-317) -----------------------------------------------------------------------------
+static int round2(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_off, uint32_t* d_out, hipStream_t st) {
+  int rc = round_enter(s, 2, d_in, d_out, true, true);
+  if (rc != MPE_OK) return rc;
+  mpe_ctx* ctx = s->ctx; const mpe_gg20_keys* K = s->K; const Dim& d = s->d; const Counts c = counts_of(d); const mpe_gg20_nonces& Z = s->Z;
+  const Slab in1 = slab_of(s, d_in, h_off, 1);
+  (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)W2 * 4, st);
+  Bump t(s->tmp);
+  int32_t* sub1_rv = t.i(c.nMB);
+  uint32_t *alpha_full = t.w(c.nMB * 64), *alpha = t.w(c.nMB * 8);
+  uint8_t* code = t.f(c.nMB);
+  Ped ped{s->pedT, t.w(c.nPI * 8), t.w(c.nPI * 16), t.w(c.nPI * 16), t.w(c.nPI * 8), t.w(c.nPI * 8)};
+  GG_LAUNCH(idx2_kernel, c.nMB, d, in1, sub1_rv);
+  if (rc == MPE_OK)      // Paillier::decrypt of the incoming c_b with my key (mta/mod.rs:165), in place
+    rc = paillier_decrypt(ctx, K->prv, (int)c.nMB, s->ix.kown_mb, rows(d_in, SUB1, sub1_rv), alpha_full, st);
+  gg_trace(st, "decrypt", rc);
   const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 : 0;      // two waves per SIMD
-  if (nMB * 4 <= lanes_fit) GG_LAUNCH(r2a_group_kernel, nMB * 4, d, ix.mbin_rv, alpha_full, kq, mbv, g_w, alpha, ok_rv);
-  else GG_LAUNCH(r2a_kernel, nMB, d, ix.mbin_rv, alpha_full, kq, mbv, g_w, alpha, ok_rv);
-  uint32_t *delta_i = OW(nPI * 8), *sigma_i = OW(nPI * 8), *lq = OW(nPI * 8);
-  Ped ped{OW(nPI * 16), OW(nPI * 16), OW(nPI * 16), OW(nPI * 8), OW(nPI * 8)};
-  GG_LAUNCH(r2b_kernel, nPI, d, kq, gq, w, alpha, beta, Z->l + oPI * 8, Z->ped_s1 + oPI * 8, Z->ped_s2 + oPI * 8, delta_i,
-            sigma_i, lq, ped);
+  if (c.nMB * 4 <= lanes_fit) GG_LAUNCH(r2a_group_kernel, c.nMB * 4, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
+  else GG_LAUNCH(r2a_kernel, c.nMB, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
+  GG_LAUNCH(r2b_kernel, c.nPI, d, s->kq, s->gq, s->w, alpha, s->beta, code, Z.l, Z.ped_s1, Z.ped_s2, s->delta_i, s->sigma_i, s->lq, ped,
+            s->status, s->bad);
+  PACK(c.nPI, 1, 1, 0, W2, 0, s->delta_i, 8); PACK(c.nPI, 1, 1, 0, W2, 8, ped.T, 16); PACK(c.nPI, 1, 1, 0, W2, 24, ped.e, 8);
+  PACK(c.nPI, 1, 1, 0, W2, 32, ped.a1, 16); PACK(c.nPI, 1, 1, 0, W2, 48, ped.a2, 16); PACK(c.nPI, 1, 1, 0, W2, 64, ped.T, 16);
+  PACK(c.nPI, 1, 1, 0, W2, 80, ped.z1, 8); PACK(c.nPI, 1, 1, 0, W2, 88, ped.z2, 8);
+  return round_exit(s, rc, "gg20 round2");
+}
 
-  // ---- Round 3, 4 ----
-  uint32_t *dinv = OW(nPI * 8), *R = OW(nPI * 16), *Rbar = OW(nPI * 16);
-  uint8_t *ok_r3 = OF(nPI), *ok_r4 = OF(nPI), *ok_r5 = OF(nPI), *ok_r6 = OF(nPI);
-  const int g3 = 2 * S <= 4 ? 4 : (2 * S <= 8 ? 8 : 16), g6 = 3 * S <= 8 ? 8 : (3 * S <= 16 ? 16 : 32);
-  if (nPI * g3 <= lanes_fit) GG_LAUNCH(r3_group_kernel, nPI * g3, d, g3, delta_i, ped, dinv, ok_r3);
-  else GG_LAUNCH(r3_kernel, nPI, d, delta_i, ped, dinv, ok_r3);
-  GG_LAUNCH(r4_kernel, nPI, d, dinv, g_gamma, com, z_blind, Bpk, kq, R, Rbar, ok_r4);
-  mpe_pdl_proof pp{OW(nPP * 64), OW(nPP * 16), OW(nPP * 128), OW(nPP * 64), OW(nPP * 25), OW(nPP * 64), OW(nPP * 89)};
-  if (q.rc == MPE_OK)                                                                                          // phase5_proof_pdl
-    q.rc = pdl_prove(ctx, K->pk, K->stm, (int)nPP, ix.key_pp, ix.st_pp, rows(c_a, 128, ix.pi_pp), rows(Rbar, 16, ix.pi_pp),
-                     rows(R, 16, ix.pi_pp), rows(kq, 8, ix.pi_pp), rows(z_ra, 64, ix.pi_pp), &pn, &pp, st);
-  gg_trace(st, "pdl_prove", q.rc);
+// ---- Round3::proceed (rounds.rs:347-402) -----------------------------------------------------------------------------
+static int round3(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_off, uint32_t* d_out, hipStream_t st) {
+  int rc = round_enter(s, 3, d_in, d_out, true, true);
+  if (rc != MPE_OK) return rc;
+  mpe_ctx* ctx = s->ctx; const Dim& d = s->d; const Counts c = counts_of(d);
+  const Slab in2 = slab_of(s, d_in, h_off, 2);
+  (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)W3 * 4, st);
+  GG_LAUNCH(gather_field_kernel, c.SB * 16, in2, d.S, d.B, 8, 16, s->tvec);                  // t_vec
+  const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 : 0;
+  const int g3 = 2 * d.S <= 4 ? 4 : (2 * d.S <= 8 ? 8 : 16);
+  if (c.nPI * g3 <= lanes_fit) GG_LAUNCH(r3_group_kernel, c.nPI * g3, d, g3, in2, s->dinv, s->status, s->bad);
+  else GG_LAUNCH(r3_kernel, c.nPI, d, in2, s->dinv, s->status, s->bad);
+  PACK(c.nPI, 1, 1, 0, W3, 0, s->Z.blind, 8); PACK(c.nPI, 1, 1, 0, W3, 8, s->g_gamma, 16);          // SignDecommitPhase1
+  return round_exit(s, rc, "gg20 round3");
+}
 
-  // ---- Round 5, 6, 7 ----
-  uint8_t* ok_pv = OF(nPV);
-  if (q.rc == MPE_OK) {
-    PdlProofRows pr{rows(pp.z, 64, ix.pp_pv), rows(pp.u1, 16, ix.pp_pv), rows(pp.u2, 128, ix.pp_pv), rows(pp.u3, 64, ix.pp_pv),
-                    rows(pp.s1, 25, ix.pp_pv), rows(pp.s2, 64, ix.pp_pv), rows(pp.s3, 89, ix.pp_pv)};
-    q.rc = pdl_verify(ctx, K->pk, K->stm, (int)nPV, ix.key_pv, ix.st_pv, rows(c_a, 128, ix.pip_pv), rows(Rbar, 16, ix.pip_pv),
-                      rows(R, 16, ix.pip_pv), pr, ok_pv, st);
+// ---- Round4::proceed (rounds.rs:431-498) -----------------------------------------------------------------------------
+static int round4(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_off, uint32_t* d_out, hipStream_t st) {
+  int rc = round_enter(s, 4, d_in, d_out, true, true);
+  if (rc != MPE_OK) return rc;
+  mpe_ctx* ctx = s->ctx; const mpe_gg20_keys* K = s->K; const Dim& d = s->d; const Counts c = counts_of(d); const mpe_gg20_nonces& Z = s->Z;
+  const int S = d.S, P1 = S - 1;
+  const Slab in3 = slab_of(s, d_in, h_off, 3);
+  (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)msg_words(S, d.n, 4) * 4, st);
+  GG_LAUNCH(r4_kernel, c.nPI, d, in3, s->dinv, s->com_all, s->bpk_in, s->kq, s->R, s->Rbar, s->status, s->bad);
+  Bump t(s->tmp);
+  mpe_pdl_proof pp{t.w(c.nPP * 64), t.w(c.nPP * 16), t.w(c.nPP * 128), t.w(c.nPP * 64), t.w(c.nPP * 25), t.w(c.nPP * 64), t.w(c.nPP * 89)};
+  mpe_pdl_nonces pn{Z.pdl_alpha, Z.pdl_beta, Z.pdl_rho, Z.pdl_gamma};
+  if (rc == MPE_OK)                                                                                            // phase5_proof_pdl
+    rc = pdl_prove(ctx, K->prv, K->stm, (int)c.nPP, s->ix.kown_pp, s->ix.st_pp, rows(s->c_a, 128, s->ix.pi_pp), rows(s->Rbar, 16, s->ix.pi_pp),
+                   rows(s->R, 16, s->ix.pi_pp), rows(s->kq, 8, s->ix.pi_pp), rows(Z.r_a, 64, s->ix.pi_pp), &pn, &pp, st);
+  gg_trace(st, "pdl_prove", rc);
+  PACK(c.nPP, P1, S, 0, SUB4, 0, pp.z, 64); PACK(c.nPP, P1, S, 0, SUB4, 64, pp.u1, 16); PACK(c.nPP, P1, S, 0, SUB4, 80, pp.u2, 128);
+  PACK(c.nPP, P1, S, 0, SUB4, 208, pp.u3, 64); PACK(c.nPP, P1, S, 0, SUB4, 272, pp.s1, 25); PACK(c.nPP, P1, S, 0, SUB4, 297, pp.s2, 64);
+  PACK(c.nPP, P1, S, 0, SUB4, 361, pp.s3, 89);
+  PACK(c.nPI, 1, S, P1, SUB4, 0, s->Rbar, 16);
+  return round_exit(s, rc, "gg20 round4");
+}
+
+// ---- Round5::proceed (rounds.rs:525-601) -----------------------------------------------------------------------------
+static int round5(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_off, uint32_t* d_out, hipStream_t st) {
+  int rc = round_enter(s, 5, d_in, d_out, true, true);
+  if (rc != MPE_OK) return rc;
+  mpe_ctx* ctx = s->ctx; const mpe_gg20_keys* K = s->K; const Dim& d = s->d; const Counts c = counts_of(d); const mpe_gg20_nonces& Z = s->Z;
+  const Slab in4 = slab_of(s, d_in, h_off, 4);
+  (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)W5 * 4, st);
+  Bump t(s->tmp);
+  int32_t *sub4_pv = t.i(c.nPV), *rdash_pv = t.i(c.nPV);
+  uint8_t* ok_pv = t.f(c.nPV);
+  Heg heg{t.w(c.nPI * 16), t.w(c.nPI * 16), t.w(c.nPI * 16), t.w(c.nPI * 8), t.w(c.nPI * 8)};
+  GG_LAUNCH(idx5_kernel, c.nPV, d, in4, sub4_pv, rdash_pv);
+  if (rc == MPE_OK) {      // phase5_verify_pdl for every prover (mine included), G = the VERIFIER's R (rounds.rs:546-558)
+    PdlProofRows pr{rows(d_in, SUB4, sub4_pv), rows(d_in + 64, SUB4, sub4_pv), rows(d_in + 80, SUB4, sub4_pv), rows(d_in + 208, SUB4, sub4_pv),
+                    rows(d_in + 272, SUB4, sub4_pv), rows(d_in + 297, SUB4, sub4_pv), rows(d_in + 361, SUB4, sub4_pv)};
+    rc = pdl_verify(ctx, K->pub, K->stm, (int)c.nPV, s->ix.kpub_pv, s->ix.st_pv, rows(s->ca_all, 128, s->ix.ca_pv), rows(d_in, SUB4, rdash_pv),
+                    rows(s->R, 16, s->ix.pi_pv), pr, ok_pv, st);
   }
-  gg_trace(st, "pdl_verify", q.rc);
-  Heg heg{OW(nPI * 16), OW(nPI * 16), OW(nPI * 16), OW(nPI * 8), OW(nPI * 8)};
-  GG_LAUNCH(r5_kernel, nPI, d, ok_pv, R, Rbar, sigma_i, lq, ped.T, Z->heg_s1 + oPI * 8, Z->heg_s2 + oPI * 8, heg, ok_r5);
-  if (nPI * g6 <= lanes_fit) GG_LAUNCH(r6_group_kernel, nPI * g6, d, g6, R, ped.T, heg, K->y, ok_r6);
-  else GG_LAUNCH(r6_kernel, nPI, d, R, ped.T, heg, K->y, ok_r6);
-  Flags fl{ok_vi, ok_rv, ok_r3, ok_r4, ok_r5, ok_r6};
-  GG_LAUNCH(r7_kernel, B, d, fl, Z->msg + (size_t)b0 * 8, R, kq, sigma_i, K->y, d_r + (size_t)b0 * 8, d_s + (size_t)b0 * 8,
-            d_recid + b0, d_R ? d_R + (size_t)b0 * 16 : nullptr, d_status + b0);
-  if (top_off + ctx->ws_off > ctx->ws_bytes && q.rc == MPE_OK) {
-    q.rc = MPE_E_NOMEM;
-    mpe_set_error_msg("gg20: workspace regions overlap (internal sizing error)");
+  gg_trace(st, "pdl_verify", rc);
+  GG_LAUNCH(r5_kernel, c.nPI, d, in4, ok_pv, s->R, s->sigma_i, s->lq, s->pedT, Z.heg_s1, Z.heg_s2, heg, s->status, s->bad);
+  PACK(c.nPI, 1, 1, 0, W5, 0, heg.S, 16); PACK(c.nPI, 1, 1, 0, W5, 16, heg.T, 16); PACK(c.nPI, 1, 1, 0, W5, 32, heg.A3, 16);
+  PACK(c.nPI, 1, 1, 0, W5, 48, heg.z1, 8); PACK(c.nPI, 1, 1, 0, W5, 56, heg.z2, 8);
+  return round_exit(s, rc, "gg20 round5");
+}
+
+// ---- Round6::proceed (rounds.rs:612-636) -----------------------------------------------------------------------------
+static int round6(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_off, hipStream_t st) {
+  int rc = round_enter(s, 6, d_in, nullptr, true, false);
+  if (rc != MPE_OK) return rc;
+  mpe_ctx* ctx = s->ctx; const Dim& d = s->d; const Counts c = counts_of(d);
+  const Slab in5 = slab_of(s, d_in, h_off, 5);
+  const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 : 0;
+  const int g6 = 3 * d.S <= 8 ? 8 : (3 * d.S <= 16 ? 16 : 32);
+  if (c.nPI * g6 <= lanes_fit) GG_LAUNCH(r6_group_kernel, c.nPI * g6, d, g6, in5, s->R, s->tvec, s->K->y, s->status, s->bad);
+  else GG_LAUNCH(r6_kernel, c.nPI, d, in5, s->R, s->tvec, s->K->y, s->status, s->bad);
+  return round_exit(s, rc, "gg20 round6");
+}
+
+// ---- Round7::new (rounds.rs:672-692) -> PartialSignature ----------------------------------------------------------------
+static int round7(mpe_gg20_session* s, const uint32_t* d_msg, uint32_t* d_out, hipStream_t st) {
+  int rc = round_enter(s, 7, d_msg, d_out, true, true);
+  if (rc != MPE_OK) return rc;
+  const Dim& d = s->d; const Counts c = counts_of(d);
+  GG_LAUNCH(r7_kernel, c.nPI, d, d_msg, s->R, s->kq, s->sigma_i, s->mq, s->rq, s->s_i);
+  PACK(c.nPI, 1, 1, 0, W6, 0, s->s_i, 8);
+  return round_exit(s, rc, "gg20 round7");
+}
+// ---- SignManual::complete (sign.rs:625-646) ---------------------------------------------------------------------------------
+static int complete(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_off, hipStream_t st) {
+  int rc = round_enter(s, 8, d_in, nullptr, true, false);
+  if (rc != MPE_OK) return rc;
+  const Dim& d = s->d; const Counts c = counts_of(d);
+  const Slab in6 = slab_of(s, d_in, h_off, 7);
+  GG_LAUNCH(complete_kernel, c.nPI, d, in6, s->R, s->mq, s->rq, s->s_i, s->K->y, s->status, s->bad, s->sig_r, s->sig_s, s->sig_recid);
+  return round_exit(s, rc, "gg20 complete");
+}
+
+static void session_release(mpe_gg20_session* s, hipStream_t st) {
+  if (!s) return;
+  if (s->mem) {
+    // secrets (k_i, gamma_i, w_i, sigma_i, nonce-derived intermediates) do not outlive the object (range_proofs.rs:26-36 zeroizes)
+    (void)hipMemsetAsync(s->mem, 0, s->mem_bytes, st);
+    if (s->from_cache) s->ctx->sess_in_use = false;
+    else { (void)hipStreamSynchronize(st); (void)hipFree(s->mem); }
   }
-  return q.finish("gg20 sign_chunk");
+  delete s;
 }
 
 }  // namespace gg
@@ -647,64 +946,239 @@ static int sign_chunk(mpe_ctx* ctx, const mpe_gg20_keys* K, int B, int b0, const
 
 extern "C" {
 
-int mpe_gg20_keys_create(mpe_ctx* ctx, int t, int n, int n_signers, const int32_t* h_signers, const uint32_t* d_x,
-                         const uint32_t* d_p, const uint32_t* d_q, const uint32_t* d_Nt, const uint32_t* d_h1,
-                         const uint32_t* d_h2, const uint32_t* d_y, const uint32_t* d_X, mpe_gg20_keys** out, void* stream) {
-  if (!ctx || !h_signers || !d_x || !d_p || !d_q || !d_Nt || !d_h1 || !d_h2 || !d_y || !d_X || !out) return MPE_E_ARG;
-  if (n < 2 || n > 8 || n_signers < 2 || n_signers > n || t < 1 || n_signers != t + 1) return MPE_E_ARG;
+int mpe_gg20_keys_create(mpe_ctx* ctx, int t, int n, int n_signers, const int32_t* h_signers, int nkeysets, int n_own,
+                         const int32_t* h_own, const uint32_t* d_x, const uint32_t* d_p, const uint32_t* d_q, const uint32_t* d_N,
+                         const uint32_t* d_Nt, const uint32_t* d_h1, const uint32_t* d_h2, const uint32_t* d_y, const uint32_t* d_X,
+                         mpe_gg20_keys** out, void* stream) {
+  if (!ctx || !h_signers || !h_own || !d_x || !d_p || !d_q || !d_N || !d_Nt || !d_h1 || !d_h2 || !d_y || !d_X || !out) return MPE_E_ARG;
+  if (n < 2 || n > 8 || n_signers < 2 || n_signers > n || t < 1 || n_signers <= t || nkeysets < 1 || n_own < 1 || n_own > n) return MPE_E_ARG;
   for (int i = 0; i < n_signers; ++i)
     if (h_signers[i] < 0 || h_signers[i] >= n || (i && h_signers[i] <= h_signers[i - 1])) return MPE_E_ARG;
+  for (int i = 0; i < n_own; ++i)
+    if (h_own[i] < 0 || h_own[i] >= n || (i && h_own[i] <= h_own[i - 1])) return MPE_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   mpe_gg20_keys* K = new (std::nothrow) mpe_gg20_keys();
   if (!K) return MPE_E_NOMEM;
-  K->t = t; K->n = n; K->S = n_signers;
+  K->t = t; K->n = n; K->S = n_signers; K->K = nkeysets; K->n_own = n_own;
+  for (int a = 0; a < 8; ++a) K->own_slot[a] = -1;
   for (int i = 0; i < n_signers; ++i) K->signers[i] = h_signers[i];
-  const size_t words = (size_t)n * 8 + (size_t)n * 16 + 16 + 8;
+  for (int i = 0; i < n_own; ++i) { K->own[i] = h_own[i]; K->own_slot[h_own[i]] = i; }
+  const size_t kk = (size_t)nkeysets;
+  const size_t words = kk * n_own * 8 + kk * n * 16 + kk * 16 + kk * n_signers * 16;
   hipError_t e = hipMalloc(&K->blob, words * 4);
   if (e != hipSuccess) { delete K; mpe_set_error("hipMalloc(gg20 keys)", e); return MPE_E_NOMEM; }
-  K->x = (uint32_t*)K->blob; K->X = K->x + (size_t)n * 8; K->y = K->X + (size_t)n * 16; K->d_signers = (int32_t*)(K->y + 16);
-  (void)hipMemcpyAsync(K->x, d_x, (size_t)n * 8 * 4, hipMemcpyDeviceToDevice, st);
-  (void)hipMemcpyAsync(K->X, d_X, (size_t)n * 16 * 4, hipMemcpyDeviceToDevice, st);
-  (void)hipMemcpyAsync(K->y, d_y, 16 * 4, hipMemcpyDeviceToDevice, st);
-  (void)hipMemcpyAsync(K->d_signers, K->signers, (size_t)n_signers * 4, hipMemcpyHostToDevice, st);
-  int rc = mpe_paillier_create_private(ctx, n, d_p, d_q, &K->pk, stream);
-  if (rc == MPE_OK) rc = mpe_statements_create(ctx, n, d_Nt, d_h1, d_h2, &K->stm, stream);
+  K->blob_bytes = words * 4;
+  K->x = (uint32_t*)K->blob; K->X = K->x + kk * n_own * 8; K->y = K->X + kk * n * 16; K->gw = K->y + kk * 16;
+  (void)hipMemcpyAsync(K->x, d_x, kk * n_own * 8 * 4, hipMemcpyDeviceToDevice, st);
+  (void)hipMemcpyAsync(K->X, d_X, kk * n * 16 * 4, hipMemcpyDeviceToDevice, st);
+  (void)hipMemcpyAsync(K->y, d_y, kk * 16 * 4, hipMemcpyDeviceToDevice, st);
+  {
+    mpe::gg::Dim d{};
+    d.S = n_signers; d.n = n; d.K = nkeysets;
+    for (int i = 0; i < n_signers; ++i) d.sg[i] = h_signers[i];
+    hipLaunchKernelGGL(mpe::gg::gw_kernel, dim3(mpe::blocks_for(nkeysets * n_signers, 64)), dim3(64), 0, st, d, K->X, K->gw);
+  }
+  int rc = mpe_paillier_create_public(ctx, nkeysets * n, d_N, &K->pub, stream);
+  if (rc == MPE_OK) rc = mpe_paillier_create_private(ctx, nkeysets * n_own, d_p, d_q, &K->prv, stream);
+  if (rc == MPE_OK) {
+    // window width of the fixed-base tables of h1, h2: the widest whose tables (2 K n bases) stay within the budget —
+    // 13 bits (0.5 GB per base) for a handful of key sets, narrower when a batch carries many wallets
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    size_t budget = free_b / 4;
+    if (getenv("MPE_FB_BUDGET_MB")) budget = (size_t)atoll(getenv("MPE_FB_BUDGET_MB")) << 20;
+    int wb = ctx->fb_window_bits;
+    while (wb > 4 && mpe_statements_table_bytes(nkeysets * n, wb) > budget) --wb;
+    rc = mpe_statements_create_wb(ctx, nkeysets * n, d_Nt, d_h1, d_h2, wb, &K->stm, stream);
+  }
   if (rc != MPE_OK) { mpe_gg20_keys_destroy(K); return rc; }
-  (void)hipStreamSynchronize(st);     // K->signers (host) was the source of an async copy
   *out = K;
   return MPE_OK;
 }
 
 int mpe_gg20_keys_destroy(mpe_gg20_keys* K) {
   if (!K) return MPE_E_ARG;
-  if (K->pk) mpe_paillier_destroy(K->pk);
+  if (K->pub) mpe_paillier_destroy(K->pub);
+  if (K->prv) mpe_paillier_destroy(K->prv);
   if (K->stm) mpe_statements_destroy(K->stm);
-  if (K->blob) (void)hipFree(K->blob);
+  if (K->blob) { (void)hipMemset(K->blob, 0, K->blob_bytes); (void)hipFree(K->blob); }      // the key shares
   delete K;
   return MPE_OK;
 }
+int mpe_gg20_keys_fb_window_bits(const mpe_gg20_keys* K) { return (K && K->stm) ? K->stm->fb_wb : MPE_E_ARG; }
 
-int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const mpe_gg20_nonces* nonces, uint32_t* d_r,
-                  uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, int dedup_verify, int chunk,
-                  void* stream) {
+int mpe_gg20_msg_words(int n_signers, int n, int round) { return mpe::gg::msg_words(n_signers, n, round); }
+
+int mpe_gg20_session_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, int n_local, const int32_t* h_local,
+                            const int32_t* d_keyset, const mpe_gg20_nonces* nonces, int dedup_verify, mpe_gg20_session** out, void* stream) {
+  if (!ctx || !keys || !nonces || !out || batch <= 0 || n_local < 1 || n_local > keys->S || !h_local) return MPE_E_ARG;
+  for (int i = 0; i < n_local; ++i) {
+    if (h_local[i] < 0 || h_local[i] >= keys->S || (i && h_local[i] <= h_local[i - 1])) return MPE_E_ARG;
+    if (keys->own_slot[keys->signers[h_local[i]]] < 0) { mpe_set_error_msg("gg20: a local party's secrets are not in the key object"); return MPE_E_ARG; }
+  }
+  if (keys->K > 1 && !d_keyset) return MPE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  mpe_gg20_session* s = new (std::nothrow) mpe_gg20_session();
+  if (!s) return MPE_E_NOMEM;
+  s->ctx = ctx; s->K = keys; s->B = batch; s->L = n_local; s->dedup = dedup_verify ? 1 : 0; s->Z = *nonces;
+  mpe::gg::Dim& d = s->d;
+  d.B = batch; d.S = keys->S; d.n = keys->n; d.L = n_local; d.V = dedup_verify ? 1 : 2; d.PV = dedup_verify ? 1 : n_local; d.K = keys->K;
+  d.n_own = keys->n_own; d.ks = d_keyset;
+  for (int i = 0; i < 8; ++i) { d.loc[i] = i < n_local ? h_local[i] : 0; d.sg[i] = keys->signers[i]; d.oslot[i] = keys->own_slot[i] < 0 ? 0 : keys->own_slot[i]; }
+  const size_t bytes = mpe::gg::layout(s, nullptr);
+  if (!ctx->sess_in_use) {
+    if (bytes > ctx->sess_bytes) {
+      if (ctx->sess_buf) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->sess_buf); ctx->sess_buf = nullptr; ctx->sess_bytes = 0; }
+      const hipError_t e = hipMalloc(&ctx->sess_buf, bytes);
+      if (e != hipSuccess) { delete s; mpe_set_error("hipMalloc(gg20 session)", e); return MPE_E_NOMEM; }
+      ctx->sess_bytes = bytes;
+    }
+    s->mem = ctx->sess_buf; s->from_cache = true; ctx->sess_in_use = true;
+  } else {
+    const hipError_t e = hipMalloc(&s->mem, bytes);
+    if (e != hipSuccess) { delete s; mpe_set_error("hipMalloc(gg20 session)", e); return MPE_E_NOMEM; }
+  }
+  s->mem_bytes = bytes;
+  (void)mpe::gg::layout(s, (char*)s->mem);
+  const mpe::gg::Counts c = mpe::gg::counts_of(d);
+  (void)hipMemsetAsync(s->status, 0, c.nPI * 4, st);
+  (void)hipMemsetAsync(s->bad, 0, c.nPI * 4, st);
+  size_t total = c.nVI;
+  if (c.nMB > total) total = c.nMB;
+  if (c.nAP > total) total = c.nAP;
+  if (c.nPV > total) total = c.nPV;
+  if (c.nPI > total) total = c.nPI;
+  hipLaunchKernelGGL(mpe::gg::idx_kernel, dim3(mpe::blocks_for((int)total, 64)), dim3(64), 0, st, d, s->ix, (int)total);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mpe_set_error("gg20 idx_kernel", e); mpe::gg::session_release(s, st); return MPE_E_HIP; }
+  *out = s;
+  return MPE_OK;
+}
+int mpe_gg20_session_destroy(mpe_gg20_session* s, void* stream) {
+  if (!s) return MPE_E_ARG;
+  mpe::gg::session_release(s, (hipStream_t)stream);
+  return MPE_OK;
+}
+
+int mpe_gg20_round0(mpe_gg20_session* s, uint32_t* d_out, void* stream) { return s ? mpe::gg::round0(s, d_out, (hipStream_t)stream) : MPE_E_ARG; }
+int mpe_gg20_round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream) {
+  return s ? mpe::gg::round1(s, d_in, h_in_off, d_out, (hipStream_t)stream) : MPE_E_ARG;
+}
+int mpe_gg20_round2(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream) {
+  return s ? mpe::gg::round2(s, d_in, h_in_off, d_out, (hipStream_t)stream) : MPE_E_ARG;
+}
+int mpe_gg20_round3(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream) {
+  return s ? mpe::gg::round3(s, d_in, h_in_off, d_out, (hipStream_t)stream) : MPE_E_ARG;
+}
+int mpe_gg20_round4(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream) {
+  return s ? mpe::gg::round4(s, d_in, h_in_off, d_out, (hipStream_t)stream) : MPE_E_ARG;
+}
+int mpe_gg20_round5(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream) {
+  return s ? mpe::gg::round5(s, d_in, h_in_off, d_out, (hipStream_t)stream) : MPE_E_ARG;
+}
+int mpe_gg20_round6(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_in_off, void* stream) {
+  return s ? mpe::gg::round6(s, d_in, h_in_off, (hipStream_t)stream) : MPE_E_ARG;
+}
+int mpe_gg20_round7(mpe_gg20_session* s, const uint32_t* d_msg, uint32_t* d_out, void* stream) {
+  return s ? mpe::gg::round7(s, d_msg, d_out, (hipStream_t)stream) : MPE_E_ARG;
+}
+int mpe_gg20_complete(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_in_off, void* stream) {
+  return s ? mpe::gg::complete(s, d_in, h_in_off, (hipStream_t)stream) : MPE_E_ARG;
+}
+int mpe_gg20_session_result(const mpe_gg20_session* s, int32_t* d_status, uint32_t* d_bad_actors, uint32_t* d_r, uint32_t* d_s,
+                            int32_t* d_recid, uint32_t* d_R, void* stream) {
+  if (!s) return MPE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const mpe::gg::Counts c = mpe::gg::counts_of(s->d);
+  hipLaunchKernelGGL(mpe::gg::result_kernel, dim3(mpe::blocks_for((int)c.nPI, 64)), dim3(64), 0, st, s->d, s->status, s->bad, s->R, d_status,
+                     d_bad_actors, d_R);
+  if (s->next_round > 8) {
+    if (d_r) (void)hipMemcpyAsync(d_r, s->sig_r, c.nPI * 32, hipMemcpyDeviceToDevice, st);
+    if (d_s) (void)hipMemcpyAsync(d_s, s->sig_s, c.nPI * 32, hipMemcpyDeviceToDevice, st);
+    if (d_recid) (void)hipMemcpyAsync(d_recid, s->sig_recid, c.nPI * 4, hipMemcpyDeviceToDevice, st);
+  } else if (d_r || d_s || d_recid) {
+    mpe_set_error_msg("gg20: the signature exists after mpe_gg20_complete");
+    return MPE_E_ARG;
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mpe_set_error("gg20 result", e); return MPE_E_HIP; }
+  return MPE_OK;
+}
+
+int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int32_t* d_keyset, const mpe_gg20_nonces* nonces, uint32_t* d_r,
+                  uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, int dedup_verify, int chunk, void* stream) {
   if (!ctx || !keys || !nonces || !d_r || !d_s || !d_recid || !d_status || batch < 0) return MPE_E_ARG;
+  const int S = keys->S, n = keys->n;
+  for (int i = 0; i < S; ++i) if (keys->own_slot[keys->signers[i]] < 0) { mpe_set_error_msg("mpe_gg20_sign needs every signer's secrets"); return MPE_E_ARG; }
+  hipStream_t st = (hipStream_t)stream;
   if (chunk <= 0) {
-    // 65 536 sessions per pass (~13 GB of workspace at t=1, n=3; the EC kernels want >= 2 waves per SIMD), fewer
-    // when the shape is wide: the workspace per session grows like S (S-1) n, keep a pass under ~64 GB
-    const size_t S = keys->S, n = keys->n, P = S * (S - 1), V = dedup_verify ? 1 : 2, PV = dedup_verify ? 1 : S;
+    // 65 536 sessions per pass (the EC kernels want >= 2 waves per SIMD), fewer when the shape is wide: state, message
+    // slabs and composite workspace per session grow like S (S-1) n; keep a pass under ~64 GB
+    const size_t P = (size_t)S * (S - 1), V = dedup_verify ? 1 : 2, PV = dedup_verify ? 1 : S;
     const size_t nVI = P * V * n, nPV = PV * P;
-    const size_t words = S * 700 + S * n * 260 + nVI * 8 + P * 2 * 720 + P * 470 + nPV * 8 +
-                         (nVI > nPV ? nVI : nPV) * 2300 + S * n * 2100 + P * 2 * 300;          // per session, as sign_chunk sizes it
+    int mw = 0;
+    for (int r = 0; r < 8; ++r) { const int w = mpe::gg::msg_words(S, n, r); if (w > mw) mw = w; }
+    const size_t words = (size_t)S * 1200 + (size_t)S * n * 260 + nVI * 8 + P * 2 * 300 + P * 470 + nPV * 8 +      // state + round scratch
+                         (nVI > nPV ? nVI : nPV) * 2300 + (size_t)S * n * 2100 +                                     // composite workspace
+                         2 * (size_t)S * mw;                                                                         // two message slabs
     size_t fit = ((size_t)64 << 30) / (words * 4);
     fit = fit >= 1024 ? (fit / 1024) * 1024 : (fit ? fit : 1);
     chunk = (int)(fit < 65536 ? fit : 65536);
   }
+  int32_t local[8];
+  for (int i = 0; i < S; ++i) local[i] = i;
+  int maxw = 0;
+  for (int r = 0; r < 8; ++r) { const int w = mpe::gg::msg_words(S, n, r); if (w > maxw) maxw = w; }
+  const int Bc = batch < chunk ? batch : chunk;
+  // two message slabs (ping-pong) + the per-party results of a pass
+  const size_t slab_words = (size_t)S * Bc * maxw;
+  const size_t res_words = (size_t)S * Bc * (1 + 8 + 8 + 1 + 16);
+  const size_t need = (2 * slab_words + res_words) * 4 + 4096;
+  if (need > ctx->slab_bytes) {
+    if (ctx->slab_buf) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->slab_buf); ctx->slab_buf = nullptr; ctx->slab_bytes = 0; }
+    const hipError_t e = hipMalloc(&ctx->slab_buf, need);
+    if (e != hipSuccess) { mpe_set_error("hipMalloc(gg20 message slabs)", e); return MPE_E_NOMEM; }
+    ctx->slab_bytes = need;
+  }
+  uint32_t* A = (uint32_t*)ctx->slab_buf;
+  uint32_t* Bs = A + slab_words;
+  int32_t* pst = (int32_t*)(Bs + slab_words);
+  uint32_t* pr = (uint32_t*)(pst + (size_t)S * Bc);
+  uint32_t* ps = pr + (size_t)S * Bc * 8;
+  int32_t* prec = (int32_t*)(ps + (size_t)S * Bc * 8);
+  uint32_t* pR = (uint32_t*)(prec + (size_t)S * Bc);
   for (int b0 = 0; b0 < batch; b0 += chunk) {
     const int B = batch - b0 < chunk ? batch - b0 : chunk;
-    int rc = mpe::gg::sign_chunk(ctx, keys, B, b0, nonces, d_r, d_s, d_recid, d_R, d_status, dedup_verify, (hipStream_t)stream);
+    const size_t oPI = (size_t)b0 * S, oAP = oPI * n, oPP = oPI * (S - 1), oMB = oPP * 2;
+    mpe_gg20_nonces Z = *nonces;
+    Z.k += oPI * 8; Z.gamma += oPI * 8; Z.blind += oPI * 8; Z.r_a += oPI * 64;
+    Z.al_alpha += oAP * 24; Z.al_beta += oAP * 64; Z.al_gamma += oAP * 88; Z.al_rho += oAP * 72;
+    Z.mb_beta_tag += oMB * 64; Z.mb_r += oMB * 64; Z.mb_nonce_b += oMB * 8; Z.mb_nonce_bt += oMB * 8;
+    Z.l += oPI * 8; Z.ped_s1 += oPI * 8; Z.ped_s2 += oPI * 8;
+    Z.pdl_alpha += oPP * 24; Z.pdl_beta += oPP * 64; Z.pdl_rho += oPP * 72; Z.pdl_gamma += oPP * 88;
+    Z.heg_s1 += oPI * 8; Z.heg_s2 += oPI * 8; Z.msg += (size_t)b0 * 8;
+    mpe_gg20_session* s = nullptr;
+    int rc = mpe_gg20_session_create(ctx, keys, B, S, local, d_keyset ? d_keyset + b0 : nullptr, &Z, dedup_verify, &s, stream);
+    if (rc != MPE_OK) return rc;
+    rc = mpe::gg::round0(s, A, st);
+    if (rc == MPE_OK) rc = mpe::gg::round1(s, A, nullptr, Bs, st);
+    if (rc == MPE_OK) rc = mpe::gg::round2(s, Bs, nullptr, A, st);
+    if (rc == MPE_OK) rc = mpe::gg::round3(s, A, nullptr, Bs, st);
+    if (rc == MPE_OK) rc = mpe::gg::round4(s, Bs, nullptr, A, st);
+    if (rc == MPE_OK) rc = mpe::gg::round5(s, A, nullptr, Bs, st);
+    if (rc == MPE_OK) rc = mpe::gg::round6(s, Bs, nullptr, st);
+    if (rc == MPE_OK) rc = mpe::gg::round7(s, Z.msg, A, st);
+    if (rc == MPE_OK) rc = mpe::gg::complete(s, A, nullptr, st);
+    if (rc == MPE_OK) rc = mpe_gg20_session_result(s, pst, nullptr, pr, ps, prec, pR, stream);
+    if (rc == MPE_OK)
+      hipLaunchKernelGGL(mpe::gg::sign_finish_kernel, dim3(mpe::blocks_for(B, 64)), dim3(64), 0, st, B, S, b0, pst, pr, ps, prec, pR, d_r, d_s,
+                         d_recid, d_R, d_status);
+    mpe::gg::session_release(s, st);
     if (rc != MPE_OK) return rc;
   }
-  return MPE_OK;
+  // the message slabs and the composite workspace held nonce-derived values of this call
+  (void)hipMemsetAsync(ctx->slab_buf, 0, need, st);
+  return mpe_ctx_wipe(ctx, stream);
 }
 
 }  // extern "C"

@@ -27,6 +27,13 @@ struct mpe_ctx {
   // bump-allocated workspace for the intermediates of composite operations (Paillier, proofs)
   void* ws = nullptr;
   size_t ws_bytes = 0, ws_off = 0;
+  // cached device memory of the GG20 round pipeline: one session object's state (mpe_gg20_session) and the message slabs of
+  // mpe_gg20_sign — kept across calls so that a step does not pay hipMalloc / hipFree
+  void* sess_buf = nullptr;
+  size_t sess_bytes = 0;
+  bool sess_in_use = false;
+  void* slab_buf = nullptr;
+  size_t slab_bytes = 0;
   mpe_launch_info last = {};
   // optional per-launch timing of the heavy kernels (HIP events on the launch stream)
   bool prof_on = false;

@@ -210,11 +210,12 @@ static int launch_pair_modexp(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Ro
 #include "mpe_mta.h"
 #include "mpe_bob.h"
 #include "mpe_gg20.h"
+#include "mpe_sigma.h"
 #include "mpe_lindell.h"
 
 extern "C" {
 
-const char* mpe_version(void) { return "mpecdsa-hip 0.2.0 (gfx950)"; }
+const char* mpe_version(void) { return "mpecdsa-hip 0.3.0 (gfx950)"; }
 const char* mpe_last_error(void) { return g_last_error.c_str(); }
 
 int mpe_ctx_create(mpe_ctx** out, int device) {
@@ -244,8 +245,60 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   return MPE_OK;
 }
 
+// Zeroes every scratch buffer the context owns (window tables, composite workspace): they hold powers of secret bases and
+// nonce-derived intermediates of the last calls (the reference zeroizes its round-1 secrets, range_proofs.rs:26-36,197-212).
+int mpe_ctx_wipe(mpe_ctx* ctx, void* stream) {
+  if (!ctx) return MPE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (ctx->tables) (void)hipMemsetAsync(ctx->tables, 0, ctx->tables_bytes, st);
+  if (ctx->ws) (void)hipMemsetAsync(ctx->ws, 0, ctx->ws_bytes, st);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mpe_set_error("mpe_ctx_wipe", e); return MPE_E_HIP; }
+  return MPE_OK;
+}
+
+// Audit of the wiping: counts the non-zero 32-bit words in every scratch region the context owns (window tables, composite
+// workspace, cached session arena, message slabs).  Synchronises the stream.
+__global__ void count_nonzero_kernel(const uint32_t* __restrict__ p, size_t words, unsigned long long* __restrict__ out) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  unsigned long long c = 0;
+  for (; g < words; g += step) c += p[g] != 0u;
+  if (c) atomicAdd(out, c);
+}
+int mpe_ctx_scratch_audit(mpe_ctx* ctx, uint64_t* nonzero_words, uint64_t* total_bytes, void* stream) {
+  if (!ctx || !nonzero_words) return MPE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* d = nullptr;
+  hipError_t e = hipMalloc((void**)&d, 8);
+  if (e != hipSuccess) { mpe_set_error("hipMalloc(audit)", e); return MPE_E_NOMEM; }
+  (void)hipMemsetAsync(d, 0, 8, st);
+  const void* ptrs[4] = {ctx->tables, ctx->ws, ctx->sess_buf, ctx->slab_buf};
+  const size_t bytes[4] = {ctx->tables_bytes, ctx->ws_bytes, ctx->sess_bytes, ctx->slab_bytes};
+  uint64_t tot = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (!ptrs[i] || !bytes[i]) continue;
+    tot += bytes[i];
+    hipLaunchKernelGGL(count_nonzero_kernel, dim3(4096), dim3(256), 0, st, (const uint32_t*)ptrs[i], bytes[i] / 4, d);
+  }
+  unsigned long long h = 0;
+  e = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d);
+  if (e != hipSuccess) { mpe_set_error("mpe_ctx_scratch_audit", e); return MPE_E_HIP; }
+  *nonzero_words = h;
+  if (total_bytes) *total_bytes = tot;
+  return MPE_OK;
+}
+
 int mpe_ctx_destroy(mpe_ctx* ctx) {
   if (!ctx) return MPE_E_ARG;
+  (void)mpe_ctx_wipe(ctx, nullptr);
+  if (ctx->sess_buf) { (void)hipMemsetAsync(ctx->sess_buf, 0, ctx->sess_bytes, nullptr); }
+  if (ctx->slab_buf) { (void)hipMemsetAsync(ctx->slab_buf, 0, ctx->slab_bytes, nullptr); }
+  (void)hipDeviceSynchronize();
+  if (ctx->sess_buf) (void)hipFree(ctx->sess_buf);
+  if (ctx->slab_buf) (void)hipFree(ctx->slab_buf);
   if (ctx->tables) (void)hipFree(ctx->tables);
   if (ctx->ws) (void)hipFree(ctx->ws);
   for (auto& ev : ctx->prof) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }

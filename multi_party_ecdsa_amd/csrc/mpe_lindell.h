@@ -84,7 +84,7 @@ int mpe_lindell_sign(mpe_ctx* ctx, const mpe_paillier* sk, int batch, const int3
   MPE_TRY(mpe::ws_reserve(ctx, (size_t)batch * (2 * (3 + 64 + 32 + 64 + 64) + 64) * 4 + (1u << 20), st));
   char* top = (char*)ctx->ws + ctx->ws_bytes;
   uint32_t* s_tag = (uint32_t*)(top -= ((size_t)batch * 64 * 4 + 255) & ~(size_t)255);
-  MPE_TRY(mpe::paillier_decrypt(ctx, sk, batch, d_key_idx, d_c3, s_tag, st));               // :538-542
+  MPE_TRY(mpe::paillier_decrypt(ctx, sk, batch, d_key_idx, mpe::rows(d_c3, 128), s_tag, st));               // :538-542
   MPE_LAUNCH_1D(mpe::lindell_p1_finish_kernel, batch, st, batch, s_tag, d_k1, d_R2, d_r, d_s, d_recid);
   return MPE_OK;
 }

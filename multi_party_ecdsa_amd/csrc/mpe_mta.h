@@ -127,7 +127,7 @@ int mpe_mta_verify_get_alpha(mpe_ctx* ctx, const mpe_paillier* sk, int batch, co
   if (!d_key_idx && sk->nkeys != 1 && sk->nkeys < batch) return MPE_E_ARG;
   if (batch == 0) return MPE_OK;
   hipStream_t st = (hipStream_t)stream;
-  MPE_TRY(mpe::paillier_decrypt(ctx, sk, batch, d_key_idx, d_cb, d_alice_share, st));             // :165
+  MPE_TRY(mpe::paillier_decrypt(ctx, sk, batch, d_key_idx, mpe::rows(d_cb, 128), d_alice_share, st));             // :165
   MPE_LAUNCH_1D(mpe::mta_alpha_kernel, batch, st, batch, d_alice_share, d_a, b_proof->pk, b_proof->R, b_proof->z,
                 beta_tag_proof->pk, beta_tag_proof->R, beta_tag_proof->z, d_alpha, d_ok);
   return MPE_OK;

@@ -370,8 +370,10 @@ static int paillier_mul_add_enc(mpe_ctx* ctx, const mpe_paillier* pk, int B, con
   return launch_modmul(ctx, pk->ms_nn, B, ksel, rows(x, 128), rows(gm, 128), d_out, st);
 }
 
-static int paillier_decrypt(mpe_ctx* ctx, const mpe_paillier* pk, int B, const int32_t* key_idx, const uint32_t* d_c,
-                            uint32_t* d_m, hipStream_t st) {
+// c: one 128-word ciphertext row per item (dense, or through c.idx / c.stride: the round pipeline decrypts in place
+// out of a message slab)
+static int paillier_decrypt(mpe_ctx* ctx, const mpe_paillier* pk, int B, const int32_t* key_idx, Rows c, uint32_t* d_m,
+                            hipStream_t st) {
   const int B2 = 2 * B;
   MPE_TRY(ws_reserve(ctx, (size_t)B2 * (3 * 4 + (64 + 32 + 64 + 64) * 4) + 16384, st));
   int32_t* item_of = ws_array<int32_t>(ctx, B2);
@@ -382,13 +384,13 @@ static int paillier_decrypt(mpe_ctx* ctx, const mpe_paillier* pk, int B, const i
   uint32_t* mh = ws_array<uint32_t>(ctx, (size_t)B2 * 64);
   uint32_t* y = ws_array<uint32_t>(ctx, (size_t)B2 * 64);
   MPE_LAUNCH_1D(dec_index_kernel, B2, st, B2, pk->nkeys, key_idx, item_of, half_of, keyj);
-  // u = c^(p-1) mod p^2 | c^(q-1) mod q^2   (c is double-width for the 2048-bit engine)
+  // u = c^(p-1) mod p^2 | c^(q-1) mod q^2   (c is double-width for the 2048-bit engine); half-item j reads row j >> 1
   if (ctx->use_pair) {
-    MPE_TRY(launch_pair_modexp(ctx, pk->ps_pp, B2, Rows{nullptr, half_of, 0, 0}, rows(d_c, 128, item_of, 128),
+    MPE_TRY(launch_pair_modexp(ctx, pk->ps_pp, B2, Rows{nullptr, half_of, 0, 0}, Rows{c.p, c.idx, c.stride, 128, 1},
                                rows(pk->em1, 32, half_of), 32, no_rows(), no_rows(), 0, u, st));
   } else {
-    MPE_TRY(launch_modexp(ctx, pk->ms_pp, B2, Rows{nullptr, half_of, 0, 0}, rows(d_c, 128, item_of, 64),
-                          rows(d_c + 64, 128, item_of, 64), rows(pk->em1, 32, half_of), 32, u, st));
+    MPE_TRY(launch_modexp(ctx, pk->ms_pp, B2, Rows{nullptr, half_of, 0, 0}, Rows{c.p, c.idx, c.stride, 64, 1},
+                          Rows{c.p + 64, c.idx, c.stride, 64, 1}, rows(pk->em1, 32, half_of), 32, u, st));
   }
   MPE_LAUNCH_1D(dec_lfunc_kernel, B2, st, B2, u, half_of, pk->inv2, t);
   // m_p = L_p(u) h_p mod p | m_q
@@ -435,7 +437,7 @@ int mpe_paillier_decrypt(mpe_ctx* ctx, const mpe_paillier* sk, int batch, const 
   if (!sk->has_private) { mpe_set_error_msg("mpe_paillier_decrypt: key set has no private part"); return MPE_E_ARG; }
   if (!d_key_idx && sk->nkeys != 1 && sk->nkeys < batch) return MPE_E_ARG;
   if (batch == 0) return MPE_OK;
-  return mpe::paillier_decrypt(ctx, sk, batch, d_key_idx, d_c, d_m, (hipStream_t)stream);
+  return mpe::paillier_decrypt(ctx, sk, batch, d_key_idx, mpe::rows(d_c, 128), d_m, (hipStream_t)stream);
 }
 int mpe_paillier_add(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const int32_t* d_key_idx, const uint32_t* d_c1,
                      const uint32_t* d_c2, uint32_t* d_out, void* stream) {

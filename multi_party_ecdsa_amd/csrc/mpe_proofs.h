@@ -24,6 +24,14 @@ struct mpe_statements {
 
 #include "mpe_fixedbase.h"
 
+// internal: statement set with an explicit window width of its fixed-base tables (the GG20 key object sizes it by memory)
+extern "C" int mpe_statements_create_wb(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const uint32_t* d_h1, const uint32_t* d_h2,
+                                        int wb, mpe_statements** out, void* stream);
+// bytes of the fixed-base tables of `count` statements at window width wb
+static inline size_t mpe_statements_table_bytes(int count, int wb) {
+  return (size_t)2 * count * mpe::fb_windows(wb) * ((size_t)1 << wb) * mpe::Cfg2048::K * sizeof(uint32_t);
+}
+
 namespace mpe {
 
 static int launch_fb_modexp(mpe_ctx* ctx, const mpe_statements* stm, int B, Rows st_sel, int which, Rows exps, int ew,
@@ -463,7 +471,12 @@ extern "C" {
 
 int mpe_statements_create(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const uint32_t* d_h1, const uint32_t* d_h2,
                           mpe_statements** out, void* stream) {
-  if (!ctx || !d_Nt || !d_h1 || !d_h2 || !out || count <= 0) return MPE_E_ARG;
+  if (!ctx) return MPE_E_ARG;
+  return mpe_statements_create_wb(ctx, count, d_Nt, d_h1, d_h2, ctx->fb_window_bits, out, stream);
+}
+int mpe_statements_create_wb(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const uint32_t* d_h1, const uint32_t* d_h2, int wb,
+                             mpe_statements** out, void* stream) {
+  if (!ctx || !d_Nt || !d_h1 || !d_h2 || !out || count <= 0 || wb < 2 || wb > 16) return MPE_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   mpe_statements* s = new (std::nothrow) mpe_statements();
   if (!s) return MPE_E_NOMEM;
@@ -481,7 +494,7 @@ int mpe_statements_create(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const u
     // fixed-base window tables of h1, h2 (26 MB per base at 8-bit windows), built on the GPU once per statement set:
     // the window bases one after the other (squarings), then every window's multiples in parallel
     using C = mpe::Cfg2048;
-    s->fb_wb = ctx->fb_window_bits;
+    s->fb_wb = wb;
     const int nwindows = mpe::fb_windows(s->fb_wb);
     const size_t bytes = (size_t)2 * count * nwindows * ((size_t)1 << s->fb_wb) * C::K * sizeof(uint32_t);
     e = hipMalloc((void**)&s->fb_tab, bytes);

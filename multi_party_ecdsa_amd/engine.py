@@ -49,6 +49,15 @@ class Context:
         N.check(N.lib.mpe_prof_collect(self.h, arr, max_records, C.byref(n)), "mpe_prof_collect")
         return [dict(kind=r.kind, bits=r.bits, exp_words=r.exp_words, batch=r.batch, ms=r.ms, exp2_words=r.exp2_words) for r in arr[:n.value]]
 
+    def wipe(self):
+        N.check(N.lib.mpe_ctx_wipe(self.h, self.stream()), "mpe_ctx_wipe")
+
+    def scratch_audit(self):
+        """(non-zero 32-bit words, total bytes) over every scratch region the context owns"""
+        nz, tot = C.c_uint64(0), C.c_uint64(0)
+        N.check(N.lib.mpe_ctx_scratch_audit(self.h, C.byref(nz), C.byref(tot), self.stream()), "mpe_ctx_scratch_audit")
+        return nz.value, tot.value
+
     def close(self):
         if self.h:
             N.lib.mpe_ctx_destroy(self.h)
@@ -377,22 +386,46 @@ def pdl_verify(ctx, pk, stm, d_cipher, d_Q, d_G, proof, d_key_idx=None, d_st_idx
 
 
 # ================================================================================================
-# GG20 signing (all parties of a batch of sessions in lock-step on one GPU)
+# GG20 signing: key object, the per-party round view, the lock-step composition
 # ================================================================================================
-class Gg20Keys:
-    """`LocalKey` material of all n parties (keygen/rounds.rs:311-322) + the signer set, resident in HBM.
-    arrays: dict of numpy uint32 arrays x,p,q,Nt,h1,h2,y,X (layouts: include/mpecdsa_hip.h)."""
+GG20_ROUNDS = [0, 1, 2, 3, 4, 5, 7]             # rounds that emit a message
 
-    def __init__(self, ctx, t, n, signers, arrays):
-        self.ctx, self.t, self.n, self.S = ctx, t, n, len(signers)
-        self.d = {f: torch.from_numpy(np.ascontiguousarray(arrays[f]).view(np.int32)).to(ctx.device)
-                  for f in ("x", "p", "q", "Nt", "h1", "h2", "y", "X")}
+
+def gg20_msg_words(S, n, rnd):
+    return N_.lib.mpe_gg20_msg_words(S, n, rnd)
+
+
+class Gg20Keys:
+    """`LocalKey` material (keygen/rounds.rs:311-322) + the signer set, resident in HBM.
+    arrays: dict of numpy uint32 arrays for ALL n parties of every key set: x [K*n,8], p, q [K*n,32], Nt, h1, h2 [K*n,64],
+    y [K,16], X [K*n,16] (and optionally N [K*n,64], else p*q).  own: the party indices whose SECRETS (x, p, q) this
+    object gets (default: all — the Simulation harness); the other parties' rows of x, p, q never leave the host."""
+
+    def __init__(self, ctx, t, n, signers, arrays, own=None, nkeysets=1):
+        self.ctx, self.t, self.n, self.S, self.K = ctx, t, n, len(signers), nkeysets
+        own = list(range(n)) if own is None else sorted(int(a) for a in own)
+        self.own = own
+        a = {f: np.ascontiguousarray(arrays[f]) for f in ("x", "p", "q", "Nt", "h1", "h2", "y", "X")}
+        if "N" in arrays and arrays["N"] is not None:
+            a["N"] = np.ascontiguousarray(arrays["N"])
+        else:
+            ps, qs = words_to_ints(a["p"]), words_to_ints(a["q"])
+            a["N"] = ints_to_words([p_ * q_ for p_, q_ in zip(ps, qs)], 64)
+        rows = [kk * n + o for kk in range(nkeysets) for o in own]
+        h = {f: a[f] for f in ("N", "Nt", "h1", "h2", "y", "X")}
+        for f in ("x", "p", "q"):
+            h[f] = np.ascontiguousarray(a[f][rows])
+        self.d = {f: torch.from_numpy(h[f].view(np.int32)).to(ctx.device) for f in h}
         sg = (C.c_int32 * len(signers))(*[int(s) for s in signers])
-        h = C.c_void_p()
-        N_.check(N_.lib.mpe_gg20_keys_create(ctx.h, t, n, len(signers), sg, *[_ptr(self.d[f]) for f in
-                                             ("x", "p", "q", "Nt", "h1", "h2", "y", "X")], C.byref(h), ctx.stream()),
+        ow = (C.c_int32 * len(own))(*own)
+        hd = C.c_void_p()
+        N_.check(N_.lib.mpe_gg20_keys_create(ctx.h, t, n, len(signers), sg, nkeysets, len(own), ow, *[_ptr(self.d[f]) for f in
+                                             ("x", "p", "q", "N", "Nt", "h1", "h2", "y", "X")], C.byref(hd), ctx.stream()),
                  "mpe_gg20_keys_create")
-        self.h = h
+        self.h = hd
+
+    def fb_window_bits(self):
+        return N_.lib.mpe_gg20_keys_fb_window_bits(self.h)
 
     def close(self):
         if self.h:
@@ -406,17 +439,122 @@ class Gg20Keys:
             pass
 
 
-def gg20_sign(ctx, keys, nonces, B, dedup_verify=False, chunk=0, want_R=False):
-    """nonces: dict of device int32 tensors (fields _native.GG20_NONCE_FIELDS).  Returns device tensors
+class Gg20Session:
+    """`RoundN::proceed` for B sessions x the local parties `local` (signer ordinals).  nonces: dict of device int32
+    tensors with leading dimensions [B][len(local)] (fields _native.GG20_NONCE_FIELDS; `msg` optional)."""
+
+    def __init__(self, ctx, keys, B, local, nonces, keyset=None, dedup_verify=False):
+        self.ctx, self.keys, self.B, self.local = ctx, keys, B, [int(x) for x in local]
+        self.S, self.n, self.L = keys.S, keys.n, len(local)
+        self._nonces = dict(nonces)
+        if "msg" not in self._nonces:
+            self._nonces["msg"] = torch.zeros((B, 8), dtype=torch.int32, device=ctx.device)
+        self._keyset = keyset
+        nn = _struct(N_.Gg20Nonces, self._nonces)
+        lc = (C.c_int32 * self.L)(*self.local)
+        h = C.c_void_p()
+        N_.check(N_.lib.mpe_gg20_session_create(ctx.h, keys.h, B, self.L, lc, _ptr(keyset), C.byref(nn), int(bool(dedup_verify)),
+                                                C.byref(h), ctx.stream()), "mpe_gg20_session_create")
+        self.h = h
+
+    def _off(self, in_off):
+        return None if in_off is None else (C.c_int64 * self.S)(*[int(x) for x in in_off])
+
+    def round(self, rnd, d_in=None, in_off=None, msg=None):
+        """Runs round `rnd` (0..7, 8 = SignManual::complete).  d_in: the previous round's records of all S senders (device
+        int32 tensor; sender j's [B][W] block at record in_off[j], default j*B).  Returns this object's outgoing records
+        [L, B, W] (None for rounds 6 and 8)."""
+        lib, st = N_.lib, self.ctx.stream()
+        W = gg20_msg_words(self.S, self.n, rnd) if rnd in GG20_ROUNDS else 0
+        out = torch.empty((self.L, self.B, W), dtype=torch.int32, device=self.ctx.device) if W else None
+        if rnd == 0:
+            N_.check(lib.mpe_gg20_round0(self.h, _ptr(out), st), "mpe_gg20_round0")
+        elif 1 <= rnd <= 5:
+            N_.check(getattr(lib, f"mpe_gg20_round{rnd}")(self.h, _ptr(d_in), self._off(in_off), _ptr(out), st), f"mpe_gg20_round{rnd}")
+        elif rnd == 6:
+            N_.check(lib.mpe_gg20_round6(self.h, _ptr(d_in), self._off(in_off), st), "mpe_gg20_round6")
+        elif rnd == 7:
+            N_.check(lib.mpe_gg20_round7(self.h, _ptr(msg), _ptr(out), st), "mpe_gg20_round7")
+        elif rnd == 8:
+            N_.check(lib.mpe_gg20_complete(self.h, _ptr(d_in), self._off(in_off), st), "mpe_gg20_complete")
+        else:
+            raise ValueError(rnd)
+        return out
+
+    def result(self, signature=True):
+        """dict of device tensors: status, bad_actors, recid [L,B]; r, s [L,B,8]; R [L,B,16]"""
+        L, B, dv = self.L, self.B, self.ctx.device
+        o = dict(status=torch.empty((L, B), dtype=torch.int32, device=dv), bad_actors=torch.empty((L, B), dtype=torch.int32, device=dv),
+                 R=torch.empty((L, B, 16), dtype=torch.int32, device=dv))
+        if signature:
+            o.update(r=torch.empty((L, B, 8), dtype=torch.int32, device=dv), s=torch.empty((L, B, 8), dtype=torch.int32, device=dv),
+                     recid=torch.empty((L, B), dtype=torch.int32, device=dv))
+        N_.check(N_.lib.mpe_gg20_session_result(self.h, _ptr(o["status"]), _ptr(o["bad_actors"]), _ptr(o.get("r")), _ptr(o.get("s")),
+                                                _ptr(o.get("recid")), _ptr(o["R"]), self.ctx.stream()), "mpe_gg20_session_result")
+        return o
+
+    def close(self):
+        if self.h:
+            N_.lib.mpe_gg20_session_destroy(self.h, self.ctx.stream())
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gg20_sign(ctx, keys, nonces, B, dedup_verify=False, chunk=0, want_R=False, keyset=None):
+    """nonces: dict of device int32 tensors (fields _native.GG20_NONCE_FIELDS, [B][S] layout).  Returns device tensors
     r [B,8], s [B,8], recid [B], status [B] (0 = signed and verified) and optionally R [B,16]."""
     r, s = _new(ctx, B, 8), _new(ctx, B, 8)
     recid = torch.empty((B,), dtype=torch.int32, device=ctx.device)
     status = torch.full((B,), -1, dtype=torch.int32, device=ctx.device)
     R = _new(ctx, B, 16) if want_R else None
     nn = _struct(N_.Gg20Nonces, nonces)
-    N_.check(N_.lib.mpe_gg20_sign(ctx.h, keys.h, B, C.byref(nn), _ptr(r), _ptr(s), _ptr(recid), _ptr(R), _ptr(status),
+    N_.check(N_.lib.mpe_gg20_sign(ctx.h, keys.h, B, _ptr(keyset), C.byref(nn), _ptr(r), _ptr(s), _ptr(recid), _ptr(R), _ptr(status),
                                   int(bool(dedup_verify)), int(chunk), ctx.stream()), "mpe_gg20_sign")
     return (r, s, recid, status, R) if want_R else (r, s, recid, status)
+
+
+# ---- curv sigma proofs of phases 3 / 6, the phase-1 commitment (device-tensor API) ----
+def pedersen_prove(ctx, d_m, d_r, d_s1, d_s2):
+    B = d_m.shape[0]
+    out = dict(com=_new(ctx, B, 16), e=_new(ctx, B, 8), a1=_new(ctx, B, 16), a2=_new(ctx, B, 16), z1=_new(ctx, B, 8), z2=_new(ctx, B, 8))
+    pr = _struct(N_.PedersenProof, out)
+    N_.check(N_.lib.mpe_pedersen_prove(ctx.h, B, _ptr(d_m), _ptr(d_r), _ptr(d_s1), _ptr(d_s2), C.byref(pr), ctx.stream()), "mpe_pedersen_prove")
+    return out
+
+
+def pedersen_verify(ctx, proof):
+    B = proof["com"].shape[0]
+    ok = _flags(ctx, B)
+    pr = _struct(N_.PedersenProof, proof)
+    N_.check(N_.lib.mpe_pedersen_verify(ctx.h, B, C.byref(pr), _ptr(ok), ctx.stream()), "mpe_pedersen_verify")
+    return ok
+
+
+def heg_prove(ctx, d_x, d_r, d_s1, d_s2, statement):
+    B = d_x.shape[0]
+    out = dict(T=_new(ctx, B, 16), A3=_new(ctx, B, 16), z1=_new(ctx, B, 8), z2=_new(ctx, B, 8))
+    stt, pr = _struct(N_.HegStatement, statement), _struct(N_.HegProof, out)
+    N_.check(N_.lib.mpe_heg_prove(ctx.h, B, _ptr(d_x), _ptr(d_r), _ptr(d_s1), _ptr(d_s2), C.byref(stt), C.byref(pr), ctx.stream()), "mpe_heg_prove")
+    return out
+
+
+def heg_verify(ctx, statement, proof):
+    B = proof["T"].shape[0]
+    ok = _flags(ctx, B)
+    stt, pr = _struct(N_.HegStatement, statement), _struct(N_.HegProof, proof)
+    N_.check(N_.lib.mpe_heg_verify(ctx.h, B, C.byref(stt), C.byref(pr), _ptr(ok), ctx.stream()), "mpe_heg_verify")
+    return ok
+
+
+def hash_commit_point(ctx, d_P, d_blind):
+    out = _new(ctx, d_P.shape[0], 8)
+    N_.check(N_.lib.mpe_hash_commit_point(ctx.h, d_P.shape[0], _ptr(d_P), _ptr(d_blind), _ptr(out), ctx.stream()), "mpe_hash_commit_point")
+    return out
 
 
 BOB_PROOF_WORDS = dict(t=64, z=64, e=8, s=64, s1=25, s2=89, t1=81, t2=89)

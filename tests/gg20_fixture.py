@@ -158,3 +158,91 @@ def py_session(lk, nonces, b):
     S, n = lk["S"], lk["n"]
     packed = {rnd: [PG.pack(rnd, m, S, n) for m in msgs[q]] for q, rnd in enumerate(ROUNDS)}
     return packed, sigs, [(p.status, p.bad) for p in parties]
+
+
+class OracleParty:
+    """One party (signer ordinal `ord`) over B sessions on the CPU oracle: `RoundN::proceed` as functions of (state, messages).
+    The key struct it receives holds ONLY this party's secrets (the other parties' x, p, q rows are zero)."""
+
+    def __init__(self, lk, ord_, B, nonces_party, keyset=None):
+        import orc
+        self.orc, self.lk, self.ord, self.B = orc, lk, ord_, B
+        self.S, self.n = lk["S"], lk["n"]
+        me = int(lk["arrays"]["signers"][ord_])
+        arr = dict(lk["arrays"])
+        K = lk.get("nkeysets", 1)
+        if "N" not in arr:
+            arr["N"] = F.words([p_ * q_ for p_, q_ in zip(F.ints(arr["p"]), F.ints(arr["q"]))], 64)
+        for f in ("x", "p", "q"):                      # nobody else's secrets
+            a = arr[f].copy()
+            mask = np.ones(a.shape[0], dtype=bool)
+            mask[[kk * self.n + me for kk in range(K)]] = False
+            a[mask] = 0
+            arr[f] = a
+        self._lk = dict(lk, arrays=arr)
+        self._nonces = {f: np.ascontiguousarray(v) for f, v in nonces_party.items()}
+        self._keyset = None if keyset is None else np.ascontiguousarray(keyset, dtype=np.int32)
+        self._ks, self._ns = keys_struct(self._lk), nonces_struct(self._nonces)
+        orc.lib.orc_gg20_party_new.restype = C.c_void_p
+        self.h = C.c_void_p(orc.lib.orc_gg20_party_new(C.byref(self._ks), ord_, B, C.byref(self._ns), 1, 0, orc._p(self._keyset)))
+        assert self.h
+
+    def round(self, rnd, d_in=None, in_off=None):
+        """d_in: numpy uint32 slab of the previous round (all senders); returns this party's [B][W] block or None"""
+        W = msg_words(self.S, self.n, rnd) if rnd in ROUNDS else 0
+        out = np.zeros((self.B, W), dtype=np.uint32) if W else None
+        off = None if in_off is None else (C.c_int64 * self.S)(*[int(x) for x in in_off])
+        self.orc.lib.orc_gg20_party_round(self.h, rnd, self.orc._p(d_in), off, self.orc._p(out), 0, self.B)
+        return out
+
+    def corrupt(self, step):
+        self.orc.lib.orc_gg20_party_corrupt(self.h, step)
+
+    def result(self):
+        B = self.B
+        o = dict(status=np.zeros(B, dtype=np.int32), bad_actors=np.zeros(B, dtype=np.uint32), r=np.zeros((B, 8), dtype=np.uint32),
+                 s=np.zeros((B, 8), dtype=np.uint32), recid=np.zeros(B, dtype=np.int32), R=np.zeros((B, 16), dtype=np.uint32))
+        self.orc.lib.orc_gg20_party_result(self.h, *[self.orc._p(o[f]) for f in ("status", "bad_actors", "r", "s", "recid", "R")])
+        return o
+
+    def close(self):
+        if self.h:
+            self.orc.lib.orc_gg20_party_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def party_nonces(nonces, lk, i):
+    """the [B][1] slice of the [B][S] nonce arrays that belongs to signer ordinal i (msg stays whole)"""
+    S, n = lk["S"], lk["n"]
+    per = dict(k=1, gamma=1, blind=1, r_a=1, l=1, ped_s1=1, ped_s2=1, heg_s1=1, heg_s2=1, al_alpha=n, al_beta=n, al_gamma=n, al_rho=n,
+               mb_beta_tag=2 * (S - 1), mb_r=2 * (S - 1), mb_nonce_b=2 * (S - 1), mb_nonce_bt=2 * (S - 1), pdl_alpha=S - 1, pdl_beta=S - 1,
+               pdl_rho=S - 1, pdl_gamma=S - 1)
+    out = {}
+    for f, v in nonces.items():
+        if f == "msg":
+            out[f] = v
+            continue
+        B = v.shape[0] // (S * per[f])
+        out[f] = np.ascontiguousarray(v.reshape(B, S, per[f], v.shape[1])[:, i].reshape(B * per[f], v.shape[1]))
+    return out
+
+
+def run_rounds(parties, msg, tamper=None):
+    """Drives any set of per-party engines (OracleParty or GPU adapters exposing .round(rnd, slab) -> [B][W] numpy and
+    .result()) through the protocol with an in-memory relay.  tamper(rnd, slab[S,B,W]) may modify a round's messages in place.
+    Returns the slabs {round: [S,B,W]}."""
+    S = len(parties)
+    slabs = {}
+    prev = None
+    for rnd in [0, 1, 2, 3, 4, 5, 6, 7, 8]:
+        outs = [p.round(rnd, prev) if rnd != 7 else p.round(7, msg) for p in parties]
+        if rnd in ROUNDS:
+            slab = np.ascontiguousarray(np.stack(outs))
+            if tamper:
+                tamper(rnd, slab)
+            slabs[rnd] = slab
+            prev = slab
+    return slabs

@@ -1,7 +1,10 @@
-"""CPU test of the N>1 path with the gloo backend, world_size 2: session sharding covers the job exactly once,
-and the whole-job timing/throughput reduction (max over ranks, counts gathered) behaves as bench.py assumes.
-The per-rank "work" here is the CPU oracle on each rank's shard: the union of the shards' outputs must equal the
-single-process result (no data-path collective is needed or used)."""
+"""CPU tests of the N>1 paths with the gloo backend (multi_party_ecdsa_amd/dist.py is engine-agnostic; here the per-party
+round engine is the CPU oracle, on the GPU it is mpe_gg20_roundN — same calling convention):
+ * Mode A (session sharding, world 2): the shards cover the job exactly once, the job time is the max over ranks;
+ * Mode B (party sharding, worlds 2 and 3): every rank holds ONLY its party's secrets, each round's messages travel through
+   one all-gather and are filtered by the receiver like the reference's relay (examples/gg20_sm_client.rs:35-40); every
+   rank's signatures equal the single-process oracle's; the balanced "rotated" placement (party p of block s on rank
+   (s + p) % world) is checked too."""
 import os
 import sys
 
@@ -13,16 +16,25 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, total, q):
+def _load_dist():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mpe_dist", os.path.join(ROOT, "multi_party_ecdsa_amd", "dist.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)          # loaded by path: the package import needs the HIP library, this helper does not
+    return D
+
+
+def _init(rank, world, port):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("mpe_dist", os.path.join(ROOT, "multi_party_ecdsa_amd", "dist.py"))
-    D = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(D)          # loaded by path: the package import needs the HIP library, this helper does not
+
+
+def _worker_a(rank, world, port, total, q):
+    _init(rank, world, port)
+    D = _load_dist()
     import fixtures as F
     import orc
     lo, hi = D.shard_range(total, rank, world)
@@ -35,23 +47,40 @@ def _worker(rank, world, port, total, q):
         np.zeros((0, 64), dtype=np.uint32)
     dist.barrier()
     elapsed = D.max_over_ranks(0.25 + rank)                # the slowest rank defines the job time
-    counts = D.gather_counts(hi - lo)
-    q.put((rank, lo, hi, F.ints(out), elapsed, counts))
+    q.put((rank, lo, hi, F.ints(out), elapsed))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_gloo():
-    world, total, port = 2, 11, 29500 + os.getpid() % 2000
+def _spawn(worker, world, args):
+    port = 29500 + (os.getpid() * 7 + world * 131 + hash(worker.__name__) % 97) % 2000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
+    import queue
+    import time
+    res, t0 = [], time.time()
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > 900:                  # a worker died (its peers would wait for it forever)
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError(f"worker failed: exit codes {dead}")
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
+    return sorted(res, key=lambda x: x[0])
+
+
+def test_two_rank_sharding_gloo():
+    world, total = 2, 11
+    res = _spawn(_worker_a, world, (total,))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import fixtures as F
     r = F.Rng("dist")
@@ -60,19 +89,15 @@ def test_two_rank_sharding_gloo():
     exp = [r.bits(256) for _ in range(total)]
     want = [pow(b, e, mods[i % 3]) for i, (b, e) in enumerate(zip(base, exp))]
     covered = []
-    for rank, lo, hi, out, elapsed, counts in res:
+    for rank, lo, hi, out, elapsed in res:
         assert out == want[lo:hi]
         covered += list(range(lo, hi))
         assert elapsed == 1.25                             # max over ranks (0.25, 1.25)
-        assert counts == [6, 5] and sum(counts) == total
     assert covered == list(range(total))                   # every unit exactly once, in order
 
 
 def test_shard_range_properties():
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("mpe_dist", os.path.join(ROOT, "multi_party_ecdsa_amd", "dist.py"))
-    D = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(D)
+    D = _load_dist()
     for total in (0, 1, 7, 65536):
         for world in (1, 2, 3, 8):
             spans = [D.shard_range(total, r, world) for r in range(world)]
@@ -80,3 +105,97 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- Mode B ---------------------------------------------------------------------------------------------------------
+class _OracleEngine:
+    """the round-engine interface of dist.PartySharded over the CPU oracle: one OracleParty per local party, each created
+    from a key struct that holds only that party's secrets"""
+
+    def __init__(self, lk, nonces_block, parties, Bblk):
+        import gg20_fixture as G
+        self.G, self.S, self.Bblk = G, lk["S"], Bblk
+        self.parties = [G.OracleParty(lk, p, Bblk, G.party_nonces(nonces_block, lk, p)) for p in parties]
+
+    def round(self, rnd, d_in, in_off, msg):
+        if rnd == 7:
+            outs = [p.round(7, np.ascontiguousarray(msg.numpy().view(np.uint32))) for p in self.parties]
+        else:
+            slab = None if d_in is None else np.ascontiguousarray(d_in.numpy().view(np.uint32))
+            outs = [p.round(rnd, slab, in_off) for p in self.parties]
+        if outs[0] is None:
+            return None
+        return torch.from_numpy(np.stack(outs).view(np.int32))
+
+    def result(self):
+        res = [p.result() for p in self.parties]
+        return {f: np.stack([r[f] for r in res]) for f in res[0]}
+
+
+def _worker_b(rank, world, port, t, n, signers, B, placement, q):
+    _init(rank, world, port)
+    D = _load_dist()
+    import fixtures as F
+    import gg20_fixture as G
+    keys = F.load_keys()
+    lk = G.make_local_keys(keys, t, n, signers)
+    S = len(signers)
+    nonces = G.make_nonces(lk, B, seed=f"modeB-{t}-{n}")          # the global job; every rank slices what its parties own
+    blocks = world if placement == "rotated" else 1
+    Bblk = B // blocks
+
+    def block_nonces(s):
+        out = {}
+        for f, v in nonces.items():
+            per = v.shape[0] // B
+            out[f] = np.ascontiguousarray(v[s * Bblk * per:(s + 1) * Bblk * per])
+        return out
+
+    def make_engine(s, parties):
+        return _OracleEngine(lk, block_nonces(s), parties, Bblk)
+    ps = D.PartySharded(S, Bblk, lambda rnd: G.msg_words(S, n, rnd), make_engine, "cpu", placement=placement)
+    msgs = {s: torch.from_numpy(block_nonces(s)["msg"].view(np.int32)) for s in ps.engines}
+    res = ps.run(msgs)
+    out = {s: {f: v.tolist() for f, v in r.items()} for s, r in res.items()}
+    hosted = {s: parties for s, (parties, _) in ps.engines.items()}
+    q.put((rank, hosted, out, ps.bytes_per_round))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_mode_b(world, t, n, signers, B, placement):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fixtures as F
+    import gg20_fixture as G
+    res = _spawn(_worker_b, world, (t, n, signers, B, placement))
+    lk = G.make_local_keys(F.load_keys(), t, n, signers)
+    nonces = G.make_nonces(lk, B, seed=f"modeB-{t}-{n}")
+    want = G.oracle_sign_ex(lk, nonces, B)
+    assert not want["status"].any()
+    blocks = world if placement == "rotated" else 1
+    Bblk = B // blocks
+    seen = set()
+    for rank, hosted, out, nbytes in res:
+        for s, parties in hosted.items():
+            r = out[s]
+            for li, p in enumerate(parties):
+                seen.add((s, p))
+                sl = slice(s * Bblk, (s + 1) * Bblk)
+                assert r["status"][li] == [0] * Bblk
+                assert np.array_equal(np.array(r["r"][li], dtype=np.uint32), want["r"][sl])
+                assert np.array_equal(np.array(r["s"][li], dtype=np.uint32), want["s"][sl])
+                assert r["recid"][li] == list(want["recid"][sl])
+        assert set(nbytes) == {0, 1, 2, 3, 4, 5, 7}
+    assert seen == {(s, p) for s in range(blocks) for p in range(len(signers))}     # every party of every block exactly once
+
+
+def test_party_sharded_world2_one_party_per_rank():
+    _check_mode_b(2, 1, 3, [0, 2], 2, "party")
+
+
+def test_party_sharded_world3_one_party_per_rank():
+    _check_mode_b(3, 2, 4, [0, 1, 3], 1, "party")
+
+
+def test_party_sharded_rotated_blocks_world3_two_signers():
+    _check_mode_b(3, 1, 3, [1, 2], 3, "rotated")

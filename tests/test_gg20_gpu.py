@@ -1,7 +1,10 @@
-"""GPU parity test of the batched GG20 signing pipeline (mpe_gg20_sign) against the CPU oracle
-(oracle/gg20_oracle.c): byte-identical (r, s, recid) and R for identical nonces, for the reference's own
-(t, n, signer-set) cases (state_machine/sign.rs:740-763); signatures re-checked by the independent
-Python ECDSA verifier (the reference's check_sig, gg_2020/test.rs:711-748)."""
+"""GPU parity tests of the GG20 signing engine against the CPU oracle (oracle/gg20_oracle.c):
+ * the ROUND VIEW (`mpe_gg20_round0..7`, one `RoundN::proceed` per call): EVERY outgoing message slab byte-identical to
+   the oracle's, with all parties local and with one party per object (which only ever holds that party's secrets);
+ * tampered messages: the same status INTEGER and bad_actors as the oracle for every check of the protocol;
+ * the lock-step composition `mpe_gg20_sign`: byte-identical (r, s, recid) and R for the reference's own
+   (t, n, signer-set) cases (state_machine/sign.rs:740-763; gg_2020/test.rs:55-67 uses S > t+1 too); signatures
+   re-checked by the independent Python ECDSA verifier (the reference's check_sig, gg_2020/test.rs:711-748)."""
 import numpy as np
 import pytest
 import torch
@@ -17,6 +20,10 @@ def _dev(ctx, arr):
     return torch.from_numpy(np.ascontiguousarray(arr).view(np.int32)).to(ctx.device)
 
 
+def _u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
 def _run(gpu_ctx, keys, t, n, signers, B, seed, **kw):
     from multi_party_ecdsa_amd import engine as E
     lk = G.make_local_keys(keys, t, n, signers)
@@ -27,12 +34,164 @@ def _run(gpu_ctx, keys, t, n, signers, B, seed, **kw):
     return lk, nonces, [o.cpu().numpy() for o in out]
 
 
+class GpuParty:
+    """adapter: a Gg20Session over the local parties `local` with numpy slabs in / out (test relay)"""
+
+    def __init__(self, ctx, gk, B, local, nonces_np, **kw):
+        from multi_party_ecdsa_amd import engine as E
+        self.ctx = ctx
+        self.keep = {f: _dev(ctx, v) for f, v in nonces_np.items()}
+        self.sess = E.Gg20Session(ctx, gk, B, local, self.keep, **kw)
+
+    def round(self, rnd, slab):
+        if rnd == 7:
+            out = self.sess.round(7, msg=_dev(self.ctx, slab))
+        else:
+            out = self.sess.round(rnd, d_in=None if slab is None else _dev(self.ctx, slab))
+        self.ctx.sync()
+        return None if out is None else _u32(out)
+
+    def result(self):
+        o = self.sess.result()
+        self.ctx.sync()
+        return {f: (_u32(v) if f in ("r", "s", "R", "bad_actors") else v.cpu().numpy()) for f, v in o.items()}
+
+
+CASES = [(1, 3, [0, 1], 3), (2, 5, [0, 2, 4], 2), (1, 3, [0, 1, 2], 2)]       # the last: S > t+1, as gg_2020/test.rs:55-67
+
+
+@pytest.mark.parametrize("t,n,signers,B", CASES)
+def test_every_round_message_is_byte_identical_all_parties_local(gpu_ctx, keys, t, n, signers, B):
+    from multi_party_ecdsa_amd import engine as E
+    lk = G.make_local_keys(keys, t, n, signers)
+    nonces = G.make_nonces(lk, B, seed=f"rounds-{t}-{n}-{signers}")
+    want = G.oracle_sign_ex(lk, nonces, B)
+    assert not want["status"].any()
+    gk = E.Gg20Keys(gpu_ctx, t, n, signers, lk["arrays"])
+    S = len(signers)
+
+    class All:
+        def __init__(self):
+            self.p = GpuParty(gpu_ctx, gk, B, list(range(S)), nonces)
+
+        def round(self, rnd, slab):
+            return self.p.round(rnd, slab)
+    eng = All()
+    prev = None
+    for rnd in range(9):
+        out = eng.round(rnd, nonces["msg"] if rnd == 7 else prev)
+        if rnd in G.ROUNDS:
+            assert out.shape == want["slabs"][rnd].shape
+            assert np.array_equal(out, want["slabs"][rnd]), f"message slab of round {rnd}"
+            prev = out
+    res = eng.p.result()
+    assert not res["status"].any() and not res["bad_actors"].any()
+    for i in range(S):
+        assert np.array_equal(res["r"][i], want["r"]) and np.array_equal(res["s"][i], want["s"]) and list(res["recid"][i]) == list(want["recid"])
+        assert np.array_equal(res["R"][i], want["R"])
+
+
+@pytest.mark.parametrize("t,n,signers,B", CASES[:2])
+def test_one_party_per_object_holds_only_its_own_secrets(gpu_ctx, keys, t, n, signers, B):
+    """The per-party view: S objects, each created from a key object that has ONE party's x_i, p_i, q_i, exchange the
+    round messages through a relay; every message and every party's signature equal the oracle's."""
+    from multi_party_ecdsa_amd import engine as E
+    lk = G.make_local_keys(keys, t, n, signers)
+    nonces = G.make_nonces(lk, B, seed=f"party-{t}-{n}-{signers}")
+    want = G.oracle_sign_ex(lk, nonces, B)
+    S = len(signers)
+    parties = []
+    for i in range(S):
+        gk = E.Gg20Keys(gpu_ctx, t, n, signers, lk["arrays"], own=[signers[i]])
+        class One:
+            def __init__(self, gk, i):
+                self.gk, self.p = gk, GpuParty(gpu_ctx, gk, B, [i], G.party_nonces(nonces, lk, i))
+            def round(self, rnd, slab):
+                o = self.p.round(rnd, slab)
+                return None if o is None else o[0]
+            def result(self):
+                return self.p.result()
+        parties.append(One(gk, i))
+    slabs = G.run_rounds(parties, nonces["msg"])
+    for rnd in G.ROUNDS:
+        assert np.array_equal(slabs[rnd], want["slabs"][rnd]), f"round {rnd}"
+    for p in parties:
+        res = p.result()
+        assert not res["status"].any()
+        assert np.array_equal(res["r"][0], want["r"]) and np.array_equal(res["s"][0], want["s"]) and list(res["recid"][0]) == list(want["recid"])
+
+
+def _other_point(words16):
+    """a different VALID point: the double of the given one"""
+    P = F.points(words16.reshape(1, 16))[0]
+    return F.point_words([pyref.ec_add(P, P)])[0]
+
+
+# (round whose outgoing message is tampered, sender ordinal, word offset, kind) -> every check of the protocol
+TAMPERS = [
+    ("range proof s1", 0, 1, 136, "flip"),              # AliceProof st 0 of party 1 -> its peers fail MessageB::b: 101
+    ("range proof z", 0, 0, 256 + 3, "flip"),           # statement 1
+    ("MessageB b_proof.z", 1, 0, 160, "flip"),          # DLogProof::verify -> 201
+    ("MessageB ciphertext", 1, 1, 5, "flip"),           # alpha wrong -> g^alpha check -> 201
+    ("w MessageB beta_tag_proof.R", 1, 0, 208 + 184, "point"),
+    ("TI != TIProof.com", 2, 1, 8, "point"),            # 303
+    ("PedersenProof z1", 2, 0, 80, "flip"),             # 302
+    ("PedersenProof a2", 2, 1, 48, "point"),            # 302
+    ("decommit g_gamma", 3, 1, 8, "point"),             # 401, bad_actors = {1}
+    ("decommit blind", 3, 0, 0, "flip"),                # 401, bad_actors = {0}
+    ("PDL s2", 4, 0, 297, "flip"),                      # 501, bad_actors = {0}
+    ("PDL u1", 4, 1, 64, "point"),                      # 501
+    ("HEG z2", 5, 1, 56, "flip"),                       # 601, bad_actors = {1}
+    ("S_i", 5, 0, 0, "point"),                          # 601 (and the sum)
+    ("partial signature", 7, 1, 0, "flip"),             # 701
+]
+
+
+@pytest.mark.parametrize("name,rnd,sender,word,kind", TAMPERS, ids=[t[0] for t in TAMPERS])
+def test_tampered_message_gives_the_oracles_status_and_bad_actors(gpu_ctx, keys, name, rnd, sender, word, kind):
+    from multi_party_ecdsa_amd import engine as E
+    t, n, signers, B = 1, 3, [0, 2], 2
+    lk = G.make_local_keys(keys, t, n, signers)
+    nonces = G.make_nonces(lk, B, seed="tamper")
+    S = len(signers)
+
+    def tamper(r, slab):
+        if r != rnd:
+            return
+        if kind == "flip":
+            slab[sender, 1, word] ^= 4                                      # session 1 only; session 0 stays clean
+        else:
+            slab[sender, 1, word:word + 16] = _other_point(slab[sender, 1, word:word + 16])
+    orc_parties = [G.OracleParty(lk, i, B, G.party_nonces(nonces, lk, i)) for i in range(S)]
+    G.run_rounds(orc_parties, nonces["msg"], tamper)
+    gk = E.Gg20Keys(gpu_ctx, t, n, signers, lk["arrays"])
+
+    class One:
+        def __init__(self, i):
+            self.p = GpuParty(gpu_ctx, gk, B, [i], G.party_nonces(nonces, lk, i))
+        def round(self, r, slab):
+            o = self.p.round(r, slab)
+            return None if o is None else o[0]
+    gpu_parties = [One(i) for i in range(S)]
+    G.run_rounds(gpu_parties, nonces["msg"], tamper)
+    seen = set()
+    for i in range(S):
+        w, g = orc_parties[i].result(), gpu_parties[i].p.result()
+        assert list(g["status"][0]) == list(w["status"]), (name, i)
+        assert list(g["bad_actors"][0]) == list(w["bad_actors"]), (name, i)
+        assert np.array_equal(g["r"][0], w["r"]) and np.array_equal(g["s"][0], w["s"])
+        assert w["status"][0] == 0                                          # the clean session signs
+        seen.add(int(w["status"][1]))
+    assert seen != {0}, "the tampering must be detected by somebody"
+
+
 @pytest.mark.parametrize("t,n,signers,B,kw", [
     (1, 3, [0, 1], 5, {}),
     (1, 3, [0, 2], 3, {"dedup_verify": True}),
     (1, 3, [1, 2], 7, {"chunk": 3}),                 # ragged chunking: 3 + 3 + 1
     (2, 5, [0, 2, 4], 3, {}),
     (2, 4, [1, 2, 3], 2, {"dedup_verify": True}),
+    (2, 5, [0, 2, 3, 4], 2, {}),                     # S = 4 > t+1 (gg_2020/test.rs:60-63)
 ])
 def test_sign_matches_oracle(gpu_ctx, keys, t, n, signers, B, kw):
     lk, nonces, (r, s, recid, status, R) = _run(gpu_ctx, keys, t, n, signers, B, f"gpu-{t}-{n}-{signers}", **kw)
@@ -69,7 +228,7 @@ def test_large_batch_kernels_on_a_small_batch(keys):
 
 
 def test_wrong_public_key_fails_only_that_check(gpu_ctx, keys):
-    """phase6_check_S_i_sum: with an inconsistent y every session reports 601, like the oracle's 602 family"""
+    """phase6_check_S_i_sum: with an inconsistent y every session reports 602 on the GPU and on the oracle, no signature leaves"""
     from multi_party_ecdsa_amd import engine as E
     lk = G.make_local_keys(keys, 1, 3, [0, 1])
     lk["arrays"]["y"][:] = F.point_words([pyref.ec_mul(999, pyref.G)])
@@ -77,8 +236,8 @@ def test_wrong_public_key_fails_only_that_check(gpu_ctx, keys):
     gk = E.Gg20Keys(gpu_ctx, 1, 3, [0, 1], lk["arrays"])
     r, s, recid, status = E.gg20_sign(gpu_ctx, gk, {f: _dev(gpu_ctx, v) for f, v in nonces.items()}, 2)
     gpu_ctx.sync()
-    assert list(status.cpu().numpy()) == [601, 601]
-    assert list(G.oracle_sign(lk, nonces, 2)[4]) == [602, 602]
+    assert list(status.cpu().numpy()) == [602, 602] == list(G.oracle_sign(lk, nonces, 2)[4])
+    assert not r.cpu().numpy().any() and not s.cpu().numpy().any()
 
 
 def test_config4_sessions_byte_identical_to_the_threaded_oracle(gpu_ctx, keys):
@@ -104,9 +263,9 @@ def test_config4_sessions_byte_identical_to_the_threaded_oracle(gpu_ctx, keys):
         assert list(recid[sl]) == list(wrecid[sl]) and np.array_equal(R.view(np.uint32)[sl], wR[sl])
 
 
-def test_inconsistent_key_share_is_caught_in_the_same_round(gpu_ctx, keys):
-    """A signer whose share x_i does not match its public X_i: Bob's g^{w} check in verify_proofs_get_alpha (rounds.rs:281)
-    fails for every session.  GPU and oracle must stop in the same round (hundreds digit of the status)."""
+def test_inconsistent_key_share_is_caught_with_the_oracles_status(gpu_ctx, keys):
+    """A signer whose share x_i does not match its public X_i: the g^{w} check of rounds.rs:281 fails at its peer: 202 on
+    the GPU and on the oracle, for every session."""
     from multi_party_ecdsa_amd import engine as E
     lk = G.make_local_keys(keys, 1, 3, [0, 2])
     lk["arrays"]["x"][0, 0] ^= 1                                   # party 1's share off by a bit; X, y untouched
@@ -116,6 +275,66 @@ def test_inconsistent_key_share_is_caught_in_the_same_round(gpu_ctx, keys):
     r, s, recid, status = E.gg20_sign(gpu_ctx, gk, {f: _dev(gpu_ctx, v) for f, v in nonces.items()}, B)
     gpu_ctx.sync()
     want = G.oracle_sign(lk, nonces, B)[4]
-    got = status.cpu().numpy()
-    assert all(int(x) != 0 for x in got) and all(int(x) != 0 for x in want)
-    assert [int(x) // 100 for x in got] == [int(x) // 100 for x in want]
+    assert list(status.cpu().numpy()) == list(want) == [202] * B
+
+
+def test_sigma_proofs_and_commitment_entry_points(gpu_ctx, keys):
+    """mpe_pedersen_* / mpe_heg_* / mpe_hash_commit_point against the oracle's restatement of the curv proofs"""
+    import orc
+    from multi_party_ecdsa_amd import engine as E
+    rg = F.Rng("sigma")
+    B = 9
+    sc = lambda: F.words([rg.below(pyref.Q - 1) + 1 for _ in range(B)], 8)
+    m, r, s1, s2 = sc(), sc(), sc(), sc()
+    m[0] = 0                                                        # x = 0: the HEG special case z1 = s1
+    o = {f: orc.u32((B, w)) for f, w in dict(com=16, e=8, a1=16, a2=16, z1=8, z2=8).items()}
+    orc.lib.orc_pedersen_prove(B, *[orc._p(a) for a in (m, r, s1, s2, o["com"], o["e"], o["a1"], o["a2"], o["z1"], o["z2"])])
+    g = E.pedersen_prove(gpu_ctx, *[_dev(gpu_ctx, a) for a in (m, r, s1, s2)])
+    gpu_ctx.sync()
+    for f in o:
+        assert np.array_equal(_u32(g[f]), o[f]), f
+    g["z1"][3, 0] ^= 1
+    assert list(E.pedersen_verify(gpu_ctx, g).cpu().numpy()) == [1, 1, 1, 0, 1, 1, 1, 1, 1]
+    pts = lambda: orc.ec_mul_base(sc())
+    Gp, H, Y = pts(), pts(), pts()
+    D = orc.ec_add(orc.ec_mul(m, H), orc.ec_mul(r, Y))               # D = x H + r Y, E = r G
+    Ee = orc.ec_mul(r, Gp)
+    ho = {f: orc.u32((B, w)) for f, w in dict(T=16, A3=16, z1=8, z2=8).items()}
+    orc.lib.orc_heg_prove(B, *[orc._p(a) for a in (m, r, s1, s2, Gp, H, Y, D, Ee, ho["T"], ho["A3"], ho["z1"], ho["z2"])])
+    stt = {f: _dev(gpu_ctx, a) for f, a in dict(G=Gp, H=H, Y=Y, D=D, E=Ee).items()}
+    hg = E.heg_prove(gpu_ctx, *[_dev(gpu_ctx, a) for a in (m, r, s1, s2)], stt)
+    gpu_ctx.sync()
+    for f in ho:
+        assert np.array_equal(_u32(hg[f]), ho[f]), f
+    ok = np.zeros(B, dtype=np.uint8)
+    orc.lib.orc_heg_verify(B, *[orc._p(a) for a in (Gp, H, Y, D, Ee, ho["T"], ho["A3"], ho["z1"], ho["z2"], ok)])
+    assert ok.all()
+    hg["z2"][5, 2] ^= 8
+    assert list(E.heg_verify(gpu_ctx, stt, hg).cpu().numpy()) == [1, 1, 1, 1, 1, 0, 1, 1, 1]
+    blind = F.words([rg.bits(256) for _ in range(B)], 8)
+    blind[1] = 0; blind[2, 7] = 0; blind[2, 6] &= 0xFF               # short blinding factors: minimal-length bytes
+    com = orc.u32((B, 8))
+    orc.lib.orc_hash_commit_point(B, orc._p(Gp), orc._p(blind), orc._p(com))
+    assert np.array_equal(_u32(E.hash_commit_point(gpu_ctx, _dev(gpu_ctx, Gp), _dev(gpu_ctx, blind))), com)
+
+
+def test_scratch_is_wiped_after_signing(keys):
+    """Secret hygiene (the reference zeroizes its round-1 secrets, range_proofs.rs:26-36): after mpe_gg20_sign the session
+    arena (k_i, gamma_i, w_i, sigma_i, ...), the message slabs, the composite workspace and the window tables of this
+    context read back as zeros — and they did hold data while a session object was alive."""
+    from multi_party_ecdsa_amd import engine as E
+    ctx = E.Context(0)
+    lk = G.make_local_keys(keys, 1, 3, [0, 1])
+    nonces = G.make_nonces(lk, 2, seed="wipe")
+    gk = E.Gg20Keys(ctx, 1, 3, [0, 1], lk["arrays"])
+    dn = {f: _dev(ctx, v) for f, v in nonces.items()}
+    sess = E.Gg20Session(ctx, gk, 2, [0, 1], dn)
+    sess.round(0)
+    nz, tot = ctx.scratch_audit()
+    assert nz > 0 and tot > 0
+    sess.close()
+    r, s, recid, status = E.gg20_sign(ctx, gk, dn, 2)
+    ctx.sync()
+    assert list(status.cpu().numpy()) == [0, 0]
+    nz, tot = ctx.scratch_audit()
+    assert nz == 0 and tot > 0
