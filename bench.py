@@ -1,5 +1,5 @@
 """bench.py — headline benchmark: GG20 (t=1, n=3) threshold-ECDSA signatures per second on MI355X, with the
-Paillier-2048 numbers of BASELINE.json's metric in the same JSON line.
+Paillier-2048 numbers of BASELINE.json's metric and every other BASELINE config in the same JSON line.
 
 One step = one pass of the hot path over one batch: B concurrent signing sessions (BASELINE config 4 shape:
 t=1, n=3, signers {1,2}, one LocalKey fixture shared by all sessions, distinct nonces and messages per
@@ -8,14 +8,23 @@ work (every range proof verified for both MessageB::b calls, every party verifie
 src/protocols/multi_party_ecdsa/gg_2020/state_machine/sign/rounds.rs:151-175,546-558).  All inputs (keys,
 nonces, messages) are resident in HBM before the timed region.  `value` = signatures / second.
 
-The dominant kernel is the 4096-bit modexp (mod N^2); `roofline` aggregates all its launches inside the timed
-region (HIP events on the launch stream, `mpe_prof_*`).  `paillier` holds BASELINE config 2 (65 536 encrypt +
-65 536 decrypt, 16 keys) measured right after the timed region.  `cpu_baseline` times the GMP oracle
-(oracle/gg20_oracle.c — the reference's formulas over the reference's own bignum engine) on the host cores
-for a bounded sample of the same sessions and checks the GPU signatures against it bit for bit.
+`roofline`: the dominant kernel is the exponentiation modulo N^2 (`pair_modexp_kernel<Cfg2048>`); all its launches of the
+timed region are timed with HIP events on the launch stream (`mpe_prof_*`).  `frac` = the 32x32+64 MACs the EXECUTED
+algorithm needs (N-adic pairs on ideal 32-bit limbs: 2 MAC(64) per squaring, 2.5 per multiplication, the kernel's own
+window counts) per second / the measured v_mad_u64_u32 issue peak — a hardware-utilisation figure <= 1.  SURVEY.md 8(d)'s
+unit (textbook CIOS on the 4096-bit integers) is reported beside it as `alg_unit_*`; it exceeds the peak because the
+kernel computes the same residues with ~0.46x those MACs.
+`configs`: c2 (65 536 Paillier encrypt + decrypt, 16 keys), c3 (262 144 EC scalar multiplications and PDL-with-slack
+prove + verify, prefix checked against the oracle, 1 % corrupted proofs all rejected), c4_literal_1024 (config 4 at its
+literal size), c5_share_t2n5_8192 (one GPU's share of config 5), measured right after the timed region.
+`cpu_baseline`: the GMP oracle (oracle/gg20_oracle.c — the reference's formulas over the reference's own bignum engine)
+on the host cores for a bounded sample of the same sessions (>= 8 per thread), plus its single-thread rate; the GPU
+signatures are checked against it bit for bit.
 
-N>1: one process per GPU, sessions sharded across ranks, no data-path collective (independent units,
-SURVEY.md §8e); torch.distributed (RCCL) only for barriers and the max-reduce of the elapsed time.
+N>1 (one process per GPU under torch.distributed.run; RCCL):
+  --mode session (default): sessions sharded across ranks, no data-path collective (independent units, SURVEY.md §8e A);
+  --mode party: the parties of a session live on different GPUs (party p of session block s on rank (s + p) % N) and
+  every round's messages travel through one all-gather (BASELINE config 5); same per-GPU work.
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -75,22 +84,6 @@ def rand_words(gen, dev, rows, width, full):
     return t
 
 
-def make_device_nonces(gen, dev, B, S, n):
-    """Synthetic nonces inside the reference's sampling ranges (party_i.rs:559-563,574; mta/mod.rs:57,97-98;
-    range_proofs.rs:48-51; zk_pdl_with_slack/mod.rs:73-77): uniform below a power of two under each bound."""
-    P = S * (S - 1)
-    sc = lambda rows: _scalar(gen, dev, rows)
-    z = dict(k=sc(B * S), gamma=sc(B * S), blind=rand_words(gen, dev, B * S, 8, 8), r_a=rand_words(gen, dev, B * S, 64, 63),
-             al_alpha=rand_words(gen, dev, B * S * n, 24, 23), al_beta=rand_words(gen, dev, B * S * n, 64, 63),
-             al_gamma=rand_words(gen, dev, B * S * n, 88, 87), al_rho=rand_words(gen, dev, B * S * n, 72, 71),
-             mb_beta_tag=rand_words(gen, dev, B * P * 2, 64, 63), mb_r=rand_words(gen, dev, B * P * 2, 64, 63),
-             mb_nonce_b=sc(B * P * 2), mb_nonce_bt=sc(B * P * 2), l=sc(B * S), ped_s1=sc(B * S), ped_s2=sc(B * S),
-             pdl_alpha=rand_words(gen, dev, B * P, 24, 23), pdl_beta=rand_words(gen, dev, B * P, 64, 63),
-             pdl_rho=rand_words(gen, dev, B * P, 72, 71), pdl_gamma=rand_words(gen, dev, B * P, 88, 87),
-             heg_s1=sc(B * S), heg_s2=sc(B * S), msg=rand_words(gen, dev, B, 8, 8))
-    return z
-
-
 def _scalar(gen, dev, rows):
     t = rand_words(gen, dev, rows, 8, 8)
     t[:, 7] &= 0x3FFFFFFF                      # < 2^254 < q, nonzero with overwhelming probability
@@ -98,7 +91,29 @@ def _scalar(gen, dev, rows):
     return t
 
 
+def make_device_nonces(gen, dev, B, L, S, n):
+    """Synthetic nonces inside the reference's sampling ranges (party_i.rs:559-563,574; mta/mod.rs:57,97-98;
+    range_proofs.rs:48-51; zk_pdl_with_slack/mod.rs:73-77): uniform below a power of two under each bound.
+    Leading dimensions [B][L] (L local parties)."""
+    P = L * (S - 1)
+    sc = lambda rows: _scalar(gen, dev, rows)
+    z = dict(k=sc(B * L), gamma=sc(B * L), blind=rand_words(gen, dev, B * L, 8, 8), r_a=rand_words(gen, dev, B * L, 64, 63),
+             al_alpha=rand_words(gen, dev, B * L * n, 24, 23), al_beta=rand_words(gen, dev, B * L * n, 64, 63),
+             al_gamma=rand_words(gen, dev, B * L * n, 88, 87), al_rho=rand_words(gen, dev, B * L * n, 72, 71),
+             mb_beta_tag=rand_words(gen, dev, B * P * 2, 64, 63), mb_r=rand_words(gen, dev, B * P * 2, 64, 63),
+             mb_nonce_b=sc(B * P * 2), mb_nonce_bt=sc(B * P * 2), l=sc(B * L), ped_s1=sc(B * L), ped_s2=sc(B * L),
+             pdl_alpha=rand_words(gen, dev, B * P, 24, 23), pdl_beta=rand_words(gen, dev, B * P, 64, 63),
+             pdl_rho=rand_words(gen, dev, B * P, 72, 71), pdl_gamma=rand_words(gen, dev, B * P, 88, 87),
+             heg_s1=sc(B * L), heg_s2=sc(B * L), msg=rand_words(gen, dev, B, 8, 8))
+    return z
+
+
+def _host(nonces):
+    return {f: np.ascontiguousarray(v.cpu().numpy().view(np.uint32)) for f, v in nonces.items()}
+
+
 def cpu_baseline_gg20(lk, host_nonces, sample, threads):
+    """the oracle on `threads` host threads over `sample` sessions (ctypes releases the GIL); returns sig/s and the signatures"""
     import gg20_fixture as G
     chunks = [c for c in np.array_split(np.arange(sample), threads) if len(c)]
     outs = {}
@@ -120,7 +135,7 @@ def cpu_baseline_gg20(lk, host_nonces, sample, threads):
 
 def paillier_config2(ctx, E, keys, F, steps=1):
     """BASELINE config 2: 65 536 encrypt + 65 536 decrypt, 16 keys.  Encryption is timed twice: by the key holder
-    (p, q known: the p^2 | q^2 path) and by a peer that only has N (the plain 4096-bit modexp r^N mod N^2 — the
+    (p, q known: the p^2 | q^2 path) and by a peer that only has N (the plain exponentiation r^N mod N^2 — the
     'Paillier-2048 modexp/s' of the metric, with its kernel time from the HIP-event records)."""
     B = 65536
     dev = ctx.device
@@ -156,10 +171,119 @@ def paillier_config2(ctx, E, keys, F, steps=1):
             "roundtrip_ok": bool(torch.equal(back, m)), "holder_equals_public_ciphertext": bool(torch.equal(c, c2)),
             "encrypt_per_s": B / t_enc, "decrypt_per_s": B / t_dec, "encrypt_public_key_per_s": B / t_pub,
             "modexp4096_2048_per_s": B / kern,
-            "modexp4096_alg_TMAC_per_s": B * modexp_macs(128, 2048) / kern / 1e12,
-            "modexp4096_frac_of_peak": B * modexp_macs(128, 2048) / kern / PEAK_MAC_PER_S,
             "modexp4096_executed_TMAC_per_s": B * pair_modexp_macs(64, 64) / kern / 1e12,
-            "modexp4096_executed_frac": B * pair_modexp_macs(64, 64) / kern / PEAK_MAC_PER_S}
+            "modexp4096_executed_frac": B * pair_modexp_macs(64, 64) / kern / PEAK_MAC_PER_S,
+            "modexp4096_alg_unit_TMAC_per_s": B * modexp_macs(128, 2048) / kern / 1e12}
+
+
+def config3(ctx, E, keys, F, B=262144, prefix=4096, threads=None, oracle=True):
+    """BASELINE config 3: B secp256k1 scalar multiplications (fixed base x G, variable base x P) and
+    B PDLwSlackProof::prove + verify over K = 16 (ek, N~, h1, h2) tuples, witnesses x uniform < 2^224 < q, nonces in the
+    reference's ranges; a `prefix` of the proofs compared with the oracle bit for bit, 100 % of the honest proofs
+    accepted, 1 % deliberately corrupted -> all rejected (and only those)."""
+    import orc
+    dev = ctx.device
+    K = len(keys)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    pk = E.PaillierKeys(ctx, p=[k.p for k in keys], q=[k.q for k in keys])          # the prover owns the key
+    pub = E.PaillierKeys(ctx, N=[k.N for k in keys])
+    stm = E.Statements(ctx, [k.Nt for k in keys], [k.h1 for k in keys], [k.h2 for k in keys])
+    x = rand_words(g, dev, B, 8, 7)
+    rr = rand_words(g, dev, B, 64, 63)
+    nonces = dict(alpha=rand_words(g, dev, B, 24, 23), beta=rand_words(g, dev, B, 64, 63), rho=rand_words(g, dev, B, 72, 71),
+                  gamma=rand_words(g, dev, B, 88, 87))
+    kidx = (torch.arange(B, device=dev, dtype=torch.int32) % K).contiguous()
+    sidx = ((torch.arange(B, device=dev, dtype=torch.int32) * 7 + 3) % K).contiguous()
+    kb = rand_words(g, dev, B, 8, 7)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out
+    E.ec_mul_base(ctx, kb[:1024])                                                    # warm-up
+    t_fix, Gp = timed(lambda: E.ec_mul_base(ctx, kb))
+    t_var, Qp = timed(lambda: E.ec_mul(ctx, x, Gp))
+    xm = torch.zeros((B, 64), dtype=torch.int32, device=dev)
+    xm[:, :8] = x
+    c = pk.encrypt_device(xm, rr, kidx)
+    small = {f: v[:256] for f, v in nonces.items()}
+    E.pdl_verify(ctx, pub, stm, c[:256], Qp[:256], Gp[:256], E.pdl_prove(ctx, pk, stm, c[:256], Qp[:256], Gp[:256], x[:256], rr[:256], small,
+                                                                         kidx[:256], sidx[:256]), kidx[:256], sidx[:256])
+    t_prove, pr = timed(lambda: E.pdl_prove(ctx, pk, stm, c, Qp, Gp, x, rr, nonces, kidx, sidx))
+    t_ver, ok = timed(lambda: E.pdl_verify(ctx, pub, stm, c, Qp, Gp, pr, kidx, sidx))
+    accepted = int(ok.sum())
+    bad = {k: v.clone() for k, v in pr.items()}
+    fields = ["z", "u2", "u3", "s1", "s2", "s3"]
+    nbad = 0
+    for q_, f in enumerate(fields):                                                   # 1 %: every 100th proof, a different field each time
+        sl = slice(q_ * 100 + 7, B, 600)
+        bad[f][sl, 1] ^= 0x10
+        nbad += len(range(*sl.indices(B)))
+    okb = E.pdl_verify(ctx, pub, stm, c, Qp, Gp, bad, kidx, sidx).cpu().numpy()
+    mask = np.zeros(B, dtype=bool)
+    for q_ in range(len(fields)):
+        mask[q_ * 100 + 7:B:600] = True
+    out = {"instances": B, "keys": K, "ec_fixed_per_s": B / t_fix, "ec_var_per_s": B / t_var, "pdl_prove_per_s": B / t_prove,
+           "pdl_verify_per_s": B / t_ver, "accepted": accepted, "accept_rate": accepted / B,
+           "corrupted": int(nbad), "corrupted_1pct_all_rejected": bool((okb[mask] == 0).all() and (okb[~mask] == 1).all())}
+    if oracle:
+        n = min(prefix, B)
+        threads = threads or min(os.cpu_count() or 1, 64)
+        h = lambda t: np.ascontiguousarray(t[:n].cpu().numpy().view(np.uint32))
+        tabs = dict(N=F.words([k.N for k in keys], 64), Nt=F.words([k.Nt for k in keys], 64), h1=F.words([k.h1 for k in keys], 64),
+                    h2=F.words([k.h2 for k in keys], 64))
+        hin = dict(c=h(c), Q=h(Qp), G=h(Gp), x=h(x), r=h(rr), **{f: h(v) for f, v in nonces.items()})
+        ki, si = kidx[:n].cpu().numpy(), sidx[:n].cpu().numpy()
+        got = {f: h(v) for f, v in pr.items()}
+        chunks = [c_ for c_ in np.array_split(np.arange(n), threads) if len(c_)]
+
+        def run(ix):
+            sl = slice(int(ix[0]), int(ix[-1]) + 1)
+            want = orc.pdl_prove(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], ki[sl], si[sl], hin["c"][sl], hin["Q"][sl], hin["G"][sl],
+                                 hin["x"][sl], hin["r"][sl], hin["alpha"][sl], hin["beta"][sl], hin["rho"][sl], hin["gamma"][sl])
+            good = all(np.array_equal(got[f][sl], want[f]) for f in want)
+            okv = orc.pdl_verify(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], ki[sl], si[sl], hin["c"][sl], hin["Q"][sl], hin["G"][sl], want)
+            return good and bool(okv.all())
+        t0 = time.time()
+        with ThreadPoolExecutor(threads) as ex:
+            res = list(ex.map(run, chunks))
+        out.update({"parity_prefix": n, f"parity_prefix_{n}": bool(all(res)), "oracle_prove_verify_per_s": n / (time.time() - t0),
+                    "oracle_threads": threads})
+        # the EC results of the prefix against the oracle too
+        out["ec_parity_prefix"] = bool(np.array_equal(hin["G"], orc.ec_mul_base(h(kb))) and np.array_equal(hin["Q"], orc.ec_mul(hin["x"], hin["G"])))
+    return out
+
+
+def gg20_config(ctx, E, G, keys, t, n, B, steps, gen, parity_sample=0, threads=None):
+    """one more GG20 shape on this GPU: sessions/s over `steps` passes of B sessions, optional parity sample vs the oracle"""
+    dev = ctx.device
+    signers = list(range(t + 1))
+    lk = G.make_local_keys(keys, t, n, signers)
+    gk = E.Gg20Keys(ctx, t, n, signers, lk["arrays"])
+    S = len(signers)
+    nonces = make_device_nonces(gen, dev, B, S, S, n)
+    out = E.gg20_sign(ctx, gk, nonces, B)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = E.gg20_sign(ctx, gk, nonces, B)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    r, s, recid, status = [o.cpu().numpy() for o in out]
+    res = {"sessions": B, "t": t, "n": n, "signatures_per_s": B / dt, "ms_per_batch": dt * 1e3, "all_sessions_signed": bool((status == 0).all())}
+    if parity_sample:
+        threads = threads or min(os.cpu_count() or 1, 64)
+        hn = _host({f: v[: parity_sample * (v.shape[0] // B)] for f, v in nonces.items()})
+        v, wr, ws, wrecid, wstatus = cpu_baseline_gg20(lk, hn, parity_sample, min(threads, parity_sample))
+        res["parity_sample"] = parity_sample
+        res["parity_vs_oracle_on_sample"] = bool((wstatus == 0).all() and np.array_equal(r[:parity_sample].view(np.uint32), wr) and
+                                                 np.array_equal(s[:parity_sample].view(np.uint32), ws) and np.array_equal(recid[:parity_sample], wrecid))
+        res["oracle_signatures_per_s"] = v
+    gk.close()
+    return res
 
 
 def lindell_section(ctx, E, keys, F, cpu=True):
@@ -195,6 +319,23 @@ def lindell_section(ctx, E, keys, F, cpu=True):
     return out
 
 
+class GpuRoundEngine:
+    """dist.PartySharded engine over mpe_gg20_roundN: one session object per session block, local = the parties this rank hosts"""
+
+    def __init__(self, ctx, E, gk, Bblk, parties, nonces):
+        self.sess = E.Gg20Session(ctx, gk, Bblk, parties, nonces)
+        self.keep = nonces
+
+    def round(self, rnd, d_in, in_off, msg):
+        return self.sess.round(rnd, d_in=d_in, in_off=in_off, msg=msg)
+
+    def result(self):
+        return self.sess.result()
+
+    def close(self):
+        self.sess.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,8 +346,9 @@ def main():
     ap.add_argument("--n", type=int, default=3, help="parties of the key")
     ap.add_argument("--chunk", type=int, default=0, help="sessions per internal pass of mpe_gg20_sign (0 = library default)")
     ap.add_argument("--dedup", action="store_true", help="evaluate identical checks once (same outputs; not the faithful path)")
+    ap.add_argument("--mode", choices=["session", "party"], default="session", help="multi-GPU layout (SURVEY.md 8e A / B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-paillier", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the c2 / c3 / c4 / c5 / Lindell sections")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -220,6 +362,7 @@ def main():
 
     import fixtures as F
     import gg20_fixture as G
+    from multi_party_ecdsa_amd import dist as mpe_dist
     from multi_party_ecdsa_amd import engine as E
     keys = F.load_keys()
     ctx = E.Context(local_rank)
@@ -228,25 +371,71 @@ def main():
     SIGNERS = list(range(T + 1))                               # parties 1..t+1 sign
     B, S, n = args.sessions, len(SIGNERS), N_PARTIES
     lk = G.make_local_keys(keys, T, N_PARTIES, SIGNERS)
-    gk = E.Gg20Keys(ctx, T, N_PARTIES, SIGNERS, lk["arrays"])
+    # the public key tables come from rank 0 once (LocalKey's public part is identical for everybody)
+    pub = {f: torch.from_numpy(np.ascontiguousarray(lk["arrays"][f]).view(np.int32)) for f in ("Nt", "h1", "h2", "y", "X")}
+    pub = mpe_dist.broadcast_tables(pub, dev)
+    arrays = dict(lk["arrays"])
+    for f in pub:
+        arrays[f] = np.ascontiguousarray(pub[f].cpu().numpy().view(np.uint32))
+    gk = E.Gg20Keys(ctx, T, N_PARTIES, SIGNERS, arrays)
     gen = torch.Generator(device=dev)
     gen.manual_seed(4242 + rank)
-    nonces = make_device_nonces(gen, dev, B, S, n)
-    torch.cuda.synchronize()
+    extra = {}
+    if args.mode == "session":
+        nonces = make_device_nonces(gen, dev, B, S, S, n)
+        torch.cuda.synchronize()
 
-    def step():
-        return E.gg20_sign(ctx, gk, nonces, B, dedup_verify=args.dedup, chunk=args.chunk)
+        def step():
+            return E.gg20_sign(ctx, gk, nonces, B, dedup_verify=args.dedup, chunk=args.chunk)
+    else:
+        # party p of session block s on rank (s + p) % world: this rank hosts S (block, party) pairs of B sessions each —
+        # the same per-GPU work as B whole sessions; the messages of every round travel through one all-gather
+        engines, block_nonces = {}, {}
+
+        def make_engine(s, parties):
+            g2 = torch.Generator(device=dev)
+            g2.manual_seed(977 * s + 13)                       # the nonces of a block are a function of the block, on every rank
+            full = make_device_nonces(g2, dev, B, S, S, n)
+            per = dict(k=1, gamma=1, blind=1, r_a=1, l=1, ped_s1=1, ped_s2=1, heg_s1=1, heg_s2=1, al_alpha=n, al_beta=n, al_gamma=n,
+                       al_rho=n, mb_beta_tag=2 * (S - 1), mb_r=2 * (S - 1), mb_nonce_b=2 * (S - 1), mb_nonce_bt=2 * (S - 1),
+                       pdl_alpha=S - 1, pdl_beta=S - 1, pdl_rho=S - 1, pdl_gamma=S - 1)
+            mine = {}
+            for f, v in full.items():
+                if f == "msg":
+                    mine[f] = v
+                else:
+                    w = v.shape[1]
+                    mine[f] = v.reshape(B, S, per[f], w)[:, parties].reshape(B * len(parties) * per[f], w).contiguous()
+            block_nonces[s] = mine
+            engines[s] = GpuRoundEngine(ctx, E, gk, B, parties, mine)
+            return engines[s]
+        ps_holder = {}
+
+        def step():
+            for e_ in engines.values():
+                e_.close()
+            engines.clear()
+            ps = mpe_dist.PartySharded(S, B, lambda rnd: E.gg20_msg_words(S, n, rnd), make_engine, dev, placement="rotated")
+            ps_holder["ps"] = ps
+            res = ps.run({s: block_nonces[s]["msg"] for s in ps.engines})
+            first = res[sorted(res)[0]]
+            return first["r"][0], first["s"][0], first["recid"][0], torch.cat([r_["status"].reshape(-1) for r_ in res.values()])
 
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
     ctx.prof_enable(True)
+    if args.mode == "party" and "ps" in ps_holder:
+        ps_holder["ps"].comm_s = 0.0
+    comm_total = 0.0
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+        if args.mode == "party":
+            comm_total += ps_holder["ps"].comm_s
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -254,8 +443,12 @@ def main():
     elapsed = time.perf_counter() - t0
     recs = ctx.prof_collect(16384)
     ctx.prof_enable(False)
-    from multi_party_ecdsa_amd import dist as mpe_dist
     elapsed = mpe_dist.max_over_ranks(elapsed, dev)          # the job ends when its slowest rank does
+    if args.mode == "party":
+        ps = ps_holder["ps"]
+        extra = {"bytes_all_gathered_per_round": {str(k): int(v) for k, v in ps.bytes_per_round.items()},
+                 "rccl_time_share": comm_total / (elapsed if elapsed > 0 else 1.0), "placement": ps.placement,
+                 "pairs_per_rank": ps.per_rank}
 
     if rank == 0:
         r, s, recid, status = [o.cpu().numpy() for o in out]
@@ -275,68 +468,80 @@ def main():
         exe_macs = sum(x["batch"] * pair_modexp_macs(64, x["exp_words"], x.get("exp2_words", 0)) for x in dom) if pair else dom_macs
         sec = [x for x in recs if x["kind"] in (0, 3) and x["bits"] == 2048]
         sec_s = sum(x["ms"] for x in sec) * 1e-3
-        sec_macs = sum(rec_macs(x, 64) for x in sec)
         heavy_s = sum(x["ms"] for x in recs) * 1e-3
-        achieved = dom_macs / dom_s                 # SURVEY.md 8(d)'s unit (textbook count) x units / time
         value = B * world * args.steps / elapsed
         # HBM traffic of the dominant kernel: measured in separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied) and committed under profiles/ — not re-measured here
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if pmc.get("sessions") == B and not args.dedup:
-                traffic = pmc["hbm_bytes_per_launch"]
-        except OSError:
-            pass
+        traffic, traffic_src = None, None
+        for rel in ("profiles/r02/pmc_traffic.json", "profiles/r01/pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, rel)) as f:
+                    pmc = json.load(f)
+                if pmc.get("sessions") == B and not args.dedup and args.mode == "session" and (T, N_PARTIES) == (1, 3):
+                    traffic, traffic_src = pmc["hbm_bytes_per_launch"], rel
+                    break
+            except OSError:
+                pass
+        nl = max(1, len(dom))
         res = {
-            "metric": f"GG20 signatures/sec (t={T}, n={N_PARTIES}; all parties of each session on the GPU) + Paillier-2048 modexp/s per GPU",
+            "metric": f"GG20 signatures/sec (t={T}, n={N_PARTIES}; all parties of each session on the node's GPUs) + Paillier-2048 modexp/s per GPU",
             "value": value, "unit": "signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (radix 2^29) / u64 accumulators", "data": "synthetic",
             "config": {"workload": f"{B} concurrent GG20 t={T} n={N_PARTIES} signing sessions per GPU, full MtA path (BASELINE config 4 shape), "
                                    f"{'deduplicated checks' if args.dedup else 'faithful work'}, one LocalKey fixture, signers {{1..{T + 1}}}",
                        "sessions_per_gpu": B, "t": T, "n": N_PARTIES, "signers": S,
-                       "parallelism": f"session-sharded x{world}, no data-path collective"},
+                       "parallelism": (f"session-sharded x{world}, no data-path collective" if args.mode == "session" else
+                                       f"party-sharded x{world}: party p of session block s on rank (s+p)%{world}, one RCCL all-gather per round"),
+                       **extra},
             "roofline": {"bound": "valu-int (v_mad_u64_u32 issue rate; HBM traffic is negligible)",
-                         "achieved": achieved / 1e12, "peak": PEAK_MAC_PER_S / 1e12,
-                         "unit": "TMAC/s (algorithmic 32x32+64 MACs, SURVEY.md 8d: CIOS on 32-bit limbs of the 4096-bit "
-                                 "modulus, 4-bit windows — independent of how the kernel is written)",
-                         "frac": achieved / PEAK_MAC_PER_S,
-                         "frac_note": "above 1 because the kernel computes the same residues with the N-adic pair arithmetic "
-                                      "(half-size Montgomery passes, DESIGN.md 3), which needs ~0.46x the MACs the 8d unit prices; "
-                                      "the hardware utilisation is executed_frac",
-                         "executed_TMAC_per_s": exe_macs / dom_s / 1e12, "executed_frac": exe_macs / dom_s / PEAK_MAC_PER_S,
-                         "executed_unit": "MACs the executed algorithm needs on ideal 32-bit limbs (2 MAC(64) per squaring, 2.5 per "
-                                          "multiplication modulo N^2)",
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_traffic.json)",
+                         "achieved": exe_macs / dom_s / 1e12 if dom_s else None, "peak": PEAK_MAC_PER_S / 1e12,
+                         "unit": "TMAC/s: 32x32+64 MACs the executed algorithm needs on ideal 32-bit limbs (N-adic pairs: 2 MAC(64) per "
+                                 "squaring, 2.5 per multiplication modulo N^2, the kernel's own window counts)",
+                         "frac": exe_macs / dom_s / PEAK_MAC_PER_S if dom_s else None,
+                         "alg_unit_TMAC_per_s": dom_macs / dom_s / 1e12 if dom_s else None,
+                         "alg_unit_frac": dom_macs / dom_s / PEAK_MAC_PER_S if dom_s else None,
+                         "alg_unit_note": "SURVEY.md 8d's unit (CIOS on 32-bit limbs of the 4096-bit modulus, 4-bit windows): above the peak "
+                                          "because the pair arithmetic computes the same residues with ~0.46x those MACs",
+                         "traffic": traffic, "traffic_unit": f"HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
                          "kernel": ("mpe::pair_modexp_kernel<Cfg<2048,29,18,4>>" if pair else "mpe::modexp_kernel<Cfg<4096,29,18,8>>") +
                                    " (all launches modulo N^2 of the timed region)",
-                         "launches": len(dom), "avg_kernel_ms": dom_s / max(1, len(dom)) * 1e3,
-                         "alg_mac_per_launch": dom_macs / max(1, len(dom)), "executed_mac_per_launch": exe_macs / max(1, len(dom)), "kernel_time_share_of_step": dom_s / elapsed},
+                         "launches": len(dom), "avg_kernel_ms": dom_s / nl * 1e3,
+                         "executed_mac_per_launch": exe_macs / nl, "alg_unit_mac_per_launch": dom_macs / nl,
+                         "kernel_time_share_of_step": dom_s / elapsed},
             "breakdown": {"modexp4096_s_per_step": dom_s / args.steps, "modexp2048_s_per_step": sec_s / args.steps,
-                          "modexp2048_alg_TMAC_per_s": sec_macs / sec_s / 1e12 if sec_s else None,
                           "heavy_kernels_s_per_step": heavy_s / args.steps, "wall_s_per_step": elapsed / args.steps,
-                          "alg_mac_per_signature": sig_macs(S, n),
-                          "whole_step_alg_TMAC_per_s": value / world * sig_macs(S, n) / 1e12,
-                          "whole_step_frac_of_peak": value / world * sig_macs(S, n) / PEAK_MAC_PER_S},
+                          "alg_unit_mac_per_signature": sig_macs(S, n), "fb_window_bits": gk.fb_window_bits()},
             "all_sessions_signed": all_signed, "launch": ctx.launch_info(),
         }
-        # the Paillier section and the CPU baseline belong to the single-GPU line (rank 0 at N=1 only): at N>1 the
-        # other ranks would just wait for them
-        if not args.no_paillier and world == 1:
-            res["paillier"] = paillier_config2(ctx, E, keys, F)
-            res["lindell17"] = lindell_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline)
-        if not args.no_cpu_baseline and world == 1:
-            threads = min(os.cpu_count() or 1, 64)
-            sample = min(B, 2 * threads)
-            host_nonces = {f: np.ascontiguousarray(v.cpu().numpy().view(np.uint32)) for f, v in nonces.items()}
+        # the other configs and the CPU baseline belong to the single-GPU line (rank 0 at N=1 only): at N>1 the other ranks
+        # would just wait for them
+        single = world == 1 and args.mode == "session"
+        threads = min(os.cpu_count() or 1, 64)
+        if single and not args.no_cpu_baseline:
+            sample = min(B, 8 * threads)
+            host_nonces = _host({f: v[: sample * (v.shape[0] // B)] for f, v in nonces.items()})
+            one = min(4, sample)
+            t1 = time.time()
+            G.oracle_sign(lk, host_nonces, one)
+            per_core = one / (time.time() - t1)
             v, wr, ws, wrecid, wstatus = cpu_baseline_gg20(lk, host_nonces, sample, threads)
             parity = bool((wstatus == 0).all() and np.array_equal(r[:sample].view(np.uint32), wr) and
                           np.array_equal(s[:sample].view(np.uint32), ws) and np.array_equal(recid[:sample], wrecid))
-            res["cpu_baseline"] = {"value": v, "unit": "signatures/s", "cores": threads, "kind": "port",
-                                   "sample": f"the first {sample} sessions of the same batch (GMP oracle, {threads} threads)"}
+            res["cpu_baseline"] = {"value": v, "unit": "signatures/s", "cores": threads, "kind": "port", "per_core_1thread": per_core,
+                                   "sample": f"the first {sample} sessions of the same batch ({sample // threads} per thread; GMP oracle, "
+                                             f"{threads} threads of {os.cpu_count()} host CPUs)"}
             res["parity_vs_oracle_on_sample"] = parity
+        if single and not args.no_configs and (T, N_PARTIES) == (1, 3):
+            gk.close()
+            cfg = {}
+            cfg["c2_paillier_65536"] = paillier_config2(ctx, E, keys, F)
+            cfg["c3_ec_pdl_262144"] = config3(ctx, E, keys, F, oracle=not args.no_cpu_baseline)
+            cfg["c4_literal_1024"] = gg20_config(ctx, E, G, keys, 1, 3, 1024, 5, gen, parity_sample=0 if args.no_cpu_baseline else 64)
+            cfg["c5_share_t2n5_8192"] = gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32)
+            res["configs"] = cfg
+            res["paillier"] = cfg["c2_paillier_65536"]
+            res["lindell17"] = lindell_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline)
         print(json.dumps(res))
     if distributed:
         dist.destroy_process_group()

@@ -26,8 +26,10 @@ __global__ void __launch_bounds__(64) bob_ext_check_kernel(int B, Rows s1, Rows 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::U256 a = ec::sc_reduce(row_of(s1, i), 25), ee = ec::sc_reduce(row_of(e, i), 8);
+  const ec::Aff Xp = ec::aff_load(X + (size_t)i * 16), up = ec::aff_load(u + (size_t)i * 16);
+  if (!ec::aff_valid(Xp) || !ec::aff_valid(up)) { ok[i] = 0; return; }
   const ec::Jac l = ec::jac_mul_gen(a);
-  const ec::Jac r = ec::jac_add_aff(ec::jac_mul(ee, ec::aff_load(X + (size_t)i * 16)), ec::aff_load(u + (size_t)i * 16));
+  const ec::Jac r = ec::jac_add_aff(ec::jac_mul(ee, Xp), up);
   if (!ec::jac_eq(l, r)) ok[i] = 0;
 }
 

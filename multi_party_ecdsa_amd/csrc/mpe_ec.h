@@ -361,6 +361,16 @@ __device__ __forceinline__ void aff_store(uint32_t* p, const Aff& a) {
   if (a.inf) { for (int i = 0; i < 16; ++i) p[i] = 0; return; }
   u256_store(p, a.x); u256_store(p + 8, a.y);
 }
+// A point that arrives from a peer: both coordinates canonical (< p), on the curve y^2 = x^3 + 7, not the point at infinity.
+// curv's Point deserialisation performs this check in the reference; without it a secret scalar multiplied into a peer's
+// point is open to invalid-curve / small-subgroup inputs.  (secp256k1 has cofactor 1: on-curve = in the group.)
+__device__ inline bool aff_valid(const Aff& a) {
+  if (a.inf || u256_ge(a.x, FP) || u256_ge(a.y, FP)) return false;
+  U256 rhs = fe_mul(fe_sqr(a.x), a.x), seven = u256_zero();
+  seven.w[0] = 7;
+  rhs = fe_add(rhs, seven);
+  return u256_eq(fe_sqr(a.y), rhs);
+}
 __device__ __forceinline__ bool aff_eq(const Aff& a, const Aff& b) {
   if (a.inf || b.inf) return a.inf && b.inf;
   return u256_eq(a.x, b.x) && u256_eq(a.y, b.y);

@@ -121,17 +121,52 @@ __global__ void gather_field_kernel(Slab s, int S, int B, int src_off, int words
   const size_t jb = g / words;
   dst[g] = rec_of(s, (int)(jb / B), (int)(jb % B))[src_off + w];
 }
-// out record of (li, b), sub-record sub0 + (item % per):  [dst_off .. dst_off+words) = src[item]
+// out record of (li, b), sub-record sub0 + (item % per):  [dst_off .. dst_off+words) = src[item].
+// A party whose status is non-zero has stopped (RoundN::proceed returned Err / panicked in the reference): it sends zeros.
 __global__ void pack_field_kernel(int nitems, int per, int L, int B, int nsub, int sub0, int subw, int dst_off,
-                                  const uint32_t* __restrict__ src, int words, uint32_t* __restrict__ out) {
+                                  const uint32_t* __restrict__ src, int words, const int32_t* __restrict__ status,
+                                  uint32_t* __restrict__ out) {
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)nitems * words) return;
   const int w = (int)(g % words), item = (int)(g / words), pi = item / per, li = pi % L, b = pi / L;
-  out[((size_t)(li * B + b) * nsub + sub0 + item % per) * subw + dst_off + w] = src[g];
+  out[((size_t)(li * B + b) * nsub + sub0 + item % per) * subw + dst_off + w] = status[pi] ? 0u : src[g];
 }
 // status / bad_actors of a party instance: the FIRST failed check sticks
 __device__ __forceinline__ void fail(int32_t* status, uint32_t* bad, int pi, int code, uint32_t mask) {
   if (status[pi] == 0) { status[pi] = code; bad[pi] = mask; }
+}
+
+// Malformed points in the messages a party is about to read (off the curve, non-canonical coordinates, infinity): in the
+// reference such a message does not even deserialise (curv's Point), so the round never sees it.  Here the party's status
+// becomes 100*round + 90 with bad_actors = the senders, BEFORE any secret scalar is multiplied into such a point.
+__device__ __forceinline__ bool pt_ok(const uint32_t* p) { return ec::aff_valid(ec::aff_load(p)); }
+__global__ void __launch_bounds__(64) validate_kernel(Dim d, Slab in, int round, int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= d.B * d.L) return;
+  const int i = d.loc[pi % d.L], b = pi / d.L, P1 = d.S - 1;
+  uint32_t mask = 0;
+  for (int j = 0; j < d.S; ++j) {
+    if (j == i) continue;
+    const uint32_t* m = rec_of(in, j, b);
+    bool good = true;
+    if (round == 2) {
+      for (int v = 0; v < 2; ++v) {
+        const uint32_t* mb = m + (size_t)(jme_of(i, j) * 2 + v) * SUB1;
+        good = good && pt_ok(mb + 128) && pt_ok(mb + 144) && pt_ok(mb + 168) && pt_ok(mb + 184);
+      }
+    } else if (round == 3) {
+      good = pt_ok(m + 8) && pt_ok(m + 32) && pt_ok(m + 48) && pt_ok(m + 64);
+    } else if (round == 4) {
+      good = pt_ok(m + 8);
+    } else if (round == 5) {
+      for (int jj = 0; jj < P1; ++jj) good = good && pt_ok(m + (size_t)jj * SUB4 + 64);
+      good = good && pt_ok(m + (size_t)P1 * SUB4);
+    } else if (round == 6) {
+      good = pt_ok(m) && pt_ok(m + 16) && pt_ok(m + 32);
+    }
+    if (!good) mask |= 1u << j;
+  }
+  if (mask) fail(status, bad, pi, 100 * round + 90, mask);
 }
 
 // ---- helpers -------------------------------------------------------------------------------------
@@ -744,7 +779,7 @@ static int round_exit(mpe_gg20_session* s, int rc, const char* what) {
 }
 #define PACK(nitems, per, nsub, sub0, subw, dst_off, src, words)                                                              \
   GG_LAUNCH(pack_field_kernel, (size_t)(nitems) * (words), (int)(nitems), (int)(per), d.L, d.B, (int)(nsub), (int)(sub0), (int)(subw),  \
-            (int)(dst_off), (const uint32_t*)(src), (int)(words), d_out)
+            (int)(dst_off), (const uint32_t*)(src), (int)(words), s->status, d_out)
 
 // ---- Round0::proceed (rounds.rs:68-104) ------------------------------------------------------------------------------
 static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
@@ -814,6 +849,7 @@ static int round2(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   mpe_ctx* ctx = s->ctx; const mpe_gg20_keys* K = s->K; const Dim& d = s->d; const Counts c = counts_of(d); const mpe_gg20_nonces& Z = s->Z;
   const Slab in1 = slab_of(s, d_in, h_off, 1);
   (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)W2 * 4, st);
+  GG_LAUNCH(validate_kernel, c.nPI, d, in1, 2, s->status, s->bad);
   Bump t(s->tmp);
   int32_t* sub1_rv = t.i(c.nMB);
   uint32_t *alpha_full = t.w(c.nMB * 64), *alpha = t.w(c.nMB * 8);
@@ -841,6 +877,7 @@ static int round3(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   mpe_ctx* ctx = s->ctx; const Dim& d = s->d; const Counts c = counts_of(d);
   const Slab in2 = slab_of(s, d_in, h_off, 2);
   (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)W3 * 4, st);
+  GG_LAUNCH(validate_kernel, c.nPI, d, in2, 3, s->status, s->bad);
   GG_LAUNCH(gather_field_kernel, c.SB * 16, in2, d.S, d.B, 8, 16, s->tvec);                  // t_vec
   const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 : 0;
   const int g3 = 2 * d.S <= 4 ? 4 : (2 * d.S <= 8 ? 8 : 16);
@@ -858,6 +895,7 @@ static int round4(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   const int S = d.S, P1 = S - 1;
   const Slab in3 = slab_of(s, d_in, h_off, 3);
   (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)msg_words(S, d.n, 4) * 4, st);
+  GG_LAUNCH(validate_kernel, c.nPI, d, in3, 4, s->status, s->bad);
   GG_LAUNCH(r4_kernel, c.nPI, d, in3, s->dinv, s->com_all, s->bpk_in, s->kq, s->R, s->Rbar, s->status, s->bad);
   Bump t(s->tmp);
   mpe_pdl_proof pp{t.w(c.nPP * 64), t.w(c.nPP * 16), t.w(c.nPP * 128), t.w(c.nPP * 64), t.w(c.nPP * 25), t.w(c.nPP * 64), t.w(c.nPP * 89)};
@@ -880,6 +918,7 @@ static int round5(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   mpe_ctx* ctx = s->ctx; const mpe_gg20_keys* K = s->K; const Dim& d = s->d; const Counts c = counts_of(d); const mpe_gg20_nonces& Z = s->Z;
   const Slab in4 = slab_of(s, d_in, h_off, 4);
   (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)W5 * 4, st);
+  GG_LAUNCH(validate_kernel, c.nPI, d, in4, 5, s->status, s->bad);
   Bump t(s->tmp);
   int32_t *sub4_pv = t.i(c.nPV), *rdash_pv = t.i(c.nPV);
   uint8_t* ok_pv = t.f(c.nPV);
@@ -904,6 +943,7 @@ static int round6(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   if (rc != MPE_OK) return rc;
   mpe_ctx* ctx = s->ctx; const Dim& d = s->d; const Counts c = counts_of(d);
   const Slab in5 = slab_of(s, d_in, h_off, 5);
+  GG_LAUNCH(validate_kernel, c.nPI, d, in5, 6, s->status, s->bad);
   const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 : 0;
   const int g6 = 3 * d.S <= 8 ? 8 : (3 * d.S <= 16 ? 16 : 32);
   if (c.nPI * g6 <= lanes_fit) GG_LAUNCH(r6_group_kernel, c.nPI * g6, d, g6, in5, s->R, s->tvec, s->K->y, s->status, s->bad);

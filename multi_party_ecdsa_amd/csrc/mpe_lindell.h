@@ -19,7 +19,13 @@ __global__ void __launch_bounds__(64) lindell_p2_prep_kernel(int B, const uint32
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::U256 k = ec::sc_reduce(k2 + (size_t)i * 8, 8);
-  const ec::Aff Rp = ec::jac_to_aff(ec::jac_mul(k, ec::aff_load(R1 + (size_t)i * 16)));   // r = R1 * k2        :401
+  const ec::Aff R1p = ec::aff_load(R1 + (size_t)i * 16);
+  if (!ec::aff_valid(R1p)) {      // the peer's ephemeral point is not on the curve (curv would not have deserialised it): fail closed,
+    for (int j = 0; j < 64; ++j) ps[(size_t)i * 64 + j] = 0u;      // the secret k2 never touches it and c3 becomes Enc(0; r)
+    for (int j = 0; j < 8; ++j) v[(size_t)i * 8 + j] = 0u;
+    return;
+  }
+  const ec::Aff Rp = ec::jac_to_aff(ec::jac_mul(k, R1p));                                  // r = R1 * k2        :401
   const ec::U256 rx = ec::sc_reduce(Rp.x.w, 8);                                            // rx = r.x mod q     :403
   const ec::U256 kinv = ec::sc_inv(k);                                                     // k2_inv             :405
   const ec::U256 t = ec::sc_mul(kinv, ec::sc_reduce(msg + (size_t)i * 8, 8));
@@ -40,7 +46,13 @@ __global__ void __launch_bounds__(64) lindell_p1_finish_kernel(int B, const uint
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::U256 k = ec::sc_reduce(k1 + (size_t)i * 8, 8);
-  const ec::Aff Rp = ec::jac_to_aff(ec::jac_mul(k, ec::aff_load(R2 + (size_t)i * 16)));
+  const ec::Aff R2p = ec::aff_load(R2 + (size_t)i * 16);
+  if (!ec::aff_valid(R2p)) {      // fail closed: no signature leaves, k1 never touches the point
+    for (int j = 0; j < 8; ++j) { r_out[(size_t)i * 8 + j] = 0u; s_out[(size_t)i * 8 + j] = 0u; }
+    recid[i] = -1;
+    return;
+  }
+  const ec::Aff Rp = ec::jac_to_aff(ec::jac_mul(k, R2p));
   const ec::U256 rx = ec::sc_reduce(Rp.x.w, 8), ry = ec::sc_reduce(Rp.y.w, 8);
   ec::U256 s = ec::sc_mul(ec::sc_reduce(s_tag + (size_t)i * 64, 64), ec::sc_inv(k));
   const ec::U256 neg = ec::sc_neg(s);

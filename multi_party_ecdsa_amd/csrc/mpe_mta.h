@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(64) mta_alpha_kernel(int B, const uint32_t* __
   ec::u256_store(alpha + (size_t)i * 8, al);
   const ec::Aff Bpk = ec::aff_load(pk + (size_t)i * 16), BTpk = ec::aff_load(tpk + (size_t)i * 16);
   const ec::Aff R1 = ec::aff_load(R + (size_t)i * 16), R2 = ec::aff_load(tR + (size_t)i * 16);
+  if (!ec::aff_valid(Bpk) || !ec::aff_valid(BTpk) || !ec::aff_valid(R1) || !ec::aff_valid(R2)) { ok[i] = 0; return; }   // the secret a is never multiplied into an unchecked point
   const ec::Jac g_alpha = ec::jac_mul_gen(al);
   const ec::Jac bb = ec::jac_add_aff(ec::jac_mul(ec::sc_reduce(a + (size_t)i * 8, 8), Bpk), BTpk);
   bool good = ec::jac_eq(g_alpha, bb);

@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(64) dlog_verify_kernel(int B, const uint32_t* 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::Aff P = ec::aff_load(pk + (size_t)i * 16), Rp = ec::aff_load(R + (size_t)i * 16);
+  if (!ec::aff_valid(P) || !ec::aff_valid(Rp)) { ok[i] = 0; return; }         // curv rejects such points when it deserialises them
   const ec::U256 c = dlog_challenge(Rp, P), zz = ec::sc_reduce(z + (size_t)i * 8, 8);
   const ec::Jac l = ec::jac_add(ec::jac_mul_gen(zz), ec::jac_mul(c, P));
   ok[i] = ec::jac_eq_aff(l, Rp) ? 1 : 0;
@@ -179,8 +180,10 @@ __global__ void __launch_bounds__(64) pdl_u1_check_kernel(int B, Rows s1, const 
   if (i >= B) return;
   const ec::U256 a = ec::sc_reduce(row_of(s1, i), 25);
   const ec::U256 ne = ec::sc_neg(ec::sc_reduce(e + (size_t)i * 8, 8));
-  const ec::Jac l = ec::jac_add(ec::jac_mul(a, ec::aff_load(row_of(G, i))), ec::jac_mul(ne, ec::aff_load(row_of(Q, i))));
-  if (!ec::jac_eq_aff(l, ec::aff_load(row_of(u1, i)))) ok[i] = 0;
+  const ec::Aff Gp = ec::aff_load(row_of(G, i)), Qp = ec::aff_load(row_of(Q, i)), U1 = ec::aff_load(row_of(u1, i));
+  if (!ec::aff_valid(Gp) || !ec::aff_valid(Qp) || !ec::aff_valid(U1)) { ok[i] = 0; return; }   // statement / proof points come from a peer
+  const ec::Jac l = ec::jac_add(ec::jac_mul(a, Gp), ec::jac_mul(ne, Qp));
+  if (!ec::jac_eq_aff(l, U1)) ok[i] = 0;
 }
 // out = (k mod q) * P with per-item rows (P.p == nullptr -> generator)
 __global__ void __launch_bounds__(64) ec_mul_rows_kernel(int B, Rows k, int kw, Rows P, uint32_t* __restrict__ out) {

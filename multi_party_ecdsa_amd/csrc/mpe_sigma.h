@@ -33,6 +33,7 @@ __global__ void __launch_bounds__(64) pedersen_verify_kernel(int B, mpe_pedersen
   if (i >= B) return;
   const ec::Aff G = ec::aff_gen(), H = ec::aff_h2();
   const ec::Aff C = ec::aff_load(p.com + (size_t)i * 16), a1 = ec::aff_load(p.a1 + (size_t)i * 16), a2 = ec::aff_load(p.a2 + (size_t)i * 16);
+  if (!ec::aff_valid(C) || !ec::aff_valid(a1) || !ec::aff_valid(a2)) { ok[i] = 0; return; }
   const ec::Aff hp[5] = {G, H, C, a1, a2};
   const ec::U256 e = gg::hash_points(hp);
   const ec::Jac lhs = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(p.z1 + (size_t)i * 8, 8)), ec::jac_mul_h2(ec::sc_reduce(p.z2 + (size_t)i * 8, 8)));
@@ -62,6 +63,7 @@ __global__ void __launch_bounds__(64) heg_verify_kernel(int B, mpe_heg_statement
   const ec::Aff G = ec::aff_load(s.G + (size_t)i * 16), H = ec::aff_load(s.H + (size_t)i * 16), Y = ec::aff_load(s.Y + (size_t)i * 16),
                 D = ec::aff_load(s.D + (size_t)i * 16), E = ec::aff_load(s.E + (size_t)i * 16);
   const ec::Aff T = ec::aff_load(p.T + (size_t)i * 16), A3 = ec::aff_load(p.A3 + (size_t)i * 16);
+  if (!(ec::aff_valid(G) && ec::aff_valid(H) && ec::aff_valid(Y) && ec::aff_valid(D) && ec::aff_valid(E) && ec::aff_valid(T) && ec::aff_valid(A3))) { ok[i] = 0; return; }
   const ec::Aff hp[7] = {T, A3, G, H, Y, D, E};
   const ec::U256 e = gg::hash_points(hp), z1 = ec::sc_reduce(p.z1 + (size_t)i * 8, 8), z2 = ec::sc_reduce(p.z2 + (size_t)i * 8, 8);
   const ec::Jac l1 = ec::jac_add(ec::jac_mul(z1, H), ec::jac_mul(z2, Y));

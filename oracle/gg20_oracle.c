@@ -33,6 +33,8 @@
  *   601 phase6_verify_proof, bad_actors = every failing prover         party_i.rs:801-833 (Error::Round6VerifyProof)
  *   602 phase6_check_S_i_sum                                           party_i.rs:835-848 (Error::Round6CheckSig)
  *   701 output_signature: verify failed                                party_i.rs:873-910 (Error::Round7)
+ *   r90 (290 .. 690) a point of a message round r reads is malformed (off the curve, coordinate >= p, infinity): curv's
+ *       deserialisation rejects the message before RoundN::proceed sees it; bad_actors = the senders
  * bad_actors is a bit mask over signer ordinals (positions in s_l), as the reference's Vec<usize>.
  *
  * Compiled into libmpe_oracle.so by #include from mpe_oracle.c (shares its static helpers). */
@@ -250,6 +252,45 @@ static const uint32_t* gg_rec(const uint32_t* in, const int64_t* off, int B, int
   return in + (size_t)(o + b) * (size_t)W;
 }
 static int words_eq(const uint32_t* a, const uint32_t* b, int n) { return memcmp(a, b, (size_t)n * 4) == 0; }
+
+/* Malformed points in the messages a party is about to read: curv's Point deserialisation (coordinates < p, on the curve; the
+ * identity never occurs in an honest message) rejects them before the round runs.  status 100*round + 90, bad_actors = senders. */
+static int pt_words_valid(const uint32_t* w) {
+  ec_setup();
+  mpz_t x, y, l, r; mpz_inits(x, y, l, r, NULL);
+  zin(x, w, 8); zin(y, w + 8, 8);
+  int ok = !(mpz_sgn(x) == 0 && mpz_sgn(y) == 0) && mpz_cmp(x, EC_P) < 0 && mpz_cmp(y, EC_P) < 0;
+  if (ok) {
+    mpz_mul(l, y, y); mpz_mod(l, l, EC_P);
+    mpz_mul(r, x, x); mpz_mul(r, r, x); mpz_add_ui(r, r, 7); mpz_mod(r, r, EC_P);
+    ok = mpz_cmp(l, r) == 0;
+  }
+  mpz_clears(x, y, l, r, NULL);
+  return ok;
+}
+static void gg_validate(orc_gg20_party* P, int b, int round, const uint32_t* in, const int64_t* off) {
+  const int S = P->K.S, n = P->K.n, i = P->ord;
+  const int W = orc_gg20_msg_words(S, n, round - 1);
+  uint32_t mask = 0;
+  for (int j = 0; j < S; ++j) {
+    if (j == i) continue;
+    const uint32_t* m = gg_rec(in, off, P->B, W, j, b);
+    int good = 1;
+    if (round == 2) {
+      for (int v = 0; v < 2; ++v) {
+        const uint32_t* mb = m + (size_t)(jme_of(i, j) * 2 + v) * GG_SUB1;
+        good = good && pt_words_valid(mb + 128) && pt_words_valid(mb + 144) && pt_words_valid(mb + 168) && pt_words_valid(mb + 184);
+      }
+    } else if (round == 3) good = pt_words_valid(m + 8) && pt_words_valid(m + 32) && pt_words_valid(m + 48) && pt_words_valid(m + 64);
+    else if (round == 4) good = pt_words_valid(m + 8);
+    else if (round == 5) {
+      for (int jj = 0; jj < S - 1; ++jj) good = good && pt_words_valid(m + (size_t)jj * GG_SUB4 + 64);
+      good = good && pt_words_valid(m + (size_t)(S - 1) * GG_SUB4);
+    } else if (round == 6) good = pt_words_valid(m) && pt_words_valid(m + 16) && pt_words_valid(m + 32);
+    if (!good) mask |= 1u << j;
+  }
+  if (mask) gg_fail(&P->s[b], 100 * round + 90, mask);
+}
 
 /* ---- Round 0 (rounds.rs:68-104): SignKeys::create, phase1_broadcast, MessageA::a ----------------------------- */
 static void gg_round0(orc_gg20_party* P, int b, uint32_t* out) {
@@ -587,15 +628,16 @@ void orc_gg20_party_round(orc_gg20_party* P, int round, const uint32_t* in, cons
     switch (round) {
       case 0: gg_round0(P, b, o); break;
       case 1: gg_round1(P, b, in, in_off, o); break;
-      case 2: gg_round2(P, b, in, in_off, o); break;
-      case 3: gg_round3(P, b, in, in_off, o); break;
-      case 4: gg_round4(P, b, in, in_off, o); break;
-      case 5: gg_round5(P, b, in, in_off, o); break;
-      case 6: gg_round6(P, b, in, in_off); break;
+      case 2: gg_validate(P, b, 2, in, in_off); gg_round2(P, b, in, in_off, o); break;
+      case 3: gg_validate(P, b, 3, in, in_off); gg_round3(P, b, in, in_off, o); break;
+      case 4: gg_validate(P, b, 4, in, in_off); gg_round4(P, b, in, in_off, o); break;
+      case 5: gg_validate(P, b, 5, in, in_off); gg_round5(P, b, in, in_off, o); break;
+      case 6: gg_validate(P, b, 6, in, in_off); gg_round6(P, b, in, in_off); break;
       case 7: gg_round7(P, b, o); break;
       case 8: gg_complete(P, b, in, in_off); break;
       default: break;
     }
+    if (o && P->s[b].status) memset(o, 0, W * 4);      /* a party that failed has stopped: RoundN::proceed returned Err, nothing is sent */
   }
 }
 /* per-session results of this party: status, bad_actors, SignatureRecid (zero when status != 0), R */

@@ -144,6 +144,14 @@ TAMPERS = [
     ("HEG z2", 5, 1, 56, "flip"),                       # 601, bad_actors = {1}
     ("S_i", 5, 0, 0, "point"),                          # 601 (and the sum)
     ("partial signature", 7, 1, 0, "flip"),             # 701
+    # points that are not on the curve: curv would not deserialise the message -> 100*round + 90, bad_actors = the sender
+    ("off-curve b_proof.pk", 1, 0, 128 + 2, "flip"),    # 290 at the receiver
+    ("off-curve T_i", 2, 1, 8 + 9, "flip"),             # 390
+    ("off-curve g_gamma", 3, 0, 8, "flip"),             # 490
+    ("off-curve R_dash", 4, 1, 450 + 1, "flip"),        # 590 (S = 2: the last sub-record)
+    ("off-curve PDL u1", 4, 0, 64 + 15, "flip"),        # 590
+    ("off-curve S_i", 5, 1, 3, "flip"),                 # 690
+    ("point at infinity as A3", 5, 0, 32, "zero"),      # 690
 ]
 
 
@@ -158,7 +166,9 @@ def test_tampered_message_gives_the_oracles_status_and_bad_actors(gpu_ctx, keys,
     def tamper(r, slab):
         if r != rnd:
             return
-        if kind == "flip":
+        if kind == "zero":
+            slab[sender, 1, word:word + 16] = 0
+        elif kind == "flip":
             slab[sender, 1, word] ^= 4                                      # session 1 only; session 0 stays clean
         else:
             slab[sender, 1, word:word + 16] = _other_point(slab[sender, 1, word:word + 16])
@@ -261,6 +271,44 @@ def test_config4_sessions_byte_identical_to_the_threaded_oracle(gpu_ctx, keys):
         assert list(wstatus[sl]) == [0] * cnt
         assert np.array_equal(r.view(np.uint32)[sl], wr[sl]) and np.array_equal(s.view(np.uint32)[sl], ws[sl])
         assert list(recid[sl]) == list(wrecid[sl]) and np.array_equal(R.view(np.uint32)[sl], wR[sl])
+
+
+def test_config5_share_t2n5_at_8192_sessions(gpu_ctx, keys):
+    """BASELINE config 5's per-GPU share (t=2, n=5, three signers, 8 192 concurrent sessions): all signed; a sample checked
+    against the oracle bit for bit (the same function bench.py reports as configs.c5_share_t2n5_8192)."""
+    import bench
+    from multi_party_ecdsa_amd import engine as E
+    gen = torch.Generator(device=gpu_ctx.device)
+    gen.manual_seed(55)
+    res = bench.gg20_config(gpu_ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=24)
+    assert res["all_sessions_signed"] and res["parity_vs_oracle_on_sample"]
+
+
+def test_multi_wallet_batch_round_robin_16_key_sets(gpu_ctx, keys):
+    """SURVEY.md 8d config 4 allows "16 fixtures round-robin": one batch whose sessions belong to different wallets
+    (key sets): byte-identical to the oracle run with the same per-session key set."""
+    from multi_party_ecdsa_amd import engine as E
+    K, t, n, signers, B = 5, 1, 3, [0, 1], 11
+    lks = [G.make_local_keys(keys[kk:] + keys[:kk], t, n, signers, seed=f"wallet-{kk}") for kk in range(K)]
+    arrays = {f: np.concatenate([lk["arrays"][f] for lk in lks]) for f in ("x", "p", "q", "Nt", "h1", "h2", "y", "X")}
+    arrays["signers"] = lks[0]["arrays"]["signers"]
+    lkm = dict(lks[0], arrays=arrays, nkeysets=K)
+    keyset = np.array([b % K for b in range(B)], dtype=np.int32)
+    r0 = F.Rng("multi-wallet")
+    # nonces must respect every wallet's own moduli: draw them per session from that wallet's fixture
+    parts = [G.make_nonces(lks[int(keyset[b])], 1, seed=f"mw-{b}") for b in range(B)]
+    nonces = {f: np.concatenate([p[f] for p in parts]) for f in parts[0]}
+    want = G.oracle_sign_ex(lkm, nonces, B, keyset=keyset)
+    assert not want["status"].any()
+    gk = E.Gg20Keys(gpu_ctx, t, n, signers, arrays, nkeysets=K)
+    r, s, recid, status, R = E.gg20_sign(gpu_ctx, gk, {f: _dev(gpu_ctx, v) for f, v in nonces.items()}, B, want_R=True,
+                                         keyset=torch.from_numpy(keyset).to(gpu_ctx.device))
+    gpu_ctx.sync()
+    assert list(status.cpu().numpy()) == [0] * B
+    assert np.array_equal(_u32(r), want["r"]) and np.array_equal(_u32(s), want["s"]) and list(recid.cpu().numpy()) == list(want["recid"])
+    for b in range(B):
+        m = F.ints(nonces["msg"][b:b + 1])[0]
+        assert pyref.ecdsa_verify(lks[int(keyset[b])]["y"], m, F.ints(want["r"][b:b + 1])[0], F.ints(want["s"][b:b + 1])[0])
 
 
 def test_inconsistent_key_share_is_caught_with_the_oracles_status(gpu_ctx, keys):
