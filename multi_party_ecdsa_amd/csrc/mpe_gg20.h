@@ -789,14 +789,22 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   const int n = d.n;
   (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)msg_words(d.S, n, 0) * 4, st);
   GG_LAUNCH(r0_kernel, c.nPI, d, K->x, Z.k, Z.gamma, Z.blind, s->kq, s->gq, s->w, s->k64, s->g_gamma, s->com);
-  if (rc == MPE_OK) rc = paillier_encrypt(ctx, K->prv, (int)c.nPI, s->ix.kown_pi, s->k64, Z.r_a, s->c_a, true, st);      // MessageA.c
+  // small batches: the encryption of k_i runs beside the first half of the range proofs (the proofs need c only for their
+  // transcript hash); both composites draw from ONE workspace reservation
+  const bool par = ctx->allow_par && (int)c.nAP <= ctx->par_items;
+  if (par && rc == MPE_OK) { rc = ws_reserve(ctx, ws_need_encrypt((int)c.nPI) + ws_need_alice_generate((int)c.nAP), st); if (rc == MPE_OK) ctx->ws_hold++; }
+  const bool held = par && rc == MPE_OK;
+  Fork g(ctx, st, 2, held, 2);
+  if (rc == MPE_OK) rc = paillier_encrypt(ctx, K->prv, (int)c.nPI, s->ix.kown_pi, s->k64, Z.r_a, s->c_a, true, g.s(1));      // MessageA.c
   gg_trace(st, "encrypt k", rc);
   Bump t(s->tmp);
   mpe_alice_proof ap{t.w(c.nAP * 64), t.w(c.nAP * 8), t.w(c.nAP * 64), t.w(c.nAP * 25), t.w(c.nAP * 89)};
   mpe_alice_nonces an{Z.al_alpha, Z.al_beta, Z.al_gamma, Z.al_rho};
   if (rc == MPE_OK)
     rc = alice_generate(ctx, K->prv, K->stm, (int)c.nAP, s->ix.kown_ap, s->ix.st_ap, rows(s->kq, 8, s->ix.pi_ap),
-                        rows(s->c_a, 128, s->ix.pi_ap), rows(Z.r_a, 64, s->ix.pi_ap), &an, &ap, st);
+                        rows(s->c_a, 128, s->ix.pi_ap), rows(Z.r_a, 64, s->ix.pi_ap), &an, &ap, st, &g);
+  else g.join();
+  if (held) ctx->ws_hold--;
   gg_trace(st, "alice_generate", rc);
   PACK(c.nAP, n, n + 1, 0, SUB0, 0, ap.z, 64); PACK(c.nAP, n, n + 1, 0, SUB0, 64, ap.e, 8); PACK(c.nAP, n, n + 1, 0, SUB0, 72, ap.s, 64);
   PACK(c.nAP, n, n + 1, 0, SUB0, 136, ap.s1, 25); PACK(c.nAP, n, n + 1, 0, SUB0, 161, ap.s2, 89);
@@ -821,20 +829,34 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   uint32_t *bsel = t.w(c.nMB * 8), *btq = t.w(c.nMB * 8), *c_b = t.w(c.nMB * 128);
   uint32_t *Bpk = t.w(c.nMB * 16), *BR = t.w(c.nMB * 16), *Bz = t.w(c.nMB * 8), *BTpk = t.w(c.nMB * 16), *BTR = t.w(c.nMB * 16), *BTz = t.w(c.nMB * 8);
   GG_LAUNCH(idx1_kernel, c.nVI, d, in0, sub0_vi);
+  // small batches: the verification of the peers' range proofs and the construction of my MessageBs are independent
+  // (the reference runs them back to back inside MessageB::b) — two streams, one workspace reservation
+  const bool par = ctx->allow_par && (int)c.nVI <= ctx->par_items;
+  if (par && rc == MPE_OK) { rc = ws_reserve(ctx, ws_need_alice_verify((int)c.nVI) + ws_need_mul_add_enc((int)c.nMB), st); if (rc == MPE_OK) ctx->ws_hold++; }
+  const bool held = par && rc == MPE_OK;
+  Fork g(ctx, st, 2, held, 2);
+  {
+    hipStream_t st2 = g.s(1);
+    if (rc == MPE_OK && c.nMB > 0)
+      hipLaunchKernelGGL(mb_prep_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, d, s->gq, s->w, Z.mb_beta_tag, bsel, btq, s->beta);
+    if (rc == MPE_OK)                                                           // encrypt, Paillier::mul, Paillier::add :133-145
+      rc = paillier_mul_add_enc(ctx, K->pub, (int)c.nMB, s->ix.kpub_mb, rows(s->ca_all, 128, s->ix.ca_mb), rows(bsel, 8), 8, Z.mb_beta_tag,
+                                Z.mb_r, c_b, st2);
+    gg_trace(st2, "MessageB ciphertext", rc);
+    if (rc == MPE_OK && c.nMB > 0) {
+      hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, bsel, Z.mb_nonce_b, Bpk, BR, Bz);      // :147
+      hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, btq, Z.mb_nonce_bt, BTpk, BTR, BTz);   // :148
+    }
+  }
   if (rc == MPE_OK) {      // every range proof of every peer, for both MessageB::b calls (mta/mod.rs:119-131), read in place
     AliceProofRows pr{rows(d_in, SUB0, sub0_vi), rows(d_in + 64, SUB0, sub0_vi), rows(d_in + 72, SUB0, sub0_vi),
                       rows(d_in + 136, SUB0, sub0_vi), rows(d_in + 161, SUB0, sub0_vi)};
     rc = alice_verify(ctx, K->pub, K->stm, (int)c.nVI, s->ix.kpub_vi, s->ix.st_vi, rows(s->ca_all, 128, s->ix.ca_vi), pr, ok_vi, st);
   }
   gg_trace(st, "alice_verify", rc);
+  g.join();
+  if (held) ctx->ws_hold--;
   GG_LAUNCH(status1_kernel, c.nPI, d, ok_vi, s->status, s->bad);
-  GG_LAUNCH(mb_prep_kernel, c.nMB, d, s->gq, s->w, Z.mb_beta_tag, bsel, btq, s->beta);
-  if (rc == MPE_OK)                                                             // encrypt, Paillier::mul, Paillier::add :133-145
-    rc = paillier_mul_add_enc(ctx, K->pub, (int)c.nMB, s->ix.kpub_mb, rows(s->ca_all, 128, s->ix.ca_mb), rows(bsel, 8), 8, Z.mb_beta_tag,
-                              Z.mb_r, c_b, st);
-  gg_trace(st, "MessageB ciphertext", rc);
-  GG_LAUNCH(dlog_prove_kernel, c.nMB, (int)c.nMB, bsel, Z.mb_nonce_b, Bpk, BR, Bz);                                     // :147
-  GG_LAUNCH(dlog_prove_kernel, c.nMB, (int)c.nMB, btq, Z.mb_nonce_bt, BTpk, BTR, BTz);                                  // :148
   const int per = 2 * P1;
   PACK(c.nMB, per, per, 0, SUB1, 0, c_b, 128); PACK(c.nMB, per, per, 0, SUB1, 128, Bpk, 16); PACK(c.nMB, per, per, 0, SUB1, 144, BR, 16);
   PACK(c.nMB, per, per, 0, SUB1, 160, Bz, 8); PACK(c.nMB, per, per, 0, SUB1, 168, BTpk, 16); PACK(c.nMB, per, per, 0, SUB1, 184, BTR, 16);

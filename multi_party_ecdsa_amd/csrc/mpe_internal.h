@@ -22,11 +22,22 @@ struct mpe_ctx {
   bool use_crt = true;            // key holders compute x^e mod N^2 through p^2 | q^2 (mpe_paillier.h modexp_nn)
   bool use_fixed_base = true;     // h1/h2 exponentiations through per-statement window tables (mpe_fixedbase.h)
   int modexp_waves_per_cu = 8;    // 2 waves/SIMD: the montmul loop holds ~230 VGPRs and already issues back-to-back
-  void* tables = nullptr;         // window-table scratch, grown on demand
-  size_t tables_bytes = 0;
+  // window-table scratch, grown on demand: one buffer per stream slot (0 = the caller's stream, 1..3 = the auxiliary streams
+  // on which small batches run independent launches concurrently)
+  void* tables[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t tables_bytes[4] = {0, 0, 0, 0};
+  // Small batches are latency-bound (a launch lasts as long as ONE exponentiation): independent parts of a proof / a round
+  // run on auxiliary streams, forked from and joined to the caller's stream with events (mpe::Fork).
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
+  bool aux_ready = false;
+  bool allow_par = true;          // MPE_NO_PAR=1 switches the concurrency off (A/B runs)
+  int par_items = 32768;          // composites fork when they have at most this many items
   // bump-allocated workspace for the intermediates of composite operations (Paillier, proofs)
   void* ws = nullptr;
   size_t ws_bytes = 0, ws_off = 0;
+  int ws_hold = 0;                // > 0: a caller runs several composites concurrently out of ONE reservation: ws_reserve only checks
+  size_t ws_top = 0;              // bytes a composite keeps at the TOP of the workspace (its own arrays): never handed out, never moved
   // cached device memory of the GG20 round pipeline: one session object's state (mpe_gg20_session) and the message slabs of
   // mpe_gg20_sign — kept across calls so that a step does not pay hipMalloc / hipFree
   void* sess_buf = nullptr;
@@ -99,6 +110,17 @@ int pair_modexp_1024(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
 // workspace: reserve once per composite call (may reallocate -> synchronises the stream), then bump-allocate
 int ws_reserve(mpe_ctx* ctx, size_t bytes, hipStream_t st);
 void* ws_alloc(mpe_ctx* ctx, size_t bytes);
+// window-table scratch of the stream slot `st` belongs to (nullptr + error set when it cannot be grown)
+uint32_t* tables_for(mpe_ctx* ctx, size_t need, hipStream_t st);
+
+// fork / join of up to 3 concurrent branches: branch 0 stays on the caller's stream, branch i > 0 runs on an auxiliary stream.
+// `first`: which auxiliary streams (composite-internal forks use 0, 1; the round-level fork uses 2 so that the two nest).
+struct Fork {
+  mpe_ctx* ctx; hipStream_t main; int n, first; bool on;
+  Fork(mpe_ctx* c, hipStream_t m, int branches, bool enable, int first_aux = 0);
+  hipStream_t s(int i) const { return (on && i > 0) ? ctx->aux[first + i - 1] : main; }
+  void join();
+};
 template <class T>
 inline T* ws_array(mpe_ctx* ctx, size_t count) { return (T*)ws_alloc(ctx, count * sizeof(T)); }
 

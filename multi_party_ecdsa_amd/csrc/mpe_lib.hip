@@ -14,8 +14,13 @@ void mpe_set_error_msg(const char* what) { g_last_error = what; }
 namespace mpe {
 
 int ws_reserve(mpe_ctx* ctx, size_t bytes, hipStream_t st) {
+  if (ctx->ws_hold) {               // several composites share one reservation (they run concurrently): no reset, no move
+    if (ctx->ws_off + bytes + ctx->ws_top > ctx->ws_bytes) { mpe_set_error_msg("workspace: the shared reservation is too small"); return MPE_E_NOMEM; }
+    return MPE_OK;
+  }
   ctx->ws_off = 0;
-  if (bytes <= ctx->ws_bytes) return MPE_OK;
+  if (bytes + ctx->ws_top <= ctx->ws_bytes) return MPE_OK;
+  if (ctx->ws_top) { mpe_set_error_msg("workspace: cannot grow while a caller keeps arrays at its top"); return MPE_E_NOMEM; }
   if (ctx->ws) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
   const size_t want = bytes + (bytes >> 2) + (1u << 20);
   hipError_t e = hipMalloc(&ctx->ws, want);
@@ -25,9 +30,46 @@ int ws_reserve(mpe_ctx* ctx, size_t bytes, hipStream_t st) {
 }
 void* ws_alloc(mpe_ctx* ctx, size_t bytes) {
   const size_t off = (ctx->ws_off + 255) & ~(size_t)255;
-  if (off + bytes > ctx->ws_bytes) return nullptr;     // ws_reserve under-estimated: a library bug
+  if (off + bytes + ctx->ws_top > ctx->ws_bytes) return nullptr;     // ws_reserve under-estimated: a library bug
   ctx->ws_off = off + bytes;
   return (char*)ctx->ws + off;
+}
+
+static int slot_of(const mpe_ctx* ctx, hipStream_t st) {
+  for (int i = 0; i < 3; ++i) if (ctx->aux[i] && st == ctx->aux[i]) return i + 1;
+  return 0;
+}
+uint32_t* tables_for(mpe_ctx* ctx, size_t need, hipStream_t st) {
+  const int sl = slot_of(ctx, st);
+  if (need > ctx->tables_bytes[sl]) {
+    if (ctx->tables[sl]) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->tables[sl]); ctx->tables[sl] = nullptr; ctx->tables_bytes[sl] = 0; }
+    hipError_t e = hipMalloc(&ctx->tables[sl], need);
+    if (e != hipSuccess) { mpe_set_error("hipMalloc(window tables)", e); return nullptr; }
+    ctx->tables_bytes[sl] = need;
+  }
+  return (uint32_t*)ctx->tables[sl];
+}
+static bool ensure_aux(mpe_ctx* ctx) {
+  if (ctx->aux_ready) return true;
+  for (int i = 0; i < 3; ++i) if (hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) != hipSuccess) return false;
+  for (int i = 0; i < 2; ++i) if (hipEventCreateWithFlags(&ctx->ev_fork[i], hipEventDisableTiming) != hipSuccess) return false;
+  for (int i = 0; i < 3; ++i) if (hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) != hipSuccess) return false;
+  ctx->aux_ready = true;
+  return true;
+}
+Fork::Fork(mpe_ctx* c, hipStream_t m, int branches, bool enable, int first_aux) : ctx(c), main(m), n(branches), first(first_aux) {
+  on = enable && c->allow_par && branches > 1 && first_aux + branches - 1 <= 3 && ensure_aux(c);
+  if (!on) return;
+  hipEvent_t ev = c->ev_fork[first_aux ? 1 : 0];
+  (void)hipEventRecord(ev, m);
+  for (int i = 1; i < n; ++i) (void)hipStreamWaitEvent(c->aux[first + i - 1], ev, 0);
+}
+void Fork::join() {
+  if (!on) return;
+  for (int i = 1; i < n; ++i) {
+    (void)hipEventRecord(ctx->ev_join[first + i - 1], ctx->aux[first + i - 1]);
+    (void)hipStreamWaitEvent(main, ctx->ev_join[first + i - 1], 0);
+  }
 }
 
 void prof_begin(mpe_ctx* ctx, hipStream_t st, int kind, int bits, int exp_words, int batch, int exp2_words) {
@@ -112,15 +154,11 @@ static int modexp_impl(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_s
     return MPE_E_ARG;
   }
   const size_t need = (size_t)grid * C::GROUPS * (((size_t)1 << wb) + (dual ? 16 : 0)) * C::K * sizeof(uint32_t);
-  if (need > ctx->tables_bytes) {
-    if (ctx->tables) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->tables); ctx->tables = nullptr; ctx->tables_bytes = 0; }
-    hipError_t e = hipMalloc(&ctx->tables, need);
-    if (e != hipSuccess) { mpe_set_error("hipMalloc(window tables)", e); return MPE_E_NOMEM; }
-    ctx->tables_bytes = need;
-  }
+  uint32_t* tabs = tables_for(ctx, need, st);
+  if (!tabs) return MPE_E_NOMEM;
   prof_begin(ctx, st, 0, C::BITS, exp_words, batch, dual ? exp2_words : 0);
   hipLaunchKernelGGL(modexp_kernel<C>, dim3(grid), dim3(64), 0, st, batch, view_of(ms), mod_sel, base_lo, base_hi, exps,
-                     exp_words, wb, base2, exps2, exp2_words, d_out, (uint32_t*)ctx->tables);
+                     exp_words, wb, base2, exps2, exp2_words, d_out, tabs);
   prof_end(ctx, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("modexp_kernel", e); return MPE_E_HIP; }
@@ -235,6 +273,7 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   if (getenv("MPE_NO_PAIR")) c->use_pair = false;
   if (getenv("MPE_FB_WINDOW_BITS")) { const int w = atoi(getenv("MPE_FB_WINDOW_BITS")); if (w >= 4 && w <= 16) c->fb_window_bits = w; }
   if (getenv("MPE_NO_POWN")) c->use_pown = false;
+  if (getenv("MPE_NO_PAR")) c->allow_par = false;
   if (getenv("MPE_NO_ADAPTIVE_LANES")) { c->adaptive_lanes = false; c->ec_lane_groups = false; }
   if (getenv("MPE_WINDOW_BITS")) { const int w = atoi(getenv("MPE_WINDOW_BITS")); if (w >= 4 && w <= 6) c->window_bits = w; }
   // comb tables of the two fixed secp256k1 generators (module globals of this device; identical on every call)
@@ -250,7 +289,7 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
 int mpe_ctx_wipe(mpe_ctx* ctx, void* stream) {
   if (!ctx) return MPE_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (ctx->tables) (void)hipMemsetAsync(ctx->tables, 0, ctx->tables_bytes, st);
+  for (int i = 0; i < 4; ++i) if (ctx->tables[i]) (void)hipMemsetAsync(ctx->tables[i], 0, ctx->tables_bytes[i], st);
   if (ctx->ws) (void)hipMemsetAsync(ctx->ws, 0, ctx->ws_bytes, st);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("mpe_ctx_wipe", e); return MPE_E_HIP; }
@@ -273,10 +312,11 @@ int mpe_ctx_scratch_audit(mpe_ctx* ctx, uint64_t* nonzero_words, uint64_t* total
   hipError_t e = hipMalloc((void**)&d, 8);
   if (e != hipSuccess) { mpe_set_error("hipMalloc(audit)", e); return MPE_E_NOMEM; }
   (void)hipMemsetAsync(d, 0, 8, st);
-  const void* ptrs[4] = {ctx->tables, ctx->ws, ctx->sess_buf, ctx->slab_buf};
-  const size_t bytes[4] = {ctx->tables_bytes, ctx->ws_bytes, ctx->sess_bytes, ctx->slab_bytes};
+  const void* ptrs[7] = {ctx->tables[0], ctx->tables[1], ctx->tables[2], ctx->tables[3], ctx->ws, ctx->sess_buf, ctx->slab_buf};
+  const size_t bytes[7] = {ctx->tables_bytes[0], ctx->tables_bytes[1], ctx->tables_bytes[2], ctx->tables_bytes[3], ctx->ws_bytes,
+                           ctx->sess_bytes, ctx->slab_bytes};
   uint64_t tot = 0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 7; ++i) {
     if (!ptrs[i] || !bytes[i]) continue;
     tot += bytes[i];
     hipLaunchKernelGGL(count_nonzero_kernel, dim3(4096), dim3(256), 0, st, (const uint32_t*)ptrs[i], bytes[i] / 4, d);
@@ -299,8 +339,12 @@ int mpe_ctx_destroy(mpe_ctx* ctx) {
   (void)hipDeviceSynchronize();
   if (ctx->sess_buf) (void)hipFree(ctx->sess_buf);
   if (ctx->slab_buf) (void)hipFree(ctx->slab_buf);
-  if (ctx->tables) (void)hipFree(ctx->tables);
+  for (int i = 0; i < 4; ++i) if (ctx->tables[i]) (void)hipFree(ctx->tables[i]);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->aux_ready) {
+    for (int i = 0; i < 3; ++i) { (void)hipStreamDestroy(ctx->aux[i]); (void)hipEventDestroy(ctx->ev_join[i]); }
+    for (int i = 0; i < 2; ++i) (void)hipEventDestroy(ctx->ev_fork[i]);
+  }
   for (auto& ev : ctx->prof) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   delete ctx;
   return MPE_OK;

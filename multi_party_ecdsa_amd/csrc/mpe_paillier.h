@@ -337,9 +337,13 @@ static int modexp_nn2(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Ro
   return launch_modexp2(ctx, pk->ms_nn, B, ksel, base, exps, ew, base2, exps2, ew2, out, st);
 }
 
+// workspace needs of the composites (a caller that runs several of them concurrently reserves the sum once)
+static inline size_t ws_need_encrypt(int B) { return (size_t)B * (256 + CRT_WS_WORDS) * 4 + 8192; }
+static inline size_t ws_need_mul_add_enc(int B) { return (size_t)B * 128 * 4 * 3 + 8192; }
+
 static int paillier_encrypt(mpe_ctx* ctx, const mpe_paillier* pk, int B, const int32_t* key_idx, const uint32_t* d_m,
                             const uint32_t* d_r, uint32_t* d_c, bool holder, hipStream_t st) {
-  MPE_TRY(ws_reserve(ctx, (size_t)B * (256 + CRT_WS_WORDS) * 4 + 8192, st));
+  MPE_TRY(ws_reserve(ctx, ws_need_encrypt(B), st));
   uint32_t* x = ws_array<uint32_t>(ctx, (size_t)B * 128);
   uint32_t* gm = ws_array<uint32_t>(ctx, (size_t)B * 128);
   // r^N mod N^2
@@ -354,7 +358,7 @@ static int paillier_encrypt(mpe_ctx* ctx, const mpe_paillier* pk, int B, const i
 // it does not own; r^N and c_a^k share one ladder.
 static int paillier_mul_add_enc(mpe_ctx* ctx, const mpe_paillier* pk, int B, const int32_t* key_idx, Rows c_a, Rows k, int kw,
                                 const uint32_t* d_m, const uint32_t* d_r, uint32_t* d_out, hipStream_t st) {
-  MPE_TRY(ws_reserve(ctx, (size_t)B * 128 * 4 * 3 + 8192, st));
+  MPE_TRY(ws_reserve(ctx, ws_need_mul_add_enc(B), st));
   uint32_t* x = ws_array<uint32_t>(ctx, (size_t)B * 128);
   uint32_t* gm = ws_array<uint32_t>(ctx, (size_t)B * 128);
   const Rows ksel = key_selector(pk, key_idx), Nrow = key_rows(pk, pk->N, 64, key_idx);

@@ -509,16 +509,12 @@ int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
     return MPE_E_ARG;
   }
   const size_t need = (size_t)grid * C::GROUPS * (((size_t)1 << wb) + (dual ? 16 : 0)) * 2 * C::K * sizeof(uint32_t);
-  if (need > ctx->tables_bytes) {
-    if (ctx->tables) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->tables); ctx->tables = nullptr; ctx->tables_bytes = 0; }
-    hipError_t e = hipMalloc(&ctx->tables, need);
-    if (e != hipSuccess) { mpe_set_error("hipMalloc(window tables)", e); return MPE_E_NOMEM; }
-    ctx->tables_bytes = need;
-  }
+  uint32_t* tabs = tables_for(ctx, need, st);
+  if (!tabs) return MPE_E_NOMEM;
   PairsetView v{ps->n_limbs, ps->n0inv, ps->one, ps->r2, ps->tp, ps->kc, ps->count};
   prof_begin(ctx, st, half ? 4 : 3, half ? C::BITS : 2 * C::BITS, exp_words, batch, dual ? exp2_words : 0);
   hipLaunchKernelGGL(pair_modexp_kernel<C>, dim3(grid), dim3(64), 0, st, batch, v, mod_sel, base, exps, exp_words, wb, base2,
-                     exps2, exp2_words, half, d_out, (uint32_t*)ctx->tables);
+                     exps2, exp2_words, half, d_out, tabs);
   prof_end(ctx, st);
   hipLaunchKernelGGL(pair_finish_kernel<C::K32>, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, mod_sel, ps->mod_words, d_out);
   hipError_t e = hipGetLastError();

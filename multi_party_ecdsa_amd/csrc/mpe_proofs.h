@@ -285,28 +285,38 @@ static Rows with_words(Rows r, int words) { r.words = words; return r; }
 
 // ---------------------------------------------------------------------------------------------
 // AliceProof::generate   (range_proofs.rs:160-193; rounds :39-67 and :78-90)
+// Small batches: z, u and w are independent and run on three streams (mpe::Fork); `outer`: a fork of the CALLER that
+// produces `cipher` concurrently (Round 0 encrypts k_i on another stream) — joined right before the transcript hash.
 // ---------------------------------------------------------------------------------------------
+static inline size_t ws_need_alice_generate(int B) { return (size_t)B * (1400 + CRT_WS_WORDS) * 4 + 65536; }
+static inline size_t ws_need_alice_verify(int B) { return (size_t)B * 1800 * 4 + 65536; }
+static int merge_rc(const Seq& a, const Seq& b, const Seq& c) { return a.rc != MPE_OK ? a.rc : (b.rc != MPE_OK ? b.rc : c.rc); }
+
 static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
                           const int32_t* st_idx, Rows a, Rows cipher, Rows r,
-                          const mpe_alice_nonces* nn, const mpe_alice_proof* out, hipStream_t st) {
-  MPE_TRY(ws_reserve(ctx, (size_t)B * (1400 + CRT_WS_WORDS) * 4 + 65536, st));
-  Seq q{ctx, st, B};
+                          const mpe_alice_nonces* nn, const mpe_alice_proof* out, hipStream_t st, Fork* outer = nullptr) {
+  MPE_TRY(ws_reserve(ctx, ws_need_alice_generate(B), st));
+  Fork f(ctx, st, 3, B <= ctx->par_items);
+  Seq q{ctx, f.s(0), B}, q1{ctx, f.s(1), B}, q2{ctx, f.s(2), B};
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
   const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
   // z = h1^a h2^rho mod N~                                                      :52
-  uint32_t* z1 = q.fb_modexp(stm, ssel, 0, h1,a, 8);
-  uint32_t* z2 = q.fb_modexp(stm, ssel, 1, h2,rows(nn->rho, 72), 72);
-  q.modmul_to(stm->ms, ssel, rows(z1, 64), rows(z2, 64), out->z);
+  uint32_t* z1 = q1.fb_modexp(stm, ssel, 0, h1,a, 8);
+  uint32_t* z2 = q1.fb_modexp(stm, ssel, 1, h2,rows(nn->rho, 72), 72);
+  q1.modmul_to(stm->ms, ssel, rows(z1, 64), rows(z2, 64), out->z);
   // u = (alpha N + 1) beta^N mod N^2                                            :53-55
   uint32_t* gu = q.words(128);
   q.muladd(rows(nn->alpha, 24), 24, Nrow, 64, no_rows(), 0, gu, 128);
   uint32_t* bn = q.modexp_nn(pk, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64, true, true);   // the prover owns the key
   uint32_t* u = q.modmul(pk->ms_nn, ksel, rows(gu, 128), rows(bn, 128));
   // w = h1^alpha h2^gamma mod N~                                                :56-57
-  uint32_t* w1 = q.fb_modexp(stm, ssel, 0, h1,rows(nn->alpha, 24), 24);
-  uint32_t* w2 = q.fb_modexp(stm, ssel, 1, h2,rows(nn->gamma, 88), 88);
-  uint32_t* w = q.modmul(stm->ms, ssel, rows(w1, 64), rows(w2, 64));
+  uint32_t* w1 = q2.fb_modexp(stm, ssel, 0, h1,rows(nn->alpha, 24), 24);
+  uint32_t* w2 = q2.fb_modexp(stm, ssel, 1, h2,rows(nn->gamma, 88), 88);
+  uint32_t* w = q2.modmul(stm->ms, ssel, rows(w1, 64), rows(w2, 64));
+  f.join();
+  if (outer) outer->join();
+  q.rc = merge_rc(q, q1, q2);
   // e = H(N, N+1, c, z, u, w)                                                   :175-182
   HashDesc d;
   d.n = 6;
@@ -322,24 +332,24 @@ static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statem
 }
 
 // ---------------------------------------------------------------------------------------------
-// AliceProof::verify   (range_proofs.rs:105-156)
+// AliceProof::verify   (range_proofs.rs:105-156).  Small batches: the N~ side and the N^2 side on separate streams.
 // ---------------------------------------------------------------------------------------------
 static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
                         const int32_t* st_idx, Rows cipher, const AliceProofRows& pr, uint8_t* ok, hipStream_t st) {
-  MPE_TRY(ws_reserve(ctx, (size_t)B * 1800 * 4 + 65536, st));
-  Seq q{ctx, st, B};
+  MPE_TRY(ws_reserve(ctx, ws_need_alice_verify(B), st));
+  Fork f(ctx, st, 3, B <= ctx->par_items);
+  Seq q{ctx, f.s(0), B}, q1{ctx, f.s(1), B}, q2{ctx, f.s(2), B};
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
   const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
   MPE_LAUNCH_1D(s1_range_kernel, B, st, B, pr.s1, 25, ok);                                         // :118
   // w' = h1^s1 h2^s2 (z^e)^-1 mod N~                                                               :122-132
   uint8_t *inv_ok1 = q.flags(), *inv_ok2 = q.flags();
-  uint32_t* ze = q.modexp(stm->ms, ssel, pr.z, pr.e, 8);
-  uint32_t* zei = q.modinv(stm->ms, ssel, rows(ze, 64), inv_ok1);
-  uint32_t* a1 = q.fb_modexp(stm, ssel, 0, h1,pr.s1, 25);
-  uint32_t* a2 = q.fb_modexp(stm, ssel, 1, h2,pr.s2, 89);
-  uint32_t* a12 = q.modmul(stm->ms, ssel, rows(a1, 64), rows(a2, 64));
-  uint32_t* w = q.modmul(stm->ms, ssel, rows(a12, 64), rows(zei, 64));
+  uint32_t* ze = q1.modexp(stm->ms, ssel, pr.z, pr.e, 8);
+  uint32_t* zei = q1.modinv(stm->ms, ssel, rows(ze, 64), inv_ok1);
+  uint32_t* a1 = q2.fb_modexp(stm, ssel, 0, h1,pr.s1, 25);
+  uint32_t* a2 = q2.fb_modexp(stm, ssel, 1, h2,pr.s2, 89);
+  uint32_t* a12 = q2.modmul(stm->ms, ssel, rows(a1, 64), rows(a2, 64));
   // u' = (s1 N + 1) s^N (c^e)^-1 mod N^2                                                           :134-141
   uint32_t* gs1 = q.words(128);
   q.muladd(pr.s1, 25, Nrow, 64, no_rows(), 0, gs1, 128);
@@ -357,6 +367,9 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
     uint32_t* b12 = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(sn, 128));
     u = q.modmul(pk->ms_nn, ksel, rows(b12, 128), rows(cei, 128));
   }
+  f.join();
+  q.rc = merge_rc(q, q1, q2);
+  uint32_t* w = q.modmul(stm->ms, ssel, rows(a12, 64), rows(zei, 64));
   // e' = H(N, N+1, c, z, u', w') == e                                                              :143-153
   uint32_t* e2 = q.words(8);
   HashDesc d;
@@ -376,25 +389,28 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
                      const int32_t* st_idx, Rows cipher, Rows Qp, Rows Gp, Rows x, Rows r, const mpe_pdl_nonces* nn,
                      const mpe_pdl_proof* out, hipStream_t st) {
   MPE_TRY(ws_reserve(ctx, (size_t)B * (1400 + CRT_WS_WORDS) * 4 + 65536, st));
-  Seq q{ctx, st, B};
+  Fork f(ctx, st, 3, B <= ctx->par_items);
+  Seq q{ctx, f.s(0), B}, q1{ctx, f.s(1), B}, q2{ctx, f.s(2), B};
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
   const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
   // z = h1^x h2^rho mod N~                                                      :79-85
-  uint32_t* z1 = q.fb_modexp(stm, ssel, 0, h1,x, 8);
-  uint32_t* z2 = q.fb_modexp(stm, ssel, 1, h2,rows(nn->rho, 72), 72);
-  q.modmul_to(stm->ms, ssel, rows(z1, 64), rows(z2, 64), out->z);
+  uint32_t* z1 = q1.fb_modexp(stm, ssel, 0, h1,x, 8);
+  uint32_t* z2 = q1.fb_modexp(stm, ssel, 1, h2,rows(nn->rho, 72), 72);
+  q1.modmul_to(stm->ms, ssel, rows(z1, 64), rows(z2, 64), out->z);
   // u1 = (alpha mod q) G                                                        :86
-  MPE_LAUNCH_1D(ec_mul_rows_kernel, B, st, B, rows(nn->alpha, 24), 24, Gp, out->u1);
+  if (B > 0) hipLaunchKernelGGL(ec_mul_rows_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, f.s(1), B, rows(nn->alpha, 24), 24, Gp, out->u1);
   // u2 = (N+1)^alpha beta^N mod N^2; (N+1)^alpha = 1 + alpha N (mod N^2), alpha N + 1 < N^2      :87-93
   uint32_t* ga = q.words(128);
   q.muladd(rows(nn->alpha, 24), 24, Nrow, 64, no_rows(), 0, ga, 128);
   uint32_t* bn = q.modexp_nn(pk, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64, true, true);   // the prover owns the key
   q.modmul_to(pk->ms_nn, ksel, rows(ga, 128), rows(bn, 128), out->u2);
   // u3 = h1^alpha h2^gamma mod N~                                               :94-100
-  uint32_t* w1 = q.fb_modexp(stm, ssel, 0, h1,rows(nn->alpha, 24), 24);
-  uint32_t* w2 = q.fb_modexp(stm, ssel, 1, h2,rows(nn->gamma, 88), 88);
-  q.modmul_to(stm->ms, ssel, rows(w1, 64), rows(w2, 64), out->u3);
+  uint32_t* w1 = q2.fb_modexp(stm, ssel, 0, h1,rows(nn->alpha, 24), 24);
+  uint32_t* w2 = q2.fb_modexp(stm, ssel, 1, h2,rows(nn->gamma, 88), 88);
+  q2.modmul_to(stm->ms, ssel, rows(w1, 64), rows(w2, 64), out->u3);
+  f.join();
+  q.rc = merge_rc(q, q1, q2);
   // e = H(G, Q, c, z, u1, u2, u3)                                               :102-110
   uint32_t* e = q.words(8);
   HashDesc d;
@@ -413,26 +429,32 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
 }
 
 // ---------------------------------------------------------------------------------------------
-// PDLwSlackProof::verify   (zk_pdl_with_slack/mod.rs:127-179)
+// PDLwSlackProof::verify   (zk_pdl_with_slack/mod.rs:127-179).  Small batches: the EC check, the N^2 side and the N~ side
+// run on three streams once the challenge is known.
 // ---------------------------------------------------------------------------------------------
 static int pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
                       const int32_t* st_idx, Rows cipher, Rows Qp, Rows Gp, const PdlProofRows& pr, uint8_t* ok,
                       hipStream_t st) {
   MPE_TRY(ws_reserve(ctx, (size_t)B * 2200 * 4 + 65536, st));
-  Seq q{ctx, st, B};
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
   const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
-  uint32_t* e = q.words(8);
+  Seq q0{ctx, st, B};
+  uint32_t* e = q0.words(8);
   HashDesc d;
   d.n = 7;
   d.f[0] = hf(Gp, 16, HF_POINT_COMPRESSED); d.f[1] = hf(Qp, 16, HF_POINT_COMPRESSED);
   d.f[2] = hf(cipher, 128); d.f[3] = hf(pr.z, 64);
   d.f[4] = hf(pr.u1, 16, HF_POINT_COMPRESSED); d.f[5] = hf(pr.u2, 128);
   d.f[6] = hf(pr.u3, 64);
-  q.hash(d, e);                                                                                     // :128-136
-  MPE_LAUNCH_1D(fill_u8_kernel, B, st, B, ok, (uint8_t)1);
-  MPE_LAUNCH_1D(pdl_u1_check_kernel, B, st, B, pr.s1, e, Gp, Qp, pr.u1, ok);                       // :138-142
+  q0.hash(d, e);                                                                                    // :128-136
+  Fork f(ctx, st, 3, B <= ctx->par_items);
+  Seq q{ctx, f.s(0), B}, q1{ctx, f.s(1), B}, q2{ctx, f.s(2), B};
+  q.rc = q0.rc;
+  if (B > 0) {
+    hipLaunchKernelGGL(fill_u8_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, f.s(1), B, ok, (uint8_t)1);
+    hipLaunchKernelGGL(pdl_u1_check_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, f.s(1), B, pr.s1, e, Gp, Qp, pr.u1, ok);   // :138-142
+  }
   uint8_t *inv_ok1 = q.flags(), *inv_ok2 = q.flags();
   // u2' = (N+1)^s1 s2^N c^-e mod N^2; (N+1)^s1 = 1 + s1 N < N^2 because s1 < 2^800                 :144-157
   uint32_t* g1 = q.words(128);
@@ -450,13 +472,15 @@ static int pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
     u2 = q.modmul(pk->ms_nn, ksel, rows(t2, 128), rows(cie, 128));
   }
   // u3' = h1^s1 h2^s3 z^-e mod N~                                                                  :159-172
-  uint32_t* a1 = q.fb_modexp(stm, ssel, 0, h1,pr.s1, 25);
-  uint32_t* a2 = q.fb_modexp(stm, ssel, 1, h2,pr.s3, 89);
-  uint32_t* a12 = q.modmul(stm->ms, ssel, rows(a1, 64), rows(a2, 64));
-  uint32_t* zred = q.modmul(stm->ms, ssel, pr.z, rows(stm->ms->one_words, 0, nullptr, 1));
-  uint32_t* zinv = q.modinv(stm->ms, ssel, rows(zred, 64), inv_ok2);
-  uint32_t* zie = q.modexp(stm->ms, ssel, rows(zinv, 64), rows(e, 8), 8);
-  uint32_t* u3 = q.modmul(stm->ms, ssel, rows(a12, 64), rows(zie, 64));
+  uint32_t* a1 = q2.fb_modexp(stm, ssel, 0, h1,pr.s1, 25);
+  uint32_t* a2 = q2.fb_modexp(stm, ssel, 1, h2,pr.s3, 89);
+  uint32_t* a12 = q2.modmul(stm->ms, ssel, rows(a1, 64), rows(a2, 64));
+  uint32_t* zred = q2.modmul(stm->ms, ssel, pr.z, rows(stm->ms->one_words, 0, nullptr, 1));
+  uint32_t* zinv = q2.modinv(stm->ms, ssel, rows(zred, 64), inv_ok2);
+  uint32_t* zie = q2.modexp(stm->ms, ssel, rows(zinv, 64), rows(e, 8), 8);
+  uint32_t* u3 = q2.modmul(stm->ms, ssel, rows(a12, 64), rows(zie, 64));
+  f.join();
+  q.rc = merge_rc(q, q1, q2);
   if (q.rc == MPE_OK) {                                                                             // :174
     hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ok, inv_ok1, inv_ok2, u2, pr.u2, 128);
     hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ok, (const uint8_t*)nullptr,
