@@ -414,10 +414,8 @@ __global__ void idx5_kernel(Dim d, Slab in4, int32_t* __restrict__ sub4_pv, int3
 }
 // my PDL verifications (rounds.rs:546-558), the R_dash sum, S_i and HomoELGamalProof::prove (party_i.rs:768-799)
 struct Heg { uint32_t *S, *T, *A3, *z1, *z2; };      // [pi]
-__global__ void __launch_bounds__(64) r5_kernel(Dim d, Slab in4, const uint8_t* __restrict__ pdl_ok, const uint32_t* __restrict__ R,
-                          const uint32_t* __restrict__ sigma_i, const uint32_t* __restrict__ lq, const uint32_t* __restrict__ pedT,
-                          const uint32_t* __restrict__ s1_in, const uint32_t* __restrict__ s2_in, Heg h, int32_t* __restrict__ status,
-                          uint32_t* __restrict__ bad) {
+__global__ void __launch_bounds__(64) r5_status_kernel(Dim d, Slab in4, const uint8_t* __restrict__ pdl_ok, int32_t* __restrict__ status,
+                                                       uint32_t* __restrict__ bad) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
   const int P1 = d.S - 1, li = pi % d.L, b = pi / d.L;
@@ -427,10 +425,17 @@ __global__ void __launch_bounds__(64) r5_kernel(Dim d, Slab in4, const uint8_t* 
     for (int jj = 0; jj < P1; ++jj)
       if (!pdl_ok[(((size_t)b * d.PV + vo) * d.S + i) * P1 + jj]) mask = 1u << i;
   if (mask) fail(status, bad, pi, 501, mask);
-  const ec::Aff G = ec::aff_gen(), H = ec::aff_h2();
   ec::Jac acc = ec::jac_inf();
   for (int j = 0; j < d.S; ++j) acc = ec::jac_add(acc, ec::jac_from_aff(ec::aff_load(rec_of(in4, j, b) + (size_t)P1 * SUB4)));
-  if (!ec::jac_eq_aff(acc, G)) fail(status, bad, pi, 502, 0);                              // phase5_check_R_dash_sum
+  if (!ec::jac_eq_aff(acc, ec::aff_gen())) fail(status, bad, pi, 502, 0);                  // phase5_check_R_dash_sum
+}
+// S_i and HomoELGamalProof::prove: independent of the verifications above (small batches run it beside them)
+__global__ void __launch_bounds__(64) r5_prove_kernel(Dim d, const uint32_t* __restrict__ R, const uint32_t* __restrict__ sigma_i,
+                          const uint32_t* __restrict__ lq, const uint32_t* __restrict__ pedT, const uint32_t* __restrict__ s1_in,
+                          const uint32_t* __restrict__ s2_in, Heg h) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= d.B * d.L) return;
+  const ec::Aff G = ec::aff_gen(), H = ec::aff_h2();
   const ec::Aff Rp = ec::aff_load(R + (size_t)pi * 16), T = ec::aff_load(pedT + (size_t)pi * 16);
   const ec::U256 si = ec::u256_load(sigma_i + (size_t)pi * 8), l = ec::u256_load(lq + (size_t)pi * 8);
   const ec::Aff Sp = mul_aff(si, Rp);
@@ -918,13 +923,18 @@ static int round4(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   const Slab in3 = slab_of(s, d_in, h_off, 3);
   (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)msg_words(S, d.n, 4) * 4, st);
   GG_LAUNCH(validate_kernel, c.nPI, d, in3, 4, s->status, s->bad);
-  GG_LAUNCH(r4_kernel, c.nPI, d, in3, s->dinv, s->com_all, s->bpk_in, s->kq, s->R, s->Rbar, s->status, s->bad);
+  // small batches: R and R_dash (two dependent scalar multiplications) beside the Paillier / N~ half of the PDL proofs
+  Fork g(ctx, st, 2, ctx->allow_par && (int)c.nPP <= ctx->par_items, 2);
+  if (rc == MPE_OK && c.nPI > 0)
+    hipLaunchKernelGGL(r4_kernel, dim3(blocks_for((int)c.nPI, 64)), dim3(64), 0, g.s(1), d, in3, s->dinv, s->com_all, s->bpk_in, s->kq, s->R, s->Rbar,
+                       s->status, s->bad);
   Bump t(s->tmp);
   mpe_pdl_proof pp{t.w(c.nPP * 64), t.w(c.nPP * 16), t.w(c.nPP * 128), t.w(c.nPP * 64), t.w(c.nPP * 25), t.w(c.nPP * 64), t.w(c.nPP * 89)};
   mpe_pdl_nonces pn{Z.pdl_alpha, Z.pdl_beta, Z.pdl_rho, Z.pdl_gamma};
   if (rc == MPE_OK)                                                                                            // phase5_proof_pdl
     rc = pdl_prove(ctx, K->prv, K->stm, (int)c.nPP, s->ix.kown_pp, s->ix.st_pp, rows(s->c_a, 128, s->ix.pi_pp), rows(s->Rbar, 16, s->ix.pi_pp),
-                   rows(s->R, 16, s->ix.pi_pp), rows(s->kq, 8, s->ix.pi_pp), rows(Z.r_a, 64, s->ix.pi_pp), &pn, &pp, st);
+                   rows(s->R, 16, s->ix.pi_pp), rows(s->kq, 8, s->ix.pi_pp), rows(Z.r_a, 64, s->ix.pi_pp), &pn, &pp, st, &g);
+  else g.join();
   gg_trace(st, "pdl_prove", rc);
   PACK(c.nPP, P1, S, 0, SUB4, 0, pp.z, 64); PACK(c.nPP, P1, S, 0, SUB4, 64, pp.u1, 16); PACK(c.nPP, P1, S, 0, SUB4, 80, pp.u2, 128);
   PACK(c.nPP, P1, S, 0, SUB4, 208, pp.u3, 64); PACK(c.nPP, P1, S, 0, SUB4, 272, pp.s1, 25); PACK(c.nPP, P1, S, 0, SUB4, 297, pp.s2, 64);
@@ -946,6 +956,9 @@ static int round5(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   uint8_t* ok_pv = t.f(c.nPV);
   Heg heg{t.w(c.nPI * 16), t.w(c.nPI * 16), t.w(c.nPI * 16), t.w(c.nPI * 8), t.w(c.nPI * 8)};
   GG_LAUNCH(idx5_kernel, c.nPV, d, in4, sub4_pv, rdash_pv);
+  Fork g(ctx, st, 2, ctx->allow_par && (int)c.nPV <= ctx->par_items, 2);
+  if (rc == MPE_OK && c.nPI > 0)
+    hipLaunchKernelGGL(r5_prove_kernel, dim3(blocks_for((int)c.nPI, 64)), dim3(64), 0, g.s(1), d, s->R, s->sigma_i, s->lq, s->pedT, Z.heg_s1, Z.heg_s2, heg);
   if (rc == MPE_OK) {      // phase5_verify_pdl for every prover (mine included), G = the VERIFIER's R (rounds.rs:546-558)
     PdlProofRows pr{rows(d_in, SUB4, sub4_pv), rows(d_in + 64, SUB4, sub4_pv), rows(d_in + 80, SUB4, sub4_pv), rows(d_in + 208, SUB4, sub4_pv),
                     rows(d_in + 272, SUB4, sub4_pv), rows(d_in + 297, SUB4, sub4_pv), rows(d_in + 361, SUB4, sub4_pv)};
@@ -953,7 +966,8 @@ static int round5(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
                     rows(s->R, 16, s->ix.pi_pv), pr, ok_pv, st);
   }
   gg_trace(st, "pdl_verify", rc);
-  GG_LAUNCH(r5_kernel, c.nPI, d, in4, ok_pv, s->R, s->sigma_i, s->lq, s->pedT, Z.heg_s1, Z.heg_s2, heg, s->status, s->bad);
+  g.join();
+  GG_LAUNCH(r5_status_kernel, c.nPI, d, in4, ok_pv, s->status, s->bad);
   PACK(c.nPI, 1, 1, 0, W5, 0, heg.S, 16); PACK(c.nPI, 1, 1, 0, W5, 16, heg.T, 16); PACK(c.nPI, 1, 1, 0, W5, 32, heg.A3, 16);
   PACK(c.nPI, 1, 1, 0, W5, 48, heg.z1, 8); PACK(c.nPI, 1, 1, 0, W5, 56, heg.z2, 8);
   return round_exit(s, rc, "gg20 round5");

@@ -120,6 +120,7 @@ struct Fork {
   Fork(mpe_ctx* c, hipStream_t m, int branches, bool enable, int first_aux = 0);
   hipStream_t s(int i) const { return (on && i > 0) ? ctx->aux[first + i - 1] : main; }
   void join();
+  void branch_done_wait(int i, hipStream_t waiter);     // `waiter` waits for what branch i has queued so far
 };
 template <class T>
 inline T* ws_array(mpe_ctx* ctx, size_t count) { return (T*)ws_alloc(ctx, count * sizeof(T)); }

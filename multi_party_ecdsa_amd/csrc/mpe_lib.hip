@@ -64,6 +64,11 @@ Fork::Fork(mpe_ctx* c, hipStream_t m, int branches, bool enable, int first_aux) 
   (void)hipEventRecord(ev, m);
   for (int i = 1; i < n; ++i) (void)hipStreamWaitEvent(c->aux[first + i - 1], ev, 0);
 }
+void Fork::branch_done_wait(int i, hipStream_t waiter) {
+  if (!on || i <= 0 || waiter == ctx->aux[first + i - 1]) return;
+  (void)hipEventRecord(ctx->ev_join[first + i - 1], ctx->aux[first + i - 1]);
+  (void)hipStreamWaitEvent(waiter, ctx->ev_join[first + i - 1], 0);
+}
 void Fork::join() {
   if (!on) return;
   for (int i = 1; i < n; ++i) {

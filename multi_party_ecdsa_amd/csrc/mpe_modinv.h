@@ -369,7 +369,7 @@ static ModsetView inv_view_of(const mpe_modset* ms) {
 }
 
 static size_t modinv_ws_words(const mpe_modset* ms, int B) {
-  const int K = ms->K, K32 = ms->bits / 32, maxch = B / 64 + ms->count + 2;
+  const int K = ms->K, K32 = ms->bits / 32, maxch = B / 16 + ms->count + 2;
   return (size_t)B * (2 * K + 3) + (size_t)maxch * (2 * K32 + 8) + ms->count + 4096;
 }
 
@@ -377,7 +377,9 @@ static size_t modinv_ws_words(const mpe_modset* ms, int B) {
 template <class C, typename LT>
 static int launch_modinv_batched(mpe_ctx* ctx, const mpe_modset* ms, int B, Rows mod_sel, Rows a, uint32_t* out, uint8_t* ok,
                                  hipStream_t st) {
-  constexpr int CH = 64;
+  // chunk = items inverted through ONE real inversion: 64 for throughput; a small batch is latency-bound, and the up / down
+  // sweeps are `chunk` sequential multiplications, so it takes short chunks (more, but concurrent, wave gcds)
+  const int CH = B <= ctx->par_items ? 16 : 64;
   const int nmod = ms->count, maxch = B / CH + nmod + 2;
   InvPlan p;
   p.cnt = ws_array<int32_t>(ctx, nmod + 1);

@@ -387,7 +387,9 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
 // ---------------------------------------------------------------------------------------------
 static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
                      const int32_t* st_idx, Rows cipher, Rows Qp, Rows Gp, Rows x, Rows r, const mpe_pdl_nonces* nn,
-                     const mpe_pdl_proof* out, hipStream_t st) {
+                     const mpe_pdl_proof* out, hipStream_t st, Fork* outer = nullptr) {
+  // outer: a fork of the CALLER whose branch 1 produces the statement points Q, G concurrently (Round 4: R, R_dash); only u1
+  // and the transcript hash need them
   MPE_TRY(ws_reserve(ctx, (size_t)B * (1400 + CRT_WS_WORDS) * 4 + 65536, st));
   Fork f(ctx, st, 3, B <= ctx->par_items);
   Seq q{ctx, f.s(0), B}, q1{ctx, f.s(1), B}, q2{ctx, f.s(2), B};
@@ -399,6 +401,7 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
   uint32_t* z2 = q1.fb_modexp(stm, ssel, 1, h2,rows(nn->rho, 72), 72);
   q1.modmul_to(stm->ms, ssel, rows(z1, 64), rows(z2, 64), out->z);
   // u1 = (alpha mod q) G                                                        :86
+  if (outer) outer->branch_done_wait(1, f.s(1));
   if (B > 0) hipLaunchKernelGGL(ec_mul_rows_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, f.s(1), B, rows(nn->alpha, 24), 24, Gp, out->u1);
   // u2 = (N+1)^alpha beta^N mod N^2; (N+1)^alpha = 1 + alpha N (mod N^2), alpha N + 1 < N^2      :87-93
   uint32_t* ga = q.words(128);
@@ -410,6 +413,7 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
   uint32_t* w2 = q2.fb_modexp(stm, ssel, 1, h2,rows(nn->gamma, 88), 88);
   q2.modmul_to(stm->ms, ssel, rows(w1, 64), rows(w2, 64), out->u3);
   f.join();
+  if (outer) outer->join();
   q.rc = merge_rc(q, q1, q2);
   // e = H(G, Q, c, z, u1, u2, u3)                                               :102-110
   uint32_t* e = q.words(8);
