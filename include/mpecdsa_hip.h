@@ -339,6 +339,50 @@ int mpe_gg20_complete(mpe_gg20_session* sess, const uint32_t* d_in, const int64_
 int mpe_gg20_session_result(const mpe_gg20_session* sess, int32_t* d_status, uint32_t* d_bad_actors, uint32_t* d_r,
                             uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, void* stream);
 
+/* Fault injection of the reference's own tests (gg_2020/test.rs:282-289,458-465,679-686): the local parties whose signer
+ * ordinal is in party_mask double their delta_i (step 5), sigma_i (step 6) or s_i (step 7).  step 0 switches it off. */
+int mpe_gg20_session_fault_inject(mpe_gg20_session* sess, int step, uint32_t party_mask);
+
+/* ---- identifiable abort: src/protocols/multi_party_ecdsa/gg_2020/blame.rs ---------------------------------------- */
+/* Every signer has opened the values the failing phase used; the functions re-derive the public ciphertexts from the
+ * openings under the signers' PUBLIC Paillier keys and name the parties whose openings do not match or whose broadcast
+ * value is inconsistent.  Layout: leading dimensions [batch][S] (signer ordinal), then the peer slot j (S-1; the peer's
+ * ordinal is ind = j < i ? j : j+1).  d_bad_actors [batch]: bit mask over signer ordinals = the reference's sorted,
+ * de-duplicated `ErrorType::bad_actors`.
+ * `GlobalStatePhase5::phase5_blame` (blame.rs:116-224), called when phase5_check_R_dash_sum failed (status 502):
+ *   k, gamma [B][S][8]; k_rand [B][S][64] (the MessageA randomness); beta_tag, beta_rand [B][S][S-1][64] (for Alice i, slot j:
+ *   what Bob `ind` used in his gamma MessageB to i); delta [B][S][8]; g_gamma [B][S][16]; c_a [B][S][128] (m_a_vec[i].c);
+ *   c_b [B][S][S-1][128] (m_b_mat[i][j].c, the gamma MessageB ciphertexts Alice i received). */
+typedef struct { const uint32_t *k, *k_rand, *gamma, *beta_tag, *beta_rand, *delta, *g_gamma, *c_a, *c_b; } mpe_gg20_blame5_in;
+int mpe_gg20_blame5(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int32_t* d_keyset, const mpe_gg20_blame5_in* in,
+                    uint32_t* d_bad_actors, void* stream);
+/* `GlobalStatePhase6::phase6_blame` (blame.rs:322-421), called when phase6_check_S_i_sum failed (status 602):
+ *   k, k_rand as above; miu, miu_rand [B][S][S-1][64] (plaintext before reduction and Paillier randomness of the w_i MessageB
+ *   ciphertexts Alice i received, `Paillier::open`); a1, a2 [B][S][16], z [B][S][8] (each signer's ECDDHProof that
+ *   S_i = sigma_i R); S [B][S][16]; c_a [B][S][128]; c_b [B][S][S-1][128] (the w_i MessageB ciphertexts); R [B][16]. */
+typedef struct { const uint32_t *k, *k_rand, *miu, *miu_rand, *a1, *a2, *z, *S, *c_a, *c_b, *R; } mpe_gg20_blame6_in;
+int mpe_gg20_blame6(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int32_t* d_keyset, const mpe_gg20_blame6_in* in,
+                    uint32_t* d_bad_actors, void* stream);
+/* `GlobalStatePhase7::phase7_blame` (blame.rs:434-454), called when the signature did not verify (status 701):
+ *   s [B][S][8] (partial signatures); r, m [B][8]; R_dash, S [B][S][16]; R [B][16]:  R s_i == m R_dash_i + r S_i. */
+typedef struct { const uint32_t *s, *r, *R_dash, *m, *R, *S; } mpe_gg20_blame7_in;
+int mpe_gg20_blame7(mpe_ctx* ctx, int n_signers, int batch, const mpe_gg20_blame7_in* in, uint32_t* d_bad_actors, void* stream);
+/* What a local party publishes for the phase-6 blame beyond the inputs it was given (LocalStatePhase6, blame.rs:227-234):
+ * d_miu [n_local][batch][S-1][64] and the ECDDH proof d_a1, d_a2 [n_local][batch][16], d_z [n_local][batch][8] that
+ * S_i = sigma_i R (`GlobalStatePhase6::ecddh_proof`, blame.rs:258-272; d_nonce [batch][n_local][8] is its sampled value).
+ * Valid after round 5.  (The Paillier randomness of the incoming ciphertexts, `Paillier::open`, is computed by the key
+ * holder's host: it needs N^-1 mod phi(N), an inverse modulo an even number.) */
+int mpe_gg20_session_blame6_state(const mpe_gg20_session* sess, const uint32_t* d_nonce, uint32_t* d_miu, uint32_t* d_a1,
+                                  uint32_t* d_a2, uint32_t* d_z, void* stream);
+/* curv `ECDDHProof::{prove, verify}` for the statement {g1, h1 = x g1, g2, h2 = x g2}: a1 = s g1, a2 = s g2,
+ * e = H(g1, h1, g2, h2, a1, a2), z = s + e x; verify: z g1 == a1 + e h1 and z g2 == a2 + e h2.  Points [batch][16]. */
+typedef struct { const uint32_t *g1, *h1, *g2, *h2; } mpe_ecddh_statement;
+typedef struct { uint32_t *a1, *a2, *z; } mpe_ecddh_proof;
+int mpe_ecddh_prove(mpe_ctx* ctx, int batch, const uint32_t* d_x, const uint32_t* d_s, const mpe_ecddh_statement* statement,
+                    const mpe_ecddh_proof* out, void* stream);
+int mpe_ecddh_verify(mpe_ctx* ctx, int batch, const mpe_ecddh_statement* statement, const mpe_ecddh_proof* proof, uint8_t* d_ok,
+                     void* stream);
+
 /* The lock-step composition of the rounds above with every signer local (needs every signer's secrets in `keys`):
  * OfflineStage Round0..Round6 and SignManual for `batch` sessions on this GPU — what `round_based::dev::Simulation`
  * does for one session (state_machine/sign.rs:667-763).  nonces: [batch][S] layout.  Outputs per session: d_r, d_s

@@ -45,6 +45,11 @@ Gg20Nonces = _ptr_struct("Gg20Nonces", GG20_NONCE_FIELDS)
 PedersenProof = _ptr_struct("PedersenProof", ["com", "e", "a1", "a2", "z1", "z2"])
 HegStatement = _ptr_struct("HegStatement", ["G", "H", "Y", "D", "E"])
 HegProof = _ptr_struct("HegProof", ["T", "A3", "z1", "z2"])
+Blame5In = _ptr_struct("Blame5In", ["k", "k_rand", "gamma", "beta_tag", "beta_rand", "delta", "g_gamma", "c_a", "c_b"])
+Blame6In = _ptr_struct("Blame6In", ["k", "k_rand", "miu", "miu_rand", "a1", "a2", "z", "S", "c_a", "c_b", "R"])
+Blame7In = _ptr_struct("Blame7In", ["s", "r", "R_dash", "m", "R", "S"])
+EcddhStatement = _ptr_struct("EcddhStatement", ["g1", "h1", "g2", "h2"])
+EcddhProof = _ptr_struct("EcddhProof", ["a1", "a2", "z"])
 
 
 def _load():
@@ -114,6 +119,13 @@ def _load():
         "mpe_heg_prove": (ip, [vp, ip, u32p, u32p, u32p, u32p, C.POINTER(HegStatement), C.POINTER(HegProof), vp]),
         "mpe_heg_verify": (ip, [vp, ip, C.POINTER(HegStatement), C.POINTER(HegProof), vp, vp]),
         "mpe_hash_commit_point": (ip, [vp, ip, u32p, u32p, u32p, vp]),
+        "mpe_gg20_session_fault_inject": (ip, [vp, ip, C.c_uint32]),
+        "mpe_gg20_blame5": (ip, [vp, vp, ip, i32p, C.POINTER(Blame5In), u32p, vp]),
+        "mpe_gg20_blame6": (ip, [vp, vp, ip, i32p, C.POINTER(Blame6In), u32p, vp]),
+        "mpe_gg20_blame7": (ip, [vp, ip, ip, C.POINTER(Blame7In), u32p, vp]),
+        "mpe_gg20_session_blame6_state": (ip, [vp, u32p, u32p, u32p, u32p, u32p, vp]),
+        "mpe_ecddh_prove": (ip, [vp, ip, u32p, u32p, C.POINTER(EcddhStatement), C.POINTER(EcddhProof), vp]),
+        "mpe_ecddh_verify": (ip, [vp, ip, C.POINTER(EcddhStatement), C.POINTER(EcddhProof), vp, vp]),
         "mpe_ctx_wipe": (ip, [vp, vp]),
         "mpe_ctx_scratch_audit": (ip, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]),
         "mpe_statements_create_wb": (ip, [vp, ip, u32p, u32p, u32p, ip, C.POINTER(vp), vp]),
@@ -152,7 +164,8 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_gg20_keys_fb_window_bits", "mpe_gg20_msg_words", "mpe_gg20_session_create", "mpe_gg20_session_destroy",
             "mpe_gg20_round0", "mpe_gg20_round1", "mpe_gg20_round2", "mpe_gg20_round3", "mpe_gg20_round4", "mpe_gg20_round5",
             "mpe_gg20_round6", "mpe_gg20_round7", "mpe_gg20_complete", "mpe_gg20_session_result", "mpe_pedersen_prove",
-            "mpe_pedersen_verify", "mpe_heg_prove", "mpe_heg_verify", "mpe_hash_commit_point", "mpe_ctx_wipe", "mpe_ctx_scratch_audit",
+            "mpe_pedersen_verify", "mpe_heg_prove", "mpe_heg_verify", "mpe_hash_commit_point", "mpe_ctx_wipe", "mpe_ctx_scratch_audit", "mpe_gg20_session_fault_inject", "mpe_gg20_blame5",
+            "mpe_gg20_blame6", "mpe_gg20_blame7", "mpe_gg20_session_blame6_state", "mpe_ecddh_prove", "mpe_ecddh_verify",
             "mpe_statements_create_wb"]
 
 

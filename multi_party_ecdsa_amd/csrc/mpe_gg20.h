@@ -308,10 +308,13 @@ __global__ void __launch_bounds__(64) r2b_kernel(Dim d, const uint32_t* __restri
                            const uint32_t* __restrict__ beta, const uint8_t* __restrict__ code, const uint32_t* __restrict__ l_in,
                            const uint32_t* __restrict__ s1_in, const uint32_t* __restrict__ s2_in,
                            uint32_t* __restrict__ delta_i, uint32_t* __restrict__ sigma_i, uint32_t* __restrict__ lq, Ped p,
-                           int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
+                           int32_t* __restrict__ status, uint32_t* __restrict__ bad, const uint32_t* __restrict__ alpha_full,
+                           uint32_t* __restrict__ miu, int fault_step, uint32_t fault_mask) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
   const int P1 = d.S - 1;
+  for (int jj = 0; jj < P1; ++jj)                                                              // LocalStatePhase6::miu
+    for (int w_ = 0; w_ < 64; ++w_) miu[((size_t)pi * P1 + jj) * 64 + w_] = alpha_full[(((size_t)pi * P1 + jj) * 2 + 1) * 64 + w_];
   const ec::U256 k = ec::u256_load(kq + (size_t)pi * 8);
   ec::U256 de = ec::sc_mul(k, ec::u256_load(gq + (size_t)pi * 8)), si = ec::sc_mul(k, ec::u256_load(w + (size_t)pi * 8));
   int st = 0;
@@ -322,6 +325,10 @@ __global__ void __launch_bounds__(64) r2b_kernel(Dim d, const uint32_t* __restri
     for (int v = 0; v < 2 && !st; ++v) if (code[m0 + v]) st = 200 + code[m0 + v];          // the loop order of rounds.rs:260-286
   }
   if (st) fail(status, bad, pi, st, 0);
+  if ((fault_mask >> d.loc[pi % d.L]) & 1u) {          // the corrupt_step of the reference's tests (test.rs:458-465)
+    if (fault_step == 5) de = ec::sc_add(de, de);
+    if (fault_step == 6) si = ec::sc_add(si, si);
+  }
   ec::u256_store(delta_i + (size_t)pi * 8, de);
   ec::u256_store(sigma_i + (size_t)pi * 8, si);
   const ec::U256 l = ec::sc_reduce(l_in + (size_t)pi * 8, 8);
@@ -599,15 +606,16 @@ __global__ void __launch_bounds__(64) r6_group_kernel(Dim d, int G, Slab in5, co
 // ---- Round 7: phase7_local_sig -> PartialSignature (party_i.rs:850-871) -------------------------------------------------
 __global__ void __launch_bounds__(64) r7_kernel(Dim d, const uint32_t* __restrict__ msg, const uint32_t* __restrict__ R,
                           const uint32_t* __restrict__ kq, const uint32_t* __restrict__ sigma_i, uint32_t* __restrict__ mq,
-                          uint32_t* __restrict__ rq, uint32_t* __restrict__ s_i) {
+                          uint32_t* __restrict__ rq, uint32_t* __restrict__ s_i, int fault_step, uint32_t fault_mask) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
   const int b = pi / d.L;
   const ec::U256 m = ec::sc_reduce(msg + (size_t)b * 8, 8), r = ec::sc_reduce(R + (size_t)pi * 16, 8);
   ec::u256_store(mq + (size_t)pi * 8, m);
   ec::u256_store(rq + (size_t)pi * 8, r);
-  ec::u256_store(s_i + (size_t)pi * 8, ec::sc_add(ec::sc_mul(m, ec::u256_load(kq + (size_t)pi * 8)),
-                                                  ec::sc_mul(r, ec::u256_load(sigma_i + (size_t)pi * 8))));
+  ec::U256 si = ec::sc_add(ec::sc_mul(m, ec::u256_load(kq + (size_t)pi * 8)), ec::sc_mul(r, ec::u256_load(sigma_i + (size_t)pi * 8)));
+  if (fault_step == 7 && ((fault_mask >> d.loc[pi % d.L]) & 1u)) si = ec::sc_add(si, si);              // test.rs:679-686
+  ec::u256_store(s_i + (size_t)pi * 8, si);
 }
 // SignManual::complete -> output_signature + verify (party_i.rs:873-936); outputs are [L][B], zero unless status == 0
 __global__ void __launch_bounds__(64) complete_kernel(Dim d, Slab in6, const uint32_t* __restrict__ R, const uint32_t* __restrict__ mq,
@@ -688,7 +696,10 @@ struct mpe_gg20_session {
   uint32_t *ca_all = nullptr, *com_all = nullptr, *bpk_in = nullptr, *delta_i = nullptr, *sigma_i = nullptr, *lq = nullptr, *pedT = nullptr;
   uint32_t *tvec = nullptr, *dinv = nullptr, *R = nullptr, *Rbar = nullptr, *mq = nullptr, *rq = nullptr, *s_i = nullptr, *bad = nullptr;
   uint32_t *sig_r = nullptr, *sig_s = nullptr;
+  uint32_t* miu = nullptr;         // [pp][64] the plaintexts of the incoming w_i MessageBs before reduction (LocalStatePhase6::miu, blame.rs:227-234)
   int32_t *status = nullptr, *sig_recid = nullptr;
+  int fault_step = 0;              // fault injection of the reference's tests (gg_2020/test.rs:282-289,458-465,679-686): 5 / 6 / 7
+  uint32_t fault_mask = 0;         // signer ordinals that double their delta_i / sigma_i / s_i
   char* tmp = nullptr;             // per-round scratch (dense outputs of the composites before they are packed)
   size_t tmp_bytes = 0;
 };
@@ -758,7 +769,7 @@ static size_t layout(mpe_gg20_session* s, char* base) {
   s->delta_i = m.w(c.nPI * 8); s->sigma_i = m.w(c.nPI * 8); s->lq = m.w(c.nPI * 8); s->pedT = m.w(c.nPI * 16);
   s->tvec = m.w(c.SB * 16); s->dinv = m.w(c.nPI * 8); s->R = m.w(c.nPI * 16); s->Rbar = m.w(c.nPI * 16);
   s->mq = m.w(c.nPI * 8); s->rq = m.w(c.nPI * 8); s->s_i = m.w(c.nPI * 8); s->bad = m.w(c.nPI);
-  s->sig_r = m.w(c.nPI * 8); s->sig_s = m.w(c.nPI * 8);
+  s->sig_r = m.w(c.nPI * 8); s->sig_s = m.w(c.nPI * 8); s->miu = m.w(c.nPP * 64);
   s->status = m.i(c.nPI); s->sig_recid = m.i(c.nPI);
   s->tmp_bytes = tmp_bytes_of(c);
   s->tmp = (char*)m.take(s->tmp_bytes);
@@ -890,7 +901,7 @@ static int round2(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   if (c.nMB * 4 <= lanes_fit) GG_LAUNCH(r2a_group_kernel, c.nMB * 4, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
   else GG_LAUNCH(r2a_kernel, c.nMB, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
   GG_LAUNCH(r2b_kernel, c.nPI, d, s->kq, s->gq, s->w, alpha, s->beta, code, Z.l, Z.ped_s1, Z.ped_s2, s->delta_i, s->sigma_i, s->lq, ped,
-            s->status, s->bad);
+            s->status, s->bad, alpha_full, s->miu, s->fault_step, s->fault_mask);
   PACK(c.nPI, 1, 1, 0, W2, 0, s->delta_i, 8); PACK(c.nPI, 1, 1, 0, W2, 8, ped.T, 16); PACK(c.nPI, 1, 1, 0, W2, 24, ped.e, 8);
   PACK(c.nPI, 1, 1, 0, W2, 32, ped.a1, 16); PACK(c.nPI, 1, 1, 0, W2, 48, ped.a2, 16); PACK(c.nPI, 1, 1, 0, W2, 64, ped.T, 16);
   PACK(c.nPI, 1, 1, 0, W2, 80, ped.z1, 8); PACK(c.nPI, 1, 1, 0, W2, 88, ped.z2, 8);
@@ -992,7 +1003,7 @@ static int round7(mpe_gg20_session* s, const uint32_t* d_msg, uint32_t* d_out, h
   int rc = round_enter(s, 7, d_msg, d_out, true, true);
   if (rc != MPE_OK) return rc;
   const Dim& d = s->d; const Counts c = counts_of(d);
-  GG_LAUNCH(r7_kernel, c.nPI, d, d_msg, s->R, s->kq, s->sigma_i, s->mq, s->rq, s->s_i);
+  GG_LAUNCH(r7_kernel, c.nPI, d, d_msg, s->R, s->kq, s->sigma_i, s->mq, s->rq, s->s_i, s->fault_step, s->fault_mask);
   PACK(c.nPI, 1, 1, 0, W6, 0, s->s_i, 8);
   return round_exit(s, rc, "gg20 round7");
 }
@@ -1136,6 +1147,11 @@ int mpe_gg20_session_destroy(mpe_gg20_session* s, void* stream) {
   return MPE_OK;
 }
 
+int mpe_gg20_session_fault_inject(mpe_gg20_session* s, int step, uint32_t party_mask) {
+  if (!s || (step != 0 && step != 5 && step != 6 && step != 7)) return MPE_E_ARG;
+  s->fault_step = step; s->fault_mask = party_mask;
+  return MPE_OK;
+}
 int mpe_gg20_round0(mpe_gg20_session* s, uint32_t* d_out, void* stream) { return s ? mpe::gg::round0(s, d_out, (hipStream_t)stream) : MPE_E_ARG; }
 int mpe_gg20_round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream) {
   return s ? mpe::gg::round1(s, d_in, h_in_off, d_out, (hipStream_t)stream) : MPE_E_ARG;

@@ -481,6 +481,18 @@ class Gg20Session:
             raise ValueError(rnd)
         return out
 
+    def fault_inject(self, step, party_mask):
+        N_.check(N_.lib.mpe_gg20_session_fault_inject(self.h, int(step), int(party_mask)), "mpe_gg20_session_fault_inject")
+
+    def blame6_state(self, d_nonce):
+        """(miu [L,B,S-1,64], a1, a2 [L,B,16], z [L,B,8]): what the local parties publish for the phase-6 blame"""
+        L, B, S, dv = self.L, self.B, self.S, self.ctx.device
+        miu = torch.empty((L, B, S - 1, 64), dtype=torch.int32, device=dv)
+        a1, a2, z = torch.empty((L, B, 16), dtype=torch.int32, device=dv), torch.empty((L, B, 16), dtype=torch.int32, device=dv), torch.empty((L, B, 8), dtype=torch.int32, device=dv)
+        N_.check(N_.lib.mpe_gg20_session_blame6_state(self.h, _ptr(d_nonce), _ptr(miu), _ptr(a1), _ptr(a2), _ptr(z), self.ctx.stream()),
+                 "mpe_gg20_session_blame6_state")
+        return miu, a1, a2, z
+
     def result(self, signature=True):
         """dict of device tensors: status, bad_actors, recid [L,B]; r, s [L,B,8]; R [L,B,16]"""
         L, B, dv = self.L, self.B, self.ctx.device
@@ -516,6 +528,45 @@ def gg20_sign(ctx, keys, nonces, B, dedup_verify=False, chunk=0, want_R=False, k
     N_.check(N_.lib.mpe_gg20_sign(ctx.h, keys.h, B, _ptr(keyset), C.byref(nn), _ptr(r), _ptr(s), _ptr(recid), _ptr(R), _ptr(status),
                                   int(bool(dedup_verify)), int(chunk), ctx.stream()), "mpe_gg20_sign")
     return (r, s, recid, status, R) if want_R else (r, s, recid, status)
+
+
+# ---- identifiable abort (gg_2020/blame.rs) ----
+def gg20_blame5(ctx, keys, B, opened, keyset=None):
+    """opened: dict of device tensors (fields _native.Blame5In) -> bad_actors bit masks [B] (device int32)"""
+    bad = torch.empty((B,), dtype=torch.int32, device=ctx.device)
+    st_ = _struct(N_.Blame5In, opened)
+    N_.check(N_.lib.mpe_gg20_blame5(ctx.h, keys.h, B, _ptr(keyset), C.byref(st_), _ptr(bad), ctx.stream()), "mpe_gg20_blame5")
+    return bad
+
+
+def gg20_blame6(ctx, keys, B, opened, keyset=None):
+    bad = torch.empty((B,), dtype=torch.int32, device=ctx.device)
+    st_ = _struct(N_.Blame6In, opened)
+    N_.check(N_.lib.mpe_gg20_blame6(ctx.h, keys.h, B, _ptr(keyset), C.byref(st_), _ptr(bad), ctx.stream()), "mpe_gg20_blame6")
+    return bad
+
+
+def gg20_blame7(ctx, S, B, opened):
+    bad = torch.empty((B,), dtype=torch.int32, device=ctx.device)
+    st_ = _struct(N_.Blame7In, opened)
+    N_.check(N_.lib.mpe_gg20_blame7(ctx.h, S, B, C.byref(st_), _ptr(bad), ctx.stream()), "mpe_gg20_blame7")
+    return bad
+
+
+def ecddh_prove(ctx, d_x, d_s, statement):
+    B = d_x.shape[0]
+    out = dict(a1=_new(ctx, B, 16), a2=_new(ctx, B, 16), z=_new(ctx, B, 8))
+    stt, pr = _struct(N_.EcddhStatement, statement), _struct(N_.EcddhProof, out)
+    N_.check(N_.lib.mpe_ecddh_prove(ctx.h, B, _ptr(d_x), _ptr(d_s), C.byref(stt), C.byref(pr), ctx.stream()), "mpe_ecddh_prove")
+    return out
+
+
+def ecddh_verify(ctx, statement, proof):
+    B = proof["z"].shape[0]
+    ok = _flags(ctx, B)
+    stt, pr = _struct(N_.EcddhStatement, statement), _struct(N_.EcddhProof, proof)
+    N_.check(N_.lib.mpe_ecddh_verify(ctx.h, B, C.byref(stt), C.byref(pr), _ptr(ok), ctx.stream()), "mpe_ecddh_verify")
+    return ok
 
 
 # ---- curv sigma proofs of phases 3 / 6, the phase-1 commitment (device-tensor API) ----

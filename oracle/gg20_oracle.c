@@ -220,6 +220,7 @@ typedef struct {
 struct orc_gg20_party {
   orc_gg20_keys K;
   int ord, B, L, li;
+  int fault_step;                  /* the reference tests' corrupt_step (test.rs:282-289): 5 / 6 / 7, 0 = honest */
   const int32_t* keyset;
   orc_gg20_nonces Z;
   gg_sess* s;
@@ -412,6 +413,8 @@ static void gg_round2(orc_gg20_party* P, int b, const uint32_t* in, const int64_
       if (v == 0) { mpz_add(de, de, t); sc_mod(de); } else { mpz_add(si, si, t); sc_mod(si); }
     }
   }
+  if (P->fault_step == 5) { mpz_add(de, de, de); sc_mod(de); }            /* test.rs:458-461 */
+  if (P->fault_step == 6) { mpz_add(si, si, si); sc_mod(si); }            /* test.rs:462-465 */
   zout(s->delta_i, 8, de); zout(s->sigma_i, 8, si);
   /* phase3_compute_t_i :620-634: T = sigma G + l H and PedersenProof::prove(sigma_i, l) */
   zin(t, P->Z.l + pi * 8, 8); sc_mod(t); zout(s->l, 8, t);
@@ -563,6 +566,7 @@ static void gg_round7(orc_gg20_party* P, int b, uint32_t* out) {
   zin(r, s->R, 8); sc_mod(r); zout(s->r, 8, r);                            /* r = R.x mod q */
   zin(t, s->k, 8); mpz_mul(t, t, m);
   zin(t2, s->sigma_i, 8); mpz_mul(t2, t2, r); mpz_add(t, t, t2); sc_mod(t);   /* s_i = m k_i + r sigma_i :864 */
+  if (P->fault_step == 7) { mpz_add(t, t, t); sc_mod(t); }                    /* test.rs:679-686 */
   zout(s->s_i, 8, t);
   memcpy(out, s->s_i, 32);
   mpz_clears(m, r, t, t2, NULL);
@@ -653,16 +657,9 @@ void orc_gg20_party_result(const orc_gg20_party* P, int32_t* status, uint32_t* b
     if (R) memcpy(R + (size_t)b * 16, x->R, 64);
   }
 }
-/* test hook (the reference's corrupt_step of gg_2020/test.rs:282-289,458-465,679-686): doubles delta_i (step 5, before it is
- * broadcast), sigma_i (step 6) or s_i (step 7) of this party in every session; call between the rounds as the test does. */
-void orc_gg20_party_corrupt(orc_gg20_party* P, int step) {
-  mpz_t t; mpz_init(t);
-  for (int b = 0; b < P->B; ++b) {
-    uint32_t* w = step == 5 ? P->s[b].delta_i : (step == 6 ? P->s[b].sigma_i : P->s[b].s_i);
-    zin(t, w, 8); mpz_add(t, t, t); sc_mod(t); zout(w, 8, t);
-  }
-  mpz_clear(t);
-}
+/* test hook = the reference tests' corrupt_step (gg_2020/test.rs:282-289,458-465,679-686): this party doubles its delta_i (step 5),
+ * sigma_i (step 6) or s_i (step 7) in every session; 0 = honest */
+void orc_gg20_party_fault(orc_gg20_party* P, int step) { P->fault_step = step; }
 
 /* ---- all parties of sessions [first, first+count) in lock-step: round_based::dev::Simulation (sign.rs:667-763) ----------
  * Z: [B][S] layout (every party's nonces).  slabs: NULL, or 7 pointers (M0..M6) to [S][B][W] arrays that receive every
@@ -711,4 +708,222 @@ void orc_gg20_sign(const orc_gg20_keys* K, const orc_gg20_nonces* Z, int first, 
                    int32_t* recid_out, uint32_t* R_out, int32_t* status) {
   /* the arrays are indexed by absolute session number: B = first + count covers them */
   orc_gg20_sign_ex(K, Z, NULL, first + count, first, count, NULL, r_out, s_out, recid_out, R_out, status, NULL, NULL);
+}
+
+/* ==========================================================================================================================
+ * Identifiable abort: src/protocols/multi_party_ecdsa/gg_2020/blame.rs.  Every signer opens the values the failing phase used;
+ * the blame functions re-derive the public ciphertexts from them and name the parties whose openings do not match (or whose
+ * broadcast delta_i / S_i / s_i is inconsistent).  Arrays: leading dimensions [B][S] (signer ordinal), then the peer slot j
+ * (S-1; ind = j < i ? j : j+1).  N: [nkeysets][n][64] must be given or derivable (p*q).  bad[b]: bit mask over signer ordinals.
+ * ========================================================================================================================== */
+/* curv ECDDHProof (SURVEY.md App. A.3 family; recalled): a1 = s g1, a2 = s g2, e = H(g1, h1, g2, h2, a1, a2), z = s + e x */
+void orc_ecddh_prove(int batch, const uint32_t* x, const uint32_t* s_in, const uint32_t* g1, const uint32_t* h1, const uint32_t* g2,
+                     const uint32_t* h2, uint32_t* a1_out, uint32_t* a2_out, uint32_t* z_out) {
+  mpz_t X, S, e, z; mpz_inits(X, S, e, z, NULL);
+  pt_t G1, H1, G2, H2, A1, A2; pt_init(&G1); pt_init(&H1); pt_init(&G2); pt_init(&H2); pt_init(&A1); pt_init(&A2);
+  for (int i = 0; i < batch; ++i) {
+    zin(X, x + (size_t)i * 8, 8); sc_mod(X); zin(S, s_in + (size_t)i * 8, 8); sc_mod(S);
+    pt_in(&G1, g1 + (size_t)i * 16); pt_in(&H1, h1 + (size_t)i * 16); pt_in(&G2, g2 + (size_t)i * 16); pt_in(&H2, h2 + (size_t)i * 16);
+    pt_mul(&A1, S, &G1); pt_mul(&A2, S, &G2);
+    const pt_t* hp[6] = {&G1, &H1, &G2, &H2, &A1, &A2};
+    hash_points_scalar(e, hp, 6);
+    mpz_mul(z, e, X); mpz_add(z, z, S); sc_mod(z);
+    pt_out(a1_out + (size_t)i * 16, &A1); pt_out(a2_out + (size_t)i * 16, &A2); zout(z_out + (size_t)i * 8, 8, z);
+  }
+  pt_clear(&G1); pt_clear(&H1); pt_clear(&G2); pt_clear(&H2); pt_clear(&A1); pt_clear(&A2); mpz_clears(X, S, e, z, NULL);
+}
+static int ecddh_verify_one(const pt_t* G1, const pt_t* H1, const pt_t* G2, const pt_t* H2, const pt_t* A1, const pt_t* A2, const mpz_t z) {
+  mpz_t e; mpz_init(e);
+  pt_t l, r, t; pt_init(&l); pt_init(&r); pt_init(&t);
+  const pt_t* hp[6] = {G1, H1, G2, H2, A1, A2};
+  hash_points_scalar(e, hp, 6);
+  pt_mul(&l, z, G1); pt_mul(&t, e, H1); pt_add(&r, A1, &t);
+  int ok = pt_eq(&l, &r);
+  pt_mul(&l, z, G2); pt_mul(&t, e, H2); pt_add(&r, A2, &t);
+  ok = ok && pt_eq(&l, &r);
+  pt_clear(&l); pt_clear(&r); pt_clear(&t); mpz_clear(e);
+  return ok;
+}
+void orc_ecddh_verify(int batch, const uint32_t* g1, const uint32_t* h1, const uint32_t* g2, const uint32_t* h2, const uint32_t* a1,
+                      const uint32_t* a2, const uint32_t* z, uint8_t* ok) {
+  mpz_t Z; mpz_init(Z);
+  pt_t G1, H1, G2, H2, A1, A2; pt_init(&G1); pt_init(&H1); pt_init(&G2); pt_init(&H2); pt_init(&A1); pt_init(&A2);
+  for (int i = 0; i < batch; ++i) {
+    pt_in(&G1, g1 + (size_t)i * 16); pt_in(&H1, h1 + (size_t)i * 16); pt_in(&G2, g2 + (size_t)i * 16); pt_in(&H2, h2 + (size_t)i * 16);
+    pt_in(&A1, a1 + (size_t)i * 16); pt_in(&A2, a2 + (size_t)i * 16); zin(Z, z + (size_t)i * 8, 8);
+    ok[i] = (uint8_t)ecddh_verify_one(&G1, &H1, &G2, &H2, &A1, &A2, Z);
+  }
+  pt_clear(&G1); pt_clear(&H1); pt_clear(&G2); pt_clear(&H2); pt_clear(&A1); pt_clear(&A2); mpz_clear(Z);
+}
+/* Paillier::open (kzen-paillier; blame.rs:252-256): m = Dec(c), r = (c (1 - m N) mod N^2)^(N^-1 mod phi) mod N — the unique r in [0, N)
+ * with c = (1 + m N) r^N mod N^2 */
+void orc_paillier_open(int batch, int nkeys, const uint32_t* p, const uint32_t* q, const int32_t* key_idx, const uint32_t* c, uint32_t* m,
+                       uint32_t* r) {
+  mpz_t P, Q, N, NN, phi, d, C, M, t; mpz_inits(P, Q, N, NN, phi, d, C, M, t, NULL);
+  for (int i = 0; i < batch; ++i) {
+    const int k = pick(key_idx, nkeys, i);
+    zin(P, p + (size_t)k * 32, 32); zin(Q, q + (size_t)k * 32, 32); zin(C, c + (size_t)i * 128, 128);
+    mpz_mul(N, P, Q); mpz_mul(NN, N, N);
+    paillier_dec(M, P, Q, C);
+    mpz_mul(t, M, N); mpz_ui_sub(t, 1, t); mpz_mod(t, t, NN);
+    mpz_mul(t, t, C); mpz_mod(t, t, NN); mpz_mod(t, t, N);
+    mpz_sub_ui(P, P, 1); mpz_sub_ui(Q, Q, 1); mpz_mul(phi, P, Q);
+    mpz_invert(d, N, phi);
+    mpz_powm(t, t, d, N);
+    zout(m + (size_t)i * 64, 64, M); zout(r + (size_t)i * 64, 64, t);
+  }
+  mpz_clears(P, Q, N, NN, phi, d, C, M, t, NULL);
+}
+
+/* GlobalStatePhase5::phase5_blame (blame.rs:116-224) */
+void orc_gg20_blame5(const orc_gg20_keys* K, const int32_t* keyset, int B, const orc_blame5_in* in, uint32_t* bad_out) {
+  const int S = K->S, n = K->n, P1 = S - 1;
+  ec_setup();
+  mpz_t t, u, al, be, kk, g; mpz_inits(t, u, al, be, kk, g, NULL);
+  pt_t G, a, b_; pt_init(&G); pt_init(&a); pt_init(&b_); pt_gen(&G);
+  orc_gg20_party fake; memset(&fake, 0, sizeof fake); fake.K = *K; fake.keyset = keyset;
+  for (int b = 0; b < B; ++b) {
+    const gg_kv kv = gg_keys_of(&fake, b);
+    uint32_t bad = 0;
+    mpz_t alpha[GG_MAXS][GG_MAXS], beta[GG_MAXS][GG_MAXS];
+    for (int i = 0; i < S; ++i) for (int j = 0; j < S; ++j) { mpz_init(alpha[i][j]); mpz_init(beta[i][j]); }
+    for (int i = 0; i < S; ++i) {                                       /* commitment to g_gamma :121-125 */
+      zin(g, in->gamma + ((size_t)b * S + i) * 8, 8);
+      pt_mul(&a, g, &G); pt_in(&b_, in->g_gamma + ((size_t)b * S + i) * 16);
+      if (!pt_eq(&a, &b_)) bad |= 1u << i;
+    }
+    for (int i = 0; i < S; ++i) {
+      uint32_t Nw[64], k64[64] = {0}, ca[128];
+      gg_N_words(&kv, K->signers[i], Nw);
+      memcpy(k64, in->k + ((size_t)b * S + i) * 8, 32);
+      orc_paillier_encrypt(1, 1, Nw, NULL, k64, in->k_rand + ((size_t)b * S + i) * 64, ca);          /* message a :128-138 */
+      if (!words_eq(ca, in->c_a + ((size_t)b * S + i) * 128, 128)) bad |= 1u << i;
+      if (bad) continue;                                                                              /* :140 */
+      zin(kk, in->k + ((size_t)b * S + i) * 8, 8);
+      for (int j = 0; j < P1; ++j) {
+        const int ind = ind_of(i, j);
+        const size_t ix = ((size_t)b * S + i) * P1 + j;
+        uint32_t cbt[128], bca[128], cb[128], g64[64] = {0};
+        memcpy(g64, in->gamma + ((size_t)b * S + ind) * 8, 32);
+        orc_paillier_encrypt(1, 1, Nw, NULL, in->beta_tag + ix * 64, in->beta_rand + ix * 64, cbt);   /* MessageB::b_with_predefined_randomness :144-152 */
+        orc_paillier_mul(1, 1, Nw, NULL, ca, g64, bca);
+        orc_paillier_add(1, 1, Nw, NULL, bca, cbt, cb);
+        if (!words_eq(cb, in->c_b + ix * 128, 128)) bad |= 1u << ind;                                  /* :154-156 */
+        zin(be, in->beta_tag + ix * 64, 64); sc_mod(be); mpz_neg(be, be); sc_mod(be);                  /* beta = -beta_tag */
+        zin(g, in->gamma + ((size_t)b * S + ind) * 8, 8);
+        mpz_mul(al, kk, g); mpz_sub(al, al, be); sc_mod(al);                                           /* alpha = k_i gamma_j - beta :158-159 */
+        mpz_set(alpha[i][j], al); mpz_set(beta[i][j], be);
+      }
+    }
+    if (!bad) {                                                                                        /* :181-211 */
+      for (int i = 0; i < S; ++i) {
+        zin(kk, in->k + ((size_t)b * S + i) * 8, 8); zin(g, in->gamma + ((size_t)b * S + i) * 8, 8);
+        mpz_mul(t, kk, g);
+        for (int j = 0; j < P1; ++j) {
+          const int ind1 = ind_of(i, j), ind2 = j < i ? i - 1 : i;
+          mpz_add(t, t, alpha[i][j]); mpz_add(t, t, beta[ind1][ind2]);
+        }
+        sc_mod(t);
+        zin(u, in->delta + ((size_t)b * S + i) * 8, 8); sc_mod(u);
+        if (mpz_cmp(t, u) != 0) bad |= 1u << i;
+      }
+    }
+    for (int i = 0; i < S; ++i) for (int j = 0; j < S; ++j) { mpz_clear(alpha[i][j]); mpz_clear(beta[i][j]); }
+    bad_out[b] = bad;
+  }
+  pt_clear(&G); pt_clear(&a); pt_clear(&b_); mpz_clears(t, u, al, be, kk, g, NULL);
+  (void)n;
+}
+
+/* GlobalStatePhase6::phase6_blame (blame.rs:322-421) */
+void orc_gg20_blame6(const orc_gg20_keys* K, const int32_t* keyset, int B, const orc_blame6_in* in, uint32_t* bad_out) {
+  const int S = K->S, P1 = S - 1;
+  ec_setup();
+  mpz_t kk, t, lam; mpz_inits(kk, t, lam, NULL);
+  pt_t G, X, gw[GG_MAXS], gni[GG_MAXS][GG_MAXS], gs, tmp, tmp2, R, Sp, A1, A2;
+  pt_init(&G); pt_init(&X); pt_init(&gs); pt_init(&tmp); pt_init(&tmp2); pt_init(&R); pt_init(&Sp); pt_init(&A1); pt_init(&A2); pt_gen(&G);
+  for (int i = 0; i < GG_MAXS; ++i) { pt_init(&gw[i]); for (int j = 0; j < GG_MAXS; ++j) pt_init(&gni[i][j]); }
+  orc_gg20_party fake; memset(&fake, 0, sizeof fake); fake.K = *K; fake.keyset = keyset;
+  for (int b = 0; b < B; ++b) {
+    const gg_kv kv = gg_keys_of(&fake, b);
+    uint32_t bad = 0;
+    for (int i = 0; i < S; ++i) {                                         /* correctness of miu :327-339 */
+      uint32_t Nw[64], c[128];
+      gg_N_words(&kv, K->signers[i], Nw);
+      for (int j = 0; j < P1; ++j) {
+        const size_t ix = ((size_t)b * S + i) * P1 + j;
+        orc_paillier_encrypt(1, 1, Nw, NULL, in->miu + ix * 64, in->miu_rand + ix * 64, c);
+        if (!words_eq(c, in->c_b + ix * 128, 128)) bad |= 1u << i;
+      }
+    }
+    for (int i = 0; i < S; ++i) {                                         /* correctness of k :342-354 */
+      uint32_t Nw[64], k64[64] = {0}, ca[128];
+      gg_N_words(&kv, K->signers[i], Nw);
+      memcpy(k64, in->k + ((size_t)b * S + i) * 8, 32);
+      orc_paillier_encrypt(1, 1, Nw, NULL, k64, in->k_rand + ((size_t)b * S + i) * 64, ca);
+      if (!words_eq(ca, in->c_a + ((size_t)b * S + i) * 128, 128)) bad |= 1u << i;
+    }
+    if (!bad) {
+      for (int i = 0; i < S; ++i) {                                       /* g_w_vec as in SignKeys::g_w_vec */
+        lagrange_at_zero(lam, K->signers, S, i);
+        pt_in(&X, kv.X + (size_t)K->signers[i] * 16);
+        pt_mul(&gw[i], lam, &X);
+      }
+      for (int i = 0; i < S; ++i) {                                       /* g_ni :360-376 */
+        zin(kk, in->k + ((size_t)b * S + i) * 8, 8);
+        for (int j = 0; j < P1; ++j) {
+          const int ind = ind_of(i, j);
+          pt_mul(&tmp, kk, &gw[ind]);
+          zin(t, in->miu + (((size_t)b * S + i) * P1 + j) * 64, 64);
+          pt_mul(&tmp2, t, &G); pt_neg(&tmp2, &tmp2);
+          pt_add(&gni[i][j], &tmp, &tmp2);
+        }
+      }
+      pt_in(&R, in->R + (size_t)b * 16);
+      for (int i = 0; i < S; ++i) {                                       /* g_sigma_i :380-397, ECDDH proof :400-414 */
+        zin(kk, in->k + ((size_t)b * S + i) * 8, 8);
+        pt_mul(&gs, kk, &gw[i]);
+        for (int j = 0; j < P1; ++j) {
+          zin(t, in->miu + (((size_t)b * S + i) * P1 + j) * 64, 64);
+          pt_mul(&tmp, t, &G); pt_add(&gs, &gs, &tmp);
+        }
+        for (int j = 0; j < P1; ++j) {
+          const int ind1 = ind_of(i, j), ind2 = j < i ? i - 1 : i;
+          pt_add(&gs, &gs, &gni[ind1][ind2]);
+        }
+        pt_in(&Sp, in->S + ((size_t)b * S + i) * 16); pt_in(&A1, in->a1 + ((size_t)b * S + i) * 16); pt_in(&A2, in->a2 + ((size_t)b * S + i) * 16);
+        zin(t, in->z + ((size_t)b * S + i) * 8, 8);
+        if (!ecddh_verify_one(&G, &gs, &R, &Sp, &A1, &A2, t)) bad |= 1u << i;
+      }
+    }
+    bad_out[b] = bad;
+  }
+  for (int i = 0; i < GG_MAXS; ++i) { pt_clear(&gw[i]); for (int j = 0; j < GG_MAXS; ++j) pt_clear(&gni[i][j]); }
+  pt_clear(&G); pt_clear(&X); pt_clear(&gs); pt_clear(&tmp); pt_clear(&tmp2); pt_clear(&R); pt_clear(&Sp); pt_clear(&A1); pt_clear(&A2);
+  mpz_clears(kk, t, lam, NULL);
+}
+
+/* GlobalStatePhase7::phase7_blame (blame.rs:434-454): R s_i == m R_dash_i + r S_i */
+void orc_gg20_blame7(int S, int B, const orc_blame7_in* in, uint32_t* bad_out) {
+  ec_setup();
+  mpz_t t; mpz_init(t);
+  pt_t R, l, a, b_, p; pt_init(&R); pt_init(&l); pt_init(&a); pt_init(&b_); pt_init(&p);
+  for (int b = 0; b < B; ++b) {
+    uint32_t bad = 0;
+    pt_in(&R, in->R + (size_t)b * 16);
+    for (int i = 0; i < S; ++i) {
+      zin(t, in->s + ((size_t)b * S + i) * 8, 8); pt_mul(&l, t, &R);
+      pt_in(&p, in->R_dash + ((size_t)b * S + i) * 16); zin(t, in->m + (size_t)b * 8, 8); pt_mul(&a, t, &p);
+      pt_in(&p, in->S + ((size_t)b * S + i) * 16); zin(t, in->r + (size_t)b * 8, 8); pt_mul(&b_, t, &p);
+      pt_add(&a, &a, &b_);
+      if (!pt_eq(&l, &a)) bad |= 1u << i;
+    }
+    bad_out[b] = bad;
+  }
+  pt_clear(&R); pt_clear(&l); pt_clear(&a); pt_clear(&b_); pt_clear(&p); mpz_clear(t);
+}
+/* read-back of a party's state for the blame protocols (what LocalStatePhase5/6 publish): sigma_i, the plaintexts miu_ij before
+ * reduction are NOT kept by the party object; tests recompute them with orc_paillier_open / decrypt */
+void orc_gg20_party_sigma(const orc_gg20_party* P, uint32_t* sigma /*[B][8]*/) {
+  for (int b = 0; b < P->B; ++b) memcpy(sigma + (size_t)b * 8, P->s[b].sigma_i, 32);
 }

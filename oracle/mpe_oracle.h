@@ -177,7 +177,7 @@ void orc_gg20_party_round(orc_gg20_party* P, int round, const uint32_t* in, cons
                           int count);
 void orc_gg20_party_result(const orc_gg20_party* P, int32_t* status, uint32_t* bad_actors, uint32_t* r, uint32_t* s,
                            int32_t* recid, uint32_t* R);
-void orc_gg20_party_corrupt(orc_gg20_party* P, int step);      /* the reference tests' corrupt_step 5 / 6 / 7 */
+void orc_gg20_party_fault(orc_gg20_party* P, int step);        /* the reference tests' corrupt_step 5 / 6 / 7 (0 = honest) */
 
 /* all parties in lock-step (round_based::dev::Simulation).  slabs: NULL or 7 pointers (M0..M6) to [S][B][W];
  * party_status / party_bad: NULL or [S][B]; status[b] = smallest non-zero party status. */
@@ -186,6 +186,22 @@ void orc_gg20_sign_ex(const orc_gg20_keys* K, const orc_gg20_nonces* Z, const in
                       int32_t* status, int32_t* party_status, uint32_t* party_bad);
 void orc_gg20_sign(const orc_gg20_keys* K, const orc_gg20_nonces* Z, int first, int count, uint32_t* r_out,
                    uint32_t* s_out, int32_t* recid_out, uint32_t* R_out, int32_t* status);
+
+/* ---- identifiable abort (gg_2020/blame.rs), all-openings-in: bad[b] = bit mask over signer ordinals ---------------- */
+void orc_ecddh_prove(int batch, const uint32_t* x, const uint32_t* s, const uint32_t* g1, const uint32_t* h1, const uint32_t* g2,
+                     const uint32_t* h2, uint32_t* a1, uint32_t* a2, uint32_t* z);
+void orc_ecddh_verify(int batch, const uint32_t* g1, const uint32_t* h1, const uint32_t* g2, const uint32_t* h2, const uint32_t* a1,
+                      const uint32_t* a2, const uint32_t* z, uint8_t* ok);
+/* Paillier::open: m [B][64], r [B][64] with c = (1 + m N) r^N mod N^2 */
+void orc_paillier_open(int batch, int nkeys, const uint32_t* p, const uint32_t* q, const int32_t* key_idx, const uint32_t* c,
+                       uint32_t* m, uint32_t* r);
+typedef struct { const uint32_t *k, *k_rand, *gamma, *beta_tag, *beta_rand, *delta, *g_gamma, *c_a, *c_b; } orc_blame5_in;
+typedef struct { const uint32_t *k, *k_rand, *miu, *miu_rand, *a1, *a2, *z, *S, *c_a, *c_b, *R; } orc_blame6_in;
+typedef struct { const uint32_t *s, *r, *R_dash, *m, *R, *S; } orc_blame7_in;
+void orc_gg20_blame5(const orc_gg20_keys* K, const int32_t* keyset, int B, const orc_blame5_in* in, uint32_t* bad);
+void orc_gg20_blame6(const orc_gg20_keys* K, const int32_t* keyset, int B, const orc_blame6_in* in, uint32_t* bad);
+void orc_gg20_blame7(int S, int B, const orc_blame7_in* in, uint32_t* bad);
+void orc_gg20_party_sigma(const orc_gg20_party* P, uint32_t* sigma);
 
 /* fixture helper (test key material only): smallest prime > start */
 void orc_nextprime(int k32, const uint32_t* start, uint32_t* out);

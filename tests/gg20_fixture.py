@@ -195,8 +195,8 @@ class OracleParty:
         self.orc.lib.orc_gg20_party_round(self.h, rnd, self.orc._p(d_in), off, self.orc._p(out), 0, self.B)
         return out
 
-    def corrupt(self, step):
-        self.orc.lib.orc_gg20_party_corrupt(self.h, step)
+    def fault(self, step):
+        self.orc.lib.orc_gg20_party_fault(self.h, step)
 
     def result(self):
         B = self.B
@@ -246,3 +246,58 @@ def run_rounds(parties, msg, tamper=None):
             slabs[rnd] = slab
             prev = slab
     return slabs
+
+
+# ---- identifiable abort (gg_2020/blame.rs): the openings every signer publishes, assembled from the nonces and the slabs ----
+def blame5_opened(lk, nonces, slabs, B):
+    """GlobalStatePhase5 (blame.rs:42-57) as arrays: [B][S] then peer slot j"""
+    S, n = lk["S"], lk["n"]
+    P1 = S - 1
+    o = dict(k=nonces["k"].copy(), k_rand=nonces["r_a"].copy(), gamma=nonces["gamma"].copy())
+    bt, br = np.zeros((B * S * P1, 64), dtype=np.uint32), np.zeros((B * S * P1, 64), dtype=np.uint32)
+    cb = np.zeros((B * S * P1, 128), dtype=np.uint32)
+    for b in range(B):
+        for i in range(S):
+            for j in range(P1):
+                ind = j if j < i else j + 1
+                jme = i if i < ind else i - 1
+                src = ((b * S + ind) * P1 + jme) * 2 + 0                      # Bob ind's gamma MessageB to Alice i
+                dst = (b * S + i) * P1 + j
+                bt[dst], br[dst] = nonces["mb_beta_tag"][src], nonces["mb_r"][src]
+                cb[dst] = slabs[1][ind, b, (jme * 2 + 0) * 208:(jme * 2 + 0) * 208 + 128]
+    o.update(beta_tag=bt, beta_rand=br, c_b=cb)
+    o["delta"] = np.ascontiguousarray(np.transpose(slabs[2][:, :, 0:8], (1, 0, 2)).reshape(B * S, 8))
+    o["g_gamma"] = np.ascontiguousarray(np.transpose(slabs[3][:, :, 8:24], (1, 0, 2)).reshape(B * S, 16))
+    o["c_a"] = np.ascontiguousarray(np.transpose(slabs[0][:, :, n * 256:n * 256 + 128], (1, 0, 2)).reshape(B * S, 128))
+    return o
+
+
+def blame6_cb(lk, slabs, B):
+    """m_b_mat[i][j].c of the w_i MtAs: [B][S][S-1][128]"""
+    S = lk["S"]
+    P1 = S - 1
+    cb = np.zeros((B * S * P1, 128), dtype=np.uint32)
+    for b in range(B):
+        for i in range(S):
+            for j in range(P1):
+                ind = j if j < i else j + 1
+                jme = i if i < ind else i - 1
+                cb[(b * S + i) * P1 + j] = slabs[1][ind, b, (jme * 2 + 1) * 208:(jme * 2 + 1) * 208 + 128]
+    return cb
+
+
+def oracle_blame(lk, which, opened, B, keyset=None):
+    import orc
+    S = lk["S"]
+    bad = np.zeros(B, dtype=np.uint32)
+    fields = dict(b5=["k", "k_rand", "gamma", "beta_tag", "beta_rand", "delta", "g_gamma", "c_a", "c_b"],
+                  b6=["k", "k_rand", "miu", "miu_rand", "a1", "a2", "z", "S", "c_a", "c_b", "R"], b7=["s", "r", "R_dash", "m", "R", "S"])[which]
+    keep = [np.ascontiguousarray(opened[f]) for f in fields]
+    st = (C.c_void_p * len(fields))(*[a.ctypes.data for a in keep])
+    if which == "b7":
+        orc.lib.orc_gg20_blame7(S, B, st, orc._p(bad))
+    else:
+        ks = keys_struct(lk)
+        kset = None if keyset is None else np.ascontiguousarray(keyset, dtype=np.int32)
+        getattr(orc.lib, "orc_gg20_blame5" if which == "b5" else "orc_gg20_blame6")(C.byref(ks), orc._p(kset), B, st, orc._p(bad))
+    return bad

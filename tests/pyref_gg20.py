@@ -307,3 +307,85 @@ def pack(round_, m, S, n):
     else:
         raise ValueError(round_)
     return bytes(out)
+
+
+# ---- identifiable abort: protocols/multi_party_ecdsa/gg_2020/blame.rs, restated on Python ints ---------------------------
+def ecddh_prove(x, s, g1, h1, g2, h2):
+    a1, a2 = R.ec_mul(s, g1), R.ec_mul(s, g2)
+    e = scalar_hash([g1, h1, g2, h2, a1, a2])
+    return a1, a2, (s + e * x) % Q
+
+
+def ecddh_verify(g1, h1, g2, h2, a1, a2, z):
+    e = scalar_hash([g1, h1, g2, h2, a1, a2])
+    return R.ec_mul(z, g1) == R.ec_add(a1, R.ec_mul(e, h1)) and R.ec_mul(z, g2) == R.ec_add(a2, R.ec_mul(e, h2))
+
+
+def paillier_open(p, q, c):
+    """Paillier::open: (m, r) with c = (1 + m n) r^n mod n^2"""
+    n = p * q
+    m = R.paillier_decrypt_textbook(p, q, c)
+    t = c * (1 - m * n) % (n * n) % n
+    return m, pow(t, pow(n, -1, (p - 1) * (q - 1)), n)
+
+
+def blame5(N, k, k_rand, gamma, beta_tag, beta_rand, delta, g_gamma, c_a, c_b):
+    """GlobalStatePhase5::phase5_blame (blame.rs:116-224).  N[i]: Paillier modulus of signer i; the lists are indexed by signer
+    ordinal i and peer slot j.  Returns the sorted bad-actor list."""
+    S = len(k)
+    bad = [i for i in range(S) if g_gamma[i] != R.ec_mul(gamma[i], G)]
+    ab = []
+    for i in range(S):
+        ca = R.paillier_encrypt(N[i], k[i] % Q, k_rand[i])
+        if ca != c_a[i]:
+            bad.append(i)
+        row = []
+        if not bad:
+            for j in range(S - 1):
+                ind = j if j < i else j + 1
+                NN = N[i] * N[i]
+                cb = pow(ca, gamma[ind] % Q, NN) * R.paillier_encrypt(N[i], beta_tag[i][j], beta_rand[i][j]) % NN
+                if cb != c_b[i][j]:
+                    bad.append(ind)
+                beta = (-(beta_tag[i][j] % Q)) % Q
+                row.append(((k[i] * gamma[ind] - beta) % Q, beta))
+        ab.append(row)
+    if not bad:
+        for i in range(S):
+            d = k[i] * gamma[i] + sum(a for a, _ in ab[i])
+            for j in range(S - 1):
+                ind1, ind2 = (j if j < i else j + 1), (i - 1 if j < i else i)
+                d += ab[ind1][ind2][1]
+            if d % Q != delta[i] % Q:
+                bad.append(i)
+    return sorted(set(bad))
+
+
+def blame6(N, g_w, k, k_rand, miu, miu_rand, proofs, S_vec, c_a, c_b, Rp):
+    """GlobalStatePhase6::phase6_blame (blame.rs:322-421)"""
+    S = len(k)
+    bad = []
+    for i in range(S):
+        for j in range(S - 1):
+            if R.paillier_encrypt(N[i], miu[i][j], miu_rand[i][j]) != c_b[i][j]:
+                bad.append(i)
+    for i in range(S):
+        if R.paillier_encrypt(N[i], k[i] % Q, k_rand[i]) != c_a[i]:
+            bad.append(i)
+    if not bad:
+        g_ni = [[R.ec_add(R.ec_mul(k[i], g_w[j if j < i else j + 1]), R.ec_neg(R.ec_mul(miu[i][j], G))) for j in range(S - 1)] for i in range(S)]
+        for i in range(S):
+            gs = R.ec_mul(k[i], g_w[i])
+            for x in miu[i]:
+                gs = R.ec_add(gs, R.ec_mul(x, G))
+            for j in range(S - 1):
+                ind1, ind2 = (j if j < i else j + 1), (i - 1 if j < i else i)
+                gs = R.ec_add(gs, g_ni[ind1][ind2])
+            if not ecddh_verify(G, gs, Rp, S_vec[i], *proofs[i]):
+                bad.append(i)
+    return sorted(set(bad))
+
+
+def blame7(s_vec, r, R_dash, m, Rp, S_vec):
+    """GlobalStatePhase7::phase7_blame (blame.rs:434-454)"""
+    return [i for i in range(len(s_vec)) if R.ec_mul(s_vec[i], Rp) != R.ec_add(R.ec_mul(m, R_dash[i]), R.ec_mul(r, S_vec[i]))]
