@@ -112,6 +112,25 @@ def _host(nonces):
     return {f: np.ascontiguousarray(v.cpu().numpy().view(np.uint32)) for f, v in nonces.items()}
 
 
+def host_cores():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota when there is one"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            a, b = f.read().split()
+        if a != "max":
+            quota = float(a) / float(b)
+    except (OSError, ValueError):
+        pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline_gg20(lk, host_nonces, sample, threads):
     """the oracle on `threads` host threads over `sample` sessions (ctypes releases the GIL); returns sig/s and the signatures"""
     import gg20_fixture as G
@@ -231,7 +250,7 @@ def config3(ctx, E, keys, F, B=262144, prefix=4096, threads=None, oracle=True):
            "corrupted": int(nbad), "corrupted_1pct_all_rejected": bool((okb[mask] == 0).all() and (okb[~mask] == 1).all())}
     if oracle:
         n = min(prefix, B)
-        threads = threads or min(os.cpu_count() or 1, 64)
+        threads = threads or min(host_cores()[0], 64)
         h = lambda t: np.ascontiguousarray(t[:n].cpu().numpy().view(np.uint32))
         tabs = dict(N=F.words([k.N for k in keys], 64), Nt=F.words([k.Nt for k in keys], 64), h1=F.words([k.h1 for k in keys], 64),
                     h2=F.words([k.h2 for k in keys], 64))
@@ -275,13 +294,41 @@ def gg20_config(ctx, E, G, keys, t, n, B, steps, gen, parity_sample=0, threads=N
     r, s, recid, status = [o.cpu().numpy() for o in out]
     res = {"sessions": B, "t": t, "n": n, "signatures_per_s": B / dt, "ms_per_batch": dt * 1e3, "all_sessions_signed": bool((status == 0).all())}
     if parity_sample:
-        threads = threads or min(os.cpu_count() or 1, 64)
+        threads = threads or min(host_cores()[0], 64)
         hn = _host({f: v[: parity_sample * (v.shape[0] // B)] for f, v in nonces.items()})
         v, wr, ws, wrecid, wstatus = cpu_baseline_gg20(lk, hn, parity_sample, min(threads, parity_sample))
         res["parity_sample"] = parity_sample
         res["parity_vs_oracle_on_sample"] = bool((wstatus == 0).all() and np.array_equal(r[:parity_sample].view(np.uint32), wr) and
                                                  np.array_equal(s[:parity_sample].view(np.uint32), ws) and np.array_equal(recid[:parity_sample], wrecid))
         res["oracle_signatures_per_s"] = v
+    gk.close()
+    return res
+
+
+def multi_wallet(ctx, E, G, keys, K, B, gen, t=1, n=3):
+    """One batch whose sessions belong to K different wallets (key sets), round-robin — SURVEY.md 8d config 4 allows "16
+    fixtures round-robin".  The 16 Paillier / N~ fixtures are reused cyclically for the K * n key slots (the per-key state
+    and the fixed-base tables are sized and addressed for K * n distinct keys); every wallet has its own Shamir shares."""
+    dev = ctx.device
+    signers = list(range(t + 1))
+    S = len(signers)
+    t0 = time.perf_counter()
+    lks = [G.make_local_keys(keys[(kk * n) % len(keys):] + keys[:(kk * n) % len(keys)], t, n, signers, seed=f"wallet-{kk}") for kk in range(min(K, 16))]
+    arrays = {f: np.concatenate([lks[kk % len(lks)]["arrays"][f] for kk in range(K)]) for f in ("x", "p", "q", "Nt", "h1", "h2", "y", "X")}
+    gk = E.Gg20Keys(ctx, t, n, signers, arrays, nkeysets=K)
+    torch.cuda.synchronize()
+    t_keys = time.perf_counter() - t0
+    keyset = (torch.arange(B, device=dev, dtype=torch.int32) % K).contiguous()
+    nonces = make_device_nonces(gen, dev, B, S, S, n)
+    out = E.gg20_sign(ctx, gk, nonces, B, keyset=keyset)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = E.gg20_sign(ctx, gk, nonces, B, keyset=keyset)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    status = out[3].cpu().numpy()
+    res = {"wallets": K, "sessions": B, "signatures_per_s": B / dt, "fb_window_bits": gk.fb_window_bits(), "key_setup_s": t_keys,
+           "all_sessions_signed": bool((status == 0).all())}
     gk.close()
     return res
 
@@ -517,7 +564,8 @@ def main():
         # the other configs and the CPU baseline belong to the single-GPU line (rank 0 at N=1 only): at N>1 the other ranks
         # would just wait for them
         single = world == 1 and args.mode == "session"
-        threads = min(os.cpu_count() or 1, 64)
+        usable, quota = host_cores()
+        threads = min(usable, 64)
         if single and not args.no_cpu_baseline:
             sample = min(B, 8 * threads)
             host_nonces = _host({f: v[: sample * (v.shape[0] // B)] for f, v in nonces.items()})
@@ -529,6 +577,7 @@ def main():
             parity = bool((wstatus == 0).all() and np.array_equal(r[:sample].view(np.uint32), wr) and
                           np.array_equal(s[:sample].view(np.uint32), ws) and np.array_equal(recid[:sample], wrecid))
             res["cpu_baseline"] = {"value": v, "unit": "signatures/s", "cores": threads, "kind": "port", "per_core_1thread": per_core,
+                                   "parallel_speedup": v / per_core, "host_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
                                    "sample": f"the first {sample} sessions of the same batch ({sample // threads} per thread; GMP oracle, "
                                              f"{threads} threads of {os.cpu_count()} host CPUs)"}
             res["parity_vs_oracle_on_sample"] = parity
@@ -539,6 +588,7 @@ def main():
             cfg["c3_ec_pdl_262144"] = config3(ctx, E, keys, F, oracle=not args.no_cpu_baseline)
             cfg["c4_literal_1024"] = gg20_config(ctx, E, G, keys, 1, 3, 1024, 5, gen, parity_sample=0 if args.no_cpu_baseline else 64)
             cfg["c5_share_t2n5_8192"] = gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32)
+            cfg["c4_multi_wallet_16384"] = [multi_wallet(ctx, E, G, keys, K_, 16384, gen) for K_ in (1, 16, 1024)]
             res["configs"] = cfg
             res["paillier"] = cfg["c2_paillier_65536"]
             res["lindell17"] = lindell_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline)

@@ -1,0 +1,212 @@
+"""Wire form of the GG20 signing messages: the JSON `serde` gives the reference's message types, to and from the fixed-size
+records of the round engine (include/mpecdsa_hip.h "GG20 round messages") — SURVEY.md §8f-1.  Host-side glue only (no
+arithmetic): a relay process uses it to let GPU-held parties talk to Rust parties through `gg20_sm_manager`
+(examples/gg20_sm_manager.rs:17-51, examples/gg20_sm_client.rs:10-53).
+
+Field names and nesting come from the reference sources (all `#[derive(Serialize, Deserialize)]`):
+  Msg{sender, receiver, body}                                   round-based 0.1.4 (examples/gg20_sm_client.rs:35-40)
+  OfflineProtocolMessage(OfflineM), OfflineM::M1..M6            state_machine/sign.rs:478-490
+  MessageA{c, range_proofs}, MessageB{c, b_proof, beta_tag_proof}   src/utilities/mta/mod.rs:34-45
+  AliceProof{z, e, s, s1, s2}                                   src/utilities/mta/range_proofs.rs:94-101
+  PDLwSlackProof{z, u1, u2, u3, s1, s2, s3}                     src/utilities/zk_pdl_with_slack/mod.rs:56-65
+  SignBroadcastPhase1{com}, SignDecommitPhase1{blind_factor, g_gamma_i}, SignatureRecid{r, s, recid}   gg_2020/party_i.rs:111-135
+  GammaI / WI / DeltaI / TI / TIProof / RDash / SI / HEGProof / PartialSignature: newtype structs    sign/rounds.rs:31-49,661
+  DLogProof{pk, pk_t_rand_commitment, challenge_response}, PedersenProof{e, a1, a2, com, z1, z2},
+  HomoELGamalProof{T, A3, z1, z2}                               curv-kzen 0.9 (un-vendored; field names recalled)
+
+THE PRIMITIVE ENCODINGS ARE RECALLED, NOT READ (curv-kzen 0.9 is not in the reference tree): BigInt as the lower-case hex
+string of its big-endian bytes, Point as {"curve": "secp256k1", "point": hex of the 33 compressed bytes}, Scalar as
+{"curve": "secp256k1", "scalar": hex of 32 bytes}.  They are isolated in the six functions below; the decoders also accept
+the other forms curv versions have used (decimal strings, byte arrays, uncompressed points), so that vectors produced by
+the real crate (tools/rust_vectors) decode whatever the exact form turns out to be."""
+import json
+
+import numpy as np
+
+P = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2F
+CURVE = "secp256k1"
+
+
+# ---- curv primitives (recalled encodings) ---------------------------------------------------------------------------
+def bigint_to_json(x):
+    h = "%x" % int(x)
+    return h if len(h) % 2 == 0 else "0" + h
+
+
+def bigint_from_json(v):
+    if isinstance(v, int):
+        return v
+    if isinstance(v, list):
+        return int.from_bytes(bytes(v), "big")
+    s = v.strip()
+    if s.startswith("0x"):
+        return int(s, 16)
+    try:
+        return int(s, 16)
+    except ValueError:
+        return int(s)
+
+
+def point_to_json(pt):
+    x, y = pt
+    return {"curve": CURVE, "point": "%02x%064x" % (2 + (y & 1), x)}
+
+
+def point_from_json(v):
+    raw = v["point"] if isinstance(v, dict) else v
+    b = bytes(raw) if isinstance(raw, list) else bytes.fromhex(raw)
+    if len(b) == 65 and b[0] == 4:
+        return int.from_bytes(b[1:33], "big"), int.from_bytes(b[33:], "big")
+    if len(b) == 33 and b[0] in (2, 3):
+        x = int.from_bytes(b[1:], "big")
+        y = pow((x * x * x + 7) % P, (P + 1) // 4, P)
+        if (y * y - x * x * x - 7) % P:
+            raise ValueError("point is not on the curve")
+        return (x, y if (y & 1) == (b[0] & 1) else P - y)
+    raise ValueError("unknown point encoding")
+
+
+def scalar_to_json(x):
+    return {"curve": CURVE, "scalar": "%064x" % int(x)}
+
+
+def scalar_from_json(v):
+    raw = v["scalar"] if isinstance(v, dict) else v
+    return int.from_bytes(bytes(raw), "big") if isinstance(raw, list) else int(raw, 16)
+
+
+# ---- words <-> ints ----------------------------------------------------------------------------------------------------
+def _int(words):
+    return int.from_bytes(np.ascontiguousarray(words, dtype="<u4").tobytes(), "little")
+
+
+def _pt(words):
+    v = _int(words)
+    return v & ((1 << 256) - 1), v >> 256
+
+
+def _put(rec, off, n, value):
+    rec[off:off + n] = np.frombuffer(int(value).to_bytes(4 * n, "little"), dtype="<u4")
+
+
+def _put_pt(rec, off, pt):
+    _put(rec, off, 8, pt[0])
+    _put(rec, off + 8, 8, pt[1])
+
+
+ALICE = (("z", 0, 64), ("e", 64, 8), ("s", 72, 64), ("s1", 136, 25), ("s2", 161, 89))
+PDL = (("z", 0, 64), ("u2", 80, 128), ("u3", 208, 64), ("s1", 272, 25), ("s2", 297, 64), ("s3", 361, 89))
+
+
+def _dlog_to_json(w, off):
+    return {"pk": point_to_json(_pt(w[off:off + 16])), "pk_t_rand_commitment": point_to_json(_pt(w[off + 16:off + 32])),
+            "challenge_response": scalar_to_json(_int(w[off + 32:off + 40]))}
+
+
+def _dlog_from_json(rec, off, j):
+    _put_pt(rec, off, point_from_json(j["pk"]))
+    _put_pt(rec, off + 16, point_from_json(j["pk_t_rand_commitment"]))
+    _put(rec, off + 32, 8, scalar_from_json(j["challenge_response"]))
+
+
+def _msgb_to_json(w):
+    return {"c": bigint_to_json(_int(w[0:128])), "b_proof": _dlog_to_json(w, 128), "beta_tag_proof": _dlog_to_json(w, 168)}
+
+
+def _msgb_from_json(rec, off, j):
+    _put(rec, off, 128, bigint_from_json(j["c"]))
+    _dlog_from_json(rec, off + 128, j["b_proof"])
+    _dlog_from_json(rec, off + 168, j["beta_tag_proof"])
+
+
+def record_to_bodies(rnd, rec, S, n, sender):
+    """One sender's record of round `rnd` (0..5, 7) -> list of (receiver or None, body) where body is the JSON value of
+    `OfflineProtocolMessage` (rounds 0..5) / `PartialSignature` (round 7).  sender, receiver: signer ordinals + 1 (the
+    reference numbers parties from 1)."""
+    w = np.ascontiguousarray(rec, dtype=np.uint32)
+    if rnd == 0:
+        proofs = [{f: bigint_to_json(_int(w[st * 256 + o:st * 256 + o + k])) for f, o, k in ALICE} for st in range(n)]
+        c = w[n * 256:]
+        return [(None, {"M1": [{"c": bigint_to_json(_int(c[0:128])), "range_proofs": proofs}, {"com": bigint_to_json(_int(c[128:136]))}]})]
+    if rnd == 1:
+        out = []
+        for jj in range(S - 1):
+            ind = jj if jj < sender - 1 else jj + 1
+            g, wi = w[(jj * 2) * 208:(jj * 2 + 1) * 208], w[(jj * 2 + 1) * 208:(jj * 2 + 2) * 208]
+            out.append((ind + 1, {"M2": [_msgb_to_json(g), _msgb_to_json(wi)]}))
+        return out
+    if rnd == 2:
+        proof = {"e": scalar_to_json(_int(w[24:32])), "a1": point_to_json(_pt(w[32:48])), "a2": point_to_json(_pt(w[48:64])),
+                 "com": point_to_json(_pt(w[64:80])), "z1": scalar_to_json(_int(w[80:88])), "z2": scalar_to_json(_int(w[88:96]))}
+        return [(None, {"M3": [scalar_to_json(_int(w[0:8])), point_to_json(_pt(w[8:24])), proof]})]
+    if rnd == 3:
+        return [(None, {"M4": {"blind_factor": bigint_to_json(_int(w[0:8])), "g_gamma_i": point_to_json(_pt(w[8:24]))}})]
+    if rnd == 4:
+        proofs = []
+        for jj in range(S - 1):
+            p = w[jj * 450:(jj + 1) * 450]
+            d = {f: bigint_to_json(_int(p[o:o + k])) for f, o, k in PDL}
+            d["u1"] = point_to_json(_pt(p[64:80]))
+            proofs.append({f: d[f] for f in ("z", "u1", "u2", "u3", "s1", "s2", "s3")})
+        return [(None, {"M5": [point_to_json(_pt(w[(S - 1) * 450:(S - 1) * 450 + 16])), proofs]})]
+    if rnd == 5:
+        proof = {"T": point_to_json(_pt(w[16:32])), "A3": point_to_json(_pt(w[32:48])), "z1": scalar_to_json(_int(w[48:56])),
+                 "z2": scalar_to_json(_int(w[56:64]))}
+        return [(None, {"M6": [point_to_json(_pt(w[0:16])), proof]})]
+    if rnd == 7:
+        return [(None, scalar_to_json(_int(w[0:8])))]
+    raise ValueError(rnd)
+
+
+def record_to_msgs(rnd, rec, S, n, sender):
+    """`Msg<OfflineProtocolMessage>` values as the relay carries them (JSON strings)"""
+    return [json.dumps({"sender": sender, "receiver": r, "body": body}) for r, body in record_to_bodies(rnd, rec, S, n, sender)]
+
+
+def bodies_to_record(rnd, bodies, S, n, sender):
+    """inverse of record_to_bodies: the messages one sender emitted in round `rnd` -> its record (uint32 words)"""
+    W = {0: 256 * (n + 1), 1: 208 * 2 * (S - 1), 2: 96, 3: 24, 4: 450 * S, 5: 64, 7: 8}[rnd]
+    rec = np.zeros(W, dtype=np.uint32)
+    if rnd == 0:
+        ma, bc = bodies[0][1]["M1"]
+        for st, pr in enumerate(ma["range_proofs"]):
+            for f, o, k in ALICE:
+                _put(rec, st * 256 + o, k, bigint_from_json(pr[f]))
+        _put(rec, n * 256, 128, bigint_from_json(ma["c"]))
+        _put(rec, n * 256 + 128, 8, bigint_from_json(bc["com"]))
+    elif rnd == 1:
+        for receiver, body in bodies:
+            ind = receiver - 1
+            jj = ind if ind < sender - 1 else ind - 1
+            g, wi = body["M2"]
+            _msgb_from_json(rec, (jj * 2) * 208, g)
+            _msgb_from_json(rec, (jj * 2 + 1) * 208, wi)
+    elif rnd == 2:
+        delta, T, pr = bodies[0][1]["M3"]
+        _put(rec, 0, 8, scalar_from_json(delta)); _put_pt(rec, 8, point_from_json(T))
+        _put(rec, 24, 8, scalar_from_json(pr["e"])); _put_pt(rec, 32, point_from_json(pr["a1"])); _put_pt(rec, 48, point_from_json(pr["a2"]))
+        _put_pt(rec, 64, point_from_json(pr["com"])); _put(rec, 80, 8, scalar_from_json(pr["z1"])); _put(rec, 88, 8, scalar_from_json(pr["z2"]))
+    elif rnd == 3:
+        d = bodies[0][1]["M4"]
+        _put(rec, 0, 8, bigint_from_json(d["blind_factor"])); _put_pt(rec, 8, point_from_json(d["g_gamma_i"]))
+    elif rnd == 4:
+        rdash, proofs = bodies[0][1]["M5"]
+        for jj, pr in enumerate(proofs):
+            for f, o, k in PDL:
+                _put(rec, jj * 450 + o, k, bigint_from_json(pr[f]))
+            _put_pt(rec, jj * 450 + 64, point_from_json(pr["u1"]))
+        _put_pt(rec, (S - 1) * 450, point_from_json(rdash))
+    elif rnd == 5:
+        Si, pr = bodies[0][1]["M6"]
+        _put_pt(rec, 0, point_from_json(Si)); _put_pt(rec, 16, point_from_json(pr["T"])); _put_pt(rec, 32, point_from_json(pr["A3"]))
+        _put(rec, 48, 8, scalar_from_json(pr["z1"])); _put(rec, 56, 8, scalar_from_json(pr["z2"]))
+    elif rnd == 7:
+        _put(rec, 0, 8, scalar_from_json(bodies[0][1]))
+    else:
+        raise ValueError(rnd)
+    return rec
+
+
+def signature_to_json(r, s, recid):
+    """`SignatureRecid` (party_i.rs:131-135)"""
+    return {"r": scalar_to_json(r), "s": scalar_to_json(s), "recid": int(recid)}

@@ -1,0 +1,133 @@
+"""Consumes tests/golden/ref_vectors.json — vectors dumped from the REAL crates by tools/rust_vectors/dump_vectors.rs — when a
+maintainer has produced it (skipped otherwise: this image has no Rust toolchain).  Every crate-generated proof must be
+accepted by the oracle's verifiers and every deterministic value reproduced byte for byte; this is what would turn the
+"parity unpinned" of oracle/mpe_oracle.h into a pinned one.  Also: the wire module decodes its own encodings."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fixtures as F
+import gg20_fixture as G
+import orc
+import pyref
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.path.join(HERE, "golden", "ref_vectors.json")
+spec = importlib.util.spec_from_file_location("mpe_wire", os.path.join(os.path.dirname(HERE), "multi_party_ecdsa_amd", "wire.py"))
+W = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(W)           # by path: the package import needs the HIP library, this module does not
+
+H = lambda s: int(s, 16)
+
+
+def _pt(v):
+    return (H(v["x"]), H(v["y"]))
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="tests/golden/ref_vectors.json not produced yet (tools/rust_vectors/README.md)")
+def test_vectors_from_the_real_crates():
+    cases = json.load(open(REF))["cases"]
+    assert cases
+    for c in cases:
+        k = c["keys"]
+        N, p, q, Nt, h1, h2 = (H(k[f]) for f in ("N", "p", "q", "Nt", "h1", "h2"))
+        assert p * q == N
+        # Paillier
+        pa = c["paillier"]
+        assert pyref.paillier_encrypt(N, H(pa["m"]), H(pa["r"])) == H(pa["c"])
+        assert F.ints(orc.paillier_decrypt(F.words([p], 32), F.words([q], 32), F.words([H(pa["c"])], 128)))[0] == H(pa["m"])
+        # AliceProof: crate-generated, oracle-verified
+        ap = {f: W.bigint_from_json(v) for f, v in c["alice_proof"]["proof"].items()}
+        widths = dict(z=64, e=8, s=64, s1=25, s2=89)
+        pr = {f: F.words([ap[f]], w) for f, w in widths.items()}
+        ok = orc.alice_verify(F.words([N], 64), F.words([Nt], 64), F.words([h1], 64), F.words([h2], 64), None, None,
+                              F.words([H(c["alice_proof"]["cipher"])], 128), pr)
+        assert ok[0] == 1, "AliceProof of the crate rejected: transcript encoding differs"
+        # PDL with slack
+        pd = c["pdl"]
+        pp = pd["proof"]
+        prf = dict(z=F.words([W.bigint_from_json(pp["z"])], 64), u1=F.point_words([W.point_from_json(pp["u1"])]),
+                   u2=F.words([W.bigint_from_json(pp["u2"])], 128), u3=F.words([W.bigint_from_json(pp["u3"])], 64),
+                   s1=F.words([W.bigint_from_json(pp["s1"])], 25), s2=F.words([W.bigint_from_json(pp["s2"])], 64),
+                   s3=F.words([W.bigint_from_json(pp["s3"])], 89))
+        ok = orc.pdl_verify(F.words([N], 64), F.words([Nt], 64), F.words([h1], 64), F.words([h2], 64), None, None, F.words([H(pd["c"])], 128),
+                            F.point_words([_pt(pd["Q"])]), F.point_words([_pt(pd["G"])]), prf)
+        assert ok[0] == 1, "PDLwSlackProof of the crate rejected"
+        assert W.point_from_json(pd["Q"]["serde"]) == _pt(pd["Q"])          # the serde form of a Point
+        # DLogProof
+        dl = c["dlog"]["proof"]
+        ok = orc.dlog_verify(F.point_words([W.point_from_json(dl["pk"])]), F.point_words([W.point_from_json(dl["pk_t_rand_commitment"])]),
+                             F.words([W.scalar_from_json(dl["challenge_response"])], 8))
+        assert ok[0] == 1, "DLogProof of the crate rejected: chain_point / result_scalar differ"
+        # PedersenProof, HomoELGamalProof, ECDDHProof
+        pe = c["pedersen"]["proof"]
+        okb = np.zeros(1, dtype=np.uint8)
+        orc.lib.orc_pedersen_verify(1, *[orc._p(a) for a in (F.point_words([W.point_from_json(pe["com"])]), F.point_words([W.point_from_json(pe["a1"])]),
+                                                             F.point_words([W.point_from_json(pe["a2"])]), F.words([W.scalar_from_json(pe["z1"])], 8),
+                                                             F.words([W.scalar_from_json(pe["z2"])], 8), okb)])
+        assert okb[0] == 1, "PedersenProof of the crate rejected"
+        he, hp = c["heg"], c["heg"]["proof"]
+        orc.lib.orc_heg_verify(1, *[orc._p(a) for a in (F.point_words([_pt(he["G"])]), F.point_words([pyref.H2]), F.point_words([pyref.G]),
+                                                        F.point_words([_pt(he["D"])]), F.point_words([_pt(he["E"])]), F.point_words([W.point_from_json(hp["T"])]),
+                                                        F.point_words([W.point_from_json(hp["A3"])]), F.words([W.scalar_from_json(hp["z1"])], 8),
+                                                        F.words([W.scalar_from_json(hp["z2"])], 8), okb)])
+        assert okb[0] == 1, "HomoELGamalProof of the crate rejected"
+        dd, dp = c["ecddh"], c["ecddh"]["proof"]
+        orc.lib.orc_ecddh_verify(1, *[orc._p(a) for a in (F.point_words([pyref.G]), F.point_words([_pt(dd["h1"])]), F.point_words([_pt(dd["g2"])]),
+                                                          F.point_words([_pt(dd["h2"])]), F.point_words([W.point_from_json(dp["a1"])]),
+                                                          F.point_words([W.point_from_json(dp["a2"])]), F.words([W.scalar_from_json(dp["z"])], 8), okb)])
+        assert okb[0] == 1, "ECDDHProof of the crate rejected"
+        # HashCommitment, base_point2
+        hc = c["hash_commitment"]
+        com = orc.u32((1, 8))
+        orc.lib.orc_hash_commit_point(1, orc._p(F.point_words([_pt(hc["point"])])), orc._p(F.words([H(hc["blind"])], 8)), orc._p(com))
+        assert F.ints(com)[0] == H(hc["com"])
+        assert _pt(c["base_point2"]) == pyref.H2
+        # MtA: MessageB of the crate passes verify_proofs_get_alpha's checks and gives the crate's alpha
+        mt = c["mta"]
+        mb = mt["m_b"]
+        share = F.ints(orc.paillier_decrypt(F.words([p], 32), F.words([q], 32), F.words([W.bigint_from_json(mb["c"])], 128)))[0]
+        assert share == H(mt["alice_share"]) and share % pyref.Q == H(mt["alpha"]["hex"])
+        for prf_ in (mb["b_proof"], mb["beta_tag_proof"]):
+            assert orc.dlog_verify(F.point_words([W.point_from_json(prf_["pk"])]), F.point_words([W.point_from_json(prf_["pk_t_rand_commitment"])]),
+                                   F.words([W.scalar_from_json(prf_["challenge_response"])], 8))[0] == 1
+
+
+@pytest.mark.parametrize("t,n,signers", [(1, 3, [0, 2]), (2, 4, [0, 1, 3])])
+def test_wire_roundtrip_of_every_round_message(keys, t, n, signers):
+    """record -> serde-shaped JSON `Msg<OfflineProtocolMessage>` -> record, for every message of a real session"""
+    lk = G.make_local_keys(keys, t, n, signers)
+    nonces = G.make_nonces(lk, 1, seed="wire")
+    got = G.oracle_sign_ex(lk, nonces, 1)
+    S = len(signers)
+    for rnd in G.ROUNDS:
+        for i in range(S):
+            rec = got["slabs"][rnd][i, 0]
+            msgs = W.record_to_msgs(rnd, rec, S, n, i + 1)
+            assert len(msgs) == (S - 1 if rnd == 1 else 1)
+            parsed = [json.loads(m) for m in msgs]
+            assert all(m["sender"] == i + 1 for m in parsed)
+            if rnd == 1:
+                assert sorted(m["receiver"] for m in parsed) == [j + 1 for j in range(S) if j != i]       # P2P
+            elif rnd != 7:
+                assert parsed[0]["receiver"] is None and list(parsed[0]["body"]) == [f"M{G.ROUNDS.index(rnd) + 1}"]
+            back = W.bodies_to_record(rnd, [(m["receiver"], m["body"]) for m in parsed], S, n, i + 1)
+            assert np.array_equal(back, rec), (rnd, i)
+    m0 = json.loads(W.record_to_msgs(0, got["slabs"][0][0, 0], S, n, 1)[0])["body"]["M1"]
+    assert set(m0[0]) == {"c", "range_proofs"} and set(m0[0]["range_proofs"][0]) == {"z", "e", "s", "s1", "s2"} and set(m0[1]) == {"com"}
+
+
+def test_primitive_decoders_accept_the_other_known_forms():
+    x = 0x1234567890abcdef1234567890
+    assert W.bigint_from_json(W.bigint_to_json(x)) == x
+    assert W.bigint_from_json(list(x.to_bytes(13, "big"))) == x
+    Pt = pyref.ec_mul(12345, pyref.G)
+    unc = "04%064x%064x" % Pt
+    assert W.point_from_json(W.point_to_json(Pt)) == Pt == W.point_from_json({"curve": "secp256k1", "point": unc})
+    assert W.point_from_json({"curve": "secp256k1", "point": list(bytes.fromhex(unc))}) == Pt
+    assert W.scalar_from_json(W.scalar_to_json(77)) == 77
+    with pytest.raises(ValueError):
+        W.point_from_json({"curve": "secp256k1", "point": "02" + "%064x" % 5})          # x = 5 is not on the curve
