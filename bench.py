@@ -583,15 +583,22 @@ def main():
             res["parity_vs_oracle_on_sample"] = parity
         if single and not args.no_configs and (T, N_PARTIES) == (1, 3):
             gk.close()
-            cfg = {}
-            cfg["c2_paillier_65536"] = paillier_config2(ctx, E, keys, F)
-            cfg["c3_ec_pdl_262144"] = config3(ctx, E, keys, F, oracle=not args.no_cpu_baseline)
-            cfg["c4_literal_1024"] = gg20_config(ctx, E, G, keys, 1, 3, 1024, 5, gen, parity_sample=0 if args.no_cpu_baseline else 64)
-            cfg["c5_share_t2n5_8192"] = gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32)
-            cfg["c4_multi_wallet_16384"] = [multi_wallet(ctx, E, G, keys, K_, 16384, gen) for K_ in (1, 16, 1024)]
+            cfg, took = {}, {}
+
+            def section(name, fn):
+                t_ = time.perf_counter()
+                cfg[name] = fn()
+                took[name] = round(time.perf_counter() - t_, 2)
+            section("c2_paillier_65536", lambda: paillier_config2(ctx, E, keys, F))
+            section("c3_ec_pdl_262144", lambda: config3(ctx, E, keys, F, oracle=not args.no_cpu_baseline))
+            section("c4_literal_1024", lambda: gg20_config(ctx, E, G, keys, 1, 3, 1024, 4, gen, parity_sample=0 if args.no_cpu_baseline else 32))
+            section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 16))
+            section("c4_multi_wallet_16384", lambda: [multi_wallet(ctx, E, G, keys, K_, 16384, gen) for K_ in (16, 1024)])
+            section("lindell17", lambda: lindell_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline))
+            res["lindell17"] = cfg.pop("lindell17")
             res["configs"] = cfg
             res["paillier"] = cfg["c2_paillier_65536"]
-            res["lindell17"] = lindell_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline)
+            res["section_seconds"] = took
         print(json.dumps(res))
     if distributed:
         dist.destroy_process_group()

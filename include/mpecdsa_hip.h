@@ -394,6 +394,25 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int3
                   uint32_t* d_r, uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, int dedup_verify, int chunk,
                   void* stream);
 
+/* ---- keygen VERIFICATION math (src/protocols/multi_party_ecdsa/gg_2020/party_i.rs:260-438) ----------------------- */
+/* What every party checks about every other party's first keygen messages and shares, batched over (verifier, prover)
+ * pairs / wallets.  Every key is its own modulus: the moduli set is built per call.  The two zk-paillier 0.4.3 proofs are
+ * un-vendored; their definitions are recalled.
+ * `NiCorrectKeyProof::verify(ek, SALT_STRING)` (party_i.rs:286-289): d_N [batch][64], d_sigma [batch][11][64]:
+ *   sigma_i^N == rho_i (mod N) for the 11 hash-derived rho_i and no prime below 6370 divides N. */
+int mpe_correct_key_verify(mpe_ctx* ctx, int batch, const uint32_t* d_N, const uint32_t* d_sigma, uint8_t* d_ok, void* stream);
+/* `CompositeDLogProof{x, y}::verify(DLogStatement{N, g, ni})` (party_i.rs:294-301; called twice per prover, bases h1 and h2):
+ *   N >= 2^128 and odd, gcd(g, N) = gcd(ni, N) = 1, e = H(x, g, N, ni), x == g^y ni^e mod N.  d_y [batch][73]. */
+int mpe_composite_dlog_verify(mpe_ctx* ctx, int batch, const uint32_t* d_N, const uint32_t* d_g, const uint32_t* d_ni,
+                              const uint32_t* d_x, const uint32_t* d_y, uint8_t* d_ok, void* stream);
+/* Feldman VSS (curv `VerifiableSS`): d_commits [batch][t1][16] (t1 = t + 1 coefficient commitments), d_index [batch]
+ * (1-based party index).  validate_share (party_i.rs:337-340): share G == sum_k index^k C_k;
+ * get_point_commitment (party_i.rs:383-385): that sum. */
+int mpe_vss_validate_share(mpe_ctx* ctx, int batch, int t1, const uint32_t* d_commits, const uint32_t* d_share, const int32_t* d_index,
+                           uint8_t* d_ok, void* stream);
+int mpe_vss_point_commitment(mpe_ctx* ctx, int batch, int t1, const uint32_t* d_commits, const int32_t* d_index, uint32_t* d_out,
+                             void* stream);
+
 /* ---- Lindell'17 two-party ECDSA, signing ---------------------------------------------- */
 /* Party two, `PartialSig::compute(ek, encrypted_secret_share, local_share, ephemeral_local_share,
  * ephemeral_other_public_share, message)` (src/protocols/two_party_ecdsa/lindell_2017/party_two.rs:390-423).

@@ -126,6 +126,10 @@ def _load():
         "mpe_gg20_session_blame6_state": (ip, [vp, u32p, u32p, u32p, u32p, u32p, vp]),
         "mpe_ecddh_prove": (ip, [vp, ip, u32p, u32p, C.POINTER(EcddhStatement), C.POINTER(EcddhProof), vp]),
         "mpe_ecddh_verify": (ip, [vp, ip, C.POINTER(EcddhStatement), C.POINTER(EcddhProof), vp, vp]),
+        "mpe_correct_key_verify": (ip, [vp, ip, u32p, u32p, vp, vp]),
+        "mpe_composite_dlog_verify": (ip, [vp, ip, u32p, u32p, u32p, u32p, u32p, vp, vp]),
+        "mpe_vss_validate_share": (ip, [vp, ip, ip, u32p, u32p, i32p, vp, vp]),
+        "mpe_vss_point_commitment": (ip, [vp, ip, ip, u32p, i32p, u32p, vp]),
         "mpe_ctx_wipe": (ip, [vp, vp]),
         "mpe_ctx_scratch_audit": (ip, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]),
         "mpe_statements_create_wb": (ip, [vp, ip, u32p, u32p, u32p, ip, C.POINTER(vp), vp]),
@@ -165,7 +169,8 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_gg20_round0", "mpe_gg20_round1", "mpe_gg20_round2", "mpe_gg20_round3", "mpe_gg20_round4", "mpe_gg20_round5",
             "mpe_gg20_round6", "mpe_gg20_round7", "mpe_gg20_complete", "mpe_gg20_session_result", "mpe_pedersen_prove",
             "mpe_pedersen_verify", "mpe_heg_prove", "mpe_heg_verify", "mpe_hash_commit_point", "mpe_ctx_wipe", "mpe_ctx_scratch_audit", "mpe_gg20_session_fault_inject", "mpe_gg20_blame5",
-            "mpe_gg20_blame6", "mpe_gg20_blame7", "mpe_gg20_session_blame6_state", "mpe_ecddh_prove", "mpe_ecddh_verify",
+            "mpe_gg20_blame6", "mpe_gg20_blame7", "mpe_correct_key_verify", "mpe_composite_dlog_verify", "mpe_vss_validate_share",
+            "mpe_vss_point_commitment", "mpe_gg20_session_blame6_state", "mpe_ecddh_prove", "mpe_ecddh_verify",
             "mpe_statements_create_wb"]
 
 

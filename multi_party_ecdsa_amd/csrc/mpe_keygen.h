@@ -1,0 +1,210 @@
+// Keygen VERIFICATION math, batched: what every party checks about every other party's first keygen
+// messages and shares — src/protocols/multi_party_ecdsa/gg_2020/party_i.rs
+//   :260-320  NiCorrectKeyProof::verify (11 x sigma^N mod N), CompositeDLogProof::verify x2, the hash commitment
+//   :322-367  VerifiableSS::validate_share (Feldman), commitments[0] == y_i
+//   :405-438  DLogProof::verify + get_commitments_to_xi
+// (Prime generation and the proofs' PROVE side stay on the host: sequential and data dependent)
+// The two zk-paillier 0.4.3 proofs are un-vendored: their definitions are recalled.  Every key is its own
+// modulus here (one modulus per item), so the moduli set is built per call.  Included by mpe_lib.hip.
+#pragma once
+#include "mpe_proofs.h"
+
+namespace mpe {
+namespace kg {
+
+constexpr int CK_M2 = 11;
+
+// zk-paillier compute_digest over BigInts as minimal big-endian bytes; one (key, i) per lane:
+//   seed = H(N, salt, i);  acc = sum_j H(seed, j) << (256 j), j < bit_length(N)/256 + 1  ->  hi (words 64..71) | lo (words 0..63)
+__global__ void __launch_bounds__(64) ck_rho_kernel(int B, const uint32_t* __restrict__ N, uint32_t* __restrict__ lo, uint32_t* __restrict__ hi) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B * CK_M2) return;
+  const int b = g / CK_M2, i = g % CK_M2;
+  const uint32_t* n = N + (size_t)b * 64;
+  ec::Sha256 s; ec::sha_init(s);
+  ec::sha_bigint(s, n, 64);
+  const uint32_t salt[1] = {0x4B5A656Eu};                       // SALT_STRING = [75, 90, 101, 110] as a BigInt
+  ec::sha_bigint(s, salt, 1);
+  const uint32_t iw[1] = {(uint32_t)i};
+  ec::sha_bigint(s, iw, 1);
+  const ec::U256 seed = ec::sha_final(s);
+  int top = 63;
+  while (top > 0 && n[top] == 0) --top;
+  const int bits = top * 32 + (32 - __clz(n[top] | 1u));
+  const int msklen = bits / 256 + 1;
+  uint32_t acc[72];
+  for (int w = 0; w < 72; ++w) acc[w] = 0;
+  for (int j = 0; j < msklen && j < 9; ++j) {
+    ec::Sha256 t; ec::sha_init(t);
+    ec::sha_bigint(t, seed.w, 8);
+    const uint32_t jw[1] = {(uint32_t)j};
+    ec::sha_bigint(t, jw, 1);
+    const ec::U256 d = ec::sha_final(t);
+    for (int w = 0; w < 8; ++w) acc[j * 8 + w] = d.w[w];        // disjoint 256-bit slots: the sum is a concatenation
+  }
+  for (int w = 0; w < 64; ++w) lo[(size_t)g * 64 + w] = acc[w];
+  for (int w = 0; w < 8; ++w) hi[(size_t)g * 8 + w] = acc[64 + w];
+}
+// key-level checks: N odd, > 1 and without a prime factor below 6370 (gcd(N, primorial) == 1, correct_key_ni.rs)
+__global__ void __launch_bounds__(64) ck_small_factor_kernel(int B, const uint32_t* __restrict__ N, uint8_t* __restrict__ ok) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t* n = N + (size_t)b * 64;
+  bool good = (n[0] & 1u) != 0;
+  for (uint32_t p = 3; p < 6370 && good; p += 2) {
+    bool prime = true;
+    for (uint32_t d = 3; d * d <= p; d += 2) if (p % d == 0) { prime = false; break; }
+    if (!prime) continue;
+    uint64_t r = 0;
+    for (int w = 63; w >= 0; --w) r = ((r << 32) | n[w]) % p;
+    if (r == 0) good = false;
+  }
+  ok[b] = good ? 1 : 0;
+}
+// rho = (hiT + lo_red) mod N and the comparison with sigma^N; ok[b] &= all 11
+__global__ void ck_finish_kernel(int B, const uint32_t* __restrict__ N, const uint32_t* __restrict__ hiT, const uint32_t* __restrict__ lo_red,
+                                 const uint32_t* __restrict__ sn, uint8_t* __restrict__ ok) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  bool good = ok[b] != 0;
+  uint32_t n[64];
+  sm::copy(n, N + (size_t)b * 64, 64);
+  for (int i = 0; i < CK_M2 && good; ++i) {
+    const size_t g = (size_t)b * CK_M2 + i;
+    uint32_t a[65], c[64];
+    sm::copy(a, hiT + g * 64, 64);
+    sm::copy(c, lo_red + g * 64, 64);
+    a[64] = sm::add(a, 64, a, 64, c, 64);
+    if (sm::cmp(a, 65, n, 64) >= 0) sm::sub(a, 65, a, 65, n, 64);
+    good = sm::cmp(a, 64, sn + g * 64, 64) == 0;
+  }
+  ok[b] = good ? 1 : 0;
+}
+__global__ void fill_words_kernel(int rows, int words, int bit, uint32_t* __restrict__ out) {       // rows of the constant 2^bit
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)rows * words) return;
+  const int w = (int)(g % words);
+  out[g] = (w == bit / 32) ? (1u << (bit % 32)) : 0u;
+}
+__global__ void iota_div_kernel(int n, int div, int32_t* __restrict__ out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n) out[g] = g / div;
+}
+// CompositeDLogProof: N >= 2^128 and odd
+__global__ void cd_n_check_kernel(int B, const uint32_t* __restrict__ N, uint8_t* __restrict__ ok) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t* n = N + (size_t)b * 64;
+  uint32_t hi = 0;
+  for (int w = 4; w < 64; ++w) hi |= n[w];
+  ok[b] = ((n[0] & 1u) && hi) ? 1 : 0;
+}
+// Feldman: sum_k index^k C_k (Horner); share != null: ok = (share G == that), else the point itself
+__global__ void __launch_bounds__(64) vss_kernel(int B, int t1, const uint32_t* __restrict__ commits, const uint32_t* __restrict__ share,
+                                                 const int32_t* __restrict__ index, uint8_t* __restrict__ ok, uint32_t* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  ec::U256 idx = ec::u256_zero();
+  idx.w[0] = (uint32_t)index[b];
+  ec::Jac acc = ec::jac_inf();
+  bool valid = true;
+  for (int k = t1 - 1; k >= 0; --k) {
+    const ec::Aff c = ec::aff_load(commits + ((size_t)b * t1 + k) * 16);
+    valid = valid && ec::aff_valid(c);
+    if (!ec::jac_is_inf(acc)) acc = ec::jac_mul(idx, ec::jac_to_aff(acc));
+    acc = ec::jac_add_aff(acc, c);
+  }
+  if (share) ok[b] = (valid && ec::jac_eq(ec::jac_mul_gen(ec::sc_reduce(share + (size_t)b * 8, 8)), acc)) ? 1 : 0;
+  if (out) ec::aff_store(out + (size_t)b * 16, ec::jac_to_aff(acc));
+}
+
+}  // namespace kg
+}  // namespace mpe
+
+extern "C" {
+
+int mpe_correct_key_verify(mpe_ctx* ctx, int batch, const uint32_t* d_N, const uint32_t* d_sigma, uint8_t* d_ok, void* stream) {
+  if (!ctx || !d_N || !d_sigma || !d_ok || batch < 0) return MPE_E_ARG;
+  if (batch == 0) return MPE_OK;
+  using namespace mpe;
+  hipStream_t st = (hipStream_t)stream;
+  const int M = kg::CK_M2, n = batch * M;
+  mpe_modset* ms = nullptr;
+  MPE_TRY(modset_create_dev(ctx, 2048, batch, d_N, &ms, st));
+  int rc = ws_reserve(ctx, ((size_t)n * (64 * 5 + 8 + 1) + (size_t)batch * 64 * 3) * 4 + 65536, st);
+  if (rc != MPE_OK) { mpe_modset_destroy(ms); return rc; }
+  int32_t* key_of = ws_array<int32_t>(ctx, n);
+  uint32_t *lo = ws_array<uint32_t>(ctx, (size_t)n * 64), *hi = ws_array<uint32_t>(ctx, (size_t)n * 8), *sn = ws_array<uint32_t>(ctx, (size_t)n * 64),
+           *hiT = ws_array<uint32_t>(ctx, (size_t)n * 64), *lor = ws_array<uint32_t>(ctx, (size_t)n * 64), *two = ws_array<uint32_t>(ctx, (size_t)batch * 64),
+           *T = ws_array<uint32_t>(ctx, (size_t)batch * 64);
+  if (!key_of || !lo || !hi || !sn || !hiT || !lor || !two || !T) { mpe_modset_destroy(ms); mpe_set_error_msg("correct_key: workspace"); return MPE_E_NOMEM; }
+  const Rows ksel{nullptr, key_of, 0, 0};
+  hipLaunchKernelGGL(kg::iota_div_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, n, M, key_of);
+  hipLaunchKernelGGL(kg::ck_small_factor_kernel, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, d_N, d_ok);
+  hipLaunchKernelGGL(kg::ck_rho_kernel, dim3(blocks_for(n, 64)), dim3(64), 0, st, batch, d_N, lo, hi);
+  // sigma_i^N mod N: the heavy part — 11 exponentiations (2048-bit modulus, 2048-bit exponent) per key
+  rc = launch_modexp(ctx, ms, n, ksel, rows(d_sigma, 64), no_rows(), rows(d_N, 64, key_of), 64, sn, st);
+  // rho = acc mod N with acc = hi 2^2048 + lo:  T = 2^2048 mod N = (2^1024)^2, rho = hi T + lo (mod N)
+  hipLaunchKernelGGL(kg::fill_words_kernel, dim3(blocks_for(batch * 64, 256)), dim3(256), 0, st, batch, 64, 1024, two);
+  if (rc == MPE_OK) rc = launch_modmul(ctx, ms, batch, rows(nullptr, 1), rows(two, 64), rows(two, 64), T, st);
+  if (rc == MPE_OK) rc = launch_modmul(ctx, ms, n, ksel, rows(hi, 8, nullptr, 8), rows(T, 64, key_of), hiT, st);
+  if (rc == MPE_OK) rc = launch_modmul(ctx, ms, n, ksel, rows(lo, 64), rows(ms->one_words, 0, nullptr, 1), lor, st);
+  if (rc == MPE_OK) hipLaunchKernelGGL(kg::ck_finish_kernel, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, d_N, hiT, lor, sn, d_ok);
+  (void)hipStreamSynchronize(st);          // the per-call moduli set is released below
+  mpe_modset_destroy(ms);
+  if (rc != MPE_OK) return rc;
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mpe_set_error("mpe_correct_key_verify", e); return MPE_E_HIP; }
+  return MPE_OK;
+}
+
+int mpe_composite_dlog_verify(mpe_ctx* ctx, int batch, const uint32_t* d_N, const uint32_t* d_g, const uint32_t* d_ni, const uint32_t* d_x,
+                              const uint32_t* d_y, uint8_t* d_ok, void* stream) {
+  if (!ctx || !d_N || !d_g || !d_ni || !d_x || !d_y || !d_ok || batch < 0) return MPE_E_ARG;
+  if (batch == 0) return MPE_OK;
+  using namespace mpe;
+  hipStream_t st = (hipStream_t)stream;
+  mpe_modset* ms = nullptr;
+  MPE_TRY(modset_create_dev(ctx, 2048, batch, d_N, &ms, st));
+  int rc = ws_reserve(ctx, ((size_t)batch * (64 * 6 + 8) + modinv_ws_words(ms, batch) * 2) * 4 + 65536, st);
+  if (rc != MPE_OK) { mpe_modset_destroy(ms); return rc; }
+  Seq q{ctx, st, batch};
+  const Rows sel = rows(nullptr, 1);                                    // modulus i for item i
+  uint8_t *ok1 = q.flags(), *ok2 = q.flags();
+  hipLaunchKernelGGL(kg::cd_n_check_kernel, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, d_N, d_ok);
+  // gcd(g, N) == gcd(ni, N) == 1: through the inversions (their ok flags)
+  uint32_t* gr = q.modmul(ms, sel, rows(d_g, 64), rows(ms->one_words, 0, nullptr, 1));
+  uint32_t* nr = q.modmul(ms, sel, rows(d_ni, 64), rows(ms->one_words, 0, nullptr, 1));
+  (void)q.modinv(ms, sel, rows(gr, 64), ok1);
+  (void)q.modinv(ms, sel, rows(nr, 64), ok2);
+  // e = H(x, g, N, ni);  x == g^y ni^e mod N
+  uint32_t* e = q.words(8);
+  HashDesc d;
+  d.n = 4;
+  d.f[0] = hf(rows(d_x, 64), 64); d.f[1] = hf(rows(d_g, 64), 64); d.f[2] = hf(rows(d_N, 64), 64); d.f[3] = hf(rows(d_ni, 64), 64);
+  q.hash(d, e);
+  uint32_t* gy = q.modexp(ms, sel, rows(d_g, 64), rows(d_y, 73), 73);
+  uint32_t* ne = q.modexp(ms, sel, rows(d_ni, 64), rows(e, 8), 8);
+  uint32_t* pr = q.modmul(ms, sel, rows(gy, 64), rows(ne, 64));
+  if (q.rc == MPE_OK) hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, d_ok, ok1, ok2, pr, rows(d_x, 64), 64);
+  rc = q.finish("mpe_composite_dlog_verify");
+  (void)hipStreamSynchronize(st);
+  mpe_modset_destroy(ms);
+  return rc;
+}
+
+int mpe_vss_validate_share(mpe_ctx* ctx, int batch, int t1, const uint32_t* d_commits, const uint32_t* d_share, const int32_t* d_index,
+                           uint8_t* d_ok, void* stream) {
+  if (!ctx || !d_commits || !d_share || !d_index || !d_ok || batch < 0 || t1 < 1 || t1 > 64) return MPE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  MPE_LAUNCH_1D(mpe::kg::vss_kernel, batch, st, batch, t1, d_commits, d_share, d_index, d_ok, (uint32_t*)nullptr);
+  return MPE_OK;
+}
+int mpe_vss_point_commitment(mpe_ctx* ctx, int batch, int t1, const uint32_t* d_commits, const int32_t* d_index, uint32_t* d_out, void* stream) {
+  if (!ctx || !d_commits || !d_index || !d_out || batch < 0 || t1 < 1 || t1 > 64) return MPE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  MPE_LAUNCH_1D(mpe::kg::vss_kernel, batch, st, batch, t1, d_commits, (const uint32_t*)nullptr, d_index, (uint8_t*)nullptr, d_out);
+  return MPE_OK;
+}
+
+}  // extern "C"

@@ -530,6 +530,34 @@ def gg20_sign(ctx, keys, nonces, B, dedup_verify=False, chunk=0, want_R=False, k
     return (r, s, recid, status, R) if want_R else (r, s, recid, status)
 
 
+# ---- keygen verification math (gg_2020/party_i.rs:260-438) ----
+def correct_key_verify(ctx, d_N, d_sigma):
+    ok = _flags(ctx, d_N.shape[0])
+    N_.check(N_.lib.mpe_correct_key_verify(ctx.h, d_N.shape[0], _ptr(d_N), _ptr(d_sigma), _ptr(ok), ctx.stream()), "mpe_correct_key_verify")
+    return ok
+
+
+def composite_dlog_verify(ctx, d_N, d_g, d_ni, d_x, d_y):
+    ok = _flags(ctx, d_N.shape[0])
+    N_.check(N_.lib.mpe_composite_dlog_verify(ctx.h, d_N.shape[0], _ptr(d_N), _ptr(d_g), _ptr(d_ni), _ptr(d_x), _ptr(d_y), _ptr(ok),
+                                              ctx.stream()), "mpe_composite_dlog_verify")
+    return ok
+
+
+def vss_validate_share(ctx, t1, d_commits, d_share, d_index):
+    ok = _flags(ctx, d_share.shape[0])
+    N_.check(N_.lib.mpe_vss_validate_share(ctx.h, d_share.shape[0], t1, _ptr(d_commits), _ptr(d_share), _ptr(d_index), _ptr(ok), ctx.stream()),
+             "mpe_vss_validate_share")
+    return ok
+
+
+def vss_point_commitment(ctx, t1, d_commits, d_index):
+    out = _new(ctx, d_index.shape[0], 16)
+    N_.check(N_.lib.mpe_vss_point_commitment(ctx.h, d_index.shape[0], t1, _ptr(d_commits), _ptr(d_index), _ptr(out), ctx.stream()),
+             "mpe_vss_point_commitment")
+    return out
+
+
 # ---- identifiable abort (gg_2020/blame.rs) ----
 def gg20_blame5(ctx, keys, B, opened, keyset=None):
     """opened: dict of device tensors (fields _native.Blame5In) -> bad_actors bit masks [B] (device int32)"""

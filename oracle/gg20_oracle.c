@@ -927,3 +927,141 @@ void orc_gg20_blame7(int S, int B, const orc_blame7_in* in, uint32_t* bad_out) {
 void orc_gg20_party_sigma(const orc_gg20_party* P, uint32_t* sigma /*[B][8]*/) {
   for (int b = 0; b < P->B; ++b) memcpy(sigma + (size_t)b * 8, P->s[b].sigma_i, 32);
 }
+
+/* ==========================================================================================================================
+ * Keygen VERIFICATION math: what every party checks about every other party's first keygen messages and
+ * shares — src/protocols/multi_party_ecdsa/gg_2020/party_i.rs:260-320 (phase1_verify_com_phase3_verify_correct_key_verify_dlog…),
+ * :322-367 (phase2_verify_vss…), :405-438 (verify_dlog_proofs_check_against_vss).  The two zk-paillier 0.4.3 proofs are
+ * un-vendored; their definitions below are RECALLED — parity unpinned like the rest of this oracle.
+ * ========================================================================================================================== */
+/* zk-paillier `compute_digest`: SHA-256 over the minimal big-endian bytes of every value, digest as BigInt */
+static void zkp_digest(mpz_t out, const mpz_t* vals, int n) {
+  sha_t sh; sha_init(&sh);
+  for (int i = 0; i < n; ++i) chain_bigint(&sh, vals[i]);
+  result_bigint(&sh, out);
+}
+/* CompositeDLogProof{x, y}::verify(statement{N, g, ni}) (zk-paillier composite_dlog_proof.rs): N >= 2^128, gcd(g, N) = gcd(ni, N) = 1,
+ * e = H(x, g, N, ni), x == g^y ni^e mod N.   y: [B][73] (r < 2^512, e 256 bit, secret < phi: y < 2^2306) */
+void orc_composite_dlog_verify(int batch, const uint32_t* N, const uint32_t* g, const uint32_t* ni, const uint32_t* x, const uint32_t* y,
+                               uint8_t* ok) {
+  mpz_t v[4], Y, e, a, b, lim; mpz_inits(v[0], v[1], v[2], v[3], Y, e, a, b, lim, NULL);
+  mpz_ui_pow_ui(lim, 2, 128);
+  for (int i = 0; i < batch; ++i) {
+    zin(v[0], x + (size_t)i * 64, 64); zin(v[1], g + (size_t)i * 64, 64); zin(v[2], N + (size_t)i * 64, 64); zin(v[3], ni + (size_t)i * 64, 64);
+    zin(Y, y + (size_t)i * 73, 73);
+    ok[i] = 0;
+    if (mpz_cmp(v[2], lim) < 0 || mpz_even_p(v[2])) continue;
+    mpz_gcd(a, v[1], v[2]); if (mpz_cmp_ui(a, 1) != 0) continue;
+    mpz_gcd(a, v[3], v[2]); if (mpz_cmp_ui(a, 1) != 0) continue;
+    zkp_digest(e, (const mpz_t*)v, 4);
+    mpz_powm(a, v[1], Y, v[2]); mpz_powm(b, v[3], e, v[2]);
+    mpz_mul(a, a, b); mpz_mod(a, a, v[2]);
+    ok[i] = (uint8_t)(mpz_cmp(a, v[0]) == 0);
+  }
+  mpz_clears(v[0], v[1], v[2], v[3], Y, e, a, b, lim, NULL);
+}
+/* CompositeDLogProof::prove with the nonce r (< 2^512) as input: x = g^r mod N, e = H(x, g, N, ni), y = r + e secret  (fixtures) */
+void orc_composite_dlog_prove(int batch, const uint32_t* N, const uint32_t* g, const uint32_t* ni, const uint32_t* secret, const uint32_t* r,
+                              uint32_t* x, uint32_t* y) {
+  mpz_t v[4], S, R, e; mpz_inits(v[0], v[1], v[2], v[3], S, R, e, NULL);
+  for (int i = 0; i < batch; ++i) {
+    zin(v[1], g + (size_t)i * 64, 64); zin(v[2], N + (size_t)i * 64, 64); zin(v[3], ni + (size_t)i * 64, 64);
+    zin(S, secret + (size_t)i * 64, 64); zin(R, r + (size_t)i * 16, 16);
+    mpz_powm(v[0], v[1], R, v[2]);
+    zkp_digest(e, (const mpz_t*)v, 4);
+    mpz_mul(e, e, S); mpz_add(e, e, R);
+    zout(x + (size_t)i * 64, 64, v[0]); zout(y + (size_t)i * 73, 73, e);
+  }
+  mpz_clears(v[0], v[1], v[2], v[3], S, R, e, NULL);
+}
+/* NiCorrectKeyProof (zk-paillier correct_key_ni.rs): M2 = 11 values sigma_i; rho_i = mask_generation(bit_length(N), H(N, salt, i)) mod N with
+ * mask_generation(len, seed) = sum_j H(seed, j) << (256 j), j < len/256 + 1; verify: sigma_i^N == rho_i mod N for all i and
+ * gcd(N, primorial(6370)) == 1 (no prime below 6370 divides N).  salt = SALT_STRING = "KZen" as BigInt. */
+#define ORC_CK_M2 11
+static void correct_key_rho(mpz_t rho, const mpz_t N, int i) {
+  mpz_t v[3], seed, d, acc, w[2]; mpz_inits(v[0], v[1], v[2], seed, d, acc, w[0], w[1], NULL);
+  static const unsigned char salt[4] = {75, 90, 101, 110};
+  mpz_set(v[0], N); mpz_import(v[1], 4, 1, 1, 0, 0, salt); mpz_set_ui(v[2], (unsigned long)i);
+  zkp_digest(seed, (const mpz_t*)v, 3);
+  const int msklen = (int)(mpz_sizeinbase(N, 2) / 256) + 1;
+  mpz_set_ui(acc, 0);
+  for (int j = 0; j < msklen; ++j) {
+    mpz_set(w[0], seed); mpz_set_ui(w[1], (unsigned long)j);
+    zkp_digest(d, (const mpz_t*)w, 2);
+    mpz_mul_2exp(d, d, 256u * (unsigned)j); mpz_add(acc, acc, d);
+  }
+  mpz_mod(rho, acc, N);
+  mpz_clears(v[0], v[1], v[2], seed, d, acc, w[0], w[1], NULL);
+}
+static int no_small_factor(const mpz_t N) {          /* gcd(N, prod of the primes < 6370) == 1 */
+  for (unsigned long p = 2; p < 6370; ++p) {
+    int prime = 1;
+    for (unsigned long d = 2; d * d <= p; ++d) if (p % d == 0) { prime = 0; break; }
+    if (prime && mpz_divisible_ui_p(N, p)) return 0;
+  }
+  return 1;
+}
+void orc_correct_key_verify(int batch, const uint32_t* N, const uint32_t* sigma /*[B][11][64]*/, uint8_t* ok) {
+  mpz_t n, s, rho; mpz_inits(n, s, rho, NULL);
+  for (int b = 0; b < batch; ++b) {
+    zin(n, N + (size_t)b * 64, 64);
+    int good = mpz_cmp_ui(n, 1) > 0 && no_small_factor(n);
+    for (int i = 0; i < ORC_CK_M2 && good; ++i) {
+      correct_key_rho(rho, n, i);
+      zin(s, sigma + ((size_t)b * ORC_CK_M2 + i) * 64, 64);
+      mpz_powm(s, s, n, n);
+      good = mpz_cmp(s, rho) == 0;
+    }
+    ok[b] = (uint8_t)good;
+  }
+  mpz_clears(n, s, rho, NULL);
+}
+/* NiCorrectKeyProof::proof (fixtures): sigma_i = rho_i^(N^-1 mod phi) mod N */
+void orc_correct_key_prove(int batch, const uint32_t* p, const uint32_t* q, uint32_t* sigma) {
+  mpz_t P, Q, n, phi, d, rho; mpz_inits(P, Q, n, phi, d, rho, NULL);
+  for (int b = 0; b < batch; ++b) {
+    zin(P, p + (size_t)b * 32, 32); zin(Q, q + (size_t)b * 32, 32);
+    mpz_mul(n, P, Q); mpz_sub_ui(P, P, 1); mpz_sub_ui(Q, Q, 1); mpz_mul(phi, P, Q);
+    mpz_invert(d, n, phi);
+    for (int i = 0; i < ORC_CK_M2; ++i) {
+      correct_key_rho(rho, n, i);
+      mpz_powm(rho, rho, d, n);
+      zout(sigma + ((size_t)b * ORC_CK_M2 + i) * 64, 64, rho);
+    }
+  }
+  mpz_clears(P, Q, n, phi, d, rho, NULL);
+}
+/* Feldman VSS (curv VerifiableSS): validate_share(share, index): share G == sum_k index^k C_k; get_point_commitment(index) = that sum.
+ * commitments: [B][t+1][16]; index: [B] (1-based party index). */
+static void vss_point(pt_t* out, const uint32_t* commits, int t1, unsigned long index) {
+  pt_t c; pt_init(&c);
+  mpz_t idx; mpz_init_set_ui(idx, index);
+  out->inf = 1;
+  for (int k = t1 - 1; k >= 0; --k) {                 /* Horner: acc = acc * index + C_k */
+    pt_mul(out, idx, out);
+    pt_in(&c, commits + (size_t)k * 16);
+    pt_add(out, out, &c);
+  }
+  pt_clear(&c); mpz_clear(idx);
+}
+void orc_vss_validate_share(int batch, int t1, const uint32_t* commits, const uint32_t* share, const int32_t* index, uint8_t* ok) {
+  ec_setup();
+  mpz_t s; mpz_init(s);
+  pt_t G, l, r; pt_init(&G); pt_init(&l); pt_init(&r); pt_gen(&G);
+  for (int b = 0; b < batch; ++b) {
+    zin(s, share + (size_t)b * 8, 8);
+    pt_mul(&l, s, &G);
+    vss_point(&r, commits + (size_t)b * t1 * 16, t1, (unsigned long)index[b]);
+    ok[b] = (uint8_t)pt_eq(&l, &r);
+  }
+  pt_clear(&G); pt_clear(&l); pt_clear(&r); mpz_clear(s);
+}
+void orc_vss_point_commitment(int batch, int t1, const uint32_t* commits, const int32_t* index, uint32_t* out) {
+  ec_setup();
+  pt_t r; pt_init(&r);
+  for (int b = 0; b < batch; ++b) {
+    vss_point(&r, commits + (size_t)b * t1 * 16, t1, (unsigned long)index[b]);
+    pt_out(out + (size_t)b * 16, &r);
+  }
+  pt_clear(&r);
+}

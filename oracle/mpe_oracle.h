@@ -203,6 +203,17 @@ void orc_gg20_blame6(const orc_gg20_keys* K, const int32_t* keyset, int B, const
 void orc_gg20_blame7(int S, int B, const orc_blame7_in* in, uint32_t* bad);
 void orc_gg20_party_sigma(const orc_gg20_party* P, uint32_t* sigma);
 
+/* ---- keygen verification math (gg_2020/party_i.rs:260-438; zk-paillier proofs recalled, App. A.5) ------------------------ */
+void orc_composite_dlog_verify(int batch, const uint32_t* N, const uint32_t* g, const uint32_t* ni, const uint32_t* x /*[B][64]*/,
+                               const uint32_t* y /*[B][73]*/, uint8_t* ok);
+void orc_composite_dlog_prove(int batch, const uint32_t* N, const uint32_t* g, const uint32_t* ni, const uint32_t* secret /*[B][64]*/,
+                              const uint32_t* r /*[B][16]*/, uint32_t* x, uint32_t* y);
+void orc_correct_key_verify(int batch, const uint32_t* N, const uint32_t* sigma /*[B][11][64]*/, uint8_t* ok);
+void orc_correct_key_prove(int batch, const uint32_t* p, const uint32_t* q, uint32_t* sigma);
+void orc_vss_validate_share(int batch, int t1, const uint32_t* commits /*[B][t1][16]*/, const uint32_t* share /*[B][8]*/,
+                            const int32_t* index /*[B]*/, uint8_t* ok);
+void orc_vss_point_commitment(int batch, int t1, const uint32_t* commits, const int32_t* index, uint32_t* out /*[B][16]*/);
+
 /* fixture helper (test key material only): smallest prime > start */
 void orc_nextprime(int k32, const uint32_t* start, uint32_t* out);
 

@@ -222,3 +222,46 @@ def lindell_sign(p, q, c3, k1, R2):
     if s2 > Q - s2:
         s2, recid = Q - s2, recid ^ 1
     return rx, s2, recid
+
+
+# ---- keygen verification math (gg_2020/party_i.rs:260-438); zk-paillier 0.4.3 proofs as recalled -----
+def zkp_digest(vals):
+    """zk-paillier compute_digest = hash_bigints"""
+    return hash_bigints(vals)
+
+
+def composite_dlog_prove(N, g, ni, secret, r):
+    x = pow(g, r, N)
+    return x, r + zkp_digest([x, g, N, ni]) * secret
+
+
+def composite_dlog_verify(N, g, ni, x, y):
+    import math
+    if N < (1 << 128) or N % 2 == 0 or math.gcd(g, N) != 1 or math.gcd(ni, N) != 1:
+        return False
+    return pow(g, y, N) * pow(ni, zkp_digest([x, g, N, ni]), N) % N == x
+
+
+def correct_key_rho(N, i):
+    seed = zkp_digest([N, int.from_bytes(bytes([75, 90, 101, 110]), "big"), i])
+    return sum(zkp_digest([seed, j]) << (256 * j) for j in range(N.bit_length() // 256 + 1)) % N
+
+
+def correct_key_prove(p, q):
+    N = p * q
+    d = pow(N, -1, (p - 1) * (q - 1))
+    return [pow(correct_key_rho(N, i), d, N) for i in range(11)]
+
+
+def correct_key_verify(N, sigma):
+    small = [p for p in range(2, 6370) if all(p % d for d in range(2, int(p ** 0.5) + 1))]
+    if N <= 1 or any(N % p == 0 for p in small):
+        return False
+    return all(pow(sigma[i], N, N) == correct_key_rho(N, i) for i in range(11))
+
+
+def vss_point(commits, index):
+    acc = None
+    for c in reversed(commits):
+        acc = ec_add(ec_mul(index, acc) if acc is not None else None, c)
+    return acc

@@ -1,0 +1,56 @@
+"""GPU: mpe_correct_key_verify / mpe_composite_dlog_verify / mpe_vss_* against the oracle (gg_2020/party_i.rs:260-438)."""
+import numpy as np
+import pytest
+import torch
+
+import fixtures as F
+import keygen_fixture as KF
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(ctx, arr):
+    return torch.from_numpy(np.ascontiguousarray(arr).view(np.int32)).to(ctx.device)
+
+
+def test_correct_key_verify_vs_oracle(gpu_ctx, keys):
+    from multi_party_ecdsa_amd import engine as E
+    N, sigma = KF.correct_key_case(keys)                                 # 16 keys x 11 roots
+    sigma[11 * 3 + 7, 5] ^= 2
+    sigma[11 * 9, 0] ^= 1
+    N[12] = F.words([keys[12].p * 6361], 64)[0]                          # small prime factor
+    want = np.zeros(16, dtype=np.uint8)
+    orc.lib.orc_correct_key_verify(16, orc._p(N), orc._p(sigma), orc._p(want))
+    got = E.correct_key_verify(gpu_ctx, _dev(gpu_ctx, N), _dev(gpu_ctx, sigma)).cpu().numpy()
+    assert list(got) == list(want) and list(want) == [0 if i in (3, 9, 12) else 1 for i in range(16)]
+
+
+def test_composite_dlog_verify_vs_oracle(gpu_ctx, keys):
+    from multi_party_ecdsa_amd import engine as E
+    N, g, ni, x, y = KF.composite_dlog_case(keys)
+    y[2, 70] ^= 1
+    x[5, 0] ^= 1
+    ni[7] = F.words([keys[7].Nt - 1], 64)[0]                             # a different statement: proof no longer matches
+    g[11] = F.words([0], 64)[0]                                          # gcd(g, N) != 1
+    want = np.zeros(16, dtype=np.uint8)
+    orc.lib.orc_composite_dlog_verify(16, *[orc._p(a) for a in (N, g, ni, x, y, want)])
+    got = E.composite_dlog_verify(gpu_ctx, *[_dev(gpu_ctx, a) for a in (N, g, ni, x, y)]).cpu().numpy()
+    assert list(got) == list(want) and list(want) == [0 if i in (2, 5, 7, 11) else 1 for i in range(16)]
+
+
+def test_feldman_vs_oracle(gpu_ctx):
+    from multi_party_ecdsa_amd import engine as E
+    t, n, B = 2, 5, 9
+    commits, shares, index, _ = KF.vss_case(t, n, B, seed="vss-gpu")
+    shares[7, 1] ^= 1
+    commits[20, 3] ^= 1                                                  # an off-curve commitment
+    want = np.zeros(B * n, dtype=np.uint8)
+    orc.lib.orc_vss_validate_share(B * n, t + 1, orc._p(commits), orc._p(shares), orc._p(index), orc._p(want))
+    got = E.vss_validate_share(gpu_ctx, t + 1, _dev(gpu_ctx, commits), _dev(gpu_ctx, shares), _dev(gpu_ctx, index)).cpu().numpy()
+    assert list(got) == list(want)
+    commits[20, 3] ^= 1
+    out = orc.u32((B * n, 16))
+    orc.lib.orc_vss_point_commitment(B * n, t + 1, orc._p(commits), orc._p(index), orc._p(out))
+    gp = E.vss_point_commitment(gpu_ctx, t + 1, _dev(gpu_ctx, commits), _dev(gpu_ctx, index)).cpu().numpy().view(np.uint32)
+    assert np.array_equal(gp, out)
