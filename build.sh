@@ -11,7 +11,9 @@ for u in mpe_lib mpe_pair2048 mpe_pair1024; do
   hipcc $FLAGS -c $CS/$u.hip -o build/$u.o 2> build/resource_usage_$u.txt &
   pids+=($!)
 done
-for p in "${pids[@]}"; do wait $p; done
+fail=0
+for p in "${pids[@]}"; do wait $p || fail=1; done
+if [ $fail -ne 0 ]; then grep -h -B2 -A8 "error" build/resource_usage_*.txt | grep -v "^remark" | head -60; echo "BUILD FAILED"; exit 1; fi
 hipcc --offload-arch=gfx950 -fPIC -shared -o build/libmpecdsa_hip.so build/mpe_lib.o build/mpe_pair2048.o build/mpe_pair1024.o
 cp build/libmpecdsa_hip.so multi_party_ecdsa_amd/libmpecdsa_hip.so
 cat build/resource_usage_mpe_lib.txt build/resource_usage_mpe_pair2048.txt build/resource_usage_mpe_pair1024.txt > build/resource_usage.txt

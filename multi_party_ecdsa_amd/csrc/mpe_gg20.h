@@ -121,21 +121,34 @@ __global__ void gather_field_kernel(Slab s, int S, int B, int src_off, int words
   const size_t jb = g / words;
   dst[g] = rec_of(s, (int)(jb / B), (int)(jb % B))[src_off + w];
 }
+// status / bad_actors of a party instance.  Every round has its own [pi] arrays (status + round * nPI): inside a round the
+// FIRST failed check sticks, and the party's status is the first non-zero round — so a check that is evaluated late (the
+// lock-step composition takes the pure verifications of rounds 1 and 5 off the critical path of small batches) still lands
+// where the reference's order of evaluation puts it.
+constexpr int NR = 9;              // rounds 0..7 and SignManual::complete
+__device__ __forceinline__ void fail(int32_t* status, uint32_t* bad, int pi, int code, uint32_t mask) {
+  if (status[pi] == 0) { status[pi] = code; bad[pi] = mask; }
+}
+__device__ __forceinline__ int resolve_status(const int32_t* status, size_t nPI, int pi, int upto, const uint32_t* bad, uint32_t* bad_out) {
+  for (int r = 0; r <= upto; ++r) {
+    const int st = status[(size_t)r * nPI + pi];
+    if (st) { if (bad_out) *bad_out = bad[(size_t)r * nPI + pi]; return st; }
+  }
+  if (bad_out) *bad_out = 0;
+  return 0;
+}
+
 // out record of (li, b), sub-record sub0 + (item % per):  [dst_off .. dst_off+words) = src[item].
 // A party whose status is non-zero has stopped (RoundN::proceed returned Err / panicked in the reference): it sends zeros.
 __global__ void pack_field_kernel(int nitems, int per, int L, int B, int nsub, int sub0, int subw, int dst_off,
-                                  const uint32_t* __restrict__ src, int words, const int32_t* __restrict__ status,
+                                  const uint32_t* __restrict__ src, int words, const int32_t* __restrict__ status, int round,
                                   uint32_t* __restrict__ out) {
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)nitems * words) return;
   const int w = (int)(g % words), item = (int)(g / words), pi = item / per, li = pi % L, b = pi / L;
-  out[((size_t)(li * B + b) * nsub + sub0 + item % per) * subw + dst_off + w] = status[pi] ? 0u : src[g];
+  const bool stopped = resolve_status(status, (size_t)L * B, pi, round, nullptr, nullptr) != 0;
+  out[((size_t)(li * B + b) * nsub + sub0 + item % per) * subw + dst_off + w] = stopped ? 0u : src[g];
 }
-// status / bad_actors of a party instance: the FIRST failed check sticks
-__device__ __forceinline__ void fail(int32_t* status, uint32_t* bad, int pi, int code, uint32_t mask) {
-  if (status[pi] == 0) { status[pi] = code; bad[pi] = mask; }
-}
-
 // Malformed points in the messages a party is about to read (off the curve, non-canonical coordinates, infinity): in the
 // reference such a message does not even deserialise (curv's Point), so the round never sees it.  Here the party's status
 // becomes 100*round + 90 with bad_actors = the senders, BEFORE any secret scalar is multiplied into such a point.
@@ -642,8 +655,9 @@ __global__ void __launch_bounds__(64) complete_kernel(Dim d, Slab in6, const uin
     const ec::Aff V = ec::jac_to_aff(ec::jac_add(ec::jac_mul_gen(u1), ec::jac_mul(u2, ec::aff_load(y + (size_t)ks_of(d, b) * 16))));
     okv = !V.inf && ec::u256_eq(ec::sc_reduce(V.x.w, 8), r);
   }
-  if (!okv) fail(status, bad, pi, 701, 0);
-  const bool good = status[pi] == 0;
+  const size_t nPI = (size_t)d.B * d.L;
+  if (!okv) fail(status + 8 * nPI, bad + 8 * nPI, pi, 701, 0);
+  const bool good = resolve_status(status, nPI, pi, NR - 1, nullptr, nullptr) == 0;
   const size_t o = (size_t)li * d.B + b;
   ec::u256_store(r_out + o * 8, good ? r : ec::u256_zero());
   ec::u256_store(s_out + o * 8, good ? s : ec::u256_zero());
@@ -655,8 +669,10 @@ __global__ void result_kernel(Dim d, const int32_t* __restrict__ status, const u
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
   const size_t o = (size_t)(pi % d.L) * d.B + pi / d.L;
-  if (st_out) st_out[o] = status[pi];
-  if (bad_out) bad_out[o] = bad[pi];
+  uint32_t bm = 0;
+  const int stv = resolve_status(status, (size_t)d.B * d.L, pi, NR - 1, bad, &bm);
+  if (st_out) st_out[o] = stv;
+  if (bad_out) bad_out[o] = bm;
   if (R_out) for (int j = 0; j < 16; ++j) R_out[o * 16 + j] = R[(size_t)pi * 16 + j];
 }
 // the lock-step composition: a session's status = the smallest non-zero party status; the signature is party 0's
@@ -698,6 +714,11 @@ struct mpe_gg20_session {
   uint32_t *sig_r = nullptr, *sig_s = nullptr;
   uint32_t* miu = nullptr;         // [pp][64] the plaintexts of the incoming w_i MessageBs before reduction (LocalStatePhase6::miu, blame.rs:227-234)
   int32_t *status = nullptr, *sig_recid = nullptr;
+  int32_t *sub0_vi = nullptr, *sub4_pv = nullptr, *rdash_pv = nullptr;
+  uint8_t *ok_vi = nullptr, *ok_pv = nullptr;
+  bool deferred1 = false, deferred5 = false;
+  bool defer = false;              // the pure verifications of rounds 1 / 5 run on background streams, joined in mpe_gg20_complete
+  mpe::gg::Slab defer_in4{};                // the M4 slab the deferred round-5 status reads
   int fault_step = 0;              // fault injection of the reference's tests (gg_2020/test.rs:282-289,458-465,679-686): 5 / 6 / 7
   uint32_t fault_mask = 0;         // signer ordinals that double their delta_i / sigma_i / s_i
   char* tmp = nullptr;             // per-round scratch (dense outputs of the composites before they are packed)
@@ -768,9 +789,11 @@ static size_t layout(mpe_gg20_session* s, char* base) {
   s->ca_all = m.w(c.SB * 128); s->com_all = m.w(c.SB * 8); s->bpk_in = m.w(c.nPP * 16);
   s->delta_i = m.w(c.nPI * 8); s->sigma_i = m.w(c.nPI * 8); s->lq = m.w(c.nPI * 8); s->pedT = m.w(c.nPI * 16);
   s->tvec = m.w(c.SB * 16); s->dinv = m.w(c.nPI * 8); s->R = m.w(c.nPI * 16); s->Rbar = m.w(c.nPI * 16);
-  s->mq = m.w(c.nPI * 8); s->rq = m.w(c.nPI * 8); s->s_i = m.w(c.nPI * 8); s->bad = m.w(c.nPI);
+  s->mq = m.w(c.nPI * 8); s->rq = m.w(c.nPI * 8); s->s_i = m.w(c.nPI * 8); s->bad = m.w(c.nPI * NR);
   s->sig_r = m.w(c.nPI * 8); s->sig_s = m.w(c.nPI * 8); s->miu = m.w(c.nPP * 64);
-  s->status = m.i(c.nPI); s->sig_recid = m.i(c.nPI);
+  s->status = m.i(c.nPI * NR); s->sig_recid = m.i(c.nPI);
+  // deferred verifications (lock-step composition of small batches): their index tables and verdicts outlive the round scratch
+  s->sub0_vi = m.i(c.nVI); s->ok_vi = m.f(c.nVI); s->sub4_pv = m.i(c.nPV); s->rdash_pv = m.i(c.nPV); s->ok_pv = m.f(c.nPV);
   s->tmp_bytes = tmp_bytes_of(c);
   s->tmp = (char*)m.take(s->tmp_bytes);
   return m.off;
@@ -793,9 +816,11 @@ static int round_exit(mpe_gg20_session* s, int rc, const char* what) {
   s->next_round++;
   return MPE_OK;
 }
+#define STAT(r) (s->status + (size_t)(r) * c.nPI)
+#define BADR(r) (s->bad + (size_t)(r) * c.nPI)
 #define PACK(nitems, per, nsub, sub0, subw, dst_off, src, words)                                                              \
   GG_LAUNCH(pack_field_kernel, (size_t)(nitems) * (words), (int)(nitems), (int)(per), d.L, d.B, (int)(nsub), (int)(sub0), (int)(subw),  \
-            (int)(dst_off), (const uint32_t*)(src), (int)(words), s->status, d_out)
+            (int)(dst_off), (const uint32_t*)(src), (int)(words), s->status, s->next_round, d_out)
 
 // ---- Round0::proceed (rounds.rs:68-104) ------------------------------------------------------------------------------
 static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
@@ -840,16 +865,33 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   GG_LAUNCH(gather_field_kernel, c.SB * 128, in0, d.S, d.B, n * SUB0, 128, s->ca_all);
   GG_LAUNCH(gather_field_kernel, c.SB * 8, in0, d.S, d.B, n * SUB0 + 128, 8, s->com_all);
   Bump t(s->tmp);
-  int32_t* sub0_vi = t.i(c.nVI);
-  uint8_t* ok_vi = t.f(c.nVI);
+  int32_t* sub0_vi = s->sub0_vi;
+  uint8_t* ok_vi = s->ok_vi;
   uint32_t *bsel = t.w(c.nMB * 8), *btq = t.w(c.nMB * 8), *c_b = t.w(c.nMB * 128);
   uint32_t *Bpk = t.w(c.nMB * 16), *BR = t.w(c.nMB * 16), *Bz = t.w(c.nMB * 8), *BTpk = t.w(c.nMB * 16), *BTR = t.w(c.nMB * 16), *BTz = t.w(c.nMB * 8);
   GG_LAUNCH(idx1_kernel, c.nVI, d, in0, sub0_vi);
   // small batches: the verification of the peers' range proofs and the construction of my MessageBs are independent
-  // (the reference runs them back to back inside MessageB::b) — two streams, one workspace reservation
+  // (the reference runs them back to back inside MessageB::b) — two streams, one workspace reservation.  In the lock-step
+  // composition (s->defer) the verification is a pure check nothing downstream consumes: it runs on a background stream out
+  // of its own workspace and its verdict (status 101) is collected when the signature is completed.
   const bool par = ctx->allow_par && (int)c.nVI <= ctx->par_items;
-  if (par && rc == MPE_OK) { rc = ws_reserve(ctx, ws_need_alice_verify((int)c.nVI) + ws_need_mul_add_enc((int)c.nMB), st); if (rc == MPE_OK) ctx->ws_hold++; }
-  const bool held = par && rc == MPE_OK;
+  const bool defer = s->defer && par && ensure_aux(ctx);
+  if (par && !defer && rc == MPE_OK) { rc = ws_reserve(ctx, ws_need_alice_verify((int)c.nVI) + ws_need_mul_add_enc((int)c.nMB), st); if (rc == MPE_OK) ctx->ws_hold++; }
+  const bool held = par && !defer && rc == MPE_OK;
+  if (defer && rc == MPE_OK) {
+    (void)hipEventRecord(ctx->ev_fork[1], st);
+    (void)hipStreamWaitEvent(ctx->bg[0], ctx->ev_fork[1], 0);
+    const bool keep = ctx->allow_par;
+    ctx->allow_par = false;                                     // one stream: the auxiliary streams belong to the critical path
+    {
+      WsSwap sw(ctx, 0);
+      AliceProofRows pr{rows(d_in, SUB0, sub0_vi), rows(d_in + 64, SUB0, sub0_vi), rows(d_in + 72, SUB0, sub0_vi),
+                        rows(d_in + 136, SUB0, sub0_vi), rows(d_in + 161, SUB0, sub0_vi)};
+      rc = alice_verify(ctx, K->pub, K->stm, (int)c.nVI, s->ix.kpub_vi, s->ix.st_vi, rows(s->ca_all, 128, s->ix.ca_vi), pr, ok_vi, ctx->bg[0]);
+    }
+    ctx->allow_par = keep;
+    (void)hipEventRecord(ctx->ev_bg[0], ctx->bg[0]);
+  }
   Fork g(ctx, st, 2, held, 2);
   {
     hipStream_t st2 = g.s(1);
@@ -864,7 +906,7 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
       hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, btq, Z.mb_nonce_bt, BTpk, BTR, BTz);   // :148
     }
   }
-  if (rc == MPE_OK) {      // every range proof of every peer, for both MessageB::b calls (mta/mod.rs:119-131), read in place
+  if (rc == MPE_OK && !defer) {      // every range proof of every peer, for both MessageB::b calls (mta/mod.rs:119-131), read in place
     AliceProofRows pr{rows(d_in, SUB0, sub0_vi), rows(d_in + 64, SUB0, sub0_vi), rows(d_in + 72, SUB0, sub0_vi),
                       rows(d_in + 136, SUB0, sub0_vi), rows(d_in + 161, SUB0, sub0_vi)};
     rc = alice_verify(ctx, K->pub, K->stm, (int)c.nVI, s->ix.kpub_vi, s->ix.st_vi, rows(s->ca_all, 128, s->ix.ca_vi), pr, ok_vi, st);
@@ -872,7 +914,8 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   gg_trace(st, "alice_verify", rc);
   g.join();
   if (held) ctx->ws_hold--;
-  GG_LAUNCH(status1_kernel, c.nPI, d, ok_vi, s->status, s->bad);
+  if (!defer) GG_LAUNCH(status1_kernel, c.nPI, d, ok_vi, STAT(1), BADR(1));
+  s->deferred1 = defer;
   const int per = 2 * P1;
   PACK(c.nMB, per, per, 0, SUB1, 0, c_b, 128); PACK(c.nMB, per, per, 0, SUB1, 128, Bpk, 16); PACK(c.nMB, per, per, 0, SUB1, 144, BR, 16);
   PACK(c.nMB, per, per, 0, SUB1, 160, Bz, 8); PACK(c.nMB, per, per, 0, SUB1, 168, BTpk, 16); PACK(c.nMB, per, per, 0, SUB1, 184, BTR, 16);
@@ -887,7 +930,7 @@ static int round2(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   mpe_ctx* ctx = s->ctx; const mpe_gg20_keys* K = s->K; const Dim& d = s->d; const Counts c = counts_of(d); const mpe_gg20_nonces& Z = s->Z;
   const Slab in1 = slab_of(s, d_in, h_off, 1);
   (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)W2 * 4, st);
-  GG_LAUNCH(validate_kernel, c.nPI, d, in1, 2, s->status, s->bad);
+  GG_LAUNCH(validate_kernel, c.nPI, d, in1, 2, STAT(2), BADR(2));
   Bump t(s->tmp);
   int32_t* sub1_rv = t.i(c.nMB);
   uint32_t *alpha_full = t.w(c.nMB * 64), *alpha = t.w(c.nMB * 8);
@@ -901,7 +944,7 @@ static int round2(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   if (c.nMB * 4 <= lanes_fit) GG_LAUNCH(r2a_group_kernel, c.nMB * 4, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
   else GG_LAUNCH(r2a_kernel, c.nMB, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
   GG_LAUNCH(r2b_kernel, c.nPI, d, s->kq, s->gq, s->w, alpha, s->beta, code, Z.l, Z.ped_s1, Z.ped_s2, s->delta_i, s->sigma_i, s->lq, ped,
-            s->status, s->bad, alpha_full, s->miu, s->fault_step, s->fault_mask);
+            STAT(2), BADR(2), alpha_full, s->miu, s->fault_step, s->fault_mask);
   PACK(c.nPI, 1, 1, 0, W2, 0, s->delta_i, 8); PACK(c.nPI, 1, 1, 0, W2, 8, ped.T, 16); PACK(c.nPI, 1, 1, 0, W2, 24, ped.e, 8);
   PACK(c.nPI, 1, 1, 0, W2, 32, ped.a1, 16); PACK(c.nPI, 1, 1, 0, W2, 48, ped.a2, 16); PACK(c.nPI, 1, 1, 0, W2, 64, ped.T, 16);
   PACK(c.nPI, 1, 1, 0, W2, 80, ped.z1, 8); PACK(c.nPI, 1, 1, 0, W2, 88, ped.z2, 8);
@@ -915,12 +958,12 @@ static int round3(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   mpe_ctx* ctx = s->ctx; const Dim& d = s->d; const Counts c = counts_of(d);
   const Slab in2 = slab_of(s, d_in, h_off, 2);
   (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)W3 * 4, st);
-  GG_LAUNCH(validate_kernel, c.nPI, d, in2, 3, s->status, s->bad);
+  GG_LAUNCH(validate_kernel, c.nPI, d, in2, 3, STAT(3), BADR(3));
   GG_LAUNCH(gather_field_kernel, c.SB * 16, in2, d.S, d.B, 8, 16, s->tvec);                  // t_vec
   const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 : 0;
   const int g3 = 2 * d.S <= 4 ? 4 : (2 * d.S <= 8 ? 8 : 16);
-  if (c.nPI * g3 <= lanes_fit) GG_LAUNCH(r3_group_kernel, c.nPI * g3, d, g3, in2, s->dinv, s->status, s->bad);
-  else GG_LAUNCH(r3_kernel, c.nPI, d, in2, s->dinv, s->status, s->bad);
+  if (c.nPI * g3 <= lanes_fit) GG_LAUNCH(r3_group_kernel, c.nPI * g3, d, g3, in2, s->dinv, STAT(3), BADR(3));
+  else GG_LAUNCH(r3_kernel, c.nPI, d, in2, s->dinv, STAT(3), BADR(3));
   PACK(c.nPI, 1, 1, 0, W3, 0, s->Z.blind, 8); PACK(c.nPI, 1, 1, 0, W3, 8, s->g_gamma, 16);          // SignDecommitPhase1
   return round_exit(s, rc, "gg20 round3");
 }
@@ -933,12 +976,12 @@ static int round4(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   const int S = d.S, P1 = S - 1;
   const Slab in3 = slab_of(s, d_in, h_off, 3);
   (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)msg_words(S, d.n, 4) * 4, st);
-  GG_LAUNCH(validate_kernel, c.nPI, d, in3, 4, s->status, s->bad);
+  GG_LAUNCH(validate_kernel, c.nPI, d, in3, 4, STAT(4), BADR(4));
   // small batches: R and R_dash (two dependent scalar multiplications) beside the Paillier / N~ half of the PDL proofs
   Fork g(ctx, st, 2, ctx->allow_par && (int)c.nPP <= ctx->par_items, 2);
   if (rc == MPE_OK && c.nPI > 0)
     hipLaunchKernelGGL(r4_kernel, dim3(blocks_for((int)c.nPI, 64)), dim3(64), 0, g.s(1), d, in3, s->dinv, s->com_all, s->bpk_in, s->kq, s->R, s->Rbar,
-                       s->status, s->bad);
+                       STAT(4), BADR(4));
   Bump t(s->tmp);
   mpe_pdl_proof pp{t.w(c.nPP * 64), t.w(c.nPP * 16), t.w(c.nPP * 128), t.w(c.nPP * 64), t.w(c.nPP * 25), t.w(c.nPP * 64), t.w(c.nPP * 89)};
   mpe_pdl_nonces pn{Z.pdl_alpha, Z.pdl_beta, Z.pdl_rho, Z.pdl_gamma};
@@ -961,24 +1004,43 @@ static int round5(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   mpe_ctx* ctx = s->ctx; const mpe_gg20_keys* K = s->K; const Dim& d = s->d; const Counts c = counts_of(d); const mpe_gg20_nonces& Z = s->Z;
   const Slab in4 = slab_of(s, d_in, h_off, 4);
   (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)W5 * 4, st);
-  GG_LAUNCH(validate_kernel, c.nPI, d, in4, 5, s->status, s->bad);
+  GG_LAUNCH(validate_kernel, c.nPI, d, in4, 5, STAT(5), BADR(5));
   Bump t(s->tmp);
-  int32_t *sub4_pv = t.i(c.nPV), *rdash_pv = t.i(c.nPV);
-  uint8_t* ok_pv = t.f(c.nPV);
+  int32_t *sub4_pv = s->sub4_pv, *rdash_pv = s->rdash_pv;
+  uint8_t* ok_pv = s->ok_pv;
   Heg heg{t.w(c.nPI * 16), t.w(c.nPI * 16), t.w(c.nPI * 16), t.w(c.nPI * 8), t.w(c.nPI * 8)};
   GG_LAUNCH(idx5_kernel, c.nPV, d, in4, sub4_pv, rdash_pv);
-  Fork g(ctx, st, 2, ctx->allow_par && (int)c.nPV <= ctx->par_items, 2);
-  if (rc == MPE_OK && c.nPI > 0)
-    hipLaunchKernelGGL(r5_prove_kernel, dim3(blocks_for((int)c.nPI, 64)), dim3(64), 0, g.s(1), d, s->R, s->sigma_i, s->lq, s->pedT, Z.heg_s1, Z.heg_s2, heg);
-  if (rc == MPE_OK) {      // phase5_verify_pdl for every prover (mine included), G = the VERIFIER's R (rounds.rs:546-558)
-    PdlProofRows pr{rows(d_in, SUB4, sub4_pv), rows(d_in + 64, SUB4, sub4_pv), rows(d_in + 80, SUB4, sub4_pv), rows(d_in + 208, SUB4, sub4_pv),
-                    rows(d_in + 272, SUB4, sub4_pv), rows(d_in + 297, SUB4, sub4_pv), rows(d_in + 361, SUB4, sub4_pv)};
-    rc = pdl_verify(ctx, K->pub, K->stm, (int)c.nPV, s->ix.kpub_pv, s->ix.st_pv, rows(s->ca_all, 128, s->ix.ca_pv), rows(d_in, SUB4, rdash_pv),
-                    rows(s->R, 16, s->ix.pi_pv), pr, ok_pv, st);
+  const bool par = ctx->allow_par && (int)c.nPV <= ctx->par_items;
+  const bool defer = s->defer && par && ensure_aux(ctx);
+  PdlProofRows pr{rows(d_in, SUB4, sub4_pv), rows(d_in + 64, SUB4, sub4_pv), rows(d_in + 80, SUB4, sub4_pv), rows(d_in + 208, SUB4, sub4_pv),
+                  rows(d_in + 272, SUB4, sub4_pv), rows(d_in + 297, SUB4, sub4_pv), rows(d_in + 361, SUB4, sub4_pv)};
+  if (defer && rc == MPE_OK) {      // the lock-step composition: phase5_verify_pdl is a pure check -> background stream, own workspace
+    (void)hipEventRecord(ctx->ev_fork[1], st);
+    (void)hipStreamWaitEvent(ctx->bg[1], ctx->ev_fork[1], 0);
+    const bool keep = ctx->allow_par;
+    ctx->allow_par = false;
+    {
+      WsSwap sw(ctx, 1);
+      rc = pdl_verify(ctx, K->pub, K->stm, (int)c.nPV, s->ix.kpub_pv, s->ix.st_pv, rows(s->ca_all, 128, s->ix.ca_pv), rows(d_in, SUB4, rdash_pv),
+                      rows(s->R, 16, s->ix.pi_pv), pr, ok_pv, ctx->bg[1]);
+    }
+    ctx->allow_par = keep;
+    (void)hipEventRecord(ctx->ev_bg[1], ctx->bg[1]);
+    s->defer_in4 = in4;
+    if (rc == MPE_OK && c.nPI > 0)
+      hipLaunchKernelGGL(r5_prove_kernel, dim3(blocks_for((int)c.nPI, 64)), dim3(64), 0, st, d, s->R, s->sigma_i, s->lq, s->pedT, Z.heg_s1, Z.heg_s2, heg);
+  } else {
+    Fork g(ctx, st, 2, par, 2);
+    if (rc == MPE_OK && c.nPI > 0)
+      hipLaunchKernelGGL(r5_prove_kernel, dim3(blocks_for((int)c.nPI, 64)), dim3(64), 0, g.s(1), d, s->R, s->sigma_i, s->lq, s->pedT, Z.heg_s1, Z.heg_s2, heg);
+    if (rc == MPE_OK)      // phase5_verify_pdl for every prover (mine included), G = the VERIFIER's R (rounds.rs:546-558)
+      rc = pdl_verify(ctx, K->pub, K->stm, (int)c.nPV, s->ix.kpub_pv, s->ix.st_pv, rows(s->ca_all, 128, s->ix.ca_pv), rows(d_in, SUB4, rdash_pv),
+                      rows(s->R, 16, s->ix.pi_pv), pr, ok_pv, st);
+    gg_trace(st, "pdl_verify", rc);
+    g.join();
+    GG_LAUNCH(r5_status_kernel, c.nPI, d, in4, ok_pv, STAT(5), BADR(5));
   }
-  gg_trace(st, "pdl_verify", rc);
-  g.join();
-  GG_LAUNCH(r5_status_kernel, c.nPI, d, in4, ok_pv, s->status, s->bad);
+  s->deferred5 = defer;
   PACK(c.nPI, 1, 1, 0, W5, 0, heg.S, 16); PACK(c.nPI, 1, 1, 0, W5, 16, heg.T, 16); PACK(c.nPI, 1, 1, 0, W5, 32, heg.A3, 16);
   PACK(c.nPI, 1, 1, 0, W5, 48, heg.z1, 8); PACK(c.nPI, 1, 1, 0, W5, 56, heg.z2, 8);
   return round_exit(s, rc, "gg20 round5");
@@ -990,11 +1052,11 @@ static int round6(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   if (rc != MPE_OK) return rc;
   mpe_ctx* ctx = s->ctx; const Dim& d = s->d; const Counts c = counts_of(d);
   const Slab in5 = slab_of(s, d_in, h_off, 5);
-  GG_LAUNCH(validate_kernel, c.nPI, d, in5, 6, s->status, s->bad);
+  GG_LAUNCH(validate_kernel, c.nPI, d, in5, 6, STAT(6), BADR(6));
   const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 : 0;
   const int g6 = 3 * d.S <= 8 ? 8 : (3 * d.S <= 16 ? 16 : 32);
-  if (c.nPI * g6 <= lanes_fit) GG_LAUNCH(r6_group_kernel, c.nPI * g6, d, g6, in5, s->R, s->tvec, s->K->y, s->status, s->bad);
-  else GG_LAUNCH(r6_kernel, c.nPI, d, in5, s->R, s->tvec, s->K->y, s->status, s->bad);
+  if (c.nPI * g6 <= lanes_fit) GG_LAUNCH(r6_group_kernel, c.nPI * g6, d, g6, in5, s->R, s->tvec, s->K->y, STAT(6), BADR(6));
+  else GG_LAUNCH(r6_kernel, c.nPI, d, in5, s->R, s->tvec, s->K->y, STAT(6), BADR(6));
   return round_exit(s, rc, "gg20 round6");
 }
 
@@ -1013,6 +1075,8 @@ static int complete(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_
   if (rc != MPE_OK) return rc;
   const Dim& d = s->d; const Counts c = counts_of(d);
   const Slab in6 = slab_of(s, d_in, h_off, 7);
+  if (s->deferred1) { (void)hipStreamWaitEvent(st, s->ctx->ev_bg[0], 0); GG_LAUNCH(status1_kernel, c.nPI, d, s->ok_vi, STAT(1), BADR(1)); }
+  if (s->deferred5) { (void)hipStreamWaitEvent(st, s->ctx->ev_bg[1], 0); GG_LAUNCH(r5_status_kernel, c.nPI, d, s->defer_in4, s->ok_pv, STAT(5), BADR(5)); }
   GG_LAUNCH(complete_kernel, c.nPI, d, in6, s->R, s->mq, s->rq, s->s_i, s->K->y, s->status, s->bad, s->sig_r, s->sig_s, s->sig_recid);
   return round_exit(s, rc, "gg20 complete");
 }
@@ -1128,8 +1192,8 @@ int mpe_gg20_session_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, 
   s->mem_bytes = bytes;
   (void)mpe::gg::layout(s, (char*)s->mem);
   const mpe::gg::Counts c = mpe::gg::counts_of(d);
-  (void)hipMemsetAsync(s->status, 0, c.nPI * 4, st);
-  (void)hipMemsetAsync(s->bad, 0, c.nPI * 4, st);
+  (void)hipMemsetAsync(s->status, 0, c.nPI * mpe::gg::NR * 4, st);
+  (void)hipMemsetAsync(s->bad, 0, c.nPI * mpe::gg::NR * 4, st);
   size_t total = c.nVI;
   if (c.nMB > total) total = c.nMB;
   if (c.nAP > total) total = c.nAP;
@@ -1222,19 +1286,30 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int3
   int maxw = 0;
   for (int r = 0; r < 8; ++r) { const int w = mpe::gg::msg_words(S, n, r); if (w > maxw) maxw = w; }
   const int Bc = batch < chunk ? batch : chunk;
-  // two message slabs (ping-pong) + the per-party results of a pass
-  const size_t slab_words = (size_t)S * Bc * maxw;
+  // Experiment switch (MPE_DEFER=1): the lock-step composition takes the pure verifications of rounds 1 and 5 off the
+  // critical path (background streams, joined when the signature is completed).  They read the round-0 / round-4 messages in
+  // place, so every round keeps its own slab in that mode; otherwise two slabs alternate.  Measured on MI355X at 1024
+  // sessions it buys nothing (166.7 ms with, 163.5 ms without): the verifications already overlap my own MessageB
+  // construction through the per-round forks and those kernels fill the chip, so it stays off by default.
+  static const int out_rounds[7] = {0, 1, 2, 3, 4, 5, 7};
+  const bool defer = ctx->allow_par && (size_t)Bc * S * (S - 1) * (dedup_verify ? 1 : 2) * n <= (size_t)ctx->par_items && getenv("MPE_DEFER");
+  size_t slab_off[7], slab_words = 0;
+  for (int q = 0; q < 7; ++q) {
+    const size_t w = (size_t)S * Bc * (defer ? mpe::gg::msg_words(S, n, out_rounds[q]) : maxw);
+    if (defer) { slab_off[q] = slab_words; slab_words += w; }
+    else { slab_off[q] = (q & 1) ? w : 0; slab_words = 2 * w; }
+  }
   const size_t res_words = (size_t)S * Bc * (1 + 8 + 8 + 1 + 16);
-  const size_t need = (2 * slab_words + res_words) * 4 + 4096;
+  const size_t need = (slab_words + res_words) * 4 + 4096;
   if (need > ctx->slab_bytes) {
     if (ctx->slab_buf) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->slab_buf); ctx->slab_buf = nullptr; ctx->slab_bytes = 0; }
     const hipError_t e = hipMalloc(&ctx->slab_buf, need);
     if (e != hipSuccess) { mpe_set_error("hipMalloc(gg20 message slabs)", e); return MPE_E_NOMEM; }
     ctx->slab_bytes = need;
   }
-  uint32_t* A = (uint32_t*)ctx->slab_buf;
-  uint32_t* Bs = A + slab_words;
-  int32_t* pst = (int32_t*)(Bs + slab_words);
+  uint32_t* M[7];
+  for (int q = 0; q < 7; ++q) M[q] = (uint32_t*)ctx->slab_buf + slab_off[q];
+  int32_t* pst = (int32_t*)((uint32_t*)ctx->slab_buf + slab_words);
   uint32_t* pr = (uint32_t*)(pst + (size_t)S * Bc);
   uint32_t* ps = pr + (size_t)S * Bc * 8;
   int32_t* prec = (int32_t*)(ps + (size_t)S * Bc * 8);
@@ -1252,15 +1327,20 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int3
     mpe_gg20_session* s = nullptr;
     int rc = mpe_gg20_session_create(ctx, keys, B, S, local, d_keyset ? d_keyset + b0 : nullptr, &Z, dedup_verify, &s, stream);
     if (rc != MPE_OK) return rc;
-    rc = mpe::gg::round0(s, A, st);
-    if (rc == MPE_OK) rc = mpe::gg::round1(s, A, nullptr, Bs, st);
-    if (rc == MPE_OK) rc = mpe::gg::round2(s, Bs, nullptr, A, st);
-    if (rc == MPE_OK) rc = mpe::gg::round3(s, A, nullptr, Bs, st);
-    if (rc == MPE_OK) rc = mpe::gg::round4(s, Bs, nullptr, A, st);
-    if (rc == MPE_OK) rc = mpe::gg::round5(s, A, nullptr, Bs, st);
-    if (rc == MPE_OK) rc = mpe::gg::round6(s, Bs, nullptr, st);
-    if (rc == MPE_OK) rc = mpe::gg::round7(s, Z.msg, A, st);
-    if (rc == MPE_OK) rc = mpe::gg::complete(s, A, nullptr, st);
+    s->defer = defer;
+    rc = mpe::gg::round0(s, M[0], st);
+    if (rc == MPE_OK) rc = mpe::gg::round1(s, M[0], nullptr, M[1], st);
+    if (rc == MPE_OK) rc = mpe::gg::round2(s, M[1], nullptr, M[2], st);
+    if (rc == MPE_OK) rc = mpe::gg::round3(s, M[2], nullptr, M[3], st);
+    if (rc == MPE_OK) rc = mpe::gg::round4(s, M[3], nullptr, M[4], st);
+    if (rc == MPE_OK) rc = mpe::gg::round5(s, M[4], nullptr, M[5], st);
+    if (rc == MPE_OK) rc = mpe::gg::round6(s, M[5], nullptr, st);
+    if (rc == MPE_OK) rc = mpe::gg::round7(s, Z.msg, M[6], st);
+    if (rc == MPE_OK) rc = mpe::gg::complete(s, M[6], nullptr, st);
+    if (rc != MPE_OK && defer) {       // never leave background work behind an error return
+      if (ctx->bg[0]) (void)hipStreamSynchronize(ctx->bg[0]);
+      if (ctx->bg[1]) (void)hipStreamSynchronize(ctx->bg[1]);
+    }
     if (rc == MPE_OK) rc = mpe_gg20_session_result(s, pst, nullptr, pr, ps, prec, pR, stream);
     if (rc == MPE_OK)
       hipLaunchKernelGGL(mpe::gg::sign_finish_kernel, dim3(mpe::blocks_for(B, 64)), dim3(64), 0, st, B, S, b0, pst, pr, ps, prec, pR, d_r, d_s,
