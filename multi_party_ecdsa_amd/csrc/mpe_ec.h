@@ -4,17 +4,16 @@
 // `Point<Secp256k1>` / `Scalar<Secp256k1>` (libsecp256k1 underneath) and `sha2::Sha256`:
 // call sites src/utilities/mta/mod.rs:147-148,166-171, src/utilities/zk_pdl_with_slack/mod.rs:86,
 // 102-110,138-142, src/protocols/multi_party_ecdsa/gg_2020/party_i.rs:546-936.
-// EC work is ~1 % of a signing session's multiplies, so these are plain
-// per-lane routines: 8x8 schoolbook with 64-bit accumulators, Jacobian coordinates, a fixed 4-bit
-// window ladder with a constant operation sequence (scalars on this path are secret).
+// One item per lane.  The base field lives in mpe_fe.h (10 x 26-bit limbs, lazy reduction: no carry chains inside a
+// multiplication), the Jacobian formulas and the window ladders in mpe_jac.h; this file keeps the 32-bit word helpers,
+// the scalar field (mod q, 8 x 32-bit words: cold), the comb tables of the two fixed generators and SHA-256.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mpe_jac.h"
 
 namespace mpe {
 namespace ec {
-
-struct U256 { uint32_t w[8]; };
 
 __device__ __constant__ const uint32_t FP[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu,
                                                  0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -73,108 +72,6 @@ __device__ __forceinline__ void mul_wide(uint32_t (&t)[16], const U256& a, const
   }
 }
 
-// a^2 -> 16 words: 28 cross products doubled + 8 squares (36 multiplies instead of 64)
-__device__ __forceinline__ void sqr_wide(uint32_t (&t)[16], const U256& a) {
-  for (int i = 0; i < 16; ++i) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    uint64_t c = 0;
-#pragma unroll
-    for (int j = i + 1; j < 8; ++j) {
-      const uint64_t v = (uint64_t)a.w[i] * a.w[j] + t[i + j] + c;
-      t[i + j] = (uint32_t)v;
-      c = v >> 32;
-    }
-    t[i + 8] = (uint32_t)c;
-  }
-  uint32_t top = 0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { const uint32_t nt = t[i] >> 31; t[i] = (t[i] << 1) | top; top = nt; }
-  uint64_t c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint64_t sq = (uint64_t)a.w[i] * a.w[i];
-    c += (uint64_t)t[2 * i] + (uint32_t)sq; t[2 * i] = (uint32_t)c; c >>= 32;
-    c += (uint64_t)t[2 * i + 1] + (sq >> 32); t[2 * i + 1] = (uint32_t)c; c >>= 32;
-  }
-}
-
-// ---- field: mod p = 2^256 - 2^32 - 977 ------------------------------------------------------
-__device__ __forceinline__ U256 fe_reduce_wide(const uint32_t (&t)[16]) {
-  // t = lo + hi 2^256,  2^256 = 2^32 + 977 (mod p):  r = lo + hi*977 + (hi << 32), twice
-  uint32_t r[10];
-  uint64_t c = 0;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const uint64_t lo = i < 8 ? t[i] : 0, h977 = i < 8 ? (uint64_t)t[8 + i] * 977u : 0, hs = i >= 1 ? t[8 + i - 1] : 0;
-    c += lo + (h977 & 0xFFFFFFFFu) + hs;
-    r[i] = (uint32_t)c;
-    c = (c >> 32) + (h977 >> 32);
-  }
-  r[9] = (uint32_t)c;                           // value < 2^(256+34)
-  // second fold: hi2 = r[8..9] (< 2^34)
-  const uint64_t hi2 = (uint64_t)r[8] | ((uint64_t)r[9] << 32);
-  U256 o;
-  uint64_t k = hi2 * 977u;                      // < 2^44
-  c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint64_t add = 0;
-    if (i == 0) add = k & 0xFFFFFFFFu;
-    if (i == 1) add = (k >> 32) + (hi2 & 0xFFFFFFFFu);
-    if (i == 2) add = hi2 >> 32;
-    c += (uint64_t)r[i] + add;
-    o.w[i] = (uint32_t)c;
-    c >>= 32;
-  }
-  // c is 0 or 1: one more tiny fold (2^256 = 2^32 + 977)
-  if (c) {
-    uint64_t d = (uint64_t)o.w[0] + 977u;
-    o.w[0] = (uint32_t)d; d >>= 32;
-    d += (uint64_t)o.w[1] + 1u; o.w[1] = (uint32_t)d; d >>= 32;
-    for (int i = 2; i < 8 && d; ++i) { d += o.w[i]; o.w[i] = (uint32_t)d; d >>= 32; }
-  }
-  if (u256_ge(o, FP)) u256_sub_m(o, o, FP);
-  return o;
-}
-__device__ __forceinline__ U256 fe_mul(const U256& a, const U256& b) { uint32_t t[16]; mul_wide(t, a, b); return fe_reduce_wide(t); }
-__device__ __forceinline__ U256 fe_sqr(const U256& a) { uint32_t t[16]; sqr_wide(t, a); return fe_reduce_wide(t); }
-__device__ __forceinline__ U256 fe_add(const U256& a, const U256& b) {
-  U256 r; const uint32_t c = u256_add(r, a, b);
-  if (c || u256_ge(r, FP)) u256_sub_m(r, r, FP);
-  return r;
-}
-__device__ __forceinline__ U256 fe_sub(const U256& a, const U256& b) {
-  U256 r; if (u256_sub(r, a, b)) u256_add_m(r, r, FP);
-  return r;
-}
-__device__ __forceinline__ U256 fe_neg(const U256& a) { return u256_is_zero(a) ? a : fe_sub(u256_zero(), a); }
-__device__ inline U256 fe_pow(const U256& a, const uint32_t* e) {   // a^e, e: 8 words (public exponents only)
-  U256 r = u256_one();
-  for (int i = 255; i >= 0; --i) {
-    r = fe_sqr(r);
-    if ((e[i >> 5] >> (i & 31)) & 1) r = fe_mul(r, a);
-  }
-  return r;
-}
-__device__ inline U256 fe_sqrn(U256 x, int n) {
-#pragma unroll 1
-  for (int i = 0; i < n; ++i) x = fe_sqr(x);
-  return x;
-}
-// a^(p-2): p - 2 = 1^223 0 1^22 0000 101101 in binary; addition chain with 255 squarings + 15 multiplications
-__device__ inline U256 fe_inv(const U256& a) {
-  const U256 x2 = fe_mul(fe_sqr(a), a), x3 = fe_mul(fe_sqr(x2), a);
-  const U256 x6 = fe_mul(fe_sqrn(x3, 3), x3), x9 = fe_mul(fe_sqrn(x6, 3), x3), x11 = fe_mul(fe_sqrn(x9, 2), x2);
-  const U256 x22 = fe_mul(fe_sqrn(x11, 11), x11), x44 = fe_mul(fe_sqrn(x22, 22), x22);
-  const U256 x88 = fe_mul(fe_sqrn(x44, 44), x44), x176 = fe_mul(fe_sqrn(x88, 88), x88);
-  const U256 x220 = fe_mul(fe_sqrn(x176, 44), x44), x223 = fe_mul(fe_sqrn(x220, 3), x3);
-  U256 t = fe_mul(fe_sqrn(x223, 23), x22);
-  t = fe_mul(fe_sqrn(t, 5), a);
-  t = fe_mul(fe_sqrn(t, 3), x2);
-  return fe_mul(fe_sqrn(t, 2), a);
-}
-
 // ---- scalars: mod q ---------------------------------------------------------------------------
 // reduce an n-word integer mod q by folding 2^256 = QC (mod q)
 __device__ inline U256 sc_reduce(const uint32_t* x, int n) {
@@ -225,131 +122,33 @@ __device__ inline U256 sc_inv(const U256& a) {   // a^(q-2) mod q
   return r;
 }
 
-// ---- points ----------------------------------------------------------------------------------------
-struct Aff { U256 x, y; bool inf; };
-struct Jac { U256 x, y, z; };                  // z == 0 <=> infinity
-
-__device__ __forceinline__ Jac jac_inf() { Jac r; r.x = u256_one(); r.y = u256_one(); r.z = u256_zero(); return r; }
-__device__ __forceinline__ bool jac_is_inf(const Jac& p) { return u256_is_zero(p.z); }
-__device__ __forceinline__ Jac jac_from_aff(const Aff& a) {
-  if (a.inf) return jac_inf();
-  Jac r; r.x = a.x; r.y = a.y; r.z = u256_one(); return r;
-}
-__device__ inline Jac jac_dbl(const Jac& p) {
-  if (jac_is_inf(p) || u256_is_zero(p.y)) return jac_inf();
-  // a = 0: dbl-2009-l
-  const U256 A = fe_sqr(p.x), B = fe_sqr(p.y), Cc = fe_sqr(B);
-  U256 D = fe_sub(fe_sqr(fe_add(p.x, B)), fe_add(A, Cc));
-  D = fe_add(D, D);
-  const U256 E = fe_add(fe_add(A, A), A), Fv = fe_sqr(E);
-  Jac r;
-  r.x = fe_sub(Fv, fe_add(D, D));
-  U256 c8 = fe_add(Cc, Cc); c8 = fe_add(c8, c8); c8 = fe_add(c8, c8);
-  r.y = fe_sub(fe_mul(E, fe_sub(D, r.x)), c8);
-  r.z = fe_mul(fe_add(p.y, p.y), p.z);
-  return r;
-}
-__device__ inline Jac jac_add(const Jac& p, const Jac& q) {
-  if (jac_is_inf(p)) return q;
-  if (jac_is_inf(q)) return p;
-  const U256 z1z1 = fe_sqr(p.z), z2z2 = fe_sqr(q.z);
-  const U256 u1 = fe_mul(p.x, z2z2), u2 = fe_mul(q.x, z1z1);
-  const U256 s1 = fe_mul(fe_mul(p.y, q.z), z2z2), s2 = fe_mul(fe_mul(q.y, p.z), z1z1);
-  const U256 h = fe_sub(u2, u1), rr = fe_sub(s2, s1);
-  if (u256_is_zero(h)) return u256_is_zero(rr) ? jac_dbl(p) : jac_inf();
-  const U256 hh = fe_sqr(h), hhh = fe_mul(h, hh), v = fe_mul(u1, hh);
-  Jac r;
-  r.x = fe_sub(fe_sub(fe_sqr(rr), hhh), fe_add(v, v));
-  r.y = fe_sub(fe_mul(rr, fe_sub(v, r.x)), fe_mul(s1, hhh));
-  r.z = fe_mul(fe_mul(p.z, q.z), h);
-  return r;
-}
-// p + q with q affine (z = 1): 8 multiplications + 3 squarings
-__device__ inline Jac jac_add_aff(const Jac& p, const Aff& q) {
-  if (q.inf) return p;
-  if (jac_is_inf(p)) { Jac r; r.x = q.x; r.y = q.y; r.z = u256_one(); return r; }
-  const U256 z1z1 = fe_sqr(p.z);
-  const U256 u2 = fe_mul(q.x, z1z1), s2 = fe_mul(fe_mul(q.y, p.z), z1z1);
-  const U256 h = fe_sub(u2, p.x), rr = fe_sub(s2, p.y);
-  if (u256_is_zero(h)) return u256_is_zero(rr) ? jac_dbl(p) : jac_inf();
-  const U256 hh = fe_sqr(h), hhh = fe_mul(h, hh), v = fe_mul(p.x, hh);
-  Jac r;
-  r.x = fe_sub(fe_sub(fe_sqr(rr), hhh), fe_add(v, v));
-  r.y = fe_sub(fe_mul(rr, fe_sub(v, r.x)), fe_mul(p.y, hhh));
-  r.z = fe_mul(p.z, h);
-  return r;
-}
-// equality without leaving projective coordinates (no inversion)
-__device__ inline bool jac_eq_aff(const Jac& p, const Aff& a) {
-  if (a.inf || jac_is_inf(p)) return a.inf && jac_is_inf(p);
-  const U256 zz = fe_sqr(p.z);
-  return u256_eq(p.x, fe_mul(a.x, zz)) && u256_eq(p.y, fe_mul(a.y, fe_mul(zz, p.z)));
-}
-__device__ inline bool jac_eq(const Jac& p, const Jac& q) {
-  if (jac_is_inf(p) || jac_is_inf(q)) return jac_is_inf(p) && jac_is_inf(q);
-  const U256 z1z1 = fe_sqr(p.z), z2z2 = fe_sqr(q.z);
-  return u256_eq(fe_mul(p.x, z2z2), fe_mul(q.x, z1z1)) &&
-         u256_eq(fe_mul(p.y, fe_mul(z2z2, q.z)), fe_mul(q.y, fe_mul(z1z1, p.z)));
-}
-__device__ inline Aff jac_to_aff(const Jac& p) {
-  Aff a;
-  if (jac_is_inf(p)) { a.inf = true; a.x = u256_zero(); a.y = u256_zero(); return a; }
-  const U256 zi = fe_inv(p.z), zi2 = fe_sqr(zi);
-  a.x = fe_mul(p.x, zi2);
-  a.y = fe_mul(p.y, fe_mul(zi2, zi));
-  a.inf = false;
-  return a;
-}
-__device__ inline Aff aff_neg(const Aff& a) { Aff r = a; if (!a.inf) r.y = fe_neg(a.y); return r; }
-// k*P, k already reduced mod q.  Fixed 4-bit windows, constant sequence of doublings and additions.
-__device__ inline Jac jac_mul(const U256& k, const Aff& P) {
-  Jac tab[16];
-  tab[0] = jac_inf();
-  tab[1] = jac_from_aff(P);
-  for (int i = 2; i < 16; ++i) tab[i] = (i & 1) ? jac_add(tab[i - 1], tab[1]) : jac_dbl(tab[i >> 1]);
-  Jac acc = jac_inf();
-#pragma unroll 1
-  for (int wi = 63; wi >= 0; --wi) {
-    acc = jac_dbl(jac_dbl(jac_dbl(jac_dbl(acc))));
-    const uint32_t d = (k.w[wi >> 3] >> ((wi & 7) * 4)) & 15u;
-    acc = jac_add(acc, tab[d]);
-  }
-  return acc;
-}
+// ---- points: mpe_jac.h; here the fixed generators and their comb tables ----------------------------------
 __device__ __forceinline__ Aff aff_gen() { Aff g; g.x = u256_load(GX); g.y = u256_load(GY); g.inf = false; return g; }
 __device__ __forceinline__ Aff aff_h2() { Aff g; g.x = u256_load(H2X); g.y = u256_load(H2Y); g.inf = false; return g; }
-// Comb tables of the two fixed generators: COMB[g][w][d-1] = d * 16^w * (g == 0 ? G : base_point2), affine x|y,
-// d = 1..15, w = 0..63 (123 KB, filled once per device by ec_comb_build_kernel when a context is created).
-// k*G is then 64 mixed additions and no doublings; the additions always run (digit 0 adds a dummy and
-// keeps the old accumulator), so the operation sequence does not depend on the scalar.
-__device__ uint32_t COMB[2][64][15][16];
+__device__ __forceinline__ Aff aff_neg(const Aff& a) {
+  Aff r = a;
+  if (!a.inf && !u256_is_zero(a.y)) u256_sub(r.y, u256_load(FP), a.y);
+  return r;
+}
+// Comb tables of the two fixed generators: COMB[g][w][d-1] = d * 16^w * (g == 0 ? G : base_point2) as 20 field limbs
+// (x | y), d = 1..15, w = 0..63 (154 KB, filled once per device by ec_comb_build_kernel when a context is created).
+// k*G is then 64 mixed additions and no doublings (jac_mul_comb).
+__device__ uint32_t COMB[2][64][15][20];
 __global__ void __launch_bounds__(64) ec_comb_build_kernel() {
   const int w = threadIdx.x & 63, g = blockIdx.x;
   if (g > 1) return;
   Jac b = jac_from_aff(g ? aff_h2() : aff_gen());
   for (int i = 0; i < 4 * w; ++i) b = jac_dbl(b);
-  const Aff ba = jac_to_aff(b);
-  Jac acc = jac_from_aff(ba);
+  const AffL ba = affl_from_aff(jac_to_aff(b));
+  Jac acc = jac_from_affl(ba);
   for (int d = 1; d <= 15; ++d) {
-    const Aff a = jac_to_aff(acc);
-    for (int j = 0; j < 8; ++j) { COMB[g][w][d - 1][j] = a.x.w[j]; COMB[g][w][d - 1][8 + j] = a.y.w[j]; }
-    acc = jac_add_aff(acc, ba);
+    const AffL a = affl_from_aff(jac_to_aff(acc));
+    for (int j = 0; j < 10; ++j) { COMB[g][w][d - 1][j] = a.x.n[j]; COMB[g][w][d - 1][10 + j] = a.y.n[j]; }
+    acc = jac_add_affl(acc, ba);
   }
 }
 // k*G (g = 0) or k*base_point2 (g = 1), k already reduced mod q
-__device__ __noinline__ Jac jac_mul_fixed(const U256& k, int g) {
-  Jac acc = jac_inf();
-#pragma unroll 1
-  for (int w = 0; w < 64; ++w) {
-    const uint32_t d = (k.w[w >> 3] >> ((w & 7) * 4)) & 15u;
-    const uint32_t* e = COMB[g][w][d ? d - 1 : 0];
-    Aff a; a.inf = false;
-    for (int j = 0; j < 8; ++j) { a.x.w[j] = e[j]; a.y.w[j] = e[8 + j]; }
-    const Jac sum = jac_add_aff(acc, a);
-    if (d) acc = sum;
-  }
-  return acc;
-}
+__device__ __noinline__ Jac jac_mul_fixed(const U256& k, int g) { return jac_mul_comb(k, &COMB[g][0][0][0]); }
 __device__ __forceinline__ Jac jac_mul_gen(const U256& k) { return jac_mul_fixed(k, 0); }
 __device__ __forceinline__ Jac jac_mul_h2(const U256& k) { return jac_mul_fixed(k, 1); }
 
@@ -366,10 +165,7 @@ __device__ __forceinline__ void aff_store(uint32_t* p, const Aff& a) {
 // point is open to invalid-curve / small-subgroup inputs.  (secp256k1 has cofactor 1: on-curve = in the group.)
 __device__ inline bool aff_valid(const Aff& a) {
   if (a.inf || u256_ge(a.x, FP) || u256_ge(a.y, FP)) return false;
-  U256 rhs = fe_mul(fe_sqr(a.x), a.x), seven = u256_zero();
-  seven.w[0] = 7;
-  rhs = fe_add(rhs, seven);
-  return u256_eq(fe_sqr(a.y), rhs);
+  return aff_on_curve(a);
 }
 __device__ __forceinline__ bool aff_eq(const Aff& a, const Aff& b) {
   if (a.inf || b.inf) return a.inf && b.inf;
