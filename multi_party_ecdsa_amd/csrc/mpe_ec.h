@@ -11,116 +11,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mpe_jac.h"
+#include "mpe_sc.h"
 
 namespace mpe {
 namespace ec {
-
-__device__ __constant__ const uint32_t FP[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu,
-                                                 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-__device__ __constant__ const uint32_t FQ[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
-                                                 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-// 2^256 - q (129 bits)
-__device__ __constant__ const uint32_t QC[5] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 0x1u};
-__device__ __constant__ const uint32_t GX[8] = {0x16F81798u, 0x59F2815Bu, 0x2DCE28D9u, 0x029BFCDBu,
-                                                 0xCE870B07u, 0x55A06295u, 0xF9DCBBACu, 0x79BE667Eu};
-__device__ __constant__ const uint32_t GY[8] = {0xFB10D4B8u, 0x9C47D08Fu, 0xA6855419u, 0xFD17B448u,
-                                                 0x0E1108A8u, 0x5DA4FBFCu, 0x26A3C465u, 0x483ADA77u};
-// curv `Point::base_point2()`
-__device__ __constant__ const uint32_t H2X[8] = {0x0378b795u, 0xa8dc7bfau, 0x5ff3ce66u, 0xdd142e4bu,
-                                                  0x4ba80116u, 0x34dd4521u, 0xe3a7326au, 0x08d13221u};
-__device__ __constant__ const uint32_t H2Y[8] = {0xf7c2be88u, 0x8217e9f7u, 0xdf0df07au, 0x807bcba1u,
-                                                  0xbd565ea2u, 0x0848d50du, 0x77614b5cu, 0x5d41ac14u};
-
-__device__ __forceinline__ U256 u256_zero() { U256 r; for (int i = 0; i < 8; ++i) r.w[i] = 0; return r; }
-__device__ __forceinline__ U256 u256_one() { U256 r = u256_zero(); r.w[0] = 1; return r; }
-__device__ __forceinline__ U256 u256_load(const uint32_t* p) { U256 r; for (int i = 0; i < 8; ++i) r.w[i] = p[i]; return r; }
-__device__ __forceinline__ void u256_store(uint32_t* p, const U256& a) { for (int i = 0; i < 8; ++i) p[i] = a.w[i]; }
-__device__ __forceinline__ bool u256_is_zero(const U256& a) { uint32_t o = 0; for (int i = 0; i < 8; ++i) o |= a.w[i]; return o == 0; }
-__device__ __forceinline__ bool u256_eq(const U256& a, const U256& b) { uint32_t o = 0; for (int i = 0; i < 8; ++i) o |= a.w[i] ^ b.w[i]; return o == 0; }
-__device__ __forceinline__ bool u256_ge(const U256& a, const uint32_t* m) {
-  for (int i = 7; i >= 0; --i) { if (a.w[i] != m[i]) return a.w[i] > m[i]; }
-  return true;
-}
-__device__ __forceinline__ uint32_t u256_add(U256& r, const U256& a, const U256& b) {
-  uint64_t c = 0;
-  for (int i = 0; i < 8; ++i) { c += (uint64_t)a.w[i] + b.w[i]; r.w[i] = (uint32_t)c; c >>= 32; }
-  return (uint32_t)c;
-}
-__device__ __forceinline__ uint32_t u256_sub_m(U256& r, const U256& a, const uint32_t* m) {
-  int64_t c = 0;
-  for (int i = 0; i < 8; ++i) { c += (int64_t)a.w[i] - (int64_t)m[i]; r.w[i] = (uint32_t)c; c >>= 32; }
-  return (uint32_t)(c & 1);
-}
-__device__ __forceinline__ uint32_t u256_sub(U256& r, const U256& a, const U256& b) { return u256_sub_m(r, a, b.w); }
-__device__ __forceinline__ void u256_add_m(U256& r, const U256& a, const uint32_t* m) {
-  uint64_t c = 0;
-  for (int i = 0; i < 8; ++i) { c += (uint64_t)a.w[i] + m[i]; r.w[i] = (uint32_t)c; c >>= 32; }
-}
-// 8x8 -> 16 words
-__device__ __forceinline__ void mul_wide(uint32_t (&t)[16], const U256& a, const U256& b) {
-  for (int i = 0; i < 16; ++i) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint64_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint64_t v = (uint64_t)a.w[i] * b.w[j] + t[i + j] + c;
-      t[i + j] = (uint32_t)v;
-      c = v >> 32;
-    }
-    t[i + 8] = (uint32_t)c;
-  }
-}
-
-// ---- scalars: mod q ---------------------------------------------------------------------------
-// reduce an n-word integer mod q by folding 2^256 = QC (mod q)
-__device__ inline U256 sc_reduce(const uint32_t* x, int n) {
-  // work buffer: fold from the top down to 8 words (+ small overflow)
-  uint32_t buf[90];
-  for (int i = 0; i < n; ++i) buf[i] = x[i];
-  for (int i = n; i < 90; ++i) buf[i] = 0;
-  int len = n < 8 ? 8 : n;
-  while (len > 8) {
-    // take the top word w at position len-1 (>= 8): buf += w * QC << 32*(len-1-8), then drop it
-    const uint32_t w = buf[len - 1];
-    buf[len - 1] = 0;
-    const int pos = len - 1 - 8;
-    uint64_t c = 0;
-    for (int j = 0; j < 5; ++j) {
-      c += (uint64_t)w * QC[j] + buf[pos + j];
-      buf[pos + j] = (uint32_t)c;
-      c >>= 32;
-    }
-    for (int j = pos + 5; c && j < 90; ++j) { c += buf[j]; buf[j] = (uint32_t)c; c >>= 32; }
-    // the carry may have re-populated word len-1 (only when pos+5 >= len-1, i.e. len <= 13): loop handles it
-    while (len > 8 && buf[len - 1] == 0) --len;
-  }
-  U256 r = u256_load(buf);
-  while (u256_ge(r, FQ)) u256_sub_m(r, r, FQ);
-  return r;
-}
-__device__ inline U256 sc_mul(const U256& a, const U256& b) { uint32_t t[16]; mul_wide(t, a, b); return sc_reduce(t, 16); }
-__device__ inline U256 sc_add(const U256& a, const U256& b) {
-  U256 r; const uint32_t c = u256_add(r, a, b);
-  if (c || u256_ge(r, FQ)) u256_sub_m(r, r, FQ);
-  return r;
-}
-__device__ inline U256 sc_sub(const U256& a, const U256& b) {
-  U256 r; if (u256_sub(r, a, b)) u256_add_m(r, r, FQ);
-  return r;
-}
-__device__ inline U256 sc_neg(const U256& a) { return u256_is_zero(a) ? a : sc_sub(u256_zero(), a); }
-__device__ inline U256 sc_inv(const U256& a) {   // a^(q-2) mod q
-  uint32_t e[8];
-  for (int i = 0; i < 8; ++i) e[i] = FQ[i];
-  e[0] -= 2;
-  U256 r = u256_one();
-  for (int i = 255; i >= 0; --i) {
-    r = sc_mul(r, r);
-    if ((e[i >> 5] >> (i & 31)) & 1) r = sc_mul(r, a);
-  }
-  return r;
-}
 
 // ---- points: mpe_jac.h; here the fixed generators and their comb tables ----------------------------------
 __device__ __forceinline__ Aff aff_gen() { Aff g; g.x = u256_load(GX); g.y = u256_load(GY); g.inf = false; return g; }

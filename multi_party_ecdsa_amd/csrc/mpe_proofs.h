@@ -289,7 +289,7 @@ static Rows with_words(Rows r, int words) { r.words = words; return r; }
 // produces `cipher` concurrently (Round 0 encrypts k_i on another stream) — joined right before the transcript hash.
 // ---------------------------------------------------------------------------------------------
 static inline size_t ws_need_alice_generate(int B) { return (size_t)B * (1400 + CRT_WS_WORDS) * 4 + 65536; }
-static inline size_t ws_need_alice_verify(int B) { return (size_t)B * 1800 * 4 + 65536; }
+static inline size_t ws_need_alice_verify(int B) { return (size_t)B * 2200 * 4 + 65536; }
 static int merge_rc(const Seq& a, const Seq& b, const Seq& c) { return a.rc != MPE_OK ? a.rc : (b.rc != MPE_OK ? b.rc : c.rc); }
 
 static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
@@ -353,8 +353,16 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
   // u' = (s1 N + 1) s^N (c^e)^-1 mod N^2                                                           :134-141
   uint32_t* gs1 = q.words(128);
   q.muladd(pr.s1, 25, Nrow, 64, no_rows(), 0, gs1, 128);
-  uint32_t* u;
-  if (ctx->use_multiexp) {
+  uint32_t *u = nullptr, *b12 = nullptr, *cie = nullptr;
+  if (f.on) {
+    // small batch (latency-bound): the 2048-bit ladder s^N starts at once; the inversion of c and the short ladder
+    // (c^-1)^e run beside it on the stream of the fixed-base side, and one more multiplication joins them
+    uint32_t* sn = q.modexp_nn(pk, ksel, with_words(pr.s, 64), Nrow, 64, false);
+    b12 = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(sn, 128));
+    uint32_t* cred = q2.modmul(pk->ms_nn, ksel, cipher, rows(pk->ms_nn->one_words, 0, nullptr, 1));   // c mod N^2
+    uint32_t* cinv = q2.modinv(pk->ms_nn, ksel, rows(cred, 128), inv_ok2);
+    cie = q2.modexp_nn(pk, ksel, rows(cinv, 128), pr.e, 8, false);
+  } else if (ctx->use_multiexp) {
     // (c^e)^-1 = (c^-1)^e: invert first, then s^N (c^-1)^e on one ladder (the 256 squarings of c^e are shared)
     uint32_t* cred = q.modmul(pk->ms_nn, ksel, cipher, rows(pk->ms_nn->one_words, 0, nullptr, 1));   // c mod N^2
     uint32_t* cinv = q.modinv(pk->ms_nn, ksel, rows(cred, 128), inv_ok2);
@@ -364,11 +372,12 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
     uint32_t* ce = q.modexp_nn(pk, ksel, cipher, pr.e, 8, false);
     uint32_t* cei = q.modinv(pk->ms_nn, ksel, rows(ce, 128), inv_ok2);
     uint32_t* sn = q.modexp_nn(pk, ksel, with_words(pr.s, 64), Nrow, 64, false);
-    uint32_t* b12 = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(sn, 128));
-    u = q.modmul(pk->ms_nn, ksel, rows(b12, 128), rows(cei, 128));
+    uint32_t* b12n = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(sn, 128));
+    u = q.modmul(pk->ms_nn, ksel, rows(b12n, 128), rows(cei, 128));
   }
   f.join();
   q.rc = merge_rc(q, q1, q2);
+  if (f.on) u = q.modmul(pk->ms_nn, ksel, rows(b12, 128), rows(cie, 128));
   uint32_t* w = q.modmul(stm->ms, ssel, rows(a12, 64), rows(zei, 64));
   // e' = H(N, N+1, c, z, u', w') == e                                                              :143-153
   uint32_t* e2 = q.words(8);
@@ -439,7 +448,7 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
 static int pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
                       const int32_t* st_idx, Rows cipher, Rows Qp, Rows Gp, const PdlProofRows& pr, uint8_t* ok,
                       hipStream_t st) {
-  MPE_TRY(ws_reserve(ctx, (size_t)B * 2200 * 4 + 65536, st));
+  MPE_TRY(ws_reserve(ctx, (size_t)B * 2600 * 4 + 65536, st));
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
   const Rows Nrow = tab_rows(pk->N, 64, key_idx, pk->nkeys);
@@ -463,17 +472,26 @@ static int pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   // u2' = (N+1)^s1 s2^N c^-e mod N^2; (N+1)^s1 = 1 + s1 N < N^2 because s1 < 2^800                 :144-157
   uint32_t* g1 = q.words(128);
   q.muladd(pr.s1, 25, Nrow, 64, no_rows(), 0, g1, 128);
-  uint32_t* cred = q.modmul(pk->ms_nn, ksel, cipher, rows(pk->ms_nn->one_words, 0, nullptr, 1));  // c mod N^2
-  uint32_t* cinv = q.modinv(pk->ms_nn, ksel, rows(cred, 128), inv_ok1);
-  uint32_t* u2;
-  if (ctx->use_multiexp) {
-    uint32_t* m = q.modexp_nn2(pk, ksel, with_words(pr.s2, 64), Nrow, 64, rows(cinv, 128), rows(e, 8), 8);
-    u2 = q.modmul(pk->ms_nn, ksel, rows(g1, 128), rows(m, 128));
-  } else {
+  uint32_t *u2 = nullptr, *t2s = nullptr, *cies = nullptr;
+  if (f.on) {
+    // small batch: s2^N starts at once; c^-1 and the short ladder (c^-1)^e follow the u1 check on its stream
     uint32_t* s2n = q.modexp_nn(pk, ksel, with_words(pr.s2, 64), Nrow, 64, false);
-    uint32_t* t2 = q.modmul(pk->ms_nn, ksel, rows(g1, 128), rows(s2n, 128));
-    uint32_t* cie = q.modexp_nn(pk, ksel, rows(cinv, 128), rows(e, 8), 8, false);
-    u2 = q.modmul(pk->ms_nn, ksel, rows(t2, 128), rows(cie, 128));
+    t2s = q.modmul(pk->ms_nn, ksel, rows(g1, 128), rows(s2n, 128));
+    uint32_t* cred = q1.modmul(pk->ms_nn, ksel, cipher, rows(pk->ms_nn->one_words, 0, nullptr, 1));  // c mod N^2
+    uint32_t* cinv = q1.modinv(pk->ms_nn, ksel, rows(cred, 128), inv_ok1);
+    cies = q1.modexp_nn(pk, ksel, rows(cinv, 128), rows(e, 8), 8, false);
+  } else {
+    uint32_t* cred = q.modmul(pk->ms_nn, ksel, cipher, rows(pk->ms_nn->one_words, 0, nullptr, 1));  // c mod N^2
+    uint32_t* cinv = q.modinv(pk->ms_nn, ksel, rows(cred, 128), inv_ok1);
+    if (ctx->use_multiexp) {
+      uint32_t* m = q.modexp_nn2(pk, ksel, with_words(pr.s2, 64), Nrow, 64, rows(cinv, 128), rows(e, 8), 8);
+      u2 = q.modmul(pk->ms_nn, ksel, rows(g1, 128), rows(m, 128));
+    } else {
+      uint32_t* s2n = q.modexp_nn(pk, ksel, with_words(pr.s2, 64), Nrow, 64, false);
+      uint32_t* t2 = q.modmul(pk->ms_nn, ksel, rows(g1, 128), rows(s2n, 128));
+      uint32_t* cie = q.modexp_nn(pk, ksel, rows(cinv, 128), rows(e, 8), 8, false);
+      u2 = q.modmul(pk->ms_nn, ksel, rows(t2, 128), rows(cie, 128));
+    }
   }
   // u3' = h1^s1 h2^s3 z^-e mod N~                                                                  :159-172
   uint32_t* a1 = q2.fb_modexp(stm, ssel, 0, h1,pr.s1, 25);
@@ -485,6 +503,7 @@ static int pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   uint32_t* u3 = q2.modmul(stm->ms, ssel, rows(a12, 64), rows(zie, 64));
   f.join();
   q.rc = merge_rc(q, q1, q2);
+  if (f.on) u2 = q.modmul(pk->ms_nn, ksel, rows(t2s, 128), rows(cies, 128));
   if (q.rc == MPE_OK) {                                                                             // :174
     hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ok, inv_ok1, inv_ok2, u2, pr.u2, 128);
     hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ok, (const uint8_t*)nullptr,

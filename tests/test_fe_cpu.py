@@ -22,7 +22,7 @@ def lib():
     src = os.path.join(ROOT, "tools", "model", "fe_host.cpp")
     inc = os.path.join(ROOT, "multi_party_ecdsa_amd", "csrc")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    deps = [src, os.path.join(inc, "mpe_fe.h"), os.path.join(inc, "mpe_jac.h")]
+    deps = [src, os.path.join(inc, "mpe_fe.h"), os.path.join(inc, "mpe_jac.h"), os.path.join(inc, "mpe_sc.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-DMPE_FE_HOST", "-I", inc, src, "-o", out])
     return ctypes.CDLL(out)
@@ -184,3 +184,74 @@ def test_comb_tables(lib):
             k %= R.Q
             lib.ech_mul_comb(arr(to_words(k), 8), tab, out)
             assert words_pt(out) == R.ec_mul(k, base), hex(k)
+
+
+def test_scalar_field(lib):
+    rng = random.Random(6)
+    Q = R.Q
+    out = arr([0] * 8, 8)
+    edge = [0, 1, 2, Q - 1, Q, Q + 1, (1 << 256) - 1, (1 << 255), (1 << 128) - 1, 1 << 128, Q >> 1]
+    # reductions of every width the kernels use (8 .. 90 words), incl. all-ones inputs and multiples of q
+    for n in [1, 5, 8, 9, 16, 24, 25, 64, 72, 88, 89, 90]:
+        vals = [0, (1 << (32 * n)) - 1, (Q * ((1 << (32 * n)) // Q)) if n >= 8 else 0, ((1 << (32 * n)) // Q) * Q - 1 if n >= 8 else 1]
+        vals += [rng.randrange(1 << (32 * n)) for _ in range(12)]
+        for v in vals:
+            lib.sch_reduce(arr(to_words(v, n), n), n, out)
+            assert words_value(out) == v % Q, (n, hex(v))
+    for a in edge:
+        for b in edge + [rng.randrange(1 << 256) for _ in range(3)]:
+            lib.sch_mul(arr(to_words(a % (1 << 256)), 8), arr(to_words(b % (1 << 256)), 8), out)
+            assert words_value(out) == (a % (1 << 256)) * (b % (1 << 256)) % Q
+    for _ in range(300):
+        a, b = rng.randrange(1 << 256), rng.randrange(1 << 256)
+        lib.sch_mul(arr(to_words(a), 8), arr(to_words(b), 8), out)
+        assert words_value(out) == a * b % Q
+    for a in [1, 2, Q - 1, Q - 2] + [rng.randrange(1, Q) for _ in range(20)]:
+        lib.sch_inv(arr(to_words(a), 8), out)
+        assert words_value(out) * a % Q == 1
+
+
+LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+BETA = 0x7AE96A2B657C07106E64479EAC3434E99CF0497512F58995C1396C28719501EE
+
+
+def test_glv_constants_and_split(lib):
+    """the endomorphism constants are re-derived here from the lattice basis; the device split is exact and 128-bit"""
+    n, p = R.Q, R.P
+    assert pow(LAMBDA, 3, n) == 1 and LAMBDA != 1 and pow(BETA, 3, p) == 1 and BETA != 1
+    assert R.ec_mul(LAMBDA, R.G) == (BETA * R.G[0] % p, R.G[1])
+    a1, b1 = 0x3086D221A7D46BCDE86C90E49284EB15, -0xE4437ED6010E88286F547FA90ABFE4C3
+    a2, b2 = 0x114CA50F7A8E2F3F657C1108D9D44CFD8, a1
+    assert (a1 + b1 * LAMBDA) % n == 0 and (a2 + b2 * LAMBDA) % n == 0
+    g1, g2 = (2 * (b2 << 384) + n) // (2 * n), (2 * ((-b1) << 384) + n) // (2 * n)
+    src = open(os.path.join(ROOT, "multi_party_ecdsa_amd", "csrc", "mpe_sc.h")).read()
+
+    def const(name):
+        body = src[src.index(name + "[8] = {") + len(name) + 7:]
+        return words_value([int(t.strip().rstrip("u"), 16) for t in body[:body.index("}")].split(",")])
+    assert const("GLV_LAMBDA") == LAMBDA and const("GLV_BETA") == BETA
+    assert const("GLV_G1") == g1 and const("GLV_G2") == g2
+    assert const("GLV_MB1") == (-b1) % n and const("GLV_MB2") == (-b2) % n
+    rng = random.Random(7)
+    r1, r2, neg = arr([0] * 8, 8), arr([0] * 8, 8), (ctypes.c_int * 2)()
+    ks = [0, 1, 2, n - 1, n - 2, n // 2, n // 2 + 1, LAMBDA, n - LAMBDA, LAMBDA + 1, (1 << 128), (1 << 128) - 1, (1 << 255)] + [rng.randrange(n) for _ in range(3000)]
+    for k in ks:
+        lib.sch_split(arr(to_words(k), 8), r1, r2, neg)
+        v1, v2 = words_value(r1), words_value(r2)
+        assert v1 < 1 << 128 and v2 < 1 << 128
+        assert ((-v1 if neg[0] else v1) + (-v2 if neg[1] else v2) * LAMBDA) % n == k
+
+
+def test_glv_ladder_matches_plain_ladder(lib):
+    rng = random.Random(8)
+    out, out2 = arr([0] * 16, 16), arr([0] * 16, 16)
+    n = R.Q
+    pts = [R.G, R.H2, R.ec_mul(rng.randrange(1, n), R.G)]
+    ks = [0, 1, 2, 15, 16, 17, 31, 32, 33, n - 1, n - 2, LAMBDA, n - LAMBDA, LAMBDA - 1, LAMBDA + 1, (LAMBDA * 16) % n, (LAMBDA * 17 + 16) % n,
+          (1 << 128) - 1, 1 << 128, 0x10842108421084210842108421084210 % n] + [rng.randrange(n) for _ in range(60)]
+    for pt in pts:
+        for k in ks:
+            lib.ech_mul(arr(to_words(k), 8), arr(pt_words(pt), 16), out)
+            lib.ech_mul_w4(arr(to_words(k), 8), arr(pt_words(pt), 16), out2)
+            assert list(out) == list(out2), hex(k)
+            assert words_pt(out) == R.ec_mul(k, pt), hex(k)

@@ -29,6 +29,7 @@ static void aff_out(uint32_t* p, const Aff& a) {
   if (a.inf) { memset(p, 0, 64); return; }
   memcpy(p, a.x.w, 32); memcpy(p + 8, a.y.w, 32); }
 void ech_mul(const uint32_t* k, const uint32_t* P, uint32_t* out) { U256 kk; memcpy(kk.w, k, 32); aff_out(out, jac_to_aff(jac_mul(kk, aff_in(P)))); }
+void ech_mul_w4(const uint32_t* k, const uint32_t* P, uint32_t* out) { U256 kk; memcpy(kk.w, k, 32); aff_out(out, jac_to_aff(jac_mul_w4(kk, aff_in(P)))); }
 void ech_add(const uint32_t* P, const uint32_t* Q, uint32_t* out) { aff_out(out, jac_to_aff(jac_add_aff(jac_from_aff(aff_in(P)), aff_in(Q)))); }
 // (a P) + (b Q) through the general Jacobian addition; a, b small
 void ech_add_jac(const uint32_t* ka, const uint32_t* P, const uint32_t* kb, const uint32_t* Q, uint32_t* out) {
@@ -56,4 +57,12 @@ void ech_comb_build(const uint32_t* B, uint32_t* tab) {
   }
 }
 void ech_mul_comb(const uint32_t* k, const uint32_t* tab, uint32_t* out) { U256 kk; memcpy(kk.w, k, 32); aff_out(out, jac_to_aff(jac_mul_comb(kk, tab))); }
+}
+
+// ---- scalar field (mpe_sc.h) ----
+extern "C" {
+void sch_split(const uint32_t* k, uint32_t* r1, uint32_t* r2, int* neg) { U256 kk; memcpy(kk.w, k, 32); const GlvSplit s = sc_split_lambda(kk); memcpy(r1, s.r1.w, 32); memcpy(r2, s.r2.w, 32); neg[0] = s.neg1; neg[1] = s.neg2; }
+void sch_reduce(const uint32_t* x, int n, uint32_t* out) { const U256 r = sc_reduce(x, n); memcpy(out, r.w, 32); }
+void sch_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) { U256 x, y; memcpy(x.w, a, 32); memcpy(y.w, b, 32); const U256 r = sc_mul(x, y); memcpy(out, r.w, 32); }
+void sch_inv(const uint32_t* a, uint32_t* out) { U256 x; memcpy(x.w, a, 32); const U256 r = sc_inv(x); memcpy(out, r.w, 32); }
 }
