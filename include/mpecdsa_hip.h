@@ -149,7 +149,8 @@ typedef struct mpe_statements mpe_statements;
 int mpe_statements_create(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const uint32_t* d_h1,
                           const uint32_t* d_h2, mpe_statements** out, void* stream);
 /* the same with an explicit window width (bits, 2..16) of the fixed-base tables of h1, h2: 2 * count tables of
- * ceil(2848 / wb) * 2^wb rows of 288 bytes (mpe_statements_create uses 13: 0.5 GB per base) */
+ * ceil(2848 / wb) * 2^wb rows of 288 bytes (mpe_statements_create uses 13: 0.5 GB per base); wb = 0: no tables
+ * (statements used once, e.g. the fresh (N~, h1, h2) of a Lindell'17 key generation) */
 int mpe_statements_create_wb(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const uint32_t* d_h1, const uint32_t* d_h2,
                              int wb, mpe_statements** out, void* stream);
 int mpe_statements_destroy(mpe_statements* s);
@@ -428,6 +429,22 @@ int mpe_lindell_partial_sig(mpe_ctx* ctx, const mpe_paillier* pk, int batch, con
 int mpe_lindell_sign(mpe_ctx* ctx, const mpe_paillier* sk, int batch, const int32_t* d_key_idx, const uint32_t* d_c3,
                      const uint32_t* d_k1, const uint32_t* d_R2, uint32_t* d_r, uint32_t* d_s, int32_t* d_recid,
                      void* stream);
+
+/* Key generation, the PDL exchange.  Party one, `pdl_proof(party1_private, paillier_key_pair)` (party_one.rs:366-401):
+ * statement {ciphertext = c_key, ek, Q = x1 G, G = generator, h1, h2, N~}, witness {x1, c_key_randomness};
+ * sk = party one's key set (private part), stm = its (N~, h1, h2) (create with mpe_statements_create); d_Q [batch][16] out.
+ * (`CompositeDLogProof::prove` for (N~, h1, h2) is a host-side muladd + one mpe_modexp.) */
+int mpe_lindell_pdl_proof(mpe_ctx* ctx, const mpe_paillier* sk, const mpe_statements* stm, int batch, const int32_t* d_key_idx,
+                          const int32_t* d_st_idx, const uint32_t* d_c_key, const uint32_t* d_x1, const uint32_t* d_r,
+                          const mpe_pdl_nonces* nonces, uint32_t* d_Q, const mpe_pdl_proof* out, void* stream);
+/* Party two, `PaillierPublic::pdl_verify(composite_dlog_proof, statement, proof, paillier_public, q1)` (party_two.rs:275-300):
+ * ok = statement.{ek, ciphertext, Q} == (pk[key], c_key, q1)  &&  CompositeDLogProof{x, y}.verify(DLogStatement{N~, h1, h2})
+ *      &&  PDLwSlackProof::verify.  Every item brings its own statement: d_Nt, d_h1, d_h2, d_dlog_x [batch][64], d_dlog_y
+ * [batch][73], d_stmt_N [batch][64], d_stmt_c / d_c_key [batch][128], d_stmt_Q / d_q1 [batch][16]. */
+int mpe_lindell_pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const int32_t* d_key_idx, const uint32_t* d_Nt,
+                           const uint32_t* d_h1, const uint32_t* d_h2, const uint32_t* d_dlog_x, const uint32_t* d_dlog_y,
+                           const uint32_t* d_stmt_N, const uint32_t* d_stmt_c, const uint32_t* d_stmt_Q, const uint32_t* d_c_key,
+                           const uint32_t* d_q1, const mpe_pdl_proof* proof, uint8_t* d_ok, void* stream);
 
 /* Kernel geometry chosen for the last launch (for bench.py's roofline accounting). */
 typedef struct {

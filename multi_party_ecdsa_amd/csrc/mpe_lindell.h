@@ -4,7 +4,10 @@
 // Both are the Paillier kernels of the GG20 path plus two per-lane EC / scalar kernels: the partial signature
 // c3 = Enc(rho q + k2^-1 m; r) * c_key^(k2^-1 rx x2) is ONE two-base ladder modulo N^2 (the peer's key: no p, q),
 // party one's s = Dec(c3) k1^-1 is the CRT decryption on the pair kernel modulo p^2 | q^2.
-// Included by mpe_lib.hip.
+// Key generation, the PDL exchange: party one `pdl_proof` (party_one.rs:366-401) and party two `PaillierPublic::pdl_verify`
+// (party_two.rs:275-300) are compositions of PDLwSlackProof::{prove, verify} and CompositeDLogProof::verify over a
+// statement (N~, h1, h2) that is fresh for every key: no fixed-base tables, every item its own moduli.
+// Included by mpe_lib.hip (after mpe_proofs.h and mpe_keygen.h).
 #pragma once
 #include "mpe_paillier.h"
 #include "mpe_ec.h"
@@ -65,9 +68,84 @@ __global__ void __launch_bounds__(64) lindell_p1_finish_kernel(int B, const uint
   recid[i] = rec;
 }
 
+__global__ void lindell_gen_point_kernel(uint32_t* __restrict__ g) {
+  if (threadIdx.x < 8) { g[threadIdx.x] = ec::GX[threadIdx.x]; g[8 + threadIdx.x] = ec::GY[threadIdx.x]; }
+}
+// ok[i] &= (statement's ek, ciphertext, Q) == (party two's ek, encrypted_secret_share, q1)          party_two.rs:282-288
+__global__ void lindell_stmt_check_kernel(int B, const uint32_t* __restrict__ sN, const uint32_t* __restrict__ N, const int32_t* __restrict__ key_idx,
+                                          const uint32_t* __restrict__ sc, const uint32_t* __restrict__ c, const uint32_t* __restrict__ sQ,
+                                          const uint32_t* __restrict__ q1, uint8_t* __restrict__ ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const uint32_t* Nk = N + (size_t)(key_idx ? key_idx[i] : i) * 64;
+  uint32_t d = 0;
+  for (int j = 0; j < 64; ++j) d |= sN[(size_t)i * 64 + j] ^ Nk[j];
+  for (int j = 0; j < 128; ++j) d |= sc[(size_t)i * 128 + j] ^ c[(size_t)i * 128 + j];
+  for (int j = 0; j < 16; ++j) d |= sQ[(size_t)i * 16 + j] ^ q1[(size_t)i * 16 + j];
+  if (d) ok[i] = 0;
+}
+__global__ void and_u8_kernel(int B, uint8_t* __restrict__ a, const uint8_t* __restrict__ b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) a[i] = a[i] && b[i];
+}
+
 }  // namespace mpe
 
 extern "C" {
+
+int mpe_lindell_pdl_proof(mpe_ctx* ctx, const mpe_paillier* sk, const mpe_statements* stm, int batch, const int32_t* d_key_idx,
+                          const int32_t* d_st_idx, const uint32_t* d_c_key, const uint32_t* d_x1, const uint32_t* d_r,
+                          const mpe_pdl_nonces* nonces, uint32_t* d_Q, const mpe_pdl_proof* out, void* stream) {
+  if (!ctx || !sk || !stm || !d_c_key || !d_x1 || !d_r || !nonces || !d_Q || !out || batch < 0) return MPE_E_ARG;
+  if (!sk->has_private) { mpe_set_error_msg("mpe_lindell_pdl_proof: key set has no private part"); return MPE_E_ARG; }
+  if (batch == 0) return MPE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* gen = nullptr;
+  if (hipMalloc((void**)&gen, 64) != hipSuccess) return MPE_E_NOMEM;
+  hipLaunchKernelGGL(mpe::lindell_gen_point_kernel, dim3(1), dim3(64), 0, st, gen);
+  hipLaunchKernelGGL(mpe::ec_mul_kernel, dim3(mpe::blocks_for(batch, 64)), dim3(64), 0, st, batch, d_x1, 8, (const uint32_t*)nullptr, d_Q);   // Q = x1 G  :384
+  const int rc = mpe::pdl_prove(ctx, sk, stm, batch, d_key_idx, d_st_idx, mpe::rows(d_c_key, 128), mpe::rows(d_Q, 16), mpe::rows(gen, 0),
+                                mpe::rows(d_x1, 8), mpe::rows(d_r, 64), nonces, out, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(gen);
+  return rc;
+}
+
+int mpe_lindell_pdl_verify(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const int32_t* d_key_idx, const uint32_t* d_Nt,
+                           const uint32_t* d_h1, const uint32_t* d_h2, const uint32_t* d_dlog_x, const uint32_t* d_dlog_y,
+                           const uint32_t* d_stmt_N, const uint32_t* d_stmt_c, const uint32_t* d_stmt_Q, const uint32_t* d_c_key,
+                           const uint32_t* d_q1, const mpe_pdl_proof* proof, uint8_t* d_ok, void* stream) {
+  if (!ctx || !pk || !d_Nt || !d_h1 || !d_h2 || !d_dlog_x || !d_dlog_y || !d_stmt_N || !d_stmt_c || !d_stmt_Q || !d_c_key || !d_q1 ||
+      !proof || !d_ok || batch < 0)
+    return MPE_E_ARG;
+  if (!d_key_idx && pk->nkeys != 1 && pk->nkeys < batch) return MPE_E_ARG;
+  if (batch == 0) return MPE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  mpe_statements* stm = nullptr;
+  MPE_TRY(mpe_statements_create_wb(ctx, batch, d_Nt, d_h1, d_h2, 0, &stm, stream));                        // statement i for item i
+  uint8_t* ok2 = nullptr;
+  if (hipMalloc((void**)&ok2, (size_t)batch + 64) != hipSuccess) { mpe_statements_destroy(stm); return MPE_E_NOMEM; }
+  uint32_t* genp = nullptr;
+  int rc = MPE_OK;
+  if (hipMalloc((void**)&genp, 64) != hipSuccess) rc = MPE_E_NOMEM;
+  if (rc == MPE_OK) {
+    hipLaunchKernelGGL(mpe::lindell_gen_point_kernel, dim3(1), dim3(64), 0, st, genp);
+    rc = mpe::pdl_verify(ctx, pk, stm, batch, d_key_idx, nullptr, mpe::rows(d_stmt_c, 128), mpe::rows(d_stmt_Q, 16), mpe::rows(genp, 0),
+                         mpe::dense(proof), d_ok, st);                                                        // :297
+  }
+  if (rc == MPE_OK) rc = mpe_composite_dlog_verify(ctx, batch, d_Nt, d_h1, d_h2, d_dlog_x, d_dlog_y, ok2, stream);   // :296
+  if (rc == MPE_OK) {
+    hipLaunchKernelGGL(mpe::and_u8_kernel, dim3(mpe::blocks_for(batch, 64)), dim3(64), 0, st, batch, d_ok, ok2);
+    hipLaunchKernelGGL(mpe::lindell_stmt_check_kernel, dim3(mpe::blocks_for(batch, 64)), dim3(64), 0, st, batch, d_stmt_N, pk->N, d_key_idx,
+                       d_stmt_c, d_c_key, d_stmt_Q, d_q1, d_ok);
+    if (hipGetLastError() != hipSuccess) rc = MPE_E_HIP;
+  }
+  (void)hipStreamSynchronize(st);
+  if (genp) (void)hipFree(genp);
+  (void)hipFree(ok2);
+  mpe_statements_destroy(stm);
+  return rc;
+}
 
 int mpe_lindell_partial_sig(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const int32_t* d_key_idx, const uint32_t* d_c_key,
                             const uint32_t* d_x2, const uint32_t* d_k2, const uint32_t* d_R1, const uint32_t* d_msg,

@@ -526,7 +526,7 @@ int mpe_statements_create(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const u
 }
 int mpe_statements_create_wb(mpe_ctx* ctx, int count, const uint32_t* d_Nt, const uint32_t* d_h1, const uint32_t* d_h2, int wb,
                              mpe_statements** out, void* stream) {
-  if (!ctx || !d_Nt || !d_h1 || !d_h2 || !out || count <= 0 || wb < 2 || wb > 16) return MPE_E_ARG;
+  if (!ctx || !d_Nt || !d_h1 || !d_h2 || !out || count <= 0 || (wb != 0 && wb < 2) || wb > 16) return MPE_E_ARG;   // wb == 0: one-off statements, no tables
   hipStream_t st = (hipStream_t)stream;
   mpe_statements* s = new (std::nothrow) mpe_statements();
   if (!s) return MPE_E_NOMEM;
@@ -540,7 +540,7 @@ int mpe_statements_create_wb(mpe_ctx* ctx, int count, const uint32_t* d_Nt, cons
   (void)hipMemcpyAsync(s->h2, d_h2, w * 4, hipMemcpyDeviceToDevice, st);
   int rc = mpe::modset_create_dev(ctx, 2048, count, s->Nt, &s->ms, st);
   if (rc != MPE_OK) { (void)hipFree(s->blob); delete s; return rc; }
-  if (ctx->use_fixed_base) {
+  if (ctx->use_fixed_base && wb != 0) {
     // fixed-base window tables of h1, h2 (26 MB per base at 8-bit windows), built on the GPU once per statement set:
     // the window bases one after the other (squarings), then every window's multiples in parallel
     using C = mpe::Cfg2048;

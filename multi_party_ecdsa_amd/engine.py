@@ -711,6 +711,28 @@ def lindell_partial_sig(ctx, pk, d_c_key, d_x2, d_k2, d_R1, d_msg, d_rho, d_r, d
     return c3
 
 
+def lindell_pdl_proof(ctx, sk, stm, d_c_key, d_x1, d_r, nonces, d_key_idx=None, d_st_idx=None):
+    """party one's `pdl_proof` (party_one.rs:366-401): returns (Q [B,16], proof dict)."""
+    B = d_x1.shape[0]
+    out = {f: _new(ctx, B, w) for f, w in PDL_PROOF_WORDS.items()}
+    Q = _new(ctx, B, 16)
+    nn, pr = _struct(N_.PdlNonces, nonces), _struct(N_.PdlProof, out)
+    N_.check(N_.lib.mpe_lindell_pdl_proof(ctx.h, sk.h, stm.h, B, _ptr(d_key_idx), _ptr(d_st_idx), _ptr(d_c_key), _ptr(d_x1), _ptr(d_r),
+                                          C.byref(nn), _ptr(Q), C.byref(pr), ctx.stream()), "mpe_lindell_pdl_proof")
+    return Q, out
+
+
+def lindell_pdl_verify(ctx, pk, d_Nt, d_h1, d_h2, d_dlog_x, d_dlog_y, d_stmt_N, d_stmt_c, d_stmt_Q, d_c_key, d_q1, proof, d_key_idx=None):
+    """party two's `PaillierPublic::pdl_verify` (party_two.rs:275-300): ok flags [B]."""
+    B = d_stmt_c.shape[0]
+    ok = _flags(ctx, B)
+    pr = _struct(N_.PdlProof, proof)
+    N_.check(N_.lib.mpe_lindell_pdl_verify(ctx.h, pk.h, B, _ptr(d_key_idx), _ptr(d_Nt), _ptr(d_h1), _ptr(d_h2), _ptr(d_dlog_x), _ptr(d_dlog_y),
+                                           _ptr(d_stmt_N), _ptr(d_stmt_c), _ptr(d_stmt_Q), _ptr(d_c_key), _ptr(d_q1), C.byref(pr), _ptr(ok),
+                                           ctx.stream()), "mpe_lindell_pdl_verify")
+    return ok
+
+
 def lindell_sign(ctx, sk, d_c3, d_k1, d_R2, d_key_idx=None):
     """`Signature::compute_with_recid` batched: returns (r [B,8], s [B,8], recid [B]) on the device."""
     B = d_c3.shape[0]
