@@ -138,6 +138,12 @@ struct Fork {
   void join();
   void branch_done_wait(int i, hipStream_t waiter);     // `waiter` waits for what branch i has queued so far
 };
+// a composite's own arrays at the top of the workspace: reserved against ws_alloc / ws_reserve until the composite returns
+struct WsTop {
+  mpe_ctx* c;
+  WsTop(mpe_ctx* ctx, const char* top) : c(ctx) { c->ws_top = (size_t)(((const char*)c->ws + c->ws_bytes) - top); }
+  ~WsTop() { c->ws_top = 0; }
+};
 template <class T>
 inline T* ws_array(mpe_ctx* ctx, size_t count) { return (T*)ws_alloc(ctx, count * sizeof(T)); }
 

@@ -159,6 +159,7 @@ int mpe_lindell_partial_sig(mpe_ctx* ctx, const mpe_paillier* pk, int batch, con
   char* top = (char*)ctx->ws + ctx->ws_bytes;
   uint32_t* ps = (uint32_t*)(top -= ((size_t)batch * 64 * 4 + 255) & ~(size_t)255);
   uint32_t* v = (uint32_t*)(top -= ((size_t)batch * 8 * 4 + 255) & ~(size_t)255);
+  mpe::WsTop hold(ctx, top);
   MPE_LAUNCH_1D(mpe::lindell_p2_prep_kernel, batch, st, batch, d_k2, d_x2, d_R1, d_msg, d_rho, ps, v);
   // c3 = c_key^v * Enc(ps; r): Paillier::encrypt, Paillier::mul, Paillier::add   :408-421
   return mpe::paillier_mul_add_enc(ctx, pk, batch, d_key_idx, mpe::rows(d_c_key, 128), mpe::rows(v, 8), 8, ps, d_r, d_c3, st);
@@ -174,6 +175,7 @@ int mpe_lindell_sign(mpe_ctx* ctx, const mpe_paillier* sk, int batch, const int3
   MPE_TRY(mpe::ws_reserve(ctx, (size_t)batch * (2 * (3 + 64 + 32 + 64 + 64) + 64) * 4 + (1u << 20), st));
   char* top = (char*)ctx->ws + ctx->ws_bytes;
   uint32_t* s_tag = (uint32_t*)(top -= ((size_t)batch * 64 * 4 + 255) & ~(size_t)255);
+  mpe::WsTop hold(ctx, top);
   MPE_TRY(mpe::paillier_decrypt(ctx, sk, batch, d_key_idx, mpe::rows(d_c3, 128), s_tag, st));               // :538-542
   MPE_LAUNCH_1D(mpe::lindell_p1_finish_kernel, batch, st, batch, s_tag, d_k1, d_R2, d_r, d_s, d_recid);
   return MPE_OK;

@@ -76,6 +76,7 @@ int mpe_mta_message_a(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   int32_t* st_of = (int32_t*)(top -= ((size_t)total * 4 + 255) & ~(size_t)255);
   int32_t* key_it = (int32_t*)(top -= ((size_t)total * 4 + 255) & ~(size_t)255);
   uint32_t* a64 = (uint32_t*)(top -= ((size_t)batch * 64 * 4 + 255) & ~(size_t)255);
+  mpe::WsTop hold(ctx, top);
   MPE_LAUNCH_1D(mpe::mta_idx_kernel, total, st, total, nst, pk->nkeys, d_key_idx, b_of, st_of, key_it);
   // c = Enc(a; r)   (:68-75)   a zero-extended to the plaintext width
   (void)hipMemsetAsync(a64, 0, (size_t)batch * 64 * 4, st);
@@ -106,6 +107,7 @@ int mpe_mta_message_b(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
   int32_t* key_it = (int32_t*)take((size_t)total * 4);
   uint8_t* ok_items = (uint8_t*)take((size_t)total);
   uint32_t* btq = (uint32_t*)take((size_t)batch * 8 * 4);
+  mpe::WsTop hold(ctx, top);
   MPE_LAUNCH_1D(mpe::mta_idx_kernel, total, st, total, nst, pk->nkeys, d_key_idx, b_of, st_of, key_it);
   // verify Alice's range proofs against every statement   (:119-131); any failure -> Err(InvalidKey) -> ok = 0
   MPE_TRY(mpe::alice_verify(ctx, pk, stm, total, key_it, st_of, mpe::rows(d_ca, 128, b_of), mpe::dense(range_proofs), ok_items, st));
