@@ -113,6 +113,10 @@ int mpe_paillier_encrypt(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const 
 int mpe_paillier_decrypt(mpe_ctx* ctx, const mpe_paillier* sk, int batch, const int32_t* d_key_idx,
                          const uint32_t* d_c, uint32_t* d_m, void* stream);
 /* c1*c2 mod N^2                   `Paillier::add` (src/utilities/mta/mod.rs:145) */
+/* kzen-paillier `Open::open(dk, c)` (blame.rs:252-256, `extract_paillier_randomness`): m = Dec(c) and the r with
+ * c = (1 + m N) r^N mod N^2, i.e. r = (c mod N)^(N^-1 mod phi(N)) mod N.  d_m, d_r [batch][64]. */
+int mpe_paillier_open(mpe_ctx* ctx, const mpe_paillier* sk, int batch, const int32_t* d_key_idx, const uint32_t* d_c,
+                      uint32_t* d_m, uint32_t* d_r, void* stream);
 int mpe_paillier_add(mpe_ctx* ctx, const mpe_paillier* pk, int batch, const int32_t* d_key_idx,
                      const uint32_t* d_c1, const uint32_t* d_c2, uint32_t* d_out, void* stream);
 /* c^k mod N^2                     `Paillier::mul` (src/utilities/mta/mod.rs:140-144); k: [batch][k_words] */
@@ -371,8 +375,7 @@ int mpe_gg20_blame7(mpe_ctx* ctx, int n_signers, int batch, const mpe_gg20_blame
 /* What a local party publishes for the phase-6 blame beyond the inputs it was given (LocalStatePhase6, blame.rs:227-234):
  * d_miu [n_local][batch][S-1][64] and the ECDDH proof d_a1, d_a2 [n_local][batch][16], d_z [n_local][batch][8] that
  * S_i = sigma_i R (`GlobalStatePhase6::ecddh_proof`, blame.rs:258-272; d_nonce [batch][n_local][8] is its sampled value).
- * Valid after round 5.  (The Paillier randomness of the incoming ciphertexts, `Paillier::open`, is computed by the key
- * holder's host: it needs N^-1 mod phi(N), an inverse modulo an even number.) */
+ * Valid after round 5.  (The Paillier randomness of the incoming ciphertexts: mpe_paillier_open.) */
 int mpe_gg20_session_blame6_state(const mpe_gg20_session* sess, const uint32_t* d_nonce, uint32_t* d_miu, uint32_t* d_a1,
                                   uint32_t* d_a2, uint32_t* d_z, void* stream);
 /* curv `ECDDHProof::{prove, verify}` for the statement {g1, h1 = x g1, g2, h2 = x g2}: a1 = s g1, a2 = s g2,

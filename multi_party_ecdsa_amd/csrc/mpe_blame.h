@@ -214,7 +214,64 @@ static Dim blame_dim(const mpe_gg20_keys* K, int B, const int32_t* d_keyset) {
 }  // namespace bl
 }  // namespace mpe
 
+// ---- kzen-paillier `Open` (blame.rs:252-256 extract_paillier_randomness) -------------------------------------------
+// c = (1 + m N) r^N mod N^2  =>  r^N = c (mod N)  =>  r = (c mod N)^d mod N with d = N^-1 mod phi(N).
+// phi is even: with u = phi^-1 mod N (N odd: the batched inversion) phi u = 1 + k N, so N (phi - k) = 1 (mod phi):
+// d = phi - (phi u - 1) / N, the exact quotient through N^-1 mod 2^2048.
+namespace mpe {
+namespace bl {
+__global__ void open_phi_kernel(int nk, const uint32_t* __restrict__ N, const uint32_t* __restrict__ pq32, uint32_t* __restrict__ phi) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nk) return;
+  uint32_t s[64];
+  const uint32_t one[1] = {1u};
+  sm::add(s, 64, pq32 + (size_t)(2 * k) * 32, 32, pq32 + (size_t)(2 * k + 1) * 32, 32);
+  sm::sub(s, 64, s, 64, one, 1);                                           // p + q - 1
+  sm::sub(phi + (size_t)k * 64, 64, N + (size_t)k * 64, 64, s, 64);        // phi = N - (p + q - 1)
+}
+__global__ void open_d_kernel(int nk, const uint32_t* __restrict__ N, const uint32_t* __restrict__ phi, const uint32_t* __restrict__ u,
+                              const uint8_t* __restrict__ ok, uint32_t* __restrict__ d) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nk) return;
+  uint32_t t[128], ninv[64], t1[64], t2[64];
+  const uint32_t one[1] = {1u};
+  sm::mul(t, phi + (size_t)k * 64, 64, u + (size_t)k * 64, 64);
+  sm::sub(t, 128, t, 128, one, 1);                                         // phi u - 1 = k N
+  sm::inv2adic(ninv, N + (size_t)k * 64, 64, t1, t2);
+  sm::mullo(t1, t, ninv, 64);                                              // k (< phi < 2^2048)
+  sm::sub(d + (size_t)k * 64, 64, phi + (size_t)k * 64, 64, t1, 64);
+  if (!ok[k]) sm::zero(d + (size_t)k * 64, 64);                            // gcd(N, phi) != 1: not a Paillier key
+}
+}  // namespace bl
+}  // namespace mpe
+
 extern "C" {
+
+int mpe_paillier_open(mpe_ctx* ctx, const mpe_paillier* sk, int batch, const int32_t* d_key_idx, const uint32_t* d_c, uint32_t* d_m,
+                      uint32_t* d_r, void* stream) {
+  using namespace mpe;
+  if (!ctx || !sk || !d_c || !d_m || !d_r || batch < 0) return MPE_E_ARG;
+  if (!sk->has_private) { mpe_set_error_msg("mpe_paillier_open: key set has no private part"); return MPE_E_ARG; }
+  if (!d_key_idx && sk->nkeys != 1 && sk->nkeys < batch) return MPE_E_ARG;
+  if (batch == 0) return MPE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  MPE_TRY(paillier_decrypt(ctx, sk, batch, d_key_idx, rows(d_c, 128), d_m, st));
+  const int nk = sk->nkeys;
+  MPE_TRY(ws_reserve(ctx, ((size_t)nk * 64 * 3 + modinv_ws_words(sk->ms_n, nk)) * 4 + 65536, st));
+  uint32_t *phi = ws_array<uint32_t>(ctx, (size_t)nk * 64), *u = ws_array<uint32_t>(ctx, (size_t)nk * 64), *d = ws_array<uint32_t>(ctx, (size_t)nk * 64);
+  uint8_t* ok = ws_array<uint8_t>(ctx, ((size_t)nk + 255) & ~(size_t)255);
+  if (!phi || !u || !d || !ok) { mpe_set_error_msg("mpe_paillier_open: workspace"); return MPE_E_NOMEM; }
+  MPE_LAUNCH_1D(bl::open_phi_kernel, nk, st, nk, sk->N, sk->pq32, phi);
+  MPE_TRY(launch_modinv(ctx, sk->ms_n, nk, rows(nullptr, 1), rows(phi, 64), u, ok, st));
+  MPE_LAUNCH_1D(bl::open_d_kernel, nk, st, nk, sk->N, phi, u, ok, d);
+  // r = (c mod N)^d mod N: the ciphertext enters the 2048-bit engine as a double-width base
+  const int rc = launch_modexp(ctx, sk->ms_n, batch, key_selector(sk, d_key_idx), Rows{d_c, nullptr, 128, 64}, Rows{d_c + 64, nullptr, 128, 64},
+                               key_rows(sk, d, 64, d_key_idx), 64, d_r, st);
+  (void)hipMemsetAsync(d, 0, (size_t)nk * 64 * 4, st);                     // d is as secret as p, q
+  (void)hipMemsetAsync(phi, 0, (size_t)nk * 64 * 4, st);
+  (void)hipMemsetAsync(u, 0, (size_t)nk * 64 * 4, st);
+  return rc;
+}
 
 int mpe_gg20_blame5(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int32_t* d_keyset, const mpe_gg20_blame5_in* in,
                     uint32_t* d_bad_actors, void* stream) {

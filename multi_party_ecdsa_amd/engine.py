@@ -711,6 +711,14 @@ def lindell_partial_sig(ctx, pk, d_c_key, d_x2, d_k2, d_R1, d_msg, d_rho, d_r, d
     return c3
 
 
+def paillier_open(ctx, sk, d_c, d_key_idx=None):
+    """kzen-paillier `Open::open`: returns (m [B,64], r [B,64]) with c = (1 + m N) r^N mod N^2."""
+    B = d_c.shape[0]
+    m, r = _new(ctx, B, 64), _new(ctx, B, 64)
+    N_.check(N_.lib.mpe_paillier_open(ctx.h, sk.h, B, _ptr(d_key_idx), _ptr(d_c), _ptr(m), _ptr(r), ctx.stream()), "mpe_paillier_open")
+    return m, r
+
+
 def lindell_pdl_proof(ctx, sk, stm, d_c_key, d_x1, d_r, nonces, d_key_idx=None, d_st_idx=None):
     """party one's `pdl_proof` (party_one.rs:366-401): returns (Q [B,16], proof dict)."""
     B = d_x1.shape[0]

@@ -56,6 +56,12 @@ def test_fault_injection_matrix(gpu_ctx, keys, t, n, signers, step, corrupted):
         tr = lambda x: np.ascontiguousarray(np.moveaxis(_u32(x), 0, 1)).reshape(-1, x.shape[-1])
         assert np.array_equal(tr(miu.reshape(S, B, -1)).reshape(-1, 64), o["miu"])
         assert np.array_equal(tr(a1), o["a1"]) and np.array_equal(tr(a2), o["a2"]) and np.array_equal(tr(z), o["z"])
+        # ... and what each key holder opens of the w_i ciphertexts it received (Paillier::open, blame.rs:252-256)
+        sg, P1 = [int(x) for x in lk["arrays"]["signers"]], S - 1
+        sk_all = E.PaillierKeys(gpu_ctx, p=[k.p for k in lk["keys"]], q=[k.q for k in lk["keys"]])
+        kx = torch.tensor([sg[(r // P1) % S] for r in range(B * S * P1)], dtype=torch.int32, device=gpu_ctx.device)
+        om, orr = E.paillier_open(gpu_ctx, sk_all, _dev(gpu_ctx, o["c_b"]), kx)
+        assert np.array_equal(_u32(om), o["miu"]) and np.array_equal(_u32(orr), o["miu_rand"])
         got = E.gg20_blame6(gpu_ctx, gk, B, {f: _dev(gpu_ctx, v) for f, v in o.items()})
     else:
         which, o = "b7", openings7(lk, nonces, slabs, oparties, B)
@@ -106,3 +112,36 @@ def test_ecddh_entry_points(gpu_ctx):
     ok = np.zeros(B, dtype=np.uint8)
     orc.lib.orc_ecddh_verify(B, *[orc._p(a) for a in (g1, h1, g2, h2, _u32(pr["a1"]), _u32(pr["a2"]), _u32(pr["z"]), ok)])
     assert list(E.ecddh_verify(gpu_ctx, stt, pr).cpu().numpy()) == list(ok) == [1, 1, 0, 1, 0, 1]
+
+
+def test_paillier_open_matches_oracle(gpu_ctx, keys):
+    """kzen-paillier `Open::open` (blame.rs:252-256): (m, r) of fresh encryptions come back exactly; edge ciphertexts
+    (1, N + 1, N^2 - 1) give the oracle's bytes as well.  (Non-units modulo N^2 are outside Paillier's domain: the L
+    function is not an exact division there and the reference's answer is an artefact of GMP's rounding.)"""
+    import torch
+    from multi_party_ecdsa_amd import engine as E
+    import fixtures as F
+    import orc
+    r = F.Rng("gpu-open")
+    B = 23
+    kidx = [(7 * i) % len(keys) for i in range(B)]
+    m = [r.below(keys[k].N) for k in kidx]
+    rr = [r.coprime_below(keys[k].N) for k in kidx]
+    m[0], m[1] = 0, keys[kidx[1]].N - 1
+    c = [pyref.paillier_encrypt(keys[k].N, mm, x) for k, mm, x in zip(kidx, m, rr)]
+    N5 = keys[kidx[5]].N
+    hostile = {18: 1, 19: keys[kidx[19]].N + 1, 20: keys[kidx[20]].N ** 2 - 1, 21: 2, 22: keys[kidx[22]].N ** 2 - keys[kidx[22]].N - 1}
+    for i, v in hostile.items():
+        c[i] = v
+    sk = E.PaillierKeys(gpu_ctx, p=[k.p for k in keys], q=[k.q for k in keys])
+    di = torch.tensor(kidx, dtype=torch.int32, device=gpu_ctx.device)
+    gm, gr = E.paillier_open(gpu_ctx, sk, E.dev(gpu_ctx, c, 128), di)
+    gpu_ctx.sync()
+    wm, wr = orc.u32((B, 64)), orc.u32((B, 64))
+    orc.lib.orc_paillier_open(B, len(keys), orc._p(F.words([k.p for k in keys], 32)), orc._p(F.words([k.q for k in keys], 32)),
+                              orc._p(np.array(kidx, dtype=np.int32)), orc._p(F.words(c, 128)), orc._p(wm), orc._p(wr))
+    gmw, grw = gm.cpu().numpy().view(np.uint32), gr.cpu().numpy().view(np.uint32)
+    assert [i for i in range(B) if not np.array_equal(gmw[i], wm[i])] == []
+    assert [i for i in range(B) if not np.array_equal(grw[i], wr[i])] == []
+    for i in range(18):
+        assert F.ints(wm[i:i + 1])[0] == m[i] and F.ints(wr[i:i + 1])[0] == rr[i]
