@@ -555,7 +555,15 @@ def main():
                                    " (all launches modulo N^2 of the timed region)",
                          "launches": len(dom), "avg_kernel_ms": dom_s / nl * 1e3,
                          "executed_mac_per_launch": exe_macs / nl, "alg_unit_mac_per_launch": dom_macs / nl,
-                         "kernel_time_share_of_step": dom_s / elapsed},
+                         "kernel_time_share_of_step": dom_s / elapsed,
+                         # the issue ceiling actually measured for this instruction (tools/ubench/valu_rate.hip): a stream of
+                         # v_mad_u64_u32 with VGPR operands sustains 31.2 T lane-ops/s at the kernel's 2 waves per SIMD, not
+                         # the 39.3 T of the 4-cycle issue model.  The kernel's VALU stream = the 29-bit-limb MACs it executes
+                         # ((72/64)^2 x 4 K^2 / 2 MAC(64) = 1.256 x the ideal count) x 740/648 instructions per MAC in its loops.
+                         "issue_ceiling": ({"measured_T_lane_ops_per_s": 31.2, "source": "profiles/r01_valu_rate.json (mad_u64_u32_vv, 2 waves/SIMD)",
+                                            "kernel_valu_T_lane_ops_per_s": exe_macs * 1.2558 * 740 / 648 / dom_s / 1e12,
+                                            "frac_of_measured": exe_macs * 1.2558 * 740 / 648 / dom_s / 31.2e12}
+                                           if pair and dom_s else None)},
             "breakdown": {"modexp4096_s_per_step": dom_s / args.steps, "modexp2048_s_per_step": sec_s / args.steps,
                           "heavy_kernels_s_per_step": heavy_s / args.steps, "wall_s_per_step": elapsed / args.steps,
                           "alg_unit_mac_per_signature": sig_macs(S, n), "fb_window_bits": gk.fb_window_bits()},
