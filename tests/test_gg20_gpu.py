@@ -57,7 +57,8 @@ class GpuParty:
         return {f: (_u32(v) if f in ("r", "s", "R", "bad_actors") else v.cpu().numpy()) for f, v in o.items()}
 
 
-CASES = [(1, 3, [0, 1], 3), (2, 5, [0, 2, 4], 2), (1, 3, [0, 1, 2], 2)]       # the last: S > t+1, as gg_2020/test.rs:55-67
+CASES = [(1, 3, [0, 1], 3), (2, 5, [0, 2, 4], 2), (1, 3, [0, 1, 2], 2),        # the third: S > t+1, as gg_2020/test.rs:55-67
+         (3, 8, [1, 2, 5, 7], 1)]                                              # n = 8: the widest shape the library takes
 
 
 @pytest.mark.parametrize("t,n,signers,B", CASES)
@@ -202,6 +203,8 @@ def test_tampered_message_gives_the_oracles_status_and_bad_actors(gpu_ctx, keys,
     (2, 5, [0, 2, 4], 3, {}),
     (2, 4, [1, 2, 3], 2, {"dedup_verify": True}),
     (2, 5, [0, 2, 3, 4], 2, {}),                     # S = 4 > t+1 (gg_2020/test.rs:60-63)
+    (5, 8, [0, 1, 3, 4, 6, 7], 1, {}),               # six of eight
+    (7, 8, [0, 1, 2, 3, 4, 5, 6, 7], 1, {}),         # every one of the eight parties signs (S = n = 8, the maximum)
 ])
 def test_sign_matches_oracle(gpu_ctx, keys, t, n, signers, B, kw):
     lk, nonces, (r, s, recid, status, R) = _run(gpu_ctx, keys, t, n, signers, B, f"gpu-{t}-{n}-{signers}", **kw)
