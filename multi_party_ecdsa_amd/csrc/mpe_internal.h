@@ -22,6 +22,7 @@ struct mpe_ctx {
   bool use_multiexp = true;       // verifiers: s^N * (c^-1)^e on one ladder instead of two exponentiations (same residue)
   bool use_crt = true;            // key holders compute x^e mod N^2 through p^2 | q^2 (mpe_paillier.h modexp_nn)
   bool use_fixed_base = true;     // h1/h2 exponentiations through per-statement window tables (mpe_fixedbase.h)
+  int wide_div = 2;               // the 2x-lanes layout is used when wide_div * batch <= the resident groups (MPE_WIDE_DIV)
   int modexp_waves_per_cu = 8;    // 2 waves/SIMD: the montmul loop holds ~230 VGPRs and already issues back-to-back
   // window-table scratch, grown on demand: one buffer per stream slot (0 = the caller's stream, 1..3 = the auxiliary streams
   // on which small batches run independent launches concurrently)

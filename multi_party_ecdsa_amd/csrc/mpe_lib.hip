@@ -288,6 +288,7 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   if (getenv("MPE_NO_PAR")) c->allow_par = false;
   if (getenv("MPE_NO_ADAPTIVE_LANES")) { c->adaptive_lanes = false; c->ec_lane_groups = false; }
   if (getenv("MPE_NO_WIDE")) c->adaptive_lanes = false;
+  if (const char* e = getenv("MPE_WIDE_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->wide_div = v; }
   if (getenv("MPE_WINDOW_BITS")) { const int w = atoi(getenv("MPE_WINDOW_BITS")); if (w >= 4 && w <= 6) c->window_bits = w; }
   // comb tables of the two fixed secp256k1 generators (module globals of this device; identical on every call)
   hipLaunchKernelGGL(mpe::ec::ec_comb_build_kernel, dim3(2), dim3(64), 0, 0);

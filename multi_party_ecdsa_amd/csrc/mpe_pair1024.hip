@@ -15,7 +15,7 @@ int pair_modexp_1024(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
   using Wide = Cfg<1024, MPE_W, MPE_L / 2, 4>;
   static_assert(Wide::K == Cfg1024::K, "the two layouts share the limb arrays");
   const long resident = (long)ctx->cus * ctx->modexp_waves_per_cu * Cfg1024::GROUPS;
-  if (ctx->adaptive_lanes && 2L * batch <= resident)
+  if (ctx->adaptive_lanes && (long)ctx->wide_div * batch <= resident)
     return pair_modexp_impl<Wide>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st);
   return pair_modexp_impl<Cfg1024>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st);
 }

@@ -15,7 +15,7 @@ int pair_modexp_2048(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
   using Wide = Cfg<2048, MPE_W, MPE_L / 2, 8>;
   static_assert(Wide::K == Cfg2048::K, "the two layouts share the limb arrays");
   const long resident = (long)ctx->cus * ctx->modexp_waves_per_cu * Cfg2048::GROUPS;
-  if (ctx->adaptive_lanes && 2L * batch <= resident)
+  if (ctx->adaptive_lanes && (long)ctx->wide_div * batch <= resident)
     return pair_modexp_impl<Wide>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st);
   return pair_modexp_impl<Cfg2048>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st);
 }
