@@ -44,14 +44,14 @@ __global__ void rows_eq_kernel(int n, int words, const uint32_t* __restrict__ a,
   eq[i] = o == 0;
 }
 // flag[pi] = (gamma_i G == g_gamma_i)      blame.rs:121-125
-__global__ void __launch_bounds__(64) gamma_check_kernel(int n, const uint32_t* __restrict__ gamma, const uint32_t* __restrict__ g_gamma,
+__global__ void __launch_bounds__(64) MPE_EC_OCC gamma_check_kernel(int n, const uint32_t* __restrict__ gamma, const uint32_t* __restrict__ g_gamma,
                                                          uint8_t* __restrict__ ok) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   ok[i] = ec::jac_eq_aff(ec::jac_mul_gen(ec::sc_reduce(gamma + (size_t)i * 8, 8)), ec::aff_load(g_gamma + (size_t)i * 16)) ? 1 : 0;
 }
 // the sequential logic of phase5_blame over the flags, and the delta reconstruction (:127-211); one session per lane
-__global__ void __launch_bounds__(64) blame5_combine_kernel(Dim d, const uint8_t* __restrict__ g_ok, const uint8_t* __restrict__ ca_ok,
+__global__ void __launch_bounds__(64) MPE_EC_OCC blame5_combine_kernel(Dim d, const uint8_t* __restrict__ g_ok, const uint8_t* __restrict__ ca_ok,
                                                             const uint8_t* __restrict__ cb_ok, const uint32_t* __restrict__ k,
                                                             const uint32_t* __restrict__ gamma, const uint32_t* __restrict__ beta_tag,
                                                             const uint32_t* __restrict__ delta, uint32_t* __restrict__ bad_out) {
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(64) blame5_combine_kernel(Dim d, const uint8_t
 }
 
 // g_ni[pp] = k_i g_w[ind] - miu_ij G       blame.rs:360-376
-__global__ void __launch_bounds__(64) gni_kernel(Dim d, const uint32_t* __restrict__ k, const uint32_t* __restrict__ miu, const uint32_t* __restrict__ gw,
+__global__ void __launch_bounds__(64) MPE_EC_OCC gni_kernel(Dim d, const uint32_t* __restrict__ k, const uint32_t* __restrict__ miu, const uint32_t* __restrict__ gw,
                                                  uint32_t* __restrict__ gni) {
   const int pp = blockIdx.x * blockDim.x + threadIdx.x;
   const int S = d.S, P1 = S - 1;
@@ -103,7 +103,7 @@ __device__ inline bool ecddh_verify(const ec::Aff& g1, const ec::Aff& h1, const 
          ec::jac_eq(ec::jac_mul(z, g2), ec::jac_add_aff(ec::jac_mul(e, h2), a2));
 }
 // g_sigma_i and the ECDDH proof of signer i  (:380-414)
-__global__ void __launch_bounds__(64) gsigma_kernel(Dim d, const uint32_t* __restrict__ k, const uint32_t* __restrict__ miu, const uint32_t* __restrict__ gw,
+__global__ void __launch_bounds__(64) MPE_EC_OCC gsigma_kernel(Dim d, const uint32_t* __restrict__ k, const uint32_t* __restrict__ miu, const uint32_t* __restrict__ gw,
                                                     const uint32_t* __restrict__ gni, const uint32_t* __restrict__ R, const uint32_t* __restrict__ Svec,
                                                     Ecddh pr, uint8_t* __restrict__ ok) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,7 +136,7 @@ __global__ void blame6_combine_kernel(Dim d, const uint8_t* __restrict__ mu_ok, 
   bad_out[b] = bad;
 }
 // phase7_blame: R s_i == m R_dash_i + r S_i   (:434-454)
-__global__ void __launch_bounds__(64) blame7_kernel(int B, int S, const uint32_t* __restrict__ s, const uint32_t* __restrict__ r, const uint32_t* __restrict__ Rdash,
+__global__ void __launch_bounds__(64) MPE_EC_OCC blame7_kernel(int B, int S, const uint32_t* __restrict__ s, const uint32_t* __restrict__ r, const uint32_t* __restrict__ Rdash,
                                                     const uint32_t* __restrict__ m, const uint32_t* __restrict__ R, const uint32_t* __restrict__ Svec,
                                                     uint8_t* __restrict__ ok) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,7 +155,7 @@ __global__ void mask_from_flags_kernel(int B, int S, const uint8_t* __restrict__
   for (int i = 0; i < S; ++i) if (!ok[(size_t)b * S + i]) bad |= 1u << i;
   bad_out[b] = bad;
 }
-__global__ void __launch_bounds__(64) ecddh_prove_kernel(int B, const uint32_t* __restrict__ x, const uint32_t* __restrict__ s_in, const uint32_t* __restrict__ g1,
+__global__ void __launch_bounds__(64) MPE_EC_OCC ecddh_prove_kernel(int B, const uint32_t* __restrict__ x, const uint32_t* __restrict__ s_in, const uint32_t* __restrict__ g1,
                                                          const uint32_t* __restrict__ h1, const uint32_t* __restrict__ g2, const uint32_t* __restrict__ h2,
                                                          uint32_t* __restrict__ a1, uint32_t* __restrict__ a2, uint32_t* __restrict__ z) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(64) ecddh_prove_kernel(int B, const uint32_t* 
   ec::aff_store(a2 + (size_t)i * 16, A2);
   ec::u256_store(z + (size_t)i * 8, ec::sc_add(s, ec::sc_mul(e, xx)));
 }
-__global__ void __launch_bounds__(64) ecddh_verify_kernel(int B, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ h1, const uint32_t* __restrict__ g2,
+__global__ void __launch_bounds__(64) MPE_EC_OCC ecddh_verify_kernel(int B, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ h1, const uint32_t* __restrict__ g2,
                                                           const uint32_t* __restrict__ h2, Ecddh pr, uint8_t* __restrict__ ok) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(64) ecddh_verify_kernel(int B, const uint32_t*
                        ec::sc_reduce(pr.z + (size_t)i * 8, 8)) ? 1 : 0;
 }
 // the session's openings for phase-6 blame: the ECDDH proof that S_i = sigma_i R (blame.rs:258-272), sigma_i never leaves
-__global__ void __launch_bounds__(64) session_ecddh_kernel(Dim d, const uint32_t* __restrict__ sigma_i, const uint32_t* __restrict__ R,
+__global__ void __launch_bounds__(64) MPE_EC_OCC session_ecddh_kernel(Dim d, const uint32_t* __restrict__ sigma_i, const uint32_t* __restrict__ R,
                                                            const uint32_t* __restrict__ nonce, uint32_t* __restrict__ a1, uint32_t* __restrict__ a2,
                                                            uint32_t* __restrict__ z) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;

@@ -21,7 +21,7 @@ __global__ void add_one_mod_kernel(int B, const uint32_t* __restrict__ a, const 
   sm::copy(out + (size_t)i * K32, x, K32);
 }
 // ok &= ( (s1 mod q) G == (e mod q) X + u )        BobProofExt::verify :522-531
-__global__ void __launch_bounds__(64) bob_ext_check_kernel(int B, Rows s1, Rows e, const uint32_t* __restrict__ X, const uint32_t* __restrict__ u,
+__global__ void __launch_bounds__(64) MPE_EC_OCC bob_ext_check_kernel(int B, Rows s1, Rows e, const uint32_t* __restrict__ X, const uint32_t* __restrict__ u,
                                      uint8_t* __restrict__ ok) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;

@@ -28,7 +28,7 @@ __device__ __forceinline__ Aff aff_neg(const Aff& a) {
 // (x | y), d = 1..15, w = 0..63 (154 KB, filled once per device by ec_comb_build_kernel when a context is created).
 // k*G is then 64 mixed additions and no doublings (jac_mul_comb).
 __device__ uint32_t COMB[2][64][15][20];
-__global__ void __launch_bounds__(64) ec_comb_build_kernel() {
+__global__ void __launch_bounds__(64) MPE_EC_OCC ec_comb_build_kernel() {
   const int w = threadIdx.x & 63, g = blockIdx.x;
   if (g > 1) return;
   Jac b = jac_from_aff(g ? aff_h2() : aff_gen());
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(64) ec_comb_build_kernel() {
   }
 }
 // k*G (g = 0) or k*base_point2 (g = 1), k already reduced mod q
-__device__ __noinline__ Jac jac_mul_fixed(const U256& k, int g) { return jac_mul_comb(k, &COMB[g][0][0][0]); }
+__device__ __forceinline__ Jac jac_mul_fixed(const U256& k, int g) { return jac_mul_comb(k, &COMB[g][0][0][0]); }
 __device__ __forceinline__ Jac jac_mul_gen(const U256& k) { return jac_mul_fixed(k, 0); }
 __device__ __forceinline__ Jac jac_mul_h2(const U256& k) { return jac_mul_fixed(k, 1); }
 

@@ -18,11 +18,19 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+// MPE_HD: small, always inlined.  MPE_HDN: whole ladders / inversions -- one out-of-line copy per translation unit (inlining
+// them into every kernel that multiplies a point made mpe_lib.hip a ten-minute compile); their call overhead is nothing
+// next to the ~10^5 instructions they run.
 #ifdef MPE_FE_HOST
 #define MPE_HD inline
+#define MPE_HDN inline
 #else
 #include <hip/hip_runtime.h>
 #define MPE_HD __device__ __forceinline__
+#define MPE_HDN __device__ __noinline__
+// every kernel that calls into the out-of-line EC functions asks for two waves per SIMD: the request propagates to the callees
+// (AMDGPU attributor), which otherwise take all 512 registers and leave their callers at one wave
+#define MPE_EC_OCC __attribute__((amdgpu_waves_per_eu(2)))
 #endif
 
 namespace mpe {
@@ -207,7 +215,7 @@ MPE_HD Fe fe_sqrn(Fe x, int n) {
 }
 // a^(p-2): p - 2 = 1^223 0 1^22 0000 101101 in binary; addition chain with 255 squarings + 15 multiplications.
 // a of magnitude <= 5; result magnitude 1.
-MPE_HD Fe fe_inv(const Fe& a) {
+MPE_HDN Fe fe_inv(const Fe& a) {
   const Fe x2 = fe_mul(fe_sqr(a), a), x3 = fe_mul(fe_sqr(x2), a);
   const Fe x6 = fe_mul(fe_sqrn(x3, 3), x3), x9 = fe_mul(fe_sqrn(x6, 3), x3), x11 = fe_mul(fe_sqrn(x9, 2), x2);
   const Fe x22 = fe_mul(fe_sqrn(x11, 11), x11), x44 = fe_mul(fe_sqrn(x22, 22), x22);

@@ -214,7 +214,7 @@ __device__ __forceinline__ ec::U256 hash_points(const ec::Aff (&pts)[N]) {
 __device__ __forceinline__ ec::Aff mul_aff(const ec::U256& k, const ec::Aff& P) { return ec::jac_to_aff(ec::jac_mul(k, P)); }
 
 // g_w_vec of a key set: lambda_j X_j for every signer (once per key object)
-__global__ void __launch_bounds__(64) gw_kernel(Dim d, const uint32_t* __restrict__ Xs, uint32_t* __restrict__ gw) {
+__global__ void __launch_bounds__(64) MPE_EC_OCC gw_kernel(Dim d, const uint32_t* __restrict__ Xs, uint32_t* __restrict__ gw) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= d.K * d.S) return;
   const int kk = g / d.S, j = g % d.S;
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(64) gw_kernel(Dim d, const uint32_t* __restric
 }
 
 // ---- Round 0: SignKeys::create + phase1_broadcast (party_i.rs:546-589) ----------------------------
-__global__ void __launch_bounds__(64) r0_kernel(Dim d, const uint32_t* __restrict__ xs, const uint32_t* __restrict__ k_in,
+__global__ void __launch_bounds__(64) MPE_EC_OCC r0_kernel(Dim d, const uint32_t* __restrict__ xs, const uint32_t* __restrict__ k_in,
                           const uint32_t* __restrict__ gamma_in, const uint32_t* __restrict__ blind, uint32_t* __restrict__ kq,
                           uint32_t* __restrict__ gq, uint32_t* __restrict__ w, uint32_t* __restrict__ k64, uint32_t* __restrict__ g_gamma,
                           uint32_t* __restrict__ com) {
@@ -290,7 +290,7 @@ __device__ __forceinline__ void r2a_finish(const Dim& d, int rv, int v, int pp, 
   else ec::aff_store(bpk_in + (size_t)pp * 16, Bpk);                                          // mb_gamma_s[jj].b_proof.pk, for phase4
   code[rv] = c;
 }
-__global__ void __launch_bounds__(64) r2a_kernel(Dim d, const int32_t* __restrict__ sub1_rv, const uint32_t* __restrict__ in1,
+__global__ void __launch_bounds__(64) MPE_EC_OCC r2a_kernel(Dim d, const int32_t* __restrict__ sub1_rv, const uint32_t* __restrict__ in1,
                            const uint32_t* __restrict__ alpha_full, const uint32_t* __restrict__ kq, const uint32_t* __restrict__ gw,
                            uint32_t* __restrict__ alpha, uint32_t* __restrict__ bpk_in, uint8_t* __restrict__ code) {
   const int rv = blockIdx.x * blockDim.x + threadIdx.x;
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(64) r2a_kernel(Dim d, const int32_t* __restric
 
 // delta_i, sigma_i, T_i + PedersenProof::prove (party_i.rs:591-634); the party's status of this round
 struct Ped { uint32_t *T, *e, *a1, *a2, *z1, *z2; };       // [pi]
-__global__ void __launch_bounds__(64) r2b_kernel(Dim d, const uint32_t* __restrict__ kq, const uint32_t* __restrict__ gq,
+__global__ void __launch_bounds__(64) MPE_EC_OCC r2b_kernel(Dim d, const uint32_t* __restrict__ kq, const uint32_t* __restrict__ gq,
                            const uint32_t* __restrict__ w, const uint32_t* __restrict__ alpha,
                            const uint32_t* __restrict__ beta, const uint8_t* __restrict__ code, const uint32_t* __restrict__ l_in,
                            const uint32_t* __restrict__ s1_in, const uint32_t* __restrict__ s2_in,
@@ -375,7 +375,7 @@ __device__ __forceinline__ void r3_finish(int pi, bool com_ok, bool ped_ok, cons
   ec::u256_store(dinv + (size_t)pi * 8, inv_ok ? ec::sc_inv(sum) : ec::u256_zero());
   if (!ped_ok) fail(status, bad, pi, 302, 0);
 }
-__global__ void __launch_bounds__(64) r3_kernel(Dim d, Slab in2, uint32_t* __restrict__ dinv, int32_t* __restrict__ status,
+__global__ void __launch_bounds__(64) MPE_EC_OCC r3_kernel(Dim d, Slab in2, uint32_t* __restrict__ dinv, int32_t* __restrict__ status,
                                                 uint32_t* __restrict__ bad) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(64) r3_kernel(Dim d, Slab in2, uint32_t* __res
 
 // ---- Round 4: phase4 -> R, R_dash (party_i.rs:642-687, rounds.rs:452) --------------------------------
 // M3 record: blind 0 | g_gamma 8
-__global__ void __launch_bounds__(64) r4_kernel(Dim d, Slab in3, const uint32_t* __restrict__ dinv, const uint32_t* __restrict__ com_all,
+__global__ void __launch_bounds__(64) MPE_EC_OCC r4_kernel(Dim d, Slab in3, const uint32_t* __restrict__ dinv, const uint32_t* __restrict__ com_all,
                           const uint32_t* __restrict__ bpk_in, const uint32_t* __restrict__ kq, uint32_t* __restrict__ R,
                           uint32_t* __restrict__ Rbar, int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,7 +434,7 @@ __global__ void idx5_kernel(Dim d, Slab in4, int32_t* __restrict__ sub4_pv, int3
 }
 // my PDL verifications (rounds.rs:546-558), the R_dash sum, S_i and HomoELGamalProof::prove (party_i.rs:768-799)
 struct Heg { uint32_t *S, *T, *A3, *z1, *z2; };      // [pi]
-__global__ void __launch_bounds__(64) r5_status_kernel(Dim d, Slab in4, const uint8_t* __restrict__ pdl_ok, int32_t* __restrict__ status,
+__global__ void __launch_bounds__(64) MPE_EC_OCC r5_status_kernel(Dim d, Slab in4, const uint8_t* __restrict__ pdl_ok, int32_t* __restrict__ status,
                                                        uint32_t* __restrict__ bad) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(64) r5_status_kernel(Dim d, Slab in4, const ui
   if (!ec::jac_eq_aff(acc, ec::aff_gen())) fail(status, bad, pi, 502, 0);                  // phase5_check_R_dash_sum
 }
 // S_i and HomoELGamalProof::prove: independent of the verifications above (small batches run it beside them)
-__global__ void __launch_bounds__(64) r5_prove_kernel(Dim d, const uint32_t* __restrict__ R, const uint32_t* __restrict__ sigma_i,
+__global__ void __launch_bounds__(64) MPE_EC_OCC r5_prove_kernel(Dim d, const uint32_t* __restrict__ R, const uint32_t* __restrict__ sigma_i,
                           const uint32_t* __restrict__ lq, const uint32_t* __restrict__ pedT, const uint32_t* __restrict__ s1_in,
                           const uint32_t* __restrict__ s2_in, Heg h) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(64) r5_prove_kernel(Dim d, const uint32_t* __r
 
 // ---- Round 6: every HomoELGamalProof; sum S_i == y (party_i.rs:801-848) --------------------------------------------
 // M5 record: S_i 0 | T 16 | A3 32 | z1 48 | z2 56
-__global__ void __launch_bounds__(64) r6_kernel(Dim d, Slab in5, const uint32_t* __restrict__ R, const uint32_t* __restrict__ tvec,
+__global__ void __launch_bounds__(64) MPE_EC_OCC r6_kernel(Dim d, Slab in5, const uint32_t* __restrict__ R, const uint32_t* __restrict__ tvec,
                           const uint32_t* __restrict__ y, int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(64) r6_kernel(Dim d, Slab in5, const uint32_t*
 // r3 22 -> 52 ms), so the rounds pick them only when the grouped launch still fits the chip.
 struct JacSlots { ec::Jac v[64]; };
 
-__global__ void __launch_bounds__(64) r2a_group_kernel(Dim d, const int32_t* __restrict__ sub1_rv, const uint32_t* __restrict__ in1,
+__global__ void __launch_bounds__(64) MPE_EC_OCC r2a_group_kernel(Dim d, const int32_t* __restrict__ sub1_rv, const uint32_t* __restrict__ in1,
                            const uint32_t* __restrict__ alpha_full, const uint32_t* __restrict__ kq, const uint32_t* __restrict__ gw,
                            uint32_t* __restrict__ alpha, uint32_t* __restrict__ bpk_in, uint8_t* __restrict__ code) {
   // 4 lanes per incoming MessageB: lanes 0..2 do  k_i B | c1 B | c2 B'  (variable base), then  alpha G | z G | z' G
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(64) r2a_group_kernel(Dim d, const int32_t* __r
 }
 
 // G lanes per party (a power of two >= 2 S): lane 2j | 2j+1 does z1_j G | z2_j H, lane j also e_j com_j
-__global__ void __launch_bounds__(64) r3_group_kernel(Dim d, int G, Slab in2, uint32_t* __restrict__ dinv, int32_t* __restrict__ status,
+__global__ void __launch_bounds__(64) MPE_EC_OCC r3_group_kernel(Dim d, int G, Slab in2, uint32_t* __restrict__ dinv, int32_t* __restrict__ status,
                                                       uint32_t* __restrict__ bad) {
   __shared__ JacSlots vs, fs;
   const int gid = blockIdx.x * 64 + threadIdx.x, pi = gid / G, sub = gid % G, base = (int)threadIdx.x - sub;
@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(64) r3_group_kernel(Dim d, int G, Slab in2, ui
 }
 
 // G lanes per party (a power of two >= 3 S): lane 3j+k does e D_j | z2_j R | e E_j; lane 2j+k does z1_j H | z2_j G
-__global__ void __launch_bounds__(64) r6_group_kernel(Dim d, int G, Slab in5, const uint32_t* __restrict__ R, const uint32_t* __restrict__ tvec,
+__global__ void __launch_bounds__(64) MPE_EC_OCC r6_group_kernel(Dim d, int G, Slab in5, const uint32_t* __restrict__ R, const uint32_t* __restrict__ tvec,
                           const uint32_t* __restrict__ y, int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
   __shared__ JacSlots vs, fs;
   const int gid = blockIdx.x * 64 + threadIdx.x, pi = gid / G, sub = gid % G, base = (int)threadIdx.x - sub;
@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(64) r6_group_kernel(Dim d, int G, Slab in5, co
 }
 
 // ---- Round 7: phase7_local_sig -> PartialSignature (party_i.rs:850-871) -------------------------------------------------
-__global__ void __launch_bounds__(64) r7_kernel(Dim d, const uint32_t* __restrict__ msg, const uint32_t* __restrict__ R,
+__global__ void __launch_bounds__(64) MPE_EC_OCC r7_kernel(Dim d, const uint32_t* __restrict__ msg, const uint32_t* __restrict__ R,
                           const uint32_t* __restrict__ kq, const uint32_t* __restrict__ sigma_i, uint32_t* __restrict__ mq,
                           uint32_t* __restrict__ rq, uint32_t* __restrict__ s_i, int fault_step, uint32_t fault_mask) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(64) r7_kernel(Dim d, const uint32_t* __restric
   ec::u256_store(s_i + (size_t)pi * 8, si);
 }
 // SignManual::complete -> output_signature + verify (party_i.rs:873-936); outputs are [L][B], zero unless status == 0
-__global__ void __launch_bounds__(64) complete_kernel(Dim d, Slab in6, const uint32_t* __restrict__ R, const uint32_t* __restrict__ mq,
+__global__ void __launch_bounds__(64) MPE_EC_OCC complete_kernel(Dim d, Slab in6, const uint32_t* __restrict__ R, const uint32_t* __restrict__ mq,
                           const uint32_t* __restrict__ rq, const uint32_t* __restrict__ s_i, const uint32_t* __restrict__ y,
                           int32_t* __restrict__ status, uint32_t* __restrict__ bad, uint32_t* __restrict__ r_out,
                           uint32_t* __restrict__ s_out, int32_t* __restrict__ recid_out) {

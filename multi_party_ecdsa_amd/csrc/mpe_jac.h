@@ -87,7 +87,7 @@ MPE_HD bool jac_eq(const Jac& p, const Jac& q) {
   return fe_eq(fe_mul(p.x, z2z2), fe_mul(q.x, z1z1), 1) &&
          fe_eq(fe_mul(p.y, fe_mul(z2z2, q.z)), fe_mul(q.y, fe_mul(z1z1, p.z)), 1);
 }
-MPE_HD Aff jac_to_aff(const Jac& p) {
+MPE_HDN Aff jac_to_aff(const Jac& p) {
   Aff a;
   if (p.inf) { a.inf = true; for (int i = 0; i < 8; ++i) a.x.w[i] = a.y.w[i] = 0; return a; }
   const Fe zi = fe_inv(p.z), zi2 = fe_sqr(zi);
@@ -104,7 +104,7 @@ MPE_HD bool aff_on_curve(const Aff& a) {
 }
 
 // k P, k already reduced mod q: plain ladder, fixed 4-bit windows (kept as the cross-check of jac_mul in the host tests)
-MPE_HD Jac jac_mul_w4(const U256& k, const Aff& P) {
+MPE_HDN Jac jac_mul_w4(const U256& k, const Aff& P) {
   if (P.inf) return jac_inf();
   const AffL pa = affl_from_aff(P);
   Jac tab[16];
@@ -139,7 +139,7 @@ MPE_HD void glv_recode(int8_t (&dg)[26], const U256& v) {
 // 1P..16P serves both halves.  26 signed 5-bit windows: 130 doublings + 52 additions instead of 256 + 64.  The sequence
 // of doublings / additions / table reads is the same for every scalar (digit 0 adds a dummy entry and keeps the old
 // accumulator; signs are selects).
-MPE_HD Jac jac_mul(const U256& k, const Aff& P) {
+MPE_HDN Jac jac_mul(const U256& k, const Aff& P) {
   if (P.inf) return jac_inf();
   const AffL pa = affl_from_aff(P);
   Jac tab[16];                                                    // tab[j] = (j + 1) P
@@ -179,7 +179,7 @@ MPE_HD Jac jac_mul(const U256& k, const Aff& P) {
 }
 // k B from a comb table: tab[w][d - 1] = d 16^w B as 20 limbs (x | y), d = 1..15, w = 0..63: 64 mixed additions, no
 // doublings; the additions always run (digit 0 adds a dummy entry and keeps the old accumulator)
-MPE_HD Jac jac_mul_comb(const U256& k, const uint32_t* tab) {
+MPE_HDN Jac jac_mul_comb(const U256& k, const uint32_t* tab) {
   Jac acc = jac_inf();
 #ifndef MPE_FE_HOST
 #pragma unroll 1

@@ -16,7 +16,7 @@ constexpr int CK_M2 = 11;
 
 // zk-paillier compute_digest over BigInts as minimal big-endian bytes; one (key, i) per lane:
 //   seed = H(N, salt, i);  acc = sum_j H(seed, j) << (256 j), j < bit_length(N)/256 + 1  ->  hi (words 64..71) | lo (words 0..63)
-__global__ void __launch_bounds__(64) ck_rho_kernel(int B, const uint32_t* __restrict__ N, uint32_t* __restrict__ lo, uint32_t* __restrict__ hi) {
+__global__ void __launch_bounds__(64) MPE_EC_OCC ck_rho_kernel(int B, const uint32_t* __restrict__ N, uint32_t* __restrict__ lo, uint32_t* __restrict__ hi) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= B * CK_M2) return;
   const int b = g / CK_M2, i = g % CK_M2;
@@ -100,7 +100,7 @@ __global__ void cd_n_check_kernel(int B, const uint32_t* __restrict__ N, uint8_t
   ok[b] = ((n[0] & 1u) && hi) ? 1 : 0;
 }
 // Feldman: sum_k index^k C_k (Horner); share != null: ok = (share G == that), else the point itself
-__global__ void __launch_bounds__(64) vss_kernel(int B, int t1, const uint32_t* __restrict__ commits, const uint32_t* __restrict__ share,
+__global__ void __launch_bounds__(64) MPE_EC_OCC vss_kernel(int B, int t1, const uint32_t* __restrict__ commits, const uint32_t* __restrict__ share,
                                                  const int32_t* __restrict__ index, uint8_t* __restrict__ ok, uint32_t* __restrict__ out) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;

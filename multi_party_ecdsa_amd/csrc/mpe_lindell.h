@@ -15,7 +15,7 @@
 namespace mpe {
 
 // per session: plaintext ps = rho q + (k2^-1 m mod q)  [64 words]  and multiplier v = k2^-1 (rx x2) mod q  [8 words]
-__global__ void __launch_bounds__(64) lindell_p2_prep_kernel(int B, const uint32_t* __restrict__ k2, const uint32_t* __restrict__ x2,
+__global__ void __launch_bounds__(64) MPE_EC_OCC lindell_p2_prep_kernel(int B, const uint32_t* __restrict__ k2, const uint32_t* __restrict__ x2,
                                                              const uint32_t* __restrict__ R1, const uint32_t* __restrict__ msg,
                                                              const uint32_t* __restrict__ rho, uint32_t* __restrict__ ps,
                                                              uint32_t* __restrict__ v) {
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(64) lindell_p2_prep_kernel(int B, const uint32
 }
 
 // per session: r = (k1 R2).x mod q, s = min(s'', q - s'') with s'' = (s_tag mod q) k1^-1, recid   (:526-561)
-__global__ void __launch_bounds__(64) lindell_p1_finish_kernel(int B, const uint32_t* __restrict__ s_tag, const uint32_t* __restrict__ k1,
+__global__ void __launch_bounds__(64) MPE_EC_OCC lindell_p1_finish_kernel(int B, const uint32_t* __restrict__ s_tag, const uint32_t* __restrict__ k1,
                                                                const uint32_t* __restrict__ R2, uint32_t* __restrict__ r_out,
                                                                uint32_t* __restrict__ s_out, int32_t* __restrict__ recid) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

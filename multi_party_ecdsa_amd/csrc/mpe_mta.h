@@ -36,7 +36,7 @@ __global__ void mta_beta_kernel(int B, const uint32_t* __restrict__ beta_tag, ui
   ec::u256_store(beta + (size_t)i * 8, ec::sc_neg(t));
 }
 // alpha = alice_share mod q; ok = DLogProof::verify x2 && b_proof.pk * a + beta_tag_proof.pk == g^alpha   (:166-178)
-__global__ void __launch_bounds__(64) mta_alpha_kernel(int B, const uint32_t* __restrict__ share, const uint32_t* __restrict__ a,
+__global__ void __launch_bounds__(64) MPE_EC_OCC mta_alpha_kernel(int B, const uint32_t* __restrict__ share, const uint32_t* __restrict__ a,
                                  const uint32_t* __restrict__ pk, const uint32_t* __restrict__ R, const uint32_t* __restrict__ z,
                                  const uint32_t* __restrict__ tpk, const uint32_t* __restrict__ tR, const uint32_t* __restrict__ tz,
                                  uint32_t* __restrict__ alpha, uint8_t* __restrict__ ok) {

@@ -54,7 +54,7 @@ static int launch_fb_modexp(mpe_ctx* ctx, const mpe_statements* stm, int B, Rows
 // secp256k1 batch kernels
 // ---------------------------------------------------------------------------------------------
 // out = (k mod q) * P;  P == nullptr -> generator
-__global__ void __launch_bounds__(64) ec_mul_kernel(int B, const uint32_t* __restrict__ k, int kw, const uint32_t* __restrict__ P,
+__global__ void __launch_bounds__(64) MPE_EC_OCC ec_mul_kernel(int B, const uint32_t* __restrict__ k, int kw, const uint32_t* __restrict__ P,
                               uint32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(64) ec_mul_kernel(int B, const uint32_t* __res
   const ec::Jac r = P ? ec::jac_mul(s, ec::aff_load(P + (size_t)i * 16)) : ec::jac_mul_gen(s);
   ec::aff_store(out + (size_t)i * 16, ec::jac_to_aff(r));
 }
-__global__ void __launch_bounds__(64) ec_add_kernel(int B, const uint32_t* __restrict__ P, const uint32_t* __restrict__ Q,
+__global__ void __launch_bounds__(64) MPE_EC_OCC ec_add_kernel(int B, const uint32_t* __restrict__ P, const uint32_t* __restrict__ Q,
                               uint32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -81,7 +81,7 @@ __device__ inline ec::U256 dlog_challenge(const ec::Aff& R, const ec::Aff& pk) {
   const ec::U256 d = ec::sha_final(s);
   return ec::sc_reduce(d.w, 8);
 }
-__global__ void __launch_bounds__(64) dlog_prove_kernel(int B, const uint32_t* __restrict__ sk, const uint32_t* __restrict__ nonce,
+__global__ void __launch_bounds__(64) MPE_EC_OCC dlog_prove_kernel(int B, const uint32_t* __restrict__ sk, const uint32_t* __restrict__ nonce,
                                   uint32_t* __restrict__ pk, uint32_t* __restrict__ R, uint32_t* __restrict__ z) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(64) dlog_prove_kernel(int B, const uint32_t* _
   ec::aff_store(R + (size_t)i * 16, Rp);
   ec::u256_store(z + (size_t)i * 8, ec::sc_sub(k, ec::sc_mul(c, s)));
 }
-__global__ void __launch_bounds__(64) dlog_verify_kernel(int B, const uint32_t* __restrict__ pk, const uint32_t* __restrict__ R,
+__global__ void __launch_bounds__(64) MPE_EC_OCC dlog_verify_kernel(int B, const uint32_t* __restrict__ pk, const uint32_t* __restrict__ R,
                                    const uint32_t* __restrict__ z, uint8_t* __restrict__ ok) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -126,7 +126,7 @@ __global__ void muladd_kernel(int B, Rows a, int na, Rows b, int nb, Rows c, int
 enum { HF_BIGINT = 0, HF_BIGINT_PLUS1 = 1, HF_POINT_COMPRESSED = 2 };
 struct HashField { Rows r; int words; int kind; };
 struct HashDesc { HashField f[14]; int n; };
-__global__ void __launch_bounds__(64) hash_kernel(int B, HashDesc d, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) MPE_EC_OCC hash_kernel(int B, HashDesc d, uint32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   ec::Sha256 s;
@@ -174,7 +174,7 @@ __global__ void fill_u8_kernel(int B, uint8_t* p, uint8_t v) {
   if (i < B) p[i] = v;
 }
 // PDL verify: ok &= ( (s1 mod q) G + (q - e) Q == u1 )      (zk_pdl_with_slack/mod.rs:138-142,174)
-__global__ void __launch_bounds__(64) pdl_u1_check_kernel(int B, Rows s1, const uint32_t* __restrict__ e, Rows G, Rows Q, Rows u1,
+__global__ void __launch_bounds__(64) MPE_EC_OCC pdl_u1_check_kernel(int B, Rows s1, const uint32_t* __restrict__ e, Rows G, Rows Q, Rows u1,
                                     uint8_t* __restrict__ ok) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(64) pdl_u1_check_kernel(int B, Rows s1, const 
   if (!ec::jac_eq_aff(l, U1)) ok[i] = 0;
 }
 // out = (k mod q) * P with per-item rows (P.p == nullptr -> generator)
-__global__ void __launch_bounds__(64) ec_mul_rows_kernel(int B, Rows k, int kw, Rows P, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) MPE_EC_OCC ec_mul_rows_kernel(int B, Rows k, int kw, Rows P, uint32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::U256 s = ec::sc_reduce(row_of(k, i), kw);

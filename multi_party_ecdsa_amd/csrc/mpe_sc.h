@@ -141,7 +141,7 @@ MPE_HD U256 sc_sub(const U256& a, const U256& b) {
 }
 MPE_HD U256 sc_neg(const U256& a) { return u256_is_zero(a) ? a : sc_sub(u256_zero(), a); }
 // a^(q-2) mod q: 4-bit windows of the (public) exponent
-MPE_HD U256 sc_inv(const U256& a) {
+MPE_HDN U256 sc_inv(const U256& a) {
   U256 tab[16];
   tab[0] = u256_one();
   tab[1] = a;
@@ -189,7 +189,7 @@ MPE_HD U256 sc_mul_shift384(const U256& k, const uint32_t* g) {
   return r;
 }
 struct GlvSplit { U256 r1, r2; bool neg1, neg2; };      // k = (neg1 ? -r1 : r1) + (neg2 ? -r2 : r2) lambda, r1, r2 < 2^128
-MPE_HD GlvSplit sc_split_lambda(const U256& k) {
+MPE_HDN GlvSplit sc_split_lambda(const U256& k) {
   const U256 c1 = sc_mul(sc_mul_shift384(k, GLV_G1), u256_load(GLV_MB1));
   const U256 c2 = sc_mul(sc_mul_shift384(k, GLV_G2), u256_load(GLV_MB2));
   GlvSplit s;

@@ -9,7 +9,7 @@
 
 namespace mpe {
 
-__global__ void __launch_bounds__(64) pedersen_prove_kernel(int B, const uint32_t* __restrict__ m, const uint32_t* __restrict__ r,
+__global__ void __launch_bounds__(64) MPE_EC_OCC pedersen_prove_kernel(int B, const uint32_t* __restrict__ m, const uint32_t* __restrict__ r,
                                                             const uint32_t* __restrict__ s1_in, const uint32_t* __restrict__ s2_in,
                                                             mpe_pedersen_proof p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(64) pedersen_prove_kernel(int B, const uint32_
   ec::u256_store(p.z1 + (size_t)i * 8, ec::sc_add(s1, ec::sc_mul(e, mm)));
   ec::u256_store(p.z2 + (size_t)i * 8, ec::sc_add(s2, ec::sc_mul(e, rr)));
 }
-__global__ void __launch_bounds__(64) pedersen_verify_kernel(int B, mpe_pedersen_proof p, uint8_t* __restrict__ ok) {
+__global__ void __launch_bounds__(64) MPE_EC_OCC pedersen_verify_kernel(int B, mpe_pedersen_proof p, uint8_t* __restrict__ ok) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::Aff G = ec::aff_gen(), H = ec::aff_h2();
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(64) pedersen_verify_kernel(int B, mpe_pedersen
   const ec::Jac rhs = ec::jac_add_aff(ec::jac_add_aff(ec::jac_mul(e, C), a1), a2);
   ok[i] = ec::jac_eq(lhs, rhs) ? 1 : 0;
 }
-__global__ void __launch_bounds__(64) heg_prove_kernel(int B, const uint32_t* __restrict__ x, const uint32_t* __restrict__ r,
+__global__ void __launch_bounds__(64) MPE_EC_OCC heg_prove_kernel(int B, const uint32_t* __restrict__ x, const uint32_t* __restrict__ r,
                                                        const uint32_t* __restrict__ s1_in, const uint32_t* __restrict__ s2_in,
                                                        mpe_heg_statement s, mpe_heg_proof p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64) heg_prove_kernel(int B, const uint32_t* __
   ec::u256_store(p.z1 + (size_t)i * 8, ec::u256_is_zero(xx) ? s1 : ec::sc_add(s1, ec::sc_mul(e, xx)));
   ec::u256_store(p.z2 + (size_t)i * 8, ec::sc_add(s2, ec::sc_mul(e, rr)));
 }
-__global__ void __launch_bounds__(64) heg_verify_kernel(int B, mpe_heg_statement s, mpe_heg_proof p, uint8_t* __restrict__ ok) {
+__global__ void __launch_bounds__(64) MPE_EC_OCC heg_verify_kernel(int B, mpe_heg_statement s, mpe_heg_proof p, uint8_t* __restrict__ ok) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::Aff G = ec::aff_load(s.G + (size_t)i * 16), H = ec::aff_load(s.H + (size_t)i * 16), Y = ec::aff_load(s.Y + (size_t)i * 16),
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64) heg_verify_kernel(int B, mpe_heg_statement
   const ec::Jac r2 = ec::jac_add_aff(ec::jac_mul(e, E), A3);
   ok[i] = (ec::jac_eq(l1, r1) && ec::jac_eq(l2, r2)) ? 1 : 0;
 }
-__global__ void __launch_bounds__(64) hash_commit_kernel(int B, const uint32_t* __restrict__ P, const uint32_t* __restrict__ blind,
+__global__ void __launch_bounds__(64) MPE_EC_OCC hash_commit_kernel(int B, const uint32_t* __restrict__ P, const uint32_t* __restrict__ blind,
                                                          uint32_t* __restrict__ com) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
