@@ -833,17 +833,39 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   // small batches: the encryption of k_i runs beside the first half of the range proofs (the proofs need c only for their
   // transcript hash); both composites draw from ONE workspace reservation
   const bool par = ctx->allow_par && (int)c.nAP <= ctx->par_items;
-  if (par && rc == MPE_OK) { rc = ws_reserve(ctx, ws_need_encrypt((int)c.nPI) + ws_need_alice_generate((int)c.nAP), st); if (rc == MPE_OK) ctx->ws_hold++; }
+  const size_t nXN = c.nPI + c.nAP;
+  if (par && rc == MPE_OK) {
+    rc = ws_reserve(ctx, ws_need_encrypt((int)c.nPI) + ws_need_alice_generate((int)c.nAP) + nXN * (64 + 128 + 1 + CRT_WS_WORDS) * 4 + 65536, st);
+    if (rc == MPE_OK) ctx->ws_hold++;
+  }
   const bool held = par && rc == MPE_OK;
+  // ... and every x^N the key holders compute this round (the randomness of MessageA.c, the beta of each range proof) goes
+  // through ONE launch: two concurrent launches of a few hundred waves each start on the same SIMDs of every CU and take
+  // 15 ms where one launch of 1 024 waves takes 11.5
+  const uint32_t *rn_pre = nullptr, *bn_pre = nullptr;
+  if (held && !getenv("MPE_NO_MERGE_XN")) {
+    uint32_t* xs = ws_array<uint32_t>(ctx, nXN * 64);
+    uint32_t* xn = ws_array<uint32_t>(ctx, nXN * 128);
+    int32_t* kx = ws_array<int32_t>(ctx, nXN);
+    if (!xs || !xn || !kx) rc = MPE_E_NOMEM;
+    if (rc == MPE_OK) {
+      (void)hipMemcpyAsync(xs, Z.r_a, c.nPI * 64 * 4, hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(xs + c.nPI * 64, Z.al_beta, c.nAP * 64 * 4, hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(kx, s->ix.kown_pi, c.nPI * 4, hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(kx + c.nPI, s->ix.kown_ap, c.nAP * 4, hipMemcpyDeviceToDevice, st);
+      rc = modexp_nn(ctx, K->prv, (int)nXN, key_selector(K->prv, kx), rows(xs, 64, nullptr, 64), key_rows(K->prv, K->prv->N, 64, kx), 64, true, xn, st, true);
+      rn_pre = xn; bn_pre = xn + c.nPI * 128;
+    }
+  }
   Fork g(ctx, st, 2, held, 2);
-  if (rc == MPE_OK) rc = paillier_encrypt(ctx, K->prv, (int)c.nPI, s->ix.kown_pi, s->k64, Z.r_a, s->c_a, true, g.s(1));      // MessageA.c
+  if (rc == MPE_OK) rc = paillier_encrypt(ctx, K->prv, (int)c.nPI, s->ix.kown_pi, s->k64, Z.r_a, s->c_a, true, g.s(1), rn_pre);      // MessageA.c
   gg_trace(st, "encrypt k", rc);
   Bump t(s->tmp);
   mpe_alice_proof ap{t.w(c.nAP * 64), t.w(c.nAP * 8), t.w(c.nAP * 64), t.w(c.nAP * 25), t.w(c.nAP * 89)};
   mpe_alice_nonces an{Z.al_alpha, Z.al_beta, Z.al_gamma, Z.al_rho};
   if (rc == MPE_OK)
     rc = alice_generate(ctx, K->prv, K->stm, (int)c.nAP, s->ix.kown_ap, s->ix.st_ap, rows(s->kq, 8, s->ix.pi_ap),
-                        rows(s->c_a, 128, s->ix.pi_ap), rows(Z.r_a, 64, s->ix.pi_ap), &an, &ap, st, &g);
+                        rows(s->c_a, 128, s->ix.pi_ap), rows(Z.r_a, 64, s->ix.pi_ap), &an, &ap, st, &g, bn_pre);
   else g.join();
   if (held) ctx->ws_hold--;
   gg_trace(st, "alice_generate", rc);

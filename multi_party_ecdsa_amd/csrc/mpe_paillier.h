@@ -341,14 +341,17 @@ static int modexp_nn2(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Ro
 static inline size_t ws_need_encrypt(int B) { return (size_t)B * (256 + CRT_WS_WORDS) * 4 + 8192; }
 static inline size_t ws_need_mul_add_enc(int B) { return (size_t)B * 128 * 4 * 3 + 8192; }
 
+// rn_pre: r^N mod N^2 already computed by the caller (a small-batch round merges every x^N of its key holders into one launch)
 static int paillier_encrypt(mpe_ctx* ctx, const mpe_paillier* pk, int B, const int32_t* key_idx, const uint32_t* d_m,
-                            const uint32_t* d_r, uint32_t* d_c, bool holder, hipStream_t st) {
+                            const uint32_t* d_r, uint32_t* d_c, bool holder, hipStream_t st, const uint32_t* rn_pre = nullptr) {
   MPE_TRY(ws_reserve(ctx, ws_need_encrypt(B), st));
   uint32_t* x = ws_array<uint32_t>(ctx, (size_t)B * 128);
   uint32_t* gm = ws_array<uint32_t>(ctx, (size_t)B * 128);
   // r^N mod N^2
-  MPE_TRY(modexp_nn(ctx, pk, B, key_selector(pk, key_idx), rows(d_r, 64, nullptr, 64), key_rows(pk, pk->N, 64, key_idx), 64,
-                    holder, x, st, true));
+  if (rn_pre) x = const_cast<uint32_t*>(rn_pre);
+  else
+    MPE_TRY(modexp_nn(ctx, pk, B, key_selector(pk, key_idx), rows(d_r, 64, nullptr, 64), key_rows(pk, pk->N, 64, key_idx), 64,
+                      holder, x, st, true));
   MPE_LAUNCH_1D(enc_gm_kernel, B, st, B, pk->nkeys, d_m, key_idx, pk->N, gm);
   return launch_modmul(ctx, pk->ms_nn, B, key_selector(pk, key_idx), rows(x, 128), rows(gm, 128), d_c, st);
 }
