@@ -716,9 +716,6 @@ struct mpe_gg20_session {
   int32_t *status = nullptr, *sig_recid = nullptr;
   int32_t *sub0_vi = nullptr, *sub4_pv = nullptr, *rdash_pv = nullptr;
   uint8_t *ok_vi = nullptr, *ok_pv = nullptr;
-  bool deferred1 = false, deferred5 = false;
-  bool defer = false;              // the pure verifications of rounds 1 / 5 run on background streams, joined in mpe_gg20_complete
-  mpe::gg::Slab defer_in4{};                // the M4 slab the deferred round-5 status reads
   int fault_step = 0;              // fault injection of the reference's tests (gg_2020/test.rs:282-289,458-465,679-686): 5 / 6 / 7
   uint32_t fault_mask = 0;         // signer ordinals that double their delta_i / sigma_i / s_i
   char* tmp = nullptr;             // per-round scratch (dense outputs of the composites before they are packed)
@@ -792,7 +789,7 @@ static size_t layout(mpe_gg20_session* s, char* base) {
   s->mq = m.w(c.nPI * 8); s->rq = m.w(c.nPI * 8); s->s_i = m.w(c.nPI * 8); s->bad = m.w(c.nPI * NR);
   s->sig_r = m.w(c.nPI * 8); s->sig_s = m.w(c.nPI * 8); s->miu = m.w(c.nPP * 64);
   s->status = m.i(c.nPI * NR); s->sig_recid = m.i(c.nPI);
-  // deferred verifications (lock-step composition of small batches): their index tables and verdicts outlive the round scratch
+  // index tables and verdicts of the two verification rounds
   s->sub0_vi = m.i(c.nVI); s->ok_vi = m.f(c.nVI); s->sub4_pv = m.i(c.nPV); s->rdash_pv = m.i(c.nPV); s->ok_pv = m.f(c.nPV);
   s->tmp_bytes = tmp_bytes_of(c);
   s->tmp = (char*)m.take(s->tmp_bytes);
@@ -893,27 +890,10 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   uint32_t *Bpk = t.w(c.nMB * 16), *BR = t.w(c.nMB * 16), *Bz = t.w(c.nMB * 8), *BTpk = t.w(c.nMB * 16), *BTR = t.w(c.nMB * 16), *BTz = t.w(c.nMB * 8);
   GG_LAUNCH(idx1_kernel, c.nVI, d, in0, sub0_vi);
   // small batches: the verification of the peers' range proofs and the construction of my MessageBs are independent
-  // (the reference runs them back to back inside MessageB::b) — two streams, one workspace reservation.  In the lock-step
-  // composition (s->defer) the verification is a pure check nothing downstream consumes: it runs on a background stream out
-  // of its own workspace and its verdict (status 101) is collected when the signature is completed.
+  // (the reference runs them back to back inside MessageB::b) — two streams, one workspace reservation
   const bool par = ctx->allow_par && (int)c.nVI <= ctx->par_items;
-  const bool defer = s->defer && par && ensure_aux(ctx);
-  if (par && !defer && rc == MPE_OK) { rc = ws_reserve(ctx, ws_need_alice_verify((int)c.nVI) + ws_need_mul_add_enc((int)c.nMB), st); if (rc == MPE_OK) ctx->ws_hold++; }
-  const bool held = par && !defer && rc == MPE_OK;
-  if (defer && rc == MPE_OK) {
-    (void)hipEventRecord(ctx->ev_fork[1], st);
-    (void)hipStreamWaitEvent(ctx->bg[0], ctx->ev_fork[1], 0);
-    const bool keep = ctx->allow_par;
-    ctx->allow_par = false;                                     // one stream: the auxiliary streams belong to the critical path
-    {
-      WsSwap sw(ctx, 0);
-      AliceProofRows pr{rows(d_in, SUB0, sub0_vi), rows(d_in + 64, SUB0, sub0_vi), rows(d_in + 72, SUB0, sub0_vi),
-                        rows(d_in + 136, SUB0, sub0_vi), rows(d_in + 161, SUB0, sub0_vi)};
-      rc = alice_verify(ctx, K->pub, K->stm, (int)c.nVI, s->ix.kpub_vi, s->ix.st_vi, rows(s->ca_all, 128, s->ix.ca_vi), pr, ok_vi, ctx->bg[0]);
-    }
-    ctx->allow_par = keep;
-    (void)hipEventRecord(ctx->ev_bg[0], ctx->bg[0]);
-  }
+  if (par && rc == MPE_OK) { rc = ws_reserve(ctx, ws_need_alice_verify((int)c.nVI) + ws_need_mul_add_enc((int)c.nMB), st); if (rc == MPE_OK) ctx->ws_hold++; }
+  const bool held = par && rc == MPE_OK;
   Fork g(ctx, st, 2, held, 2);
   {
     hipStream_t st2 = g.s(1);
@@ -928,7 +908,7 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
       hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, btq, Z.mb_nonce_bt, BTpk, BTR, BTz);   // :148
     }
   }
-  if (rc == MPE_OK && !defer) {      // every range proof of every peer, for both MessageB::b calls (mta/mod.rs:119-131), read in place
+  if (rc == MPE_OK) {      // every range proof of every peer, for both MessageB::b calls (mta/mod.rs:119-131), read in place
     AliceProofRows pr{rows(d_in, SUB0, sub0_vi), rows(d_in + 64, SUB0, sub0_vi), rows(d_in + 72, SUB0, sub0_vi),
                       rows(d_in + 136, SUB0, sub0_vi), rows(d_in + 161, SUB0, sub0_vi)};
     rc = alice_verify(ctx, K->pub, K->stm, (int)c.nVI, s->ix.kpub_vi, s->ix.st_vi, rows(s->ca_all, 128, s->ix.ca_vi), pr, ok_vi, st);
@@ -936,8 +916,7 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   gg_trace(st, "alice_verify", rc);
   g.join();
   if (held) ctx->ws_hold--;
-  if (!defer) GG_LAUNCH(status1_kernel, c.nPI, d, ok_vi, STAT(1), BADR(1));
-  s->deferred1 = defer;
+  GG_LAUNCH(status1_kernel, c.nPI, d, ok_vi, STAT(1), BADR(1));
   const int per = 2 * P1;
   PACK(c.nMB, per, per, 0, SUB1, 0, c_b, 128); PACK(c.nMB, per, per, 0, SUB1, 128, Bpk, 16); PACK(c.nMB, per, per, 0, SUB1, 144, BR, 16);
   PACK(c.nMB, per, per, 0, SUB1, 160, Bz, 8); PACK(c.nMB, per, per, 0, SUB1, 168, BTpk, 16); PACK(c.nMB, per, per, 0, SUB1, 184, BTR, 16);
@@ -1033,36 +1012,17 @@ static int round5(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   Heg heg{t.w(c.nPI * 16), t.w(c.nPI * 16), t.w(c.nPI * 16), t.w(c.nPI * 8), t.w(c.nPI * 8)};
   GG_LAUNCH(idx5_kernel, c.nPV, d, in4, sub4_pv, rdash_pv);
   const bool par = ctx->allow_par && (int)c.nPV <= ctx->par_items;
-  const bool defer = s->defer && par && ensure_aux(ctx);
   PdlProofRows pr{rows(d_in, SUB4, sub4_pv), rows(d_in + 64, SUB4, sub4_pv), rows(d_in + 80, SUB4, sub4_pv), rows(d_in + 208, SUB4, sub4_pv),
                   rows(d_in + 272, SUB4, sub4_pv), rows(d_in + 297, SUB4, sub4_pv), rows(d_in + 361, SUB4, sub4_pv)};
-  if (defer && rc == MPE_OK) {      // the lock-step composition: phase5_verify_pdl is a pure check -> background stream, own workspace
-    (void)hipEventRecord(ctx->ev_fork[1], st);
-    (void)hipStreamWaitEvent(ctx->bg[1], ctx->ev_fork[1], 0);
-    const bool keep = ctx->allow_par;
-    ctx->allow_par = false;
-    {
-      WsSwap sw(ctx, 1);
-      rc = pdl_verify(ctx, K->pub, K->stm, (int)c.nPV, s->ix.kpub_pv, s->ix.st_pv, rows(s->ca_all, 128, s->ix.ca_pv), rows(d_in, SUB4, rdash_pv),
-                      rows(s->R, 16, s->ix.pi_pv), pr, ok_pv, ctx->bg[1]);
-    }
-    ctx->allow_par = keep;
-    (void)hipEventRecord(ctx->ev_bg[1], ctx->bg[1]);
-    s->defer_in4 = in4;
-    if (rc == MPE_OK && c.nPI > 0)
-      hipLaunchKernelGGL(r5_prove_kernel, dim3(blocks_for((int)c.nPI, 64)), dim3(64), 0, st, d, s->R, s->sigma_i, s->lq, s->pedT, Z.heg_s1, Z.heg_s2, heg);
-  } else {
-    Fork g(ctx, st, 2, par, 2);
-    if (rc == MPE_OK && c.nPI > 0)
-      hipLaunchKernelGGL(r5_prove_kernel, dim3(blocks_for((int)c.nPI, 64)), dim3(64), 0, g.s(1), d, s->R, s->sigma_i, s->lq, s->pedT, Z.heg_s1, Z.heg_s2, heg);
-    if (rc == MPE_OK)      // phase5_verify_pdl for every prover (mine included), G = the VERIFIER's R (rounds.rs:546-558)
-      rc = pdl_verify(ctx, K->pub, K->stm, (int)c.nPV, s->ix.kpub_pv, s->ix.st_pv, rows(s->ca_all, 128, s->ix.ca_pv), rows(d_in, SUB4, rdash_pv),
-                      rows(s->R, 16, s->ix.pi_pv), pr, ok_pv, st);
-    gg_trace(st, "pdl_verify", rc);
-    g.join();
-    GG_LAUNCH(r5_status_kernel, c.nPI, d, in4, ok_pv, STAT(5), BADR(5));
-  }
-  s->deferred5 = defer;
+  Fork g(ctx, st, 2, par, 2);
+  if (rc == MPE_OK && c.nPI > 0)
+    hipLaunchKernelGGL(r5_prove_kernel, dim3(blocks_for((int)c.nPI, 64)), dim3(64), 0, g.s(1), d, s->R, s->sigma_i, s->lq, s->pedT, Z.heg_s1, Z.heg_s2, heg);
+  if (rc == MPE_OK)      // phase5_verify_pdl for every prover (mine included), G = the VERIFIER's R (rounds.rs:546-558)
+    rc = pdl_verify(ctx, K->pub, K->stm, (int)c.nPV, s->ix.kpub_pv, s->ix.st_pv, rows(s->ca_all, 128, s->ix.ca_pv), rows(d_in, SUB4, rdash_pv),
+                    rows(s->R, 16, s->ix.pi_pv), pr, ok_pv, st);
+  gg_trace(st, "pdl_verify", rc);
+  g.join();
+  GG_LAUNCH(r5_status_kernel, c.nPI, d, in4, ok_pv, STAT(5), BADR(5));
   PACK(c.nPI, 1, 1, 0, W5, 0, heg.S, 16); PACK(c.nPI, 1, 1, 0, W5, 16, heg.T, 16); PACK(c.nPI, 1, 1, 0, W5, 32, heg.A3, 16);
   PACK(c.nPI, 1, 1, 0, W5, 48, heg.z1, 8); PACK(c.nPI, 1, 1, 0, W5, 56, heg.z2, 8);
   return round_exit(s, rc, "gg20 round5");
@@ -1097,8 +1057,6 @@ static int complete(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_
   if (rc != MPE_OK) return rc;
   const Dim& d = s->d; const Counts c = counts_of(d);
   const Slab in6 = slab_of(s, d_in, h_off, 7);
-  if (s->deferred1) { (void)hipStreamWaitEvent(st, s->ctx->ev_bg[0], 0); GG_LAUNCH(status1_kernel, c.nPI, d, s->ok_vi, STAT(1), BADR(1)); }
-  if (s->deferred5) { (void)hipStreamWaitEvent(st, s->ctx->ev_bg[1], 0); GG_LAUNCH(r5_status_kernel, c.nPI, d, s->defer_in4, s->ok_pv, STAT(5), BADR(5)); }
   GG_LAUNCH(complete_kernel, c.nPI, d, in6, s->R, s->mq, s->rq, s->s_i, s->K->y, s->status, s->bad, s->sig_r, s->sig_s, s->sig_recid);
   return round_exit(s, rc, "gg20 complete");
 }
@@ -1308,19 +1266,10 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int3
   int maxw = 0;
   for (int r = 0; r < 8; ++r) { const int w = mpe::gg::msg_words(S, n, r); if (w > maxw) maxw = w; }
   const int Bc = batch < chunk ? batch : chunk;
-  // Experiment switch (MPE_DEFER=1): the lock-step composition takes the pure verifications of rounds 1 and 5 off the
-  // critical path (background streams, joined when the signature is completed).  They read the round-0 / round-4 messages in
-  // place, so every round keeps its own slab in that mode; otherwise two slabs alternate.  Measured on MI355X at 1024
-  // sessions it buys nothing (166.7 ms with, 163.5 ms without): the verifications already overlap my own MessageB
-  // construction through the per-round forks and those kernels fill the chip, so it stays off by default.
-  static const int out_rounds[7] = {0, 1, 2, 3, 4, 5, 7};
-  const bool defer = ctx->allow_par && (size_t)Bc * S * (S - 1) * (dedup_verify ? 1 : 2) * n <= (size_t)ctx->par_items && getenv("MPE_DEFER");
-  size_t slab_off[7], slab_words = 0;
-  for (int q = 0; q < 7; ++q) {
-    const size_t w = (size_t)S * Bc * (defer ? mpe::gg::msg_words(S, n, out_rounds[q]) : maxw);
-    if (defer) { slab_off[q] = slab_words; slab_words += w; }
-    else { slab_off[q] = (q & 1) ? w : 0; slab_words = 2 * w; }
-  }
+  // two message slabs alternate: round q writes slab q & 1 and reads the other
+  size_t slab_off[7];
+  const size_t slab_one = (size_t)S * Bc * maxw, slab_words = 2 * slab_one;
+  for (int q = 0; q < 7; ++q) slab_off[q] = (q & 1) ? slab_one : 0;
   const size_t res_words = (size_t)S * Bc * (1 + 8 + 8 + 1 + 16);
   const size_t need = (slab_words + res_words) * 4 + 4096;
   if (need > ctx->slab_bytes) {
@@ -1349,7 +1298,6 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int3
     mpe_gg20_session* s = nullptr;
     int rc = mpe_gg20_session_create(ctx, keys, B, S, local, d_keyset ? d_keyset + b0 : nullptr, &Z, dedup_verify, &s, stream);
     if (rc != MPE_OK) return rc;
-    s->defer = defer;
     rc = mpe::gg::round0(s, M[0], st);
     if (rc == MPE_OK) rc = mpe::gg::round1(s, M[0], nullptr, M[1], st);
     if (rc == MPE_OK) rc = mpe::gg::round2(s, M[1], nullptr, M[2], st);
@@ -1359,10 +1307,6 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int3
     if (rc == MPE_OK) rc = mpe::gg::round6(s, M[5], nullptr, st);
     if (rc == MPE_OK) rc = mpe::gg::round7(s, Z.msg, M[6], st);
     if (rc == MPE_OK) rc = mpe::gg::complete(s, M[6], nullptr, st);
-    if (rc != MPE_OK && defer) {       // never leave background work behind an error return
-      if (ctx->bg[0]) (void)hipStreamSynchronize(ctx->bg[0]);
-      if (ctx->bg[1]) (void)hipStreamSynchronize(ctx->bg[1]);
-    }
     if (rc == MPE_OK) rc = mpe_gg20_session_result(s, pst, nullptr, pr, ps, prec, pR, stream);
     if (rc == MPE_OK)
       hipLaunchKernelGGL(mpe::gg::sign_finish_kernel, dim3(mpe::blocks_for(B, 64)), dim3(64), 0, st, B, S, b0, pst, pr, ps, prec, pR, d_r, d_s,

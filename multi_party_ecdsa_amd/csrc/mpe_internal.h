@@ -26,7 +26,7 @@ struct mpe_ctx {
   int modexp_waves_per_cu = 8;    // 2 waves/SIMD: the montmul loop holds ~230 VGPRs and already issues back-to-back
   // window-table scratch, grown on demand: one buffer per stream slot (0 = the caller's stream, 1..3 = the auxiliary streams
   // on which small batches run independent launches concurrently)
-  void* tables[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // slots 4, 5: the background streams
+  void* tables[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // slot 0: the caller's stream, 1..3: the auxiliary streams
   size_t tables_bytes[6] = {0, 0, 0, 0, 0, 0};
   // Small batches are latency-bound (a launch lasts as long as ONE exponentiation): independent parts of a proof / a round
   // run on auxiliary streams, forked from and joined to the caller's stream with events (mpe::Fork).
@@ -34,10 +34,6 @@ struct mpe_ctx {
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
   // background streams of the lock-step composition (small batches): the pure verifications of rounds 1 and 5 run there,
   // each with its own workspace, and are joined when the signature is completed
-  hipStream_t bg[2] = {nullptr, nullptr};
-  hipEvent_t ev_bg[2] = {nullptr, nullptr};
-  void* ws_bg[2] = {nullptr, nullptr};
-  size_t ws_bg_bytes[2] = {0, 0};
   bool aux_ready = false;
   bool allow_par = true;          // MPE_NO_PAR=1 switches the concurrency off (A/B runs)
   int par_items = 32768;          // composites fork when they have at most this many items
@@ -120,14 +116,6 @@ int ws_reserve(mpe_ctx* ctx, size_t bytes, hipStream_t st);
 void* ws_alloc(mpe_ctx* ctx, size_t bytes);
 // window-table scratch of the stream slot `st` belongs to (nullptr + error set when it cannot be grown)
 uint32_t* tables_for(mpe_ctx* ctx, size_t need, hipStream_t st);
-
-// Runs what follows out of background workspace `which` (the composites allocate from ctx->ws): swapped back on destruction.
-struct WsSwap {
-  mpe_ctx* ctx; int which;
-  WsSwap(mpe_ctx* c, int w) : ctx(c), which(w) { swap(); ctx->ws_off = 0; }
-  ~WsSwap() { swap(); }
-  void swap() { std::swap(ctx->ws, ctx->ws_bg[which]); std::swap(ctx->ws_bytes, ctx->ws_bg_bytes[which]); }
-};
 bool ensure_aux(mpe_ctx* ctx);
 
 // fork / join of up to 3 concurrent branches: branch 0 stays on the caller's stream, branch i > 0 runs on an auxiliary stream.

@@ -37,7 +37,6 @@ void* ws_alloc(mpe_ctx* ctx, size_t bytes) {
 
 static int slot_of(const mpe_ctx* ctx, hipStream_t st) {
   for (int i = 0; i < 3; ++i) if (ctx->aux[i] && st == ctx->aux[i]) return i + 1;
-  for (int i = 0; i < 2; ++i) if (ctx->bg[i] && st == ctx->bg[i]) return 4 + i;
   return 0;
 }
 uint32_t* tables_for(mpe_ctx* ctx, size_t need, hipStream_t st) {
@@ -53,10 +52,6 @@ uint32_t* tables_for(mpe_ctx* ctx, size_t need, hipStream_t st) {
 bool ensure_aux(mpe_ctx* ctx) {
   if (ctx->aux_ready) return true;
   for (int i = 0; i < 3; ++i) if (hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) != hipSuccess) return false;
-  for (int i = 0; i < 2; ++i) {
-    if (hipStreamCreateWithFlags(&ctx->bg[i], hipStreamNonBlocking) != hipSuccess) return false;
-    if (hipEventCreateWithFlags(&ctx->ev_bg[i], hipEventDisableTiming) != hipSuccess) return false;
-  }
   for (int i = 0; i < 2; ++i) if (hipEventCreateWithFlags(&ctx->ev_fork[i], hipEventDisableTiming) != hipSuccess) return false;
   for (int i = 0; i < 3; ++i) if (hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) != hipSuccess) return false;
   ctx->aux_ready = true;
@@ -305,7 +300,6 @@ int mpe_ctx_wipe(mpe_ctx* ctx, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   for (int i = 0; i < 6; ++i) if (ctx->tables[i]) (void)hipMemsetAsync(ctx->tables[i], 0, ctx->tables_bytes[i], st);
   if (ctx->ws) (void)hipMemsetAsync(ctx->ws, 0, ctx->ws_bytes, st);
-  for (int i = 0; i < 2; ++i) if (ctx->ws_bg[i]) (void)hipMemsetAsync(ctx->ws_bg[i], 0, ctx->ws_bg_bytes[i], st);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("mpe_ctx_wipe", e); return MPE_E_HIP; }
   return MPE_OK;
@@ -328,9 +322,9 @@ int mpe_ctx_scratch_audit(mpe_ctx* ctx, uint64_t* nonzero_words, uint64_t* total
   if (e != hipSuccess) { mpe_set_error("hipMalloc(audit)", e); return MPE_E_NOMEM; }
   (void)hipMemsetAsync(d, 0, 8, st);
   const void* ptrs[11] = {ctx->tables[0], ctx->tables[1], ctx->tables[2], ctx->tables[3], ctx->tables[4], ctx->tables[5], ctx->ws,
-                          ctx->ws_bg[0], ctx->ws_bg[1], ctx->sess_buf, ctx->slab_buf};
+                          nullptr, nullptr, ctx->sess_buf, ctx->slab_buf};
   const size_t bytes[11] = {ctx->tables_bytes[0], ctx->tables_bytes[1], ctx->tables_bytes[2], ctx->tables_bytes[3], ctx->tables_bytes[4],
-                            ctx->tables_bytes[5], ctx->ws_bytes, ctx->ws_bg_bytes[0], ctx->ws_bg_bytes[1], ctx->sess_bytes, ctx->slab_bytes};
+                            ctx->tables_bytes[5], ctx->ws_bytes, 0, 0, ctx->sess_bytes, ctx->slab_bytes};
   uint64_t tot = 0;
   for (int i = 0; i < 11; ++i) {
     if (!ptrs[i] || !bytes[i]) continue;
@@ -357,9 +351,7 @@ int mpe_ctx_destroy(mpe_ctx* ctx) {
   if (ctx->slab_buf) (void)hipFree(ctx->slab_buf);
   for (int i = 0; i < 6; ++i) if (ctx->tables[i]) (void)hipFree(ctx->tables[i]);
   if (ctx->ws) (void)hipFree(ctx->ws);
-  for (int i = 0; i < 2; ++i) if (ctx->ws_bg[i]) (void)hipFree(ctx->ws_bg[i]);
   if (ctx->aux_ready) {
-    for (int i = 0; i < 2; ++i) { (void)hipStreamDestroy(ctx->bg[i]); (void)hipEventDestroy(ctx->ev_bg[i]); }
     for (int i = 0; i < 3; ++i) { (void)hipStreamDestroy(ctx->aux[i]); (void)hipEventDestroy(ctx->ev_join[i]); }
     for (int i = 0; i < 2; ++i) (void)hipEventDestroy(ctx->ev_fork[i]);
   }
