@@ -409,6 +409,15 @@ int mpe_correct_key_verify(mpe_ctx* ctx, int batch, const uint32_t* d_N, const u
  *   N >= 2^128 and odd, gcd(g, N) = gcd(ni, N) = 1, e = H(x, g, N, ni), x == g^y ni^e mod N.  d_y [batch][73]. */
 int mpe_composite_dlog_verify(mpe_ctx* ctx, int batch, const uint32_t* d_N, const uint32_t* d_g, const uint32_t* d_ni,
                               const uint32_t* d_x, const uint32_t* d_y, uint8_t* d_ok, void* stream);
+/* The PROVE side of the same two proofs (what a party sends in keygen round 1, party_i.rs:219-258); key generation itself
+ * (prime search) stays on the host.
+ * `NiCorrectKeyProof::proof(dk, SALT_STRING)` for EVERY key of a private key set: d_sigma [nkeys][11][64],
+ *   sigma_i = rho_i^(N^-1 mod phi(N)) mod N. */
+int mpe_correct_key_prove(mpe_ctx* ctx, const mpe_paillier* sk, uint32_t* d_sigma, void* stream);
+/* `CompositeDLogProof::prove(DLogStatement{N, g, ni}, secret)` with the sampled r (< 2^512, d_r [batch][16]) as input:
+ *   x = g^r mod N, e = H(x, g, N, ni), y = r + e secret.  d_secret [batch][64]; outputs d_x [batch][64], d_y [batch][73]. */
+int mpe_composite_dlog_prove(mpe_ctx* ctx, int batch, const uint32_t* d_N, const uint32_t* d_g, const uint32_t* d_ni,
+                             const uint32_t* d_secret, const uint32_t* d_r, uint32_t* d_x, uint32_t* d_y, void* stream);
 /* Feldman VSS (curv `VerifiableSS`): d_commits [batch][t1][16] (t1 = t + 1 coefficient commitments), d_index [batch]
  * (1-based party index).  validate_share (party_i.rs:337-340): share G == sum_k index^k C_k;
  * get_point_commitment (party_i.rs:383-385): that sum. */

@@ -74,6 +74,8 @@ def _load():
         "mpe_modmul": (ip, [vp, vp, ip, i32p, u32p, u32p, u32p, vp]),
         "mpe_lindell_partial_sig": (ip, [vp, vp, ip, i32p, u32p, u32p, u32p, u32p, u32p, u32p, u32p, u32p, vp]),
         "mpe_lindell_sign": (ip, [vp, vp, ip, i32p, u32p, u32p, u32p, u32p, u32p, i32p, vp]),
+        "mpe_correct_key_prove": (ip, [vp, vp, u32p, vp]),
+        "mpe_composite_dlog_prove": (ip, [vp, ip, u32p, u32p, u32p, u32p, u32p, u32p, u32p, vp]),
         "mpe_paillier_open": (ip, [vp, vp, ip, i32p, u32p, u32p, u32p, vp]),
         "mpe_lindell_pdl_proof": (ip, [vp, vp, vp, ip, i32p, i32p, u32p, u32p, u32p, vp, u32p, vp, vp]),
         "mpe_lindell_pdl_verify": (ip, [vp, vp, ip, i32p, u32p, u32p, u32p, u32p, u32p, u32p, u32p, u32p, u32p, u32p, vp, vp, vp]),
@@ -167,7 +169,7 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_dlog_prove", "mpe_dlog_verify", "mpe_statements_create", "mpe_statements_destroy",
             "mpe_alice_generate", "mpe_alice_verify", "mpe_pdl_prove", "mpe_pdl_verify", "mpe_gg20_keys_create",
             "mpe_gg20_keys_destroy", "mpe_gg20_sign", "mpe_bob_generate", "mpe_bob_verify", "mpe_mta_message_a",
-            "mpe_mta_message_b", "mpe_mta_verify_get_alpha", "mpe_lindell_partial_sig", "mpe_lindell_sign", "mpe_lindell_pdl_proof", "mpe_lindell_pdl_verify", "mpe_paillier_open",
+            "mpe_mta_message_b", "mpe_mta_verify_get_alpha", "mpe_lindell_partial_sig", "mpe_lindell_sign", "mpe_lindell_pdl_proof", "mpe_lindell_pdl_verify", "mpe_paillier_open", "mpe_correct_key_prove", "mpe_composite_dlog_prove",
             "mpe_gg20_keys_fb_window_bits", "mpe_gg20_msg_words", "mpe_gg20_session_create", "mpe_gg20_session_destroy",
             "mpe_gg20_round0", "mpe_gg20_round1", "mpe_gg20_round2", "mpe_gg20_round3", "mpe_gg20_round4", "mpe_gg20_round5",
             "mpe_gg20_round6", "mpe_gg20_round7", "mpe_gg20_complete", "mpe_gg20_session_result", "mpe_pedersen_prove",

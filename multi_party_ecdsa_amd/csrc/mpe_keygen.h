@@ -3,7 +3,8 @@
 //   :260-320  NiCorrectKeyProof::verify (11 x sigma^N mod N), CompositeDLogProof::verify x2, the hash commitment
 //   :322-367  VerifiableSS::validate_share (Feldman), commitments[0] == y_i
 //   :405-438  DLogProof::verify + get_commitments_to_xi
-// (Prime generation and the proofs' PROVE side stay on the host: sequential and data dependent)
+// and the PROVE side of the two zk-paillier proofs (party_i.rs:219-258: NiCorrectKeyProof::proof, CompositeDLogProof::prove) —
+// modexp-shaped as well.  Prime generation stays on the host: sequential and data dependent, SURVEY.md §2 row 7.
 // The two zk-paillier 0.4.3 proofs are un-vendored: their definitions are recalled.  Every key is its own
 // modulus here (one modulus per item), so the moduli set is built per call.  Included by mpe_lib.hip.
 #pragma once
@@ -118,10 +119,96 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC vss_kernel(int B, int t1, const
   if (out) ec::aff_store(out + (size_t)b * 16, ec::jac_to_aff(acc));
 }
 
+// rho = (hiT + lo_red) mod N, one (key, i) per lane
+__global__ void ck_rho_sum_kernel(int n, const uint32_t* __restrict__ N, const uint32_t* __restrict__ hiT, const uint32_t* __restrict__ lo_red,
+                                  uint32_t* __restrict__ rho) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  uint32_t a[65], c[64], m[64];
+  sm::copy(m, N + (size_t)(g / CK_M2) * 64, 64);
+  sm::copy(a, hiT + (size_t)g * 64, 64);
+  sm::copy(c, lo_red + (size_t)g * 64, 64);
+  a[64] = sm::add(a, 64, a, 64, c, 64);
+  if (sm::cmp(a, 65, m, 64) >= 0) sm::sub(a, 65, a, 65, m, 64);
+  sm::copy(rho + (size_t)g * 64, a, 64);
+}
+// y = r + e secret (plain integers: r 16 words, e 8, secret 64 -> 73 words)
+__global__ void cd_y_kernel(int B, const uint32_t* __restrict__ r, const uint32_t* __restrict__ e, const uint32_t* __restrict__ secret,
+                            uint32_t* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  uint32_t t[73];
+  sm::mul(t, e + (size_t)i * 8, 8, secret + (size_t)i * 64, 64);          // 72 words
+  t[72] = 0;
+  sm::add(t, 73, t, 73, r + (size_t)i * 16, 16);
+  sm::copy(y + (size_t)i * 73, t, 73);
+}
 }  // namespace kg
 }  // namespace mpe
 
 extern "C" {
+
+// NiCorrectKeyProof::proof(dk, SALT_STRING) for every key of a private key set: sigma_i = rho_i^(N^-1 mod phi(N)) mod N, i < 11
+int mpe_correct_key_prove(mpe_ctx* ctx, const mpe_paillier* sk, uint32_t* d_sigma, void* stream) {
+  using namespace mpe;
+  if (!ctx || !sk || !d_sigma) return MPE_E_ARG;
+  if (!sk->has_private) { mpe_set_error_msg("mpe_correct_key_prove: key set has no private part"); return MPE_E_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const int nk = sk->nkeys, M = kg::CK_M2, n = nk * M;
+  MPE_TRY(ws_reserve(ctx, ((size_t)n * (64 * 4 + 8 + 1) + (size_t)nk * 64 * 5 + modinv_ws_words(sk->ms_n, nk)) * 4 + 65536, st));
+  int32_t* key_of = ws_array<int32_t>(ctx, n);
+  uint32_t *lo = ws_array<uint32_t>(ctx, (size_t)n * 64), *hi = ws_array<uint32_t>(ctx, (size_t)n * 8), *hiT = ws_array<uint32_t>(ctx, (size_t)n * 64),
+           *lor = ws_array<uint32_t>(ctx, (size_t)n * 64), *rho = ws_array<uint32_t>(ctx, (size_t)n * 64), *two = ws_array<uint32_t>(ctx, (size_t)nk * 64),
+           *T = ws_array<uint32_t>(ctx, (size_t)nk * 64), *phi = ws_array<uint32_t>(ctx, (size_t)nk * 64), *u = ws_array<uint32_t>(ctx, (size_t)nk * 64),
+           *d = ws_array<uint32_t>(ctx, (size_t)nk * 64);
+  uint8_t* ok = ws_array<uint8_t>(ctx, ((size_t)nk + 255) & ~(size_t)255);
+  if (!key_of || !lo || !hi || !hiT || !lor || !rho || !two || !T || !phi || !u || !d || !ok) { mpe_set_error_msg("correct_key_prove: workspace"); return MPE_E_NOMEM; }
+  const Rows ksel{nullptr, key_of, 0, 0};
+  hipLaunchKernelGGL(kg::iota_div_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, n, M, key_of);
+  hipLaunchKernelGGL(kg::ck_rho_kernel, dim3(blocks_for(n, 64)), dim3(64), 0, st, nk, sk->N, lo, hi);
+  // rho = acc mod N with acc = hi 2^2048 + lo, as the verifier derives it
+  hipLaunchKernelGGL(kg::fill_words_kernel, dim3(blocks_for(nk * 64, 256)), dim3(256), 0, st, nk, 64, 1024, two);
+  MPE_TRY(launch_modmul(ctx, sk->ms_n, nk, rows(nullptr, 1), rows(two, 64), rows(two, 64), T, st));
+  MPE_TRY(launch_modmul(ctx, sk->ms_n, n, ksel, rows(hi, 8, nullptr, 8), rows(T, 64, key_of), hiT, st));
+  MPE_TRY(launch_modmul(ctx, sk->ms_n, n, ksel, rows(lo, 64), rows(sk->ms_n->one_words, 0, nullptr, 1), lor, st));
+  hipLaunchKernelGGL(kg::ck_rho_sum_kernel, dim3(blocks_for(n, 64)), dim3(64), 0, st, n, sk->N, hiT, lor, rho);
+  // d = N^-1 mod phi(N) (the same derivation as mpe_paillier_open), sigma = rho^d mod N
+  MPE_LAUNCH_1D(bl::open_phi_kernel, nk, st, nk, sk->N, sk->pq32, phi);
+  MPE_TRY(launch_modinv(ctx, sk->ms_n, nk, rows(nullptr, 1), rows(phi, 64), u, ok, st));
+  MPE_LAUNCH_1D(bl::open_d_kernel, nk, st, nk, sk->N, phi, u, ok, d);
+  const int rc = launch_modexp(ctx, sk->ms_n, n, ksel, rows(rho, 64), no_rows(), rows(d, 64, key_of), 64, d_sigma, st);
+  (void)hipMemsetAsync(d, 0, (size_t)nk * 64 * 4, st);
+  (void)hipMemsetAsync(phi, 0, (size_t)nk * 64 * 4, st);
+  (void)hipMemsetAsync(u, 0, (size_t)nk * 64 * 4, st);
+  return rc;
+}
+
+// CompositeDLogProof::prove(statement{N, g, ni}, secret) with the sampled r (< 2^512) as input: x = g^r mod N, e = H(x, g, N, ni),
+// y = r + e secret.  d_secret [batch][64], d_r [batch][16]; outputs d_x [batch][64], d_y [batch][73].
+int mpe_composite_dlog_prove(mpe_ctx* ctx, int batch, const uint32_t* d_N, const uint32_t* d_g, const uint32_t* d_ni, const uint32_t* d_secret,
+                             const uint32_t* d_r, uint32_t* d_x, uint32_t* d_y, void* stream) {
+  using namespace mpe;
+  if (!ctx || !d_N || !d_g || !d_ni || !d_secret || !d_r || !d_x || !d_y || batch < 0) return MPE_E_ARG;
+  if (batch == 0) return MPE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  mpe_modset* ms = nullptr;
+  MPE_TRY(modset_create_dev(ctx, 2048, batch, d_N, &ms, st));
+  int rc = ws_reserve(ctx, (size_t)batch * (64 + 8) * 4 + 65536, st);
+  if (rc != MPE_OK) { mpe_modset_destroy(ms); return rc; }
+  Seq q{ctx, st, batch};
+  uint32_t* e = q.words(8);
+  rc = launch_modexp(ctx, ms, batch, rows(nullptr, 1), rows(d_g, 64), no_rows(), rows(d_r, 16), 16, d_x, st);
+  q.rc = rc;
+  HashDesc d;
+  d.n = 4;
+  d.f[0] = hf(rows(d_x, 64), 64); d.f[1] = hf(rows(d_g, 64), 64); d.f[2] = hf(rows(d_N, 64), 64); d.f[3] = hf(rows(d_ni, 64), 64);
+  q.hash(d, e);
+  if (q.rc == MPE_OK) hipLaunchKernelGGL(kg::cd_y_kernel, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, d_r, e, d_secret, d_y);
+  rc = q.finish("mpe_composite_dlog_prove");
+  (void)hipStreamSynchronize(st);
+  mpe_modset_destroy(ms);
+  return rc;
+}
 
 int mpe_correct_key_verify(mpe_ctx* ctx, int batch, const uint32_t* d_N, const uint32_t* d_sigma, uint8_t* d_ok, void* stream) {
   if (!ctx || !d_N || !d_sigma || !d_ok || batch < 0) return MPE_E_ARG;

@@ -544,6 +544,21 @@ def composite_dlog_verify(ctx, d_N, d_g, d_ni, d_x, d_y):
     return ok
 
 
+def correct_key_prove(ctx, sk):
+    """`NiCorrectKeyProof::proof` for every key of a private key set: sigma [nkeys, 11, 64]"""
+    sigma = torch.zeros((sk.nkeys, 11, 64), dtype=torch.int32, device=ctx.device)
+    N_.check(N_.lib.mpe_correct_key_prove(ctx.h, sk.h, _ptr(sigma), ctx.stream()), "mpe_correct_key_prove")
+    return sigma
+
+
+def composite_dlog_prove(ctx, d_N, d_g, d_ni, d_secret, d_r):
+    B = d_N.shape[0]
+    x, y = _new(ctx, B, 64), _new(ctx, B, 73)
+    N_.check(N_.lib.mpe_composite_dlog_prove(ctx.h, B, _ptr(d_N), _ptr(d_g), _ptr(d_ni), _ptr(d_secret), _ptr(d_r), _ptr(x), _ptr(y), ctx.stream()),
+             "mpe_composite_dlog_prove")
+    return x, y
+
+
 def vss_validate_share(ctx, t1, d_commits, d_share, d_index):
     ok = _flags(ctx, d_share.shape[0])
     N_.check(N_.lib.mpe_vss_validate_share(ctx.h, d_share.shape[0], t1, _ptr(d_commits), _ptr(d_share), _ptr(d_index), _ptr(ok), ctx.stream()),

@@ -54,3 +54,28 @@ def test_feldman_vs_oracle(gpu_ctx):
     orc.lib.orc_vss_point_commitment(B * n, t + 1, orc._p(commits), orc._p(index), orc._p(out))
     gp = E.vss_point_commitment(gpu_ctx, t + 1, _dev(gpu_ctx, commits), _dev(gpu_ctx, index)).cpu().numpy().view(np.uint32)
     assert np.array_equal(gp, out)
+
+
+def test_keygen_prove_side_vs_oracle(gpu_ctx, keys):
+    """NiCorrectKeyProof::proof and CompositeDLogProof::prove (party_i.rs:219-258): the bytes the oracle's prove side gives,
+    and they verify on the GPU"""
+    from multi_party_ecdsa_amd import engine as E
+    import pyref
+    N, want_sigma = KF.correct_key_case(keys)
+    sk = E.PaillierKeys(gpu_ctx, p=[k.p for k in keys], q=[k.q for k in keys])
+    sigma = E.correct_key_prove(gpu_ctx, sk)
+    gpu_ctx.sync()
+    got = sigma.cpu().numpy().view(np.uint32).reshape(-1, 64)
+    assert np.array_equal(got, want_sigma)
+    assert list(E.correct_key_verify(gpu_ctx, _dev(gpu_ctx, N), sigma.reshape(-1, 64)).cpu().numpy()) == [1] * len(keys)
+    # composite dlog: same statements, secrets and nonces as the fixture -> same (x, y)
+    r = F.Rng("cdlog")
+    Ns, g, sec, nonce = [], [], [], []
+    for k in keys:
+        Ns.append(k.Nt); g.append(k.h1); sec.append(r.below(k.Nt >> 2)); nonce.append(r.bits(512))
+    Nw, gw, nw, wx, wy = KF.composite_dlog_case(keys)
+    x, y = E.composite_dlog_prove(gpu_ctx, _dev(gpu_ctx, Nw), _dev(gpu_ctx, gw), _dev(gpu_ctx, nw), _dev(gpu_ctx, F.words(sec, 64)),
+                                  _dev(gpu_ctx, F.words(nonce, 16)))
+    gpu_ctx.sync()
+    assert np.array_equal(x.cpu().numpy().view(np.uint32), wx) and np.array_equal(y.cpu().numpy().view(np.uint32), wy)
+    assert list(E.composite_dlog_verify(gpu_ctx, _dev(gpu_ctx, Nw), _dev(gpu_ctx, gw), _dev(gpu_ctx, nw), x, y).cpu().numpy()) == [1] * len(keys)
