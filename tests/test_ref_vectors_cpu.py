@@ -80,6 +80,22 @@ def test_vectors_from_the_real_crates():
                                                           F.point_words([_pt(dd["h2"])]), F.point_words([W.point_from_json(dp["a1"])]),
                                                           F.point_words([W.point_from_json(dp["a2"])]), F.words([W.scalar_from_json(dp["z"])], 8), okb)])
         assert okb[0] == 1, "ECDDHProof of the crate rejected"
+        # zk-paillier keygen proofs and kzen-paillier's Open (when the dump has them: schema additions of round 2)
+        if "correct_key" in c:
+            sig = [W.bigint_from_json(v) for v in c["correct_key"]["proof"]["sigma_vec"]]
+            assert len(sig) == 11
+            okb2 = np.zeros(1, dtype=np.uint8)
+            orc.lib.orc_correct_key_verify(1, orc._p(F.words([N], 64)), orc._p(F.words(sig, 64)), orc._p(okb2))
+            assert okb2[0] == 1, "NiCorrectKeyProof of the crate rejected: salt / mask generation differ"
+        if "composite_dlog" in c and c["composite_dlog"]["verifies"]:
+            cdp = c["composite_dlog"]["proof"]
+            orc.lib.orc_composite_dlog_verify(1, orc._p(F.words([Nt], 64)), orc._p(F.words([h1], 64)), orc._p(F.words([h2], 64)),
+                                              orc._p(F.words([W.bigint_from_json(cdp["x"])], 64)), orc._p(F.words([W.bigint_from_json(cdp["y"])], 73)), orc._p(okb))
+            assert okb[0] == 1, "CompositeDLogProof of the crate rejected"
+        if "open" in c:
+            om, orr = orc.u32((1, 64)), orc.u32((1, 64))
+            orc.lib.orc_paillier_open(1, 1, orc._p(F.words([p], 32)), orc._p(F.words([q], 32)), None, orc._p(F.words([H(c["open"]["c"])], 128)), orc._p(om), orc._p(orr))
+            assert F.ints(om)[0] == H(c["open"]["m"]) and F.ints(orr)[0] == H(c["open"]["r"])
         # HashCommitment, base_point2
         hc = c["hash_commitment"]
         com = orc.u32((1, 8))
