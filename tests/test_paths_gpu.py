@@ -1,0 +1,28 @@
+"""The code paths LARGE batches take (one stream, 18 limbs per lane, one-item-per-lane EC round kernels, two-base verifier
+ladders), exercised on small parity cases through a context pinned to them (conftest.gpu_ctx_serial): the ordinary GPU tests
+run tiny batches and therefore the small-batch variants (forks, 9-limb lanes, lane-group kernels, split inversions)."""
+import numpy as np
+import pytest
+
+import fixtures as F
+import gg20_fixture as G
+import pyref
+from test_gg20_gpu import TAMPERS, _run, tamper_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("t,n,signers,B,kw", [(1, 3, [0, 2], 5, {}), (2, 5, [0, 2, 3, 4], 2, {}), (1, 3, [1, 2], 3, {"dedup_verify": True})])
+def test_sign_matches_oracle_on_the_large_batch_paths(gpu_ctx_serial, keys, t, n, signers, B, kw):
+    lk, nonces, (r, s, recid, status, R) = _run(gpu_ctx_serial, keys, t, n, signers, B, f"serial-{t}-{n}-{signers}", **kw)
+    wr, ws, wrecid, wR, wstatus = G.oracle_sign(lk, nonces, B)
+    assert list(status) == [0] * B == list(wstatus)
+    assert np.array_equal(r.view(np.uint32), wr) and np.array_equal(s.view(np.uint32), ws) and list(recid) == list(wrecid)
+    assert np.array_equal(R.view(np.uint32), wR)
+    for b in range(B):
+        assert pyref.ecdsa_verify(lk["y"], F.ints(nonces["msg"][b:b + 1])[0], F.ints(wr[b:b + 1])[0], F.ints(ws[b:b + 1])[0])
+
+
+@pytest.mark.parametrize("name,rnd,sender,word,kind", TAMPERS, ids=[t[0] for t in TAMPERS])
+def test_tamper_matrix_on_the_large_batch_paths(gpu_ctx_serial, keys, name, rnd, sender, word, kind):
+    tamper_case(gpu_ctx_serial, keys, name, rnd, sender, word, kind)
