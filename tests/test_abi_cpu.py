@@ -47,3 +47,33 @@ def test_word_conversion_roundtrip():
     from multi_party_ecdsa_amd.words import ints_to_words, words_to_ints
     vals = [0, 1, (1 << 2048) - 1, 0x1234567890abcdef << 1000]
     assert words_to_ints(ints_to_words(vals, 64)) == vals
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/mpecdsa_hip.h compiles as C11 with -Wall -Werror -pedantic and a C program that binds the library sees the
+    version string and the argument checks — the boundary is a C ABI, not a C++ or Python one"""
+    import subprocess
+    lib = _build_if_missing()
+    src = tmp_path / "abi.c"
+    src.write_text('''
+#include <stdio.h>
+#include <string.h>
+#include "mpecdsa_hip.h"
+int main(void) {
+  mpe_alice_proof ap; mpe_pdl_proof pp; mpe_gg20_nonces nn; mpe_gg20_blame6_in b6;
+  memset(&ap, 0, sizeof ap); memset(&pp, 0, sizeof pp); memset(&nn, 0, sizeof nn); memset(&b6, 0, sizeof b6);
+  if (!strstr(mpe_version(), "gfx950")) return 1;
+  if (mpe_ctx_create(NULL, 0) != MPE_E_ARG) return 2;
+  if (mpe_gg20_msg_words(2, 3, 0) != 256 * 4 || mpe_gg20_msg_words(2, 3, 4) != 900 || mpe_gg20_msg_words(2, 3, 6) != 0) return 3;
+  if (mpe_gg20_round1(NULL, NULL, NULL, NULL, NULL) != MPE_E_ARG) return 4;
+  if (mpe_paillier_open(NULL, NULL, 1, NULL, NULL, NULL, NULL, NULL) != MPE_E_ARG) return 5;
+  printf("%s\\n", mpe_version());
+  return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           lib, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    assert "gfx950" in out.stdout
