@@ -210,3 +210,72 @@ def bodies_to_record(rnd, bodies, S, n, sender):
 def signature_to_json(r, s, recid):
     """`SignatureRecid` (party_i.rs:131-135)"""
     return {"r": scalar_to_json(r), "s": scalar_to_json(s), "recid": int(recid)}
+
+
+# ---- LocalKey (state_machine/keygen/rounds.rs:311-322) -------------------------------------------------------------------
+# What `gg20_keygen` writes to local-share{i}.json (examples/gg20_keygen.rs:52-56) and `gg20_signing` reads back: the serde
+# form of LocalKey<Secp256k1>{paillier_dk{p,q}, pk_vec, keys_linear{y,x_i}, paillier_key_vec[{n}], y_sum_s,
+# h1_h2_n_tilde_vec[{N,g,ni}], vss_scheme{parameters{threshold,share_count},commitments}, i, t, n}.  `i` is 1-based.
+def local_key_to_json(i, t, n, p, q, x_i, y, pk_vec, N_vec, stm_vec, vss_commitments=None):
+    """i: 1-based party index; stm_vec: [(N~, h1, h2)] per party; vss_commitments: t+1 points (optional: signing never reads them)"""
+    return {
+        "paillier_dk": {"p": bigint_to_json(p), "q": bigint_to_json(q)},
+        "pk_vec": [point_to_json(P_) for P_ in pk_vec],
+        "keys_linear": {"y": point_to_json(y), "x_i": scalar_to_json(x_i)},
+        "paillier_key_vec": [{"n": bigint_to_json(N_)} for N_ in N_vec],
+        "y_sum_s": point_to_json(y),
+        "h1_h2_n_tilde_vec": [{"N": bigint_to_json(a), "g": bigint_to_json(b), "ni": bigint_to_json(c)} for a, b, c in stm_vec],
+        "vss_scheme": {"parameters": {"threshold": t, "share_count": n}, "commitments": [point_to_json(c) for c in (vss_commitments or [])]},
+        "i": i, "t": t, "n": n,
+    }
+
+
+def local_key_from_json(obj):
+    """-> dict(i (1-based), t, n, p, q, x_i, y, pk_vec, N_vec, stm_vec) of Python ints / (x, y) points"""
+    if isinstance(obj, (str, bytes)):
+        obj = json.loads(obj)
+    ek = lambda e: bigint_from_json(e["n"] if isinstance(e, dict) else e)
+    out = dict(i=int(obj["i"]), t=int(obj["t"]), n=int(obj["n"]), p=bigint_from_json(obj["paillier_dk"]["p"]),
+               q=bigint_from_json(obj["paillier_dk"]["q"]), x_i=scalar_from_json(obj["keys_linear"]["x_i"]),
+               y=point_from_json(obj["y_sum_s"]), pk_vec=[point_from_json(v) for v in obj["pk_vec"]],
+               N_vec=[ek(e) for e in obj["paillier_key_vec"]],
+               stm_vec=[(bigint_from_json(s["N"]), bigint_from_json(s["g"]), bigint_from_json(s["ni"])) for s in obj["h1_h2_n_tilde_vec"]])
+    n = out["n"]
+    if not (len(out["pk_vec"]) == len(out["N_vec"]) == len(out["stm_vec"]) == n and 1 <= out["i"] <= n and out["t"] < n):
+        raise ValueError("LocalKey: inconsistent vector lengths / indices")
+    if out["p"] * out["q"] != out["N_vec"][out["i"] - 1]:
+        raise ValueError("LocalKey: paillier_dk does not match paillier_key_vec[i-1]")
+    return out
+
+
+def _words(vals, nwords):
+    out = np.zeros((len(vals), nwords), dtype=np.uint32)
+    for r, v in enumerate(vals):
+        _put(out[r], 0, nwords, v)
+    return out
+
+
+def _pt_words(pts):
+    out = np.zeros((len(pts), 16), dtype=np.uint32)
+    for r, pt in enumerate(pts):
+        _put_pt(out[r], 0, pt)
+    return out
+
+
+def local_keys_to_arrays(local_keys):
+    """One or more LocalKeys of ONE wallet (one per party this process acts for; dicts from local_key_from_json) -> the arrays of
+    mpe_gg20_keys_create / engine.Gg20Keys plus `own` (0-based party indices whose secrets are present).  Rows of x, p, q of the
+    parties that are not present stay zero: build the key object with own=... and they never reach the device."""
+    lk0 = local_keys[0]
+    n, t = lk0["n"], lk0["t"]
+    for lk in local_keys[1:]:
+        same = all(lk[f] == lk0[f] for f in ("t", "n", "y", "pk_vec", "N_vec", "stm_vec"))
+        if not same:
+            raise ValueError("LocalKeys of different wallets")
+    xs, ps, qs = [0] * n, [0] * n, [0] * n
+    for lk in local_keys:
+        xs[lk["i"] - 1], ps[lk["i"] - 1], qs[lk["i"] - 1] = lk["x_i"], lk["p"], lk["q"]
+    arrays = dict(x=_words(xs, 8), p=_words(ps, 32), q=_words(qs, 32), N=_words(lk0["N_vec"], 64),
+                  Nt=_words([s[0] for s in lk0["stm_vec"]], 64), h1=_words([s[1] for s in lk0["stm_vec"]], 64),
+                  h2=_words([s[2] for s in lk0["stm_vec"]], 64), y=_pt_words([lk0["y"]]), X=_pt_words(lk0["pk_vec"]))
+    return dict(t=t, n=n, arrays=arrays, own=sorted(lk["i"] - 1 for lk in local_keys))

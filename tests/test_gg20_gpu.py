@@ -122,6 +122,39 @@ def test_one_party_per_object_holds_only_its_own_secrets(gpu_ctx, keys, t, n, si
         assert np.array_equal(res["r"][0], want["r"]) and np.array_equal(res["s"][0], want["s"]) and list(res["recid"][0]) == list(want["recid"])
 
 
+def test_parties_built_from_their_local_key_json(gpu_ctx, keys):
+    """Each party's key object comes from its own LocalKey JSON (what the reference's gg20_keygen leaves on disk,
+    keygen/rounds.rs:311-322) through multi_party_ecdsa_amd.wire: nobody sees another party's x_i, p, q; signatures = oracle's"""
+    import json
+    from multi_party_ecdsa_amd import engine as E, wire as W
+    t, n, signers, B = 1, 3, [0, 2], 2
+    lk = G.make_local_keys(keys, t, n, signers)
+    nonces = G.make_nonces(lk, B, seed="local-key-json")
+    want = G.oracle_sign_ex(lk, nonces, B)
+    A = lk["arrays"]
+    xs, X, y = F.ints(A["x"]), F.points(A["X"]), F.points(A["y"])[0]
+    Ns, stm = [k.N for k in lk["keys"]], [(k.Nt, k.h1, k.h2) for k in lk["keys"]]
+    parties = []
+    for i, party in enumerate(signers):
+        doc = json.dumps(W.local_key_to_json(party + 1, t, n, lk["keys"][party].p, lk["keys"][party].q, xs[party], y, X, Ns, stm))
+        ka = W.local_keys_to_arrays([W.local_key_from_json(doc)])
+        gk = E.Gg20Keys(gpu_ctx, ka["t"], ka["n"], signers, ka["arrays"], own=ka["own"])
+
+        class One:
+            def __init__(self, gk, i):
+                self.gk, self.p = gk, GpuParty(gpu_ctx, gk, B, [i], G.party_nonces(nonces, lk, i))
+            def round(self, rnd, slab):
+                o = self.p.round(rnd, slab)
+                return None if o is None else o[0]
+        parties.append(One(gk, i))
+    slabs = G.run_rounds(parties, nonces["msg"])
+    for rnd in G.ROUNDS:
+        assert np.array_equal(slabs[rnd], want["slabs"][rnd]), f"round {rnd}"
+    for p_ in parties:
+        res = p_.p.result()
+        assert not res["status"].any() and np.array_equal(res["r"][0], want["r"]) and np.array_equal(res["s"][0], want["s"])
+
+
 def _other_point(words16):
     """a different VALID point: the double of the given one"""
     P = F.points(words16.reshape(1, 16))[0]

@@ -147,3 +147,35 @@ def test_primitive_decoders_accept_the_other_known_forms():
     assert W.scalar_from_json(W.scalar_to_json(77)) == 77
     with pytest.raises(ValueError):
         W.point_from_json({"curve": "secp256k1", "point": "02" + "%064x" % 5})          # x = 5 is not on the curve
+
+
+def test_local_key_json_roundtrip_and_key_arrays(keys):
+    """LocalKey (keygen/rounds.rs:311-322) as `gg20_keygen` stores it -> the arrays mpe_gg20_keys_create takes: identical to the
+    fixture's for every party, own-secret rows only, and inconsistent shares are refused"""
+    t, n = 2, 5
+    lk = G.make_local_keys(keys, t, n, [0, 2, 4])
+    A = lk["arrays"]
+    xs, X, y = F.ints(A["x"]), F.points(A["X"]), F.points(A["y"])[0]
+    Ns = [k.N for k in lk["keys"]]
+    stm = [(k.Nt, k.h1, k.h2) for k in lk["keys"]]
+    docs = [json.dumps(W.local_key_to_json(i + 1, t, n, lk["keys"][i].p, lk["keys"][i].q, xs[i], y, X, Ns, stm)) for i in range(n)]
+    parsed = [W.local_key_from_json(d) for d in docs]
+    assert [p_["i"] for p_ in parsed] == [1, 2, 3, 4, 5] and parsed[3]["x_i"] == xs[3]
+    one = W.local_keys_to_arrays([parsed[2]])                                   # the deployment: one party per process
+    assert one["own"] == [2] and (one["t"], one["n"]) == (t, n)
+    for f in ("Nt", "h1", "h2", "y", "X"):
+        assert np.array_equal(one["arrays"][f], A[f]), f
+    assert np.array_equal(one["arrays"]["N"], F.words(Ns, 64))
+    assert np.array_equal(one["arrays"]["x"][2], A["x"][2]) and not one["arrays"]["x"][[0, 1, 3, 4]].any()
+    assert np.array_equal(one["arrays"]["p"][2], A["p"][2]) and not one["arrays"]["q"][[0, 1, 3, 4]].any()
+    every = W.local_keys_to_arrays(parsed)                                      # the Simulation harness: all of them
+    for f in ("x", "p", "q"):
+        assert np.array_equal(every["arrays"][f], A[f]), f
+    bad = json.loads(docs[1])
+    bad["paillier_dk"]["p"] = W.bigint_to_json(lk["keys"][0].p)
+    with pytest.raises(ValueError):
+        W.local_key_from_json(bad)
+    other = W.local_key_from_json(docs[0])
+    other["y"] = X[0]
+    with pytest.raises(ValueError):
+        W.local_keys_to_arrays([parsed[1], other])
