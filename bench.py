@@ -497,6 +497,19 @@ def main():
                  "rccl_time_share": comm_total / (elapsed if elapsed > 0 else 1.0), "placement": ps.placement,
                  "pairs_per_rank": ps.per_rank}
 
+    # north_star asks for Paillier ops/s at 1, 2, 4 and 8 GPUs too: at N > 1 every rank runs BASELINE config 2 at the same time
+    # (after the timed signing region) and the rates add up; at N = 1 it is the c2 section below
+    node_paillier = None
+    if distributed and (world > 1 or os.environ.get("MPE_BENCH_FORCE_NODE_PAILLIER")) and args.mode == "session" and not args.no_configs:
+        dist.barrier()
+        p2 = paillier_config2(ctx, E, keys, F)
+        agg = torch.tensor([p2["ops_per_s"], p2["encrypt_per_s"], p2["decrypt_per_s"], p2["modexp4096_2048_per_s"]], dtype=torch.float64, device=dev)
+        lo = agg.clone()
+        dist.all_reduce(agg)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        node_paillier = {"n_gpus": world, "batch_per_gpu": p2["batch"], "ops_per_s": float(agg[0]), "encrypt_per_s": float(agg[1]),
+                         "decrypt_per_s": float(agg[2]), "modexp4096_2048_per_s": float(agg[3]), "slowest_gpu_ops_per_s": float(lo[0]),
+                         "roundtrip_ok": bool(p2["roundtrip_ok"]), "note": "sum over ranks of BASELINE config 2 run concurrently on every GPU"}
     if rank == 0:
         r, s, recid, status = [o.cpu().numpy() for o in out]
         all_signed = bool((status == 0).all())
@@ -607,6 +620,8 @@ def main():
             res["configs"] = cfg
             res["paillier"] = cfg["c2_paillier_65536"]
             res["section_seconds"] = took
+        if node_paillier is not None:
+            res["paillier"] = node_paillier
         print(json.dumps(res))
     if distributed:
         dist.destroy_process_group()
