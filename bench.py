@@ -152,7 +152,7 @@ def cpu_baseline_gg20(lk, host_nonces, sample, threads):
     return sample / dt, r, s, recid, status
 
 
-def paillier_config2(ctx, E, keys, F, steps=1):
+def paillier_config2(ctx, E, keys, F, steps=1, oracle_threads=0):
     """BASELINE config 2: 65 536 encrypt + 65 536 decrypt, 16 keys.  Encryption is timed twice: by the key holder
     (p, q known: the p^2 | q^2 path) and by a peer that only has N (the plain exponentiation r^N mod N^2 — the
     'Paillier-2048 modexp/s' of the metric, with its kernel time from the HIP-event records)."""
@@ -186,7 +186,31 @@ def paillier_config2(ctx, E, keys, F, steps=1):
     recs = ctx.prof_collect()
     ctx.prof_enable(False)
     kern = float(np.mean([r["ms"] for r in recs if r["kind"] in (0, 3) and r["bits"] == 4096])) * 1e-3
-    return {"ops_per_s": 2 * B / (t_enc + t_dec), "batch": B,
+    cpu = {}
+    if oracle_threads:
+        # the reference CPU path beside it: the GMP oracle (reference formulas over mpz_powm) on a bounded prefix, bit-exact check included
+        import orc
+        per = 24
+        n_cpu = per * oracle_threads
+        Nw, pw, qw = F.words([k.N for k in keys], 64), F.words([k.p for k in keys], 32), F.words([k.q for k in keys], 32)
+        hm, hr, hi = (np.ascontiguousarray(t_[:n_cpu].cpu().numpy().view(np.uint32)) for t_ in (m, rr, idx))
+        hi = hi.view(np.int32).reshape(-1)
+        outs = {}
+
+        def run(j):
+            sl = slice(j * per, (j + 1) * per)
+            cc = orc.paillier_encrypt(Nw, hm[sl], hr[sl], list(hi[sl]))
+            outs[j] = (cc, orc.paillier_decrypt(pw, qw, cc, list(hi[sl])))
+        t0 = time.time()
+        with ThreadPoolExecutor(oracle_threads) as ex:
+            list(ex.map(run, range(oracle_threads)))
+        dt = time.time() - t0
+        gc, gb = c[:n_cpu].cpu().numpy().view(np.uint32), back[:n_cpu].cpu().numpy().view(np.uint32)
+        same = all(np.array_equal(outs[j][0], gc[j * per:(j + 1) * per]) and np.array_equal(outs[j][1], gb[j * per:(j + 1) * per])
+                   for j in range(oracle_threads))
+        cpu = {"oracle_ops_per_s": 2 * n_cpu / dt, "oracle_threads": oracle_threads, "oracle_sample": n_cpu, "parity_prefix": n_cpu,
+               "parity_vs_oracle_on_prefix": bool(same)}
+    return {**cpu, "ops_per_s": 2 * B / (t_enc + t_dec), "batch": B,
             "roundtrip_ok": bool(torch.equal(back, m)), "holder_equals_public_ciphertext": bool(torch.equal(c, c2)),
             "encrypt_per_s": B / t_enc, "decrypt_per_s": B / t_dec, "encrypt_public_key_per_s": B / t_pub,
             "modexp4096_2048_per_s": B / kern,
@@ -610,7 +634,7 @@ def main():
                 t_ = time.perf_counter()
                 cfg[name] = fn()
                 took[name] = round(time.perf_counter() - t_, 2)
-            section("c2_paillier_65536", lambda: paillier_config2(ctx, E, keys, F))
+            section("c2_paillier_65536", lambda: paillier_config2(ctx, E, keys, F, oracle_threads=0 if args.no_cpu_baseline else threads))
             section("c3_ec_pdl_262144", lambda: config3(ctx, E, keys, F, oracle=not args.no_cpu_baseline))
             section("c4_literal_1024", lambda: gg20_config(ctx, E, G, keys, 1, 3, 1024, 4, gen, parity_sample=0 if args.no_cpu_baseline else 32))
             section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 16))
