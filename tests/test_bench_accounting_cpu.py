@@ -1,0 +1,70 @@
+"""bench.py's roofline arithmetic, checked without a GPU: the MAC models against their closed forms and SURVEY.md's table, and
+the committed bench lines (profiles/r02/*.json) against the models — `frac`, `achieved`, `executed_mac_per_launch` and the
+per-launch batch sizes must be the numbers the formulas give for the workload the line names."""
+import importlib.util
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("mpe_bench", os.path.join(ROOT, "bench.py"))
+B = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(B)
+
+
+def test_mac_models():
+    assert B.mac(64) == 2 * 64 * 64 + 64 and B.mac(128) == 2 * 128 * 128 + 128
+    # "Paillier-2048 modexp" = modexp(128, 2048) = 8.474e7 MACs; a (1, 3) signature = 4.17e9
+    assert abs(B.modexp_macs(128, 2048) - 8.474e7) / 8.474e7 < 1e-3
+    assert abs(B.sig_macs(2, 3) - 4.174e9) / 4.174e9 < 1e-3
+    # SURVEY.md 8a-work exponent-bit totals for (S, n) = (2, 3) and (3, 5)
+    bits = lambda S, n: (n * 6400 + 2 * (S - 1) * n * 3842 + 2 * (S - 1) * 2048 + (S - 1) * 6400 + S * (S - 1) * 3843,
+                         2048 + n * 2048 + 2 * (S - 1) * (n * 2304 + 2304) + (S - 1) * 2816 + S * (S - 1) * 3074)
+    assert bits(2, 3) == (60434, 35588) and bits(3, 5) == (152890, 91660)
+    # the pair engine: 6-bit windows for a 2048-bit exponent: 342 windows, 2046 squarings, 64 + 342 + 2 multiplications
+    assert B.window_bits(64) == 6 and B.window_bits(8) == 4 and B.window_bits(25) == 5
+    assert B.pair_modexp_macs(64, 64) == (2 * 2046 + 2.5 * (64 + 342 + 2)) * B.mac(64)
+    # a second (256-bit) base on the same ladder adds its 16-entry table, 64 window multiplications and one conversion
+    assert B.pair_modexp_macs(64, 64, 8) - B.pair_modexp_macs(64, 64) == 2.5 * (16 + 64 + 1) * B.mac(64)
+    # the pair arithmetic needs half the MACs of the textbook exponentiation on the 4096-bit integers ...
+    assert 0.49 < B.pair_modexp_macs(64, 64) / B.modexp_macs(128, 2048) < 0.51
+    assert B.PEAK_MAC_PER_S == 16 * 4 * 256 * 2.4e9
+
+
+@pytest.mark.parametrize("name", ["bench_gg20_default.json", "bench_gg20_driver_flags.json"])
+def test_committed_bench_lines_follow_the_models(name):
+    path = os.path.join(ROOT, "profiles", "r02", name)
+    if not os.path.exists(path):
+        pytest.skip("no committed bench line")
+    b = json.loads(open(path).read().strip().splitlines()[-1])
+    rf, cfg = b["roofline"], b["config"]
+    assert b["unit"] == "signatures/s" and b["higher_is_better"] and b["scaling"] == "weak" and b["vs_baseline"] is None
+    sessions, S, n = cfg["sessions_per_gpu"], cfg["signers"], cfg["n"]
+    # value = sessions * steps / time
+    assert abs(b["value"] - sessions * b["n_gpus"] / (b["ms_per_step"] * 1e-3)) / b["value"] < 1e-6
+    # the three launches modulo N^2 of a faithful (S, n) = (2, 3) step: AliceProof::verify for both MessageB::b calls
+    # (2 (S-1) n per party, two-base), MessageB's ciphertext (2 (S-1), two-base), PDLwSlackProof::verify (S (S-1) per local party set, two-base)
+    per_session = S * (2 * (S - 1) * n + 2 * (S - 1)) + S * S * (S - 1)
+    model = sessions * per_session * B.pair_modexp_macs(64, 64, 8) / 3
+    assert abs(rf["executed_mac_per_launch"] - model) / model < 1e-9
+    assert rf["launches"] == 3 * b["steps"]
+    achieved = rf["executed_mac_per_launch"] / (rf["avg_kernel_ms"] * 1e-3) / 1e12
+    assert abs(achieved - rf["achieved"]) / achieved < 1e-6
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] <= 1
+    assert abs(rf["peak"] - B.PEAK_MAC_PER_S / 1e12) < 1e-9
+    assert rf["alg_unit_frac"] > 1 > rf["frac"]                       # the SURVEY unit over-counts; the executed figure is the utilisation
+    # ... and ~0.46x on the launch mix, where the short second exponent of a two-base ladder rides on the long one's squarings
+    assert 0.44 < rf["executed_mac_per_launch"] / rf["alg_unit_mac_per_launch"] < 0.48
+    if "issue_ceiling" in rf:
+        ic = rf["issue_ceiling"]
+        assert abs(ic["kernel_valu_T_lane_ops_per_s"] - rf["achieved"] * 1.2558 * 740 / 648) < 1e-6
+        assert 0.9 < ic["frac_of_measured"] < 1.15
+    # the dominant kernel's time is part of the step
+    assert rf["avg_kernel_ms"] * 3 <= b["ms_per_step"] and 0.5 < rf["kernel_time_share_of_step"] < 0.8
+    cb = b["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and b["parity_vs_oracle_on_sample"] is True
+    c = b["configs"]
+    assert c["c2_paillier_65536"]["roundtrip_ok"] and c["c2_paillier_65536"]["holder_equals_public_ciphertext"]
+    assert c["c3_ec_pdl_262144"]["accept_rate"] == 1.0 and c["c3_ec_pdl_262144"]["corrupted_1pct_all_rejected"]
+    assert c["c4_literal_1024"]["all_sessions_signed"] and c["c5_share_t2n5_8192"]["all_sessions_signed"]
