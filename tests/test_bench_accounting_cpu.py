@@ -68,3 +68,24 @@ def test_committed_bench_lines_follow_the_models(name):
     assert c["c2_paillier_65536"]["roundtrip_ok"] and c["c2_paillier_65536"]["holder_equals_public_ciphertext"]
     assert c["c3_ec_pdl_262144"]["accept_rate"] == 1.0 and c["c3_ec_pdl_262144"]["corrupted_1pct_all_rejected"]
     assert c["c4_literal_1024"]["all_sessions_signed"] and c["c5_share_t2n5_8192"]["all_sessions_signed"]
+
+
+def test_rocprof_artifacts_agree_with_the_bench_line():
+    """profiles/r02: the rocprofv3 --stats average of the dominant kernel vs the HIP-event average in the bench line (different
+    boxes: within 3 %), and the PMC traffic figure the bench line quotes"""
+    import csv
+    d = os.path.join(ROOT, "profiles", "r02")
+    if not os.path.exists(os.path.join(d, "gg20_bench_kernel_stats.csv")):
+        pytest.skip("no committed profile")
+    rows = list(csv.DictReader(open(os.path.join(d, "gg20_bench_kernel_stats.csv"))))
+    dom = [r for r in rows if "pair_modexp_kernel<mpe::Cfg<2048, 29, 18, 4>" in r["Name"]][0]
+    assert rows[0] is dom                                               # it IS the kernel that dominates the step
+    b = json.loads(open(os.path.join(d, "bench_gg20_default.json")).read().strip().splitlines()[-1])
+    assert abs(float(dom["AverageNs"]) / 1e6 - b["roofline"]["avg_kernel_ms"]) / b["roofline"]["avg_kernel_ms"] < 0.03
+    assert 0.6 < float(dom["Percentage"]) / 100 < 0.72
+    pmc = json.load(open(os.path.join(d, "pmc_traffic.json")))
+    k = [v for n, v in pmc["kernels"].items() if "pair_modexp_kernel" in n and "2048, 29, 18, 4" in n][0]
+    assert abs(b["roofline"]["traffic"] - k["hbm_bytes_per_launch"]) / k["hbm_bytes_per_launch"] < 0.01
+    assert pmc["sessions"] == b["config"]["sessions_per_gpu"]
+    # HBM is not the bound: the kernel moves ~2 % of 8 TB/s
+    assert k["hbm_GB_per_s"] < 0.05 * 8000
