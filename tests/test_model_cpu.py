@@ -27,3 +27,14 @@ def test_montmul_model_bounds():
     for bits, w, l, tpi in ((4096, 29, 18, 8), (2048, 29, 18, 4)):
         st = mm.run(bits, w, l, tpi, iters=2)
         assert st["maxcol"] < 1 << 64
+
+
+def test_pair_model_with_71_steps_for_2048_bit_moduli():
+    """The variant DESIGN.md section 9 lists as a next step — 71 CIOS steps instead of 72 when the modulus has 2048 bits
+    (R = 2^(29 * 71) still exceeds 4 N and the multipliers' 72nd limb is zero) — is correct and within the same bounds in the
+    model: right residues modulo N^2, columns below 2^64, lazy limbs below 2^29 + 2^12, the z0 >= N corner.  Not in the kernel."""
+    pm = _load("pair_model")
+    for stress in (False, True):
+        st = pm.run(2048, 4, 2, 5, stress, steps=71)
+        assert st["maxcol"] < 1 << 64
+        assert st["maxlimb"] < (1 << 29) + (1 << 12)

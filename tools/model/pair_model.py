@@ -23,12 +23,18 @@ def from_limbs(l):
     return sum(v << (W * i) for i, v in enumerate(l))
 
 
-def cios(c0, streams, n, n0inv, TPI, stats, keep_m=False):
-    """One CIOS pass.  c0: K initial column values (lane-distributed as limbs), streams: [(a_limbs, b_limbs), ...]."""
+def cios(c0, streams, n, n0inv, TPI, stats, keep_m=False, steps=None):
+    """One CIOS pass.  c0: K initial column values (lane-distributed as limbs), streams: [(a_limbs, b_limbs), ...].
+    steps: outer steps = limbs of the multipliers that are read (default K).  With steps = K - 1 the pass divides by
+    2^(W (K-1)) instead of 2^(W K): legitimate whenever the multipliers' top limb is zero and 2^(W (K-1)) > 4 N (the
+    2048-bit moduli: 71 x 29 = 2059 bits) -- the "71 steps" variant DESIGN.md section 9 lists, studied here before any kernel work."""
     K = L * TPI
+    steps = K if steps is None else steps
     c = [[c0[t * L + i] for i in range(L)] for t in range(TPI)]
     ms = []
-    for j in range(K):
+    for a, b in streams:
+        assert all(v == 0 for v in b[steps:]), "multiplier limbs beyond the steps must be zero"
+    for j in range(steps):
         for a, b in streams:
             for t in range(TPI):
                 for i in range(L):
@@ -67,17 +73,19 @@ def cios(c0, streams, n, n0inv, TPI, stats, keep_m=False):
     return (r, ms) if keep_m else r
 
 
-def pairmul(X, Y, n, n0inv, kc, TPI, stats, sq):
-    """X, Y: pairs of limb lists (lazy).  Returns the pair of limb lists of X * Y * R^-1 (mod N^2)."""
+def pairmul(X, Y, n, n0inv, kc, TPI, stats, sq, steps=None):
+    """X, Y: pairs of limb lists (lazy).  Returns the pair of limb lists of X * Y * R^-1 (mod N^2), R = 2^(W steps)."""
     K = L * TPI
+    steps = K if steps is None else steps
     x0, x1 = X
     y0, y1 = Y
-    u, ms = cios([0] * K, [(x0, y0)], n, n0inv, TPI, stats, keep_m=True)
-    pre = [kc[i] + MASK - ms[i] for i in range(K)]           # K_c + (R - 1 - m), limb-wise non-negative
+    u, ms = cios([0] * K, [(x0, y0)], n, n0inv, TPI, stats, keep_m=True, steps=steps)
+    # K_c + (R - 1 - m), limb-wise non-negative: R - 1 is all-ones over `steps` limbs, the digits beyond do not exist
+    pre = [kc[i] + (MASK - ms[i] if i < steps else 0) for i in range(K)]
     if sq:
-        z1 = cios(pre, [(x1, [2 * v for v in x0])], n, n0inv, TPI, stats)
+        z1 = cios(pre, [(x1, [2 * v for v in x0])], n, n0inv, TPI, stats, steps=steps)
     else:
-        z1 = cios(pre, [(x0, y1), (x1, y0)], n, n0inv, TPI, stats)
+        z1 = cios(pre, [(x0, y1), (x1, y0)], n, n0inv, TPI, stats, steps=steps)
     return u, z1
 
 
@@ -94,10 +102,12 @@ def finish(Z, N):
     return z0 + z1 * N
 
 
-def run(bits, TPI, iters, seed, stress):
+def run(bits, TPI, iters, seed, stress, steps=None):
     rnd = random.Random(seed)
     K = L * TPI
-    R = 1 << (W * K)
+    steps = K if steps is None else steps
+    R = 1 << (W * steps)
+    assert R > 4 << bits, "the Montgomery radix must exceed 4 N"
     while True:
         N = rnd.getrandbits(bits) | (1 << (bits - 1)) | 1
         if stress:
@@ -127,17 +137,17 @@ def run(bits, TPI, iters, seed, stress):
             Y = (to_limbs(rnd.randrange(2 * N), K), to_limbs(rnd.randrange(2 * N), K))
         for sq in (True, False):
             Yp = X if sq else Y
-            Z = pairmul(X, Yp, n, n0inv, kc, TPI, stats, sq)
+            Z = pairmul(X, Yp, n, n0inv, kc, TPI, stats, sq, steps)
             assert val(Z) == val(X) * val(Yp) * Rinv % NN, "wrong residue"
             assert from_limbs(Z[0]) < 2 * N + (1 << (bits - 30)) and from_limbs(Z[1]) < 2 * N + (1 << (bits - 30)), "value bound"
     # the corner the final normalisation has to get right: the base N itself (x0 = N is the lazy form of 0)
     one = (to_limbs(1, K), to_limbs(0, K))
     XN = (to_limbs(N, K), to_limbs(0, K))                                    # the plain pair of the value N
     r2 = (R * R) % NN
-    F_N = pairmul(XN, (to_limbs(r2 % N, K), to_limbs(r2 // N, K)), n, n0inv, kc, TPI, stats, False)   # its form
-    back = pairmul(F_N, one, n, n0inv, kc, TPI, stats, False)
+    F_N = pairmul(XN, (to_limbs(r2 % N, K), to_limbs(r2 // N, K)), n, n0inv, kc, TPI, stats, False, steps)   # its form
+    back = pairmul(F_N, one, n, n0inv, kc, TPI, stats, False, steps)
     assert finish(back, N) == N, "z0 >= N must carry into z1"
-    assert finish(pairmul(pairmul(F_N, F_N, n, n0inv, kc, TPI, stats, True), one, n, n0inv, kc, TPI, stats, False), N) == 0
+    assert finish(pairmul(pairmul(F_N, F_N, n, n0inv, kc, TPI, stats, True, steps), one, n, n0inv, kc, TPI, stats, False, steps), N) == 0
     assert stats['maxcol'] < (1 << 64), "column overflow"
     assert stats['maxlimb'] <= lazy, "lazy limb bound"
     return stats
@@ -150,3 +160,7 @@ if __name__ == '__main__':
             st = run(bits, TPI, 3 if bits == 2048 else 6, 7, stress)
             print(f"bits={bits} TPI={TPI} {'stress' if stress else 'random'}: max column 2^{math.log2(st['maxcol']):.3f}, "
                   f"max lazy limb 2^{math.log2(st['maxlimb']):.4f}")
+    for stress in (False, True):                    # the 71-step variant for 2048-bit moduli (not in the kernel yet)
+        st = run(2048, 4, 3, 11, stress, steps=71)
+        print(f"bits=2048 TPI=4 steps=71 {'stress' if stress else 'random'}: max column 2^{math.log2(st['maxcol']):.3f}, "
+              f"max lazy limb 2^{math.log2(st['maxlimb']):.4f}")
