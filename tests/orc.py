@@ -17,8 +17,12 @@ def build():
 
 
 def load():
-    if not os.path.exists(LIB):
+    # `make` is a no-op when the library is newer than its sources and rebuilds a stale one (a kept work tree)
+    try:
         build()
+    except (OSError, subprocess.CalledProcessError):
+        if not os.path.exists(LIB):
+            raise
     return C.CDLL(LIB)
 
 
