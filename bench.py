@@ -152,7 +152,7 @@ def cpu_baseline_gg20(lk, host_nonces, sample, threads):
     return sample / dt, r, s, recid, status
 
 
-def paillier_config2(ctx, E, keys, F, steps=1, oracle_threads=0):
+def paillier_config2(ctx, E, keys, F, steps=1, oracle_threads=0, oracle_items=0):
     """BASELINE config 2: 65 536 encrypt + 65 536 decrypt, 16 keys.  Encryption is timed twice: by the key holder
     (p, q known: the p^2 | q^2 path) and by a peer that only has N (the plain exponentiation r^N mod N^2 — the
     'Paillier-2048 modexp/s' of the metric, with its kernel time from the HIP-event records)."""
@@ -190,8 +190,9 @@ def paillier_config2(ctx, E, keys, F, steps=1, oracle_threads=0):
     if oracle_threads:
         # the reference CPU path beside it: the GMP oracle (reference formulas over mpz_powm) on a bounded prefix, bit-exact check included
         import orc
-        per = 24
-        n_cpu = per * oracle_threads
+        per = max(1, (oracle_items + oracle_threads - 1) // oracle_threads) if oracle_items else 24   # tests ask for all 65 536
+        n_cpu = min(B, per * oracle_threads)
+        oracle_threads = (n_cpu + per - 1) // per
         Nw, pw, qw = F.words([k.N for k in keys], 64), F.words([k.p for k in keys], 32), F.words([k.q for k in keys], 32)
         hm, hr, hi = (np.ascontiguousarray(t_[:n_cpu].cpu().numpy().view(np.uint32)) for t_ in (m, rr, idx))
         hi = hi.view(np.int32).reshape(-1)
@@ -297,10 +298,23 @@ def config3(ctx, E, keys, F, B=262144, prefix=4096, threads=None, oracle=True):
                     "oracle_threads": threads})
         # the EC results of the prefix against the oracle too
         out["ec_parity_prefix"] = bool(np.array_equal(hin["G"], orc.ec_mul_base(h(kb))) and np.array_equal(hin["Q"], orc.ec_mul(hin["x"], hin["G"])))
+        import ossl
+        out["ec_parity_prefix_openssl"] = bool(np.array_equal(hin["G"], ossl.ec_mul(h(kb), threads=threads)) and
+                                               np.array_equal(hin["Q"], ossl.ec_mul(hin["x"], hin["G"], threads=threads)))
     return out
 
 
-def gg20_config(ctx, E, G, keys, t, n, B, steps, gen, parity_sample=0, threads=None):
+def openssl_verify_all(y_words, msg, r, s, threads):
+    """every signature of a batch under the wallet's public key with OpenSSL's ECDSA_do_verify (tests/ossl.py): the independent
+    third-party check the reference runs with libsecp256k1 (gg_2020/test.rs:711-748).  After the timed region, on host copies."""
+    import ossl
+    u = lambda a: np.ascontiguousarray(a if isinstance(a, np.ndarray) else a.cpu().numpy()).view(np.uint32)
+    t0 = time.time()
+    ok = ossl.ecdsa_verify(u(y_words), u(msg), u(r), u(s), threads=threads)
+    return {"openssl_verified": int(ok.sum()), "of": int(ok.shape[0]), "openssl": ossl.version(), "seconds": round(time.time() - t0, 2)}
+
+
+def gg20_config(ctx, E, G, keys, t, n, B, steps, gen, parity_sample=0, threads=None, openssl=False):
     """one more GG20 shape on this GPU: sessions/s over `steps` passes of B sessions, optional parity sample vs the oracle"""
     dev = ctx.device
     signers = list(range(t + 1))
@@ -325,6 +339,8 @@ def gg20_config(ctx, E, G, keys, t, n, B, steps, gen, parity_sample=0, threads=N
         res["parity_vs_oracle_on_sample"] = bool((wstatus == 0).all() and np.array_equal(r[:parity_sample].view(np.uint32), wr) and
                                                  np.array_equal(s[:parity_sample].view(np.uint32), ws) and np.array_equal(recid[:parity_sample], wrecid))
         res["oracle_signatures_per_s"] = v
+    if openssl:
+        res["openssl"] = openssl_verify_all(lk["arrays"]["y"][0], nonces["msg"], r, s, threads or min(host_cores()[0], 64))
     gk.close()
     return res
 
@@ -391,20 +407,41 @@ def lindell_section(ctx, E, keys, F, cpu=True):
 
 
 class GpuRoundEngine:
-    """dist.PartySharded engine over mpe_gg20_roundN: one session object per session block, local = the parties this rank hosts"""
+    """dist.PartySharded engine over mpe_gg20_roundN: one session object per session block, local = the parties this rank
+    hosts; the object lives across steps (mpe_gg20_session_rearm) and writes its records into the gather buffer"""
+    writes_in_place = True
 
     def __init__(self, ctx, E, gk, Bblk, parties, nonces):
         self.sess = E.Gg20Session(ctx, gk, Bblk, parties, nonces)
         self.keep = nonces
 
-    def round(self, rnd, d_in, in_off, msg):
-        return self.sess.round(rnd, d_in=d_in, in_off=in_off, msg=msg)
+    def rearm(self):
+        self.sess.rearm(self.keep)
+
+    def round(self, rnd, d_in, in_off, msg, out=None):
+        return self.sess.round(rnd, d_in=d_in, in_off=in_off, msg=msg, out=out)
 
     def result(self):
         return self.sess.result()
 
     def close(self):
         self.sess.close()
+
+
+def respawn_under_torchrun(n, argv):
+    """`python bench.py --gpus N` with no torch.distributed environment: this process becomes the launcher of N ranks, one
+    per GPU (the same command line the driver would use), and exits with their status; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -420,16 +457,44 @@ def main():
     ap.add_argument("--mode", choices=["session", "party"], default="session", help="multi-GPU layout (SURVEY.md 8e A / B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the c2 / c3 / c4 / c5 / Lindell sections")
+    ap.add_argument("--share-device", action="store_true",
+                    help="all ranks use cuda:0 and talk through gloo (host-staged): exercises the N>1 code path on a 1-GPU box; "
+                         "the ranks time-share one GPU, so `value` says nothing about a node")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        # no launcher around us: become it (N ranks, one per GPU, RCCL over xGMI)
+        sys.exit(respawn_under_torchrun(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; reporting n_gpus = {world}", file=sys.stderr)
     distributed = world > 1 or "RANK" in os.environ          # under torch.distributed.run even one rank goes through RCCL
+    share = args.share_device or bool(os.environ.get("MPE_BENCH_SHARE_DEVICE"))
+    if not share and distributed and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible); "
+                         "--share-device runs all ranks on cuda:0 over gloo")
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    rccl = None
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # the collective library really is there and really spans the ranks: all-reduce of ones == world
+            ones = torch.ones(1, dtype=torch.float32, device=torch.device("cuda", local_rank))
+            dist.all_reduce(ones)
+            torch.cuda.synchronize()
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                ver = None
+            rccl = {"backend": dist.get_backend(), "all_reduce_of_ones": float(ones.item()), "ok": float(ones.item()) == world,
+                    "version": ver}
 
     import fixtures as F
     import gg20_fixture as G
@@ -444,7 +509,8 @@ def main():
     lk = G.make_local_keys(keys, T, N_PARTIES, SIGNERS)
     # the public key tables come from rank 0 once (LocalKey's public part is identical for everybody)
     pub = {f: torch.from_numpy(np.ascontiguousarray(lk["arrays"][f]).view(np.int32)) for f in ("Nt", "h1", "h2", "y", "X")}
-    pub = mpe_dist.broadcast_tables(pub, dev)
+    coll_dev = torch.device("cpu") if share else dev           # where the (tiny) control collectives run: gloo works on host tensors
+    pub = mpe_dist.broadcast_tables(pub, coll_dev)
     arrays = dict(lk["arrays"])
     for f in pub:
         arrays[f] = np.ascontiguousarray(pub[f].cpu().numpy().view(np.uint32))
@@ -480,14 +546,17 @@ def main():
             block_nonces[s] = mine
             engines[s] = GpuRoundEngine(ctx, E, gk, B, parties, mine)
             return engines[s]
-        ps_holder = {}
+        # the session objects live across steps, as a party process would keep them: a step re-arms them with the block's
+        # sampled values (mpe_gg20_session_rearm) and runs the nine rounds
+        ps = mpe_dist.PartySharded(S, B, lambda rnd: E.gg20_msg_words(S, n, rnd), make_engine, dev, placement="rotated",
+                                   colocate=world < S)
+        ps_holder = {"ps": ps, "armed": True}
 
         def step():
-            for e_ in engines.values():
-                e_.close()
-            engines.clear()
-            ps = mpe_dist.PartySharded(S, B, lambda rnd: E.gg20_msg_words(S, n, rnd), make_engine, dev, placement="rotated")
-            ps_holder["ps"] = ps
+            if not ps_holder["armed"]:
+                for _, e_ in ps.engines.values():
+                    e_.rearm()
+            ps_holder["armed"] = False
             res = ps.run({s: block_nonces[s]["msg"] for s in ps.engines})
             first = res[sorted(res)[0]]
             return first["r"][0], first["s"][0], first["recid"][0], torch.cat([r_["status"].reshape(-1) for r_ in res.values()])
@@ -496,8 +565,8 @@ def main():
         out = step()
     torch.cuda.synchronize()
     ctx.prof_enable(True)
-    if args.mode == "party" and "ps" in ps_holder:
-        ps_holder["ps"].comm_s = 0.0
+    if args.mode == "party":
+        ps_holder["ps"].comm_seconds()                     # drop the warm-up's share
     comm_total = 0.0
     if distributed:
         dist.barrier()
@@ -505,16 +574,24 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-        if args.mode == "party":
-            comm_total += ps_holder["ps"].comm_s
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if args.mode == "party":
+        comm_total = ps_holder["ps"].comm_seconds()        # HIP events around every all-gather of the timed region
     recs = ctx.prof_collect(16384)
     ctx.prof_enable(False)
-    elapsed = mpe_dist.max_over_ranks(elapsed, dev)          # the job ends when its slowest rank does
+    own_elapsed = elapsed
+    elapsed = mpe_dist.max_over_ranks(elapsed, coll_dev)     # the job ends when its slowest rank does
+    per_rank = None
+    if distributed:
+        mine = torch.tensor([B * args.steps / own_elapsed, float(bool((out[3] == 0).all().item()))], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rates = [float(t_[0]) for t_ in every]
+        per_rank = {"signatures_per_s": rates, "min": min(rates), "max": max(rates), "all_ranks_signed": all(float(t_[1]) == 1.0 for t_ in every)}
     if args.mode == "party":
         ps = ps_holder["ps"]
         extra = {"bytes_all_gathered_per_round": {str(k): int(v) for k, v in ps.bytes_per_round.items()},
@@ -527,7 +604,7 @@ def main():
     if distributed and (world > 1 or os.environ.get("MPE_BENCH_FORCE_NODE_PAILLIER")) and args.mode == "session" and not args.no_configs:
         dist.barrier()
         p2 = paillier_config2(ctx, E, keys, F)
-        agg = torch.tensor([p2["ops_per_s"], p2["encrypt_per_s"], p2["decrypt_per_s"], p2["modexp4096_2048_per_s"]], dtype=torch.float64, device=dev)
+        agg = torch.tensor([p2["ops_per_s"], p2["encrypt_per_s"], p2["decrypt_per_s"], p2["modexp4096_2048_per_s"]], dtype=torch.float64, device=coll_dev)
         lo = agg.clone()
         dist.all_reduce(agg)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -606,6 +683,11 @@ def main():
                           "alg_unit_mac_per_signature": sig_macs(S, n), "fb_window_bits": gk.fb_window_bits()},
             "all_sessions_signed": all_signed, "launch": ctx.launch_info(),
         }
+        if distributed:
+            res["per_rank"] = per_rank
+            res["all_sessions_signed"] = all_signed and per_rank["all_ranks_signed"]
+            res["rccl"] = rccl if rccl is not None else {"backend": "gloo", "note": "--share-device: every rank on cuda:0, collectives staged "
+                                                         "through host memory; the ranks time-share one GPU (a functional run, not a node figure)"}
         # the other configs and the CPU baseline belong to the single-GPU line (rank 0 at N=1 only): at N>1 the other ranks
         # would just wait for them
         single = world == 1 and args.mode == "session"
@@ -626,6 +708,11 @@ def main():
                                    "sample": f"the first {sample} sessions of the same batch ({sample // threads} per thread; GMP oracle, "
                                              f"{threads} threads of {os.cpu_count()} host CPUs)"}
             res["parity_vs_oracle_on_sample"] = parity
+            res["parity_sample"] = sample
+        if single:
+            # every signature of the timed batch under OpenSSL (not only "status == 0", which is the device's own verdict)
+            res["openssl"] = openssl_verify_all(lk["arrays"]["y"][0], nonces["msg"], r, s, threads)
+            res["openssl_verified"] = res["openssl"]["openssl_verified"]
         if single and not args.no_configs and (T, N_PARTIES) == (1, 3):
             gk.close()
             cfg, took = {}, {}
@@ -636,8 +723,10 @@ def main():
                 took[name] = round(time.perf_counter() - t_, 2)
             section("c2_paillier_65536", lambda: paillier_config2(ctx, E, keys, F, oracle_threads=0 if args.no_cpu_baseline else threads))
             section("c3_ec_pdl_262144", lambda: config3(ctx, E, keys, F, oracle=not args.no_cpu_baseline))
-            section("c4_literal_1024", lambda: gg20_config(ctx, E, G, keys, 1, 3, 1024, 4, gen, parity_sample=0 if args.no_cpu_baseline else 32))
-            section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 16))
+            section("c4_literal_1024", lambda: gg20_config(ctx, E, G, keys, 1, 3, 1024, 4, gen, parity_sample=0 if args.no_cpu_baseline else 128,
+                                                           openssl=True))
+            section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32,
+                                                              openssl=True))
             section("c4_multi_wallet_16384", lambda: [multi_wallet(ctx, E, G, keys, K_, 16384, gen) for K_ in (16, 1024)])
             section("lindell17", lambda: lindell_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline))
             res["lindell17"] = cfg.pop("lindell17")

@@ -332,6 +332,10 @@ int mpe_gg20_session_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, 
                             const int32_t* d_keyset, const mpe_gg20_nonces* nonces, int dedup_verify, mpe_gg20_session** out,
                             void* stream);
 int mpe_gg20_session_destroy(mpe_gg20_session* sess, void* stream);
+/* The next batch of the same shape on the same object (a party process signs batch after batch: `SignManual::new` again
+ * with fresh `SignKeys`, sign.rs:540-569): new sampled values (and key-set choice), state of the previous batch zeroed, rounds
+ * start again at 0.  Results are identical to those of a freshly created session. */
+int mpe_gg20_session_rearm(mpe_gg20_session* sess, const int32_t* d_keyset, const mpe_gg20_nonces* nonces, void* stream);
 int mpe_gg20_round0(mpe_gg20_session* sess, uint32_t* d_out, void* stream);
 int mpe_gg20_round1(mpe_gg20_session* sess, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream);
 int mpe_gg20_round2(mpe_gg20_session* sess, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream);

@@ -125,6 +125,7 @@ def _load():
         "mpe_heg_verify": (ip, [vp, ip, C.POINTER(HegStatement), C.POINTER(HegProof), vp, vp]),
         "mpe_hash_commit_point": (ip, [vp, ip, u32p, u32p, u32p, vp]),
         "mpe_gg20_session_fault_inject": (ip, [vp, ip, C.c_uint32]),
+        "mpe_gg20_session_rearm": (ip, [vp, i32p, C.POINTER(Gg20Nonces), vp]),
         "mpe_gg20_blame5": (ip, [vp, vp, ip, i32p, C.POINTER(Blame5In), u32p, vp]),
         "mpe_gg20_blame6": (ip, [vp, vp, ip, i32p, C.POINTER(Blame6In), u32p, vp]),
         "mpe_gg20_blame7": (ip, [vp, ip, ip, C.POINTER(Blame7In), u32p, vp]),
@@ -176,7 +177,7 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_pedersen_verify", "mpe_heg_prove", "mpe_heg_verify", "mpe_hash_commit_point", "mpe_ctx_wipe", "mpe_ctx_scratch_audit", "mpe_gg20_session_fault_inject", "mpe_gg20_blame5",
             "mpe_gg20_blame6", "mpe_gg20_blame7", "mpe_correct_key_verify", "mpe_composite_dlog_verify", "mpe_vss_validate_share",
             "mpe_vss_point_commitment", "mpe_gg20_session_blame6_state", "mpe_ecddh_prove", "mpe_ecddh_verify",
-            "mpe_statements_create_wb"]
+            "mpe_statements_create_wb", "mpe_gg20_session_rearm"]
 
 
 def check(rc, what):

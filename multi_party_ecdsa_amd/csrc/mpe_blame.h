@@ -283,7 +283,7 @@ int mpe_gg20_blame5(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const in
   const int S = keys->S, P1 = S - 1, nPI = batch * S, nPP = nPI * P1;
   const bl::Dim d = bl::blame_dim(keys, batch, d_keyset);
   // own arrays at the top of the workspace (never handed out, never moved: ws_top), the Paillier composites below
-  const size_t own = ((size_t)nPI * (64 + 128) + (size_t)nPP * 128) * 4 + (size_t)(nPI + nPP) * 4 * 2 + (size_t)nPI * 2 + nPP + 16 * 256;
+  const size_t own = ((size_t)nPI * (64 + 128) + (size_t)nPP * 128) * 4 + ((size_t)nPI + 3 * (size_t)nPP) * 4 + (size_t)nPI * 2 + nPP + 16 * 256;   // BIdx: one [nPI] + three [nPP] arrays; 256 B slack per take()
   MPE_TRY(ws_reserve(ctx, own + ws_need_encrypt(nPI) + ws_need_mul_add_enc(nPP) + (1u << 20), st));
   char* top = (char*)ctx->ws + ctx->ws_bytes;
   auto take = [&](size_t bytes) { top -= (bytes + 255) & ~(size_t)255; return (void*)top; };
@@ -323,7 +323,7 @@ int mpe_gg20_blame6(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const in
   hipStream_t st = (hipStream_t)stream;
   const int S = keys->S, P1 = S - 1, nPI = batch * S, nPP = nPI * P1;
   const bl::Dim d = bl::blame_dim(keys, batch, d_keyset);
-  const size_t own = ((size_t)nPI * (64 + 128) + (size_t)nPP * (128 + 16)) * 4 + (size_t)(nPI + nPP) * 4 * 2 + (size_t)nPI * 2 + nPP + 16 * 256;
+  const size_t own = ((size_t)nPI * (64 + 128) + (size_t)nPP * (128 + 16)) * 4 + ((size_t)nPI + 3 * (size_t)nPP) * 4 + (size_t)nPI * 2 + nPP + 16 * 256;   // BIdx: one [nPI] + three [nPP] arrays; 256 B slack per take()
   MPE_TRY(ws_reserve(ctx, own + ws_need_encrypt(nPP) + (1u << 20), st));
   char* top = (char*)ctx->ws + ctx->ws_bytes;
   auto take = [&](size_t bytes) { top -= (bytes + 255) & ~(size_t)255; return (void*)top; };

@@ -1191,6 +1191,27 @@ int mpe_gg20_session_destroy(mpe_gg20_session* s, void* stream) {
   return MPE_OK;
 }
 
+int mpe_gg20_session_rearm(mpe_gg20_session* s, const int32_t* d_keyset, const mpe_gg20_nonces* nonces, void* stream) {
+  // a long-lived party process signs batch after batch with the same (keys, batch, local parties) shape: the state arrays and
+  // the index tables stay, everything nonce-derived is zeroed and the round counter starts again
+  if (!s || !nonces) return MPE_E_ARG;
+  if (s->K->K > 1 && !d_keyset) return MPE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const mpe::gg::Counts c = mpe::gg::counts_of(s->d);
+  s->Z = *nonces; s->d.ks = d_keyset; s->next_round = 0; s->fault_step = 0; s->fault_mask = 0;
+  // the state region after the index tables: secrets of the previous batch do not outlive it
+  (void)hipMemsetAsync(s->kq, 0, (size_t)((char*)s->mem + s->mem_bytes - (char*)s->kq), st);
+  size_t total = c.nVI;                 // the key indices follow the (possibly different) key-set choice
+  if (c.nMB > total) total = c.nMB;
+  if (c.nAP > total) total = c.nAP;
+  if (c.nPV > total) total = c.nPV;
+  if (c.nPI > total) total = c.nPI;
+  hipLaunchKernelGGL(mpe::gg::idx_kernel, dim3(mpe::blocks_for((int)total, 64)), dim3(64), 0, st, s->d, s->ix, (int)total);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mpe_set_error("gg20 session rearm", e); return MPE_E_HIP; }
+  return MPE_OK;
+}
+
 int mpe_gg20_session_fault_inject(mpe_gg20_session* s, int step, uint32_t party_mask) {
   if (!s || (step != 0 && step != 5 && step != 6 && step != 7)) return MPE_E_ARG;
   s->fault_step = step; s->fault_mask = party_mask;

@@ -14,8 +14,15 @@ mesh, no ring all-reduce anywhere.  Placements:
   * "party":   world == a divisor pattern of S (rank r hosts the signer ordinals p with p % world == r) — one party per
                rank when world == S: a rank only ever holds its own party's secrets;
   * "rotated": the sessions are cut into `world` blocks and party p of block s lives on rank (s + p) % world — every
-               rank hosts S (block, party) pairs, so any world size >= S is perfectly balanced (config 5: t=2, n=5,
-               S=3 on 8 GPUs) and no two parties of a session share a GPU."""
+               rank hosts S (block, party) pairs, so any world size is perfectly balanced (config 5: t=2, n=5, S=3 on 8
+               GPUs); with world >= S no two parties of a session share a GPU.  world < S would put two parties of a
+               session on one rank: refused unless the caller says `colocate=True` (a throughput run on fewer GPUs than
+               signers; each party's secrets still live in their own key object).
+
+The exchange is stream-ordered: a round's records are written by `mpe_gg20_roundN` straight into this rank's slot of the
+gather buffer, the all-gather is queued behind them on the same stream (RCCL) and the next round reads the gathered buffer
+in place through `h_in_off` — no host synchronisation, no staging copy, two alternating buffers.  Under gloo (CPU tensors,
+or GPU engines that share one device in the tests) the slab is staged through host memory."""
 import time
 
 import torch
@@ -57,13 +64,15 @@ class PartySharded:
     """Party-sharded GG20 signing over `world` ranks.
 
     make_engine(block, local_parties) -> an object with
-        round(rnd, d_in, in_off, msg) -> tensor [len(local_parties), Bblk, W] (or None for rounds 6 and 8)
+        round(rnd, d_in, in_off, msg[, out]) -> tensor [len(local_parties), Bblk, W] (or None for rounds 6 and 8)
         result() -> dict of tensors (status, bad_actors, r, s, recid [L, Bblk, ..])
     d_in is the gathered slab of the previous round (a flat tensor of records) and in_off[j] the record offset of sender
-    ordinal j's [Bblk][W] block in it — the calling convention of mpe_gg20_roundN."""
+    ordinal j's [Bblk][W] block in it — the calling convention of mpe_gg20_roundN.  An engine that sets
+    `writes_in_place = True` accepts `out=` (a contiguous [L, Bblk, W] view of the gather buffer) and writes its records
+    there; the others return a tensor that is copied into the slot."""
 
-    def __init__(self, S, Bblk, msg_words, make_engine, device, placement="rotated", rank=None, world=None):
-        self.S, self.Bblk, self.msg_words, self.device = S, Bblk, msg_words, device
+    def __init__(self, S, Bblk, msg_words, make_engine, device, placement="rotated", rank=None, world=None, colocate=False):
+        self.S, self.Bblk, self.msg_words, self.device = S, Bblk, msg_words, torch.device(device)
         self.dist = dist.is_available() and dist.is_initialized()
         self.rank = (dist.get_rank() if self.dist else 0) if rank is None else rank
         self.world = (dist.get_world_size() if self.dist else 1) if world is None else world
@@ -74,6 +83,9 @@ class PartySharded:
             self.blocks = 1
             self._where = lambda s, p: (p % G, p // G)
         elif placement == "rotated":
+            if G < S and not colocate:
+                raise ValueError(f"placement 'rotated' with world {G} < {S} signers puts two parties of a session on one rank "
+                                 "(pass colocate=True to accept that)")
             self.blocks = G
             self._where = lambda s, p: ((s + p) % G, p)
         else:
@@ -88,6 +100,10 @@ class PartySharded:
             self.engines[s] = (parties, make_engine(s, parties))
         self.comm_s = 0.0
         self.bytes_per_round = {}
+        self._bufs = [None, None]
+        self._events = []
+        self.backend = dist.get_backend() if self.dist else None
+        self.maxw = max(self.msg_words(r) for r in ROUNDS_OUT)
 
     def in_off(self, s):
         """record offset, in the gathered slab, of every sender ordinal's block for session block s"""
@@ -97,35 +113,63 @@ class PartySharded:
             off.append((r * self.per_rank + slot) * self.Bblk)
         return off
 
-    def _gather(self, rank_slab):
+    def _buffer(self, q, W):
+        """gather buffer q & 1 viewed as [world * per_rank, Bblk, W] (rank r's slab = rows [r * per_rank, (r+1) * per_rank))"""
+        rows = self.world * self.per_rank
+        if self._bufs[q & 1] is None:
+            self._bufs[q & 1] = torch.empty(rows * self.Bblk * self.maxw, dtype=torch.int32, device=self.device)
+        return self._bufs[q & 1][: rows * self.Bblk * W].view(rows, self.Bblk, W)
+
+    def _gather(self, buf, mine):
+        """all ranks' slabs into `buf` (`mine` = this rank's rows of it, already written)"""
+        if not (self.dist and self.world > 1):
+            return
+        cuda = buf.is_cuda
+        if cuda and self.backend == "nccl":
+            # in-place RCCL all-gather queued behind the round's kernels on the current stream; timed with events
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1))
+            e1.record()
+            self._events.append((e0, e1))
+            return
         t0 = time.perf_counter()
-        if self.dist and self.world > 1:
-            out = torch.empty((self.world * rank_slab.shape[0],) + tuple(rank_slab.shape[1:]), dtype=rank_slab.dtype,
-                              device=rank_slab.device)                  # rank r's slab = rows [r * per_rank, (r+1) * per_rank)
-            if rank_slab.is_cuda:
-                torch.cuda.synchronize(rank_slab.device)
-                t0 = time.perf_counter()
-            dist.all_gather_into_tensor(out, rank_slab)
-            if rank_slab.is_cuda:
-                torch.cuda.synchronize(rank_slab.device)
+        if cuda:                                     # gloo with GPU engines: through host memory
+            h_out = torch.empty(buf.shape, dtype=buf.dtype)
+            dist.all_gather_into_tensor(h_out.view(-1), mine.cpu().reshape(-1))
+            buf.copy_(h_out)
         else:
-            out = rank_slab
+            dist.all_gather_into_tensor(buf.view(-1), mine.clone().reshape(-1))
         self.comm_s += time.perf_counter() - t0
-        return out.reshape(-1)
+
+    def comm_seconds(self):
+        """time spent in the all-gathers since the last call (drains the event pairs: call it after a synchronize)"""
+        for e0, e1 in self._events:
+            self.comm_s += e0.elapsed_time(e1) * 1e-3
+        self._events = []
+        t, self.comm_s = self.comm_s, 0.0
+        return t
 
     def run(self, msgs):
         """msgs: {block: tensor [Bblk, 8]} for the blocks this rank hosts.  Returns {block: result dict}."""
-        S, Bblk = self.S, self.Bblk
-        gathered = None
+        gathered, q = None, 0
         for rnd in range(9):
             W = self.msg_words(rnd) if rnd in ROUNDS_OUT else 0
-            slab = torch.zeros((self.per_rank, Bblk, W), dtype=torch.int32, device=self.device) if W else None
+            buf = self._buffer(q, W) if W else None
+            mine = buf[self.rank * self.per_rank:(self.rank + 1) * self.per_rank] if W else None
             for s, (parties, eng) in self.engines.items():
-                out = eng.round(rnd, gathered, self.in_off(s), msgs[s] if rnd == 7 else None)
-                if out is not None:
-                    for li, p in enumerate(parties):
-                        slab[self._where(s, p)[1]] = out[li]
-            if slab is not None:
-                self.bytes_per_round[rnd] = slab.numel() * 4 * self.world
-                gathered = self._gather(slab)
+                slots = [self._where(s, p)[1] for p in parties]
+                msg = msgs[s] if rnd == 7 else None
+                if W and getattr(eng, "writes_in_place", False) and slots == list(range(slots[0], slots[0] + len(slots))):
+                    eng.round(rnd, gathered, self.in_off(s), msg, out=mine[slots[0]:slots[0] + len(slots)])
+                else:
+                    out = eng.round(rnd, gathered, self.in_off(s), msg)
+                    if out is not None:
+                        for li, slot in enumerate(slots):
+                            mine[slot] = out[li]
+            if W:
+                self.bytes_per_round[rnd] = buf.numel() * 4
+                self._gather(buf, mine)
+                gathered = buf.view(-1)
+                q += 1
         return {s: eng.result() for s, (parties, eng) in self.engines.items()}

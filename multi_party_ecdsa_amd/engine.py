@@ -460,13 +460,27 @@ class Gg20Session:
     def _off(self, in_off):
         return None if in_off is None else (C.c_int64 * self.S)(*[int(x) for x in in_off])
 
-    def round(self, rnd, d_in=None, in_off=None, msg=None):
+    def rearm(self, nonces, keyset=None):
+        """the next batch of the same shape on this object (mpe_gg20_session_rearm): fresh sampled values, rounds from 0"""
+        self._nonces = dict(nonces)
+        if "msg" not in self._nonces:
+            self._nonces["msg"] = torch.zeros((self.B, 8), dtype=torch.int32, device=self.ctx.device)
+        self._keyset = keyset
+        nn = _struct(N_.Gg20Nonces, self._nonces)
+        N_.check(N_.lib.mpe_gg20_session_rearm(self.h, _ptr(keyset), C.byref(nn), self.ctx.stream()), "mpe_gg20_session_rearm")
+
+    def round(self, rnd, d_in=None, in_off=None, msg=None, out=None):
         """Runs round `rnd` (0..7, 8 = SignManual::complete).  d_in: the previous round's records of all S senders (device
         int32 tensor; sender j's [B][W] block at record in_off[j], default j*B).  Returns this object's outgoing records
-        [L, B, W] (None for rounds 6 and 8)."""
+        [L, B, W] (None for rounds 6 and 8); `out`: a contiguous [L, B, W] int32 device tensor to write them into (e.g. this
+        rank's slot of an all-gather buffer)."""
         lib, st = N_.lib, self.ctx.stream()
         W = gg20_msg_words(self.S, self.n, rnd) if rnd in GG20_ROUNDS else 0
-        out = torch.empty((self.L, self.B, W), dtype=torch.int32, device=self.ctx.device) if W else None
+        if out is not None and W:
+            if not (out.is_contiguous() and out.dtype == torch.int32 and out.numel() == self.L * self.B * W and out.device == self.ctx.device):
+                raise ValueError("round(out=...): need a contiguous int32 [L, B, W] tensor on the context's device")
+        else:
+            out = torch.empty((self.L, self.B, W), dtype=torch.int32, device=self.ctx.device) if W else None
         if rnd == 0:
             N_.check(lib.mpe_gg20_round0(self.h, _ptr(out), st), "mpe_gg20_round0")
         elif 1 <= rnd <= 5:

@@ -14,12 +14,19 @@ Field names and nesting come from the reference sources (all `#[derive(Serialize
   DLogProof{pk, pk_t_rand_commitment, challenge_response}, PedersenProof{e, a1, a2, com, z1, z2},
   HomoELGamalProof{T, A3, z1, z2}                               curv-kzen 0.9 (un-vendored; field names recalled)
 
-THE PRIMITIVE ENCODINGS ARE RECALLED, NOT READ (curv-kzen 0.9 is not in the reference tree): BigInt as the lower-case hex
-string of its big-endian bytes, Point as {"curve": "secp256k1", "point": hex of the 33 compressed bytes}, Scalar as
-{"curve": "secp256k1", "scalar": hex of 32 bytes}.  They are isolated in the six functions below; the decoders also accept
-the other forms curv versions have used (decimal strings, byte arrays, uncompressed points), so that vectors produced by
-the real crate (tools/rust_vectors) decode whatever the exact form turns out to be."""
+THE PRIMITIVE ENCODINGS ARE RECALLED, NOT READ (curv-kzen 0.9, kzen-paillier 0.4.2 are not in the reference tree), so the
+ENCODERS are configurable (`Style`) and the DECODERS accept every form the crates are believed to have used:
+  * curv `BigInt`: lower-case hex string of the big-endian bytes (human-readable serializers) — or a byte array;
+  * curv `Point<Secp256k1>` / `Scalar<Secp256k1>`: {"curve": "secp256k1", "point" / "scalar": BYTES}, where serde_json writes
+    bytes as an array of numbers (Style point="bytes", the default: what a real local-share.json is believed to hold) — or a
+    hex string (point="hex"); points compressed (33 bytes), uncompressed accepted;
+  * kzen-paillier `EncryptionKey{n}` / `DecryptionKey{p,q}`: its own `serialize::bigint` module, believed to write RADIX-10
+    strings (Style paillier="decimal", the default) — or hex (paillier="hex").  A digit-only string is ambiguous between the
+    two radices: `local_key_from_json` decodes both ways and keeps the reading in which p * q == paillier_key_vec[i-1].n.
+Unknown fields are ignored.  They are isolated in the functions below, so that vectors produced by the real crates
+(tools/rust_vectors) settle the form in one place."""
 import json
+from dataclasses import dataclass
 
 import numpy as np
 
@@ -27,13 +34,35 @@ P = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2F
 CURVE = "secp256k1"
 
 
-# ---- curv primitives (recalled encodings) ---------------------------------------------------------------------------
-def bigint_to_json(x):
+@dataclass(frozen=True)
+class Style:
+    """which of the believed serde forms the encoders write"""
+    point: str = "bytes"        # "bytes": [2, 121, ...] (serde_json's rendering of serde bytes) | "hex": "0279be..."
+    scalar: str = "bytes"       # likewise for Scalar
+    bigint: str = "hex"         # curv BigInt: "hex" string | "bytes" array
+    paillier: str = "decimal"   # kzen-paillier keys: "decimal" string | "hex" string
+
+    def __post_init__(self):
+        for f, allowed in (("point", ("bytes", "hex")), ("scalar", ("bytes", "hex")), ("bigint", ("hex", "bytes")), ("paillier", ("decimal", "hex"))):
+            if getattr(self, f) not in allowed:
+                raise ValueError(f"Style.{f} must be one of {allowed}")
+
+
+DEFAULT_STYLE = Style()
+HEX_STYLE = Style(point="hex", scalar="hex", bigint="hex", paillier="hex")     # the round-2 form of this module
+
+
+# ---- curv / kzen-paillier primitives (recalled encodings) --------------------------------------------------------------
+def bigint_to_json(x, style=DEFAULT_STYLE):
     h = "%x" % int(x)
-    return h if len(h) % 2 == 0 else "0" + h
+    h = h if len(h) % 2 == 0 else "0" + h
+    return list(bytes.fromhex(h)) if style.bigint == "bytes" else h
 
 
-def bigint_from_json(v):
+def bigint_from_json(v, radix=16):
+    """curv BigInt: hex string (radix=16) / byte array / int.  radix=10 reads a digit string as decimal (kzen-paillier)."""
+    if isinstance(v, bool):
+        raise ValueError("not a big integer")
     if isinstance(v, int):
         return v
     if isinstance(v, list):
@@ -41,33 +70,62 @@ def bigint_from_json(v):
     s = v.strip()
     if s.startswith("0x"):
         return int(s, 16)
+    return int(s, radix)
+
+
+def paillier_bigint_to_json(x, style=DEFAULT_STYLE):
+    return str(int(x)) if style.paillier == "decimal" else "%x" % int(x)
+
+
+def paillier_bigint_readings(v):
+    """every integer a kzen-paillier key field may mean: [decimal reading, hex reading] for a digit-only string"""
+    if isinstance(v, (int, list)) and not isinstance(v, bool):
+        return [bigint_from_json(v)]
+    s = v.strip()
+    out = []
+    if s.isdigit():
+        out.append(int(s, 10))
     try:
-        return int(s, 16)
+        h = int(s, 16)
+        if h not in out:
+            out.append(h)
     except ValueError:
-        return int(s)
+        pass
+    if not out:
+        raise ValueError("not a big integer")
+    return out
 
 
-def point_to_json(pt):
+def _bytes_json(b, how):
+    return list(b) if how == "bytes" else b.hex()
+
+
+def point_to_json(pt, style=DEFAULT_STYLE):
     x, y = pt
-    return {"curve": CURVE, "point": "%02x%064x" % (2 + (y & 1), x)}
+    return {"curve": CURVE, "point": _bytes_json(bytes([2 + (y & 1)]) + int(x).to_bytes(32, "big"), style.point)}
 
 
 def point_from_json(v):
     raw = v["point"] if isinstance(v, dict) else v
+    if isinstance(v, dict) and v.get("curve", CURVE) != CURVE:
+        raise ValueError("point of another curve")
     b = bytes(raw) if isinstance(raw, list) else bytes.fromhex(raw)
     if len(b) == 65 and b[0] == 4:
-        return int.from_bytes(b[1:33], "big"), int.from_bytes(b[33:], "big")
+        x, y = int.from_bytes(b[1:33], "big"), int.from_bytes(b[33:], "big")
+        if (y * y - x * x * x - 7) % P or x >= P or y >= P:
+            raise ValueError("point is not on the curve")
+        return x, y
     if len(b) == 33 and b[0] in (2, 3):
         x = int.from_bytes(b[1:], "big")
         y = pow((x * x * x + 7) % P, (P + 1) // 4, P)
-        if (y * y - x * x * x - 7) % P:
+        if (y * y - x * x * x - 7) % P or x >= P:
             raise ValueError("point is not on the curve")
         return (x, y if (y & 1) == (b[0] & 1) else P - y)
     raise ValueError("unknown point encoding")
 
 
-def scalar_to_json(x):
-    return {"curve": CURVE, "scalar": "%064x" % int(x)}
+def scalar_to_json(x, style=DEFAULT_STYLE):
+    return {"curve": CURVE, "scalar": _bytes_json(int(x).to_bytes(32, "big"), style.scalar)}
 
 
 def scalar_from_json(v):
@@ -98,9 +156,9 @@ ALICE = (("z", 0, 64), ("e", 64, 8), ("s", 72, 64), ("s1", 136, 25), ("s2", 161,
 PDL = (("z", 0, 64), ("u2", 80, 128), ("u3", 208, 64), ("s1", 272, 25), ("s2", 297, 64), ("s3", 361, 89))
 
 
-def _dlog_to_json(w, off):
-    return {"pk": point_to_json(_pt(w[off:off + 16])), "pk_t_rand_commitment": point_to_json(_pt(w[off + 16:off + 32])),
-            "challenge_response": scalar_to_json(_int(w[off + 32:off + 40]))}
+def _dlog_to_json(w, off, style=DEFAULT_STYLE):
+    return {"pk": point_to_json(_pt(w[off:off + 16]), style), "pk_t_rand_commitment": point_to_json(_pt(w[off + 16:off + 32]), style),
+            "challenge_response": scalar_to_json(_int(w[off + 32:off + 40]), style)}
 
 
 def _dlog_from_json(rec, off, j):
@@ -109,8 +167,8 @@ def _dlog_from_json(rec, off, j):
     _put(rec, off + 32, 8, scalar_from_json(j["challenge_response"]))
 
 
-def _msgb_to_json(w):
-    return {"c": bigint_to_json(_int(w[0:128])), "b_proof": _dlog_to_json(w, 128), "beta_tag_proof": _dlog_to_json(w, 168)}
+def _msgb_to_json(w, style=DEFAULT_STYLE):
+    return {"c": bigint_to_json(_int(w[0:128]), style), "b_proof": _dlog_to_json(w, 128, style), "beta_tag_proof": _dlog_to_json(w, 168, style)}
 
 
 def _msgb_from_json(rec, off, j):
@@ -119,48 +177,48 @@ def _msgb_from_json(rec, off, j):
     _dlog_from_json(rec, off + 168, j["beta_tag_proof"])
 
 
-def record_to_bodies(rnd, rec, S, n, sender):
+def record_to_bodies(rnd, rec, S, n, sender, style=DEFAULT_STYLE):
     """One sender's record of round `rnd` (0..5, 7) -> list of (receiver or None, body) where body is the JSON value of
     `OfflineProtocolMessage` (rounds 0..5) / `PartialSignature` (round 7).  sender, receiver: signer ordinals + 1 (the
     reference numbers parties from 1)."""
     w = np.ascontiguousarray(rec, dtype=np.uint32)
     if rnd == 0:
-        proofs = [{f: bigint_to_json(_int(w[st * 256 + o:st * 256 + o + k])) for f, o, k in ALICE} for st in range(n)]
+        proofs = [{f: bigint_to_json(_int(w[st * 256 + o:st * 256 + o + k]), style) for f, o, k in ALICE} for st in range(n)]
         c = w[n * 256:]
-        return [(None, {"M1": [{"c": bigint_to_json(_int(c[0:128])), "range_proofs": proofs}, {"com": bigint_to_json(_int(c[128:136]))}]})]
+        return [(None, {"M1": [{"c": bigint_to_json(_int(c[0:128]), style), "range_proofs": proofs}, {"com": bigint_to_json(_int(c[128:136]), style)}]})]
     if rnd == 1:
         out = []
         for jj in range(S - 1):
             ind = jj if jj < sender - 1 else jj + 1
             g, wi = w[(jj * 2) * 208:(jj * 2 + 1) * 208], w[(jj * 2 + 1) * 208:(jj * 2 + 2) * 208]
-            out.append((ind + 1, {"M2": [_msgb_to_json(g), _msgb_to_json(wi)]}))
+            out.append((ind + 1, {"M2": [_msgb_to_json(g, style), _msgb_to_json(wi, style)]}))
         return out
     if rnd == 2:
-        proof = {"e": scalar_to_json(_int(w[24:32])), "a1": point_to_json(_pt(w[32:48])), "a2": point_to_json(_pt(w[48:64])),
-                 "com": point_to_json(_pt(w[64:80])), "z1": scalar_to_json(_int(w[80:88])), "z2": scalar_to_json(_int(w[88:96]))}
-        return [(None, {"M3": [scalar_to_json(_int(w[0:8])), point_to_json(_pt(w[8:24])), proof]})]
+        proof = {"e": scalar_to_json(_int(w[24:32]), style), "a1": point_to_json(_pt(w[32:48]), style), "a2": point_to_json(_pt(w[48:64]), style),
+                 "com": point_to_json(_pt(w[64:80]), style), "z1": scalar_to_json(_int(w[80:88]), style), "z2": scalar_to_json(_int(w[88:96]), style)}
+        return [(None, {"M3": [scalar_to_json(_int(w[0:8]), style), point_to_json(_pt(w[8:24]), style), proof]})]
     if rnd == 3:
-        return [(None, {"M4": {"blind_factor": bigint_to_json(_int(w[0:8])), "g_gamma_i": point_to_json(_pt(w[8:24]))}})]
+        return [(None, {"M4": {"blind_factor": bigint_to_json(_int(w[0:8]), style), "g_gamma_i": point_to_json(_pt(w[8:24]), style)}})]
     if rnd == 4:
         proofs = []
         for jj in range(S - 1):
             p = w[jj * 450:(jj + 1) * 450]
-            d = {f: bigint_to_json(_int(p[o:o + k])) for f, o, k in PDL}
-            d["u1"] = point_to_json(_pt(p[64:80]))
+            d = {f: bigint_to_json(_int(p[o:o + k]), style) for f, o, k in PDL}
+            d["u1"] = point_to_json(_pt(p[64:80]), style)
             proofs.append({f: d[f] for f in ("z", "u1", "u2", "u3", "s1", "s2", "s3")})
-        return [(None, {"M5": [point_to_json(_pt(w[(S - 1) * 450:(S - 1) * 450 + 16])), proofs]})]
+        return [(None, {"M5": [point_to_json(_pt(w[(S - 1) * 450:(S - 1) * 450 + 16]), style), proofs]})]
     if rnd == 5:
-        proof = {"T": point_to_json(_pt(w[16:32])), "A3": point_to_json(_pt(w[32:48])), "z1": scalar_to_json(_int(w[48:56])),
-                 "z2": scalar_to_json(_int(w[56:64]))}
-        return [(None, {"M6": [point_to_json(_pt(w[0:16])), proof]})]
+        proof = {"T": point_to_json(_pt(w[16:32]), style), "A3": point_to_json(_pt(w[32:48]), style), "z1": scalar_to_json(_int(w[48:56]), style),
+                 "z2": scalar_to_json(_int(w[56:64]), style)}
+        return [(None, {"M6": [point_to_json(_pt(w[0:16]), style), proof]})]
     if rnd == 7:
-        return [(None, scalar_to_json(_int(w[0:8])))]
+        return [(None, scalar_to_json(_int(w[0:8]), style))]
     raise ValueError(rnd)
 
 
-def record_to_msgs(rnd, rec, S, n, sender):
+def record_to_msgs(rnd, rec, S, n, sender, style=DEFAULT_STYLE):
     """`Msg<OfflineProtocolMessage>` values as the relay carries them (JSON strings)"""
-    return [json.dumps({"sender": sender, "receiver": r, "body": body}) for r, body in record_to_bodies(rnd, rec, S, n, sender)]
+    return [json.dumps({"sender": sender, "receiver": r, "body": body}) for r, body in record_to_bodies(rnd, rec, S, n, sender, style)]
 
 
 def bodies_to_record(rnd, bodies, S, n, sender):
@@ -207,44 +265,64 @@ def bodies_to_record(rnd, bodies, S, n, sender):
     return rec
 
 
-def signature_to_json(r, s, recid):
+def signature_to_json(r, s, recid, style=DEFAULT_STYLE):
     """`SignatureRecid` (party_i.rs:131-135)"""
-    return {"r": scalar_to_json(r), "s": scalar_to_json(s), "recid": int(recid)}
+    return {"r": scalar_to_json(r, style), "s": scalar_to_json(s, style), "recid": int(recid)}
 
 
 # ---- LocalKey (state_machine/keygen/rounds.rs:311-322) -------------------------------------------------------------------
 # What `gg20_keygen` writes to local-share{i}.json (examples/gg20_keygen.rs:52-56) and `gg20_signing` reads back: the serde
 # form of LocalKey<Secp256k1>{paillier_dk{p,q}, pk_vec, keys_linear{y,x_i}, paillier_key_vec[{n}], y_sum_s,
 # h1_h2_n_tilde_vec[{N,g,ni}], vss_scheme{parameters{threshold,share_count},commitments}, i, t, n}.  `i` is 1-based.
-def local_key_to_json(i, t, n, p, q, x_i, y, pk_vec, N_vec, stm_vec, vss_commitments=None):
+def local_key_to_json(i, t, n, p, q, x_i, y, pk_vec, N_vec, stm_vec, vss_commitments=None, style=DEFAULT_STYLE):
     """i: 1-based party index; stm_vec: [(N~, h1, h2)] per party; vss_commitments: t+1 points (optional: signing never reads them)"""
     return {
-        "paillier_dk": {"p": bigint_to_json(p), "q": bigint_to_json(q)},
-        "pk_vec": [point_to_json(P_) for P_ in pk_vec],
-        "keys_linear": {"y": point_to_json(y), "x_i": scalar_to_json(x_i)},
-        "paillier_key_vec": [{"n": bigint_to_json(N_)} for N_ in N_vec],
-        "y_sum_s": point_to_json(y),
-        "h1_h2_n_tilde_vec": [{"N": bigint_to_json(a), "g": bigint_to_json(b), "ni": bigint_to_json(c)} for a, b, c in stm_vec],
-        "vss_scheme": {"parameters": {"threshold": t, "share_count": n}, "commitments": [point_to_json(c) for c in (vss_commitments or [])]},
+        "paillier_dk": {"p": paillier_bigint_to_json(p, style), "q": paillier_bigint_to_json(q, style)},
+        "pk_vec": [point_to_json(P_, style) for P_ in pk_vec],
+        "keys_linear": {"y": point_to_json(y, style), "x_i": scalar_to_json(x_i, style)},
+        "paillier_key_vec": [{"n": paillier_bigint_to_json(N_, style)} for N_ in N_vec],
+        "y_sum_s": point_to_json(y, style),
+        "h1_h2_n_tilde_vec": [{"N": bigint_to_json(a, style), "g": bigint_to_json(b, style), "ni": bigint_to_json(c, style)} for a, b, c in stm_vec],
+        "vss_scheme": {"parameters": {"threshold": t, "share_count": n}, "commitments": [point_to_json(c, style) for c in (vss_commitments or [])]},
         "i": i, "t": t, "n": n,
     }
 
 
 def local_key_from_json(obj):
-    """-> dict(i (1-based), t, n, p, q, x_i, y, pk_vec, N_vec, stm_vec) of Python ints / (x, y) points"""
+    """-> dict(i (1-based), t, n, p, q, x_i, y, pk_vec, N_vec, stm_vec) of Python ints / (x, y) points.
+    The kzen-paillier fields (paillier_dk.p/q, paillier_key_vec[].n) are read in the radix that makes p * q == n[i-1] and
+    every n a 2047/2048-bit integer (party_i.rs:287-290 enforces that size on receipt): decimal first, then hex."""
     if isinstance(obj, (str, bytes)):
         obj = json.loads(obj)
-    ek = lambda e: bigint_from_json(e["n"] if isinstance(e, dict) else e)
-    out = dict(i=int(obj["i"]), t=int(obj["t"]), n=int(obj["n"]), p=bigint_from_json(obj["paillier_dk"]["p"]),
-               q=bigint_from_json(obj["paillier_dk"]["q"]), x_i=scalar_from_json(obj["keys_linear"]["x_i"]),
-               y=point_from_json(obj["y_sum_s"]), pk_vec=[point_from_json(v) for v in obj["pk_vec"]],
-               N_vec=[ek(e) for e in obj["paillier_key_vec"]],
-               stm_vec=[(bigint_from_json(s["N"]), bigint_from_json(s["g"]), bigint_from_json(s["ni"])) for s in obj["h1_h2_n_tilde_vec"]])
-    n = out["n"]
-    if not (len(out["pk_vec"]) == len(out["N_vec"]) == len(out["stm_vec"]) == n and 1 <= out["i"] <= n and out["t"] < n):
+    i, n = int(obj["i"]), int(obj["n"])
+    ek = lambda e: e["n"] if isinstance(e, dict) else e
+    pr, qr = paillier_bigint_readings(obj["paillier_dk"]["p"]), paillier_bigint_readings(obj["paillier_dk"]["q"])
+    if not (len(obj["paillier_key_vec"]) == n and 1 <= i <= n):
         raise ValueError("LocalKey: inconsistent vector lengths / indices")
-    if out["p"] * out["q"] != out["N_vec"][out["i"] - 1]:
-        raise ValueError("LocalKey: paillier_dk does not match paillier_key_vec[i-1]")
+    nr = [paillier_bigint_readings(ek(e)) for e in obj["paillier_key_vec"]]
+    pick = None
+    for p_ in pr:
+        for q_ in qr:
+            if p_ * q_ in nr[i - 1]:
+                pick = (p_, q_)
+                break
+        if pick:
+            break
+    if pick is None:
+        raise ValueError("LocalKey: paillier_dk does not match paillier_key_vec[i-1] in any radix")
+    # the other parties' moduli: the reading with the size the reference accepts; both radices plausible -> the one my own key used
+    mine_decimal = isinstance(obj["paillier_dk"]["p"], str) and obj["paillier_dk"]["p"].strip().isdigit() and pick[0] == pr[0]
+    N_vec = []
+    for k, cand in enumerate(nr):
+        good = [c for c in cand if c.bit_length() in (2047, 2048)] or cand
+        if k == i - 1:
+            good = [pick[0] * pick[1]]
+        N_vec.append(good[0] if (mine_decimal or len(good) == 1) else good[-1])
+    out = dict(i=i, t=int(obj["t"]), n=n, p=pick[0], q=pick[1], x_i=scalar_from_json(obj["keys_linear"]["x_i"]),
+               y=point_from_json(obj["y_sum_s"]), pk_vec=[point_from_json(v) for v in obj["pk_vec"]], N_vec=N_vec,
+               stm_vec=[(bigint_from_json(s_["N"]), bigint_from_json(s_["g"]), bigint_from_json(s_["ni"])) for s_ in obj["h1_h2_n_tilde_vec"]])
+    if not (len(out["pk_vec"]) == len(out["stm_vec"]) == n and out["t"] < n):
+        raise ValueError("LocalKey: inconsistent vector lengths / indices")
     return out
 
 

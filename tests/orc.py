@@ -16,12 +16,23 @@ def build():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 
 
+def _stale():
+    """the library is missing or older than one of its sources"""
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    src = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle")) if f.endswith((".c", ".h")) and f != "ossl_check.c"]
+    return any(os.path.getmtime(f) > t for f in src)
+
+
 def load():
-    # `make` is a no-op when the library is newer than its sources and rebuilds a stale one (a kept work tree)
+    # `make` is a no-op when the libraries are newer than their sources and rebuilds stale ones (a kept work tree).  A failed
+    # build is only tolerated when the library on disk is NEWER than every source (e.g. a box without make): a stale oracle
+    # must never be loaded silently.
     try:
         build()
     except (OSError, subprocess.CalledProcessError):
-        if not os.path.exists(LIB):
+        if _stale():
             raise
     return C.CDLL(LIB)
 

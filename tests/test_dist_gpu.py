@@ -1,0 +1,244 @@
+"""GPU tests of the N>1 paths on the ONE device a test box has:
+ * Mode B with the real round engine: `dist.PartySharded` at world 2 and 3, every rank a separate PROCESS with its own
+   `mpe_ctx`, key object (only its parties' secrets) and `mpe_gg20_session`s on cuda:0; the round slabs travel through a
+   gloo all-gather (staged through host memory — RCCL refuses two ranks on one device); every rank's `mpe_gg20_roundN`
+   reads the gathered buffer in place through `h_in_off` and writes its records into its slot of the next buffer.
+   Signatures, R and status of every (block, party) equal the oracle's lock-step run (`orc_gg20_sign_ex`).  This is the
+   topology of the reference's deployment: one party per process, messages relayed (examples/gg20_sm_client.rs:35-40);
+ * `mpe_gg20_round1..complete` fed a slab whose sender blocks are PERMUTED and separated by garbage padding (a non-default
+   `h_in_off`): same messages, same signatures as the oracle;
+ * `mpe_gg20_session_rearm`: a second batch on the same session objects equals a fresh session's output;
+ * `bench.py --gpus 2 --share-device`: the self-spawning N>1 launch produces one JSON line with n_gpus = 2, both modes."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import fixtures as F
+import gg20_fixture as G
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dev(ctx, arr):
+    return torch.from_numpy(np.ascontiguousarray(arr).view(np.int32)).to(ctx.device)
+
+
+def _u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+# ---- Mode B, GPU engines, one process per rank ---------------------------------------------------------------------------
+def _worker(rank, world, port, t, n, signers, B, placement, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multi_party_ecdsa_amd import dist as D
+        from multi_party_ecdsa_amd import engine as E
+        ctx = E.Context(0)
+        keys = F.load_keys()
+        lk = G.make_local_keys(keys, t, n, signers)
+        S = len(signers)
+        nonces = G.make_nonces(lk, B, seed=f"modeB-gpu-{t}-{n}-{placement}")
+        blocks = world if placement == "rotated" else 1
+        Bblk = B // blocks
+
+        def block_nonces(s):
+            return {f: np.ascontiguousarray(v[s * Bblk * (v.shape[0] // B):(s + 1) * Bblk * (v.shape[0] // B)]) for f, v in nonces.items()}
+
+        class Eng:
+            writes_in_place = True
+
+            def __init__(self, s, parties):
+                # a key object with ONLY the hosted parties' secrets (the other rows of x, p, q never reach the device)
+                self.gk = E.Gg20Keys(ctx, t, n, signers, lk["arrays"], own=[signers[p] for p in parties])
+                bn = block_nonces(s)
+                mine = {}
+                for f, v in bn.items():
+                    if f == "msg":
+                        mine[f] = v
+                    else:
+                        per = v.shape[0] // (Bblk * S)
+                        mine[f] = np.ascontiguousarray(v.reshape(Bblk, S, per, v.shape[1])[:, parties].reshape(-1, v.shape[1]))
+                self.keep = {f: _dev(ctx, v) for f, v in mine.items()}
+                self.sess = E.Gg20Session(ctx, self.gk, Bblk, parties, self.keep)
+
+            def round(self, rnd, d_in, in_off, msg, out=None):
+                return self.sess.round(rnd, d_in=d_in, in_off=in_off, msg=msg, out=out)
+
+            def result(self):
+                return self.sess.result()
+
+        ps = D.PartySharded(S, Bblk, lambda rnd: E.gg20_msg_words(S, n, rnd), Eng, ctx.device, placement=placement)
+        msgs = {s: _dev(ctx, block_nonces(s)["msg"]) for s in ps.engines}
+        res = ps.run(msgs)
+        ctx.sync()
+        out = {s: {f: (_u32(v) if f in ("r", "s", "R", "bad_actors") else v.cpu().numpy()).tolist() for f, v in r.items()} for s, r in res.items()}
+        hosted = {s: parties for s, (parties, _) in ps.engines.items()}
+        q.put((rank, hosted, out, dict(ps.bytes_per_round)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(world, args):
+    import queue
+    import time
+    import torch.multiprocessing as mp
+    port = 23000 + (os.getpid() * 11 + world * 137 + len(str(args)) * 7) % 4000
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_worker, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res, t0 = [], time.time()
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > 600:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError(f"worker failed: exit codes {dead}")
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return sorted(res, key=lambda x: x[0])
+
+
+@pytest.mark.parametrize("world,t,n,signers,B,placement", [
+    (2, 1, 3, [0, 2], 4, "party"),            # one party per rank: the reference's deployment
+    (2, 1, 3, [1, 2], 6, "rotated"),          # party p of block s on rank (s + p) % 2
+    (3, 2, 5, [0, 2, 4], 3, "rotated"),       # BASELINE config 5's shape, three ranks
+    (3, 2, 4, [0, 1, 3], 2, "party"),
+])
+def test_party_sharded_gpu_engines_over_gloo(world, t, n, signers, B, placement):
+    res = _spawn(world, (t, n, signers, B, placement))
+    lk = G.make_local_keys(F.load_keys(), t, n, signers)
+    nonces = G.make_nonces(lk, B, seed=f"modeB-gpu-{t}-{n}-{placement}")
+    want = G.oracle_sign_ex(lk, nonces, B)
+    assert not want["status"].any()
+    blocks = world if placement == "rotated" else 1
+    Bblk = B // blocks
+    seen = set()
+    for rank, hosted, out, nbytes in res:
+        for s, parties in hosted.items():
+            r = out[s]
+            sl = slice(s * Bblk, (s + 1) * Bblk)
+            for li, p in enumerate(parties):
+                seen.add((s, p))
+                assert r["status"][li] == [0] * Bblk and r["bad_actors"][li] == [0] * Bblk
+                assert np.array_equal(np.array(r["r"][li], dtype=np.uint32), want["r"][sl])
+                assert np.array_equal(np.array(r["s"][li], dtype=np.uint32), want["s"][sl])
+                assert np.array_equal(np.array(r["R"][li], dtype=np.uint32), want["R"][sl])
+                assert r["recid"][li] == list(want["recid"][sl])
+        assert set(nbytes) == {0, 1, 2, 3, 4, 5, 7}
+    assert seen == {(s, p) for s in range(blocks) for p in range(len(signers))}
+
+
+# ---- non-default h_in_off: permuted sender blocks with garbage between them --------------------------------------------
+@pytest.mark.parametrize("t,n,signers,B", [(1, 3, [0, 1], 3), (2, 5, [0, 2, 4], 2)])
+def test_rounds_read_a_permuted_padded_slab_through_in_off(gpu_ctx, keys, t, n, signers, B):
+    from multi_party_ecdsa_amd import engine as E
+    lk = G.make_local_keys(keys, t, n, signers)
+    nonces = G.make_nonces(lk, B, seed=f"inoff-{t}-{n}")
+    want = G.oracle_sign_ex(lk, nonces, B)
+    S = len(signers)
+    # one object per party (each only its own secrets); the "relay" lays the senders' blocks out in REVERSE order,
+    # each preceded by a different amount of garbage records
+    parties = []
+    for i in range(S):
+        gk = E.Gg20Keys(gpu_ctx, t, n, signers, lk["arrays"], own=[signers[i]])
+        keep = {f: _dev(gpu_ctx, v) for f, v in G.party_nonces(nonces, lk, i).items()}
+        parties.append((gk, keep, E.Gg20Session(gpu_ctx, gk, B, [i], keep)))
+    gen = torch.Generator(device=gpu_ctx.device)
+    gen.manual_seed(5)
+    slab, off = None, None
+    for rnd in range(9):
+        W = E.gg20_msg_words(S, n, rnd) if rnd in G.ROUNDS else 0
+        outs = []
+        for i, (_, _, sess) in enumerate(parties):
+            o = sess.round(rnd, d_in=slab, in_off=off, msg=_dev(gpu_ctx, nonces["msg"]) if rnd == 7 else None)
+            outs.append(o)
+        if W:
+            for i in range(S):
+                assert np.array_equal(_u32(outs[i])[0], want["slabs"][rnd][i]), f"round {rnd}, party {i}"
+            pads = [3 + 2 * j for j in range(S)]                       # records of garbage in front of each block
+            total = sum(pads) + S * B + 5
+            slab = torch.randint(-2**31, 2**31 - 1, (total, W), dtype=torch.int32, device=gpu_ctx.device, generator=gen)
+            off, pos = [0] * S, 0
+            for k, j in enumerate(reversed(range(S))):                 # sender S-1 first
+                pos += pads[k]
+                off[j] = pos
+                slab[pos:pos + B] = outs[j][0]
+                pos += B
+            slab = slab.reshape(-1)
+    for i, (_, _, sess) in enumerate(parties):
+        res = sess.result()
+        gpu_ctx.sync()
+        assert not res["status"].cpu().numpy().any()
+        assert np.array_equal(_u32(res["r"])[0], want["r"]) and np.array_equal(_u32(res["s"])[0], want["s"])
+        assert list(res["recid"].cpu().numpy()[0]) == list(want["recid"])
+
+
+# ---- session re-arm -----------------------------------------------------------------------------------------------------
+def test_rearmed_session_equals_a_fresh_one(gpu_ctx, keys):
+    from multi_party_ecdsa_amd import engine as E
+    t, n, signers, B = 1, 3, [0, 2], 3
+    lk = G.make_local_keys(keys, t, n, signers)
+    S = len(signers)
+    gk = E.Gg20Keys(gpu_ctx, t, n, signers, lk["arrays"])
+    n1, n2 = G.make_nonces(lk, B, seed="rearm-1"), G.make_nonces(lk, B, seed="rearm-2")
+    w2 = G.oracle_sign_ex(lk, n2, B)
+
+    def run(sess, nn):
+        prev = None
+        slabs = {}
+        for rnd in range(9):
+            out = sess.round(rnd, d_in=prev, msg=_dev(gpu_ctx, nn["msg"]) if rnd == 7 else None)
+            if out is not None:
+                prev = out.reshape(-1)
+                slabs[rnd] = _u32(out)
+        return slabs, sess.result()
+    keep1 = {f: _dev(gpu_ctx, v) for f, v in n1.items()}
+    sess = E.Gg20Session(gpu_ctx, gk, B, list(range(S)), keep1)
+    run(sess, n1)
+    keep2 = {f: _dev(gpu_ctx, v) for f, v in n2.items()}
+    sess.rearm(keep2)
+    slabs, res = run(sess, n2)
+    gpu_ctx.sync()
+    for rnd in G.ROUNDS:
+        assert np.array_equal(slabs[rnd], w2["slabs"][rnd]), f"round {rnd} after re-arm"
+    assert not res["status"].cpu().numpy().any()
+    for i in range(S):
+        assert np.array_equal(_u32(res["r"])[i], w2["r"]) and np.array_equal(_u32(res["s"])[i], w2["s"])
+
+
+# ---- bench.py --gpus N spawns its own ranks -----------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["session", "party"])
+def test_bench_self_spawns_two_ranks(mode):
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--steps", "1", "--warmup", "1",
+           "--sessions", "256", "--mode", mode, "--no-configs", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["all_sessions_signed"] is True
+    assert len(rec["per_rank"]["signatures_per_s"]) == 2 and rec["per_rank"]["all_ranks_signed"]
+    assert abs(rec["value"] - 2 * 256 * 1 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
+    if mode == "party":
+        assert set(rec["config"]["bytes_all_gathered_per_round"]) == {"0", "1", "2", "3", "4", "5", "7"}

@@ -179,3 +179,72 @@ def test_local_key_json_roundtrip_and_key_arrays(keys):
     other["y"] = X[0]
     with pytest.raises(ValueError):
         W.local_keys_to_arrays([parsed[1], other])
+
+
+STYLES = [W.DEFAULT_STYLE, W.HEX_STYLE, W.Style(point="bytes", scalar="hex", bigint="bytes", paillier="decimal"),
+          W.Style(point="hex", scalar="bytes", bigint="hex", paillier="decimal")]
+
+
+@pytest.mark.parametrize("style", STYLES, ids=lambda s: f"{s.point}-{s.scalar}-{s.bigint}-{s.paillier}")
+def test_every_encoder_style_decodes_to_the_same_records_and_keys(keys, style):
+    """both believed serde forms of every primitive (byte arrays vs hex strings for Point / Scalar, decimal vs hex for the
+    kzen-paillier keys): whatever the encoder writes, the decoders read the same values back"""
+    t, n, signers = 1, 3, [0, 2]
+    lk = G.make_local_keys(keys, t, n, signers)
+    got = G.oracle_sign_ex(lk, G.make_nonces(lk, 1, seed="wire-style"), 1)
+    S = len(signers)
+    for rnd in G.ROUNDS:
+        for i in range(S):
+            rec = got["slabs"][rnd][i, 0]
+            parsed = [json.loads(m) for m in W.record_to_msgs(rnd, rec, S, n, i + 1, style=style)]
+            assert np.array_equal(W.bodies_to_record(rnd, [(m["receiver"], m["body"]) for m in parsed], S, n, i + 1), rec), (rnd, i)
+    body = json.loads(W.record_to_msgs(3, got["slabs"][3][0, 0], S, n, 1, style=style)[0])["body"]["M4"]
+    assert isinstance(body["g_gamma_i"]["point"], list if style.point == "bytes" else str)
+    A = lk["arrays"]
+    xs, X, y = F.ints(A["x"]), F.points(A["X"]), F.points(A["y"])[0]
+    Ns, stm = [k.N for k in lk["keys"]], [(k.Nt, k.h1, k.h2) for k in lk["keys"]]
+    for i in range(n):
+        doc = W.local_key_to_json(i + 1, t, n, lk["keys"][i].p, lk["keys"][i].q, xs[i], y, X, Ns, stm, style=style)
+        if style.paillier == "decimal":
+            assert doc["paillier_dk"]["p"].isdigit() and doc["paillier_key_vec"][0]["n"] == str(Ns[0])
+        back = W.local_key_from_json(json.dumps(doc))
+        assert (back["p"], back["q"], back["x_i"], back["y"], back["pk_vec"], back["N_vec"], back["stm_vec"]) == \
+               (lk["keys"][i].p, lk["keys"][i].q, xs[i], y, X, Ns, stm)
+
+
+def test_digit_only_decimal_key_fields_are_not_misread_as_hex(keys):
+    """kzen-paillier writes radix-10 strings; a digit-only string also parses as hex.  The decoder must pick the
+    reading in which p * q == n — for decimal documents AND for hex documents whose digits happen to be all 0-9."""
+    lk = G.make_local_keys(keys, 1, 3, [0, 1])
+    A = lk["arrays"]
+    xs, X, y = F.ints(A["x"]), F.points(A["X"]), F.points(A["y"])[0]
+    Ns, stm = [k.N for k in lk["keys"]], [(k.Nt, k.h1, k.h2) for k in lk["keys"]]
+    doc = W.local_key_to_json(2, 1, 3, lk["keys"][1].p, lk["keys"][1].q, xs[1], y, X, Ns, stm)
+    assert int(doc["paillier_dk"]["p"]) == lk["keys"][1].p and int(doc["paillier_dk"]["p"], 16) != lk["keys"][1].p
+    doc["some_future_field"] = {"ignored": True}                                      # unknown fields are tolerated
+    back = W.local_key_from_json(doc)
+    assert back["p"] == lk["keys"][1].p and back["N_vec"] == Ns
+    assert W.paillier_bigint_readings("255") == [255, 0x255] and W.paillier_bigint_readings("ff") == [255]
+    # a toy hex document whose digits are all decimal digits: 0x11 * 0x13 = 0x143
+    toy = dict(doc, paillier_dk={"p": "11", "q": "13"}, paillier_key_vec=[{"n": "99"}, {"n": "143"}, {"n": "77"}])
+    toy_back = W.local_key_from_json(toy)
+    assert (toy_back["p"], toy_back["q"], toy_back["N_vec"][1]) in ((11, 13, 143), (0x11, 0x13, 0x143))
+    bad = dict(doc, paillier_dk={"p": doc["paillier_dk"]["q"], "q": doc["paillier_dk"]["q"]})
+    with pytest.raises(ValueError):
+        W.local_key_from_json(bad)
+
+
+def test_local_share_json_shaped_like_the_reference_writes_it(keys):
+    """A document with the layout `gg20_keygen` leaves on disk (examples/gg20_keygen.rs:52-56: serde_json of
+    LocalKey<Secp256k1>, keygen/rounds.rs:311-322) in the believed curv 0.9 / kzen-paillier forms — byte arrays for points and
+    scalars, decimal strings for the Paillier key, hex strings for N~, h1, h2 — becomes the key arrays of the engine."""
+    with open(os.path.join(HERE, "golden", "local_share_like.json")) as f:
+        doc = json.load(f)
+    assert isinstance(doc["pk_vec"][0]["point"], list) and doc["paillier_dk"]["p"].isdigit() and isinstance(doc["h1_h2_n_tilde_vec"][0]["N"], str)
+    lk = W.local_key_from_json(doc)
+    assert lk["i"] == doc["i"] and lk["p"] * lk["q"] == lk["N_vec"][lk["i"] - 1]
+    arr = W.local_keys_to_arrays([lk])
+    assert arr["own"] == [lk["i"] - 1] and arr["arrays"]["X"].shape == (lk["n"], 16)
+    want = G.make_local_keys(keys, 1, 3, [0, 1])["arrays"]
+    for f in ("Nt", "h1", "h2", "y", "X"):
+        assert np.array_equal(arr["arrays"][f], want[f]), f
