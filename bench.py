@@ -70,6 +70,73 @@ def pair_modexp_macs(k, exp_words, exp2_words=0):
     return (2 * sq + 2.5 * mul) * mac(k)
 
 
+def plain_modexp_macs(k, exp_words, exp2_words=0):
+    """MACs of one fixed-window Montgomery exponentiation on k ideal 32-bit limbs with the kernel's own window rule
+    (modexp_kernel, and the pair kernel's `half` mode): one MAC(k) per squaring / multiplication"""
+    wb = window_bits(exp_words)
+    nwin = (32 * exp_words + wb - 1) // wb
+    mul = (1 << wb) + nwin + 2
+    if exp2_words:
+        mul += 16 + 8 * exp2_words + 1
+    return ((nwin - 1) * wb + mul) * mac(k)
+
+
+def fixed_base_macs(k, exp_words, fb_wb):
+    """fixed-base ladder: one Montgomery multiplication per table window, plus the conversion out"""
+    return ((32 * exp_words + fb_wb - 1) // fb_wb + 1) * mac(k)
+
+
+def secondary_rooflines(recs, elapsed):
+    """executed-MAC rate of every heavy kernel besides the dominant one, from the same HIP-event records: which share of the
+    step each takes and how far from the v_mad_u64_u32 peak it runs (same accounting as `roofline`: ideal 32-bit limbs)"""
+    groups = {
+        "pair_modexp_kernel<Cfg<1024,29,18,2>> (key holder's CRT halves modulo p^2 | q^2)":
+            ([x for x in recs if x["kind"] == 3 and x["bits"] == 2048], lambda x: pair_modexp_macs(32, x["exp_words"], x.get("exp2_words", 0))),
+        "pair_modexp_kernel<Cfg<1024,...>> half mode (x^(q mod p-1) modulo p)":
+            ([x for x in recs if x["kind"] == 4 and x["bits"] == 1024], lambda x: plain_modexp_macs(32, x["exp_words"], x.get("exp2_words", 0))),
+        "pair_modexp_kernel<Cfg<2048,...>> half mode (modulo N)":
+            ([x for x in recs if x["kind"] == 4 and x["bits"] == 2048], lambda x: plain_modexp_macs(64, x["exp_words"], x.get("exp2_words", 0))),
+        "modexp_kernel<Cfg<2048,29,18,4>> (variable base modulo N~)":
+            ([x for x in recs if x["kind"] == 0 and x["bits"] == 2048], lambda x: plain_modexp_macs(64, x["exp_words"], x.get("exp2_words", 0))),
+        "fb_modexp_kernel<Cfg<2048,29,18,4>> (h1^x, h2^x modulo N~ from window tables)":
+            ([x for x in recs if x["kind"] == 5], lambda x: fixed_base_macs(64, x["exp_words"], x.get("exp2_words", 0) or 13)),
+        "modmul_kernel (2048 / 4096 bit)":
+            ([x for x in recs if x["kind"] == 1], lambda x: mac(x["bits"] // 32)),
+    }
+    out = []
+    for name, (rs, macs) in groups.items():
+        if not rs:
+            continue
+        t = sum(x["ms"] for x in rs) * 1e-3
+        m = sum(x["batch"] * macs(x) for x in rs)
+        out.append({"kernel": name, "launches": len(rs), "seconds": t, "time_share_of_step": t / elapsed, "executed_TMAC_per_s": m / t / 1e12 if t else None,
+                    "frac": m / t / PEAK_MAC_PER_S if t else None})
+    return out
+
+
+def executed_macs(recs):
+    """32x32+64 MACs (ideal 32-bit limbs) of every profiled heavy launch: the whole-step companion of `roofline`"""
+    tot = 0.0
+    for x in recs:
+        k, b, ew, e2 = x["kind"], x["bits"], x["exp_words"], x.get("exp2_words", 0)
+        if k == 3:
+            tot += x["batch"] * pair_modexp_macs(b // 64, ew, e2)
+        elif k in (0, 4):
+            tot += x["batch"] * plain_modexp_macs(b // 32, ew, e2)
+        elif k == 5:
+            tot += x["batch"] * fixed_base_macs(b // 32, ew, e2 or 13)
+        elif k == 1:
+            tot += x["batch"] * mac(b // 32)
+    return tot
+
+
+def whole_step(recs, wall_s):
+    m = executed_macs(recs)
+    return {"executed_TMAC_per_s": m / wall_s / 1e12, "frac": m / wall_s / PEAK_MAC_PER_S, "heavy_kernel_seconds": sum(x["ms"] for x in recs) * 1e-3,
+            "wall_seconds": wall_s, "note": "all modexp / modmul launches of the pass (executed MACs on ideal 32-bit limbs) / wall time / peak; "
+                                            "EC, hashing, packing and idle gaps count as time only"}
+
+
 def sig_macs(S, n):
     """algorithmic MACs per signature, faithful path"""
     b2048 = n * 6400 + 2 * (S - 1) * n * 3842 + 2 * (S - 1) * 2048 + (S - 1) * 6400 + S * (S - 1) * 3843
@@ -256,8 +323,13 @@ def config3(ctx, E, keys, F, B=262144, prefix=4096, threads=None, oracle=True):
     small = {f: v[:256] for f, v in nonces.items()}
     E.pdl_verify(ctx, pub, stm, c[:256], Qp[:256], Gp[:256], E.pdl_prove(ctx, pk, stm, c[:256], Qp[:256], Gp[:256], x[:256], rr[:256], small,
                                                                          kidx[:256], sidx[:256]), kidx[:256], sidx[:256])
+    ctx.prof_enable(True)
     t_prove, pr = timed(lambda: E.pdl_prove(ctx, pk, stm, c, Qp, Gp, x, rr, nonces, kidx, sidx))
+    rec_prove = ctx.prof_collect(4096)
+    ctx.prof_enable(True)                                                            # (re-arming clears the records)
     t_ver, ok = timed(lambda: E.pdl_verify(ctx, pub, stm, c, Qp, Gp, pr, kidx, sidx))
+    rec_ver = ctx.prof_collect(4096)
+    ctx.prof_enable(False)
     accepted = int(ok.sum())
     bad = {k: v.clone() for k, v in pr.items()}
     fields = ["z", "u2", "u3", "s1", "s2", "s3"]
@@ -272,7 +344,8 @@ def config3(ctx, E, keys, F, B=262144, prefix=4096, threads=None, oracle=True):
         mask[q_ * 100 + 7:B:600] = True
     out = {"instances": B, "keys": K, "ec_fixed_per_s": B / t_fix, "ec_var_per_s": B / t_var, "pdl_prove_per_s": B / t_prove,
            "pdl_verify_per_s": B / t_ver, "accepted": accepted, "accept_rate": accepted / B,
-           "corrupted": int(nbad), "corrupted_1pct_all_rejected": bool((okb[mask] == 0).all() and (okb[~mask] == 1).all())}
+           "corrupted": int(nbad), "corrupted_1pct_all_rejected": bool((okb[mask] == 0).all() and (okb[~mask] == 1).all()),
+           "pdl_prove_whole_step": whole_step(rec_prove, t_prove), "pdl_verify_whole_step": whole_step(rec_ver, t_ver)}
     if oracle:
         n = min(prefix, B)
         threads = threads or min(host_cores()[0], 64)
@@ -314,6 +387,85 @@ def openssl_verify_all(y_words, msg, r, s, threads):
     return {"openssl_verified": int(ok.sum()), "of": int(ok.shape[0]), "openssl": ossl.version(), "seconds": round(time.time() - t0, 2)}
 
 
+def bob_section(ctx, E, keys, F, B=65536, prefix=1024, oracle=True, threads=None):
+    """The Bob-side MtA range proof as a measured workload (SURVEY.md 8a row a24: `BobProof::generate` / `BobProofExt::verify`,
+    range_proofs.rs:321-534 — not called by the GG20 state machine, so no other section times it): B instances over K = 16
+    (ek, N~, h1, h2) tuples with check = true (the `u = alpha G` / `s1 G = e X + u` extension included), nonces in the reference's
+    ranges (:231-237); a prefix compared with the oracle bit for bit, every honest proof accepted, 1 % corrupted all rejected."""
+    import orc
+    dev = ctx.device
+    K = len(keys)
+    g = torch.Generator(device=dev)
+    g.manual_seed(24)
+    pub = E.PaillierKeys(ctx, N=[k.N for k in keys])                                  # Bob only has Alice's public key
+    stm = E.Statements(ctx, [k.Nt for k in keys], [k.h1 for k in keys], [k.h2 for k in keys])
+    kidx = (torch.arange(B, device=dev, dtype=torch.int32) % K).contiguous()
+    sidx = ((torch.arange(B, device=dev, dtype=torch.int32) * 5 + 1) % K).contiguous()
+    a = rand_words(g, dev, B, 64, 7)
+    b = rand_words(g, dev, B, 8, 7)
+    beta_prim = rand_words(g, dev, B, 64, 63)
+    r = rand_words(g, dev, B, 64, 63)
+    a_enc = pub.encrypt_device(a, rand_words(g, dev, B, 64, 63), kidx)
+    mta = pub.add_device(pub.mul_device(a_enc, b, kidx), pub.encrypt_device(beta_prim, r, kidx), kidx)     # c_a^b * Enc(beta'; r), mta/mod.rs:133-145
+    nonces = dict(alpha=rand_words(g, dev, B, 24, 23), beta=rand_words(g, dev, B, 64, 63), gamma=rand_words(g, dev, B, 80, 79),
+                  rho=rand_words(g, dev, B, 72, 71), rho_prim=rand_words(g, dev, B, 88, 87), sigma=rand_words(g, dev, B, 72, 71),
+                  tau=rand_words(g, dev, B, 88, 87))
+    X = E.ec_mul_base(ctx, b)
+    sm = lambda d_, n_: {f: v[:n_] for f, v in d_.items()}
+    pr0, u0 = E.bob_generate(ctx, pub, stm, a_enc[:256], mta[:256], b[:256], beta_prim[:256], r[:256], sm(nonces, 256), True, kidx[:256], sidx[:256])
+    E.bob_verify(ctx, pub, stm, a_enc[:256], mta[:256], pr0, X[:256], u0, kidx[:256], sidx[:256])            # warm-up
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out
+    ctx.prof_enable(True)
+    t_gen, (pr, u) = timed(lambda: E.bob_generate(ctx, pub, stm, a_enc, mta, b, beta_prim, r, nonces, True, kidx, sidx))
+    rec_gen = ctx.prof_collect(4096)
+    ctx.prof_enable(True)
+    t_ver, ok = timed(lambda: E.bob_verify(ctx, pub, stm, a_enc, mta, pr, X, u, kidx, sidx))
+    rec_ver = ctx.prof_collect(4096)
+    ctx.prof_enable(False)
+    accepted = int(ok.sum())
+    bad = {k_: v.clone() for k_, v in pr.items()}
+    fields = ["t", "z", "e", "s", "s1", "s2", "t1", "t2"]
+    mask = np.zeros(B, dtype=bool)
+    for q_, f in enumerate(fields):                                                   # 1 %: every 100th proof, a different field each time
+        bad[f][q_ * 100 + 3:B:800, 1] ^= 0x20
+        mask[q_ * 100 + 3:B:800] = True
+    okb = E.bob_verify(ctx, pub, stm, a_enc, mta, bad, X, u, kidx, sidx).cpu().numpy()
+    out = {"instances": B, "keys": K, "check": True, "bob_generate_per_s": B / t_gen, "bob_verify_ext_per_s": B / t_ver, "accepted": accepted,
+           "accept_rate": accepted / B, "corrupted": int(mask.sum()), "corrupted_1pct_all_rejected": bool((okb[mask] == 0).all() and (okb[~mask] == 1).all()),
+           "generate_whole_step": whole_step(rec_gen, t_gen), "verify_whole_step": whole_step(rec_ver, t_ver)}
+    if oracle:
+        n_ = min(prefix, B)
+        threads = threads or min(host_cores()[0], 64)
+        h = lambda t_: np.ascontiguousarray(t_[:n_].cpu().numpy().view(np.uint32))
+        tabs = dict(N=F.words([k.N for k in keys], 64), Nt=F.words([k.Nt for k in keys], 64), h1=F.words([k.h1 for k in keys], 64),
+                    h2=F.words([k.h2 for k in keys], 64))
+        hin = dict(a_enc=h(a_enc), mta=h(mta), b=h(b), bp=h(beta_prim), r=h(r), X=h(X), **{f: h(v) for f, v in nonces.items()})
+        ki, si = kidx[:n_].cpu().numpy(), sidx[:n_].cpu().numpy()
+        got, gu = {f: h(v) for f, v in pr.items()}, h(u)
+        chunks = [c_ for c_ in np.array_split(np.arange(n_), threads) if len(c_)]
+
+        def run(ix):
+            sl = slice(int(ix[0]), int(ix[-1]) + 1)
+            want, wu = orc.bob_generate(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], ki[sl], si[sl], hin["a_enc"][sl], hin["mta"][sl], hin["b"][sl],
+                                        hin["bp"][sl], hin["r"][sl], hin["alpha"][sl], hin["beta"][sl], hin["gamma"][sl], hin["rho"][sl],
+                                        hin["rho_prim"][sl], hin["sigma"][sl], hin["tau"][sl], True)
+            good = all(np.array_equal(got[f][sl], want[f]) for f in want) and np.array_equal(gu[sl], wu)
+            okv = orc.bob_verify(tabs["N"], tabs["Nt"], tabs["h1"], tabs["h2"], ki[sl], si[sl], hin["a_enc"][sl], hin["mta"][sl], want, hin["X"][sl], wu)
+            return good and bool(np.all(okv))
+        t0 = time.time()
+        with ThreadPoolExecutor(threads) as ex:
+            res = list(ex.map(run, chunks))
+        out.update({"parity_prefix": n_, "parity_vs_oracle_on_prefix": bool(all(res)), "oracle_generate_verify_per_s": n_ / (time.time() - t0),
+                    "oracle_threads": threads})
+    return out
+
+
 def gg20_config(ctx, E, G, keys, t, n, B, steps, gen, parity_sample=0, threads=None, openssl=False):
     """one more GG20 shape on this GPU: sessions/s over `steps` passes of B sessions, optional parity sample vs the oracle"""
     dev = ctx.device
@@ -324,13 +476,17 @@ def gg20_config(ctx, E, G, keys, t, n, B, steps, gen, parity_sample=0, threads=N
     nonces = make_device_nonces(gen, dev, B, S, S, n)
     out = E.gg20_sign(ctx, gk, nonces, B)
     torch.cuda.synchronize()
+    ctx.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         out = E.gg20_sign(ctx, gk, nonces, B)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    recs = ctx.prof_collect(16384)
+    ctx.prof_enable(False)
     r, s, recid, status = [o.cpu().numpy() for o in out]
-    res = {"sessions": B, "t": t, "n": n, "signatures_per_s": B / dt, "ms_per_batch": dt * 1e3, "all_sessions_signed": bool((status == 0).all())}
+    res = {"sessions": B, "t": t, "n": n, "signatures_per_s": B / dt, "ms_per_batch": dt * 1e3, "all_sessions_signed": bool((status == 0).all()),
+           "whole_step": whole_step(recs, dt * steps)}
     if parity_sample:
         threads = threads or min(host_cores()[0], 64)
         hn = _host({f: v[: parity_sample * (v.shape[0] // B)] for f, v in nonces.items()})
@@ -681,6 +837,8 @@ def main():
             "breakdown": {"modexp4096_s_per_step": dom_s / args.steps, "modexp2048_s_per_step": sec_s / args.steps,
                           "heavy_kernels_s_per_step": heavy_s / args.steps, "wall_s_per_step": elapsed / args.steps,
                           "alg_unit_mac_per_signature": sig_macs(S, n), "fb_window_bits": gk.fb_window_bits()},
+            "roofline_secondary": secondary_rooflines(recs, elapsed),
+            "whole_step": whole_step(recs, elapsed),
             "all_sessions_signed": all_signed, "launch": ctx.launch_info(),
         }
         if distributed:
@@ -723,6 +881,7 @@ def main():
                 took[name] = round(time.perf_counter() - t_, 2)
             section("c2_paillier_65536", lambda: paillier_config2(ctx, E, keys, F, oracle_threads=0 if args.no_cpu_baseline else threads))
             section("c3_ec_pdl_262144", lambda: config3(ctx, E, keys, F, oracle=not args.no_cpu_baseline))
+            section("c3b_bob_65536", lambda: bob_section(ctx, E, keys, F, oracle=not args.no_cpu_baseline))
             section("c4_literal_1024", lambda: gg20_config(ctx, E, G, keys, 1, 3, 1024, 4, gen, parity_sample=0 if args.no_cpu_baseline else 128,
                                                            openssl=True))
             section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32,

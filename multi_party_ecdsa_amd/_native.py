@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpecdsa_hip.so")
+# MPE_LIB_PATH: another build of the SAME library (A/B measurements of kernel variants, tools/ab.sh); never a different backend
+LIB_PATH = os.environ.get("MPE_LIB_PATH") or os.path.join(_HERE, "libmpecdsa_hip.so")
 
 MPE_OK, MPE_E_ARG, MPE_E_HIP, MPE_E_NOMEM = 0, -1, -2, -3
 

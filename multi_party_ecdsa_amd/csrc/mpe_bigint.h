@@ -36,6 +36,13 @@ struct Cfg {
   static constexpr int K = L_ * TPI_;       // internal limbs per integer
   static constexpr int GROUPS = 64 / TPI_;  // integers per wave
   static constexpr uint32_t MASK = (1u << W_) - 1u;
+  // outer CIOS steps of the N-adic pair engine (mpe_pairexp.h): R = 2^(W STEPS) only has to exceed 8N, and a multiplier
+  // < 2N has no limbs beyond that — 71 of the 72 limbs for 2048-bit moduli (29 x 71 = 2059 bits), all 36 for 1024 bit
+#ifdef MPE_FULL_STEPS                           // A/B switch: one step per limb, R = 2^(W K)
+  static constexpr int STEPS = L_ * TPI_;
+#else
+  static constexpr int STEPS = (BITS_ + 3 + W_ - 1) / W_;
+#endif
   static_assert(W_ * L_ * TPI_ >= BITS_ + 2, "R must exceed 4N");
   static_assert(K >= K32 + 2, "staging region reuse");
   // LDS words per group: K limbs + padding, chosen so the groups of one 32-lane half hit

@@ -15,6 +15,7 @@
 // 8 K^2 for the Montgomery multiplication of the 2K-limb integers.  The residues produced are the same numbers
 // mpz_powm returns: the pair is converted back (multiply by (1, 0), normalise, z0 + z1 N) at the end.
 #pragma once
+#include <type_traits>
 #include "mpe_internal.h"
 #include "mpe_small.h"
 
@@ -70,8 +71,34 @@ __device__ __forceinline__ void cios_tail(uint32_t (&res)[C::L], const uint64_t 
   res[1] += (uint32_t)(cin >> W) + (v0 >> W);
 }
 
+// After STEPS = K - 1 outer steps the rotating column names are one position short of a full turn: logical column i sits in
+// c[(L - 1 + i) % L].  (A renaming: no instruction.)
+template <class C>
+__device__ __forceinline__ void cios_finish(uint32_t (&res)[C::L], const uint64_t (&c)[C::L], const Lane& ln) {
+  static_assert(C::STEPS == C::K || C::STEPS == C::K - 1, "the pair engine runs K or K - 1 outer steps");
+  if constexpr (C::STEPS == C::K) {
+    cios_tail<C>(res, c, ln);
+  } else {
+    uint64_t cc[C::L];
+#pragma unroll
+    for (int i = 0; i < C::L; ++i) cc[i] = c[(C::L - 1 + i) % C::L];
+    cios_tail<C>(res, cc, ln);
+  }
+}
+
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, N) — the CIOS steps name their registers by the step index
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 // One CIOS pass with ONE product stream:  res = (c_in + a * b + m n) / R,  quotient digits m_j stored to ml[j].
 // (montmul of mpe_bigint.h with pre-loaded columns and the digits kept.)
+// STEPS = K - 1 (2048-bit moduli): the last trip ends after L - 1 steps, and that is the loop's ONLY exit — the column names
+// have one rotation state there (cios_finish), nothing for the compiler to reconcile.
 template <class C, bool STORE_M>
 __device__ __forceinline__ void cios1(uint32_t (&res)[C::L], uint64_t (&c)[C::L], const uint32_t (&a)[C::L],
                                       const uint32_t* __restrict__ bl, uint32_t* __restrict__ ml,
@@ -80,11 +107,11 @@ __device__ __forceinline__ void cios1(uint32_t (&res)[C::L], uint64_t (&c)[C::L]
   uint32_t maskv = C::MASK;
   asm volatile("" : "+v"(maskv));
 #pragma unroll 1
-  for (int jj = 0; jj < C::TPI; ++jj) {
+  for (int jj = 0;; ++jj) {
     const uint32_t* bp = bl + jj * L;
     uint32_t* mp = ml + jj * L;
-#pragma unroll
-    for (int r = 0; r < L; ++r) {
+    auto step = [&](auto rc) {
+      constexpr int r = decltype(rc)::value;
       const uint32_t bj = bp[r];
       c[r] += (uint64_t)a[0] * bj;
       const uint32_t m = bcast0_masked<C::TPI>((uint32_t)c[r] * n0inv, maskv);
@@ -95,9 +122,13 @@ __device__ __forceinline__ void cios1(uint32_t (&res)[C::L], uint64_t (&c)[C::L]
       for (int i = 0; i < L; ++i) c[(r + i) % L] += (uint64_t)m * n[i];
       c[(r + 1) % L] += c[r] >> W;
       c[r] = (uint64_t)(pull_next((uint32_t)c[r]) & maskv);
-    }
+    };
+    static_for<0, L - 1>(step);
+    if (C::STEPS < C::K && jj == C::TPI - 1) break;          // step K - 1 does not exist: R = 2^(W STEPS)
+    step(std::integral_constant<int, L - 1>{});
+    if (C::STEPS == C::K && jj == C::TPI - 1) break;
   }
-  cios_tail<C>(res, c, ln);
+  cios_finish<C>(res, c, ln);
 }
 
 // One CIOS pass with TWO product streams:  res = (c_in + a0 * b1 + a1 * b0 + m n) / R
@@ -110,11 +141,11 @@ __device__ __forceinline__ void cios2(uint32_t (&res)[C::L], uint64_t (&c)[C::L]
   uint32_t maskv = C::MASK;
   asm volatile("" : "+v"(maskv));
 #pragma unroll 1
-  for (int jj = 0; jj < C::TPI; ++jj) {
+  for (int jj = 0;; ++jj) {
     const uint32_t* bp0 = bl0 + jj * L;
     const uint32_t* bp1 = bl1 + jj * L;
-#pragma unroll
-    for (int r = 0; r < L; ++r) {
+    auto step = [&](auto rc) {
+      constexpr int r = decltype(rc)::value;
       const uint32_t b0j = bp0[r], b1j = bp1[r];
       c[r] += (uint64_t)a0[0] * b1j;
       c[r] += (uint64_t)a1[0] * b0j;
@@ -128,9 +159,13 @@ __device__ __forceinline__ void cios2(uint32_t (&res)[C::L], uint64_t (&c)[C::L]
       for (int i = 0; i < L; ++i) c[(r + i) % L] += (uint64_t)m * n[i];
       c[(r + 1) % L] += c[r] >> W;
       c[r] = (uint64_t)(pull_next((uint32_t)c[r]) & maskv);
-    }
+    };
+    static_for<0, L - 1>(step);
+    if (C::STEPS < C::K && jj == C::TPI - 1) break;          // step K - 1 does not exist: R = 2^(W STEPS)
+    step(std::integral_constant<int, L - 1>{});
+    if (C::STEPS == C::K && jj == C::TPI - 1) break;
   }
-  cios_tail<C>(res, c, ln);
+  cios_finish<C>(res, c, ln);
 }
 
 // (r0, r1) = (a0, a1) * (y0, y1) R^-1 in Z/N^2.  The group's LDS region holds y0 in B0 and y1 in B1; for a squaring
@@ -154,7 +189,11 @@ __device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::
     return;
   }
 #pragma unroll
-  for (int i = 0; i < L; ++i) c[i] = (uint64_t)(gl[PL::KC + ln.t * L + i] - gl[PL::M + ln.t * L + i]);
+  for (int i = 0; i < L; ++i) {
+    uint32_t mi = gl[PL::M + ln.t * L + i];
+    if (C::STEPS < C::K && i == L - 1) mi = (ln.t == C::TPI - 1) ? 0u : mi;      // there is no digit m_(K-1)
+    c[i] = (uint64_t)(gl[PL::KC + ln.t * L + i] - mi);
+  }
   wave_lds_sync();
   // u waits in the M region (its digits are consumed) so that pass B does not carry 18 more live registers
 #pragma unroll
@@ -216,7 +255,7 @@ __global__ void __launch_bounds__(64) pairset_setup_kernel(int count, const uint
       dst[(size_t)idx * 2 * C::K + C::K + ln.t * C::L + i] = (uint32_t)x1[i];
     }
   };
-  constexpr int WK = C::W * C::K;
+  constexpr int WK = C::W * C::STEPS;          // R = 2^WK: the radix the CIOS passes divide by
 #pragma unroll 1
   for (int d = 1; d <= 2 * WK; ++d) {
     // (x0, x1) <- 2 (x0, x1):  x0 = 2 x0 [- N, carry 1];  x1 = 2 x1 + carry [- N]
@@ -309,7 +348,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     {
       const uint32_t* kc = ps.kc + (size_t)mi * C::K;         // K_c + (R - 1), limb-wise, stays in LDS for the item
 #pragma unroll
-      for (int i = 0; i < C::L; ++i) gl[PL::KC + ln.t + C::TPI * i] = kc[ln.t + C::TPI * i] + C::MASK;
+      for (int i = 0; i < C::L; ++i)                          // R - 1 is all-ones over STEPS limbs
+        gl[PL::KC + ln.t + C::TPI * i] = kc[ln.t + C::TPI * i] + ((ln.t + C::TPI * i) < C::STEPS ? C::MASK : 0u);
       uint32_t t0[C::L], t1[C::L];                            // tab[0] = the form of 1
       load_owner<C>(t0, ps.one + (size_t)mi * K2, ln);
       load_owner<C>(t1, ps.one + (size_t)mi * K2 + C::K, ln);
@@ -330,6 +370,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll 1
     while (ph != PP_DONE) {
       bool sq = false;
+#ifdef MPE_TOUCH_ROW
+      // A/B variant (profiles/r03: no measurable gain, the kernel is issue-bound): during the squaring that precedes a table
+      // multiplication, pull the row it will read towards the CU with two loads whose result is only kept alive
+      uint32_t touch = 0;
+      if (ph == PP_SQ && ((b - 1) % wb) == 0) {
+        const volatile uint32_t* rowp = tab + (size_t)exp_window(ex, exp_words, (b - 1) / wb, wb) * K2;
+        touch = rowp[(ln.t & 3) * (K2 / 4)] ^ rowp[K2 - 1 - (ln.t & 3) * 4];   // one word in (almost) every 128-byte line of the row
+      }
+#endif
       // ---- multiplier pair -> LDS ----
       if (ph == PP_IN) {
         copy_pair_to_lds<C>(gl, ps.tp + (size_t)mi * K2, ln);
@@ -360,6 +409,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       uint32_t r0[C::L], r1[C::L];
       pairmul<C>(r0, r1, cur0, cur1, gl, n, n0inv, sq, half != 0, ln);
       wave_lds_sync();
+#ifdef MPE_TOUCH_ROW
+      asm volatile("" ::"v"(touch));
+#endif
 #pragma unroll
       for (int i = 0; i < C::L; ++i) { cur0[i] = r0[i]; cur1[i] = r1[i]; }
 

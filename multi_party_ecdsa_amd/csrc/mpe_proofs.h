@@ -44,7 +44,9 @@ static int launch_fb_modexp(mpe_ctx* ctx, const mpe_statements* stm, int B, Rows
   ModsetView v;
   v.n_limbs = stm->ms->n_limbs; v.one_limbs = stm->ms->one_limbs; v.r2_limbs = stm->ms->r2_limbs;
   v.r2h_limbs = stm->ms->r2h_limbs; v.n0inv = stm->ms->n0inv; v.count = stm->ms->count;
+  prof_begin(ctx, st, 5, C::BITS, ew, B, stm->fb_wb);          // kind 5: fixed-base ladder; exp2_words carries the window width
   hipLaunchKernelGGL(fb_modexp_kernel<C>, dim3(grid), dim3(64), 0, st, B, v, st_sel, which, stm->fb_tab, stm->fb_wb, exps, ew, out);
+  prof_end(ctx, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("fb_modexp_kernel", e); return MPE_E_HIP; }
   return MPE_OK;

@@ -133,6 +133,8 @@ class PartySharded:
             e1.record()
             self._events.append((e0, e1))
             return
+        if cuda:
+            torch.cuda.synchronize(buf.device)       # the wait for the round's kernels is not communication time
         t0 = time.perf_counter()
         if cuda:                                     # gloo with GPU engines: through host memory
             h_out = torch.empty(buf.shape, dtype=buf.dtype)
