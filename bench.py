@@ -57,14 +57,52 @@ def window_bits(exp_words):
     return 4 if exp_words <= 8 else (5 if exp_words < 48 else 6)       # the library's rule (mpe_lib.hip)
 
 
-def pair_modexp_macs(k, exp_words, exp2_words=0):
+_SLIDING = {}
+
+
+def sliding_counts(bits, wb):
+    """(squarings, window multiplications) of the kernel's left-to-right sliding-window schedule (mpe_pairexp.h slide_window),
+    averaged over 32 seeded exponents of `bits` bits with the top bit set — the public exponents are RSA moduli N"""
+    if (bits, wb) not in _SLIDING:
+        import random
+        rnd = random.Random(2048)
+        sq_t = mul_t = 0
+        for _ in range(32):
+            e = rnd.getrandbits(bits) | (1 << (bits - 1)) | 1
+            i, first, sq, mul = bits - 1, True, 0, 0
+            while i >= 0:
+                if not (e >> i) & 1:
+                    i -= 1
+                    sq += 1
+                    continue
+                lo = max(i - wb + 1, 0)
+                while not (e >> lo) & 1:
+                    lo += 1
+                if not first:
+                    sq += i - lo + 1
+                    mul += 1
+                first = False
+                i = lo - 1
+            sq_t += sq
+            mul_t += mul
+        _SLIDING[(bits, wb)] = (sq_t / 32, mul_t / 32)
+    return _SLIDING[(bits, wb)]
+
+
+def pair_modexp_macs(k, exp_words, exp2_words=0, sliding=False):
     """32x32->64 MACs of ONE exponentiation modulo a square N^2 in the N-adic pair arithmetic the kernel runs
     (mpe_pairexp.h), counted on k 32-bit limbs of N (the ideal radix): a squaring is 2 half-size Montgomery passes
-    (2 MAC(k)), a multiplication 2.5; fixed windows as the kernel chooses them."""
+    (2 MAC(k)), a multiplication 2.5.  Fixed windows as the kernel chooses them; sliding=True: the schedule it runs for the
+    PUBLIC exponent N (odd powers only in the table: one squaring + 2^(wb-1) - 1 multiplications; expected window count)."""
     wb = window_bits(exp_words)
-    nwin = (32 * exp_words + wb - 1) // wb
-    sq = (nwin - 1) * wb
-    mul = (1 << wb) + nwin + 2                      # table (with the conversion in), one per window, conversion out
+    if sliding:
+        sq, win = sliding_counts(32 * exp_words, wb)
+        sq += 1                                     # x^2 for the table of odd powers
+        mul = (1 << (wb - 1)) - 1 + win + 2         # x^3 .. x^(2^wb - 1), the windows, conversion in and out
+    else:
+        nwin = (32 * exp_words + wb - 1) // wb
+        sq = (nwin - 1) * wb
+        mul = (1 << wb) + nwin + 2                  # table (with the conversion in), one per window, conversion out
     if exp2_words:
         mul += 16 + 8 * exp2_words + 1
     return (2 * sq + 2.5 * mul) * mac(k)
@@ -91,7 +129,7 @@ def secondary_rooflines(recs, elapsed):
     step each takes and how far from the v_mad_u64_u32 peak it runs (same accounting as `roofline`: ideal 32-bit limbs)"""
     groups = {
         "pair_modexp_kernel<Cfg<1024,29,18,2>> (key holder's CRT halves modulo p^2 | q^2)":
-            ([x for x in recs if x["kind"] == 3 and x["bits"] == 2048], lambda x: pair_modexp_macs(32, x["exp_words"], x.get("exp2_words", 0))),
+            ([x for x in recs if x["kind"] in (3, 6) and x["bits"] == 2048], lambda x: pair_modexp_macs(32, x["exp_words"], x.get("exp2_words", 0), sliding=x["kind"] == 6)),
         "pair_modexp_kernel<Cfg<1024,...>> half mode (x^(q mod p-1) modulo p)":
             ([x for x in recs if x["kind"] == 4 and x["bits"] == 1024], lambda x: plain_modexp_macs(32, x["exp_words"], x.get("exp2_words", 0))),
         "pair_modexp_kernel<Cfg<2048,...>> half mode (modulo N)":
@@ -119,8 +157,8 @@ def executed_macs(recs):
     tot = 0.0
     for x in recs:
         k, b, ew, e2 = x["kind"], x["bits"], x["exp_words"], x.get("exp2_words", 0)
-        if k == 3:
-            tot += x["batch"] * pair_modexp_macs(b // 64, ew, e2)
+        if k in (3, 6):
+            tot += x["batch"] * pair_modexp_macs(b // 64, ew, e2, sliding=k == 6)
         elif k in (0, 4):
             tot += x["batch"] * plain_modexp_macs(b // 32, ew, e2)
         elif k == 5:
@@ -252,7 +290,8 @@ def paillier_config2(ctx, E, keys, F, steps=1, oracle_threads=0, oracle_items=0)
     t_pub = timed(lambda: pk.encrypt_device(m, rr, idx, c2))
     recs = ctx.prof_collect()
     ctx.prof_enable(False)
-    kern = float(np.mean([r["ms"] for r in recs if r["kind"] in (0, 3) and r["bits"] == 4096])) * 1e-3
+    kern = float(np.mean([r["ms"] for r in recs if r["kind"] in (0, 3, 6) and r["bits"] == 4096])) * 1e-3
+    c2_sliding = any(r["kind"] == 6 for r in recs)
     cpu = {}
     if oracle_threads:
         # the reference CPU path beside it: the GMP oracle (reference formulas over mpz_powm) on a bounded prefix, bit-exact check included
@@ -282,8 +321,8 @@ def paillier_config2(ctx, E, keys, F, steps=1, oracle_threads=0, oracle_items=0)
             "roundtrip_ok": bool(torch.equal(back, m)), "holder_equals_public_ciphertext": bool(torch.equal(c, c2)),
             "encrypt_per_s": B / t_enc, "decrypt_per_s": B / t_dec, "encrypt_public_key_per_s": B / t_pub,
             "modexp4096_2048_per_s": B / kern,
-            "modexp4096_executed_TMAC_per_s": B * pair_modexp_macs(64, 64) / kern / 1e12,
-            "modexp4096_executed_frac": B * pair_modexp_macs(64, 64) / kern / PEAK_MAC_PER_S,
+            "modexp4096_executed_TMAC_per_s": B * pair_modexp_macs(64, 64, sliding=c2_sliding) / kern / 1e12,
+            "modexp4096_executed_frac": B * pair_modexp_macs(64, 64, sliding=c2_sliding) / kern / PEAK_MAC_PER_S, "modexp4096_sliding_windows": c2_sliding,
             "modexp4096_alg_unit_TMAC_per_s": B * modexp_macs(128, 2048) / kern / 1e12}
 
 
@@ -771,9 +810,9 @@ def main():
         r, s, recid, status = [o.cpu().numpy() for o in out]
         all_signed = bool((status == 0).all())
         # roofline of the dominant kernel: every launch modulo N^2 (4096 bit) of the timed region
-        dom = [x for x in recs if x["kind"] in (0, 3) and x["bits"] == 4096]
+        dom = [x for x in recs if x["kind"] in (0, 3, 6) and x["bits"] == 4096]
         dom_s = sum(x["ms"] for x in dom) * 1e-3
-        pair = bool(dom) and all(x["kind"] == 3 for x in dom)
+        pair = bool(dom) and all(x["kind"] in (3, 6) for x in dom)
         # a two-base launch (mpe_modexp2 pattern) does the algorithmic work of both exponentiations
         def rec_macs(x, k):
             m = modexp_macs(k, EXP_BITS.get(x["exp_words"], 32 * x["exp_words"]))
@@ -782,8 +821,9 @@ def main():
             return x["batch"] * m
         dom_macs = sum(rec_macs(x, 128) for x in dom)
         # the MACs the executed algorithm needs (N-adic pairs: half-size passes) — what the hardware is asked to do
-        exe_macs = sum(x["batch"] * pair_modexp_macs(64, x["exp_words"], x.get("exp2_words", 0)) for x in dom) if pair else dom_macs
-        sec = [x for x in recs if x["kind"] in (0, 3) and x["bits"] == 2048]
+        exe_macs = sum(x["batch"] * pair_modexp_macs(64, x["exp_words"], x.get("exp2_words", 0), sliding=x["kind"] == 6) for x in dom) if pair else dom_macs
+        n_sliding = sum(1 for x in dom if x["kind"] == 6)
+        sec = [x for x in recs if x["kind"] in (0, 3, 6) and x["bits"] == 2048]
         sec_s = sum(x["ms"] for x in sec) * 1e-3
         heavy_s = sum(x["ms"] for x in recs) * 1e-3
         value = B * world * args.steps / elapsed
@@ -823,7 +863,7 @@ def main():
                          "traffic": traffic, "traffic_unit": f"HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
                          "kernel": ("mpe::pair_modexp_kernel<Cfg<2048,29,18,4>>" if pair else "mpe::modexp_kernel<Cfg<4096,29,18,8>>") +
                                    " (all launches modulo N^2 of the timed region)",
-                         "launches": len(dom), "avg_kernel_ms": dom_s / nl * 1e3,
+                         "launches": len(dom), "launches_on_sliding_windows": n_sliding, "avg_kernel_ms": dom_s / nl * 1e3,
                          "executed_mac_per_launch": exe_macs / nl, "alg_unit_mac_per_launch": dom_macs / nl,
                          "kernel_time_share_of_step": dom_s / elapsed,
                          # the issue ceiling actually measured for this instruction (tools/ubench/valu_rate.hip): a stream of

@@ -476,7 +476,8 @@ int mpe_last_launch_info(const mpe_ctx* ctx, mpe_launch_info* out);
 /* Per-launch timing of the heavy kernels with HIP events recorded on the launch stream (used by
  * bench.py for the roofline line).  kind: 0 = modexp kernel (bits = modulus width), 1 = modmul kernel, 3 = N-adic pair kernel
  * (bits = width of the SQUARE: 4096 for N^2, 2048 for p^2 | q^2), 4 = the pair kernel in `half` mode (plain Montgomery ladder
- * modulo N or p; bits = that width), 5 = fixed-base ladder modulo N~ (exp2_words = the table's window width in bits). */
+ * modulo N or p; bits = that width), 5 = fixed-base ladder modulo N~ (exp2_words = the table's window width in bits),
+ * 6 = the pair kernel with a PUBLIC exponent (the key N): items ordered by key, sliding windows wherever a wave shares it. */
 typedef struct { int kind; int bits; int exp_words; int batch; float ms; int exp2_words; } mpe_prof_rec;  /* exp2_words != 0: mpe_modexp2-style launch */
 int mpe_prof_enable(mpe_ctx* ctx, int on);       /* clears earlier records */
 int mpe_prof_collect(mpe_ctx* ctx, mpe_prof_rec* out, int max_records, int* n_out);  /* waits for the events */

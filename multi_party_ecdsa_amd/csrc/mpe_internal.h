@@ -22,6 +22,7 @@ struct mpe_ctx {
   bool use_multiexp = true;       // verifiers: s^N * (c^-1)^e on one ladder instead of two exponentiations (same residue)
   bool use_crt = true;            // key holders compute x^e mod N^2 through p^2 | q^2 (mpe_paillier.h modexp_nn)
   bool use_fixed_base = true;     // h1/h2 exponentiations through per-statement window tables (mpe_fixedbase.h)
+  bool use_sliding = true;        // x^N with the PUBLIC exponent N: items ordered by key, sliding windows per wave (mpe_pairexp.h)
   int wide_div = 2;               // the 2x-lanes layout is used when wide_div * batch <= the resident groups (MPE_WIDE_DIV)
   int modexp_waves_per_cu = 8;    // 2 waves/SIMD: the montmul loop holds ~230 VGPRs and already issues back-to-back
   // window-table scratch, grown on demand: one buffer per stream slot (0 = the caller's stream, 1..3 = the auxiliary streams
@@ -107,9 +108,9 @@ void prof_end(mpe_ctx* ctx, hipStream_t st);
 int pairset_create_2048(int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st);
 int pairset_create_1024(int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st);
 int pair_modexp_2048(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
-                     Rows base2, Rows exps2, int exp2_words, int half, uint32_t* out, hipStream_t st);
+                     Rows base2, Rows exps2, int exp2_words, int half, uint32_t* out, hipStream_t st, int public_exp);
 int pair_modexp_1024(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
-                     Rows base2, Rows exps2, int exp2_words, int half, uint32_t* out, hipStream_t st);
+                     Rows base2, Rows exps2, int exp2_words, int half, uint32_t* out, hipStream_t st, int public_exp);
 
 // workspace: reserve once per composite call (may reallocate -> synchronises the stream), then bump-allocate
 int ws_reserve(mpe_ctx* ctx, size_t bytes, hipStream_t st);

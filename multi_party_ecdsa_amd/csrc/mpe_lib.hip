@@ -239,12 +239,14 @@ static int pairset_create(int half_bits, int count, const uint32_t* d_moduli, mp
 // base^exps [* base2^exps2] modulo the SQUARE of modulus mod_sel(i) of `ps`; out rows are 2 * half_bits/32 words
 // half != 0: plain exponentiation modulo the modulus itself (out rows keep the 2 * half_bits/32 layout, value < N)
 static int launch_pair_modexp(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
-                              Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st, int half = 0) {
+                              Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st, int half = 0, int public_exp = 0) {
+  // public_exp: the caller vouches that `exps` is public (the key N itself): the kernel may then let the operation sequence
+  // depend on it (sliding windows).  Everything else (nonces, shares, p, q, challenges of a prover) keeps the fixed schedule.
   if (batch == 0) return MPE_OK;
   if (ps->half_bits == 2048)
-    return pair_modexp_2048(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st);
+    return pair_modexp_2048(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st, public_exp);
   if (ps->half_bits == 1024)
-    return pair_modexp_1024(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st);
+    return pair_modexp_1024(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st, public_exp);
   return MPE_E_ARG;
 }
 }  // namespace mpe
@@ -280,6 +282,7 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   if (getenv("MPE_NO_PAIR")) c->use_pair = false;
   if (getenv("MPE_FB_WINDOW_BITS")) { const int w = atoi(getenv("MPE_FB_WINDOW_BITS")); if (w >= 4 && w <= 16) c->fb_window_bits = w; }
   if (getenv("MPE_NO_POWN")) c->use_pown = false;
+  if (getenv("MPE_NO_SLIDING")) c->use_sliding = false;
   if (getenv("MPE_NO_PAR")) c->allow_par = false;
   if (getenv("MPE_NO_ADAPTIVE_LANES")) { c->adaptive_lanes = false; c->ec_lane_groups = false; }
   if (getenv("MPE_NO_WIDE")) c->adaptive_lanes = false;

@@ -299,7 +299,8 @@ constexpr size_t CRT_WS_WORDS = 2 + 2 * 64 + 2 * 128 + 192;
 static int modexp_nn(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Rows base, Rows exps, int ew, bool holder,
                      uint32_t* out, hipStream_t st, bool pow_n = false) {
   if (!(holder && pk->has_private && ctx->use_crt)) {
-    if (ctx->use_pair) return launch_pair_modexp(ctx, pk->ps_nn, B, ksel, base, exps, ew, no_rows(), no_rows(), 0, out, st);
+    // the exponent rows ARE the public-key table: x^N for a public N (r^N, s^N) — the one case that may run on sliding windows
+    if (ctx->use_pair) return launch_pair_modexp(ctx, pk->ps_nn, B, ksel, base, exps, ew, no_rows(), no_rows(), 0, out, st, 0, exps.p == pk->N);
     return launch_modexp(ctx, pk->ms_nn, B, ksel, base, no_rows(), exps, ew, out, st);
   }
   const int B2 = 2 * B;
@@ -333,7 +334,7 @@ static int modexp_nn(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Row
 // base^exps * base2^exps2 mod N_k^2 on one ladder, for a party that does NOT own the key (the verifiers, MessageB)
 static int modexp_nn2(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Rows base, Rows exps, int ew, Rows base2,
                       Rows exps2, int ew2, uint32_t* out, hipStream_t st) {
-  if (ctx->use_pair) return launch_pair_modexp(ctx, pk->ps_nn, B, ksel, base, exps, ew, base2, exps2, ew2, out, st);
+  if (ctx->use_pair) return launch_pair_modexp(ctx, pk->ps_nn, B, ksel, base, exps, ew, base2, exps2, ew2, out, st, 0, exps.p == pk->N);
   return launch_modexp2(ctx, pk->ms_nn, B, ksel, base, exps, ew, base2, exps2, ew2, out, st);
 }
 

@@ -8,7 +8,7 @@ int pairset_create_2048(int count, const uint32_t* d_moduli, mpe_pairset** out, 
   return pairset_create_impl<Cfg2048>(count, d_moduli, out, st);
 }
 int pair_modexp_2048(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
-                     Rows base2, Rows exps2, int exp2_words, int half, uint32_t* out, hipStream_t st) {
+                     Rows base2, Rows exps2, int exp2_words, int half, uint32_t* out, hipStream_t st, int public_exp) {
   // A launch lasts as long as ONE exponentiation however few there are.  When the batch fills less than half of
   // the resident groups, spread every integer over twice the lanes (9 limbs per lane): the same limbs, the same
   // per-modulus constants, about half the latency.
@@ -16,8 +16,8 @@ int pair_modexp_2048(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
   static_assert(Wide::K == Cfg2048::K, "the two layouts share the limb arrays");
   const long resident = (long)ctx->cus * ctx->modexp_waves_per_cu * Cfg2048::GROUPS;
   if (ctx->adaptive_lanes && (long)ctx->wide_div * batch <= resident)
-    return pair_modexp_impl<Wide>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st);
-  return pair_modexp_impl<Cfg2048>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st);
+    return pair_modexp_impl<Wide>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st, public_exp);
+  return pair_modexp_impl<Cfg2048>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st, public_exp);
 }
 
 }  // namespace mpe

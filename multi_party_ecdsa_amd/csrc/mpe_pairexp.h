@@ -310,12 +310,79 @@ __global__ void __launch_bounds__(64) pairset_setup_kernel(int count, const uint
 //   z0 + z1 N = base^exp [* base2^exp2]  mod N^2        (pair_finish_kernel then forms that integer in place)
 // base rows may be any number of words (chunks of K32 words, Horner); phases as in modexp_kernel.
 // ---------------------------------------------------------------------------------------------
-enum PairPhase { PP_IN, PP_MONT, PP_TAB, PP_SQ, PP_MUL1, PP_MUL2, PP_FINAL, PP_DONE };
+enum PairPhase { PP_IN, PP_MONT, PP_TSQ, PP_TAB, PP_SQ, PP_MUL1, PP_MUL2, PP_FINAL, PP_DONE };
 
-template <class C>
+// Sliding windows for a PUBLIC exponent that the whole wave shares (every exponentiation of the dominant kernel raises to the
+// public key N: s^N of the range-proof verifiers, r^N of MessageB — range_proofs.rs:134-141, zk_pdl_with_slack/mod.rs:144-157,
+// mta/mod.rs:133-137): the highest set bit at or below `from` starts a window of at most wb bits that ENDS in a set bit.
+// Returns its low end (-1: no bit left), val = its (odd) value.  All operands are wave-uniform: scalar control flow.
+// (ex lives in the constant address space: the key table is never written while the kernel runs, so the reads are scalar
+// loads and the compiler can see that the schedule is wave-uniform — a generic pointer would make every load "divergent")
+typedef const uint32_t __attribute__((address_space(4))) * UniformWords;
+__device__ __forceinline__ int slide_window(UniformWords ex, int exp_words, int from, int wb, uint32_t& val) {
+  if (from >= exp_words * 32) from = exp_words * 32 - 1;
+  if (from < 0) return -1;
+  int w = from >> 5;
+  uint32_t x = ex[w] & (0xFFFFFFFFu >> (31 - (from & 31)));
+  while (x == 0) {
+    if (--w < 0) return -1;
+    x = ex[w];
+  }
+  const int hi = w * 32 + 31 - __clz((int)x);
+  int lo = hi - wb + 1;
+  if (lo < 0) lo = 0;
+  const int q = lo >> 5, sh = lo & 31;
+  uint64_t two = ex[q];
+  if (q + 1 < exp_words) two |= (uint64_t)ex[q + 1] << 32;
+  const uint32_t v = (uint32_t)(two >> sh) & ((1u << (hi - lo + 1)) - 1u);
+  const int tz = __ffs((int)v) - 1;                 // v != 0: bit hi is set
+  val = v >> tz;
+  return lo + tz;
+}
+
+// items ordered by key, so that the 16 exponentiations of a wave share their (public) exponent: LDS histogram per block,
+// one global atomic per (block, key present), then the scatter.  The order inside a key is arbitrary (results do not depend on it).
+static __global__ void __launch_bounds__(256) key_hist_kernel(int batch, Rows sel, int nkeys, int32_t* __restrict__ cnt) {
+  extern __shared__ int32_t sh[];
+  for (int k = threadIdx.x; k < nkeys; k += blockDim.x) sh[k] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < batch) atomicAdd(&sh[sel_index(sel, i)], 1);
+  __syncthreads();
+  for (int k = threadIdx.x; k < nkeys; k += blockDim.x)
+    if (sh[k]) atomicAdd(&cnt[k], sh[k]);
+}
+static __global__ void __launch_bounds__(64) key_scan_kernel(int nkeys, const int32_t* __restrict__ cnt, int32_t* __restrict__ cursor) {
+  // exclusive prefix sums by one wave: each lane sums a contiguous chunk, a DPP-free serial pass over the 64 partials
+  __shared__ int32_t part[64];
+  const int per = (nkeys + 63) / 64, lo = threadIdx.x * per, hi = lo + per < nkeys ? lo + per : nkeys;
+  int32_t s = 0;
+  for (int k = lo; k < hi; ++k) s += cnt[k];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  int32_t base = 0;
+  for (int t = 0; t < (int)threadIdx.x; ++t) base += part[t];
+  for (int k = lo; k < hi; ++k) { cursor[k] = base; base += cnt[k]; }
+}
+static __global__ void __launch_bounds__(256) key_scatter_kernel(int batch, Rows sel, int nkeys, int32_t* __restrict__ cursor, int32_t* __restrict__ perm) {
+  extern __shared__ int32_t sh[];                   // [nkeys] counts of this block, [nkeys] their global bases
+  for (int k = threadIdx.x; k < 2 * nkeys; k += blockDim.x) sh[k] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int mi = i < batch ? sel_index(sel, i) : -1;
+  const int local = mi >= 0 ? atomicAdd(&sh[mi], 1) : 0;
+  __syncthreads();
+  for (int k = threadIdx.x; k < nkeys; k += blockDim.x)
+    if (sh[k]) sh[nkeys + k] = atomicAdd(&cursor[k], sh[k]);
+  __syncthreads();
+  if (mi >= 0) perm[sh[nkeys + mi] + local] = i;
+}
+
+template <class C, bool SLIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) pair_modexp_kernel(int batch, PairsetView ps, Rows mod_sel, Rows base, Rows exps,
                                                          int exp_words, int wb, Rows base2, Rows exps2, int exp2_words,
-                                                         int half, uint32_t* __restrict__ out, uint32_t* __restrict__ tables) {
+                                                         int half, uint32_t* __restrict__ out, uint32_t* __restrict__ tables,
+                                                         const int32_t* __restrict__ perm, int slide) {
   using PL = PairLds<C>;
   __shared__ uint32_t lds[PL::WORDS];
   const Lane ln = make_lane<C>();
@@ -337,10 +404,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   for (int trip = 0; trip < trips; ++trip) {
     const int inst = trip * nslots + slot;
     const bool active = inst < batch;
-    const int idx = active ? inst : batch - 1;
+    const int pos = active ? inst : batch - 1;
+    const int idx = (SLIDE && perm) ? perm[pos] : pos;        // perm: the launch's items ordered by key (sliding windows)
     const int mi = sel_index(mod_sel, idx);
     const uint32_t* ex = row_of(exps, idx);
     const uint32_t* ex2 = dual ? row_of(exps2, idx) : ex;
+    // sliding windows: only when all the wave's exponentiations read the SAME exponent row (waves that straddle a key
+    // boundary of the ordered launch keep the fixed windows) and, on a two-base ladder, the first window stays above exps2
+    bool sl = false;
+    int sw_lo = -1;                                           // the pending window multiplication: after the squaring that
+    uint32_t sw_val = 0;                                      // brings b down to sw_lo, times tab[sw_val]
+    UniformWords exu = nullptr;                               // the wave's exponent row through a scalar pointer: the window
+    if (SLIDE && slide) {                                     // schedule stays in SGPRs and the phase machine wave-uniform
+      const uint64_t ea = (uint64_t)(uintptr_t)ex;
+      const uint32_t e_lo = __builtin_amdgcn_readfirstlane((uint32_t)ea), e_hi = __builtin_amdgcn_readfirstlane((uint32_t)(ea >> 32));
+      sl = __ballot(ea != (((uint64_t)e_hi << 32) | e_lo)) == 0;
+      exu = (UniformWords)(((uint64_t)e_hi << 32) | e_lo);
+      if (sl) {
+        sw_lo = slide_window(exu, exp_words, exp_words * 32 - 1, wb, sw_val);
+        if (sw_lo < 0 || (dual && sw_lo < 32 * exp2_words)) sl = false;
+      }
+    }
 
     uint32_t n[C::L];
     load_owner<C>(n, ps.n_limbs + (size_t)mi * C::K, ln);
@@ -357,6 +441,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       store_owner<C>(tab + C::K, t1, ln);
     }
 
+    const bool sl_ = SLIDE && sl;                             // (the fixed-window instantiation carries none of this)
+#define sl sl_
     uint32_t cur0[C::L], cur1[C::L];
     int which = 0;                                            // 0: base / tab, 1: base2 / tab2
     const uint32_t* bw = row_of(base, idx);
@@ -370,29 +456,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll 1
     while (ph != PP_DONE) {
       bool sq = false;
-#ifdef MPE_TOUCH_ROW
-      // A/B variant (profiles/r03: no measurable gain, the kernel is issue-bound): during the squaring that precedes a table
-      // multiplication, pull the row it will read towards the CU with two loads whose result is only kept alive
-      uint32_t touch = 0;
-      if (ph == PP_SQ && ((b - 1) % wb) == 0) {
-        const volatile uint32_t* rowp = tab + (size_t)exp_window(ex, exp_words, (b - 1) / wb, wb) * K2;
-        touch = rowp[(ln.t & 3) * (K2 / 4)] ^ rowp[K2 - 1 - (ln.t & 3) * 4];   // one word in (almost) every 128-byte line of the row
-      }
-#endif
       // ---- multiplier pair -> LDS ----
       if (ph == PP_IN) {
         copy_pair_to_lds<C>(gl, ps.tp + (size_t)mi * K2, ln);
       } else if (ph == PP_MONT) {
         copy_pair_to_lds<C>(gl, ps.r2 + (size_t)mi * K2, ln);
       } else if (ph == PP_TAB) {
-        if (k == 1) { put_limbs<C>(gl + PL::B0, cur0, ln); put_limbs<C>(gl + PL::B1, cur1, ln); }
-      } else if (ph == PP_SQ) {
+        // fixed windows: the multiplier is x (written once); sliding: it is x^2, left in place by PP_TSQ
+        if (k == 1 && !(sl && !which)) { put_limbs<C>(gl + PL::B0, cur0, ln); put_limbs<C>(gl + PL::B1, cur1, ln); }
+      } else if (ph == PP_SQ || (SLIDE && ph == PP_TSQ)) {
         put_limbs<C>(gl + PL::B0, cur0, ln);
 #pragma unroll
         for (int i = 0; i < C::L; ++i) gl[PL::B1 + ln.t * C::L + i] = cur0[i] << 1;
         sq = true;
       } else if (ph == PP_MUL1) {
-        const uint32_t w = exp_window(ex, exp_words, b / wb, wb);
+        const uint32_t w = sl ? sw_val : exp_window(ex, exp_words, b / wb, wb);
         copy_pair_to_lds<C>(gl, tab + (size_t)w * K2, ln);
       } else if (ph == PP_MUL2) {
         const int wi = b >> 2;
@@ -409,9 +487,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       uint32_t r0[C::L], r1[C::L];
       pairmul<C>(r0, r1, cur0, cur1, gl, n, n0inv, sq, half != 0, ln);
       wave_lds_sync();
-#ifdef MPE_TOUCH_ROW
-      asm volatile("" ::"v"(touch));
-#endif
 #pragma unroll
       for (int i = 0; i < C::L; ++i) { cur0[i] = r0[i]; cur1[i] = r1[i]; }
 
@@ -433,12 +508,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         store_owner<C>(T + K2, cur0, ln);
         store_owner<C>(T + K2 + C::K, cur1, ln);
         k = 1;
+        ph = (sl && !which) ? PP_TSQ : PP_TAB;
+      } else if (SLIDE && ph == PP_TSQ) {
+        // sliding windows need the ODD powers only: x^2 becomes the multiplier of the table phase, x comes back from the table
+        put_limbs<C>(gl + PL::B0, cur0, ln);
+        put_limbs<C>(gl + PL::B1, cur1, ln);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        load_owner<C>(cur0, tab + K2, ln);
+        load_owner<C>(cur1, tab + K2 + C::K, ln);
         ph = PP_TAB;
       } else if (ph == PP_TAB) {
         uint32_t* T = which ? tab2 : tab;
-        store_owner<C>(T + (size_t)(k + 1) * K2, cur0, ln);
-        store_owner<C>(T + (size_t)(k + 1) * K2 + C::K, cur1, ln);
-        if (++k > (which ? 14 : TE - 2)) {
+        const int step = (sl && !which) ? 2 : 1;              // x^3, x^5, ... x^(TE-1)  |  x^2, x^3, ...
+        k += step;
+        store_owner<C>(T + (size_t)k * K2, cur0, ln);
+        store_owner<C>(T + (size_t)k * K2 + C::K, cur1, ln);
+        if (k > (which ? 14 : TE - 2)) {
           if (!which && dual) {
             which = 1;
             bw = row_of(base2, idx);
@@ -456,19 +541,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         ph = PP_DONE;
       } else {
         if (ph == PP_SQ) --b;
-        const bool m1 = ph == PP_SQ && (b % wb) == 0;
+        if (ph == PP_MUL1 && sl) sw_lo = slide_window(exu, exp_words, b - 1, wb, sw_val);     // the next window below this one
+        const bool m1 = ph == PP_SQ && (sl ? b == sw_lo : (b % wb) == 0);
         const bool m2 = ph != PP_MUL2 && dual && (b & 3) == 0 && (b >> 2) < nwin2;
         ph = m1 ? PP_MUL1 : (m2 ? PP_MUL2 : (b == 0 ? PP_FINAL : PP_SQ));
       }
       if (tables_done) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        const uint32_t w = exp_window(ex, exp_words, nwin - 1, wb);
+        const uint32_t w = sl ? sw_val : exp_window(ex, exp_words, nwin - 1, wb);
         load_owner<C>(cur0, tab + (size_t)w * K2, ln);
         load_owner<C>(cur1, tab + (size_t)w * K2 + C::K, ln);
-        b = top_bit;
+        b = sl ? sw_lo : top_bit;
+        if (sl) sw_lo = slide_window(exu, exp_words, b - 1, wb, sw_val);
         ph = b == 0 ? PP_FINAL : PP_SQ;
       }
     }
+#undef sl
     // canonical digits -> interface words z0 | z1.  The pair means the INTEGER z0 + z1 N with z0 < 2N lazily, so a
     // subtraction of N from z0 carries 1 into z1 (z0 >= N is a 2^-38 event for random operands, but e.g. the base N
     // itself lands exactly there); z1 is then reduced modulo N (multiples of N^2 drop out).
@@ -549,7 +637,7 @@ int pairset_create_impl(int count, const uint32_t* d_moduli, mpe_pairset** out, 
 
 template <class C>
 int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
-                     Rows base2, Rows exps2, int exp2_words, int half, uint32_t* d_out, hipStream_t st) {
+                     Rows base2, Rows exps2, int exp2_words, int half, uint32_t* d_out, hipStream_t st, int public_exp) {
   const int need_w = (batch + C::GROUPS - 1) / C::GROUPS, cap = ctx->cus * ctx->modexp_waves_per_cu;
   int grid = need_w;
   if (need_w > cap) { const int trips = (need_w + cap - 1) / cap; grid = (need_w + trips - 1) / trips; }
@@ -561,12 +649,33 @@ int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
     return MPE_E_ARG;
   }
   const size_t need = (size_t)grid * C::GROUPS * (((size_t)1 << wb) + (dual ? 16 : 0)) * 2 * C::K * sizeof(uint32_t);
-  uint32_t* tabs = tables_for(ctx, need, st);
+  // A PUBLIC long exponent (the caller vouches: it is the key N) runs on sliding windows wherever a wave's 16 exponentiations
+  // share it.  With several keys in the launch the items are first ordered by key (perm): three small kernels.
+  const int slide = (public_exp && ctx->use_sliding && !half && exp_words >= 16 && wb >= 5) ? 1 : 0;
+  const bool by_key = slide && ps->count > 1 && (mod_sel.idx || mod_sel.stride) && ps->count <= 4096 && batch > C::GROUPS;
+  const size_t extra = by_key ? ((size_t)batch + 2 * (size_t)ps->count + 64) * sizeof(int32_t) : 0;
+  uint32_t* tabs = tables_for(ctx, need + extra, st);
   if (!tabs) return MPE_E_NOMEM;
+  const int32_t* perm = nullptr;
+  if (by_key) {
+    int32_t* pm = (int32_t*)((char*)tabs + need);
+    int32_t *cnt = pm + batch, *cursor = cnt + ps->count;
+    (void)hipMemsetAsync(cnt, 0, (size_t)ps->count * sizeof(int32_t), st);
+    const int nb = (batch + 255) / 256;
+    hipLaunchKernelGGL(key_hist_kernel, dim3(nb), dim3(256), (size_t)ps->count * 4, st, batch, mod_sel, ps->count, cnt);
+    hipLaunchKernelGGL(key_scan_kernel, dim3(1), dim3(64), 0, st, ps->count, cnt, cursor);
+    hipLaunchKernelGGL(key_scatter_kernel, dim3(nb), dim3(256), (size_t)ps->count * 8, st, batch, mod_sel, ps->count, cursor, pm);
+    perm = pm;
+  }
   PairsetView v{ps->n_limbs, ps->n0inv, ps->one, ps->r2, ps->tp, ps->kc, ps->count};
-  prof_begin(ctx, st, half ? 4 : 3, half ? C::BITS : 2 * C::BITS, exp_words, batch, dual ? exp2_words : 0);
-  hipLaunchKernelGGL(pair_modexp_kernel<C>, dim3(grid), dim3(64), 0, st, batch, v, mod_sel, base, exps, exp_words, wb, base2,
-                     exps2, exp2_words, half, d_out, tabs);
+  // kind 6: the pair kernel on sliding windows (the executed multiplication count differs: bench.py's accounting)
+  prof_begin(ctx, st, half ? 4 : (slide ? 6 : 3), half ? C::BITS : 2 * C::BITS, exp_words, batch, dual ? exp2_words : 0);
+  if (slide)
+    hipLaunchKernelGGL((pair_modexp_kernel<C, true>), dim3(grid), dim3(64), 0, st, batch, v, mod_sel, base, exps, exp_words, wb, base2,
+                       exps2, exp2_words, half, d_out, tabs, perm, slide);
+  else
+    hipLaunchKernelGGL((pair_modexp_kernel<C, false>), dim3(grid), dim3(64), 0, st, batch, v, mod_sel, base, exps, exp_words, wb, base2,
+                       exps2, exp2_words, half, d_out, tabs, perm, slide);
   prof_end(ctx, st);
   hipLaunchKernelGGL(pair_finish_kernel<C::K32>, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, mod_sel, ps->mod_words, d_out);
   hipError_t e = hipGetLastError();

@@ -38,3 +38,18 @@ def test_pair_model_with_71_steps_for_2048_bit_moduli():
         st = pm.run(2048, 4, 2, 5, stress, steps=71)
         assert st["maxcol"] < 1 << 64
         assert st["maxlimb"] < (1 << 29) + (1 << 12)
+
+
+def test_sliding_window_schedule_of_the_public_exponent():
+    """the schedule the pair kernel runs when the exponent is the PUBLIC key N (mpe_pairexp.h slide_window + phase machine):
+    word-wise window scan, odd-power table from x^2, pending-window bookkeeping, a short second exponent on fixed 4-bit windows
+    riding the same squarings — reproduces pow() for random and edge exponents (single bit, all ones, 64..2048 bits)"""
+    sm = _load("sliding_model")
+    assert sm.run(iters=60, seed=9) > 0
+    # and the averages bench.py prices the launches with: a 2048-bit exponent on 6-bit windows
+    import random
+    rnd = random.Random(1)
+    e = rnd.getrandbits(2048) | (1 << 2047) | 1
+    val, sq, mul = sm.ladder(3, e, (1 << 2048) - 159, 6, 64)
+    assert val == pow(3, e, (1 << 2048) - 159)
+    assert 2040 <= sq <= 2049 and 31 + 270 <= mul <= 31 + 315         # vs 2046 squarings + 62 + 342 multiplications on fixed windows

@@ -191,3 +191,39 @@ def test_holder_paths_on_degenerate_randomness(pk, keys, gpu_ctx):
     want = F.ints(orc.paillier_encrypt(F.words([k.N for k in keys], 64), F.words(m, 64), F.words(rr, 64), kidx))
     assert pk.encrypt(m, rr, kidx) == want
     assert pub.encrypt(m, rr, kidx) == want
+
+
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 333])
+def test_public_exponent_sliding_windows_equal_fixed_windows_and_the_oracle(gpu_ctx, keys, B):
+    """x^N for the PUBLIC exponent N runs on sliding windows with the launch ordered by key (mpe_pairexp.h); a context created
+    under MPE_NO_SLIDING=1 keeps the fixed windows.  Peer-side encryption (r^N mod N^2) and the two-base MessageB ciphertext
+    c_a^b r^N over 16 keys in an order that makes every wave straddle key boundaries: both contexts and the GMP oracle agree
+    bit for bit, at batch sizes around the wave's 16 groups."""
+    from multi_party_ecdsa_amd import engine as E
+    os.environ["MPE_NO_SLIDING"] = "1"
+    try:
+        ctx_fixed = E.Context(0)
+    finally:
+        del os.environ["MPE_NO_SLIDING"]
+    r = F.Rng(f"sliding-{B}")
+    kidx = [(5 * i + i // 7) % len(keys) for i in range(B)]
+    m = [r.below(keys[k].N) for k in kidx]
+    rr = [r.below(keys[k].N) for k in kidx]
+    rr[0] = 1                                                    # edge bases
+    if B > 1:
+        rr[1] = keys[kidx[1]].N - 1
+    N = F.words([k.N for k in keys], 64)
+    want = F.ints(orc.paillier_encrypt(N, F.words(m, 64), F.words(rr, 64), kidx))
+    outs = []
+    b = [r.below(pyref.Q) for _ in range(B)]
+    for ctx in (gpu_ctx, ctx_fixed):
+        pub = E.PaillierKeys(ctx, N=[k.N for k in keys])
+        assert pub.encrypt(m, rr, kidx) == want
+        # MessageB::b's ciphertext: c_a^b * Enc(beta'; r) — the short SECRET exponent b stays on fixed windows
+        c_a = want
+        got = pub.add(pub.mul(c_a, b, kidx), pub.encrypt(m, rr, kidx), kidx)
+        ref = [pow(ca, bb, keys[k].N ** 2) * w % keys[k].N ** 2 for ca, bb, w, k in zip(c_a, b, want, kidx)]
+        assert got == ref
+        outs.append(got)
+    assert outs[0] == outs[1]
+    ctx_fixed.close()

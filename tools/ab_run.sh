@@ -6,6 +6,7 @@ mkdir -p gpurun_out/ab
 for rep in 1 2; do
 for so in tools/ab/*.so; do
   name=$(basename $so .so)
+  unset MPE_NO_SLIDING; case $name in *noslide*) export MPE_NO_SLIDING=1;; esac
   MPE_LIB_PATH=$PWD/$so python bench.py --steps ${STEPS:-3} --warmup 1 --no-configs --no-cpu-baseline ${AB_ARGS} > gpurun_out/ab/$name.$rep.json 2> gpurun_out/ab/$name.$rep.err
   python3 - "$name" "$rep" <<'PY'
 import json, sys

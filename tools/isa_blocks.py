@@ -10,7 +10,7 @@ def main():
     m = re.match(r"Cfg<(\d+),(\d+),(\d+),(\d+)>", want)
     tag = "CfgILi%sELi%sELi%sELi%sE" % m.groups() if m else want
     lines = open(path).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3mpe") and tag in l and "pair_modexp_kernel" in l and l.split(":")[0].endswith("_"))
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3mpe") and tag in l and "pair_modexp_kernel" in l and ":" in l and not l.startswith("\t"))
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
     blocks, cur = [], ["entry", []]
     blocks.append(cur)
