@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_MAC_PER_S = 16 * 4 * 256 * 2.4e9     # gfx950 v_mad_u64_u32: 16 lanes/clk/SIMD (profiles/r01_valu_rate.json)
+LIMB_INFLATION = 4 * 72 * 71 / (2 * (2 * 64 * 64 + 64))   # executed 29-bit MACs of a squaring modulo N^2 (2 passes x 2 streams x 72 limbs x 71 steps) / its ideal 2 MAC(64)
 EXP_BITS = {8: 256, 24: 768, 25: 769, 32: 1024, 64: 2048, 72: 2304, 80: 2560, 81: 2561, 88: 2816, 89: 2817}
 
 
@@ -830,7 +831,7 @@ def main():
         # HBM traffic of the dominant kernel: measured in separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied) and committed under profiles/ — not re-measured here
         traffic, traffic_src = None, None
-        for rel in ("profiles/r02/pmc_traffic.json", "profiles/r01/pmc_traffic.json"):
+        for rel in ("profiles/r03/pmc_traffic.json", "profiles/r02/pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, rel)) as f:
                     pmc = json.load(f)
@@ -869,10 +870,12 @@ def main():
                          # the issue ceiling actually measured for this instruction (tools/ubench/valu_rate.hip): a stream of
                          # v_mad_u64_u32 with VGPR operands sustains 31.2 T lane-ops/s at the kernel's 2 waves per SIMD, not
                          # the 39.3 T of the 4-cycle issue model.  The kernel's VALU stream = the 29-bit-limb MACs it executes
-                         # ((72/64)^2 x 4 K^2 / 2 MAC(64) = 1.256 x the ideal count) x 740/648 instructions per MAC in its loops.
+                         # (72 limbs x 71 CIOS steps per pass against MAC(64): LIMB_INFLATION = 1.238 x the ideal count) x 740/648
+                         # instructions per MAC in its loops.
                          "issue_ceiling": ({"measured_T_lane_ops_per_s": 31.2, "source": "profiles/r01_valu_rate.json (mad_u64_u32_vv, 2 waves/SIMD)",
-                                            "kernel_valu_T_lane_ops_per_s": exe_macs * 1.2558 * 740 / 648 / dom_s / 1e12,
-                                            "frac_of_measured": exe_macs * 1.2558 * 740 / 648 / dom_s / 31.2e12}
+                                            "kernel_valu_T_lane_ops_per_s": exe_macs * LIMB_INFLATION * 740 / 648 / dom_s / 1e12,
+                                            "frac_of_measured": exe_macs * LIMB_INFLATION * 740 / 648 / dom_s / 31.2e12,
+                                            "limb_inflation": LIMB_INFLATION}
                                            if pair and dom_s else None)},
             "breakdown": {"modexp4096_s_per_step": dom_s / args.steps, "modexp2048_s_per_step": sec_s / args.steps,
                           "heavy_kernels_s_per_step": heavy_s / args.steps, "wall_s_per_step": elapsed / args.steps,

@@ -26,6 +26,14 @@ for mode in session party; do
   tail -c 200 "$OUT/bench_torchrun1_$mode.json"; echo
 done
 
+# the N>1 launch as the driver starts it, on the one GPU a test box has: bench.py spawns its own ranks, every rank on cuda:0,
+# the round slabs through a gloo all-gather (a functional run of the code path; the ranks time-share the device)
+for mode in session party; do
+  timeout 600 $BENCH --gpus 2 --share-device --mode $mode --sessions 16384 --steps 1 --warmup 1 --no-cpu-baseline --no-configs \
+    > "$OUT/bench_2ranks_shared_device_$mode.json" 2> "$OUT/bench_2ranks_shared_device_$mode.err"
+  tail -c 200 "$OUT/bench_2ranks_shared_device_$mode.json"; echo
+done
+
 rm -rf /tmp/p_stats /tmp/p_1k
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o s -- $BENCH $LIGHT --warmup 1 \
   > "$OUT/stats_bench.json" 2> /dev/null
@@ -47,4 +55,7 @@ pmc_pass() {  # name, counters...
 pmc_pass fetch FETCH_SIZE
 pmc_pass write WRITE_SIZE
 pmc_pass sq GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES
+# where a wave spends its cycles (two more passes: the SQ block counts 8 counters at a time)
+pmc_pass stall_wave_cycles SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA
+pmc_pass stall_inst_counts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_IFETCH SQ_BUSY_CYCLES SQ_WAVES
 ls -la "$OUT"

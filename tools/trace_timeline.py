@@ -27,6 +27,8 @@ def main():
     for r in seg:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         gap = max(0, s - prev_end)
+        if gap > 20e6:                      # the step is over: what follows is the teardown of the bench process
+            break
         out.append({"t_ms": (s - t0) / 1e6, "dur_ms": (e - s) / 1e6, "gap_ms": gap / 1e6, "kernel": short(r["Kernel_Name"])})
         if e > prev_end:
             busy += e - max(s, prev_end)
