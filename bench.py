@@ -14,14 +14,20 @@ algorithm needs (N-adic pairs on ideal 32-bit limbs: 2 MAC(64) per squaring, 2.5
 window counts) per second / the measured v_mad_u64_u32 issue peak — a hardware-utilisation figure <= 1.  SURVEY.md 8(d)'s
 unit (textbook CIOS on the 4096-bit integers) is reported beside it as `alg_unit_*`; it exceeds the peak because the
 kernel computes the same residues with ~0.46x those MACs.
+`roofline_secondary[]` / `whole_step`: the same accounting for every other profiled kernel and for the whole step.
+`openssl_verified`: every signature of the timed batch under OpenSSL's ECDSA_do_verify (after the timed region; tests/ossl.py).
 `configs`: c2 (65 536 Paillier encrypt + decrypt, 16 keys), c3 (262 144 EC scalar multiplications and PDL-with-slack
-prove + verify, prefix checked against the oracle, 1 % corrupted proofs all rejected), c4_literal_1024 (config 4 at its
-literal size), c5_share_t2n5_8192 (one GPU's share of config 5), measured right after the timed region.
+prove + verify, prefix checked against the oracle and OpenSSL, 1 % corrupted proofs all rejected), c3b (65 536 BobProof generate +
+BobProofExt verify), c4_literal_1024 (config 4 at its literal size), c5_share_t2n5_8192 (one GPU's share of config 5), measured
+right after the timed region.
 `cpu_baseline`: the GMP oracle (oracle/gg20_oracle.c — the reference's formulas over the reference's own bignum engine)
-on the host cores for a bounded sample of the same sessions (>= 8 per thread), plus its single-thread rate; the GPU
+on the host cores for a bounded sample of the same sessions (16 per thread), plus its single-thread rate; the GPU
 signatures are checked against it bit for bit.
 
-N>1 (one process per GPU under torch.distributed.run; RCCL):
+N>1 (one process per GPU; RCCL).  `python bench.py --gpus N` with no launcher around it spawns its N ranks itself (re-exec under
+torch.distributed.run, 127.0.0.1, a free port); under the driver's own torch.distributed.run line it reads the environment.
+The line then carries n_gpus, per_rank{signatures_per_s[], min, max}, an rccl{} block (all-reduce of ones == N, version) and —
+session mode — the node's Paillier ops/s.  --share-device: every rank on cuda:0 over gloo (the same code path on a 1-GPU box).
   --mode session (default): sessions sharded across ranks, no data-path collective (independent units, SURVEY.md §8e A);
   --mode party: the parties of a session live on different GPUs (party p of session block s on rank (s + p) % N) and
   every round's messages travel through one all-gather (BASELINE config 5); same per-GPU work.
@@ -895,7 +901,7 @@ def main():
         usable, quota = host_cores()
         threads = min(usable, 64)
         if single and not args.no_cpu_baseline:
-            sample = min(B, 8 * threads)
+            sample = min(B, 16 * threads)
             host_nonces = _host({f: v[: sample * (v.shape[0] // B)] for f, v in nonces.items()})
             one = min(4, sample)
             t1 = time.time()

@@ -1,5 +1,6 @@
 // Translation unit of the N-adic pair engine for 2048-bit moduli (arithmetic modulo their squares); see mpe_pairexp.h.
 // Kept apart from mpe_lib.hip only so that the three units compile in parallel.
+#include <cstdlib>
 #include "mpe_pairexp.h"
 
 namespace mpe {
@@ -15,6 +16,15 @@ int pair_modexp_2048(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
   using Wide = Cfg<2048, MPE_W, MPE_L / 2, 8>;
   static_assert(Wide::K == Cfg2048::K, "the two layouts share the limb arrays");
   const long resident = (long)ctx->cus * ctx->modexp_waves_per_cu * Cfg2048::GROUPS;
+  // ... and a really small batch (a sixteenth of the resident groups) over four times the lanes (5 limbs per lane: the same
+  // constants, zero-padded).  Measured (profiles/r03/xwide_sweep.json): -6 % per batch at 256 sessions, nothing at 1 024 and
+  // +13 % when the threshold lets mid-size launches take it: with 10 MACs per step the quotient-digit dependency chain
+  // (mad -> mul_lo -> three DPP moves -> mad) is no longer hidden, so the layout only pays while the chip is nearly empty.
+  using XWide = Cfg<2048, MPE_W, 5, 16>;
+  const char* xenv = getenv("MPE_XWIDE_DIV");                 // read per call (A/B runs, tests of the 9-limb layout): 0 switches it off
+  const int xdiv = xenv ? atoi(xenv) : 16;
+  if (ctx->adaptive_lanes && xdiv > 0 && (long)xdiv * batch <= resident)
+    return pair_modexp_impl<XWide>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st, public_exp);
   if (ctx->adaptive_lanes && (long)ctx->wide_div * batch <= resident)
     return pair_modexp_impl<Wide>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st, public_exp);
   return pair_modexp_impl<Cfg2048>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st, public_exp);

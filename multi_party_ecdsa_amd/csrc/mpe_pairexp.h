@@ -42,7 +42,12 @@ struct PairLds {
   static constexpr int WORDS = STRIDE * C::GROUPS;
 };
 
-// per-modulus constants of the pair arithmetic (limb arrays, modulus-major)
+// Limbs per component in the STORED per-modulus constants: the widest layout of that modulus size (16 lanes x 5 limbs = 80 for
+// 2048 bit, 8 x 5 = 40 for 1024 bit), zero-padded — every layout (18 / 9 / 5 limbs per lane) reads the same arrays, its own K
+// limbs of each component.  (R = 2^(W STEPS) does not depend on the layout, so neither do the constants.)
+__host__ __device__ constexpr int pair_kstore(int bits) { return bits == 2048 ? 80 : (bits == 1024 ? 40 : 0); }
+
+// per-modulus constants of the pair arithmetic (limb arrays, modulus-major, pair_kstore limbs per component)
 struct PairsetView {
   const uint32_t* n_limbs;   // [count][K]
   const uint32_t* n0inv;     // [count]
@@ -71,17 +76,18 @@ __device__ __forceinline__ void cios_tail(uint32_t (&res)[C::L], const uint64_t 
   res[1] += (uint32_t)(cin >> W) + (v0 >> W);
 }
 
-// After STEPS = K - 1 outer steps the rotating column names are one position short of a full turn: logical column i sits in
-// c[(L - 1 + i) % L].  (A renaming: no instruction.)
+// The outer loop ends after STEPS = LAST_TRIP * L + REM steps (STEPS <= K: the multiplier has no limbs beyond STEPS): the rotating
+// column names are then REM positions into a turn — logical column i sits in c[(REM + i) % L].  (A renaming: no instruction.)
 template <class C>
 __device__ __forceinline__ void cios_finish(uint32_t (&res)[C::L], const uint64_t (&c)[C::L], const Lane& ln) {
-  static_assert(C::STEPS == C::K || C::STEPS == C::K - 1, "the pair engine runs K or K - 1 outer steps");
-  if constexpr (C::STEPS == C::K) {
+  static_assert(C::STEPS <= C::K && C::STEPS > C::K - 2 * C::L, "STEPS must lie in the last two trips");
+  constexpr int REM = C::STEPS % C::L;
+  if constexpr (REM == 0) {
     cios_tail<C>(res, c, ln);
   } else {
     uint64_t cc[C::L];
 #pragma unroll
-    for (int i = 0; i < C::L; ++i) cc[i] = c[(C::L - 1 + i) % C::L];
+    for (int i = 0; i < C::L; ++i) cc[i] = c[(REM + i) % C::L];
     cios_tail<C>(res, cc, ln);
   }
 }
@@ -97,8 +103,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // One CIOS pass with ONE product stream:  res = (c_in + a * b + m n) / R,  quotient digits m_j stored to ml[j].
 // (montmul of mpe_bigint.h with pre-loaded columns and the digits kept.)
-// STEPS = K - 1 (2048-bit moduli): the last trip ends after L - 1 steps, and that is the loop's ONLY exit — the column names
-// have one rotation state there (cios_finish), nothing for the compiler to reconcile.
+// The loop has ONE exit, after STEPS = (STEPS / L) * L + STEPS % L steps (71 of 72 for 2048-bit moduli at 18 or 9 limbs per lane,
+// 71 of 80 at 5 limbs per lane; all 36 for 1024 bit): the column names have one rotation state there (cios_finish), nothing for
+// the compiler to reconcile.
 template <class C, bool STORE_M>
 __device__ __forceinline__ void cios1(uint32_t (&res)[C::L], uint64_t (&c)[C::L], const uint32_t (&a)[C::L],
                                       const uint32_t* __restrict__ bl, uint32_t* __restrict__ ml,
@@ -123,10 +130,9 @@ __device__ __forceinline__ void cios1(uint32_t (&res)[C::L], uint64_t (&c)[C::L]
       c[(r + 1) % L] += c[r] >> W;
       c[r] = (uint64_t)(pull_next((uint32_t)c[r]) & maskv);
     };
-    static_for<0, L - 1>(step);
-    if (C::STEPS < C::K && jj == C::TPI - 1) break;          // step K - 1 does not exist: R = 2^(W STEPS)
-    step(std::integral_constant<int, L - 1>{});
-    if (C::STEPS == C::K && jj == C::TPI - 1) break;
+    static_for<0, C::STEPS % L>(step);
+    if (jj == C::STEPS / L) break;                            // the ONLY exit: after STEPS steps (R = 2^(W STEPS))
+    static_for<C::STEPS % L, L>(step);
   }
   cios_finish<C>(res, c, ln);
 }
@@ -160,10 +166,9 @@ __device__ __forceinline__ void cios2(uint32_t (&res)[C::L], uint64_t (&c)[C::L]
       c[(r + 1) % L] += c[r] >> W;
       c[r] = (uint64_t)(pull_next((uint32_t)c[r]) & maskv);
     };
-    static_for<0, L - 1>(step);
-    if (C::STEPS < C::K && jj == C::TPI - 1) break;          // step K - 1 does not exist: R = 2^(W STEPS)
-    step(std::integral_constant<int, L - 1>{});
-    if (C::STEPS == C::K && jj == C::TPI - 1) break;
+    static_for<0, C::STEPS % L>(step);
+    if (jj == C::STEPS / L) break;                            // the ONLY exit: after STEPS steps (R = 2^(W STEPS))
+    static_for<C::STEPS % L, L>(step);
   }
   cios_finish<C>(res, c, ln);
 }
@@ -191,7 +196,11 @@ __device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::
 #pragma unroll
   for (int i = 0; i < L; ++i) {
     uint32_t mi = gl[PL::M + ln.t * L + i];
-    if (C::STEPS < C::K && i == L - 1) mi = (ln.t == C::TPI - 1) ? 0u : mi;      // there is no digit m_(K-1)
+    if (C::STEPS == C::K - 1) {
+      if (i == L - 1) mi = (ln.t == C::TPI - 1) ? 0u : mi;                       // there is no digit m_(K-1)
+    } else if (C::STEPS < C::K) {
+      mi = (ln.t * L + i < C::STEPS) ? mi : 0u;                                  // nor any digit beyond STEPS
+    }
     c[i] = (uint64_t)(gl[PL::KC + ln.t * L + i] - mi);
   }
   wave_lds_sync();
@@ -208,13 +217,14 @@ __device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::
   for (int i = 0; i < L; ++i) r0[i] = gl[PL::M + ln.t * L + i];
 }
 
+// off1: where the second component starts in `src` (C::K in a window table, pair_kstore in the per-modulus constants)
 template <class C>
-__device__ __forceinline__ void copy_pair_to_lds(uint32_t* gl, const uint32_t* __restrict__ src, const Lane& ln) {
+__device__ __forceinline__ void copy_pair_to_lds(uint32_t* gl, const uint32_t* __restrict__ src, const Lane& ln, int off1 = C::K) {
   using PL = PairLds<C>;
 #pragma unroll
   for (int i = 0; i < C::L; ++i) {
     gl[PL::B0 + ln.t + C::TPI * i] = src[ln.t + C::TPI * i];
-    gl[PL::B1 + ln.t + C::TPI * i] = src[C::K + ln.t + C::TPI * i];
+    gl[PL::B1 + ln.t + C::TPI * i] = src[off1 + ln.t + C::TPI * i];
   }
 }
 
@@ -228,6 +238,7 @@ __global__ void __launch_bounds__(64) pairset_setup_kernel(int count, const uint
                                                            uint32_t* __restrict__ one, uint32_t* __restrict__ r2,
                                                            uint32_t* __restrict__ tp, uint32_t* __restrict__ kc) {
   __shared__ uint32_t lds[C::LDS_WORDS];
+  constexpr int KS = pair_kstore(C::BITS);          // storage stride (the arrays were zeroed: the padding limbs stay 0)
   const Lane ln = make_lane<C>();
   uint32_t* gl = lds + ln.g * C::STRIDE;
   const int slot = blockIdx.x * C::GROUPS + ln.g;
@@ -251,8 +262,8 @@ __global__ void __launch_bounds__(64) pairset_setup_kernel(int count, const uint
     if (!active) return;
 #pragma unroll
     for (int i = 0; i < C::L; ++i) {
-      dst[(size_t)idx * 2 * C::K + ln.t * C::L + i] = (uint32_t)x0[i];
-      dst[(size_t)idx * 2 * C::K + C::K + ln.t * C::L + i] = (uint32_t)x1[i];
+      dst[(size_t)idx * 2 * KS + ln.t * C::L + i] = (uint32_t)x0[i];
+      dst[(size_t)idx * 2 * KS + KS + ln.t * C::L + i] = (uint32_t)x1[i];
     }
   };
   constexpr int WK = C::W * C::STEPS;          // R = 2^WK: the radix the CIOS passes divide by
@@ -291,7 +302,7 @@ __global__ void __launch_bounds__(64) pairset_setup_kernel(int count, const uint
       }
       if (active) {
 #pragma unroll
-        for (int i = 0; i < C::L; ++i) kc[(size_t)idx * C::K + ln.t * C::L + i] = (uint32_t)z[i];
+        for (int i = 0; i < C::L; ++i) kc[(size_t)idx * KS + ln.t * C::L + i] = (uint32_t)z[i];
       }
     }
     if (d == WK + C::BITS) store_pair(tp);
@@ -299,7 +310,7 @@ __global__ void __launch_bounds__(64) pairset_setup_kernel(int count, const uint
   store_pair(r2);
   if (active) {
 #pragma unroll
-    for (int i = 0; i < C::L; ++i) n_limbs[(size_t)idx * C::K + ln.t * C::L + i] = n[i];
+    for (int i = 0; i < C::L; ++i) n_limbs[(size_t)idx * KS + ln.t * C::L + i] = n[i];
     if (ln.t0) n0inv_out[idx] = n0inv;
   }
 }
@@ -427,16 +438,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
 
     uint32_t n[C::L];
-    load_owner<C>(n, ps.n_limbs + (size_t)mi * C::K, ln);
+    constexpr int KS = pair_kstore(C::BITS);
+    load_owner<C>(n, ps.n_limbs + (size_t)mi * KS, ln);
     const uint32_t n0inv = ps.n0inv[mi];
     {
-      const uint32_t* kc = ps.kc + (size_t)mi * C::K;         // K_c + (R - 1), limb-wise, stays in LDS for the item
+      const uint32_t* kc = ps.kc + (size_t)mi * KS;           // K_c + (R - 1), limb-wise, stays in LDS for the item
 #pragma unroll
       for (int i = 0; i < C::L; ++i)                          // R - 1 is all-ones over STEPS limbs
         gl[PL::KC + ln.t + C::TPI * i] = kc[ln.t + C::TPI * i] + ((ln.t + C::TPI * i) < C::STEPS ? C::MASK : 0u);
       uint32_t t0[C::L], t1[C::L];                            // tab[0] = the form of 1
-      load_owner<C>(t0, ps.one + (size_t)mi * K2, ln);
-      load_owner<C>(t1, ps.one + (size_t)mi * K2 + C::K, ln);
+      load_owner<C>(t0, ps.one + (size_t)mi * 2 * KS, ln);
+      load_owner<C>(t1, ps.one + (size_t)mi * 2 * KS + KS, ln);
       store_owner<C>(tab, t0, ln);
       store_owner<C>(tab + C::K, t1, ln);
     }
@@ -458,9 +470,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       bool sq = false;
       // ---- multiplier pair -> LDS ----
       if (ph == PP_IN) {
-        copy_pair_to_lds<C>(gl, ps.tp + (size_t)mi * K2, ln);
+        copy_pair_to_lds<C>(gl, ps.tp + (size_t)mi * 2 * KS, ln, KS);
       } else if (ph == PP_MONT) {
-        copy_pair_to_lds<C>(gl, ps.r2 + (size_t)mi * K2, ln);
+        copy_pair_to_lds<C>(gl, ps.r2 + (size_t)mi * 2 * KS, ln, KS);
       } else if (ph == PP_TAB) {
         // fixed windows: the multiplier is x (written once); sliding: it is x^2, left in place by PP_TSQ
         if (k == 1 && !(sl && !which)) { put_limbs<C>(gl + PL::B0, cur0, ln); put_limbs<C>(gl + PL::B1, cur1, ln); }
@@ -617,9 +629,11 @@ int pairset_create_impl(int count, const uint32_t* d_moduli, mpe_pairset** out, 
   ps->half_bits = C::BITS;
   ps->count = count;
   ps->mod_words = d_moduli;
-  const size_t K = C::K, words = (size_t)count * (K + 1 + 3 * 2 * K + K);
+  const size_t K = pair_kstore(C::BITS), words = (size_t)count * (K + 1 + 3 * 2 * K + K);
+  static_assert(pair_kstore(C::BITS) >= C::K, "the stored constants must hold the layout's limbs");
   hipError_t e = hipMalloc(&ps->blob, words * 4);
   if (e != hipSuccess) { delete ps; mpe_set_error("hipMalloc(pairset)", e); return MPE_E_NOMEM; }
+  (void)hipMemsetAsync(ps->blob, 0, words * 4, st);          // the padding limbs of every component are zero
   uint32_t* p = (uint32_t*)ps->blob;
   ps->n_limbs = p; p += count * K;
   ps->n0inv = p; p += count;

@@ -122,9 +122,9 @@ class PartySharded:
 
     def _gather(self, buf, mine):
         """all ranks' slabs into `buf` (`mine` = this rank's rows of it, already written)"""
-        if not (self.dist and self.world > 1):
-            return
         cuda = buf.is_cuda
+        if not self.dist or (self.world == 1 and not (cuda and self.backend == "nccl")):
+            return                                   # (one RCCL rank still issues the collective: the same call path as N ranks)
         if cuda and self.backend == "nccl":
             # in-place RCCL all-gather queued behind the round's kernels on the current stream; timed with events
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
