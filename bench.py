@@ -639,7 +639,7 @@ def respawn_under_torchrun(n, argv):
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
+           "--master-port", str(port), "--", os.path.abspath(__file__)] + argv     # "--": our own flags (--n, --t) are not the launcher's
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")

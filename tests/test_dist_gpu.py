@@ -226,12 +226,14 @@ def test_rearmed_session_equals_a_fresh_one(gpu_ctx, keys):
 
 
 # ---- bench.py --gpus N spawns its own ranks -----------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["session", "party"])
-def test_bench_self_spawns_two_ranks(mode):
+@pytest.mark.parametrize("mode,shape", [("session", []), ("party", []), ("party", ["--t", "2", "--n", "5"])])
+def test_bench_self_spawns_two_ranks(mode, shape):
+    """(the third case: three signers on two ranks — two parties of a session share a rank, `colocate` — and bench flags that
+    are prefixes of the launcher's own options, which must reach bench.py untouched)"""
     env = dict(os.environ)
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--steps", "1", "--warmup", "1",
-           "--sessions", "256", "--mode", mode, "--no-configs", "--no-cpu-baseline"]
+           "--sessions", "256", "--mode", mode, "--no-configs", "--no-cpu-baseline"] + shape
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
