@@ -13,7 +13,7 @@ import json, sys
 name, rep = sys.argv[1], sys.argv[2]
 try:
     d = json.loads([l for l in open(f"gpurun_out/ab/{name}.{rep}.json") if l.startswith("{")][-1])
-    sec = {s["kernel"].split("<")[1][:18] + ("h" if "half" in s["kernel"] else ""): round(s["seconds"] / d["steps"], 4) for s in d.get("roofline_secondary", [])}
+    sec = {s["kernel"].split("<")[-1][:18] + ("h" if "half" in s["kernel"] else ""): round(s["seconds"] / d["steps"], 4) for s in d.get("roofline_secondary", [])}
     print(f"{name:14s} rep {rep}: {d['value']:9.1f} sig/s  step {d['ms_per_step']:8.1f} ms  dom avg {d['roofline']['avg_kernel_ms']:8.2f} ms  frac {d['roofline']['frac']:.4f}  signed {d['all_sessions_signed']} ossl {d.get('openssl_verified')}  {sec}")
 except Exception as e:
     print(name, rep, "FAILED", e)
