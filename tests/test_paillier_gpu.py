@@ -227,3 +227,20 @@ def test_public_exponent_sliding_windows_equal_fixed_windows_and_the_oracle(gpu_
         outs.append(got)
     assert outs[0] == outs[1]
     ctx_fixed.close()
+
+
+def test_sliding_windows_on_sparse_and_dense_public_exponents(gpu_ctx):
+    """the window scan on exponents an RSA modulus never looks like: long runs of zeros (a window every few hundred bits), all
+    ones (back-to-back full windows), a lone top bit above a low word — r^N mod N^2 against Python's pow, 20 items per 'key'
+    so that every wave holds one key and the sliding schedule really runs"""
+    from multi_party_ecdsa_amd import engine as E
+    mods = [(1 << 2047) + (1 << 1000) + 1, (1 << 2048) - 159, (1 << 2047) + 0xF00F, (1 << 2047) + (1 << 1536) + (1 << 1024) + (1 << 512) + 3,
+            ((1 << 2048) - 1) // 3 | (1 << 2047) | 1]
+    pub = E.PaillierKeys(gpu_ctx, N=mods)
+    r = F.Rng("sliding-sparse")
+    kidx = [i % len(mods) for i in range(20 * len(mods))]
+    rr = [r.below(mods[k]) for k in kidx]
+    m = [r.below(mods[k]) for k in kidx]
+    got = pub.encrypt(m, rr, kidx)
+    want = [(1 + mm * mods[k]) * pow(x, mods[k], mods[k] ** 2) % mods[k] ** 2 for mm, x, k in zip(m, rr, kidx)]
+    assert got == want
