@@ -422,18 +422,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const uint32_t* ex2 = dual ? row_of(exps2, idx) : ex;
     // sliding windows: only when all the wave's exponentiations read the SAME exponent row (waves that straddle a key
     // boundary of the ordered launch keep the fixed windows) and, on a two-base ladder, the first window stays above exps2
-    bool sl = false;
+    bool sl_rt = false;                                       // does THIS wave run the sliding schedule?
     int sw_lo = -1;                                           // the pending window multiplication: after the squaring that
     uint32_t sw_val = 0;                                      // brings b down to sw_lo, times tab[sw_val]
     UniformWords exu = nullptr;                               // the wave's exponent row through a scalar pointer: the window
     if (SLIDE && slide) {                                     // schedule stays in SGPRs and the phase machine wave-uniform
       const uint64_t ea = (uint64_t)(uintptr_t)ex;
       const uint32_t e_lo = __builtin_amdgcn_readfirstlane((uint32_t)ea), e_hi = __builtin_amdgcn_readfirstlane((uint32_t)(ea >> 32));
-      sl = __ballot(ea != (((uint64_t)e_hi << 32) | e_lo)) == 0;
+      sl_rt = __ballot(ea != (((uint64_t)e_hi << 32) | e_lo)) == 0;
       exu = (UniformWords)(((uint64_t)e_hi << 32) | e_lo);
-      if (sl) {
+      if (sl_rt) {
         sw_lo = slide_window(exu, exp_words, exp_words * 32 - 1, wb, sw_val);
-        if (sw_lo < 0 || (dual && sw_lo < 32 * exp2_words)) sl = false;
+        if (sw_lo < 0 || (dual && sw_lo < 32 * exp2_words)) sl_rt = false;
       }
     }
 
@@ -453,8 +453,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       store_owner<C>(tab + C::K, t1, ln);
     }
 
-    const bool sl_ = SLIDE && sl;                             // (the fixed-window instantiation carries none of this)
-#define sl sl_
+    const bool sl = SLIDE && sl_rt;                           // (the fixed-window instantiation carries none of this)
     uint32_t cur0[C::L], cur1[C::L];
     int which = 0;                                            // 0: base / tab, 1: base2 / tab2
     const uint32_t* bw = row_of(base, idx);
@@ -568,7 +567,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         ph = b == 0 ? PP_FINAL : PP_SQ;
       }
     }
-#undef sl
     // canonical digits -> interface words z0 | z1.  The pair means the INTEGER z0 + z1 N with z0 < 2N lazily, so a
     // subtraction of N from z0 carries 1 into z1 (z0 >= N is a 2^-38 event for random operands, but e.g. the base N
     // itself lands exactly there); z1 is then reduced modulo N (multiples of N^2 drop out).
