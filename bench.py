@@ -716,11 +716,12 @@ def main():
     arrays = dict(lk["arrays"])
     for f in pub:
         arrays[f] = np.ascontiguousarray(pub[f].cpu().numpy().view(np.uint32))
-    gk = E.Gg20Keys(ctx, T, N_PARTIES, SIGNERS, arrays)
     gen = torch.Generator(device=dev)
     gen.manual_seed(4242 + rank)
     extra = {}
+    gk = None
     if args.mode == "session":
+        gk = E.Gg20Keys(ctx, T, N_PARTIES, SIGNERS, arrays)      # every signer local: the Simulation harness of the reference
         nonces = make_device_nonces(gen, dev, B, S, S, n)
         torch.cuda.synchronize()
 
@@ -746,7 +747,11 @@ def main():
                     w = v.shape[1]
                     mine[f] = v.reshape(B, S, per[f], w)[:, parties].reshape(B * len(parties) * per[f], w).contiguous()
             block_nonces[s] = mine
-            engines[s] = GpuRoundEngine(ctx, E, gk, B, parties, mine)
+            # a key object per hosted (block, parties): ONLY those parties' x_i, p, q reach it (mpe_gg20_keys_create n_own / h_own),
+            # as in the reference's deployment where a process holds one party's LocalKey
+            gk_own = E.Gg20Keys(ctx, T, N_PARTIES, SIGNERS, arrays, own=[SIGNERS[p_] for p_ in parties])
+            engines[s] = GpuRoundEngine(ctx, E, gk_own, B, parties, mine)
+            engines[s].keys = gk_own
             return engines[s]
         # the session objects live across steps, as a party process would keep them: a step re-arms them with the block's
         # sampled values (mpe_gg20_session_rearm) and runs the nine rounds
@@ -885,7 +890,8 @@ def main():
                                            if pair and dom_s else None)},
             "breakdown": {"modexp4096_s_per_step": dom_s / args.steps, "modexp2048_s_per_step": sec_s / args.steps,
                           "heavy_kernels_s_per_step": heavy_s / args.steps, "wall_s_per_step": elapsed / args.steps,
-                          "alg_unit_mac_per_signature": sig_macs(S, n), "fb_window_bits": gk.fb_window_bits()},
+                          "alg_unit_mac_per_signature": sig_macs(S, n),
+                          "fb_window_bits": (gk if gk is not None else next(iter(engines.values())).keys).fb_window_bits()},
             "roofline_secondary": secondary_rooflines(recs, elapsed),
             "whole_step": whole_step(recs, elapsed),
             "all_sessions_signed": all_signed, "launch": ctx.launch_info(),
