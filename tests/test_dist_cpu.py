@@ -132,7 +132,20 @@ class _OracleEngine:
         return {f: np.stack([r[f] for r in res]) for f in res[0]}
 
 
-def _worker_b(rank, world, port, t, n, signers, B, placement, q):
+class _OracleEngineInPlace(_OracleEngine):
+    """the same engine with the calling convention of the GPU one: it is handed its slot of the gather buffer and writes there"""
+    writes_in_place = True
+
+    def round(self, rnd, d_in, in_off, msg, out=None):
+        res = super().round(rnd, d_in, in_off, msg)
+        if res is None or out is None:
+            return res
+        assert out.is_contiguous() and out.shape == res.shape
+        out.copy_(res)
+        return out
+
+
+def _worker_b(rank, world, port, t, n, signers, B, placement, in_place, q):
     _init(rank, world, port)
     D = _load_dist()
     import fixtures as F
@@ -152,7 +165,8 @@ def _worker_b(rank, world, port, t, n, signers, B, placement, q):
         return out
 
     def make_engine(s, parties):
-        return _OracleEngine(lk, block_nonces(s), parties, Bblk)
+        cls = _OracleEngineInPlace if in_place else _OracleEngine
+        return cls(lk, block_nonces(s), parties, Bblk)
     ps = D.PartySharded(S, Bblk, lambda rnd: G.msg_words(S, n, rnd), make_engine, "cpu", placement=placement)
     msgs = {s: torch.from_numpy(block_nonces(s)["msg"].view(np.int32)) for s in ps.engines}
     res = ps.run(msgs)
@@ -163,11 +177,11 @@ def _worker_b(rank, world, port, t, n, signers, B, placement, q):
     dist.destroy_process_group()
 
 
-def _check_mode_b(world, t, n, signers, B, placement):
+def _check_mode_b(world, t, n, signers, B, placement, in_place=False):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import fixtures as F
     import gg20_fixture as G
-    res = _spawn(_worker_b, world, (t, n, signers, B, placement))
+    res = _spawn(_worker_b, world, (t, n, signers, B, placement, in_place))
     lk = G.make_local_keys(F.load_keys(), t, n, signers)
     nonces = G.make_nonces(lk, B, seed=f"modeB-{t}-{n}")
     want = G.oracle_sign_ex(lk, nonces, B)
@@ -199,3 +213,9 @@ def test_party_sharded_world3_one_party_per_rank():
 
 def test_party_sharded_rotated_blocks_world3_two_signers():
     _check_mode_b(3, 1, 3, [1, 2], 3, "rotated")
+
+
+def test_party_sharded_engines_that_write_into_the_gather_buffer():
+    """the GPU engine's calling convention (round(out=slot of the gather buffer), two alternating buffers, in-place all-gather)
+    with the oracle as the engine: world 2, rotated blocks"""
+    _check_mode_b(2, 1, 3, [0, 1], 4, "rotated", in_place=True)
