@@ -106,3 +106,23 @@ def test_rocprof_artifacts_agree_with_the_bench_line(rnd):
     assert pmc["sessions"] == b["config"]["sessions_per_gpu"]
     # HBM is not the bound: the kernel moves ~2 % of 8 TB/s
     assert k["hbm_GB_per_s"] < 0.05 * 8000
+
+
+def test_self_spawn_command_line(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run: one rank per GPU on
+    127.0.0.1, and bench.py's own flags (some are prefixes of the launcher's options: --n, --t) travel behind a `--`"""
+    import subprocess
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    rc = B.respawn_under_torchrun(4, ["--gpus", "4", "--mode", "party", "--t", "2", "--n", "5"])
+    cmd = seen["cmd"]
+    assert rc == 0 and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    sep = cmd.index("--")
+    assert cmd[sep + 1].endswith("bench.py") and cmd[sep + 2:] == ["--gpus", "4", "--mode", "party", "--t", "2", "--n", "5"]
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
