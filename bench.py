@@ -895,6 +895,8 @@ def main():
             "roofline_secondary": secondary_rooflines(recs, elapsed),
             "whole_step": whole_step(recs, elapsed),
             "all_sessions_signed": all_signed, "launch": ctx.launch_info(),
+            "device": {"name": torch.cuda.get_device_name(local_rank), "host": os.uname().nodename,
+                       "note": "boxes of this pool differ by up to ~3 % in signatures/s (profiles/r03/README.md)"},
         }
         if distributed:
             res["per_rank"] = per_rank
