@@ -861,7 +861,7 @@ def main():
                                    f"{'deduplicated checks' if args.dedup else 'faithful work'}, one LocalKey fixture, signers {{1..{T + 1}}}",
                        "sessions_per_gpu": B, "t": T, "n": N_PARTIES, "signers": S,
                        "parallelism": (f"session-sharded x{world}, no data-path collective" if args.mode == "session" else
-                                       f"party-sharded x{world}: party p of session block s on rank (s+p)%{world}, one RCCL all-gather per round"),
+                                       f"party-sharded x{world}: party p of session block s on rank (s+p)%{world}, one {'gloo (host-staged)' if share else 'RCCL'} all-gather per round"),
                        **extra},
             "roofline": {"bound": "valu-int (v_mad_u64_u32 issue rate; HBM traffic is negligible)",
                          "achieved": exe_macs / dom_s / 1e12 if dom_s else None, "peak": PEAK_MAC_PER_S / 1e12,
