@@ -65,18 +65,22 @@ def window_bits(exp_words):
 
 
 _SLIDING = {}
+SLIDING_EXPONENTS = None      # the PUBLIC exponents the timed launches really raise to (the signers' Paillier moduli N); set by main()
 
 
 def sliding_counts(bits, wb):
-    """(squarings, window multiplications) of the kernel's left-to-right sliding-window schedule (mpe_pairexp.h slide_window),
-    averaged over 32 seeded exponents of `bits` bits with the top bit set — the public exponents are RSA moduli N"""
+    """(squarings, window multiplications) of the kernel's left-to-right sliding-window schedule (mpe_pairexp.h slide_window)
+    for the public exponents of the run — the fixture's own moduli N when main() has set them (SLIDING_EXPONENTS: an exact
+    count, averaged over the keys in use), else the expectation over 32 seeded `bits`-bit exponents with the top bit set"""
     if (bits, wb) not in _SLIDING:
         import random
         rnd = random.Random(2048)
         sq_t = mul_t = 0
-        for _ in range(32):
-            e = rnd.getrandbits(bits) | (1 << (bits - 1)) | 1
-            i, first, sq, mul = bits - 1, True, 0, 0
+        exps = [e for e in (SLIDING_EXPONENTS or []) if e.bit_length() > bits - 32]
+        if not exps:
+            exps = [rnd.getrandbits(bits) | (1 << (bits - 1)) | 1 for _ in range(32)]
+        for e in exps:
+            i, first, sq, mul = e.bit_length() - 1, True, 0, 0
             while i >= 0:
                 if not (e >> i) & 1:
                     i -= 1
@@ -92,8 +96,18 @@ def sliding_counts(bits, wb):
                 i = lo - 1
             sq_t += sq
             mul_t += mul
-        _SLIDING[(bits, wb)] = (sq_t / 32, mul_t / 32)
+        _SLIDING[(bits, wb)] = (sq_t / len(exps), mul_t / len(exps))
     return _SLIDING[(bits, wb)]
+
+
+def slid(x):
+    """share of a launch that ran the sliding-window schedule: counted by the kernel itself per (wave, trip) (mpe_prof_rec.
+    sliding_frac) — "kind 6" only says the launch was ALLOWED to slide; waves that straddle a key boundary and two-base ladders
+    whose first window would dip below the second exponent keep the fixed windows"""
+    if x["kind"] != 6:
+        return 0.0
+    f = x.get("sliding_frac", -1.0)
+    return 1.0 if f is None or f < 0 else min(1.0, float(f))
 
 
 def pair_modexp_macs(k, exp_words, exp2_words=0, sliding=False):
@@ -102,17 +116,23 @@ def pair_modexp_macs(k, exp_words, exp2_words=0, sliding=False):
     (2 MAC(k)), a multiplication 2.5.  Fixed windows as the kernel chooses them; sliding=True: the schedule it runs for the
     PUBLIC exponent N (odd powers only in the table: one squaring + 2^(wb-1) - 1 multiplications; expected window count)."""
     wb = window_bits(exp_words)
-    if sliding:
-        sq, win = sliding_counts(32 * exp_words, wb)
-        sq += 1                                     # x^2 for the table of odd powers
-        mul = (1 << (wb - 1)) - 1 + win + 2         # x^3 .. x^(2^wb - 1), the windows, conversion in and out
-    else:
-        nwin = (32 * exp_words + wb - 1) // wb
-        sq = (nwin - 1) * wb
-        mul = (1 << wb) + nwin + 2                  # table (with the conversion in), one per window, conversion out
-    if exp2_words:
-        mul += 16 + 8 * exp2_words + 1
-    return (2 * sq + 2.5 * mul) * mac(k)
+    f = float(sliding)                              # True / False, or the measured share of the launch on the sliding schedule
+    tot = 0.0
+    for share, sl in ((f, True), (1.0 - f, False)):
+        if share <= 0:
+            continue
+        if sl:
+            sq, win = sliding_counts(32 * exp_words, wb)
+            sq += 1                                     # x^2 for the table of odd powers
+            mul = (1 << (wb - 1)) - 1 + win + 2         # x^3 .. x^(2^wb - 1), the windows, conversion in and out
+        else:
+            nwin = (32 * exp_words + wb - 1) // wb
+            sq = (nwin - 1) * wb
+            mul = (1 << wb) + nwin + 2                  # table (with the conversion in), one per window, conversion out
+        if exp2_words:
+            mul += 16 + 8 * exp2_words + 1
+        tot += share * (2 * sq + 2.5 * mul) * mac(k)
+    return tot
 
 
 def plain_modexp_macs(k, exp_words, exp2_words=0):
@@ -136,7 +156,7 @@ def secondary_rooflines(recs, elapsed):
     step each takes and how far from the v_mad_u64_u32 peak it runs (same accounting as `roofline`: ideal 32-bit limbs)"""
     groups = {
         "pair_modexp_kernel<Cfg<1024,29,18,2>> (key holder's CRT halves modulo p^2 | q^2)":
-            ([x for x in recs if x["kind"] in (3, 6) and x["bits"] == 2048], lambda x: pair_modexp_macs(32, x["exp_words"], x.get("exp2_words", 0), sliding=x["kind"] == 6)),
+            ([x for x in recs if x["kind"] in (3, 6) and x["bits"] == 2048], lambda x: pair_modexp_macs(32, x["exp_words"], x.get("exp2_words", 0), sliding=slid(x))),
         "pair_modexp_kernel<Cfg<1024,...>> half mode (x^(q mod p-1) modulo p)":
             ([x for x in recs if x["kind"] == 4 and x["bits"] == 1024], lambda x: plain_modexp_macs(32, x["exp_words"], x.get("exp2_words", 0))),
         "pair_modexp_kernel<Cfg<2048,...>> half mode (modulo N)":
@@ -165,7 +185,7 @@ def executed_macs(recs):
     for x in recs:
         k, b, ew, e2 = x["kind"], x["bits"], x["exp_words"], x.get("exp2_words", 0)
         if k in (3, 6):
-            tot += x["batch"] * pair_modexp_macs(b // 64, ew, e2, sliding=k == 6)
+            tot += x["batch"] * pair_modexp_macs(b // 64, ew, e2, sliding=slid(x))
         elif k in (0, 4):
             tot += x["batch"] * plain_modexp_macs(b // 32, ew, e2)
         elif k == 5:
@@ -298,7 +318,8 @@ def paillier_config2(ctx, E, keys, F, steps=1, oracle_threads=0, oracle_items=0)
     recs = ctx.prof_collect()
     ctx.prof_enable(False)
     kern = float(np.mean([r["ms"] for r in recs if r["kind"] in (0, 3, 6) and r["bits"] == 4096])) * 1e-3
-    c2_sliding = any(r["kind"] == 6 for r in recs)
+    c2_recs = [r for r in recs if r["kind"] == 6 and r["bits"] == 4096]
+    c2_sliding = float(np.mean([slid(r) for r in c2_recs])) if c2_recs else 0.0          # the share the kernel itself counted
     cpu = {}
     if oracle_threads:
         # the reference CPU path beside it: the GMP oracle (reference formulas over mpz_powm) on a bounded prefix, bit-exact check included
@@ -329,7 +350,7 @@ def paillier_config2(ctx, E, keys, F, steps=1, oracle_threads=0, oracle_items=0)
             "encrypt_per_s": B / t_enc, "decrypt_per_s": B / t_dec, "encrypt_public_key_per_s": B / t_pub,
             "modexp4096_2048_per_s": B / kern,
             "modexp4096_executed_TMAC_per_s": B * pair_modexp_macs(64, 64, sliding=c2_sliding) / kern / 1e12,
-            "modexp4096_executed_frac": B * pair_modexp_macs(64, 64, sliding=c2_sliding) / kern / PEAK_MAC_PER_S, "modexp4096_sliding_windows": c2_sliding,
+            "modexp4096_executed_frac": B * pair_modexp_macs(64, 64, sliding=c2_sliding) / kern / PEAK_MAC_PER_S, "modexp4096_sliding_windows": c2_sliding > 0, "modexp4096_sliding_share_of_waves": c2_sliding,
             "modexp4096_alg_unit_TMAC_per_s": B * modexp_macs(128, 2048) / kern / 1e12}
 
 
@@ -547,6 +568,87 @@ def gg20_config(ctx, E, G, keys, t, n, B, steps, gen, parity_sample=0, threads=N
     return res
 
 
+def c4_stream(E, G, keys, dev_index, batches=8, B=1024, inflight=2, parity_sample=64, threads=None, oracle=True):
+    """BASELINE config 4 as a SERVICE sees it: a stream of `batches` successive 1 024-session (t=1, n=3) batches, at most
+    `inflight` of them in flight, each on its own host thread with its own context and HIP stream (the §8b threading contract;
+    the reference runs its parties concurrently through `Simulation`, state_machine/sign.rs:667-691, and every round through
+    spawn_blocking).  One batch alone is latency-bound — four chains of ~2 048 dependent squarings at ~12 % occupancy
+    (profiles/r03/timeline_1024_sessions.json) — so the latency-bound rounds of one batch overlap the throughput-bound round 1
+    of another.  Every batch has its own freshly sampled nonces and messages.  Every signature is checked afterwards: all of
+    them under OpenSSL's ECDSA_do_verify, a sample of every batch bit for bit against the GMP oracle."""
+    import threading
+    t, n, signers = 1, 3, [0, 1]
+    S = len(signers)
+    lk = G.make_local_keys(keys, t, n, signers)
+    dev = torch.device("cuda", dev_index)
+    workers = []
+    for w in range(inflight):
+        ctx = E.Context(dev_index)
+        workers.append(dict(ctx=ctx, gk=E.Gg20Keys(ctx, t, n, signers, lk["arrays"]), stream=torch.cuda.Stream(device=dev)))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1024)
+    nonces = [make_device_nonces(gen, dev, B, S, S, n) for _ in range(batches)]
+    torch.cuda.synchronize()
+    results, errors = [None] * batches, []
+    go = threading.Barrier(inflight + 1)
+
+    def work(w, warm):
+        try:
+            wk = workers[w]
+            with torch.cuda.stream(wk["stream"]):
+                if warm:
+                    E.gg20_sign(wk["ctx"], wk["gk"], nonces[w % batches], B)
+                    wk["ctx"].sync()
+                    return
+                go.wait(timeout=300)
+                for b in range(w, batches, inflight):
+                    results[b] = E.gg20_sign(wk["ctx"], wk["gk"], nonces[b], B)
+                wk["ctx"].sync()
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(repr(e))
+            try:
+                go.abort()
+            except Exception:                                    # noqa: BLE001
+                pass
+    for warm in (True, False):
+        ths = [threading.Thread(target=work, args=(w, warm)) for w in range(inflight)]
+        for th in ths:
+            th.start()
+        if not warm:
+            torch.cuda.synchronize()
+            go.wait(timeout=300)
+            t0 = time.perf_counter()
+        for th in ths:
+            th.join()
+        if not warm:
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+    if errors:
+        return {"error": errors}
+    res = {"batches": batches, "sessions_per_batch": B, "in_flight": inflight, "signatures_per_s": batches * B / dt, "seconds": dt,
+           "ms_per_batch_sustained": dt / batches * 1e3,
+           "what": f"{batches} successive {B}-session t=1 n=3 batches, {inflight} in flight on {inflight} host threads x contexts x streams"}
+    threads = threads or min(host_cores()[0], 64)
+    signed, verified, parity = True, 0, True
+    for b in range(batches):
+        r, s_, recid, status = [o.cpu().numpy() for o in results[b]]
+        signed = signed and bool((status == 0).all())
+        verified += openssl_verify_all(lk["arrays"]["y"][0], nonces[b]["msg"], r, s_, threads)["openssl_verified"]
+        if oracle and parity_sample:
+            k = min(parity_sample, B)
+            hn = _host({f: v[: k * (v.shape[0] // B)] for f, v in nonces[b].items()})
+            _, wr, ws, wrecid, wstatus = cpu_baseline_gg20(lk, hn, k, min(threads, k))
+            parity = parity and bool((wstatus == 0).all() and np.array_equal(r[:k].view(np.uint32), wr) and np.array_equal(s_[:k].view(np.uint32), ws) and
+                                     np.array_equal(recid[:k], wrecid))
+    res.update(all_sessions_signed=signed, openssl_verified=verified, openssl_of=batches * B)
+    if oracle and parity_sample:
+        res.update(parity_vs_oracle_on_sample=parity, parity_sample_per_batch=min(parity_sample, B))
+    for wk in workers:
+        wk["gk"].close()
+        wk["ctx"].close()
+    return res
+
+
 def multi_wallet(ctx, E, G, keys, K, B, gen, t=1, n=3):
     """One batch whose sessions belong to K different wallets (key sets), round-robin — SURVEY.md 8d config 4 allows "16
     fixtures round-robin".  The 16 Paillier / N~ fixtures are reused cyclically for the K * n key slots (the per-key state
@@ -630,6 +732,83 @@ class GpuRoundEngine:
         self.sess.close()
 
 
+class PartyMode:
+    """Mode B on this rank: party p of session block s lives on rank (s + p) % world, this rank hosts S
+    (block, party) pairs of B sessions each, every round's records travel through ONE all-gather (dist.PartySharded).  The
+    session objects live across steps, as a party process would keep them: a step re-arms them and runs the nine rounds.
+
+    BENCHMARK ONLY: every step re-arms a block with the SAME sampled values (`keep`) so that the timed region holds nothing but
+    protocol work.  A real party samples fresh k_i, gamma_i and Paillier randomness for every batch — re-using them across two
+    signatures leaks the key share (include/mpecdsa_hip.h: mpe_gg20_session_rearm)."""
+
+    def __init__(self, ctx, E, G, mpe_dist, lk, arrays, T, n, signers, B, dev, world, parity_sessions=0):
+        self.E, self.G, self.lk, self.B, self.S, self.n = E, G, lk, B, len(signers), n
+        self.engines, self.block_nonces, self.block_sample = {}, {}, {}
+        S = self.S
+
+        def make_engine(s, parties):
+            g2 = torch.Generator(device=dev)
+            g2.manual_seed(977 * s + 13 + 7919 * n)            # the nonces of a block are a function of the block, on every rank
+            full = make_device_nonces(g2, dev, B, S, S, n)
+            if parity_sessions:                                # the whole block's sampled values of the first sessions, for the oracle
+                k = min(parity_sessions, B)
+                self.block_sample[s] = _host({f: v[: k * (v.shape[0] // B)] for f, v in full.items()})
+            per = dict(k=1, gamma=1, blind=1, r_a=1, l=1, ped_s1=1, ped_s2=1, heg_s1=1, heg_s2=1, al_alpha=n, al_beta=n, al_gamma=n,
+                       al_rho=n, mb_beta_tag=2 * (S - 1), mb_r=2 * (S - 1), mb_nonce_b=2 * (S - 1), mb_nonce_bt=2 * (S - 1),
+                       pdl_alpha=S - 1, pdl_beta=S - 1, pdl_rho=S - 1, pdl_gamma=S - 1)
+            mine = {}
+            for f, v in full.items():
+                if f == "msg":
+                    mine[f] = v
+                else:
+                    w = v.shape[1]
+                    mine[f] = v.reshape(B, S, per[f], w)[:, parties].reshape(B * len(parties) * per[f], w).contiguous()
+            self.block_nonces[s] = mine
+            # a key object per hosted (block, parties): ONLY those parties' x_i, p, q reach it (mpe_gg20_keys_create n_own / h_own),
+            # as in the reference's deployment where a process holds one party's LocalKey
+            gk_own = E.Gg20Keys(ctx, T, n, signers, arrays, own=[signers[p_] for p_ in parties])
+            self.engines[s] = GpuRoundEngine(ctx, E, gk_own, B, parties, mine)
+            self.engines[s].keys = gk_own
+            self.engines[s].parties = parties
+            return self.engines[s]
+        self.ps = mpe_dist.PartySharded(S, B, lambda rnd: E.gg20_msg_words(S, n, rnd), make_engine, dev, placement="rotated",
+                                        colocate=world < S, timing=True)
+        self.armed = True
+        self.last = None
+
+    def step(self):
+        if not self.armed:
+            for _, e_ in self.ps.engines.values():
+                e_.rearm()
+        self.armed = False
+        res = self.ps.run({s: self.block_nonces[s]["msg"] for s in self.ps.engines})
+        self.last = res
+        first = res[sorted(res)[0]]
+        return first["r"][0], first["s"][0], first["recid"][0], torch.cat([r_["status"].reshape(-1) for r_ in res.values()])
+
+    def parity(self, threads):
+        """the first sessions of this rank's first hosted block: the signature each hosted party of the block ended with against
+        the GMP oracle's for the same sampled values (bit for bit) -> (ok, sessions compared)"""
+        if not self.block_sample or self.last is None:
+            return None, 0
+        s0 = sorted(self.block_sample)[0]
+        host = self.block_sample[s0]
+        k = host["msg"].shape[0]
+        _, wr, ws, wrecid, wstatus = cpu_baseline_gg20(self.lk, host, k, max(1, min(threads, k)))
+        res = self.last[s0]
+        ok = bool((wstatus == 0).all())
+        for li in range(res["r"].shape[0]):
+            ok = ok and np.array_equal(res["r"][li, :k].cpu().numpy().view(np.uint32), wr)
+            ok = ok and np.array_equal(res["s"][li, :k].cpu().numpy().view(np.uint32), ws)
+            ok = ok and np.array_equal(res["recid"][li, :k].cpu().numpy(), wrecid)
+        return ok, k
+
+    def close(self):
+        for e_ in self.engines.values():
+            e_.close()
+            e_.keys.close()
+
+
 def respawn_under_torchrun(n, argv):
     """`python bench.py --gpus N` with no torch.distributed environment: this process becomes the launcher of N ranks, one
     per GPU (the same command line the driver would use), and exits with their status; rank 0 prints the JSON line."""
@@ -659,6 +838,11 @@ def main():
     ap.add_argument("--mode", choices=["session", "party"], default="session", help="multi-GPU layout (SURVEY.md 8e A / B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the c2 / c3 / c4 / c5 / Lindell sections")
+    ap.add_argument("--stream-inflight", type=int, default=2, help="c4_stream_1024: batches in flight (host threads x contexts x streams)")
+    ap.add_argument("--only", default="", help="comma list of config sections to run after the timed region (default: all)")
+    ap.add_argument("--no-mode-b", action="store_true", help="N > 1, session mode: skip the party-sharded (config 5 shape) pass after the timed region")
+    ap.add_argument("--mode-b-sessions", type=int, default=0, help="sessions per block of that pass (0 = min(8192, --sessions))")
+    ap.add_argument("--mode-b-steps", type=int, default=2)
     ap.add_argument("--share-device", action="store_true",
                     help="all ranks use cuda:0 and talk through gloo (host-staged): exercises the N>1 code path on a 1-GPU box; "
                          "the ranks time-share one GPU, so `value` says nothing about a node")
@@ -709,6 +893,8 @@ def main():
     SIGNERS = list(range(T + 1))                               # parties 1..t+1 sign
     B, S, n = args.sessions, len(SIGNERS), N_PARTIES
     lk = G.make_local_keys(keys, T, N_PARTIES, SIGNERS)
+    global SLIDING_EXPONENTS
+    SLIDING_EXPONENTS = [keys[i].N for i in SIGNERS]            # every launch on sliding windows raises to a signer's modulus N
     # the public key tables come from rank 0 once (LocalKey's public part is identical for everybody)
     pub = {f: torch.from_numpy(np.ascontiguousarray(lk["arrays"][f]).view(np.int32)) for f in ("Nt", "h1", "h2", "y", "X")}
     coll_dev = torch.device("cpu") if share else dev           # where the (tiny) control collectives run: gloo works on host tensors
@@ -730,43 +916,11 @@ def main():
     else:
         # party p of session block s on rank (s + p) % world: this rank hosts S (block, party) pairs of B sessions each —
         # the same per-GPU work as B whole sessions; the messages of every round travel through one all-gather
-        engines, block_nonces = {}, {}
-
-        def make_engine(s, parties):
-            g2 = torch.Generator(device=dev)
-            g2.manual_seed(977 * s + 13)                       # the nonces of a block are a function of the block, on every rank
-            full = make_device_nonces(g2, dev, B, S, S, n)
-            per = dict(k=1, gamma=1, blind=1, r_a=1, l=1, ped_s1=1, ped_s2=1, heg_s1=1, heg_s2=1, al_alpha=n, al_beta=n, al_gamma=n,
-                       al_rho=n, mb_beta_tag=2 * (S - 1), mb_r=2 * (S - 1), mb_nonce_b=2 * (S - 1), mb_nonce_bt=2 * (S - 1),
-                       pdl_alpha=S - 1, pdl_beta=S - 1, pdl_rho=S - 1, pdl_gamma=S - 1)
-            mine = {}
-            for f, v in full.items():
-                if f == "msg":
-                    mine[f] = v
-                else:
-                    w = v.shape[1]
-                    mine[f] = v.reshape(B, S, per[f], w)[:, parties].reshape(B * len(parties) * per[f], w).contiguous()
-            block_nonces[s] = mine
-            # a key object per hosted (block, parties): ONLY those parties' x_i, p, q reach it (mpe_gg20_keys_create n_own / h_own),
-            # as in the reference's deployment where a process holds one party's LocalKey
-            gk_own = E.Gg20Keys(ctx, T, N_PARTIES, SIGNERS, arrays, own=[SIGNERS[p_] for p_ in parties])
-            engines[s] = GpuRoundEngine(ctx, E, gk_own, B, parties, mine)
-            engines[s].keys = gk_own
-            return engines[s]
-        # the session objects live across steps, as a party process would keep them: a step re-arms them with the block's
-        # sampled values (mpe_gg20_session_rearm) and runs the nine rounds
-        ps = mpe_dist.PartySharded(S, B, lambda rnd: E.gg20_msg_words(S, n, rnd), make_engine, dev, placement="rotated",
-                                   colocate=world < S)
-        ps_holder = {"ps": ps, "armed": True}
-
-        def step():
-            if not ps_holder["armed"]:
-                for _, e_ in ps.engines.values():
-                    e_.rearm()
-            ps_holder["armed"] = False
-            res = ps.run({s: block_nonces[s]["msg"] for s in ps.engines})
-            first = res[sorted(res)[0]]
-            return first["r"][0], first["s"][0], first["recid"][0], torch.cat([r_["status"].reshape(-1) for r_ in res.values()])
+        pm = PartyMode(ctx, E, G, mpe_dist, lk, arrays, T, N_PARTIES, SIGNERS, B, dev, world, parity_sessions=0 if args.no_cpu_baseline else 8)
+        engines = pm.engines
+        gather_test = pm.ps.layout_self_test()                 # the gather layout on the real backend, before anything is timed
+        ps_holder = {"ps": pm.ps}
+        step = pm.step
 
     for _ in range(args.warmup):
         out = step()
@@ -799,11 +953,86 @@ def main():
         dist.all_gather(every, mine)
         rates = [float(t_[0]) for t_ in every]
         per_rank = {"signatures_per_s": rates, "min": min(rates), "max": max(rates), "all_ranks_signed": all(float(t_[1]) == 1.0 for t_ in every)}
+    usable_cores, _quota = host_cores()
+    rank_threads = max(1, min(16, usable_cores // max(1, world if not share else world)))      # the ranks share the host's cores
+    gather_layout = None
     if args.mode == "party":
         ps = ps_holder["ps"]
+        gather_layout = gather_test
         extra = {"bytes_all_gathered_per_round": {str(k): int(v) for k, v in ps.bytes_per_round.items()},
                  "rccl_time_share": comm_total / (elapsed if elapsed > 0 else 1.0), "placement": ps.placement,
-                 "pairs_per_rank": ps.per_rank}
+                 "pairs_per_rank": ps.per_rank, "gather_mode": ps.gather_mode,
+                 "nonces": "benchmark only: every step re-arms a block with the same sampled values (a real party samples fresh ones per batch)"}
+
+    # (c) a parity sample against the GMP oracle on EVERY rank at N > 1 (at N = 1 the cpu_baseline leg below does it on 256+ sessions)
+    rank_parity = None
+    if distributed and not args.no_cpu_baseline:
+        if args.mode == "session":
+            k = min(B, 16)
+            host_n = _host({f: v[: k * (v.shape[0] // B)] for f, v in nonces.items()})
+            _, wr, ws, wrecid, wstatus = cpu_baseline_gg20(lk, host_n, k, min(rank_threads, k))
+            ok = bool((wstatus == 0).all() and np.array_equal(out[0][:k].cpu().numpy().view(np.uint32), wr) and
+                      np.array_equal(out[1][:k].cpu().numpy().view(np.uint32), ws) and np.array_equal(out[2][:k].cpu().numpy(), wrecid))
+        else:
+            ok, k = pm.parity(rank_threads)
+        flags = torch.tensor([1.0 if ok else 0.0, float(k)], dtype=torch.float64, device=coll_dev)
+        every_f = [torch.zeros_like(flags) for _ in range(world)]
+        dist.all_gather(every_f, flags)
+        rank_parity = {"ok_per_rank": [bool(float(t_[0])) for t_ in every_f], "sessions_per_rank": int(k),
+                       "all_ok": all(float(t_[0]) == 1.0 for t_ in every_f),
+                       "what": "(r, s, recid) of the first sessions of every rank's own batch, bit for bit against the GMP oracle"}
+        if per_rank is not None:
+            per_rank["parity_vs_oracle"] = rank_parity
+
+    # (b) Mode B in the SAME line: after the session-sharded timed region a short party-sharded pass at BASELINE config 5's
+    # per-GPU share (t=2, n=5: S=3 signers; party p of session block s on rank (s+p) % N; one all-gather per round), so that
+    # the driver's one command `bench.py --gpus N` exercises the RCCL data path and reports its rate beside Mode A's
+    mode_b = None
+    want_b = (world > 1 or os.environ.get("MPE_BENCH_FORCE_MODE_B")) and distributed and args.mode == "session" and not args.no_mode_b
+    if want_b:
+        try:
+            tb, nb, sg_b = 2, 5, [0, 1, 2]
+            Bb = args.mode_b_sessions if args.mode_b_sessions else min(8192, B)
+            lk_b = G.make_local_keys(keys, tb, nb, sg_b)
+            pm_b = PartyMode(ctx, E, G, mpe_dist, lk_b, lk_b["arrays"], tb, nb, sg_b, Bb, dev, world,
+                             parity_sessions=0 if args.no_cpu_baseline else 4)
+            gather_layout = pm_b.ps.layout_self_test()
+            pm_b.step()                                        # warm-up
+            torch.cuda.synchronize()
+            pm_b.ps.comm_seconds()
+            dist.barrier()
+            torch.cuda.synchronize()
+            tb0 = time.perf_counter()
+            for _ in range(args.mode_b_steps):
+                out_b = pm_b.step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            own_b = time.perf_counter() - tb0
+            comm_b = pm_b.ps.comm_seconds()
+            el_b = mpe_dist.max_over_ranks(own_b, coll_dev)
+            ok_b, k_b = (None, 0) if args.no_cpu_baseline else pm_b.parity(rank_threads)
+            signed_b = bool((out_b[3] == 0).all().item())
+            mine_b = torch.tensor([Bb * args.mode_b_steps / own_b, 1.0 if signed_b else 0.0, 1.0 if (ok_b or ok_b is None) else 0.0, comm_b],
+                                  dtype=torch.float64, device=coll_dev)
+            every_b = [torch.zeros_like(mine_b) for _ in range(world)]
+            dist.all_gather(every_b, mine_b)
+            S_b = len(sg_b)
+            # a rank hosts S (block, party) pairs of Bb sessions: world blocks of Bb sessions are signed per step by the node
+            mode_b = {"workload": f"{Bb} sessions per GPU-share, t={tb} n={nb} (BASELINE config 5's shape), party-sharded: party p of session block s on "
+                                  f"rank (s+p)%{world}, {world} blocks, one {'gloo (host-staged)' if share else 'RCCL'} all-gather per round",
+                      "signatures_per_s": Bb * world * args.mode_b_steps / el_b, "ms_per_step": el_b / args.mode_b_steps * 1e3,
+                      "steps": args.mode_b_steps, "sessions_per_block": Bb, "blocks": world, "signers": S_b,
+                      "rccl_time_share": max(float(t_[3]) for t_ in every_b) / el_b,
+                      "bytes_all_gathered_per_round": {str(k_): int(v_) for k_, v_ in pm_b.ps.bytes_per_round.items()},
+                      "gather_mode": pm_b.ps.gather_mode, "per_rank_signatures_per_s": [float(t_[0]) for t_ in every_b],
+                      "all_sessions_signed": all(float(t_[1]) == 1.0 for t_ in every_b),
+                      "parity_sample_vs_oracle": None if args.no_cpu_baseline else all(float(t_[2]) == 1.0 for t_ in every_b),
+                      "parity_sessions_per_rank": int(k_b),
+                      "nonces": "benchmark only: every step re-arms a block with the same sampled values"}
+            pm_b.close()
+        except Exception as e_b:                               # noqa: BLE001 — the Mode-A line must survive a Mode-B failure, and say so
+            mode_b = {"error": repr(e_b)}
 
     # north_star asks for Paillier ops/s at 1, 2, 4 and 8 GPUs too: at N > 1 every rank runs BASELINE config 2 at the same time
     # (after the timed signing region) and the rates add up; at N = 1 it is the c2 section below
@@ -833,7 +1062,7 @@ def main():
             return x["batch"] * m
         dom_macs = sum(rec_macs(x, 128) for x in dom)
         # the MACs the executed algorithm needs (N-adic pairs: half-size passes) — what the hardware is asked to do
-        exe_macs = sum(x["batch"] * pair_modexp_macs(64, x["exp_words"], x.get("exp2_words", 0), sliding=x["kind"] == 6) for x in dom) if pair else dom_macs
+        exe_macs = sum(x["batch"] * pair_modexp_macs(64, x["exp_words"], x.get("exp2_words", 0), sliding=slid(x)) for x in dom) if pair else dom_macs
         n_sliding = sum(1 for x in dom if x["kind"] == 6)
         sec = [x for x in recs if x["kind"] in (0, 3, 6) and x["bits"] == 2048]
         sec_s = sum(x["ms"] for x in sec) * 1e-3
@@ -842,12 +1071,16 @@ def main():
         # HBM traffic of the dominant kernel: measured in separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied) and committed under profiles/ — not re-measured here
         traffic, traffic_src = None, None
-        for rel in ("profiles/r03/pmc_traffic.json", "profiles/r02/pmc_traffic.json"):
+        for rel in ("profiles/r04/pmc_traffic.json", "profiles/r03/pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, rel)) as f:
                     pmc = json.load(f)
                 if pmc.get("sessions") == B and not args.dedup and args.mode == "session" and (T, N_PARTIES) == (1, 3):
-                    traffic, traffic_src = pmc["hbm_bytes_per_launch"], rel
+                    # a figure QUOTED from a committed PMC pass (another box, possibly an earlier kernel build): say so next to it
+                    traffic = pmc["hbm_bytes_per_launch"]
+                    traffic_src = {"file": rel, "measured_in_this_run": False, "host": pmc.get("host"), "commit": pmc.get("commit"),
+                                   "sessions": pmc.get("sessions"),
+                                   "kernel_avg_ms_there": pmc.get("kernels", {}).get(pmc.get("dominant_kernel", ""), {}).get("avg_ms")}
                     break
             except OSError:
                 pass
@@ -872,10 +1105,15 @@ def main():
                          "alg_unit_frac": dom_macs / dom_s / PEAK_MAC_PER_S if dom_s else None,
                          "alg_unit_note": "SURVEY.md 8d's unit (CIOS on 32-bit limbs of the 4096-bit modulus, 4-bit windows): above the peak "
                                           "because the pair arithmetic computes the same residues with ~0.46x those MACs",
-                         "traffic": traffic, "traffic_unit": f"HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE; separate rocprofv3 --pmc passes)",
+                         "traffic_source": traffic_src,
                          "kernel": ("mpe::pair_modexp_kernel<Cfg<2048,29,18,4>>" if pair else "mpe::modexp_kernel<Cfg<4096,29,18,8>>") +
                                    " (all launches modulo N^2 of the timed region)",
-                         "launches": len(dom), "launches_on_sliding_windows": n_sliding, "avg_kernel_ms": dom_s / nl * 1e3,
+                         "launches": len(dom), "launches_on_sliding_windows": n_sliding,
+                         "sliding_share_of_waves": (sum(slid(x) * x["batch"] for x in dom) / max(1, sum(x["batch"] for x in dom if x["kind"] == 6))
+                                                    if n_sliding else 0.0),
+                         "sliding_schedule_priced_on": "the signers' own moduli N (exact left-to-right window counts)",
+                         "avg_kernel_ms": dom_s / nl * 1e3,
                          "executed_mac_per_launch": exe_macs / nl, "alg_unit_mac_per_launch": dom_macs / nl,
                          "kernel_time_share_of_step": dom_s / elapsed,
                          # the issue ceiling actually measured for this instruction (tools/ubench/valu_rate.hip): a stream of
@@ -901,15 +1139,19 @@ def main():
         if distributed:
             res["per_rank"] = per_rank
             res["all_sessions_signed"] = all_signed and per_rank["all_ranks_signed"]
+            if mode_b is not None:
+                res["mode_b"] = mode_b
             res["rccl"] = rccl if rccl is not None else {"backend": "gloo", "note": "--share-device: every rank on cuda:0, collectives staged "
                                                          "through host memory; the ranks time-share one GPU (a functional run, not a node figure)"}
+            # the layout of the round all-gather checked on the real backend before any party-sharded work (dist.PartySharded.layout_self_test)
+            res["rccl"]["all_gather_layout_self_test"] = gather_layout
         # the other configs and the CPU baseline belong to the single-GPU line (rank 0 at N=1 only): at N>1 the other ranks
         # would just wait for them
         single = world == 1 and args.mode == "session"
         usable, quota = host_cores()
         threads = min(usable, 64)
         if single and not args.no_cpu_baseline:
-            sample = min(B, 16 * threads)
+            sample = min(B, max(1024, 16 * threads))     # >= BASELINE config 4's full size: the driver's line alone carries its parity
             host_nonces = _host({f: v[: sample * (v.shape[0] // B)] for f, v in nonces.items()})
             one = min(4, sample)
             t1 = time.time()
@@ -932,7 +1174,11 @@ def main():
             gk.close()
             cfg, took = {}, {}
 
+            only = [x for x in args.only.split(",") if x]
+
             def section(name, fn):
+                if only and not any(name.startswith(o) for o in only):
+                    return
                 t_ = time.perf_counter()
                 cfg[name] = fn()
                 took[name] = round(time.perf_counter() - t_, 2)
@@ -941,13 +1187,17 @@ def main():
             section("c3b_bob_65536", lambda: bob_section(ctx, E, keys, F, oracle=not args.no_cpu_baseline))
             section("c4_literal_1024", lambda: gg20_config(ctx, E, G, keys, 1, 3, 1024, 4, gen, parity_sample=0 if args.no_cpu_baseline else 128,
                                                            openssl=True))
+            section("c4_stream_1024", lambda: c4_stream(E, G, keys, local_rank, batches=8, B=1024, inflight=args.stream_inflight,
+                                                        oracle=not args.no_cpu_baseline))
             section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32,
                                                               openssl=True))
             section("c4_multi_wallet_16384", lambda: [multi_wallet(ctx, E, G, keys, K_, 16384, gen) for K_ in (16, 1024)])
             section("lindell17", lambda: lindell_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline))
-            res["lindell17"] = cfg.pop("lindell17")
+            if "lindell17" in cfg:
+                res["lindell17"] = cfg.pop("lindell17")
             res["configs"] = cfg
-            res["paillier"] = cfg["c2_paillier_65536"]
+            if "c2_paillier_65536" in cfg:
+                res["paillier"] = cfg["c2_paillier_65536"]
             res["section_seconds"] = took
         if node_paillier is not None:
             res["paillier"] = node_paillier

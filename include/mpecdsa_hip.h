@@ -16,7 +16,21 @@
  *  - Return value: 0 = ok, negative = MPE_E_* (argument/launch errors).  Verifiers additionally
  *    write a per-item uint8_t ok[] (1 = accept) — the batched form of the reference's
  *    bool / Result<(), Error> returns; one bad item never aborts the batch.
- *  - No global state: distinct mpe_ctx may be used from distinct host threads / streams.
+ *  - No mutable global state: distinct mpe_ctx may be used from distinct host threads / streams at the same time
+ *    (tests/test_threads_gpu.py).  The environment is read only inside mpe_ctx_create; mpe_last_error() is per thread.
+ *
+ * Two caveats a binder must know
+ *  - RECALLED conventions.  curv-kzen 0.9, kzen-paillier 0.4.2 and zk-paillier 0.4.3 are not vendored with the reference
+ *    (Cargo.toml:36-47), so these byte-level details are believed, not read: DigestExt::chain_point hashing the 65-byte
+ *    uncompressed point; BigInt::to_bytes(0) = one 0x00 byte; the order of the points in the challenges of DLogProof,
+ *    PedersenProof, HomoELGamalProof, ECDDHProof; zk-paillier's SALT_STRING, mask_generation block order and
+ *    CompositeDLogProof field order; the serde forms of BigInt / Point / Scalar (host side only: multi_party_ecdsa_amd/wire.py).
+ *    Each is a run-time field of `mpe_encoding` (mpe_ctx_set_encoding below), exercised in every alternative by the tests;
+ *    tools/diagnose_encodings.py finds the profile of the real crates from one dump of vectors (tools/rust_vectors/run.sh).
+ *  - Side channels.  No secret-dependent control flow (fixed window schedules, masked selects; the one exponent whose bits
+ *    steer the operation sequence is the PUBLIC key N), but window tables in HBM are indexed by secret exponent windows:
+ *    the kernels are NOT constant-time against a co-tenant observing memory-access patterns on the same GPU.  Deploy on a
+ *    GPU dedicated to the signing service.  (The reference's mpz_powm makes no constant-time claim either.)
  */
 #ifndef MPECDSA_HIP_H
 #define MPECDSA_HIP_H
@@ -50,6 +64,44 @@ int mpe_ctx_wipe(mpe_ctx* ctx, void* stream);
 int mpe_ctx_scratch_audit(mpe_ctx* ctx, uint64_t* nonzero_words, uint64_t* total_bytes, void* stream);
 /* Blocks the host until everything queued on `stream` has finished (hipStreamSynchronize). */
 int mpe_sync(mpe_ctx* ctx, void* stream);
+
+/* ---- byte-level conventions of the un-vendored crates -------------------------------------------------------------------
+ * The reference pulls curv-kzen 0.9, kzen-paillier 0.4.2 and zk-paillier 0.4.3 from crates.io (Cargo.toml:36-47); none is
+ * vendored under /root/reference, so the byte strings their Fiat-Shamir transcripts hash are RECALLED, not read.  Every such
+ * convention is a run-time property of a context — never a build-time constant — so that the day a vector dumped from the
+ * real crates (tools/rust_vectors/run.sh -> tests/golden/ref_vectors.json) disagrees with a default below, the fix is one
+ * mpe_ctx_set_encoding call, not a kernel edit.  tools/diagnose_encodings.py reads such a dump and prints the profile the
+ * crates actually use.  The defaults are what this repository believes curv 0.9 does.
+ *
+ * What is NOT here because the reference's own source fixes it: AliceProof / BobProof / PDLwSlackProof transcripts
+ * (range_proofs.rs:143-150,175-182,375-405; zk_pdl_with_slack/mod.rs:102-110: chain_bigint of every field, points as
+ * BigInt::from_bytes(to_bytes(true))) and the message of the HashCommitment (party_i.rs:577-580: the compressed point as a
+ * BigInt).  They depend on the crates only through `zero_bytes`. */
+typedef struct mpe_encoding {
+  uint8_t chain_point;      /* curv `DigestExt::chain_point(P)` (DLogProof mta/mod.rs:147-148,170-171; PedersenProof party_i.rs:620-634;
+                             * HomoELGamalProof :778-833; ECDDHProof blame.rs:258-320):
+                             * 0 = P.to_bytes(false), 65 bytes 04|x|y (default);  1 = P.to_bytes(true), 33 bytes 02/03|x */
+  uint8_t zero_bytes;       /* `BigInt::to_bytes()` of the value 0, as hashed by chain_bigint / zk-paillier's compute_digest:
+                             * 0 = one 0x00 byte (rust-gmp exports sizeinbase(0) = 1 digit; default);  1 = the empty string */
+  uint8_t ck_mask_order;    /* zk-paillier `mask_generation` of NiCorrectKeyProof (party_i.rs:283-301): the 256-bit blocks
+                             * H(seed, j), j = 0.. are combined as  0 = sum_j H(seed, j) << (256 j) (default);
+                             * 1 = H(seed, 0) || H(seed, 1) || ... (block 0 most significant) */
+  uint8_t reserved;         /* must be 0 */
+  uint32_t ck_salt;         /* NiCorrectKeyProof's salt as an integer: SALT_STRING = b"KZen" = 0x4B5A656E (default) */
+  /* order of the points inside the challenge hash of each curv sigma proof: ord[i] = index (into the canonical list named
+   * here) of the point hashed i-th; the default is the identity.  Unused tail entries are ignored. */
+  uint8_t ord_dlog[4];      /* DLogProof        (R = pk_t_rand_commitment, G, pk) */
+  uint8_t ord_pedersen[8];  /* PedersenProof    (g, h, com, a1, a2) */
+  uint8_t ord_heg[8];       /* HomoELGamalProof (T, A3, G, H, Y, D, E) */
+  uint8_t ord_ecddh[8];     /* ECDDHProof       (g1, h1, g2, h2, a1, a2) */
+  uint8_t ord_cdlog[4];     /* zk-paillier CompositeDLogProof challenge, BigInts (x, g, N, ni)  (party_i.rs:219-258) */
+} mpe_encoding;
+/* Fills *out with the defaults above.  Never touches the GPU. */
+void mpe_encoding_default(mpe_encoding* out);
+/* Installs / reads the profile of a context.  set returns MPE_E_ARG unless every flag is 0/1 and every ord_* prefix is a
+ * permutation.  Takes effect for every later call on the context (objects created earlier hold no encoded state). */
+int mpe_ctx_set_encoding(mpe_ctx* ctx, const mpe_encoding* enc);
+int mpe_ctx_get_encoding(const mpe_ctx* ctx, mpe_encoding* out);
 
 /* ---- moduli ------------------------------------------------------------------------------ */
 /* Precomputes, ON THE GPU, the Montgomery constants of `count` odd moduli of `bits` (2048|4096)
@@ -334,7 +386,10 @@ int mpe_gg20_session_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, 
 int mpe_gg20_session_destroy(mpe_gg20_session* sess, void* stream);
 /* The next batch of the same shape on the same object (a party process signs batch after batch: `SignManual::new` again
  * with fresh `SignKeys`, sign.rs:540-569): new sampled values (and key-set choice), state of the previous batch zeroed, rounds
- * start again at 0.  Results are identical to those of a freshly created session. */
+ * start again at 0.  Results are identical to those of a freshly created session.
+ * `nonces` MUST hold freshly sampled values (the same buffers refilled are fine): signing two batches with the same k_i,
+ * gamma_i or Paillier randomness leaks the key share, and the library cannot detect it.  MPE_E_ARG when the previous batch is
+ * half-way through the protocol (finish it with mpe_gg20_complete or destroy the object); MPE_E_HIP when the wipe fails. */
 int mpe_gg20_session_rearm(mpe_gg20_session* sess, const int32_t* d_keyset, const mpe_gg20_nonces* nonces, void* stream);
 int mpe_gg20_round0(mpe_gg20_session* sess, uint32_t* d_out, void* stream);
 int mpe_gg20_round1(mpe_gg20_session* sess, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream);
@@ -478,7 +533,13 @@ int mpe_last_launch_info(const mpe_ctx* ctx, mpe_launch_info* out);
  * (bits = width of the SQUARE: 4096 for N^2, 2048 for p^2 | q^2), 4 = the pair kernel in `half` mode (plain Montgomery ladder
  * modulo N or p; bits = that width), 5 = fixed-base ladder modulo N~ (exp2_words = the table's window width in bits),
  * 6 = the pair kernel with a PUBLIC exponent (the key N): items ordered by key, sliding windows wherever a wave shares it. */
-typedef struct { int kind; int bits; int exp_words; int batch; float ms; int exp2_words; } mpe_prof_rec;  /* exp2_words != 0: mpe_modexp2-style launch */
+typedef struct {
+  int kind; int bits; int exp_words; int batch; float ms;
+  int exp2_words;       /* != 0: mpe_modexp2-style launch (two bases on one ladder) */
+  float sliding_frac;   /* kind 6: the share of the launch's (wave, trip) pairs that really ran the sliding-window schedule, counted by
+                         * the kernel (waves that straddle a key boundary, and two-base ladders whose first window would dip below
+                         * the second exponent, keep fixed windows); 0 for the other kinds; -1 = not counted */
+} mpe_prof_rec;
 int mpe_prof_enable(mpe_ctx* ctx, int on);       /* clears earlier records */
 int mpe_prof_collect(mpe_ctx* ctx, mpe_prof_rec* out, int max_records, int* n_out);  /* waits for the events */
 

@@ -23,7 +23,35 @@ class LaunchInfo(C.Structure):
 
 
 class ProfRec(C.Structure):
-    _fields_ = [("kind", C.c_int), ("bits", C.c_int), ("exp_words", C.c_int), ("batch", C.c_int), ("ms", C.c_float), ("exp2_words", C.c_int)]
+    _fields_ = [("kind", C.c_int), ("bits", C.c_int), ("exp_words", C.c_int), ("batch", C.c_int), ("ms", C.c_float), ("exp2_words", C.c_int),
+                ("sliding_frac", C.c_float)]
+
+
+class Encoding(C.Structure):
+    """`mpe_encoding` (include/mpecdsa_hip.h): the recalled byte-level conventions of curv / zk-paillier as a run-time profile"""
+    _fields_ = [("chain_point", C.c_uint8), ("zero_bytes", C.c_uint8), ("ck_mask_order", C.c_uint8), ("reserved", C.c_uint8),
+                ("ck_salt", C.c_uint32), ("ord_dlog", C.c_uint8 * 4), ("ord_pedersen", C.c_uint8 * 8), ("ord_heg", C.c_uint8 * 8),
+                ("ord_ecddh", C.c_uint8 * 8), ("ord_cdlog", C.c_uint8 * 4)]
+    SIZES = dict(ord_dlog=3, ord_pedersen=5, ord_heg=7, ord_ecddh=6, ord_cdlog=4)
+
+    @classmethod
+    def from_dict(cls, d):
+        """d: {"chain_point": 0|1, "zero_bytes": 0|1, "ck_mask_order": 0|1, "ck_salt": int, "ord_*": [..]} (missing = default)"""
+        e = cls()
+        lib.mpe_encoding_default(C.byref(e))
+        for k, v in d.items():
+            if k.startswith("ord_"):
+                arr = getattr(e, k)
+                for i, x in enumerate(v):
+                    arr[i] = x
+            else:
+                setattr(e, k, v)
+        return e
+
+    def as_dict(self):
+        out = {k: getattr(self, k) for k in ("chain_point", "zero_bytes", "ck_mask_order", "ck_salt")}
+        out.update({k: list(getattr(self, k))[:n] for k, n in self.SIZES.items()})
+        return out
 
 
 def _ptr_struct(name, fields):
@@ -66,6 +94,9 @@ def _load():
         "mpe_ctx_create": (ip, [C.POINTER(vp), ip]),
         "mpe_ctx_destroy": (ip, [vp]),
         "mpe_sync": (ip, [vp, vp]),
+        "mpe_encoding_default": (None, [C.POINTER(Encoding)]),
+        "mpe_ctx_set_encoding": (ip, [vp, C.POINTER(Encoding)]),
+        "mpe_ctx_get_encoding": (ip, [vp, C.POINTER(Encoding)]),
         "mpe_modset_create": (ip, [vp, ip, ip, u32p, C.POINTER(vp), vp]),
         "mpe_modset_destroy": (ip, [vp]),
         "mpe_modset_count": (ip, [vp]),
@@ -163,6 +194,7 @@ lib = _load()
 
 # every symbol include/mpecdsa_hip.h declares; tests check the library exports all of them
 EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy", "mpe_sync",
+            "mpe_encoding_default", "mpe_ctx_set_encoding", "mpe_ctx_get_encoding",
             "mpe_modset_create", "mpe_modset_destroy", "mpe_modset_count", "mpe_modset_bits",
             "mpe_modexp", "mpe_modexp2", "mpe_modmul", "mpe_last_launch_info", "mpe_paillier_create_public",
             "mpe_paillier_create_private", "mpe_paillier_destroy", "mpe_paillier_nkeys", "mpe_paillier_n",

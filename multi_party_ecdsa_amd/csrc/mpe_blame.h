@@ -95,10 +95,10 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC gni_kernel(Dim d, const uint32_
 }
 struct Ecddh { const uint32_t *a1, *a2, *z; };
 __device__ inline bool ecddh_verify(const ec::Aff& g1, const ec::Aff& h1, const ec::Aff& g2, const ec::Aff& h2, const ec::Aff& a1,
-                                    const ec::Aff& a2, const ec::U256& z) {
+                                    const ec::Aff& a2, const ec::U256& z, const ec::Enc& enc) {
   if (!(ec::aff_valid(g1) && ec::aff_valid(h1) && ec::aff_valid(g2) && ec::aff_valid(h2) && ec::aff_valid(a1) && ec::aff_valid(a2))) return false;
   const ec::Aff hp[6] = {g1, h1, g2, h2, a1, a2};
-  const ec::U256 e = gg::hash_points(hp);
+  const ec::U256 e = gg::hash_points(hp, enc, enc.ord_ecddh);
   return ec::jac_eq(ec::jac_mul(z, g1), ec::jac_add_aff(ec::jac_mul(e, h1), a1)) &&
          ec::jac_eq(ec::jac_mul(z, g2), ec::jac_add_aff(ec::jac_mul(e, h2), a2));
 }
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC gsigma_kernel(Dim d, const uint
   }
   const ec::Aff gs = ec::jac_to_aff(acc);
   ok[pi] = ecddh_verify(ec::aff_gen(), gs, ec::aff_load(R + (size_t)b * 16), ec::aff_load(Svec + (size_t)pi * 16),
-                        ec::aff_load(pr.a1 + (size_t)pi * 16), ec::aff_load(pr.a2 + (size_t)pi * 16), ec::sc_reduce(pr.z + (size_t)pi * 8, 8)) ? 1 : 0;
+                        ec::aff_load(pr.a1 + (size_t)pi * 16), ec::aff_load(pr.a2 + (size_t)pi * 16), ec::sc_reduce(pr.z + (size_t)pi * 8, 8), d.enc) ? 1 : 0;
 }
 __global__ void blame6_combine_kernel(Dim d, const uint8_t* __restrict__ mu_ok, const uint8_t* __restrict__ ca_ok, const uint8_t* __restrict__ dd_ok,
                                       uint32_t* __restrict__ bad_out) {
@@ -155,7 +155,7 @@ __global__ void mask_from_flags_kernel(int B, int S, const uint8_t* __restrict__
   for (int i = 0; i < S; ++i) if (!ok[(size_t)b * S + i]) bad |= 1u << i;
   bad_out[b] = bad;
 }
-__global__ void __launch_bounds__(64) MPE_EC_OCC ecddh_prove_kernel(int B, const uint32_t* __restrict__ x, const uint32_t* __restrict__ s_in, const uint32_t* __restrict__ g1,
+__global__ void __launch_bounds__(64) MPE_EC_OCC ecddh_prove_kernel(int B, ec::Enc enc, const uint32_t* __restrict__ x, const uint32_t* __restrict__ s_in, const uint32_t* __restrict__ g1,
                                                          const uint32_t* __restrict__ h1, const uint32_t* __restrict__ g2, const uint32_t* __restrict__ h2,
                                                          uint32_t* __restrict__ a1, uint32_t* __restrict__ a2, uint32_t* __restrict__ z) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,18 +165,18 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC ecddh_prove_kernel(int B, const
                 H2 = ec::aff_load(h2 + (size_t)i * 16);
   const ec::Aff A1 = gg::mul_aff(s, G1), A2 = gg::mul_aff(s, G2);
   const ec::Aff hp[6] = {G1, H1, G2, H2, A1, A2};
-  const ec::U256 e = gg::hash_points(hp);
+  const ec::U256 e = gg::hash_points(hp, enc, enc.ord_ecddh);
   ec::aff_store(a1 + (size_t)i * 16, A1);
   ec::aff_store(a2 + (size_t)i * 16, A2);
   ec::u256_store(z + (size_t)i * 8, ec::sc_add(s, ec::sc_mul(e, xx)));
 }
-__global__ void __launch_bounds__(64) MPE_EC_OCC ecddh_verify_kernel(int B, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ h1, const uint32_t* __restrict__ g2,
+__global__ void __launch_bounds__(64) MPE_EC_OCC ecddh_verify_kernel(int B, ec::Enc enc, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ h1, const uint32_t* __restrict__ g2,
                                                           const uint32_t* __restrict__ h2, Ecddh pr, uint8_t* __restrict__ ok) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   ok[i] = ecddh_verify(ec::aff_load(g1 + (size_t)i * 16), ec::aff_load(h1 + (size_t)i * 16), ec::aff_load(g2 + (size_t)i * 16),
                        ec::aff_load(h2 + (size_t)i * 16), ec::aff_load(pr.a1 + (size_t)i * 16), ec::aff_load(pr.a2 + (size_t)i * 16),
-                       ec::sc_reduce(pr.z + (size_t)i * 8, 8)) ? 1 : 0;
+                       ec::sc_reduce(pr.z + (size_t)i * 8, 8), enc) ? 1 : 0;
 }
 // the session's openings for phase-6 blame: the ECDDH proof that S_i = sigma_i R (blame.rs:258-272), sigma_i never leaves
 __global__ void __launch_bounds__(64) MPE_EC_OCC session_ecddh_kernel(Dim d, const uint32_t* __restrict__ sigma_i, const uint32_t* __restrict__ R,
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC session_ecddh_kernel(Dim d, con
   const ec::Aff H1 = ec::jac_to_aff(ec::jac_mul_gen(x)), H2 = gg::mul_aff(x, G2);
   const ec::Aff A1 = ec::jac_to_aff(ec::jac_mul_gen(s)), A2 = gg::mul_aff(s, G2);
   const ec::Aff hp[6] = {G1, H1, G2, H2, A1, A2};
-  const ec::U256 e = gg::hash_points(hp);
+  const ec::U256 e = gg::hash_points(hp, d.enc, d.enc.ord_ecddh);
   ec::aff_store(a1 + o * 16, A1);
   ec::aff_store(a2 + o * 16, A2);
   ec::u256_store(z + o * 8, ec::sc_add(s, ec::sc_mul(e, x)));
@@ -204,8 +204,9 @@ __global__ void miu_out_kernel(Dim d, const uint32_t* __restrict__ miu, uint32_t
   out[((pi % d.L) * d.B + pi / d.L) * per + w] = miu[g];
 }
 
-static Dim blame_dim(const mpe_gg20_keys* K, int B, const int32_t* d_keyset) {
+static Dim blame_dim(const mpe_ctx* ctx, const mpe_gg20_keys* K, int B, const int32_t* d_keyset) {
   Dim d{};
+  d.enc = ctx->enc;
   d.B = B; d.S = K->S; d.n = K->n; d.L = K->S; d.K = K->K; d.n_own = K->n_own; d.ks = d_keyset;
   for (int i = 0; i < 8; ++i) { d.loc[i] = i; d.sg[i] = K->signers[i]; d.oslot[i] = K->own_slot[i] < 0 ? 0 : K->own_slot[i]; }
   return d;
@@ -281,7 +282,7 @@ int mpe_gg20_blame5(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const in
   using namespace mpe;
   hipStream_t st = (hipStream_t)stream;
   const int S = keys->S, P1 = S - 1, nPI = batch * S, nPP = nPI * P1;
-  const bl::Dim d = bl::blame_dim(keys, batch, d_keyset);
+  const bl::Dim d = bl::blame_dim(ctx, keys, batch, d_keyset);
   // own arrays at the top of the workspace (never handed out, never moved: ws_top), the Paillier composites below
   const size_t own = ((size_t)nPI * (64 + 128) + (size_t)nPP * 128) * 4 + ((size_t)nPI + 3 * (size_t)nPP) * 4 + (size_t)nPI * 2 + nPP + 16 * 256;   // BIdx: one [nPI] + three [nPP] arrays; 256 B slack per take()
   MPE_TRY(ws_reserve(ctx, own + ws_need_encrypt(nPI) + ws_need_mul_add_enc(nPP) + (1u << 20), st));
@@ -322,7 +323,7 @@ int mpe_gg20_blame6(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const in
   using namespace mpe;
   hipStream_t st = (hipStream_t)stream;
   const int S = keys->S, P1 = S - 1, nPI = batch * S, nPP = nPI * P1;
-  const bl::Dim d = bl::blame_dim(keys, batch, d_keyset);
+  const bl::Dim d = bl::blame_dim(ctx, keys, batch, d_keyset);
   const size_t own = ((size_t)nPI * (64 + 128) + (size_t)nPP * (128 + 16)) * 4 + ((size_t)nPI + 3 * (size_t)nPP) * 4 + (size_t)nPI * 2 + nPP + 16 * 256;   // BIdx: one [nPI] + three [nPP] arrays; 256 B slack per take()
   MPE_TRY(ws_reserve(ctx, own + ws_need_encrypt(nPP) + (1u << 20), st));
   char* top = (char*)ctx->ws + ctx->ws_bytes;
@@ -375,13 +376,13 @@ int mpe_ecddh_prove(mpe_ctx* ctx, int batch, const uint32_t* d_x, const uint32_t
                     const mpe_ecddh_proof* out, void* stream) {
   if (!ctx || !d_x || !d_s || !statement || !out || batch < 0) return MPE_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  MPE_LAUNCH_1D(mpe::bl::ecddh_prove_kernel, batch, st, batch, d_x, d_s, statement->g1, statement->h1, statement->g2, statement->h2, out->a1, out->a2, out->z);
+  MPE_LAUNCH_1D(mpe::bl::ecddh_prove_kernel, batch, st, batch, ctx->enc, d_x, d_s, statement->g1, statement->h1, statement->g2, statement->h2, out->a1, out->a2, out->z);
   return MPE_OK;
 }
 int mpe_ecddh_verify(mpe_ctx* ctx, int batch, const mpe_ecddh_statement* statement, const mpe_ecddh_proof* proof, uint8_t* d_ok, void* stream) {
   if (!ctx || !statement || !proof || !d_ok || batch < 0) return MPE_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  MPE_LAUNCH_1D(mpe::bl::ecddh_verify_kernel, batch, st, batch, statement->g1, statement->h1, statement->g2, statement->h2,
+  MPE_LAUNCH_1D(mpe::bl::ecddh_verify_kernel, batch, st, batch, ctx->enc, statement->g1, statement->h1, statement->g2, statement->h2,
                 mpe::bl::Ecddh{proof->a1, proof->a2, proof->z}, d_ok);
   return MPE_OK;
 }

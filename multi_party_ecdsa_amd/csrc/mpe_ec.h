@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/mpecdsa_hip.h"
 #include "mpe_jac.h"
 #include "mpe_sc.h"
 
@@ -112,13 +113,17 @@ __device__ inline void sha_byte(Sha256& s, uint32_t byte) {
   s.len++;
   if ((s.len & 63) == 0) sha_block(s);
 }
-// DigestExt::chain_bigint: big-endian magnitude, minimal length (0 -> one 0x00 byte)
-__device__ inline void sha_bigint(Sha256& s, const uint32_t* x, int nwords) {
+// The byte-level conventions of curv / zk-paillier that the reference's own source does not fix are a run-time property of the
+// context (mpe_encoding, include/mpecdsa_hip.h): every kernel that hashes takes it by value in its kernel arguments.
+using Enc = mpe_encoding;
+// DigestExt::chain_bigint: big-endian magnitude, minimal length (0 -> one 0x00 byte, or nothing: enc.zero_bytes)
+__device__ inline void sha_bigint(Sha256& s, const uint32_t* x, int nwords, const Enc& enc) {
   int top = nwords - 1;
   while (top > 0 && x[top] == 0) --top;
   int nb = 4;
   const uint32_t tw = x[top];
   if (tw < (1u << 8)) nb = 1; else if (tw < (1u << 16)) nb = 2; else if (tw < (1u << 24)) nb = 3;
+  if (top == 0 && tw == 0 && enc.zero_bytes) nb = 0;
   for (int b = nb - 1; b >= 0; --b) sha_byte(s, tw >> (8 * b));
   for (int i = top - 1; i >= 0; --i) {
     const uint32_t w = x[i];
@@ -131,8 +136,12 @@ __device__ inline void sha_be32(Sha256& s, const U256& v) {
 }
 // Point::to_bytes(true) as hashed by zk_pdl_with_slack (BigInt::from_bytes(33 bytes) -> to_bytes: identical bytes)
 __device__ inline void sha_point_compressed(Sha256& s, const Aff& p) { sha_byte(s, 2u + (p.y.w[0] & 1u)); sha_be32(s, p.x); }
-// DigestExt::chain_point: Point::to_bytes(false), 65 bytes  [SURVEY.md App. A.2, recalled]
-__device__ inline void sha_point_uncompressed(Sha256& s, const Aff& p) { sha_byte(s, 4u); sha_be32(s, p.x); sha_be32(s, p.y); }
+// DigestExt::chain_point  [SURVEY.md App. A.2, recalled: the form is enc.chain_point]
+__device__ inline void sha_chain_point(Sha256& s, const Aff& p, const Enc& enc) {
+  sha_byte(s, enc.chain_point ? 2u + (p.y.w[0] & 1u) : 4u);
+  sha_be32(s, p.x);
+  if (!enc.chain_point) sha_be32(s, p.y);
+}
 // digest as 8 little-endian interface words (result_bigint)
 __device__ inline U256 sha_final(Sha256& s) {
   const uint64_t bits = s.len * 8;

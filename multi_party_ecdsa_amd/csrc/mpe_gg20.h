@@ -63,6 +63,7 @@ struct Dim {
   int sg[8];         // signer ordinal -> party index
   int oslot[8];      // party index -> slot among the own parties
   const int32_t* ks; // [B] key set of a session, or null
+  ec::Enc enc;       // the context's transcript conventions (include/mpecdsa_hip.h: mpe_encoding), copied when the object is built
 };
 __device__ __forceinline__ int ind_of(int i, int jj) { return jj < i ? jj : jj + 1; }
 __device__ __forceinline__ int jme_of(int i, int ind) { return i < ind ? i : i - 1; }
@@ -195,19 +196,27 @@ __device__ inline ec::U256 lagrange0(const int* sg, int S, int i) {
   return ec::sc_mul(num, ec::sc_inv(den));
 }
 // HashCommitment(compressed point as BigInt, blind)  (party_i.rs:577-580)
-__device__ inline ec::U256 commit_point(const ec::Aff& P, const uint32_t* blind) {
+__device__ inline ec::U256 commit_point(const ec::Aff& P, const uint32_t* blind, const ec::Enc& enc) {
   ec::Sha256 s; ec::sha_init(s);
   ec::sha_point_compressed(s, P);
-  ec::sha_bigint(s, blind, 8);
+  ec::sha_bigint(s, blind, 8, enc);
   return ec::sha_final(s);
 }
 // (the points are passed as an array reference and the function is force-inlined: handing a pointer to a
 //  lane-private array to an out-of-line function hung the kernel on gfx950 / ROCm 7.2)
+// `pts` is the canonical list of the proof (include/mpecdsa_hip.h names it per proof); `ord[i]` = which of them is hashed
+// i-th.  The selection is a compare-and-select chain, never a dynamic index into the lane-private array.
 template <int N>
-__device__ __forceinline__ ec::U256 hash_points(const ec::Aff (&pts)[N]) {
+__device__ __forceinline__ ec::U256 hash_points(const ec::Aff (&pts)[N], const ec::Enc& enc, const uint8_t* ord) {
   ec::Sha256 s; ec::sha_init(s);
 #pragma unroll
-  for (int i = 0; i < N; ++i) ec::sha_point_uncompressed(s, pts[i]);
+  for (int i = 0; i < N; ++i) {
+    const int o = ord[i];
+    ec::Aff P = pts[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) if (o == j) P = pts[j];
+    ec::sha_chain_point(s, P, enc);
+  }
   const ec::U256 d = ec::sha_final(s);
   return ec::sc_reduce(d.w, 8);
 }
@@ -237,7 +246,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r0_kernel(Dim d, const uint32_t
   for (int j = 0; j < 64; ++j) k64[(size_t)pi * 64 + j] = j < 8 ? k.w[j] : 0u;
   const ec::Aff gg = ec::jac_to_aff(ec::jac_mul_gen(g));
   ec::aff_store(g_gamma + (size_t)pi * 16, gg);
-  ec::u256_store(com + (size_t)pi * 8, commit_point(gg, blind + (size_t)pi * 8));
+  ec::u256_store(com + (size_t)pi * 8, commit_point(gg, blind + (size_t)pi * 8, d.enc));
 }
 
 // ---- Round 1 -------------------------------------------------------------------------------------------------------
@@ -306,7 +315,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r2a_kernel(Dim d, const int32_t
   bool good = ec::jac_eq(g_alpha, ba_btag);
   {  // DLogProof::verify x2
     const ec::Aff R1 = ec::aff_load(m + 144), R2 = ec::aff_load(m + 184);
-    const ec::U256 c1 = dlog_challenge(R1, Bpk), c2 = dlog_challenge(R2, BTpk);
+    const ec::U256 c1 = dlog_challenge(R1, Bpk, d.enc), c2 = dlog_challenge(R2, BTpk, d.enc);
     const ec::Jac l1 = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(m + 160, 8)), ec::jac_mul(c1, Bpk));
     const ec::Jac l2 = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(m + 200, 8)), ec::jac_mul(c2, BTpk));
     good = good && ec::jac_eq_aff(l1, R1) && ec::jac_eq_aff(l2, R2);
@@ -351,7 +360,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r2b_kernel(Dim d, const uint32_
   const ec::U256 s1 = ec::sc_reduce(s1_in + (size_t)pi * 8, 8), s2 = ec::sc_reduce(s2_in + (size_t)pi * 8, 8);
   const ec::Aff a1 = ec::jac_to_aff(ec::jac_mul_gen(s1)), a2 = ec::jac_to_aff(ec::jac_mul_h2(s2));
   const ec::Aff hp[5] = {G, H, T, a1, a2};
-  const ec::U256 e = hash_points(hp);
+  const ec::U256 e = hash_points(hp, d.enc, d.enc.ord_pedersen);
   ec::aff_store(p.T + (size_t)pi * 16, T);
   ec::u256_store(p.e + (size_t)pi * 8, e);
   ec::aff_store(p.a1 + (size_t)pi * 16, a1);
@@ -389,7 +398,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r3_kernel(Dim d, Slab in2, uint
     com_ok = com_ok && words_eq(m + 8, m + 64, 16);
     const ec::Aff C = ec::aff_load(m + 64), a1 = ec::aff_load(m + 32), a2 = ec::aff_load(m + 48);
     const ec::Aff hp[5] = {G, H, C, a1, a2};
-    const ec::U256 e = hash_points(hp);
+    const ec::U256 e = hash_points(hp, d.enc, d.enc.ord_pedersen);
     const ec::Jac lhs = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(m + 80, 8)), ec::jac_mul_h2(ec::sc_reduce(m + 88, 8)));
     const ec::Jac rhs = ec::jac_add_aff(ec::jac_add_aff(ec::jac_mul(e, C), a1), a2);
     ped_ok = ped_ok && ec::jac_eq(lhs, rhs);
@@ -411,7 +420,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r4_kernel(Dim d, Slab in3, cons
     const uint32_t* m = rec_of(in3, ind, b);
     const ec::Aff gg = ec::aff_load(m + 8);
     bool good = ec::aff_eq(ec::aff_load(bpk_in + ((size_t)pi * P1 + jj) * 16), gg);
-    good = good && ec::u256_eq(commit_point(gg, m), ec::u256_load(com_all + ((size_t)ind * d.B + b) * 8));
+    good = good && ec::u256_eq(commit_point(gg, m, d.enc), ec::u256_load(com_all + ((size_t)ind * d.B + b) * 8));
     if (!good) mask |= 1u << ind;
   }
   if (mask) fail(status, bad, pi, 401, mask);
@@ -462,7 +471,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r5_prove_kernel(Dim d, const ui
   const ec::U256 s1 = ec::sc_reduce(s1_in + (size_t)pi * 8, 8), s2 = ec::sc_reduce(s2_in + (size_t)pi * 8, 8);
   const ec::Aff A3 = mul_aff(s2, Rp), TT = ec::jac_to_aff(ec::jac_add(ec::jac_mul_h2(s1), ec::jac_mul_gen(s2)));
   const ec::Aff hp[7] = {TT, A3, Rp, H, G, T, Sp};
-  const ec::U256 e = hash_points(hp);
+  const ec::U256 e = hash_points(hp, d.enc, d.enc.ord_heg);
   ec::aff_store(h.S + (size_t)pi * 16, Sp);
   ec::aff_store(h.T + (size_t)pi * 16, TT);
   ec::aff_store(h.A3 + (size_t)pi * 16, A3);
@@ -485,7 +494,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r6_kernel(Dim d, Slab in5, cons
     const ec::Aff E = ec::aff_load(m), TT = ec::aff_load(m + 16), A3 = ec::aff_load(m + 32),
                   D = ec::aff_load(tvec + ((size_t)j * d.B + b) * 16);
     const ec::Aff hp[7] = {TT, A3, Rp, H, G, D, E};
-    const ec::U256 e = hash_points(hp), z1 = ec::sc_reduce(m + 48, 8), z2 = ec::sc_reduce(m + 56, 8);
+    const ec::U256 e = hash_points(hp, d.enc, d.enc.ord_heg), z1 = ec::sc_reduce(m + 48, 8), z2 = ec::sc_reduce(m + 56, 8);
     const ec::Jac l1 = ec::jac_add(ec::jac_mul_h2(z1), ec::jac_mul_gen(z2));
     const ec::Jac r1 = ec::jac_add_aff(ec::jac_mul(e, D), TT);
     const ec::Jac l2 = ec::jac_mul(z2, Rp);
@@ -522,7 +531,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r2a_group_kernel(Dim d, const i
   const ec::Aff R1 = ec::aff_load(m + 144), R2 = ec::aff_load(m + 184);
   ec::Jac res = ec::jac_inf(), fr = ec::jac_inf();
   if (live && sub < 3) {
-    const ec::U256 sc = sub == 0 ? ec::u256_load(kq + (size_t)pi * 8) : (sub == 1 ? dlog_challenge(R1, Bpk) : dlog_challenge(R2, BTpk));
+    const ec::U256 sc = sub == 0 ? ec::u256_load(kq + (size_t)pi * 8) : (sub == 1 ? dlog_challenge(R1, Bpk, d.enc) : dlog_challenge(R2, BTpk, d.enc));
     res = ec::jac_mul(sc, sub == 2 ? BTpk : Bpk);
     const ec::U256 fk = sub == 0 ? al : ec::sc_reduce(m + (sub == 1 ? 160 : 200), 8);
     fr = ec::jac_mul_gen(fk);
@@ -551,7 +560,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r3_group_kernel(Dim d, int G, S
     const uint32_t* m = rec_of(in2, sub, b);
     const ec::Aff C = ec::aff_load(m + 64), a1 = ec::aff_load(m + 32), a2 = ec::aff_load(m + 48);
     const ec::Aff hp[5] = {Gp, H, C, a1, a2};
-    res = ec::jac_mul(hash_points(hp), C);
+    res = ec::jac_mul(hash_points(hp, d.enc, d.enc.ord_pedersen), C);
   }
   if (live && sub < 2 * d.S) {
     const uint32_t* m = rec_of(in2, sub >> 1, b);
@@ -590,7 +599,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r6_group_kernel(Dim d, int G, S
     const ec::Aff E = ec::aff_load(m), TT = ec::aff_load(m + 16), A3 = ec::aff_load(m + 32),
                   D = ec::aff_load(tvec + ((size_t)j * d.B + b) * 16);
     const ec::Aff hp[7] = {TT, A3, Rp, H, Gp, D, E};
-    const ec::U256 e = hash_points(hp);
+    const ec::U256 e = hash_points(hp, d.enc, d.enc.ord_heg);
     res = ec::jac_mul(kind == 1 ? ec::sc_reduce(m + 56, 8) : e, kind == 0 ? D : (kind == 1 ? Rp : E));
   }
   if (live && sub < 2 * d.S) {
@@ -804,6 +813,7 @@ static Slab slab_of(const mpe_gg20_session* s, const uint32_t* p, const int64_t*
 static int round_enter(mpe_gg20_session* s, int round, const void* in, const void* out, bool need_in, bool need_out) {
   if (!s || (need_in && !in) || (need_out && !out)) return MPE_E_ARG;
   if (s->next_round != round) { mpe_set_error_msg("gg20: rounds must be run in order"); return MPE_E_ARG; }
+  s->d.enc = s->ctx->enc;          // the transcript conventions are the context's, read when a round starts
   return MPE_OK;
 }
 static int round_exit(mpe_gg20_session* s, int rc, const char* what) {
@@ -840,7 +850,7 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   // through ONE launch: two concurrent launches of a few hundred waves each start on the same SIMDs of every CU and take
   // 15 ms where one launch of 1 024 waves takes 11.5
   const uint32_t *rn_pre = nullptr, *bn_pre = nullptr;
-  if (held && !getenv("MPE_NO_MERGE_XN")) {
+  if (held && ctx->merge_xn) {
     uint32_t* xs = ws_array<uint32_t>(ctx, nXN * 64);
     uint32_t* xn = ws_array<uint32_t>(ctx, nXN * 128);
     int32_t* kx = ws_array<int32_t>(ctx, nXN);
@@ -904,8 +914,8 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
                                 Z.mb_r, c_b, st2);
     gg_trace(st2, "MessageB ciphertext", rc);
     if (rc == MPE_OK && c.nMB > 0) {
-      hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, bsel, Z.mb_nonce_b, Bpk, BR, Bz);      // :147
-      hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, btq, Z.mb_nonce_bt, BTpk, BTR, BTz);   // :148
+      hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, ctx->enc, bsel, Z.mb_nonce_b, Bpk, BR, Bz);      // :147
+      hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, ctx->enc, btq, Z.mb_nonce_bt, BTpk, BTR, BTz);   // :148
     }
   }
   if (rc == MPE_OK) {      // every range proof of every peer, for both MessageB::b calls (mta/mod.rs:119-131), read in place
@@ -1116,8 +1126,7 @@ int mpe_gg20_keys_create(mpe_ctx* ctx, int t, int n, int n_signers, const int32_
     // 13 bits (0.5 GB per base) for a handful of key sets, narrower when a batch carries many wallets
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    size_t budget = free_b / 4;
-    if (getenv("MPE_FB_BUDGET_MB")) budget = (size_t)atoll(getenv("MPE_FB_BUDGET_MB")) << 20;
+    const size_t budget = ctx->fb_budget_bytes ? ctx->fb_budget_bytes : free_b / 4;
     int wb = ctx->fb_window_bits;
     while (wb > 4 && mpe_statements_table_bytes(nkeysets * n, wb) > budget) --wb;
     rc = mpe_statements_create_wb(ctx, nkeysets * n, d_Nt, d_h1, d_h2, wb, &K->stm, stream);
@@ -1154,7 +1163,7 @@ int mpe_gg20_session_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, 
   s->ctx = ctx; s->K = keys; s->B = batch; s->L = n_local; s->dedup = dedup_verify ? 1 : 0; s->Z = *nonces;
   mpe::gg::Dim& d = s->d;
   d.B = batch; d.S = keys->S; d.n = keys->n; d.L = n_local; d.V = dedup_verify ? 1 : 2; d.PV = dedup_verify ? 1 : n_local; d.K = keys->K;
-  d.n_own = keys->n_own; d.ks = d_keyset;
+  d.n_own = keys->n_own; d.ks = d_keyset; d.enc = ctx->enc;
   for (int i = 0; i < 8; ++i) { d.loc[i] = i < n_local ? h_local[i] : 0; d.sg[i] = keys->signers[i]; d.oslot[i] = keys->own_slot[i] < 0 ? 0 : keys->own_slot[i]; }
   const size_t bytes = mpe::gg::layout(s, nullptr);
   if (!ctx->sess_in_use) {
@@ -1196,11 +1205,16 @@ int mpe_gg20_session_rearm(mpe_gg20_session* s, const int32_t* d_keyset, const m
   // the index tables stay, everything nonce-derived is zeroed and the round counter starts again
   if (!s || !nonces) return MPE_E_ARG;
   if (s->K->K > 1 && !d_keyset) return MPE_E_ARG;
+  // a batch that is half-way through the protocol is not silently thrown away: finish it (round 8 = complete) or destroy it
+  if (s->next_round != 0 && s->next_round <= 8) { mpe_set_error_msg("gg20 session rearm: the previous batch has not completed"); return MPE_E_ARG; }
+  // The caller passes FRESHLY SAMPLED values for every batch (re-using k, gamma or a Paillier randomness leaks the key share);
+  // the library cannot tell fresh from stale device arrays — the arrays may legitimately be the same buffers refilled.
   hipStream_t st = (hipStream_t)stream;
   const mpe::gg::Counts c = mpe::gg::counts_of(s->d);
-  s->Z = *nonces; s->d.ks = d_keyset; s->next_round = 0; s->fault_step = 0; s->fault_mask = 0;
   // the state region after the index tables: secrets of the previous batch do not outlive it
-  (void)hipMemsetAsync(s->kq, 0, (size_t)((char*)s->mem + s->mem_bytes - (char*)s->kq), st);
+  const hipError_t em = hipMemsetAsync(s->kq, 0, (size_t)((char*)s->mem + s->mem_bytes - (char*)s->kq), st);
+  if (em != hipSuccess) { mpe_set_error("gg20 session rearm (wipe)", em); return MPE_E_HIP; }
+  s->Z = *nonces; s->d.ks = d_keyset; s->next_round = 0; s->fault_step = 0; s->fault_mask = 0;
   size_t total = c.nVI;                 // the key indices follow the (possibly different) key-set choice
   if (c.nMB > total) total = c.nMB;
   if (c.nAP > total) total = c.nAP;

@@ -24,6 +24,9 @@ struct mpe_ctx {
   bool use_fixed_base = true;     // h1/h2 exponentiations through per-statement window tables (mpe_fixedbase.h)
   bool use_sliding = true;        // x^N with the PUBLIC exponent N: items ordered by key, sliding windows per wave (mpe_pairexp.h)
   int wide_div = 2;               // the 2x-lanes layout is used when wide_div * batch <= the resident groups (MPE_WIDE_DIV)
+  int xwide_div = 16;             // the 4x-lanes (5 limbs per lane) layout: xwide_div * batch <= the resident groups; 0 = off (MPE_XWIDE_DIV)
+  bool merge_xn = true;           // round 0: every x^N of the key holders in ONE launch (MPE_NO_MERGE_XN switches it off)
+  size_t fb_budget_bytes = 0;     // memory budget of the fixed-base tables of a key object; 0 = a quarter of free HBM (MPE_FB_BUDGET_MB)
   int modexp_waves_per_cu = 8;    // 2 waves/SIMD: the montmul loop holds ~230 VGPRs and already issues back-to-back
   // window-table scratch, grown on demand: one buffer per stream slot (0 = the caller's stream, 1..3 = the auxiliary streams
   // on which small batches run independent launches concurrently)
@@ -51,10 +54,16 @@ struct mpe_ctx {
   void* slab_buf = nullptr;
   size_t slab_bytes = 0;
   mpe_launch_info last = {};
+  // byte-level conventions of the un-vendored crates (include/mpecdsa_hip.h: mpe_encoding); kernels take it by value
+  mpe_encoding enc = {};
   // optional per-launch timing of the heavy kernels (HIP events on the launch stream)
   bool prof_on = false;
-  struct ProfEvt { hipEvent_t a, b; int kind, bits, exp_words, batch, exp2_words; };
+  struct ProfEvt { hipEvent_t a, b; int kind, bits, exp_words, batch, exp2_words; int wave_trips; };
   std::vector<ProfEvt> prof;
+  // one device counter per record (allocated by mpe_prof_enable): the pair kernel adds 1 per wave-trip that really ran the
+  // sliding-window schedule — "kind 6" is a property of the launch, whether a wave slides is decided at run time
+  uint32_t* prof_ctr = nullptr;
+  int prof_ctr_cap = 0;
 };
 
 struct mpe_modset {
@@ -103,6 +112,9 @@ int modset_create_dev(mpe_ctx* ctx, int bits, int count, const uint32_t* d_modul
 // per-launch timing records (mpe_prof_*), defined in mpe_lib.hip
 void prof_begin(mpe_ctx* ctx, hipStream_t st, int kind, int bits, int exp_words, int batch, int exp2_words = 0);
 void prof_end(mpe_ctx* ctx, hipStream_t st);
+// device counter of the record prof_begin just opened (nullptr when profiling is off or the counters are exhausted);
+// wave_trips = the number of (wave, trip) pairs of the launch, the counter's maximum
+uint32_t* prof_counter(mpe_ctx* ctx, int wave_trips);
 
 // N-adic pair engine (mpe_pair2048.hip / mpe_pair1024.hip)
 int pairset_create_2048(int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st);

@@ -17,17 +17,17 @@ constexpr int CK_M2 = 11;
 
 // zk-paillier compute_digest over BigInts as minimal big-endian bytes; one (key, i) per lane:
 //   seed = H(N, salt, i);  acc = sum_j H(seed, j) << (256 j), j < bit_length(N)/256 + 1  ->  hi (words 64..71) | lo (words 0..63)
-__global__ void __launch_bounds__(64) MPE_EC_OCC ck_rho_kernel(int B, const uint32_t* __restrict__ N, uint32_t* __restrict__ lo, uint32_t* __restrict__ hi) {
+__global__ void __launch_bounds__(64) MPE_EC_OCC ck_rho_kernel(int B, ec::Enc enc, const uint32_t* __restrict__ N, uint32_t* __restrict__ lo, uint32_t* __restrict__ hi) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= B * CK_M2) return;
   const int b = g / CK_M2, i = g % CK_M2;
   const uint32_t* n = N + (size_t)b * 64;
   ec::Sha256 s; ec::sha_init(s);
-  ec::sha_bigint(s, n, 64);
-  const uint32_t salt[1] = {0x4B5A656Eu};                       // SALT_STRING = [75, 90, 101, 110] as a BigInt
-  ec::sha_bigint(s, salt, 1);
+  ec::sha_bigint(s, n, 64, enc);
+  const uint32_t salt[1] = {enc.ck_salt};                       // SALT_STRING = [75, 90, 101, 110] as a BigInt = 0x4B5A656E
+  ec::sha_bigint(s, salt, 1, enc);
   const uint32_t iw[1] = {(uint32_t)i};
-  ec::sha_bigint(s, iw, 1);
+  ec::sha_bigint(s, iw, 1, enc);                                // i = 0: BigInt::to_bytes(0), enc.zero_bytes
   const ec::U256 seed = ec::sha_final(s);
   int top = 63;
   while (top > 0 && n[top] == 0) --top;
@@ -37,11 +37,12 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC ck_rho_kernel(int B, const uint
   for (int w = 0; w < 72; ++w) acc[w] = 0;
   for (int j = 0; j < msklen && j < 9; ++j) {
     ec::Sha256 t; ec::sha_init(t);
-    ec::sha_bigint(t, seed.w, 8);
+    ec::sha_bigint(t, seed.w, 8, enc);
     const uint32_t jw[1] = {(uint32_t)j};
-    ec::sha_bigint(t, jw, 1);
+    ec::sha_bigint(t, jw, 1, enc);
     const ec::U256 d = ec::sha_final(t);
-    for (int w = 0; w < 8; ++w) acc[j * 8 + w] = d.w[w];        // disjoint 256-bit slots: the sum is a concatenation
+    const int slot = enc.ck_mask_order ? (msklen < 9 ? msklen : 9) - 1 - j : j;      // block j at bit 256 j, or block 0 on top
+    for (int w = 0; w < 8; ++w) acc[slot * 8 + w] = d.w[w];     // disjoint 256-bit slots: the sum is a concatenation
   }
   for (int w = 0; w < 64; ++w) lo[(size_t)g * 64 + w] = acc[w];
   for (int w = 0; w < 8; ++w) hi[(size_t)g * 8 + w] = acc[64 + w];
@@ -165,7 +166,7 @@ int mpe_correct_key_prove(mpe_ctx* ctx, const mpe_paillier* sk, uint32_t* d_sigm
   if (!key_of || !lo || !hi || !hiT || !lor || !rho || !two || !T || !phi || !u || !d || !ok) { mpe_set_error_msg("correct_key_prove: workspace"); return MPE_E_NOMEM; }
   const Rows ksel{nullptr, key_of, 0, 0};
   hipLaunchKernelGGL(kg::iota_div_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, n, M, key_of);
-  hipLaunchKernelGGL(kg::ck_rho_kernel, dim3(blocks_for(n, 64)), dim3(64), 0, st, nk, sk->N, lo, hi);
+  hipLaunchKernelGGL(kg::ck_rho_kernel, dim3(blocks_for(n, 64)), dim3(64), 0, st, nk, ctx->enc, sk->N, lo, hi);
   // rho = acc mod N with acc = hi 2^2048 + lo, as the verifier derives it
   hipLaunchKernelGGL(kg::fill_words_kernel, dim3(blocks_for(nk * 64, 256)), dim3(256), 0, st, nk, 64, 1024, two);
   MPE_TRY(launch_modmul(ctx, sk->ms_n, nk, rows(nullptr, 1), rows(two, 64), rows(two, 64), T, st));
@@ -201,7 +202,8 @@ int mpe_composite_dlog_prove(mpe_ctx* ctx, int batch, const uint32_t* d_N, const
   q.rc = rc;
   HashDesc d;
   d.n = 4;
-  d.f[0] = hf(rows(d_x, 64), 64); d.f[1] = hf(rows(d_g, 64), 64); d.f[2] = hf(rows(d_N, 64), 64); d.f[3] = hf(rows(d_ni, 64), 64);
+  { const HashField canon[4] = {hf(rows(d_x, 64), 64), hf(rows(d_g, 64), 64), hf(rows(d_N, 64), 64), hf(rows(d_ni, 64), 64)};   // (x, g, N, ni)
+    for (int k = 0; k < 4; ++k) d.f[k] = canon[ctx->enc.ord_cdlog[k] & 3]; }
   q.hash(d, e);
   if (q.rc == MPE_OK) hipLaunchKernelGGL(kg::cd_y_kernel, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, d_r, e, d_secret, d_y);
   rc = q.finish("mpe_composite_dlog_prove");
@@ -228,7 +230,7 @@ int mpe_correct_key_verify(mpe_ctx* ctx, int batch, const uint32_t* d_N, const u
   const Rows ksel{nullptr, key_of, 0, 0};
   hipLaunchKernelGGL(kg::iota_div_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, n, M, key_of);
   hipLaunchKernelGGL(kg::ck_small_factor_kernel, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, d_N, d_ok);
-  hipLaunchKernelGGL(kg::ck_rho_kernel, dim3(blocks_for(n, 64)), dim3(64), 0, st, batch, d_N, lo, hi);
+  hipLaunchKernelGGL(kg::ck_rho_kernel, dim3(blocks_for(n, 64)), dim3(64), 0, st, batch, ctx->enc, d_N, lo, hi);
   // sigma_i^N mod N: the heavy part — 11 exponentiations (2048-bit modulus, 2048-bit exponent) per key
   rc = launch_modexp(ctx, ms, n, ksel, rows(d_sigma, 64), no_rows(), rows(d_N, 64, key_of), 64, sn, st);
   // rho = acc mod N with acc = hi 2^2048 + lo:  T = 2^2048 mod N = (2^1024)^2, rho = hi T + lo (mod N)
@@ -268,7 +270,8 @@ int mpe_composite_dlog_verify(mpe_ctx* ctx, int batch, const uint32_t* d_N, cons
   uint32_t* e = q.words(8);
   HashDesc d;
   d.n = 4;
-  d.f[0] = hf(rows(d_x, 64), 64); d.f[1] = hf(rows(d_g, 64), 64); d.f[2] = hf(rows(d_N, 64), 64); d.f[3] = hf(rows(d_ni, 64), 64);
+  { const HashField canon[4] = {hf(rows(d_x, 64), 64), hf(rows(d_g, 64), 64), hf(rows(d_N, 64), 64), hf(rows(d_ni, 64), 64)};   // (x, g, N, ni)
+    for (int k = 0; k < 4; ++k) d.f[k] = canon[ctx->enc.ord_cdlog[k] & 3]; }
   q.hash(d, e);
   uint32_t* gy = q.modexp(ms, sel, rows(d_g, 64), rows(d_y, 73), 73);
   uint32_t* ne = q.modexp(ms, sel, rows(d_ni, 64), rows(e, 8), 8);

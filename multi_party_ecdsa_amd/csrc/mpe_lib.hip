@@ -1,4 +1,6 @@
 // libmpecdsa_hip.so — C-ABI (include/mpecdsa_hip.h) over the gfx950 kernels.  Single translation unit.
+#include <string.h>
+#include <mutex>
 #include "mpe_internal.h"
 #include "mpe_ec.h"
 
@@ -80,11 +82,16 @@ void Fork::join() {
 void prof_begin(mpe_ctx* ctx, hipStream_t st, int kind, int bits, int exp_words, int batch, int exp2_words) {
   if (!ctx->prof_on) return;
   mpe_ctx::ProfEvt ev;
-  ev.kind = kind; ev.bits = bits; ev.exp_words = exp_words; ev.batch = batch; ev.exp2_words = exp2_words;
+  ev.kind = kind; ev.bits = bits; ev.exp_words = exp_words; ev.batch = batch; ev.exp2_words = exp2_words; ev.wave_trips = 0;
   (void)hipEventCreate(&ev.a);
   (void)hipEventCreate(&ev.b);
   (void)hipEventRecord(ev.a, st);
   ctx->prof.push_back(ev);
+}
+uint32_t* prof_counter(mpe_ctx* ctx, int wave_trips) {
+  if (!ctx->prof_on || ctx->prof.empty() || !ctx->prof_ctr || (int)ctx->prof.size() > ctx->prof_ctr_cap) return nullptr;
+  ctx->prof.back().wave_trips = wave_trips;
+  return ctx->prof_ctr + (ctx->prof.size() - 1);
 }
 void prof_end(mpe_ctx* ctx, hipStream_t st) {
   if (ctx->prof_on && !ctx->prof.empty()) (void)hipEventRecord(ctx->prof.back().b, st);
@@ -265,6 +272,34 @@ extern "C" {
 const char* mpe_version(void) { return "mpecdsa-hip 0.3.0 (gfx950)"; }
 const char* mpe_last_error(void) { return g_last_error.c_str(); }
 
+void mpe_encoding_default(mpe_encoding* e) {
+  if (!e) return;
+  memset(e, 0, sizeof *e);
+  e->ck_salt = 0x4B5A656Eu;                         // b"KZen"
+  for (int i = 0; i < 4; ++i) e->ord_dlog[i] = e->ord_cdlog[i] = (uint8_t)i;
+  for (int i = 0; i < 8; ++i) e->ord_pedersen[i] = e->ord_heg[i] = e->ord_ecddh[i] = (uint8_t)i;
+}
+static bool is_perm(const uint8_t* o, int n) {
+  unsigned seen = 0;
+  for (int i = 0; i < n; ++i) { if (o[i] >= n || (seen >> o[i]) & 1u) return false; seen |= 1u << o[i]; }
+  return true;
+}
+int mpe_ctx_set_encoding(mpe_ctx* ctx, const mpe_encoding* e) {
+  if (!ctx || !e) return MPE_E_ARG;
+  if (e->chain_point > 1 || e->zero_bytes > 1 || e->ck_mask_order > 1 || e->reserved != 0 || !is_perm(e->ord_dlog, 3) ||
+      !is_perm(e->ord_pedersen, 5) || !is_perm(e->ord_heg, 7) || !is_perm(e->ord_ecddh, 6) || !is_perm(e->ord_cdlog, 4)) {
+    mpe_set_error_msg("mpe_ctx_set_encoding: a flag is not 0/1 or an order is not a permutation");
+    return MPE_E_ARG;
+  }
+  ctx->enc = *e;
+  return MPE_OK;
+}
+int mpe_ctx_get_encoding(const mpe_ctx* ctx, mpe_encoding* out) {
+  if (!ctx || !out) return MPE_E_ARG;
+  *out = ctx->enc;
+  return MPE_OK;
+}
+
 int mpe_ctx_create(mpe_ctx** out, int device) {
   if (!out) return MPE_E_ARG;
   hipError_t e = hipSetDevice(device);
@@ -276,6 +311,7 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   if (!c) return MPE_E_NOMEM;
   c->device = device;
   c->cus = prop.multiProcessorCount;
+  mpe_encoding_default(&c->enc);
   if (getenv("MPE_NO_FIXED_BASE")) c->use_fixed_base = false;     // A/B switches for measurements
   if (getenv("MPE_NO_CRT")) c->use_crt = false;
   if (getenv("MPE_NO_MULTIEXP")) c->use_multiexp = false;
@@ -287,10 +323,21 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   if (getenv("MPE_NO_ADAPTIVE_LANES")) { c->adaptive_lanes = false; c->ec_lane_groups = false; }
   if (getenv("MPE_NO_WIDE")) c->adaptive_lanes = false;
   if (const char* e = getenv("MPE_WIDE_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->wide_div = v; }
+  // every switch is read HERE, once: no entry point reads the environment afterwards (contexts on several host threads)
+  if (const char* e = getenv("MPE_XWIDE_DIV")) { const int v = atoi(e); if (v >= 0) c->xwide_div = v; }
+  if (getenv("MPE_NO_MERGE_XN")) c->merge_xn = false;
+  if (const char* e = getenv("MPE_FB_BUDGET_MB")) c->fb_budget_bytes = (size_t)atoll(e) << 20;
   if (getenv("MPE_WINDOW_BITS")) { const int w = atoi(getenv("MPE_WINDOW_BITS")); if (w >= 4 && w <= 6) c->window_bits = w; }
-  // comb tables of the two fixed secp256k1 generators (module globals of this device; identical on every call)
-  hipLaunchKernelGGL(mpe::ec::ec_comb_build_kernel, dim3(2), dim3(64), 0, 0);
-  e = hipDeviceSynchronize();
+  // comb tables of the two fixed secp256k1 generators: module globals, built ONCE per device (immutable afterwards — the only
+  // process-wide state of the library; a second context never rewrites them under the kernels of the first)
+  static std::once_flag comb_once[64];
+  static hipError_t comb_err[64];
+  if (device < 0 || device >= 64) { delete c; return MPE_E_ARG; }
+  std::call_once(comb_once[device], [device]() {
+    hipLaunchKernelGGL(mpe::ec::ec_comb_build_kernel, dim3(2), dim3(64), 0, 0);
+    comb_err[device] = hipDeviceSynchronize();
+  });
+  e = comb_err[device];
   if (e != hipSuccess) { mpe_set_error("ec_comb_build_kernel", e); delete c; return MPE_E_HIP; }
   *out = c;
   return MPE_OK;
@@ -359,6 +406,7 @@ int mpe_ctx_destroy(mpe_ctx* ctx) {
     for (int i = 0; i < 2; ++i) (void)hipEventDestroy(ctx->ev_fork[i]);
   }
   for (auto& ev : ctx->prof) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  if (ctx->prof_ctr) (void)hipFree(ctx->prof_ctr);
   delete ctx;
   return MPE_OK;
 }
@@ -381,19 +429,34 @@ int mpe_prof_enable(mpe_ctx* ctx, int on) {
   for (auto& ev : ctx->prof) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   ctx->prof.clear();
   ctx->prof_on = on != 0;
+  if (ctx->prof_on) {
+    if (!ctx->prof_ctr) {
+      ctx->prof_ctr_cap = 1 << 16;
+      if (hipMalloc((void**)&ctx->prof_ctr, (size_t)ctx->prof_ctr_cap * sizeof(uint32_t)) != hipSuccess) { ctx->prof_ctr = nullptr; ctx->prof_ctr_cap = 0; }
+    }
+    if (ctx->prof_ctr) (void)hipMemset(ctx->prof_ctr, 0, (size_t)ctx->prof_ctr_cap * sizeof(uint32_t));
+  }
   return MPE_OK;
 }
 
 int mpe_prof_collect(mpe_ctx* ctx, mpe_prof_rec* out, int max_records, int* n_out) {
   if (!ctx || !out || !n_out) return MPE_E_ARG;
   int n = 0;
+  std::vector<uint32_t> ctr;
+  size_t ix = 0;
   for (auto& ev : ctx->prof) {
+    const size_t my = ix++;
     if (n >= max_records) break;
     if (hipEventSynchronize(ev.b) != hipSuccess) continue;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ev.a, ev.b) != hipSuccess) continue;
+    if (ctr.empty() && ctx->prof_ctr) {               // every event up to here has completed: the counters are final
+      ctr.resize(ctx->prof.size() < (size_t)ctx->prof_ctr_cap ? ctx->prof.size() : (size_t)ctx->prof_ctr_cap);
+      if (hipMemcpy(ctr.data(), ctx->prof_ctr, ctr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) ctr.assign(ctr.size(), 0u);
+    }
     out[n].kind = ev.kind; out[n].bits = ev.bits; out[n].exp_words = ev.exp_words; out[n].batch = ev.batch; out[n].ms = ms;
     out[n].exp2_words = ev.exp2_words;
+    out[n].sliding_frac = (ev.wave_trips > 0 && my < ctr.size()) ? (float)ctr[my] / (float)ev.wave_trips : (ev.kind == 6 ? -1.f : 0.f);
     ++n;
   }
   *n_out = n;

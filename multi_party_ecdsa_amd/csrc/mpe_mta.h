@@ -36,7 +36,7 @@ __global__ void mta_beta_kernel(int B, const uint32_t* __restrict__ beta_tag, ui
   ec::u256_store(beta + (size_t)i * 8, ec::sc_neg(t));
 }
 // alpha = alice_share mod q; ok = DLogProof::verify x2 && b_proof.pk * a + beta_tag_proof.pk == g^alpha   (:166-178)
-__global__ void __launch_bounds__(64) MPE_EC_OCC mta_alpha_kernel(int B, const uint32_t* __restrict__ share, const uint32_t* __restrict__ a,
+__global__ void __launch_bounds__(64) MPE_EC_OCC mta_alpha_kernel(int B, ec::Enc enc, const uint32_t* __restrict__ share, const uint32_t* __restrict__ a,
                                  const uint32_t* __restrict__ pk, const uint32_t* __restrict__ R, const uint32_t* __restrict__ z,
                                  const uint32_t* __restrict__ tpk, const uint32_t* __restrict__ tR, const uint32_t* __restrict__ tz,
                                  uint32_t* __restrict__ alpha, uint8_t* __restrict__ ok) {
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC mta_alpha_kernel(int B, const u
   const ec::Jac g_alpha = ec::jac_mul_gen(al);
   const ec::Jac bb = ec::jac_add_aff(ec::jac_mul(ec::sc_reduce(a + (size_t)i * 8, 8), Bpk), BTpk);
   bool good = ec::jac_eq(g_alpha, bb);
-  const ec::U256 c1 = dlog_challenge(R1, Bpk), c2 = dlog_challenge(R2, BTpk);
+  const ec::U256 c1 = dlog_challenge(R1, Bpk, enc), c2 = dlog_challenge(R2, BTpk, enc);
   const ec::Jac l1 = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(z + (size_t)i * 8, 8)), ec::jac_mul(c1, Bpk));
   const ec::Jac l2 = ec::jac_add(ec::jac_mul_gen(ec::sc_reduce(tz + (size_t)i * 8, 8)), ec::jac_mul(c2, BTpk));
   good = good && ec::jac_eq_aff(l1, R1) && ec::jac_eq_aff(l2, R2);
@@ -117,8 +117,8 @@ int mpe_mta_message_b(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements
                                     st));                                                      // Alice's key, Bob computes
   MPE_LAUNCH_1D(mpe::mta_beta_kernel, batch, st, batch, d_beta_tag, btq, d_beta);
   // DLogProof::prove(b), DLogProof::prove(beta_tag_fe)   (:147-148)
-  MPE_LAUNCH_1D(mpe::dlog_prove_kernel, batch, st, batch, d_b, d_nonce_b, b_proof->pk, b_proof->R, b_proof->z);
-  MPE_LAUNCH_1D(mpe::dlog_prove_kernel, batch, st, batch, btq, d_nonce_bt, beta_tag_proof->pk, beta_tag_proof->R, beta_tag_proof->z);
+  MPE_LAUNCH_1D(mpe::dlog_prove_kernel, batch, st, batch, ctx->enc, d_b, d_nonce_b, b_proof->pk, b_proof->R, b_proof->z);
+  MPE_LAUNCH_1D(mpe::dlog_prove_kernel, batch, st, batch, ctx->enc, btq, d_nonce_bt, beta_tag_proof->pk, beta_tag_proof->R, beta_tag_proof->z);
   return MPE_OK;
 }
 
@@ -131,7 +131,7 @@ int mpe_mta_verify_get_alpha(mpe_ctx* ctx, const mpe_paillier* sk, int batch, co
   if (batch == 0) return MPE_OK;
   hipStream_t st = (hipStream_t)stream;
   MPE_TRY(mpe::paillier_decrypt(ctx, sk, batch, d_key_idx, mpe::rows(d_cb, 128), d_alice_share, st));             // :165
-  MPE_LAUNCH_1D(mpe::mta_alpha_kernel, batch, st, batch, d_alice_share, d_a, b_proof->pk, b_proof->R, b_proof->z,
+  MPE_LAUNCH_1D(mpe::mta_alpha_kernel, batch, st, batch, ctx->enc, d_alice_share, d_a, b_proof->pk, b_proof->R, b_proof->z,
                 beta_tag_proof->pk, beta_tag_proof->R, beta_tag_proof->z, d_alpha, d_ok);
   return MPE_OK;
 }

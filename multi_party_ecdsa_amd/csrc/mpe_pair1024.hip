@@ -1,6 +1,5 @@
 // Translation unit of the N-adic pair engine for 1024-bit moduli (arithmetic modulo their squares); see mpe_pairexp.h.
 // Kept apart from mpe_lib.hip only so that the three units compile in parallel.
-#include <cstdlib>
 #include "mpe_pairexp.h"
 
 namespace mpe {
@@ -21,8 +20,7 @@ int pair_modexp_1024(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
   // +13 % when the threshold lets mid-size launches take it: with 10 MACs per step the quotient-digit dependency chain
   // (mad -> mul_lo -> three DPP moves -> mad) is no longer hidden, so the layout only pays while the chip is nearly empty.
   using XWide = Cfg<1024, MPE_W, 5, 8>;
-  const char* xenv = getenv("MPE_XWIDE_DIV");                 // read per call (A/B runs, tests of the 9-limb layout): 0 switches it off
-  const int xdiv = xenv ? atoi(xenv) : 16;
+  const int xdiv = ctx->xwide_div;                            // MPE_XWIDE_DIV, read when the context was created; 0 switches the layout off
   if (ctx->adaptive_lanes && xdiv > 0 && (long)xdiv * batch <= resident)
     return pair_modexp_impl<XWide>(ctx, ps, batch, mod_sel, base, exps, exp_words, base2, exps2, exp2_words, half, out, st, public_exp);
   if (ctx->adaptive_lanes && (long)ctx->wide_div * batch <= resident)

@@ -393,7 +393,8 @@ template <class C, bool SLIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) pair_modexp_kernel(int batch, PairsetView ps, Rows mod_sel, Rows base, Rows exps,
                                                          int exp_words, int wb, Rows base2, Rows exps2, int exp2_words,
                                                          int half, uint32_t* __restrict__ out, uint32_t* __restrict__ tables,
-                                                         const int32_t* __restrict__ perm, int slide) {
+                                                         const int32_t* __restrict__ perm, int slide,
+                                                         uint32_t* __restrict__ slid_ctr) {
   using PL = PairLds<C>;
   __shared__ uint32_t lds[PL::WORDS];
   const Lane ln = make_lane<C>();
@@ -435,6 +436,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         sw_lo = slide_window(exu, exp_words, exp_words * 32 - 1, wb, sw_val);
         if (sw_lo < 0 || (dual && sw_lo < 32 * exp2_words)) sl_rt = false;
       }
+#ifndef MPE_NO_SLIDE_COUNTER                                    // (A/B switch: tools/ab.sh nocounter -DMPE_NO_SLIDE_COUNTER)
+      if (slid_ctr && sl_rt && threadIdx.x == 0) atomicAdd(slid_ctr, 1u);      // profiling only: (wave, trip) pairs on the sliding schedule
+#endif
     }
 
     uint32_t n[C::L];
@@ -682,12 +686,14 @@ int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
   PairsetView v{ps->n_limbs, ps->n0inv, ps->one, ps->r2, ps->tp, ps->kc, ps->count};
   // kind 6: the pair kernel on sliding windows (the executed multiplication count differs: bench.py's accounting)
   prof_begin(ctx, st, half ? 4 : (slide ? 6 : 3), half ? C::BITS : 2 * C::BITS, exp_words, batch, dual ? exp2_words : 0);
+  const int nslots = grid * C::GROUPS;
+  uint32_t* slid_ctr = slide ? prof_counter(ctx, grid * ((batch + nslots - 1) / nslots)) : nullptr;
   if (slide)
     hipLaunchKernelGGL((pair_modexp_kernel<C, true>), dim3(grid), dim3(64), 0, st, batch, v, mod_sel, base, exps, exp_words, wb, base2,
-                       exps2, exp2_words, half, d_out, tabs, perm, slide);
+                       exps2, exp2_words, half, d_out, tabs, perm, slide, slid_ctr);
   else
     hipLaunchKernelGGL((pair_modexp_kernel<C, false>), dim3(grid), dim3(64), 0, st, batch, v, mod_sel, base, exps, exp_words, wb, base2,
-                       exps2, exp2_words, half, d_out, tabs, perm, slide);
+                       exps2, exp2_words, half, d_out, tabs, perm, slide, slid_ctr);
   prof_end(ctx, st);
   hipLaunchKernelGGL(pair_finish_kernel<C::K32>, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, mod_sel, ps->mod_words, d_out);
   hipError_t e = hipGetLastError();

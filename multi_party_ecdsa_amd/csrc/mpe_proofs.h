@@ -74,33 +74,37 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC ec_add_kernel(int B, const uint
 }
 
 // curv DLogProof: pk = sk G, R = rho G, c = H(R, G, pk) mod q, z = rho - c sk
-__device__ inline ec::U256 dlog_challenge(const ec::Aff& R, const ec::Aff& pk) {
+// (point form and order of the three points: ec::Enc — recalled conventions are run-time properties of the context)
+__device__ inline ec::U256 dlog_challenge(const ec::Aff& R, const ec::Aff& pk, const ec::Enc& enc) {
   ec::Sha256 s;
   ec::sha_init(s);
-  ec::sha_point_uncompressed(s, R);
-  ec::sha_point_uncompressed(s, ec::aff_gen());
-  ec::sha_point_uncompressed(s, pk);
+  const ec::Aff G = ec::aff_gen();
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int o = enc.ord_dlog[i];
+    ec::sha_chain_point(s, o == 0 ? R : (o == 1 ? G : pk), enc);
+  }
   const ec::U256 d = ec::sha_final(s);
   return ec::sc_reduce(d.w, 8);
 }
-__global__ void __launch_bounds__(64) MPE_EC_OCC dlog_prove_kernel(int B, const uint32_t* __restrict__ sk, const uint32_t* __restrict__ nonce,
+__global__ void __launch_bounds__(64) MPE_EC_OCC dlog_prove_kernel(int B, ec::Enc enc, const uint32_t* __restrict__ sk, const uint32_t* __restrict__ nonce,
                                   uint32_t* __restrict__ pk, uint32_t* __restrict__ R, uint32_t* __restrict__ z) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::U256 s = ec::sc_reduce(sk + (size_t)i * 8, 8), k = ec::sc_reduce(nonce + (size_t)i * 8, 8);
   const ec::Aff Rp = ec::jac_to_aff(ec::jac_mul_gen(k)), P = ec::jac_to_aff(ec::jac_mul_gen(s));
-  const ec::U256 c = dlog_challenge(Rp, P);
+  const ec::U256 c = dlog_challenge(Rp, P, enc);
   ec::aff_store(pk + (size_t)i * 16, P);
   ec::aff_store(R + (size_t)i * 16, Rp);
   ec::u256_store(z + (size_t)i * 8, ec::sc_sub(k, ec::sc_mul(c, s)));
 }
-__global__ void __launch_bounds__(64) MPE_EC_OCC dlog_verify_kernel(int B, const uint32_t* __restrict__ pk, const uint32_t* __restrict__ R,
+__global__ void __launch_bounds__(64) MPE_EC_OCC dlog_verify_kernel(int B, ec::Enc enc, const uint32_t* __restrict__ pk, const uint32_t* __restrict__ R,
                                    const uint32_t* __restrict__ z, uint8_t* __restrict__ ok) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::Aff P = ec::aff_load(pk + (size_t)i * 16), Rp = ec::aff_load(R + (size_t)i * 16);
   if (!ec::aff_valid(P) || !ec::aff_valid(Rp)) { ok[i] = 0; return; }         // curv rejects such points when it deserialises them
-  const ec::U256 c = dlog_challenge(Rp, P), zz = ec::sc_reduce(z + (size_t)i * 8, 8);
+  const ec::U256 c = dlog_challenge(Rp, P, enc), zz = ec::sc_reduce(z + (size_t)i * 8, 8);
   const ec::Jac l = ec::jac_add(ec::jac_mul_gen(zz), ec::jac_mul(c, P));
   ok[i] = ec::jac_eq_aff(l, Rp) ? 1 : 0;
 }
@@ -128,7 +132,7 @@ __global__ void muladd_kernel(int B, Rows a, int na, Rows b, int nb, Rows c, int
 enum { HF_BIGINT = 0, HF_BIGINT_PLUS1 = 1, HF_POINT_COMPRESSED = 2 };
 struct HashField { Rows r; int words; int kind; };
 struct HashDesc { HashField f[14]; int n; };
-__global__ void __launch_bounds__(64) MPE_EC_OCC hash_kernel(int B, HashDesc d, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) MPE_EC_OCC hash_kernel(int B, ec::Enc enc, HashDesc d, uint32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   ec::Sha256 s;
@@ -141,9 +145,9 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC hash_kernel(int B, HashDesc d, 
       uint32_t t[130];
       const uint32_t one[1] = {1};
       t[d.f[k].words] = sm::add(t, d.f[k].words, p, d.f[k].words, one, 1);
-      ec::sha_bigint(s, t, d.f[k].words + 1);
+      ec::sha_bigint(s, t, d.f[k].words + 1, enc);
     } else {
-      ec::sha_bigint(s, p, d.f[k].words);
+      ec::sha_bigint(s, p, d.f[k].words, enc);
     }
   }
   ec::u256_store(out + (size_t)i * 8, ec::sha_final(s));
@@ -256,7 +260,7 @@ struct Seq {
   }
   void hash(const HashDesc& d, uint32_t* out) {
     if (rc != MPE_OK) return;
-    hipLaunchKernelGGL(hash_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, d, out);
+    hipLaunchKernelGGL(hash_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ctx->enc, d, out);
   }
   int finish(const char* what) {
     if (rc != MPE_OK) return rc;
@@ -598,14 +602,14 @@ int mpe_dlog_prove(mpe_ctx* ctx, int batch, const uint32_t* d_sk, const uint32_t
                    uint32_t* d_R, uint32_t* d_z, void* stream) {
   if (!ctx || !d_sk || !d_nonce || !d_pk || !d_R || !d_z || batch < 0) return MPE_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  MPE_LAUNCH_1D(mpe::dlog_prove_kernel, batch, st, batch, d_sk, d_nonce, d_pk, d_R, d_z);
+  MPE_LAUNCH_1D(mpe::dlog_prove_kernel, batch, st, batch, ctx->enc, d_sk, d_nonce, d_pk, d_R, d_z);
   return MPE_OK;
 }
 int mpe_dlog_verify(mpe_ctx* ctx, int batch, const uint32_t* d_pk, const uint32_t* d_R, const uint32_t* d_z,
                     uint8_t* d_ok, void* stream) {
   if (!ctx || !d_pk || !d_R || !d_z || !d_ok || batch < 0) return MPE_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  MPE_LAUNCH_1D(mpe::dlog_verify_kernel, batch, st, batch, d_pk, d_R, d_z, d_ok);
+  MPE_LAUNCH_1D(mpe::dlog_verify_kernel, batch, st, batch, ctx->enc, d_pk, d_R, d_z, d_ok);
   return MPE_OK;
 }
 int mpe_modinv(mpe_ctx* ctx, const mpe_modset* ms, int batch, const int32_t* d_mod_idx, const uint32_t* d_a,

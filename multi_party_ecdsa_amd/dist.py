@@ -22,7 +22,15 @@ mesh, no ring all-reduce anywhere.  Placements:
 The exchange is stream-ordered: a round's records are written by `mpe_gg20_roundN` straight into this rank's slot of the
 gather buffer, the all-gather is queued behind them on the same stream (RCCL) and the next round reads the gathered buffer
 in place through `h_in_off` — no host synchronisation, no staging copy, two alternating buffers.  Under gloo (CPU tensors,
-or GPU engines that share one device in the tests) the slab is staged through host memory."""
+or GPU engines that share one device in the tests) the slab is staged through host memory.
+
+Gather modes (`PartySharded.gather_mode`; MPE_DIST_GATHER in the environment forces one): "inplace" — the default on RCCL:
+the collective's input is this rank's slice of its output; "outofplace" — the input is a separate copy of that slice (what
+`layout_self_test` falls back to if the in-place form ever misplaces a row on some backend / version); "staged" — synchronise,
+copy through host memory (gloo with GPU engines; also the conservative fallback).  `layout_self_test()` runs one collective of
+known row patterns on the REAL backend before any timing and picks the first mode under which every row of every rank lands
+where `in_off` says it does — all ranks agree on the mode through an all-reduce."""
+import os
 import time
 
 import torch
@@ -71,7 +79,8 @@ class PartySharded:
     `writes_in_place = True` accepts `out=` (a contiguous [L, Bblk, W] view of the gather buffer) and writes its records
     there; the others return a tensor that is copied into the slot."""
 
-    def __init__(self, S, Bblk, msg_words, make_engine, device, placement="rotated", rank=None, world=None, colocate=False):
+    def __init__(self, S, Bblk, msg_words, make_engine, device, placement="rotated", rank=None, world=None, colocate=False,
+                 timing=False):
         self.S, self.Bblk, self.msg_words, self.device = S, Bblk, msg_words, torch.device(device)
         self.dist = dist.is_available() and dist.is_initialized()
         self.rank = (dist.get_rank() if self.dist else 0) if rank is None else rank
@@ -102,8 +111,15 @@ class PartySharded:
         self.bytes_per_round = {}
         self._bufs = [None, None]
         self._events = []
+        self.timing = timing                   # record a HIP event pair around every RCCL all-gather (bench.py); off for a service loop
         self.backend = dist.get_backend() if self.dist else None
         self.maxw = max(self.msg_words(r) for r in ROUNDS_OUT)
+        cuda = self.device.type == "cuda"
+        self.gather_mode = "inplace" if (cuda and self.backend == "nccl") else ("staged" if cuda else "outofplace")
+        forced = os.environ.get("MPE_DIST_GATHER")
+        if forced in ("inplace", "outofplace", "staged") and cuda:
+            self.gather_mode = forced
+        self.self_test = None
 
     def in_off(self, s):
         """record offset, in the gathered slab, of every sender ordinal's block for session block s"""
@@ -120,29 +136,79 @@ class PartySharded:
             self._bufs[q & 1] = torch.empty(rows * self.Bblk * self.maxw, dtype=torch.int32, device=self.device)
         return self._bufs[q & 1][: rows * self.Bblk * W].view(rows, self.Bblk, W)
 
+    def _collective(self, buf, mine, mode):
+        if mode == "inplace":                        # input = this rank's slice of the output
+            dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1))
+        elif mode == "outofplace":
+            dist.all_gather_into_tensor(buf.view(-1), mine.clone().reshape(-1))
+        else:                                        # staged through host memory
+            h_out = torch.empty(buf.shape, dtype=buf.dtype)
+            dist.all_gather_into_tensor(h_out.view(-1), mine.cpu().reshape(-1))
+            buf.copy_(h_out)
+
     def _gather(self, buf, mine):
         """all ranks' slabs into `buf` (`mine` = this rank's rows of it, already written)"""
         cuda = buf.is_cuda
         if not self.dist or (self.world == 1 and not (cuda and self.backend == "nccl")):
             return                                   # (one RCCL rank still issues the collective: the same call path as N ranks)
-        if cuda and self.backend == "nccl":
-            # in-place RCCL all-gather queued behind the round's kernels on the current stream; timed with events
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1))
-            e1.record()
-            self._events.append((e0, e1))
+        mode = self.gather_mode if cuda else "outofplace"
+        if cuda and mode != "staged":
+            # RCCL all-gather queued behind the round's kernels on the current stream; timed with events when asked
+            if self.timing:
+                if len(self._events) >= 4096:        # a caller that never drains: keep the newest, bounded
+                    self._events = self._events[-1024:]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._collective(buf, mine, mode)
+                e1.record()
+                self._events.append((e0, e1))
+            else:
+                self._collective(buf, mine, mode)
             return
         if cuda:
             torch.cuda.synchronize(buf.device)       # the wait for the round's kernels is not communication time
         t0 = time.perf_counter()
-        if cuda:                                     # gloo with GPU engines: through host memory
-            h_out = torch.empty(buf.shape, dtype=buf.dtype)
-            dist.all_gather_into_tensor(h_out.view(-1), mine.cpu().reshape(-1))
-            buf.copy_(h_out)
-        else:
-            dist.all_gather_into_tensor(buf.view(-1), mine.clone().reshape(-1))
+        self._collective(buf, mine, mode)
         self.comm_s += time.perf_counter() - t0
+
+    def layout_self_test(self):
+        """One all-gather of known patterns on the real backend, BEFORE any timed or signing work: row (rank r, slot k) carries
+        the value (r * per_rank + k) * 65536 + column; after the collective every row of every rank must sit where `in_off`
+        will look for it.  Tries the current mode first, then the remaining ones; all ranks settle on the first mode that is
+        right everywhere (all-reduce MIN of the verdicts).  Returns and stores {"mode", "ok", "tried": {mode: ok}}."""
+        if not self.dist:
+            self.self_test = dict(mode=self.gather_mode, ok=True, tried={}, skipped="no process group")
+            return self.self_test
+        cuda = self.device.type == "cuda"
+        rows, W = self.world * self.per_rank, 16
+        cols = torch.arange(self.Bblk * W, dtype=torch.int32, device=self.device).view(1, self.Bblk, W) % 65536
+        ids = torch.arange(rows, dtype=torch.int32, device=self.device).view(rows, 1, 1)
+        want = ids * 65536 + cols
+        order = [self.gather_mode] + [m for m in (("inplace", "outofplace", "staged") if cuda else ("outofplace",)) if m != self.gather_mode]
+        if cuda and self.backend != "nccl":
+            order = ["staged"]
+        tried = {}
+        for mode in order:
+            buf = torch.full((rows, self.Bblk, W), -1, dtype=torch.int32, device=self.device)
+            mine = buf[self.rank * self.per_rank:(self.rank + 1) * self.per_rank]
+            mine.copy_(want[self.rank * self.per_rank:(self.rank + 1) * self.per_rank])
+            try:
+                self._collective(buf, mine, mode)
+                if cuda:
+                    torch.cuda.synchronize(self.device)
+                ok = bool(torch.equal(buf, want))
+            except RuntimeError:
+                ok = False
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if (cuda and self.backend == "nccl") else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            tried[mode] = bool(flag.item())
+            if tried[mode]:
+                if cuda:
+                    self.gather_mode = mode
+                self.self_test = dict(mode=mode, ok=True, tried=tried)
+                return self.self_test
+        self.self_test = dict(mode=None, ok=False, tried=tried)
+        raise RuntimeError(f"all-gather layout self-test failed under every mode: {tried}")
 
     def comm_seconds(self):
         """time spent in the all-gathers since the last call (drains the event pairs: call it after a synchronize)"""
@@ -154,6 +220,8 @@ class PartySharded:
 
     def run(self, msgs):
         """msgs: {block: tensor [Bblk, 8]} for the blocks this rank hosts.  Returns {block: result dict}."""
+        if not self.timing:
+            self._events = []
         gathered, q = None, 0
         for rnd in range(9):
             W = self.msg_words(rnd) if rnd in ROUNDS_OUT else 0

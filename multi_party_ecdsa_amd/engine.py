@@ -21,13 +21,26 @@ def _to_np_u32(t):
 
 
 class Context:
-    def __init__(self, device=0):
+    def __init__(self, device=0, encoding=None):
+        """encoding: None (the defaults of include/mpecdsa_hip.h) or a dict / N.Encoding — the profile of the recalled
+        curv / zk-paillier byte conventions this context hashes with (mpe_ctx_set_encoding)"""
         if not torch.cuda.is_available():
             raise N.MpeError("no GPU visible: the HIP path cannot run (there is no CPU fallback)")
         self.device = torch.device("cuda", device)
         h = C.c_void_p()
         N.check(N.lib.mpe_ctx_create(C.byref(h), device), "mpe_ctx_create")
         self.h = h
+        if encoding is not None:
+            self.set_encoding(encoding)
+
+    def set_encoding(self, encoding):
+        e = encoding if isinstance(encoding, N.Encoding) else N.Encoding.from_dict(dict(encoding))
+        N.check(N.lib.mpe_ctx_set_encoding(self.h, C.byref(e)), "mpe_ctx_set_encoding")
+
+    def encoding(self):
+        e = N.Encoding()
+        N.check(N.lib.mpe_ctx_get_encoding(self.h, C.byref(e)), "mpe_ctx_get_encoding")
+        return e.as_dict()
 
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -47,7 +60,8 @@ class Context:
         arr = (N.ProfRec * max_records)()
         n = C.c_int(0)
         N.check(N.lib.mpe_prof_collect(self.h, arr, max_records, C.byref(n)), "mpe_prof_collect")
-        return [dict(kind=r.kind, bits=r.bits, exp_words=r.exp_words, batch=r.batch, ms=r.ms, exp2_words=r.exp2_words) for r in arr[:n.value]]
+        return [dict(kind=r.kind, bits=r.bits, exp_words=r.exp_words, batch=r.batch, ms=r.ms, exp2_words=r.exp2_words,
+                     sliding_frac=r.sliding_frac) for r in arr[:n.value]]
 
     def wipe(self):
         N.check(N.lib.mpe_ctx_wipe(self.h, self.stream()), "mpe_ctx_wipe")

@@ -76,9 +76,12 @@ static void hash_commit_point(mpz_t out, const pt_t* P, const mpz_t blind) {
   result_bigint(&sh, out);
   mpz_clear(m);
 }
+/* pts: the canonical list of the proof — 5 = PedersenProof (g, h, com, a1, a2), 7 = HomoELGamalProof (T, A3, G, H, Y, D, E),
+ * 6 = ECDDHProof (g1, h1, g2, h2, a1, a2); hashed in the order ORC_ENC names (identity by default) */
 static void hash_points_scalar(mpz_t out, const pt_t** pts, int n) {
   sha_t sh; sha_init(&sh);
-  for (int i = 0; i < n; ++i) chain_point(&sh, pts[i]);
+  const uint8_t* ord = n == 5 ? ORC_ENC.ord_pedersen : (n == 7 ? ORC_ENC.ord_heg : ORC_ENC.ord_ecddh);
+  for (int i = 0; i < n; ++i) chain_point(&sh, pts[ord[i] % n]);
   result_bigint(&sh, out);
   sc_mod(out);
 }
@@ -940,6 +943,12 @@ static void zkp_digest(mpz_t out, const mpz_t* vals, int n) {
   for (int i = 0; i < n; ++i) chain_bigint(&sh, vals[i]);
   result_bigint(&sh, out);
 }
+/* e = H(x, g, N, ni) of CompositeDLogProof; v = the canonical list, hashed in ORC_ENC.ord_cdlog order */
+static void cdlog_digest(mpz_t e, const mpz_t* v) {
+  sha_t sh; sha_init(&sh);
+  for (int i = 0; i < 4; ++i) chain_bigint(&sh, v[ORC_ENC.ord_cdlog[i] & 3]);
+  result_bigint(&sh, e);
+}
 /* CompositeDLogProof{x, y}::verify(statement{N, g, ni}) (zk-paillier composite_dlog_proof.rs): N >= 2^128, gcd(g, N) = gcd(ni, N) = 1,
  * e = H(x, g, N, ni), x == g^y ni^e mod N.   y: [B][73] (r < 2^512, e 256 bit, secret < phi: y < 2^2306) */
 void orc_composite_dlog_verify(int batch, const uint32_t* N, const uint32_t* g, const uint32_t* ni, const uint32_t* x, const uint32_t* y,
@@ -953,7 +962,7 @@ void orc_composite_dlog_verify(int batch, const uint32_t* N, const uint32_t* g, 
     if (mpz_cmp(v[2], lim) < 0 || mpz_even_p(v[2])) continue;
     mpz_gcd(a, v[1], v[2]); if (mpz_cmp_ui(a, 1) != 0) continue;
     mpz_gcd(a, v[3], v[2]); if (mpz_cmp_ui(a, 1) != 0) continue;
-    zkp_digest(e, (const mpz_t*)v, 4);
+    cdlog_digest(e, (const mpz_t*)v);
     mpz_powm(a, v[1], Y, v[2]); mpz_powm(b, v[3], e, v[2]);
     mpz_mul(a, a, b); mpz_mod(a, a, v[2]);
     ok[i] = (uint8_t)(mpz_cmp(a, v[0]) == 0);
@@ -968,7 +977,7 @@ void orc_composite_dlog_prove(int batch, const uint32_t* N, const uint32_t* g, c
     zin(v[1], g + (size_t)i * 64, 64); zin(v[2], N + (size_t)i * 64, 64); zin(v[3], ni + (size_t)i * 64, 64);
     zin(S, secret + (size_t)i * 64, 64); zin(R, r + (size_t)i * 16, 16);
     mpz_powm(v[0], v[1], R, v[2]);
-    zkp_digest(e, (const mpz_t*)v, 4);
+    cdlog_digest(e, (const mpz_t*)v);
     mpz_mul(e, e, S); mpz_add(e, e, R);
     zout(x + (size_t)i * 64, 64, v[0]); zout(y + (size_t)i * 73, 73, e);
   }
@@ -980,15 +989,14 @@ void orc_composite_dlog_prove(int batch, const uint32_t* N, const uint32_t* g, c
 #define ORC_CK_M2 11
 static void correct_key_rho(mpz_t rho, const mpz_t N, int i) {
   mpz_t v[3], seed, d, acc, w[2]; mpz_inits(v[0], v[1], v[2], seed, d, acc, w[0], w[1], NULL);
-  static const unsigned char salt[4] = {75, 90, 101, 110};
-  mpz_set(v[0], N); mpz_import(v[1], 4, 1, 1, 0, 0, salt); mpz_set_ui(v[2], (unsigned long)i);
+  mpz_set(v[0], N); mpz_set_ui(v[1], (unsigned long)ORC_ENC.ck_salt); mpz_set_ui(v[2], (unsigned long)i);   /* salt: b"KZen" as a BigInt */
   zkp_digest(seed, (const mpz_t*)v, 3);
   const int msklen = (int)(mpz_sizeinbase(N, 2) / 256) + 1;
   mpz_set_ui(acc, 0);
   for (int j = 0; j < msklen; ++j) {
     mpz_set(w[0], seed); mpz_set_ui(w[1], (unsigned long)j);
     zkp_digest(d, (const mpz_t*)w, 2);
-    mpz_mul_2exp(d, d, 256u * (unsigned)j); mpz_add(acc, acc, d);
+    mpz_mul_2exp(d, d, 256u * (unsigned)(ORC_ENC.ck_mask_order ? msklen - 1 - j : j)); mpz_add(acc, acc, d);
   }
   mpz_mod(rho, acc, N);
   mpz_clears(v[0], v[1], v[2], seed, d, acc, w[0], w[1], NULL);

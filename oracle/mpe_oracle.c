@@ -238,11 +238,20 @@ static void sha_final(sha_t* s, uint8_t out[32]) {
 void orc_sha256(const uint8_t* msg, uint64_t len, uint8_t out[32]) {
   sha_t s; sha_init(&s); sha_update(&s, msg, (size_t)len); sha_final(&s, out);
 }
+/* The byte-level conventions of the un-vendored crates that the reference's source does not fix (the same struct, field for
+ * field, as mpe_encoding of include/mpecdsa_hip.h — kept textually separate: the oracle never includes product headers).
+ * Process-wide: set once by the test harness before the threads of a batch start. */
+static orc_encoding ORC_ENC = {0, 0, 0, 0, 0x4B5A656Eu, {0, 1, 2, 3}, {0, 1, 2, 3, 4, 5, 6, 7}, {0, 1, 2, 3, 4, 5, 6, 7},
+                               {0, 1, 2, 3, 4, 5, 6, 7}, {0, 1, 2, 3}};
+void orc_set_encoding(const orc_encoding* e) { if (e) ORC_ENC = *e; }
+void orc_get_encoding(orc_encoding* out) { if (out) *out = ORC_ENC; }
+
 /* DigestExt::chain_bigint: update(BigInt::to_bytes()) = big-endian magnitude, minimal length
- * (rust-gmp exports 0 as one 0x00 byte). */
+ * (rust-gmp exports 0 as one 0x00 byte — or, ORC_ENC.zero_bytes = 1, as nothing). */
 static void chain_bigint(sha_t* s, const mpz_t x) {
   uint8_t buf[1024];
   size_t cnt = (mpz_sizeinbase(x, 2) + 7) / 8;
+  if (mpz_sgn(x) == 0 && ORC_ENC.zero_bytes) cnt = 0;
   if (cnt > sizeof buf) abort();
   memset(buf, 0, cnt);
   mpz_export(buf, NULL, 1, 1, 0, 0, x);
@@ -397,8 +406,12 @@ static void pt_bytes(const pt_t* p, int compressed, uint8_t* out) {
 static void pt_as_bigint(mpz_t out, const pt_t* p) {
   uint8_t b[33]; pt_bytes(p, 1, b); mpz_import(out, 33, 1, 1, 0, 0, b);
 }
-/* DigestExt::chain_point: update(P.to_bytes(false))  [RECALLED, App. A.2] */
-static void chain_point(sha_t* s, const pt_t* p) { uint8_t b[65]; pt_bytes(p, 0, b); sha_update(s, b, 65); }
+/* DigestExt::chain_point: update(P.to_bytes(false))  [RECALLED, App. A.2; ORC_ENC.chain_point = 1: to_bytes(true)] */
+static void chain_point(sha_t* s, const pt_t* p) {
+  uint8_t b[65];
+  pt_bytes(p, ORC_ENC.chain_point, b);
+  sha_update(s, b, ORC_ENC.chain_point ? 33 : 65);
+}
 
 void orc_ec_mul_base(int batch, const uint32_t* k, uint32_t* out) {
   mpz_t kk; mpz_init(kk); pt_t g, r; pt_init(&g); pt_init(&r); pt_gen(&g);
@@ -759,7 +772,8 @@ void orc_pdl_verify(int batch, int nkeys, const uint32_t* N, int nst, const uint
 /* ------------------------------------------------------------------------------------------ */
 static void dlog_challenge(mpz_t c, const pt_t* R, const pt_t* G, const pt_t* pk) {
   sha_t sh; sha_init(&sh);
-  chain_point(&sh, R); chain_point(&sh, G); chain_point(&sh, pk);
+  const pt_t* canon[3] = {R, G, pk};
+  for (int i = 0; i < 3; ++i) chain_point(&sh, canon[ORC_ENC.ord_dlog[i] % 3]);
   result_bigint(&sh, c);
   mpz_mod(c, c, EC_Q);                                  /* result_scalar */
 }

@@ -40,6 +40,17 @@ extern "C" {
 
 const char* orc_version(void);
 
+/* The recalled byte-level conventions of curv-kzen 0.9 / zk-paillier 0.4.3 as a run-time profile — the oracle's mirror of
+ * the product's mpe_encoding (include/mpecdsa_hip.h documents every field; same layout, so a test passes one ctypes struct to
+ * both).  Process-wide; defaults = what this repository believes the crates do. */
+typedef struct {
+  uint8_t chain_point, zero_bytes, ck_mask_order, reserved;
+  uint32_t ck_salt;
+  uint8_t ord_dlog[4], ord_pedersen[8], ord_heg[8], ord_ecddh[8], ord_cdlog[4];
+} orc_encoding;
+void orc_set_encoding(const orc_encoding* e);
+void orc_get_encoding(orc_encoding* out);
+
 /* ---- curv BigInt (A.1) ---------------------------------------------------------------- */
 /* out = base^exp mod m  (mpz_powm; BigInt::mod_pow).  mods: [nmods][k32]; mod_idx NULL -> (nmods==1?0:i) */
 void orc_modexp(int k32, int batch, int nmods, const uint32_t* mods, const int32_t* mod_idx,

@@ -41,6 +41,36 @@ lib = load()
 lib.orc_version.restype = C.c_char_p
 
 
+class Encoding(C.Structure):
+    """orc_encoding (oracle/mpe_oracle.h) — field for field the product's mpe_encoding"""
+    _fields_ = [("chain_point", C.c_uint8), ("zero_bytes", C.c_uint8), ("ck_mask_order", C.c_uint8), ("reserved", C.c_uint8),
+                ("ck_salt", C.c_uint32), ("ord_dlog", C.c_uint8 * 4), ("ord_pedersen", C.c_uint8 * 8), ("ord_heg", C.c_uint8 * 8),
+                ("ord_ecddh", C.c_uint8 * 8), ("ord_cdlog", C.c_uint8 * 4)]
+    SIZES = dict(ord_dlog=3, ord_pedersen=5, ord_heg=7, ord_ecddh=6, ord_cdlog=4)
+
+
+def get_encoding():
+    e = Encoding()
+    lib.orc_get_encoding(C.byref(e))
+    out = {k: getattr(e, k) for k in ("chain_point", "zero_bytes", "ck_mask_order", "ck_salt")}
+    out.update({k: list(getattr(e, k))[:n] for k, n in Encoding.SIZES.items()})
+    return out
+
+
+def set_encoding(d):
+    """d: the dict form of a profile (pyref.Encoding.as_dict()); fields left out keep their current value.  Process-wide."""
+    e = Encoding()
+    lib.orc_get_encoding(C.byref(e))
+    for k, v in d.items():
+        if k.startswith("ord_"):
+            arr = getattr(e, k)
+            for i, x in enumerate(v):
+                arr[i] = x
+        else:
+            setattr(e, k, v)
+    lib.orc_set_encoding(C.byref(e))
+
+
 def _p(a):
     if a is None:
         return None

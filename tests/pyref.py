@@ -51,9 +51,75 @@ def pt_bytes(pt, compressed):
     return b"\x04" + pt[0].to_bytes(32, "big") + pt[1].to_bytes(32, "big")
 
 
+# ---- the byte-level conventions of the un-vendored crates, as a profile (mirror of mpe_encoding / orc_encoding) --------
+class Encoding:
+    """Same fields as `mpe_encoding` (include/mpecdsa_hip.h documents each).  Defaults = what this repository believes
+    curv-kzen 0.9 / zk-paillier 0.4.3 do; every alternative is exercised by tests/test_encodings_*.py."""
+    FIELDS = ("chain_point", "zero_bytes", "ck_mask_order", "ck_salt", "ord_dlog", "ord_pedersen", "ord_heg", "ord_ecddh", "ord_cdlog")
+    SIZES = dict(ord_dlog=3, ord_pedersen=5, ord_heg=7, ord_ecddh=6, ord_cdlog=4)
+
+    def __init__(self, chain_point=0, zero_bytes=0, ck_mask_order=0, ck_salt=0x4B5A656E, ord_dlog=(0, 1, 2),
+                 ord_pedersen=(0, 1, 2, 3, 4), ord_heg=(0, 1, 2, 3, 4, 5, 6), ord_ecddh=(0, 1, 2, 3, 4, 5), ord_cdlog=(0, 1, 2, 3)):
+        self.chain_point, self.zero_bytes, self.ck_mask_order, self.ck_salt = chain_point, zero_bytes, ck_mask_order, ck_salt
+        self.ord_dlog, self.ord_pedersen, self.ord_heg = tuple(ord_dlog), tuple(ord_pedersen), tuple(ord_heg)
+        self.ord_ecddh, self.ord_cdlog = tuple(ord_ecddh), tuple(ord_cdlog)
+        for f, n in self.SIZES.items():
+            assert sorted(getattr(self, f)) == list(range(n)), f
+
+    def as_dict(self):
+        return {f: (list(getattr(self, f)) if f.startswith("ord_") else getattr(self, f)) for f in self.FIELDS}
+
+    def replace(self, **kw):
+        d = self.as_dict()
+        d.update(kw)
+        return Encoding(**d)
+
+    def __eq__(self, o):
+        return isinstance(o, Encoding) and self.as_dict() == o.as_dict()
+
+    def __repr__(self):
+        dflt = Encoding().as_dict()
+        diff = {k: v for k, v in self.as_dict().items() if v != dflt[k]}
+        return "Encoding(" + ", ".join(f"{k}={v}" for k, v in diff.items()) + ")" if diff else "Encoding(default)"
+
+
+ENC = Encoding()          # the profile in force for this module (tests switch it with `use_encoding`)
+
+
+class use_encoding:
+    """with use_encoding(enc): ...   (restores the previous profile)"""
+
+    def __init__(self, enc):
+        self.enc = enc
+
+    def __enter__(self):
+        global ENC
+        self.prev, ENC = ENC, self.enc
+        return self.enc
+
+    def __exit__(self, *a):
+        global ENC
+        ENC = self.prev
+
+
+def chain_point_bytes(pt):
+    """DigestExt::chain_point: Point::to_bytes(false) (65 B) — or to_bytes(true) under ENC.chain_point = 1"""
+    return pt_bytes(pt, bool(ENC.chain_point))
+
+
+def hash_points_scalar(canon, ord_field):
+    """Sha256::new().chain_points(..).result_scalar() over the proof's canonical point list in the profile's order"""
+    h = hashlib.sha256()
+    for k in getattr(ENC, ord_field):
+        h.update(chain_point_bytes(canon[k]))
+    return int.from_bytes(h.digest(), "big") % Q
+
+
 # ---- curv BigInt / DigestExt ------------------------------------------------------------------------
 def to_bytes(x):
-    """BigInt::to_bytes: big-endian magnitude, minimal length (0 -> b'\\x00' under rust-gmp)."""
+    """BigInt::to_bytes: big-endian magnitude, minimal length (0 -> b'\\x00' under rust-gmp; b'' under ENC.zero_bytes = 1)."""
+    if x == 0 and ENC.zero_bytes:
+        return b""
     return x.to_bytes(max(1, (x.bit_length() + 7) // 8), "big")
 
 
@@ -179,8 +245,7 @@ def bob_verify(N, Nt, h1, h2, a_enc, mta_enc, pr, X=None, u=None):
 
 # ---- curv DLogProof ------------------------------------------------------------------
 def dlog_challenge(R, pk):
-    h = hashlib.sha256(pt_bytes(R, False) + pt_bytes(G, False) + pt_bytes(pk, False)).digest()
-    return int.from_bytes(h, "big") % Q
+    return hash_points_scalar([R, G, pk], "ord_dlog")
 
 
 def dlog_prove(sk, nonce):
@@ -230,21 +295,27 @@ def zkp_digest(vals):
     return hash_bigints(vals)
 
 
+def cdlog_digest(x, g, N, ni):
+    canon = [x, g, N, ni]
+    return zkp_digest([canon[k] for k in ENC.ord_cdlog])
+
+
 def composite_dlog_prove(N, g, ni, secret, r):
     x = pow(g, r, N)
-    return x, r + zkp_digest([x, g, N, ni]) * secret
+    return x, r + cdlog_digest(x, g, N, ni) * secret
 
 
 def composite_dlog_verify(N, g, ni, x, y):
     import math
     if N < (1 << 128) or N % 2 == 0 or math.gcd(g, N) != 1 or math.gcd(ni, N) != 1:
         return False
-    return pow(g, y, N) * pow(ni, zkp_digest([x, g, N, ni]), N) % N == x
+    return pow(g, y, N) * pow(ni, cdlog_digest(x, g, N, ni), N) % N == x
 
 
 def correct_key_rho(N, i):
-    seed = zkp_digest([N, int.from_bytes(bytes([75, 90, 101, 110]), "big"), i])
-    return sum(zkp_digest([seed, j]) << (256 * j) for j in range(N.bit_length() // 256 + 1)) % N
+    seed = zkp_digest([N, ENC.ck_salt, i])                    # SALT_STRING = b"KZen" as a BigInt by default
+    msklen = N.bit_length() // 256 + 1
+    return sum(zkp_digest([seed, j]) << (256 * ((msklen - 1 - j) if ENC.ck_mask_order else j)) for j in range(msklen)) % N
 
 
 def correct_key_prove(p, q):

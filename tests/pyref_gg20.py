@@ -17,11 +17,10 @@ Q, G, H2 = R.Q, R.G, R.H2
 
 
 def scalar_hash(points):
-    """Sha256::new().chain_points(..).result_scalar(): 65-byte uncompressed points, digest mod q"""
-    h = hashlib.sha256()
-    for p in points:
-        h.update(R.pt_bytes(p, False))
-    return int.from_bytes(h.digest(), "big") % Q
+    """Sha256::new().chain_points(..).result_scalar() over a proof's canonical point list — 5 points = PedersenProof
+    (g, h, com, a1, a2), 7 = HomoELGamalProof (T, A3, G, H, Y, D, E), 6 = ECDDHProof (g1, h1, g2, h2, a1, a2) — in the byte
+    form and order of the profile in force (pyref.ENC; default: 65-byte uncompressed points, the order listed)"""
+    return R.hash_points_scalar(points, {5: "ord_pedersen", 7: "ord_heg", 6: "ord_ecddh"}[len(points)])
 
 
 def hash_commitment(point, blind):

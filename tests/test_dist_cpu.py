@@ -168,6 +168,8 @@ def _worker_b(rank, world, port, t, n, signers, B, placement, in_place, q):
         cls = _OracleEngineInPlace if in_place else _OracleEngine
         return cls(lk, block_nonces(s), parties, Bblk)
     ps = D.PartySharded(S, Bblk, lambda rnd: G.msg_words(S, n, rnd), make_engine, "cpu", placement=placement)
+    st = ps.layout_self_test()                     # the gather layout on the real backend (gloo here), before any signing work
+    assert st["ok"] and st["mode"] == "outofplace" and st["tried"] == {"outofplace": True}
     msgs = {s: torch.from_numpy(block_nonces(s)["msg"].view(np.int32)) for s in ps.engines}
     res = ps.run(msgs)
     out = {s: {f: v.tolist() for f, v in r.items()} for s, r in res.items()}
@@ -219,3 +221,36 @@ def test_party_sharded_engines_that_write_into_the_gather_buffer():
     """the GPU engine's calling convention (round(out=slot of the gather buffer), two alternating buffers, in-place all-gather)
     with the oracle as the engine: world 2, rotated blocks"""
     _check_mode_b(2, 1, 3, [0, 1], 4, "rotated", in_place=True)
+
+
+def test_gather_layout_self_test_catches_a_misplaced_row():
+    """the self-test really checks placement: a collective that delivers the ranks' slabs in the wrong order is refused under
+    that mode and the next mode is tried (single process, world 2 simulated by patching the collective)"""
+    import pytest
+    D = _load_dist()
+
+    class Fake(D.PartySharded):
+        def __init__(self):
+            pass
+    ps = Fake()
+    ps.dist, ps.world, ps.rank, ps.per_rank, ps.Bblk = True, 2, 0, 3, 5
+    ps.device, ps.backend, ps.gather_mode, ps.self_test = torch.device("cpu"), "gloo", "outofplace", None
+    calls = []
+
+    def bad_collective(buf, mine, mode):
+        calls.append(mode)
+        rows = ps.world * ps.per_rank
+        cols = torch.arange(ps.Bblk * 16, dtype=torch.int32).view(1, ps.Bblk, 16) % 65536
+        ids = torch.arange(rows, dtype=torch.int32).view(rows, 1, 1)
+        good = ids * 65536 + cols
+        buf.copy_(good.flip(0) if len(calls) == 1 else good)          # first attempt: rows reversed
+    ps._collective = bad_collective
+    import torch.distributed as dist
+    real = dist.all_reduce
+    dist.all_reduce = lambda t, op=None: None                          # one process: the verdict is this rank's own
+    try:
+        with pytest.raises(RuntimeError):
+            ps.layout_self_test()                                      # CPU tensors only know one mode: it failed, nothing left
+    finally:
+        dist.all_reduce = real
+    assert calls == ["outofplace"] and ps.self_test["ok"] is False

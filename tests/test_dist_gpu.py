@@ -244,3 +244,31 @@ def test_bench_self_spawns_two_ranks(mode, shape):
     assert abs(rec["value"] - 2 * 256 * 1 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
     if mode == "party":
         assert set(rec["config"]["bytes_all_gathered_per_round"]) == {"0", "1", "2", "3", "4", "5", "7"}
+
+
+def test_the_drivers_one_command_tells_both_modes_and_checks_itself():
+    """`bench.py --gpus 2` exactly as the driver starts it (plus --share-device: one GPU here) prints ONE line that carries the
+    session-sharded headline, a per-rank parity sample against the oracle, the all-gather LAYOUT self-test on the real backend,
+    and a party-sharded pass at BASELINE config 5's shape (t=2, n=5) with its own rate, all-gather share, bytes per round and
+    parity — nothing else is needed from the driver to learn about Mode B."""
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--steps", "1", "--warmup", "1",
+           "--sessions", "128", "--no-configs", "--mode-b-sessions", "32", "--mode-b-steps", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["all_sessions_signed"] is True
+    par = rec["per_rank"]["parity_vs_oracle"]
+    assert par["all_ok"] is True and par["ok_per_rank"] == [True, True] and par["sessions_per_rank"] == 16
+    st = rec["rccl"]["all_gather_layout_self_test"]
+    assert st["ok"] is True and st["mode"] in ("inplace", "outofplace", "staged") and st["tried"][st["mode"]] is True
+    mb = rec["mode_b"]
+    assert "error" not in mb, mb
+    assert mb["all_sessions_signed"] is True and mb["parity_sample_vs_oracle"] is True and mb["parity_sessions_per_rank"] == 4
+    assert mb["blocks"] == 2 and mb["signers"] == 3 and mb["sessions_per_block"] == 32
+    assert set(mb["bytes_all_gathered_per_round"]) == {"0", "1", "2", "3", "4", "5", "7"}
+    assert 0 <= mb["rccl_time_share"] < 1 and mb["signatures_per_s"] > 0 and len(mb["per_rank_signatures_per_s"]) == 2
+    assert abs(mb["signatures_per_s"] - 2 * 32 * 1 / (mb["ms_per_step"] * 1e-3)) < 1e-6 * mb["signatures_per_s"]

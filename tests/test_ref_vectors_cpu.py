@@ -9,6 +9,7 @@ import os
 import numpy as np
 import pytest
 
+import enc_profiles as ENCS
 import fixtures as F
 import gg20_fixture as G
 import orc
@@ -28,13 +29,31 @@ def _pt(v):
 
 
 SELFMADE = os.path.join(HERE, "golden", "selfmade_vectors.json")
+SELFMADE_ALT = os.path.join(HERE, "golden", "selfmade_vectors_alt.json")
+
+
+def diagnosed_profile(cases, what):
+    """Self-diagnosing consumer: search every combination of the recalled conventions (enc_profiles.diagnose), say which one
+    the file was produced under, and fail ONLY when some proof verifies under none."""
+    prof, report = ENCS.diagnose(cases, wire=W)
+    print(f"\n[{what}] encoding profile found: {prof!r}   (defaults of include/mpecdsa_hip.h: {prof == ENCS.DEFAULT})")
+    for name in ("dlog", "pedersen", "heg", "ecddh", "correct_key", "composite_dlog"):
+        if name in report:
+            print(f"    {name:15s} combinations that verify: {report[name]['n_matches']}  first: {report[name]['matches'][:1]}")
+    assert prof is not None, f"no combination of the known conventions verifies {report['no_combination_for']}: a recalled FORMULA differs, not an encoding"
+    return prof
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="tests/golden/ref_vectors.json not produced yet (tools/rust_vectors/run.sh)")
 def test_vectors_from_the_real_crates():
+    """THE pin.  Whatever conventions the real crates use, the run reports them (-s shows the profile; it is also written to
+    tests/golden/encoding_profile.json by tools/diagnose_encodings.py) and every crate-generated value must then be
+    reproduced / accepted by the oracle configured with that profile."""
     doc = json.load(open(REF))
     assert "SELF-MADE" not in doc["crate"]
-    check_cases(doc["cases"])
+    prof = diagnosed_profile(doc["cases"], "ref_vectors.json")
+    with ENCS.applied(prof):
+        check_cases(doc["cases"])
 
 
 def test_consumer_on_selfmade_vectors_of_the_same_schema():
@@ -42,7 +61,24 @@ def test_consumer_on_selfmade_vectors_of_the_same_schema():
     it keeps the consumer exercised, so that the real dump is checked by code known to work)"""
     doc = json.load(open(SELFMADE))
     assert doc["schema"] == 1 and "SELF-MADE" in doc["crate"]
-    check_cases(doc["cases"])
+    prof = diagnosed_profile(doc["cases"], "selfmade_vectors.json")
+    assert prof == ENCS.DEFAULT
+    with ENCS.applied(prof):
+        check_cases(doc["cases"])
+
+
+def test_diagnoser_recovers_a_non_default_profile_and_the_oracle_follows_it():
+    """selfmade_vectors_alt.json was written under the "all-alt" profile (compressed chain_point, empty zero, reversed
+    transcript orders, big-endian mask blocks) in the OTHER wire style: the diagnoser must find exactly that profile from the
+    vectors alone, the oracle configured with it must accept everything, and the oracle on its defaults must NOT."""
+    doc = json.load(open(SELFMADE_ALT))
+    assert doc["selfmade_profile"] == "all-alt"
+    prof = diagnosed_profile(doc["cases"], "selfmade_vectors_alt.json")
+    assert prof == ENCS.PROFILES["all-alt"]
+    with ENCS.applied(prof):
+        check_cases(doc["cases"])
+    with pytest.raises(AssertionError):
+        check_cases(doc["cases"])                    # defaults: the transcripts differ, so the proofs are rejected
 
 
 def check_cases(cases):

@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.path.join(HERE, "golden", "ref_vectors.json")
 SELFMADE = os.path.join(HERE, "golden", "selfmade_vectors.json")
+SELFMADE_ALT = os.path.join(HERE, "golden", "selfmade_vectors_alt.json")
 spec = importlib.util.spec_from_file_location("mpe_wire", os.path.join(os.path.dirname(HERE), "multi_party_ecdsa_amd", "wire.py"))
 W = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(W)
@@ -109,14 +110,43 @@ def check_cases_on_gpu(ctx, cases):
     ctx.sync()
 
 
+def _ctx_for(cases, what):
+    """a context configured with the profile the vectors were produced under (found by enc_profiles.diagnose from the vectors
+    alone: every point form x permutation x zero encoding x mask order) — the engine never needs a rebuild to follow the crates"""
+    import enc_profiles as ENCS
+    from multi_party_ecdsa_amd import engine as E
+    prof, report = ENCS.diagnose(cases, wire=W)
+    print(f"\n[{what}] encoding profile found: {prof!r}")
+    assert prof is not None, f"no combination of the known conventions verifies {report['no_combination_for']}"
+    return E.Context(0, encoding=prof.as_dict()), prof
+
+
 @pytest.mark.skipif(not os.path.exists(REF), reason="tests/golden/ref_vectors.json not produced yet (tools/rust_vectors/run.sh)")
-def test_engine_accepts_the_vectors_of_the_real_crates(gpu_ctx):
+def test_engine_accepts_the_vectors_of_the_real_crates():
     doc = json.load(open(REF))
     assert "SELF-MADE" not in doc["crate"]
-    check_cases_on_gpu(gpu_ctx, doc["cases"])
+    ctx, _ = _ctx_for(doc["cases"], "ref_vectors.json")
+    check_cases_on_gpu(ctx, doc["cases"])
 
 
 def test_engine_consumer_on_selfmade_vectors_of_the_same_schema(gpu_ctx):
+    import enc_profiles as ENCS
     doc = json.load(open(SELFMADE))
     assert doc["schema"] == 1 and "SELF-MADE" in doc["crate"]
-    check_cases_on_gpu(gpu_ctx, doc["cases"])
+    ctx, prof = _ctx_for(doc["cases"], "selfmade_vectors.json")
+    assert prof == ENCS.DEFAULT
+    check_cases_on_gpu(ctx, doc["cases"])
+    check_cases_on_gpu(gpu_ctx, doc["cases"])                 # a context left on its defaults is the same thing
+
+
+def test_engine_follows_a_non_default_profile_found_from_the_vectors(gpu_ctx):
+    """selfmade_vectors_alt.json: written under the "all-alt" profile in the hex wire style.  The diagnoser recovers the profile,
+    a context configured with it accepts every proof and reproduces every value; the default context must reject the
+    sigma proofs (their transcripts differ) — proof that the switch reaches the kernels."""
+    import enc_profiles as ENCS
+    doc = json.load(open(SELFMADE_ALT))
+    ctx, prof = _ctx_for(doc["cases"], "selfmade_vectors_alt.json")
+    assert prof == ENCS.PROFILES["all-alt"] and ctx.encoding() == prof.as_dict()
+    check_cases_on_gpu(ctx, doc["cases"])
+    with pytest.raises(AssertionError, match="rejected"):
+        check_cases_on_gpu(gpu_ctx, doc["cases"])

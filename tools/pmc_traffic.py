@@ -13,7 +13,12 @@ def main():
     d, sessions = sys.argv[1], int(sys.argv[2])
     load = lambda n: {k["kernel"]: k for k in json.load(open(os.path.join(d, n)))["kernels"]}
     fe, wr, sq = load("pmc_fetch.json"), load("pmc_write.json"), load("pmc_sq.json")
-    out = {"sessions": sessions,
+    import subprocess
+    try:
+        commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
+    except Exception:                                    # noqa: BLE001 — the GPU box has no .git: the caller passes it in MPE_COMMIT
+        commit = os.environ.get("MPE_COMMIT")
+    out = {"sessions": sessions, "host": os.uname().nodename, "commit": commit,
            "command": "tools/profile_round.sh (bench.py --no-cpu-baseline --no-configs --steps 1 --warmup 0 under rocprofv3 --kernel-trace "
                       "--pmc <counters>, one pass per counter group)",
            "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> x2; "
