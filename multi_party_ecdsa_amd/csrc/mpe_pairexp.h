@@ -173,6 +173,143 @@ __device__ __forceinline__ void cios2(uint32_t (&res)[C::L], uint64_t (&c)[C::L]
   cios_finish<C>(res, c, ln);
 }
 
+// ---- the same passes with the multiplier limbs QUEUED two steps ahead (MPE_BQ) ---------------------------------------------------
+// Where the waiting is (profiles/r03/pmc_stall_wave_cycles.json: 13.6 % of the wave cycles in s_waitcnt; the ISA of the loops
+// above): hipcc issues the ds_read of a trip's first multiplier limbs at the TOP of the 18-step trip and waits for them three
+// instructions later — a full LDS latency, 7 times per pass (more in the two-stream pass) — and when both waves of a SIMD sit
+// there the multiplier idles (VALU port 87.5 % busy).  Source-level software pipelining does not survive the compiler (it sinks
+// the loop-carried reads back to the loop top: tried, profiles/r04/README.md).  So the reads are issued BY HAND: limbs travel in
+// pairs (one ds_read_b64 per two steps) through three 64-bit registers; at the first step of pair h the read of pair h+2 is
+// issued and `s_waitcnt lgkmcnt(2)` lets exactly the two youngest reads stay in flight — LDS operations of a wave complete in
+// order, so pair h has landed whatever else the compiler queued in between (its own ds_writes of the quotient digits only make
+// the wait longer, never shorter).  The wait is tied to the destination register ("+v"), so no use can be scheduled above it.
+// hipcc does not know the register is pending between the two statements: tools/check_bq_isa.py verifies in the emitted ISA that
+// nothing reads, writes, copies or spills a destination between its ds_read and its wait (build.sh runs it).
+template <int OFF>
+__device__ __forceinline__ void bq_issue(uint64_t& d, uint32_t lds_addr) {
+  // "+v": the destination is TIED to the register the previous pair of this slot lived in — one register per slot for the whole
+  // pass, so the loop-carried value needs no copy (a copy of a register whose read is still in flight would copy stale bits)
+  asm volatile("ds_read_b64 %0, %1 offset:%2 ; BQ_ISSUE %0" : "+v"(d) : "v"(lds_addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void bq_wait(uint64_t& d) {         // at most the N youngest LDS operations may still be in flight
+  asm volatile("s_waitcnt lgkmcnt(%1) ; BQ_WAIT %0" : "+v"(d) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void bq_wait(uint64_t& d, uint64_t& e) {
+  asm volatile("s_waitcnt lgkmcnt(%2) ; BQ_WAIT %0 ; BQ_WAIT %1" : "+v"(d), "+v"(e) : "n"(N));
+}
+__device__ __forceinline__ uint32_t lds_byte_address(const uint32_t* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)p;
+}
+template <class C>
+constexpr bool bq_layout_ok() { return C::L % 6 == 0; }       // pairs of limbs, three registers: L/2 pairs per trip, a multiple of 3
+
+template <class C, bool STORE_M>
+__device__ __forceinline__ void cios1q(uint32_t (&res)[C::L], uint64_t (&c)[C::L], const uint32_t (&a)[C::L],
+                                       const uint32_t* __restrict__ bl, uint32_t* __restrict__ ml,
+                                       const uint32_t (&n)[C::L], uint32_t n0inv, const Lane& ln) {
+  constexpr int L = C::L, W = C::W;
+  static_assert(bq_layout_ok<C>(), "cios1q needs L % 6 == 0");
+  uint32_t maskv = C::MASK;
+  asm volatile("" : "+v"(maskv));
+  uint64_t q0, q1, q2;                                         // pair h of a trip lives in q(h % 3)
+  asm volatile("" : "=v"(q0), "=v"(q1), "=v"(q2));             // (defined, contents irrelevant: the first issue overwrites them)
+  const uint32_t base = lds_byte_address(bl);
+  bq_issue<0>(q0, base);
+  bq_issue<8>(q1, base);
+#pragma unroll 1
+  for (int jj = 0;; ++jj) {
+    uint32_t* mp = ml + jj * L;
+    const uint32_t at = base + (uint32_t)(jj * L * 4);
+    auto step = [&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      constexpr int h = r / 2;
+      if constexpr (r % 2 == 0) {
+        // pair h + 2 (pairs L/2 and L/2 + 1 are the first two of the next trip: the limbs are contiguous; in the last trip they are
+        // reads past the multiplier, into the group's own LDS region — harmless, drained after the loop).  ALWAYS issued: every
+        // slot is re-armed right after its last use, on every path, so its register is one unbroken live range
+        if constexpr ((h + 2) % 3 == 0) bq_issue<8 * (h + 2)>(q0, at); else if constexpr ((h + 2) % 3 == 1) bq_issue<8 * (h + 2)>(q1, at); else bq_issue<8 * (h + 2)>(q2, at);
+        // pair h is due: exactly two younger reads are in flight
+        if constexpr (h % 3 == 0) bq_wait<2>(q0); else if constexpr (h % 3 == 1) bq_wait<2>(q1); else bq_wait<2>(q2);
+      }
+      const uint64_t qv = (h % 3 == 0) ? q0 : ((h % 3 == 1) ? q1 : q2);
+      const uint32_t bj = (r & 1) ? (uint32_t)(qv >> 32) : (uint32_t)qv;
+      c[r] += (uint64_t)a[0] * bj;
+      const uint32_t m = bcast0_masked<C::TPI>((uint32_t)c[r] * n0inv, maskv);
+      if (STORE_M) mp[r] = m;                    // every lane of the group writes the same word
+#pragma unroll
+      for (int i = 1; i < L; ++i) c[(r + i) % L] += (uint64_t)a[i] * bj;
+#pragma unroll
+      for (int i = 0; i < L; ++i) c[(r + i) % L] += (uint64_t)m * n[i];
+      c[(r + 1) % L] += c[r] >> W;
+      c[r] = (uint64_t)(pull_next((uint32_t)c[r]) & maskv);
+    };
+    static_for<0, C::STEPS % L>(step);
+    if (jj == C::STEPS / L) break;                            // the ONLY exit: after STEPS steps (R = 2^(W STEPS))
+    static_for<C::STEPS % L, L>(step);
+  }
+  // the reads the last pairs of the last trip asked for are still in flight: let them land before their registers are reused
+  static_assert((C::STEPS % C::L) >= C::L - 2 || (C::STEPS % C::L) == 0, "the exit must lie in the trip's last pair");
+  bq_wait<0>(q0, q1);
+  bq_wait<0>(q2);
+  cios_finish<C>(res, c, ln);
+}
+
+template <class C>
+__device__ __forceinline__ void cios2q(uint32_t (&res)[C::L], uint64_t (&c)[C::L], const uint32_t (&a0)[C::L],
+                                       const uint32_t (&a1)[C::L], const uint32_t* __restrict__ bl0,
+                                       const uint32_t* __restrict__ bl1, const uint32_t (&n)[C::L], uint32_t n0inv,
+                                       const Lane& ln) {
+  constexpr int L = C::L, W = C::W;
+  static_assert(bq_layout_ok<C>(), "cios2q needs L % 6 == 0");
+  uint32_t maskv = C::MASK;
+  asm volatile("" : "+v"(maskv));
+  // two streams: pair h of stream 0 in x(h % 3), of stream 1 in y(h % 3); reads are issued x then y, so when pair h is due the
+  // reads younger than (x_h, y_h) are x_(h+1), y_(h+1), x_(h+2), y_(h+2): four may stay in flight
+  uint64_t x0, x1, x2, y0, y1, y2;
+  asm volatile("" : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(y0), "=v"(y1), "=v"(y2));
+  const uint32_t base0 = lds_byte_address(bl0), base1 = lds_byte_address(bl1);
+  bq_issue<0>(x0, base0); bq_issue<0>(y0, base1);
+  bq_issue<8>(x1, base0); bq_issue<8>(y1, base1);
+#pragma unroll 1
+  for (int jj = 0;; ++jj) {
+    const uint32_t at0 = base0 + (uint32_t)(jj * L * 4), at1 = base1 + (uint32_t)(jj * L * 4);
+    auto step = [&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      constexpr int h = r / 2;
+      if constexpr (r % 2 == 0) {
+        if constexpr ((h + 2) % 3 == 0) { bq_issue<8 * (h + 2)>(x0, at0); bq_issue<8 * (h + 2)>(y0, at1); }
+        else if constexpr ((h + 2) % 3 == 1) { bq_issue<8 * (h + 2)>(x1, at0); bq_issue<8 * (h + 2)>(y1, at1); }
+        else { bq_issue<8 * (h + 2)>(x2, at0); bq_issue<8 * (h + 2)>(y2, at1); }
+        // four younger reads (x, y of pairs h+1, h+2) may stay in flight
+        if constexpr (h % 3 == 0) bq_wait<4>(x0, y0); else if constexpr (h % 3 == 1) bq_wait<4>(x1, y1); else bq_wait<4>(x2, y2);
+      }
+      const uint64_t xv = (h % 3 == 0) ? x0 : ((h % 3 == 1) ? x1 : x2), yv = (h % 3 == 0) ? y0 : ((h % 3 == 1) ? y1 : y2);
+      const uint32_t b0j = (r & 1) ? (uint32_t)(xv >> 32) : (uint32_t)xv, b1j = (r & 1) ? (uint32_t)(yv >> 32) : (uint32_t)yv;
+      c[r] += (uint64_t)a0[0] * b1j;
+      c[r] += (uint64_t)a1[0] * b0j;
+      const uint32_t m = bcast0_masked<C::TPI>((uint32_t)c[r] * n0inv, maskv);
+#pragma unroll
+      for (int i = 1; i < L; ++i) {
+        c[(r + i) % L] += (uint64_t)a0[i] * b1j;
+        c[(r + i) % L] += (uint64_t)a1[i] * b0j;
+      }
+#pragma unroll
+      for (int i = 0; i < L; ++i) c[(r + i) % L] += (uint64_t)m * n[i];
+      c[(r + 1) % L] += c[r] >> W;
+      c[r] = (uint64_t)(pull_next((uint32_t)c[r]) & maskv);
+    };
+    static_for<0, C::STEPS % L>(step);
+    if (jj == C::STEPS / L) break;
+    static_for<C::STEPS % L, L>(step);
+  }
+  bq_wait<0>(x0, y0);
+  bq_wait<0>(x1, y1);
+  bq_wait<0>(x2, y2);
+  cios_finish<C>(res, c, ln);
+}
+
 // (r0, r1) = (a0, a1) * (y0, y1) R^-1 in Z/N^2.  The group's LDS region holds y0 in B0 and y1 in B1; for a squaring
 // (sq: y == a) B1 holds 2 y0 instead, so that pass B is the single stream a1 * (2 a0).
 // Column bound: a pass-B column absorbs per lane block 18 x (2^59.01 + 2^58.01) (squaring: the doubled stream) or
@@ -186,6 +323,10 @@ __device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::
   uint64_t c[L];
 #pragma unroll
   for (int i = 0; i < L; ++i) c[i] = 0;
+#ifdef MPE_BQ
+  if constexpr (bq_layout_ok<C>()) cios1q<C, true>(r0, c, a0, gl + PL::B0, gl + PL::M, n, n0inv, ln);
+  else
+#endif
   cios1<C, true>(r0, c, a0, gl + PL::B0, gl + PL::M, n, n0inv, ln);           // pass A: u, digits -> M
   wave_lds_sync();
   if (half) {                                      // arithmetic modulo N only: the x1 components stay 0
@@ -207,6 +348,19 @@ __device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::
   // u waits in the M region (its digits are consumed) so that pass B does not carry 18 more live registers
 #pragma unroll
   for (int i = 0; i < L; ++i) gl[PL::M + ln.t * L + i] = r0[i];
+#ifdef MPE_BQ
+  if constexpr (bq_layout_ok<C>()) {
+    if (sq) {
+      cios1q<C, false>(r1, c, a1, gl + PL::B1, gl + PL::M, n, n0inv, ln);     // pass B: a1 * (2 a0) - m
+    } else {
+#ifdef MPE_BQ2
+      cios2q<C>(r1, c, a0, a1, gl + PL::B0, gl + PL::B1, n, n0inv, ln);       // pass B: a0 * y1 + a1 * y0 - m
+#else
+      cios2<C>(r1, c, a0, a1, gl + PL::B0, gl + PL::B1, n, n0inv, ln);
+#endif
+    }
+  } else
+#endif
   if (sq) {
     cios1<C, false>(r1, c, a1, gl + PL::B1, gl + PL::M, n, n0inv, ln);        // pass B: a1 * (2 a0) - m
   } else {
@@ -225,6 +379,26 @@ __device__ __forceinline__ void copy_pair_to_lds(uint32_t* gl, const uint32_t* _
   for (int i = 0; i < C::L; ++i) {
     gl[PL::B0 + ln.t + C::TPI * i] = src[ln.t + C::TPI * i];
     gl[PL::B1 + ln.t + C::TPI * i] = src[off1 + ln.t + C::TPI * i];
+  }
+}
+// A window-table row is y0 | y1 = 2K CONTIGUOUS words, and so are B0 | B1 in the group's LDS region: the multiplier of a
+// window multiplication moves as 16-byte global loads (a quarter of the memory instructions of the word-by-word copy, one
+// request per 4 limbs) and 8-byte LDS stores (the group regions are 8-byte aligned: PairLds::STRIDE is even).
+template <class C>
+__device__ __forceinline__ void copy_row_to_lds(uint32_t* gl, const uint32_t* __restrict__ row, const Lane& ln) {
+  using PL = PairLds<C>;
+  static_assert(PL::B0 == 0 && PL::B1 == C::K && (2 * C::K) % 4 == 0 && PL::STRIDE % 2 == 0, "B0 | B1 must be one 8-byte aligned run");
+  constexpr int CHUNKS = 2 * C::K / 4;                       // 16-byte chunks of the row
+  const uint4* __restrict__ r4 = reinterpret_cast<const uint4*>(row);
+  uint2* l2 = reinterpret_cast<uint2*>(gl + PL::B0);
+#pragma unroll
+  for (int i = 0; i < (CHUNKS + C::TPI - 1) / C::TPI; ++i) {
+    const int ch = ln.t + C::TPI * i;
+    if ((i + 1) * C::TPI <= CHUNKS || ch < CHUNKS) {
+      const uint4 v = r4[ch];
+      l2[2 * ch] = make_uint2(v.x, v.y);
+      l2[2 * ch + 1] = make_uint2(v.z, v.w);
+    }
   }
 }
 
@@ -389,14 +563,35 @@ static __global__ void __launch_bounds__(256) key_scatter_kernel(int batch, Rows
   if (mi >= 0) perm[sh[nkeys + mi] + local] = i;
 }
 
+// The sliding decision of pair_modexp_kernel<C, true>, replayed per (wave, trip) for the profiler (mpe_prof_rec.sliding_frac): a
+// wave slides iff its GROUPS exponentiations read the same exponent row and the first window stays above a second exponent.
+static __global__ void pair_slide_audit_kernel(int batch, int grid, int trips, int groups, Rows exps, int exp_words, int wb, int exp2_words,
+                                               const int32_t* __restrict__ perm, uint32_t* __restrict__ ctr) {
+  const int wt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (wt >= grid * trips) return;
+  const int wave = wt % grid, trip = wt / grid, nslots = grid * groups;
+  const uint32_t* first = nullptr;
+  bool same = true;
+  for (int g = 0; g < groups; ++g) {
+    const int inst = trip * nslots + wave * groups + g;
+    const int pos = inst < batch ? inst : batch - 1;
+    const uint32_t* ex = row_of(exps, perm ? perm[pos] : pos);
+    if (g == 0) first = ex; else same = same && ex == first;
+  }
+  if (!same) return;
+  uint32_t val = 0;
+  const int lo = slide_window((UniformWords)(uintptr_t)first, exp_words, exp_words * 32 - 1, wb, val);
+  if (lo < 0 || (exp2_words && lo < 32 * exp2_words)) return;
+  atomicAdd(ctr, 1u);
+}
+
 template <class C, bool SLIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) pair_modexp_kernel(int batch, PairsetView ps, Rows mod_sel, Rows base, Rows exps,
                                                          int exp_words, int wb, Rows base2, Rows exps2, int exp2_words,
                                                          int half, uint32_t* __restrict__ out, uint32_t* __restrict__ tables,
-                                                         const int32_t* __restrict__ perm, int slide,
-                                                         uint32_t* __restrict__ slid_ctr) {
+                                                         const int32_t* __restrict__ perm, int slide) {
   using PL = PairLds<C>;
-  __shared__ uint32_t lds[PL::WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[PL::WORDS];
   const Lane ln = make_lane<C>();
   uint32_t* gl = lds + ln.g * PL::STRIDE;
   constexpr int K2 = 2 * C::K;
@@ -436,9 +631,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         sw_lo = slide_window(exu, exp_words, exp_words * 32 - 1, wb, sw_val);
         if (sw_lo < 0 || (dual && sw_lo < 32 * exp2_words)) sl_rt = false;
       }
-#ifndef MPE_NO_SLIDE_COUNTER                                    // (A/B switch: tools/ab.sh nocounter -DMPE_NO_SLIDE_COUNTER)
-      if (slid_ctr && sl_rt && threadIdx.x == 0) atomicAdd(slid_ctr, 1u);      // profiling only: (wave, trip) pairs on the sliding schedule
-#endif
     }
 
     uint32_t n[C::L];
@@ -486,11 +678,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         sq = true;
       } else if (ph == PP_MUL1) {
         const uint32_t w = sl ? sw_val : exp_window(ex, exp_words, b / wb, wb);
+#ifdef MPE_WIDE_COPY
+        copy_row_to_lds<C>(gl, tab + (size_t)w * K2, ln);
+#else
         copy_pair_to_lds<C>(gl, tab + (size_t)w * K2, ln);
+#endif
       } else if (ph == PP_MUL2) {
         const int wi = b >> 2;
         const uint32_t w = (ex2[wi >> 3] >> ((wi & 7) * 4)) & 15u;
+#ifdef MPE_WIDE_COPY
+        copy_row_to_lds<C>(gl, w ? tab2 + (size_t)w * K2 : tab, ln);
+#else
         copy_pair_to_lds<C>(gl, w ? tab2 + (size_t)w * K2 : tab, ln);
+#endif
       } else {                                                // PP_FINAL: times the plain pair (1, 0)
 #pragma unroll
         for (int i = 0; i < C::L; ++i) {
@@ -686,15 +886,22 @@ int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
   PairsetView v{ps->n_limbs, ps->n0inv, ps->one, ps->r2, ps->tp, ps->kc, ps->count};
   // kind 6: the pair kernel on sliding windows (the executed multiplication count differs: bench.py's accounting)
   prof_begin(ctx, st, half ? 4 : (slide ? 6 : 3), half ? C::BITS : 2 * C::BITS, exp_words, batch, dual ? exp2_words : 0);
-  const int nslots = grid * C::GROUPS;
-  uint32_t* slid_ctr = slide ? prof_counter(ctx, grid * ((batch + nslots - 1) / nslots)) : nullptr;
   if (slide)
     hipLaunchKernelGGL((pair_modexp_kernel<C, true>), dim3(grid), dim3(64), 0, st, batch, v, mod_sel, base, exps, exp_words, wb, base2,
-                       exps2, exp2_words, half, d_out, tabs, perm, slide, slid_ctr);
+                       exps2, exp2_words, half, d_out, tabs, perm, slide);
   else
     hipLaunchKernelGGL((pair_modexp_kernel<C, false>), dim3(grid), dim3(64), 0, st, batch, v, mod_sel, base, exps, exp_words, wb, base2,
-                       exps2, exp2_words, half, d_out, tabs, perm, slide, slid_ctr);
+                       exps2, exp2_words, half, d_out, tabs, perm, slide);
   prof_end(ctx, st);
+  if (slide) {
+    // profiling only: "kind 6" says the launch was ALLOWED to slide; whether a wave does is decided at run time.  A counter
+    // inside the hot kernel perturbs its register allocation (measured: +0.6 % kernel time, profiles/r04/ab_kernel_variants.json),
+    // so the decision is REPLAYED by a one-thread-per-(wave, trip) audit kernel with the kernel's own rule and geometry.
+    const int nslots = grid * C::GROUPS, trips = (batch + nslots - 1) / nslots;
+    if (uint32_t* ctr = prof_counter(ctx, grid * trips))
+      hipLaunchKernelGGL(pair_slide_audit_kernel, dim3(blocks_for(grid * trips, 64)), dim3(64), 0, st, batch, grid, trips, (int)C::GROUPS, exps,
+                         exp_words, wb, dual ? exp2_words : 0, perm, ctr);
+  }
   hipLaunchKernelGGL(pair_finish_kernel<C::K32>, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, mod_sel, ps->mod_words, d_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("pair_modexp_kernel", e); return MPE_E_HIP; }

@@ -59,8 +59,11 @@ def bigint_to_json(x, style=DEFAULT_STYLE):
     return list(bytes.fromhex(h)) if style.bigint == "bytes" else h
 
 
-def bigint_from_json(v, radix=16):
-    """curv BigInt: hex string (radix=16) / byte array / int.  radix=10 reads a digit string as decimal (kzen-paillier)."""
+def bigint_from_json(v, radix=16, strict=False):
+    """curv BigInt: hex string (radix=16) / byte array / int.  radix=10 reads a digit string as decimal (kzen-paillier).
+    A digit-only string is BOTH a decimal and a hexadecimal numeral; curv 0.9 is believed to write hex (even length), which
+    is what radix=16 reads.  strict=True refuses such a string when the two readings differ — for callers that have no
+    cross-check (the Paillier key fields have one: p q = n, `paillier_bigint_readings`) and would rather fail than guess."""
     if isinstance(v, bool):
         raise ValueError("not a big integer")
     if isinstance(v, int):
@@ -70,6 +73,8 @@ def bigint_from_json(v, radix=16):
     s = v.strip()
     if s.startswith("0x"):
         return int(s, 16)
+    if strict and s.isdigit() and int(s, 10) != int(s, 16):
+        raise ValueError(f"ambiguous big integer {s[:20]!r}: digit-only, decimal and hexadecimal readings differ")
     return int(s, radix)
 
 

@@ -198,6 +198,11 @@ def test_primitive_decoders_accept_the_other_known_forms():
     assert W.point_from_json(W.point_to_json(Pt)) == Pt == W.point_from_json({"curve": "secp256k1", "point": unc})
     assert W.point_from_json({"curve": "secp256k1", "point": list(bytes.fromhex(unc))}) == Pt
     assert W.scalar_from_json(W.scalar_to_json(77)) == 77
+    # a digit-only string is a decimal AND a hexadecimal numeral; the default reads curv's hex, strict refuses to guess
+    assert W.bigint_from_json("10") == 16 and W.bigint_from_json("10", radix=10) == 10 and W.bigint_from_json("0a", strict=True) == 10
+    with pytest.raises(ValueError, match="ambiguous"):
+        W.bigint_from_json("1234", strict=True)
+    assert W.bigint_from_json("0", strict=True) == 0
     with pytest.raises(ValueError):
         W.point_from_json({"curve": "secp256k1", "point": "02" + "%064x" % 5})          # x = 5 is not on the curve
 
