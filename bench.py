@@ -40,6 +40,11 @@ import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
+# A signing service keeps several batches in flight on separate streams (c4_stream_1024); the HIP runtime multiplexes streams onto
+# 4 hardware queues by default and streams that share a queue serialize.  8 queues measured +10 % on that section
+# (profiles/r04/stream_sweep.log) and nothing on the single-stream sections.  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -568,7 +573,7 @@ def gg20_config(ctx, E, G, keys, t, n, B, steps, gen, parity_sample=0, threads=N
     return res
 
 
-def c4_stream(E, G, keys, dev_index, batches=8, B=1024, inflight=2, parity_sample=64, threads=None, oracle=True):
+def c4_stream(E, G, keys, dev_index, batches=12, B=1024, inflight=3, parity_sample=64, threads=None, oracle=True, share_hint=False):
     """BASELINE config 4 as a SERVICE sees it: a stream of `batches` successive 1 024-session (t=1, n=3) batches, at most
     `inflight` of them in flight, each on its own host thread with its own context and HIP stream (the §8b threading contract;
     the reference runs its parties concurrently through `Simulation`, state_machine/sign.rs:667-691, and every round through
@@ -584,6 +589,8 @@ def c4_stream(E, G, keys, dev_index, batches=8, B=1024, inflight=2, parity_sampl
     workers = []
     for w in range(inflight):
         ctx = E.Context(dev_index)
+        if share_hint:
+            ctx.set_device_share(inflight)         # the batches share the chip: keep the efficient lane layouts (mpe_ctx_set_device_share)
         workers.append(dict(ctx=ctx, gk=E.Gg20Keys(ctx, t, n, signers, lk["arrays"]), stream=torch.cuda.Stream(device=dev)))
     gen = torch.Generator(device=dev)
     gen.manual_seed(1024)
@@ -625,7 +632,8 @@ def c4_stream(E, G, keys, dev_index, batches=8, B=1024, inflight=2, parity_sampl
             dt = time.perf_counter() - t0
     if errors:
         return {"error": errors}
-    res = {"batches": batches, "sessions_per_batch": B, "in_flight": inflight, "signatures_per_s": batches * B / dt, "seconds": dt,
+    res = {"batches": batches, "sessions_per_batch": B, "in_flight": inflight, "device_share_hint": bool(share_hint), "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+           "signatures_per_s": batches * B / dt, "seconds": dt,
            "ms_per_batch_sustained": dt / batches * 1e3,
            "what": f"{batches} successive {B}-session t=1 n=3 batches, {inflight} in flight on {inflight} host threads x contexts x streams"}
     threads = threads or min(host_cores()[0], 64)
@@ -838,7 +846,10 @@ def main():
     ap.add_argument("--mode", choices=["session", "party"], default="session", help="multi-GPU layout (SURVEY.md 8e A / B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the c2 / c3 / c4 / c5 / Lindell sections")
-    ap.add_argument("--stream-inflight", type=int, default=2, help="c4_stream_1024: batches in flight (host threads x contexts x streams)")
+    ap.add_argument("--stream-inflight", type=int, default=3, help="c4_stream_1024: batches in flight (host threads x contexts x streams)")
+    ap.add_argument("--stream-batches", type=int, default=12)
+    ap.add_argument("--share-hint", action="store_true", help="c4_stream_1024: mpe_ctx_set_device_share(in flight) on every context — keeps the efficient "
+                                                              "lane layouts; measured neutral within the run-to-run noise (profiles/r04/stream_sweep.log)")
     ap.add_argument("--only", default="", help="comma list of config sections to run after the timed region (default: all)")
     ap.add_argument("--no-mode-b", action="store_true", help="N > 1, session mode: skip the party-sharded (config 5 shape) pass after the timed region")
     ap.add_argument("--mode-b-sessions", type=int, default=0, help="sessions per block of that pass (0 = min(8192, --sessions))")
@@ -1187,8 +1198,8 @@ def main():
             section("c3b_bob_65536", lambda: bob_section(ctx, E, keys, F, oracle=not args.no_cpu_baseline))
             section("c4_literal_1024", lambda: gg20_config(ctx, E, G, keys, 1, 3, 1024, 4, gen, parity_sample=0 if args.no_cpu_baseline else 128,
                                                            openssl=True))
-            section("c4_stream_1024", lambda: c4_stream(E, G, keys, local_rank, batches=8, B=1024, inflight=args.stream_inflight,
-                                                        oracle=not args.no_cpu_baseline))
+            section("c4_stream_1024", lambda: c4_stream(E, G, keys, local_rank, batches=args.stream_batches, B=1024, inflight=args.stream_inflight,
+                                                        oracle=not args.no_cpu_baseline, share_hint=args.share_hint))
             section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32,
                                                               openssl=True))
             section("c4_multi_wallet_16384", lambda: [multi_wallet(ctx, E, G, keys, K_, 16384, gen) for K_ in (16, 1024)])

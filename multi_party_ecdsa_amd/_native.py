@@ -94,6 +94,7 @@ def _load():
         "mpe_ctx_create": (ip, [C.POINTER(vp), ip]),
         "mpe_ctx_destroy": (ip, [vp]),
         "mpe_sync": (ip, [vp, vp]),
+        "mpe_ctx_set_device_share": (ip, [vp, ip]),
         "mpe_encoding_default": (None, [C.POINTER(Encoding)]),
         "mpe_ctx_set_encoding": (ip, [vp, C.POINTER(Encoding)]),
         "mpe_ctx_get_encoding": (ip, [vp, C.POINTER(Encoding)]),
@@ -194,7 +195,7 @@ lib = _load()
 
 # every symbol include/mpecdsa_hip.h declares; tests check the library exports all of them
 EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy", "mpe_sync",
-            "mpe_encoding_default", "mpe_ctx_set_encoding", "mpe_ctx_get_encoding",
+            "mpe_encoding_default", "mpe_ctx_set_encoding", "mpe_ctx_get_encoding", "mpe_ctx_set_device_share",
             "mpe_modset_create", "mpe_modset_destroy", "mpe_modset_count", "mpe_modset_bits",
             "mpe_modexp", "mpe_modexp2", "mpe_modmul", "mpe_last_launch_info", "mpe_paillier_create_public",
             "mpe_paillier_create_private", "mpe_paillier_destroy", "mpe_paillier_nkeys", "mpe_paillier_n",

@@ -951,7 +951,7 @@ static int round2(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   if (rc == MPE_OK)      // Paillier::decrypt of the incoming c_b with my key (mta/mod.rs:165), in place
     rc = paillier_decrypt(ctx, K->prv, (int)c.nMB, s->ix.kown_mb, rows(d_in, SUB1, sub1_rv), alpha_full, st);
   gg_trace(st, "decrypt", rc);
-  const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 : 0;      // two waves per SIMD
+  const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 / ctx->device_share : 0;      // two waves per SIMD
   if (c.nMB * 4 <= lanes_fit) GG_LAUNCH(r2a_group_kernel, c.nMB * 4, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
   else GG_LAUNCH(r2a_kernel, c.nMB, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
   GG_LAUNCH(r2b_kernel, c.nPI, d, s->kq, s->gq, s->w, alpha, s->beta, code, Z.l, Z.ped_s1, Z.ped_s2, s->delta_i, s->sigma_i, s->lq, ped,
@@ -971,7 +971,7 @@ static int round3(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)W3 * 4, st);
   GG_LAUNCH(validate_kernel, c.nPI, d, in2, 3, STAT(3), BADR(3));
   GG_LAUNCH(gather_field_kernel, c.SB * 16, in2, d.S, d.B, 8, 16, s->tvec);                  // t_vec
-  const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 : 0;
+  const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 / ctx->device_share : 0;
   const int g3 = 2 * d.S <= 4 ? 4 : (2 * d.S <= 8 ? 8 : 16);
   if (c.nPI * g3 <= lanes_fit) GG_LAUNCH(r3_group_kernel, c.nPI * g3, d, g3, in2, s->dinv, STAT(3), BADR(3));
   else GG_LAUNCH(r3_kernel, c.nPI, d, in2, s->dinv, STAT(3), BADR(3));
@@ -1045,7 +1045,7 @@ static int round6(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   mpe_ctx* ctx = s->ctx; const Dim& d = s->d; const Counts c = counts_of(d);
   const Slab in5 = slab_of(s, d_in, h_off, 5);
   GG_LAUNCH(validate_kernel, c.nPI, d, in5, 6, STAT(6), BADR(6));
-  const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 : 0;
+  const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 / ctx->device_share : 0;
   const int g6 = 3 * d.S <= 8 ? 8 : (3 * d.S <= 16 ? 16 : 32);
   if (c.nPI * g6 <= lanes_fit) GG_LAUNCH(r6_group_kernel, c.nPI * g6, d, g6, in5, s->R, s->tvec, s->K->y, STAT(6), BADR(6));
   else GG_LAUNCH(r6_kernel, c.nPI, d, in5, s->R, s->tvec, s->K->y, STAT(6), BADR(6));

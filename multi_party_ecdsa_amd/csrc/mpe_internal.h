@@ -24,6 +24,8 @@ struct mpe_ctx {
   bool use_fixed_base = true;     // h1/h2 exponentiations through per-statement window tables (mpe_fixedbase.h)
   bool use_sliding = true;        // x^N with the PUBLIC exponent N: items ordered by key, sliding windows per wave (mpe_pairexp.h)
   int wide_div = 2;               // the 2x-lanes layout is used when wide_div * batch <= the resident groups (MPE_WIDE_DIV)
+  int device_share = 1;           // contexts expected to run on this device AT THE SAME TIME (mpe_ctx_set_device_share): the small-batch
+                                  // heuristics below compare a launch with 1/device_share of the chip, not with all of it
   int xwide_div = 16;             // the 4x-lanes (5 limbs per lane) layout: xwide_div * batch <= the resident groups; 0 = off (MPE_XWIDE_DIV)
   bool merge_xn = true;           // round 0: every x^N of the key holders in ONE launch (MPE_NO_MERGE_XN switches it off)
   size_t fb_budget_bytes = 0;     // memory budget of the fixed-base tables of a key object; 0 = a quarter of free HBM (MPE_FB_BUDGET_MB)

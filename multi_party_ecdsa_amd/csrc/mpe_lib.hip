@@ -294,6 +294,11 @@ int mpe_ctx_set_encoding(mpe_ctx* ctx, const mpe_encoding* e) {
   ctx->enc = *e;
   return MPE_OK;
 }
+int mpe_ctx_set_device_share(mpe_ctx* ctx, int contexts) {
+  if (!ctx || contexts < 1 || contexts > 64) return MPE_E_ARG;
+  ctx->device_share = contexts;
+  return MPE_OK;
+}
 int mpe_ctx_get_encoding(const mpe_ctx* ctx, mpe_encoding* out) {
   if (!ctx || !out) return MPE_E_ARG;
   *out = ctx->enc;

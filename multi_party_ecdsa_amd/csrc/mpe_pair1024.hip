@@ -14,7 +14,7 @@ int pair_modexp_1024(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
   // per-modulus constants, about half the latency.
   using Wide = Cfg<1024, MPE_W, MPE_L / 2, 4>;
   static_assert(Wide::K == Cfg1024::K, "the two layouts share the limb arrays");
-  const long resident = (long)ctx->cus * ctx->modexp_waves_per_cu * Cfg1024::GROUPS;
+  const long resident = (long)ctx->cus * ctx->modexp_waves_per_cu * Cfg1024::GROUPS / ctx->device_share;   // this context's share of the chip
   // ... and a really small batch (a sixteenth of the resident groups) over four times the lanes (5 limbs per lane: the same
   // constants, zero-padded).  Measured (profiles/r03/xwide_sweep.json): -6 % per batch at 256 sessions, nothing at 1 024 and
   // +13 % when the threshold lets mid-size launches take it: with 10 MACs per step the quotient-digit dependency chain

@@ -678,7 +678,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         sq = true;
       } else if (ph == PP_MUL1) {
         const uint32_t w = sl ? sw_val : exp_window(ex, exp_words, b / wb, wb);
-#ifdef MPE_WIDE_COPY
+#ifndef MPE_NARROW_COPY                                     // (A/B switch: the word-by-word copy of rounds 1-3)
         copy_row_to_lds<C>(gl, tab + (size_t)w * K2, ln);
 #else
         copy_pair_to_lds<C>(gl, tab + (size_t)w * K2, ln);
@@ -686,7 +686,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       } else if (ph == PP_MUL2) {
         const int wi = b >> 2;
         const uint32_t w = (ex2[wi >> 3] >> ((wi & 7) * 4)) & 15u;
-#ifdef MPE_WIDE_COPY
+#ifndef MPE_NARROW_COPY
         copy_row_to_lds<C>(gl, w ? tab2 + (size_t)w * K2 : tab, ln);
 #else
         copy_pair_to_lds<C>(gl, w ? tab2 + (size_t)w * K2 : tab, ln);

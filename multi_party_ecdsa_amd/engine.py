@@ -33,6 +33,10 @@ class Context:
         if encoding is not None:
             self.set_encoding(encoding)
 
+    def set_device_share(self, contexts):
+        """this many contexts work on the device at the same time (mpe_ctx_set_device_share): keep the efficient lane layouts"""
+        N.check(N.lib.mpe_ctx_set_device_share(self.h, int(contexts)), "mpe_ctx_set_device_share")
+
     def set_encoding(self, encoding):
         e = encoding if isinstance(encoding, N.Encoding) else N.Encoding.from_dict(dict(encoding))
         N.check(N.lib.mpe_ctx_set_encoding(self.h, C.byref(e)), "mpe_ctx_set_encoding")

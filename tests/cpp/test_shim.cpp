@@ -1,0 +1,229 @@
+// The reference's own unit tests of the hot path, re-stated over include/mpecdsa.hpp (the C++ host layer above the C-ABI) and
+// run on the GPU, batched; every value the GPU returns is also compared bit for bit with the CPU oracle (oracle/mpe_oracle.h).
+//
+//   alice_zkp                          src/utilities/mta/range_proofs.rs:614-633
+//   test_mta                           src/utilities/mta/test.rs:6-19            (alpha + beta == a * b)
+//   test_zk_pdl_with_slack             src/utilities/zk_pdl_with_slack/test.rs:12-68
+//   test_zk_pdl_with_slack_soundness   src/utilities/zk_pdl_with_slack/test.rs:70-129   (#[should_panic]: Enc(x + 1) must be refused)
+//
+// Inputs (keys, scalars, every value the reference samples from OsRng) come from a fixture file written by
+// tests/test_cpp_shim_gpu.py — the same seeded fixtures the Python tests use.  Test infrastructure: links the oracle and libgmp;
+// the product library links neither.  Exit status 0 = all passed; prints one line per test.
+#include <gmp.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <string>
+
+#include "mpe_oracle.h"
+#include "mpecdsa.hpp"
+
+using namespace mpecdsa;
+using paillier::DecryptionKeys;
+using paillier::EncryptionKeys;
+using paillier::Paillier;
+using zk_paillier::DLogStatements;
+
+static std::map<std::string, Batch> load_fixture(const char* path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) { std::fprintf(stderr, "cannot open %s\n", path); std::exit(2); }
+  std::map<std::string, Batch> m;
+  for (;;) {
+    uint32_t nl = 0;
+    if (!f.read((char*)&nl, 4)) break;
+    std::string name(nl, ' ');
+    f.read(&name[0], nl);
+    uint32_t words = 0, rows = 0;
+    f.read((char*)&words, 4);
+    f.read((char*)&rows, 4);
+    Batch b(rows, (int)words);
+    f.read((char*)b.w.data(), (std::streamsize)b.w.size() * 4);
+    m[name] = std::move(b);
+  }
+  return m;
+}
+static Index as_index(const Batch& b) { return Index(b.w.begin(), b.w.end()); }
+
+#define REQUIRE(cond)                                                                 \
+  do {                                                                                \
+    if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return false; } \
+  } while (0)
+
+static void to_mpz(mpz_t z, const uint32_t* w, int n) { mpz_import(z, (size_t)n, -1, 4, 0, 0, w); }
+static bool all_ones(const Flags& f) { for (auto x : f) if (x != 1) return false; return !f.empty(); }
+
+struct Fixture {
+  std::map<std::string, Batch> a;
+  const Batch& operator[](const char* k) const {
+    auto it = a.find(k);
+    if (it == a.end()) { std::fprintf(stderr, "fixture lacks %s\n", k); std::exit(2); }
+    return it->second;
+  }
+};
+
+// range_proofs.rs:614-633
+static bool alice_zkp(Context& ctx, const Fixture& F, const EncryptionKeys& ek, const DLogStatements& stm) {
+  const Batch &a = F["a"], &r = F["r_a"], &N = F["N"];
+  const Index ki = as_index(F["key_idx"]), si = as_index(F["st_idx"]);
+  const int B = (int)a.size();
+  Batch a64(B, W_N);                                               // RawPlaintext::from(a): the scalar as a plaintext
+  for (int i = 0; i < B; ++i) std::memcpy(a64.row(i), a.row(i), 32);
+  const Batch cipher = Paillier::encrypt_with_chosen_randomness(ctx, ek, ki, a64, r);
+  Batch want_c(B, W_NN);
+  orc_paillier_encrypt(B, (int)N.size(), N.w.data(), ki.data(), a64.w.data(), r.w.data(), want_c.w.data());
+  REQUIRE(cipher == want_c);
+  const mta::range_proofs::AliceNonces nn{F["one_alpha"], F["one_beta"], F["one_gamma"], F["one_rho"]};
+  const auto proof = mta::range_proofs::AliceProof::generate(ctx, ek, stm, ki, si, a, cipher, r, nn);
+  // the oracle's proof from the same inputs: byte-identical
+  Batch z(B, W_N), e(B, W_SCALAR), s(B, W_N), s1(B, W_S1), s2(B, W_S2);
+  orc_alice_generate(B, (int)N.size(), N.w.data(), (int)F["Nt"].size(), F["Nt"].w.data(), F["h1"].w.data(), F["h2"].w.data(), ki.data(), si.data(),
+                     a.w.data(), cipher.w.data(), r.w.data(), nn.alpha.w.data(), nn.beta.w.data(), nn.gamma.w.data(), nn.rho.w.data(), z.w.data(),
+                     e.w.data(), s.w.data(), s1.w.data(), s2.w.data());
+  REQUIRE(proof.z == z && proof.e == e && proof.s == s && proof.s1 == s1 && proof.s2 == s2);
+  REQUIRE(all_ones(proof.verify(ctx, ek, stm, ki, si, cipher)));              // assert!(alice_proof.verify(&cipher, &ek, &dlog_statement))
+  auto bad = proof;
+  bad.s1.row(1)[0] ^= 1u;                                                     // a tampered proof is `false`, the rest of the batch stays `true`
+  const Flags v = bad.verify(ctx, ek, stm, ki, si, cipher);
+  for (int i = 0; i < B; ++i) REQUIRE(v[i] == (i == 1 ? 0 : 1));
+  return true;
+}
+
+// mta/test.rs:6-19
+static bool test_mta(Context& ctx, const Fixture& F, const EncryptionKeys& ek_alice, const DecryptionKeys& dk_alice, const DLogStatements& stm) {
+  const Batch &alice_input = F["a"], &bob_input = F["b"];
+  const Index ki = as_index(F["key_idx"]);
+  const int B = (int)alice_input.size();
+  const mta::range_proofs::AliceNonces nn{F["al_alpha"], F["al_beta"], F["al_gamma"], F["al_rho"]};
+  const auto m_a = mta::MessageA::a_with_predefined_randomness(ctx, dk_alice, stm, ki, alice_input, F["r_a"], nn);
+  auto [m_b, beta, ok_b] = mta::MessageB::b_with_predefined_randomness(ctx, ek_alice, stm, ki, bob_input, m_a, F["mb_r"], F["beta_tag"], F["nonce_b"],
+                                                                       F["nonce_bt"]);
+  REQUIRE(all_ones(ok_b));                                                    // .unwrap()
+  auto [alpha, alice_share, ok_a] = m_b.verify_proofs_get_alpha(ctx, dk_alice, ki, alice_input);
+  REQUIRE(all_ones(ok_a));                                                    // .expect("wrong dlog or m_b")
+  // let left = alpha.0 + beta; let right = alice_input * bob_input; assert_eq!(left, right);
+  mpz_t q, l, rr, x, y;
+  mpz_inits(q, l, rr, x, y, NULL);
+  mpz_set_str(q, "FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141", 16);
+  bool same = true;
+  for (int i = 0; i < B; ++i) {
+    to_mpz(x, alpha.row(i), W_SCALAR); to_mpz(y, beta.row(i), W_SCALAR);
+    mpz_add(l, x, y); mpz_mod(l, l, q);
+    to_mpz(x, alice_input.row(i), W_SCALAR); to_mpz(y, bob_input.row(i), W_SCALAR);
+    mpz_mul(rr, x, y); mpz_mod(rr, rr, q);
+    same = same && mpz_cmp(l, rr) == 0;
+  }
+  mpz_clears(q, l, rr, x, y, NULL);
+  REQUIRE(same);
+  // ... and every message byte-identical to the oracle's composition of the same calls
+  const Batch& N = F["N"];
+  Batch a64(B, W_N), b64(B, W_N), want_ca(B, W_NN), t1(B, W_NN), t2(B, W_NN), want_cb(B, W_NN);
+  for (int i = 0; i < B; ++i) { std::memcpy(a64.row(i), alice_input.row(i), 32); std::memcpy(b64.row(i), bob_input.row(i), 32); }
+  orc_paillier_encrypt(B, (int)N.size(), N.w.data(), ki.data(), a64.w.data(), F["r_a"].w.data(), want_ca.w.data());
+  REQUIRE(m_a.c == want_ca);
+  orc_paillier_mul(B, (int)N.size(), N.w.data(), ki.data(), want_ca.w.data(), b64.w.data(), t1.w.data());
+  orc_paillier_encrypt(B, (int)N.size(), N.w.data(), ki.data(), F["beta_tag"].w.data(), F["mb_r"].w.data(), t2.w.data());
+  orc_paillier_add(B, (int)N.size(), N.w.data(), ki.data(), t1.w.data(), t2.w.data(), want_cb.w.data());
+  REQUIRE(m_b.c == want_cb);
+  Batch pk(B, W_POINT), R(B, W_POINT), z(B, W_SCALAR);
+  orc_dlog_prove(B, bob_input.w.data(), F["nonce_b"].w.data(), pk.w.data(), R.w.data(), z.w.data());
+  REQUIRE(m_b.b_proof.pk == pk && m_b.b_proof.pk_t_rand_commitment == R && m_b.b_proof.challenge_response == z);
+  Batch share(B, W_N);
+  orc_paillier_decrypt(B, (int)N.size(), F["p"].w.data(), F["q"].w.data(), ki.data(), want_cb.w.data(), share.w.data());
+  REQUIRE(alice_share == share);
+  // Err(InvalidKey): a MessageA whose range proof was tampered with  (mta/mod.rs:119-131)
+  auto forged = m_a;
+  forged.range_proofs.s.row(2 * stm.count() + 1)[3] ^= 1u;
+  auto [m_b2, beta2, ok2] = mta::MessageB::b_with_predefined_randomness(ctx, ek_alice, stm, ki, bob_input, forged, F["mb_r"], F["beta_tag"], F["nonce_b"],
+                                                                        F["nonce_bt"]);
+  (void)m_b2; (void)beta2;
+  for (int i = 0; i < B; ++i) REQUIRE(ok2[i] == (i == 2 ? 0 : 1));
+  return true;
+}
+
+// zk_pdl_with_slack/test.rs:12-68 and :70-129.  `prover`: the key set the proving side computes with — the public key as in the
+// reference's test, or the holder's DecryptionKeys (GG20's phase5_proof_pdl proves about the holder's own ciphertext, party_i.rs:
+// 691-717: x^N through p^2 | q^2); the residues, hence the proof bytes, are the same.  The verifier only ever has `ek`.
+template <class ProverKeys>
+static bool test_zk_pdl_with_slack(Context& ctx, const Fixture& F, const ProverKeys& prover, const EncryptionKeys& ek, const DLogStatements& stm,
+                                   bool soundness) {
+  const Batch &x = F["a"], &randomness = F["r_a"], &N = F["N"];
+  const Index ki = as_index(F["key_idx"]), si = as_index(F["st_idx"]);
+  const int B = (int)x.size();
+  const Batch Q = ec_mul_base(ctx, x);                                        // let Q = Point::generator() * &x;
+  Batch G(B, W_POINT), one(1, W_SCALAR);
+  one.row(0)[0] = 1;
+  const Batch g1 = ec_mul_base(ctx, one);
+  for (int i = 0; i < B; ++i) std::memcpy(G.row(i), g1.row(0), 64);           // G: Point::generator().to_point()
+  Batch m(B, W_N);
+  for (int i = 0; i < B; ++i) {
+    std::memcpy(m.row(i), x.row(i), 32);
+    if (soundness) {                                                          // here we encrypt x + 1 instead of x
+      for (int k = 0; k < W_N; ++k) { if (++m.row(i)[k] != 0u) break; }
+    }
+  }
+  const Batch c = Paillier::encrypt_with_chosen_randomness(ctx, prover, ki, m, randomness);
+  const zk_pdl_with_slack::PDLwSlackStatement statement{c, Q, G, ki, si};
+  const zk_pdl_with_slack::PDLwSlackWitness witness{x, randomness};
+  const zk_pdl_with_slack::PDLwSlackNonces nn{F["pdl_alpha"], F["pdl_beta"], F["pdl_rho"], F["pdl_gamma"]};
+  const auto proof = zk_pdl_with_slack::PDLwSlackProof::prove(ctx, prover, stm, witness, statement, nn);
+  Batch z(B, W_N), u1(B, W_POINT), u2(B, W_NN), u3(B, W_N), s1(B, W_S1), s2(B, W_N), s3(B, W_S2);
+  orc_pdl_prove(B, (int)N.size(), N.w.data(), (int)F["Nt"].size(), F["Nt"].w.data(), F["h1"].w.data(), F["h2"].w.data(), ki.data(), si.data(),
+                c.w.data(), Q.w.data(), G.w.data(), x.w.data(), randomness.w.data(), nn.alpha.w.data(), nn.beta.w.data(), nn.rho.w.data(),
+                nn.gamma.w.data(), z.w.data(), u1.w.data(), u2.w.data(), u3.w.data(), s1.w.data(), s2.w.data(), s3.w.data());
+  REQUIRE(proof.z == z && proof.u1 == u1 && proof.u2 == u2 && proof.u3 == u3 && proof.s1 == s1 && proof.s2 == s2 && proof.s3 == s3);
+  const Flags result = proof.verify(ctx, ek, stm, statement);
+  Flags want(B);
+  orc_pdl_verify(B, (int)N.size(), N.w.data(), (int)F["Nt"].size(), F["Nt"].w.data(), F["h1"].w.data(), F["h2"].w.data(), ki.data(), si.data(),
+                 c.w.data(), Q.w.data(), G.w.data(), z.w.data(), u1.w.data(), u2.w.data(), u3.w.data(), s1.w.data(), s2.w.data(), s3.w.data(), want.data());
+  REQUIRE(result == want);
+  if (!soundness) {
+    REQUIRE(all_ones(result));                                                // assert!(result.is_ok());
+  } else {
+    for (auto v : result) REQUIRE(v == 0);                                    // #[should_panic]: result.is_ok() must not hold for any item
+  }
+  return true;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { std::fprintf(stderr, "usage: test_shim <fixture.bin>\n"); return 2; }
+  Fixture F{load_fixture(argv[1])};
+  int failed = 0;
+  try {
+    Context ctx(0);
+    EncryptionKeys ek(ctx, F["N"]);
+    DecryptionKeys dk(ctx, F["p"], F["q"]);
+    DLogStatements stm(ctx, F["Nt"], F["h1"], F["h2"]);
+    struct { const char* name; bool ok; } results[] = {
+        {"alice_zkp", alice_zkp(ctx, F, ek, stm)},
+        {"test_mta", test_mta(ctx, F, ek, dk, stm)},
+        {"test_zk_pdl_with_slack", test_zk_pdl_with_slack(ctx, F, ek, ek, stm, false)},
+        {"test_zk_pdl_with_slack_soundness", test_zk_pdl_with_slack(ctx, F, ek, ek, stm, true)},
+        {"test_zk_pdl_with_slack_key_holder_proves", test_zk_pdl_with_slack(ctx, F, dk, ek, stm, false)},
+        {"test_zk_pdl_with_slack_soundness_key_holder_proves", test_zk_pdl_with_slack(ctx, F, dk, ek, stm, true)},
+    };
+    for (auto& r : results) {
+      std::printf("test %s ... %s\n", r.name, r.ok ? "ok" : "FAILED");
+      failed += r.ok ? 0 : 1;
+    }
+    // argument errors surface as exceptions carrying mpe_last_error()
+    bool threw = false;
+    try {
+      mpe_encoding bad;
+      mpe_encoding_default(&bad);
+      bad.chain_point = 9;
+      ctx.set_encoding(bad);
+    } catch (const Error& e) {
+      threw = e.code == MPE_E_ARG && std::string(e.what()).find("permutation") != std::string::npos;
+    }
+    std::printf("test error_mapping ... %s\n", threw ? "ok" : "FAILED");
+    failed += threw ? 0 : 1;
+  } catch (const std::exception& e) {
+    std::printf("EXCEPTION %s\n", e.what());
+    return 1;
+  }
+  std::printf("%s\n", failed ? "SOME TESTS FAILED" : "all tests passed");
+  return failed ? 1 : 0;
+}

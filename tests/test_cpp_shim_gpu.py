@@ -1,0 +1,27 @@
+"""-m gpu: the reference's own unit tests of the hot path — `alice_zkp` (mta/range_proofs.rs:614-633), `test_mta`
+(mta/test.rs:6-19: alpha + beta == a b), `test_zk_pdl_with_slack` and its `#[should_panic]` soundness twin
+(zk_pdl_with_slack/test.rs:12-129) — re-stated in C++ over include/mpecdsa.hpp (the host layer a maintainer would write over the
+C-ABI, with the reference's type and method names) and run on the GPU.  No Python, no torch in that process: a compiled host of
+the C-ABI.  Every value is also compared bit for bit with the CPU oracle inside the program."""
+import os
+import subprocess
+
+import pytest
+
+import cpp_shim
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_unit_tests_over_the_cpp_host_layer(tmp_path, keys):
+    exe = cpp_shim.build(str(tmp_path))
+    fx = os.path.join(str(tmp_path), "fixture.bin")
+    cpp_shim.write_fixture(fx, keys)
+    p = subprocess.run([exe, fx], capture_output=True, text=True, timeout=600)
+    print(p.stdout)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-2000:])
+    for name in ("alice_zkp", "test_mta", "test_zk_pdl_with_slack", "test_zk_pdl_with_slack_soundness", "error_mapping"):
+        assert f"test {name} ... ok" in p.stdout, name
+    assert "all tests passed" in p.stdout
+    maps_check = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libmpecdsa_hip.so" in maps_check
