@@ -41,9 +41,11 @@ import time
 from concurrent.futures import ThreadPoolExecutor
 
 # A signing service keeps several batches in flight on separate streams (c4_stream_1024); the HIP runtime multiplexes streams onto
-# 4 hardware queues by default and streams that share a queue serialize.  8 queues measured +10 % on that section
-# (profiles/r04/stream_sweep.log) and nothing on the single-stream sections.  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# 4 hardware queues by default and streams that share a queue serialize.  Measured on that section, 48 batches of 1 024 sessions
+# (profiles/r04/stream_sweep{2,3,5}.log): 4 queues 9.3 k signatures/s, 8 queues 11.1 k, 16 queues 12.6 k (3 in flight) .. 14.1 k (10 in
+# flight); 20 or more queues abort inside the runtime (HSA_STATUS_ERROR_OUT_OF_RESOURCES).  Nothing changes for the single-stream
+# sections.  Must be set before the runtime initialises; ranks that SHARE a device (--share-device) get 2 each (respawn_under_torchrun).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 import torch
@@ -830,6 +832,8 @@ def respawn_under_torchrun(n, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
+    if "--share-device" in argv:
+        env["GPU_MAX_HW_QUEUES"] = "2"            # n processes on ONE device: the queues of all of them add up (the runtime aborts beyond ~16)
     return subprocess.call(cmd, env=env)
 
 
@@ -846,8 +850,9 @@ def main():
     ap.add_argument("--mode", choices=["session", "party"], default="session", help="multi-GPU layout (SURVEY.md 8e A / B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the c2 / c3 / c4 / c5 / Lindell sections")
-    ap.add_argument("--stream-inflight", type=int, default=3, help="c4_stream_1024: batches in flight (host threads x contexts x streams)")
-    ap.add_argument("--stream-batches", type=int, default=12)
+    ap.add_argument("--stream-inflight", default="3,2,8", help="c4_stream_1024: batches in flight (host threads x contexts x streams); a comma "
+                                                               "list: the first depth is the section's headline, the others are reported under other_depths")
+    ap.add_argument("--stream-batches", type=int, default=24)
     ap.add_argument("--share-hint", action="store_true", help="c4_stream_1024: mpe_ctx_set_device_share(in flight) on every context — keeps the efficient "
                                                               "lane layouts; measured neutral within the run-to-run noise (profiles/r04/stream_sweep.log)")
     ap.add_argument("--only", default="", help="comma list of config sections to run after the timed region (default: all)")
@@ -1198,8 +1203,15 @@ def main():
             section("c3b_bob_65536", lambda: bob_section(ctx, E, keys, F, oracle=not args.no_cpu_baseline))
             section("c4_literal_1024", lambda: gg20_config(ctx, E, G, keys, 1, 3, 1024, 4, gen, parity_sample=0 if args.no_cpu_baseline else 128,
                                                            openssl=True))
-            section("c4_stream_1024", lambda: c4_stream(E, G, keys, local_rank, batches=args.stream_batches, B=1024, inflight=args.stream_inflight,
-                                                        oracle=not args.no_cpu_baseline, share_hint=args.share_hint))
+            def stream_section():
+                # the primary depth with the full checks, then the other depths of the list (fewer oracle sessions per batch)
+                depths = [int(x) for x in str(args.stream_inflight).split(",") if x]
+                main_ = c4_stream(E, G, keys, local_rank, batches=args.stream_batches, B=1024, inflight=depths[0], oracle=not args.no_cpu_baseline,
+                                  share_hint=args.share_hint, parity_sample=32)
+                main_["other_depths"] = {str(k_): c4_stream(E, G, keys, local_rank, batches=args.stream_batches, B=1024, inflight=k_,
+                                                            oracle=not args.no_cpu_baseline, share_hint=args.share_hint, parity_sample=8) for k_ in depths[1:]}
+                return main_
+            section("c4_stream_1024", stream_section)
             section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32,
                                                               openssl=True))
             section("c4_multi_wallet_16384", lambda: [multi_wallet(ctx, E, G, keys, K_, 16384, gen) for K_ in (16, 1024)])

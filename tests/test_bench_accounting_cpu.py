@@ -41,12 +41,31 @@ def test_mac_models():
     assert abs(B.LIMB_INFLATION - 4 * 72 * 71 / (2 * B.mac(64))) < 1e-12 and 1.23 < B.LIMB_INFLATION < 1.24
 
 
+@pytest.fixture
+def sliding_priced_on(request):
+    """round 4 prices the sliding schedule on the signers' own moduli N (exact window counts); earlier lines on 32 seeded exponents"""
+    def set_for(rnd):
+        B._SLIDING.clear()
+        if rnd >= "r04":
+            import sys
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import fixtures as F
+            B.SLIDING_EXPONENTS = [F.load_keys()[i].N for i in (0, 1)]
+        else:
+            B.SLIDING_EXPONENTS = None
+    yield set_for
+    B._SLIDING.clear()
+    B.SLIDING_EXPONENTS = None
+
+
 @pytest.mark.parametrize("rnd,name", [("r02", "bench_gg20_default.json"), ("r02", "bench_gg20_driver_flags.json"),
-                                      ("r03", "bench_gg20_default.json"), ("r03", "bench_gg20_driver_flags.json")])
-def test_committed_bench_lines_follow_the_models(rnd, name):
+                                      ("r03", "bench_gg20_default.json"), ("r03", "bench_gg20_driver_flags.json"),
+                                      ("r04", "bench_gg20_default.json"), ("r04", "bench_gg20_driver_flags.json")])
+def test_committed_bench_lines_follow_the_models(rnd, name, sliding_priced_on):
     path = os.path.join(ROOT, "profiles", rnd, name)
     if not os.path.exists(path):
         pytest.skip("no committed bench line")
+    sliding_priced_on(rnd)
     b = json.loads([ln for ln in open(path).read().strip().splitlines() if ln.startswith("{")][-1])
     sliding = rnd != "r02"
     rf, cfg = b["roofline"], b["config"]
@@ -81,12 +100,19 @@ def test_committed_bench_lines_follow_the_models(rnd, name):
     cb = b["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and b["parity_vs_oracle_on_sample"] is True
     c = b["configs"]
+    if rnd >= "r04":
+        # round 4: the profiler's own count of the waves that slid, the 1 024-session parity sample, the stream section
+        assert rf["sliding_share_of_waves"] == 1.0 and b["parity_sample"] >= 1024
+        st = c["c4_stream_1024"]
+        assert st["all_sessions_signed"] and st["openssl_verified"] == st["openssl_of"] == st["batches"] * 1024 and st["parity_vs_oracle_on_sample"] is True
+        assert abs(st["signatures_per_s"] - st["batches"] * 1024 / st["seconds"]) < 1e-6 * st["signatures_per_s"]
+        assert rf["traffic_source"] is None or rf["traffic_source"]["measured_in_this_run"] is False
     assert c["c2_paillier_65536"]["roundtrip_ok"] and c["c2_paillier_65536"]["holder_equals_public_ciphertext"]
     assert c["c3_ec_pdl_262144"]["accept_rate"] == 1.0 and c["c3_ec_pdl_262144"]["corrupted_1pct_all_rejected"]
     assert c["c4_literal_1024"]["all_sessions_signed"] and c["c5_share_t2n5_8192"]["all_sessions_signed"]
 
 
-@pytest.mark.parametrize("rnd", ["r02", "r03"])
+@pytest.mark.parametrize("rnd", ["r02", "r03", "r04"])
 def test_rocprof_artifacts_agree_with_the_bench_line(rnd):
     """profiles/<round>: the rocprofv3 --stats average of the dominant kernel vs the HIP-event average in the bench line (different
     boxes: within 3 %), and the PMC traffic figure the bench line quotes"""
@@ -100,7 +126,8 @@ def test_rocprof_artifacts_agree_with_the_bench_line(rnd):
     b = json.loads([ln for ln in open(os.path.join(d, "bench_gg20_default.json")).read().strip().splitlines() if ln.startswith("{")][-1])
     assert abs(float(dom["AverageNs"]) / 1e6 - b["roofline"]["avg_kernel_ms"]) / b["roofline"]["avg_kernel_ms"] < 0.03
     assert 0.6 < float(dom["Percentage"]) / 100 < 0.72
-    pmc = json.load(open(os.path.join(d, "pmc_traffic.json")))
+    src = (b["roofline"].get("traffic_source") or {}).get("file")          # round 4: the line names the PMC pass it quotes
+    pmc = json.load(open(os.path.join(ROOT, src) if src else os.path.join(d, "pmc_traffic.json")))
     k = [v for n, v in pmc["kernels"].items() if "pair_modexp_kernel" in n and "2048, 29, 18, 4" in n][0]
     assert abs(b["roofline"]["traffic"] - k["hbm_bytes_per_launch"]) / k["hbm_bytes_per_launch"] < 0.01
     assert pmc["sessions"] == b["config"]["sessions_per_gpu"]

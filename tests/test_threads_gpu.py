@@ -30,7 +30,7 @@ def test_concurrent_contexts_on_distinct_streams(keys):
     from multi_party_ecdsa_amd import engine as E
     from test_gg20_gpu import GpuParty
     jobs = [dict(kind="sign", t=1, n=3, signers=[0, 1], B=24, seed="thr-a", shift=0),
-            dict(kind="sign", t=2, n=5, signers=[0, 2, 4], B=6, seed="thr-b", shift=5),
+            dict(kind="sign", t=2, n=5, signers=[0, 2, 4], B=6, seed="thr-b", shift=5, share=4),      # mpe_ctx_set_device_share: other lane layouts, same bytes
             dict(kind="rounds", t=1, n=3, signers=[1, 2], B=5, seed="thr-c", shift=9),
             dict(kind="paillier", B=96, seed="thr-d")]
     want = []
@@ -57,6 +57,8 @@ def test_concurrent_contexts_on_distinct_streams(keys):
         j = jobs[ix]
         try:
             ctx = E.Context(0)
+            if j.get("share"):
+                ctx.set_device_share(j["share"])
             with torch.cuda.stream(torch.cuda.Stream(device=ctx.device)):          # torch's current stream is per thread
                 assert ctx.stream().value != 0
                 start.wait(timeout=120)

@@ -28,11 +28,16 @@ done
 
 # the N>1 launch as the driver starts it, on the one GPU a test box has: bench.py spawns its own ranks, every rank on cuda:0,
 # the round slabs through a gloo all-gather (a functional run of the code path; the ranks time-share the device)
+# (round 4: the session-mode line carries the all-gather layout self-test, a per-rank parity sample against the oracle and the
+#  party-sharded pass at BASELINE config 5's shape — mode_b{} — so it runs WITH the oracle legs)
 for mode in session party; do
-  timeout 600 $BENCH --gpus 2 --share-device --mode $mode --sessions 16384 --steps 1 --warmup 1 --no-cpu-baseline --no-configs \
+  timeout 900 $BENCH --gpus 2 --share-device --mode $mode --sessions 16384 --mode-b-sessions 2048 --steps 1 --warmup 1 --no-configs \
     > "$OUT/bench_2ranks_shared_device_$mode.json" 2> "$OUT/bench_2ranks_shared_device_$mode.err"
   tail -c 200 "$OUT/bench_2ranks_shared_device_$mode.json"; echo
 done
+MPE_FB_WINDOW_BITS=10 timeout 900 $BENCH --gpus 8 --share-device --sessions 512 --mode-b-sessions 256 --steps 1 --warmup 1 --no-configs \
+  > "$OUT/bench_8ranks_shared_device_session.json" 2> "$OUT/bench_8ranks_shared_device_session.err"
+tail -c 200 "$OUT/bench_8ranks_shared_device_session.json"; echo
 
 rm -rf /tmp/p_stats /tmp/p_1k
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o s -- $BENCH $LIGHT --warmup 1 \

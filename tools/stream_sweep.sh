@@ -1,16 +1,19 @@
 #!/bin/bash
-# On the GPU box: bench.py's c4_stream_1024 section (a stream of 1 024-session batches, several in flight on separate host threads /
-# contexts / streams) against (a) the number of batches in flight, (b) the device-share hint of the contexts (mpe_ctx_set_device_share:
-# keep the efficient lane layouts because other batches fill the idle lanes), (c) the number of hardware queues the HIP runtime uses.
-# One line per run; full JSON under gpurun_out/stream/.
+# On the GPU box: bench.py's c4_stream_1024 section (a stream of 1 024-session GG20 batches, several in flight on separate host threads /
+# contexts / streams) against
+#   QUEUES  the hardware queues the HIP runtime may use (GPU_MAX_HW_QUEUES; the runtime's default is 4, 20+ abort in the runtime)
+#   DEPTHS  batches in flight
+#   HINTS   nohint | hint  (mpe_ctx_set_device_share on every context)
+#   BATCHES batches per run,  REPS repetitions
+# e.g.  QUEUES="4 8 16" DEPTHS="2 3 8" tools/stream_sweep.sh      One line per run; full JSON lines under gpurun_out/stream/.
+# (profiles/r04/stream_sweep*.log are runs of this script and its earlier forms; each log's first lines name the settings.)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/stream
-for hwq in 4 8; do
-for hint in hint nohint; do
-for k in 2 3 4; do
+echo "# QUEUES=${QUEUES:=16} DEPTHS=${DEPTHS:=2 3 8} HINTS=${HINTS:=nohint} BATCHES=${BATCHES:=48} REPS=${REPS:=1}"
+for hwq in $QUEUES; do for hint in $HINTS; do for k in $DEPTHS; do for rep in $(seq 1 $REPS); do
   flag=""; [ $hint = hint ] && flag="--share-hint"
-  name=q${hwq}_${hint}_k$k
-  GPU_MAX_HW_QUEUES=$hwq timeout 200 python bench.py --sessions 1024 --steps 1 --warmup 0 --no-cpu-baseline --only c4_stream --stream-batches ${BATCHES:-24} \
+  name=q${hwq}_${hint}_k${k}_r$rep
+  GPU_MAX_HW_QUEUES=$hwq timeout 300 python bench.py --sessions 1024 --steps 1 --warmup 0 --no-cpu-baseline --only c4_stream --stream-batches $BATCHES \
       --stream-inflight $k $flag > gpurun_out/stream/$name.json 2> gpurun_out/stream/$name.err
   python3 - $name <<'PY'
 import json, sys
@@ -18,8 +21,8 @@ n = sys.argv[1]
 try:
     d = json.loads([l for l in open(f"gpurun_out/stream/{n}.json") if l.startswith("{")][-1])
     c = d["configs"]["c4_stream_1024"]
-    print(f"{n:18s} {c['signatures_per_s']:9.1f} sig/s  {c['ms_per_batch_sustained']:7.2f} ms/batch  signed {c['all_sessions_signed']} ossl {c['openssl_verified']}/{c['openssl_of']}   (single 1024 batch, same process: {d['value']:.0f} sig/s)")
+    print(f"{n:22s} {c['signatures_per_s']:9.1f} sig/s  {c['ms_per_batch_sustained']:7.2f} ms/batch  signed {c['all_sessions_signed']} ossl {c['openssl_verified']}/{c['openssl_of']}")
 except Exception as e:
-    print(n, "FAILED", e)
+    print(n, "FAILED", repr(e), open(f"gpurun_out/stream/{n}.err").read()[-200:].replace("\n", " "))
 PY
-done; done; done
+done; done; done; done
