@@ -40,13 +40,8 @@ import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
-# A signing service keeps several batches in flight on separate streams (c4_stream_1024); the HIP runtime multiplexes streams onto
-# 4 hardware queues by default and streams that share a queue serialize.  Measured on that section, 48 batches of 1 024 sessions
-# (profiles/r04/stream_sweep{2,3,5}.log): 4 queues 9.3 k signatures/s, 8 queues 11.1 k, 16 queues 12.6 k (3 in flight) .. 14.1 k (10 in
-# flight); 20 or more queues abort inside the runtime (HSA_STATUS_ERROR_OUT_OF_RESOURCES).  Nothing changes for the single-stream
-# sections.  Must be set before the runtime initialises; ranks that SHARE a device (--share-device) get 2 each (respawn_under_torchrun).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
+# (c4_stream_1024 runs in a child process with GPU_MAX_HW_QUEUES=16 — see stream_section(): the variable must be set before the HIP
+#  runtime initialises, and the headline path keeps the runtime's defaults)
 import numpy as np
 import torch
 
@@ -832,8 +827,6 @@ def respawn_under_torchrun(n, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    if "--share-device" in argv:
-        env["GPU_MAX_HW_QUEUES"] = "2"            # n processes on ONE device: the queues of all of them add up (the runtime aborts beyond ~16)
     return subprocess.call(cmd, env=env)
 
 
@@ -853,6 +846,9 @@ def main():
     ap.add_argument("--stream-inflight", default="3,2,8", help="c4_stream_1024: batches in flight (host threads x contexts x streams); a comma "
                                                                "list: the first depth is the section's headline, the others are reported under other_depths")
     ap.add_argument("--stream-batches", type=int, default=24)
+    ap.add_argument("--stream-hw-queues", type=int, default=16, help="GPU_MAX_HW_QUEUES of the child process that runs c4_stream_1024")
+    ap.add_argument("--stream-child", action="store_true", help="(internal) run only the c4_stream_1024 depths and print their JSON")
+    ap.add_argument("--device", type=int, default=0, help="(internal, --stream-child) device index")
     ap.add_argument("--share-hint", action="store_true", help="c4_stream_1024: mpe_ctx_set_device_share(in flight) on every context — keeps the efficient "
                                                               "lane layouts; measured neutral within the run-to-run noise (profiles/r04/stream_sweep.log)")
     ap.add_argument("--only", default="", help="comma list of config sections to run after the timed region (default: all)")
@@ -863,6 +859,20 @@ def main():
                     help="all ranks use cuda:0 and talk through gloo (host-staged): exercises the N>1 code path on a 1-GPU box; "
                          "the ranks time-share one GPU, so `value` says nothing about a node")
     args = ap.parse_args()
+
+    if args.stream_child:
+        import fixtures as F
+        import gg20_fixture as G
+        from multi_party_ecdsa_amd import engine as E
+        keys = F.load_keys()
+        depths = [int(x) for x in str(args.stream_inflight).split(",") if x]
+        # the first depth with the full checks, then the others (fewer oracle sessions per batch)
+        main_ = c4_stream(E, G, keys, args.device, batches=args.stream_batches, B=1024, inflight=depths[0], oracle=not args.no_cpu_baseline,
+                          share_hint=args.share_hint, parity_sample=32)
+        main_["other_depths"] = {str(k_): c4_stream(E, G, keys, args.device, batches=args.stream_batches, B=1024, inflight=k_,
+                                                    oracle=not args.no_cpu_baseline, share_hint=args.share_hint, parity_sample=8) for k_ in depths[1:]}
+        print(json.dumps(main_))
+        return
 
     if "RANK" not in os.environ and args.gpus > 1:
         # no launcher around us: become it (N ranks, one per GPU, RCCL over xGMI)
@@ -1204,13 +1214,26 @@ def main():
             section("c4_literal_1024", lambda: gg20_config(ctx, E, G, keys, 1, 3, 1024, 4, gen, parity_sample=0 if args.no_cpu_baseline else 128,
                                                            openssl=True))
             def stream_section():
-                # the primary depth with the full checks, then the other depths of the list (fewer oracle sessions per batch)
-                depths = [int(x) for x in str(args.stream_inflight).split(",") if x]
-                main_ = c4_stream(E, G, keys, local_rank, batches=args.stream_batches, B=1024, inflight=depths[0], oracle=not args.no_cpu_baseline,
-                                  share_hint=args.share_hint, parity_sample=32)
-                main_["other_depths"] = {str(k_): c4_stream(E, G, keys, local_rank, batches=args.stream_batches, B=1024, inflight=k_,
-                                                            oracle=not args.no_cpu_baseline, share_hint=args.share_hint, parity_sample=8) for k_ in depths[1:]}
-                return main_
+                # A signing service keeps several batches in flight on separate streams; the HIP runtime multiplexes the streams of a
+                # process onto 4 hardware queues by default and streams that share a queue serialize.  Measured on this section, 48
+                # batches per run (profiles/r04/stream_sweep*.log): 4 queues 9.3 k signatures/s, 8 queues 11.1 k, 16 queues 12.6 k (3 in
+                # flight) .. 14.1 k (10 in flight); 20 or more abort inside the runtime (HSA_STATUS_ERROR_OUT_OF_RESOURCES).  The variable
+                # must be set before the runtime initialises, so the section runs in a CHILD process (this one keeps the defaults; a
+                # failure of the child is reported here and cannot take the line down).
+                import subprocess
+                env = dict(os.environ)
+                env["GPU_MAX_HW_QUEUES"] = str(args.stream_hw_queues)
+                cmd = [sys.executable, os.path.abspath(__file__), "--stream-child", "--stream-inflight", str(args.stream_inflight), "--stream-batches",
+                       str(args.stream_batches), "--device", str(local_rank)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + \
+                      (["--share-hint"] if args.share_hint else [])
+                try:
+                    p_ = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+                    lines_ = [ln for ln in p_.stdout.splitlines() if ln.startswith("{")]
+                    if p_.returncode != 0 or not lines_:
+                        return {"error": f"child exited {p_.returncode}", "stderr_tail": p_.stderr[-400:]}
+                    return json.loads(lines_[-1])
+                except subprocess.TimeoutExpired:
+                    return {"error": "child timed out"}
             section("c4_stream_1024", stream_section)
             section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32,
                                                               openssl=True))

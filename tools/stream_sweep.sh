@@ -13,14 +13,14 @@ echo "# QUEUES=${QUEUES:=16} DEPTHS=${DEPTHS:=2 3 8} HINTS=${HINTS:=nohint} BATC
 for hwq in $QUEUES; do for hint in $HINTS; do for k in $DEPTHS; do for rep in $(seq 1 $REPS); do
   flag=""; [ $hint = hint ] && flag="--share-hint"
   name=q${hwq}_${hint}_k${k}_r$rep
-  GPU_MAX_HW_QUEUES=$hwq timeout 300 python bench.py --sessions 1024 --steps 1 --warmup 0 --no-cpu-baseline --only c4_stream --stream-batches $BATCHES \
+  GPU_MAX_HW_QUEUES=$hwq timeout 300 python bench.py --stream-child --no-cpu-baseline --stream-batches $BATCHES \
       --stream-inflight $k $flag > gpurun_out/stream/$name.json 2> gpurun_out/stream/$name.err
   python3 - $name <<'PY'
 import json, sys
 n = sys.argv[1]
 try:
     d = json.loads([l for l in open(f"gpurun_out/stream/{n}.json") if l.startswith("{")][-1])
-    c = d["configs"]["c4_stream_1024"]
+    c = d
     print(f"{n:22s} {c['signatures_per_s']:9.1f} sig/s  {c['ms_per_batch_sustained']:7.2f} ms/batch  signed {c['all_sessions_signed']} ossl {c['openssl_verified']}/{c['openssl_of']}")
 except Exception as e:
     print(n, "FAILED", repr(e), open(f"gpurun_out/stream/{n}.err").read()[-200:].replace("\n", " "))
