@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(64) fb_modexp_kernel(int batch, ModsetView ms,
                                                        const uint32_t* __restrict__ tab, int wb, Rows exps, int exp_words,
                                                        uint32_t* __restrict__ out) {
   const int FB_WB = wb, FB_TE = 1 << wb, FB_MAX_WINDOWS = fb_windows(wb);
-  __shared__ uint32_t lds[C::LDS_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[C::LDS_WORDS];
   const Lane ln = make_lane<C>();
   uint32_t* gl = lds + ln.g * C::STRIDE;
   const int slot = blockIdx.x * C::GROUPS + ln.g;
@@ -125,32 +125,58 @@ __global__ void __launch_bounds__(64) fb_modexp_kernel(int batch, ModsetView ms,
     uint32_t n[C::L];
     load_owner<C>(n, ms.n_limbs + (size_t)st * C::K, ln);
     const uint32_t n0inv = ms.n0inv[st];
-    uint32_t cur[C::L], nx[C::L];
+    uint32_t cur[C::L];
     load_owner<C>(cur, T + (size_t)fb_digit(ex, exp_words, 0, wb) * C::K, ln);
-    // steps 1..nwin-1: cur <- cur * T[i][digit_i]; step nwin: cur <- cur * 1.  The next table row is fetched
-    // (coalesced within the group) before the multiplication that hides its latency.
-    auto fetch = [&](int i) {
-      const uint32_t* src = T + ((size_t)i * FB_TE + fb_digit(ex, exp_words, i, wb)) * C::K;
+    // steps 1..nwin-1: cur <- cur * T[i][digit_i]; step nwin: cur <- cur * 1.  Two table rows are in flight while a third is
+    // multiplied (rows s+1 and s+2 travel during step s): one Montgomery product is ~1.4 us of VALU work, an HBM/L2 miss of a
+    // table row is about the same, so one row ahead left the tail of the fetch exposed (r04 A/B: -1.4 % on this kernel).
+    // A row is K contiguous words (288 B at K = 72) and so is the multiplier in the group's LDS region: it moves as 16-byte loads
+    // — the group's four lanes cover one 64-byte sector per instruction, each sector requested once (a word-by-word fetch asks
+    // for every sector four times, 18 instructions per lane instead of 5: -3.4 %) — and 8-byte LDS stores (C::STRIDE is even).
+    static_assert(C::K % 4 == 0 && C::STRIDE % 2 == 0, "wide row fetch needs 16-byte chunks and 8-byte aligned group regions");
+    constexpr int CHUNKS = C::K / 4, PER = (CHUNKS + C::TPI - 1) / C::TPI;
+    uint4 odd[PER], even[PER];                       // the rows of the next odd and the next even step
+    auto fetch = [&](uint4 (&dst)[PER], int i) {
+      const uint4* src = reinterpret_cast<const uint4*>(T + ((size_t)i * FB_TE + fb_digit(ex, exp_words, i, wb)) * C::K);
 #pragma unroll
-      for (int k = 0; k < C::L; ++k) nx[k] = src[ln.t + C::TPI * k];
-    };
-    if (nwin > 1) fetch(1);
-#pragma unroll 1
-    for (int s = 1; s <= nwin; ++s) {
-      if (s < nwin) {
-#pragma unroll
-        for (int k = 0; k < C::L; ++k) gl[ln.t + C::TPI * k] = nx[k];
-        if (s + 1 < nwin) fetch(s + 1);
-      } else {
-#pragma unroll
-        for (int k = 0; k < C::L; ++k) gl[ln.t * C::L + k] = (ln.t == 0 && k == 0) ? 1u : 0u;
+      for (int k = 0; k < PER; ++k) {
+        const int ch = ln.t + C::TPI * k;
+        if ((k + 1) * C::TPI <= CHUNKS || ch < CHUNKS) dst[k] = src[ch];
       }
+    };
+    auto put = [&](const uint4 (&row)[PER]) {
+      uint2* l2 = reinterpret_cast<uint2*>(gl);
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int ch = ln.t + C::TPI * k;
+        if ((k + 1) * C::TPI <= CHUNKS || ch < CHUNKS) {
+          l2[2 * ch] = make_uint2(row[k].x, row[k].y);
+          l2[2 * ch + 1] = make_uint2(row[k].z, row[k].w);
+        }
+      }
+    };
+    auto put_one = [&]() {
+#pragma unroll
+      for (int k = 0; k < C::L; ++k) gl[ln.t * C::L + k] = (ln.t == 0 && k == 0) ? 1u : 0u;
+    };
+    auto mul_by_lds = [&]() {
       wave_lds_sync();
       uint32_t r[C::L];
       montmul<C>(r, cur, gl, n, n0inv, ln);
       wave_lds_sync();
 #pragma unroll
       for (int k = 0; k < C::L; ++k) cur[k] = r[k];
+    };
+    if (nwin > 1) fetch(odd, 1);
+    if (nwin > 2) fetch(even, 2);
+#pragma unroll 1
+    for (int s = 1; s <= nwin; s += 2) {
+      if (s < nwin) { put(odd); if (s + 2 < nwin) fetch(odd, s + 2); } else put_one();
+      mul_by_lds();
+      if (s + 1 <= nwin) {
+        if (s + 1 < nwin) { put(even); if (s + 3 < nwin) fetch(even, s + 3); } else put_one();
+        mul_by_lds();
+      }
     }
     reduce_once<C>(cur, n, ln);
     store_limbs_as_words<C>(out + (size_t)idx * C::K32, gl, cur, active, ln);
