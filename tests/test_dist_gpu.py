@@ -34,17 +34,20 @@ def _u32(t):
 
 
 # ---- Mode B, GPU engines, one process per rank ---------------------------------------------------------------------------
-def _worker(rank, world, port, t, n, signers, B, placement, q):
+def _worker(rank, world, port, t, n, signers, B, placement, q, backend="gloo", runs=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # this pool's driver only supports dmabuf IPC
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)                                   # RCCL: one device per rank
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from multi_party_ecdsa_amd import dist as D
         from multi_party_ecdsa_amd import engine as E
-        ctx = E.Context(0)
+        ctx = E.Context(rank if backend == "nccl" else 0)
         keys = F.load_keys()
         lk = G.make_local_keys(keys, t, n, signers)
         S = len(signers)
@@ -78,26 +81,39 @@ def _worker(rank, world, port, t, n, signers, B, placement, q):
             def result(self):
                 return self.sess.result()
 
+            def rearm(self):
+                self.sess.rearm(self.keep)      # the same sampled values again: a test of the buffers, never a deployment pattern
+
         ps = D.PartySharded(S, Bblk, lambda rnd: E.gg20_msg_words(S, n, rnd), Eng, ctx.device, placement=placement)
+        selftest = ps.layout_self_test() if backend == "nccl" else None
         msgs = {s: _dev(ctx, block_nonces(s)["msg"]) for s in ps.engines}
         res = ps.run(msgs)
         ctx.sync()
+        for _ in range(runs - 1):               # consecutive batches on the same objects and the same double buffers
+            first = {s: {f: v.clone() for f, v in r.items()} for s, r in res.items()}
+            for eng, _parties in [(e, p) for (p, e) in ps.engines.values()]:
+                eng.rearm()
+            res = ps.run(msgs)
+            ctx.sync()
+            for s in res:
+                for f in res[s]:
+                    assert torch.equal(res[s][f], first[s][f]), f"run after re-arm differs in {f} of block {s}"
         out = {s: {f: (_u32(v) if f in ("r", "s", "R", "bad_actors") else v.cpu().numpy()).tolist() for f, v in r.items()} for s, r in res.items()}
         hosted = {s: parties for s, (parties, _) in ps.engines.items()}
-        q.put((rank, hosted, out, dict(ps.bytes_per_round)))
+        q.put((rank, hosted, out, dict(ps.bytes_per_round)) + ((selftest,) if selftest is not None else ()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def _spawn(world, args):
+def _spawn(world, args, **kw):
     import queue
     import time
     import torch.multiprocessing as mp
     port = 23000 + (os.getpid() * 11 + world * 137 + len(str(args)) * 7) % 4000
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_worker, args=(r, world, port) + args + (q,)) for r in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port) + args + (q,), kwargs=kw) for r in range(world)]
     for p in procs:
         p.start()
     res, t0 = [], time.time()
@@ -124,7 +140,7 @@ def _spawn(world, args):
     (3, 2, 4, [0, 1, 3], 2, "party"),
 ])
 def test_party_sharded_gpu_engines_over_gloo(world, t, n, signers, B, placement):
-    res = _spawn(world, (t, n, signers, B, placement))
+    res = _spawn(world, (t, n, signers, B, placement), runs=2)       # two batches on the same sessions and gather buffers
     lk = G.make_local_keys(F.load_keys(), t, n, signers)
     nonces = G.make_nonces(lk, B, seed=f"modeB-gpu-{t}-{n}-{placement}")
     want = G.oracle_sign_ex(lk, nonces, B)
@@ -145,6 +161,30 @@ def test_party_sharded_gpu_engines_over_gloo(world, t, n, signers, B, placement)
                 assert r["recid"][li] == list(want["recid"][sl])
         assert set(nbytes) == {0, 1, 2, 3, 4, 5, 7}
     assert seen == {(s, p) for s in range(blocks) for p in range(len(signers))}
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two devices: RCCL refuses two ranks on one")
+@pytest.mark.parametrize("world,t,n,signers,B,placement", [
+    (2, 1, 3, [0, 2], 4, "party"),
+    (2, 1, 3, [1, 2], 6, "rotated"),
+])
+def test_party_sharded_over_rccl_on_distinct_devices(world, t, n, signers, B, placement):
+    """the stream-ordered all-gather on the REAL backend at world > 1 (a one-GPU test box skips this; the driver's 8-GPU node
+    runs it): layout self-test, then two consecutive run() calls on the same sessions and the same double buffers
+    (mpe_gg20_session_rearm in between) — both bit-identical to the oracle's lock-step run"""
+    res = _spawn(world, (t, n, signers, B, placement), backend="nccl", runs=2)
+    lk = G.make_local_keys(F.load_keys(), t, n, signers)
+    want = G.oracle_sign_ex(lk, G.make_nonces(lk, B, seed=f"modeB-gpu-{t}-{n}-{placement}"), B)
+    blocks = world if placement == "rotated" else 1
+    Bblk = B // blocks
+    for rank, hosted, out, nbytes, selftest in res:
+        assert selftest["ok"] is True and selftest["mode"] in ("inplace", "outofplace", "staged"), selftest
+        for s, parties in hosted.items():
+            sl = slice(s * Bblk, (s + 1) * Bblk)
+            for li, p in enumerate(parties):
+                assert out[s]["status"][li] == [0] * Bblk
+                assert np.array_equal(np.array(out[s]["r"][li], dtype=np.uint32), want["r"][sl])
+                assert np.array_equal(np.array(out[s]["s"][li], dtype=np.uint32), want["s"][sl])
 
 
 # ---- non-default h_in_off: permuted sender blocks with garbage between them --------------------------------------------

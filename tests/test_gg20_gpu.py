@@ -234,6 +234,8 @@ def tamper_case(gpu_ctx, keys, name, rnd, sender, word, kind):
 
 
 @pytest.mark.parametrize("t,n,signers,B,kw", [
+    (1, 2, [0, 1], 2, {}),                           # the reference's own three shapes, literally: gg_2020/test.rs:56-58,
+    (4, 8, [0, 1, 2, 4, 6, 7], 1, {}),               # :65-67 (six of eight at t = 4) and (2, 5, [0, 2, 3, 4]) below (:61-63)
     (1, 3, [0, 1], 5, {}),
     (1, 3, [0, 2], 3, {"dedup_verify": True}),
     (1, 3, [1, 2], 7, {"chunk": 3}),                 # ragged chunking: 3 + 3 + 1
