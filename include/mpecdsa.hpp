@@ -11,6 +11,8 @@
 //         MessageB::verify_proofs_get_alpha}                                     src/utilities/mta/mod.rs:62-179
 //   zk_pdl_with_slack::PDLwSlackProof::{prove, verify}                           src/utilities/zk_pdl_with_slack/mod.rs:68-179
 //   curv DLogProof::{prove, verify}                                              mta/mod.rs:147-148,170-171
+//   gg_2020::state_machine::sign::{OfflineStage, CompletedOfflineStage, SignManual}  gg_2020/state_machine/sign.rs:66-330,540-646
+//       (one party of `batch` concurrent signing sessions: `RoundN::proceed`, state_machine/sign/rounds.rs:68-692)
 //
 // Values sampled from OsRng inside the reference's primitives are explicit arguments (`*Nonces`), which is what makes a bit-exact
 // comparison possible; `bool` / `Result<(), _>` returns become one flag per item (a bad item never aborts the batch — the
@@ -24,8 +26,12 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <optional>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -377,5 +383,260 @@ inline Batch ec_mul_base(Context& ctx, const Batch& k) {
   ctx.sync();
   return down(o, W_POINT);
 }
+
+// ---- GG20 signing, the state-machine surface ------------------------------------------------------------------------------------
+namespace gg_2020 {
+
+// `LocalKey<Secp256k1>` as keygen leaves it with party `i` (state_machine/keygen/rounds.rs:311-322), in interface words
+struct LocalKey {
+  uint16_t i = 0, t = 0, n = 0;                 // `i` in [1, n]
+  Batch paillier_key_vec;                       // [n][64]  EncryptionKey.n of every party
+  Batch n_tilde_vec, h1_vec, h2_vec;            // [n][64]  `h1_h2_n_tilde_vec` (DLogStatement{N, g, ni})
+  Batch y_sum_s;                                // [1][16]  the joint public key
+  Batch pk_vec;                                 // [n][16]  X_j = x_j G
+  Batch x_i;                                    // [1][8]   `keys_linear.x_i`
+  Batch p, q;                                   // [1][32]  `paillier_dk`
+};
+
+// Every value ONE party samples from OsRng while signing, for `batch` sessions: the C-ABI's mpe_gg20_nonces with one local party
+// (leading dimension [batch]; then statement st (n), peer slot jj (S-1), MessageB variant v (2) — see include/mpecdsa_hip.h).
+struct SignNonces {
+  Batch k, gamma, blind, r_a, al_alpha, al_beta, al_gamma, al_rho, mb_beta_tag, mb_r, mb_nonce_b, mb_nonce_bt, l, ped_s1, ped_s2, pdl_alpha,
+      pdl_beta, pdl_rho, pdl_gamma, heg_s1, heg_s2;
+};
+
+namespace state_machine {
+namespace sign {
+
+// `sign::Error` (sign.rs:520-560).  A failed CHECK of the protocol is not an exception here: the batch goes on and the session's
+// status says which check failed (`ProceedRound(rounds::Error)` per session: OfflineStage::status(), mpecdsa_hip.h lists the codes).
+struct Error : std::runtime_error {
+  enum Kind { TooFewParties, InvalidPartyIndex, InvalidSl, ReceivedOutOfOrderMessage, HandleMessage, DoublePickOutput, OfflineStageReused };
+  Kind kind;
+  Error(Kind k, const std::string& what) : std::runtime_error(what), kind(k) {}
+};
+
+// `Msg<OfflineProtocolMessage>` (sign.rs:340-366): `sender` = position in s_l (1-based), `round` = the round that consumes it
+// (M1..M6), `body` = one fixed-layout record per session.  Every message travels as a broadcast and the receiver picks what is
+// addressed to it, as the relay of examples/gg20_sm_manager.rs does.
+struct Msg {
+  uint16_t sender = 0, round = 0;
+  Batch body;
+};
+
+namespace detail {
+struct Party {
+  Context& ctx;
+  mpe_gg20_keys* keys = nullptr;
+  mpe_gg20_session* sess = nullptr;
+  int batch = 0, S = 0, n = 0, me = 0;                             // me: 0-based position in s_l
+  Batch y_sum_s;
+  std::vector<std::unique_ptr<Dev<uint32_t>>> sampled;              // the nonce arrays: valid until round 5 is queued (mpecdsa_hip.h)
+  std::map<int, Batch> mine;                                        // what this party sent, by consuming round (1..6; 8 = partial signature)
+  bool signed_once = false;
+  explicit Party(Context& c) : ctx(c) {}
+  ~Party() {
+    if (sess) (void)mpe_gg20_session_destroy(sess, nullptr);        // zeroes k_i, gamma_i, w_i, sigma_i
+    if (keys) (void)mpe_gg20_keys_destroy(keys);
+  }
+  Party(const Party&) = delete;
+  int words(int emitting_round) const { return mpe_gg20_msg_words(S, n, emitting_round); }
+  // the records of ALL senders for one round, sender-major: own block at `me`
+  Dev<uint32_t> slab(const Batch& own, const std::map<uint16_t, Batch>& peers) const {
+    const size_t blk = own.w.size();
+    std::vector<uint32_t> h((size_t)S * blk);
+    for (int j = 0; j < S; ++j) {
+      const Batch& b = j == me ? own : peers.at((uint16_t)(j + 1));
+      std::copy(b.w.begin(), b.w.end(), h.begin() + (size_t)j * blk);
+    }
+    return Dev<uint32_t>(h);
+  }
+};
+}  // namespace detail
+
+// `CompletedOfflineStage` (rounds.rs:560-570): everything `SignManual` needs; may be copied like the reference's (it is `Clone`),
+// but signs ONE message — a second SignManual::new on any copy throws (two signatures with one k_i leak the key share).
+class CompletedOfflineStage {
+ public:
+  const Batch& public_key() const { return p_->y_sum_s; }           // `public_key()` (rounds.rs:572-574)
+ private:
+  friend class OfflineStage;
+  friend class SignManual;
+  explicit CompletedOfflineStage(std::shared_ptr<detail::Party> p) : p_(std::move(p)) {}
+  std::shared_ptr<detail::Party> p_;
+};
+
+// `OfflineStage` (sign.rs:43-330): one party of the offline stage, for `batch` concurrent sessions with the same signer set.
+class OfflineStage {
+ public:
+  // `OfflineStage::new(i, s_l, local_key)` (sign.rs:77-121): i in [1, |s_l|], s_l = keygen indices of the signers.  This layer
+  // takes s_l in ascending order (the order the C-ABI's signer ordinals use; every test of the reference does).
+  OfflineStage(Context& ctx, uint16_t i, const std::vector<uint16_t>& s_l, const LocalKey& local_key, int batch, const SignNonces& sampled)
+      : p_(std::make_shared<detail::Party>(ctx)) {
+    if (s_l.size() < 2) throw Error(Error::TooFewParties, "at least 2 parties are required for signing");
+    if (i == 0 || i > s_l.size()) throw Error(Error::InvalidPartyIndex, "party index is not in range [1; n]");
+    for (size_t a = 0; a < s_l.size(); ++a) {
+      if (s_l[a] == 0 || s_l[a] > local_key.n) throw Error(Error::InvalidSl, "invalid s_l");
+      if (a && s_l[a] <= s_l[a - 1]) throw Error(Error::InvalidSl, s_l[a] == s_l[a - 1] ? "invalid s_l" : "invalid s_l (this layer: ascending order)");
+    }
+    if (s_l[i - 1] != local_key.i) throw Error(Error::InvalidSl, "invalid s_l (s_l[i] is not this key's keygen index)");
+    detail::Party& P = *p_;
+    P.batch = batch; P.S = (int)s_l.size(); P.n = local_key.n; P.me = i - 1; P.y_sum_s = local_key.y_sum_s;
+    std::vector<int32_t> signers(s_l.begin(), s_l.end());
+    for (auto& v : signers) v -= 1;
+    const int32_t own = local_key.i - 1, local = P.me;
+    {
+      Dev<uint32_t> x = up(local_key.x_i), dp = up(local_key.p), dq = up(local_key.q), N = up(local_key.paillier_key_vec), Nt = up(local_key.n_tilde_vec),
+                    h1 = up(local_key.h1_vec), h2 = up(local_key.h2_vec), y = up(local_key.y_sum_s), X = up(local_key.pk_vec);
+      check(mpe_gg20_keys_create(ctx.get(), local_key.t, local_key.n, P.S, signers.data(), 1, 1, &own, x.get(), dp.get(), dq.get(), N.get(), Nt.get(),
+                                 h1.get(), h2.get(), y.get(), X.get(), &P.keys, nullptr), "mpe_gg20_keys_create");
+      ctx.sync();
+    }
+    const Batch* f[] = {&sampled.k, &sampled.gamma, &sampled.blind, &sampled.r_a, &sampled.al_alpha, &sampled.al_beta, &sampled.al_gamma, &sampled.al_rho,
+                        &sampled.mb_beta_tag, &sampled.mb_r, &sampled.mb_nonce_b, &sampled.mb_nonce_bt, &sampled.l, &sampled.ped_s1, &sampled.ped_s2,
+                        &sampled.pdl_alpha, &sampled.pdl_beta, &sampled.pdl_rho, &sampled.pdl_gamma, &sampled.heg_s1, &sampled.heg_s2};
+    for (const Batch* b : f) P.sampled.emplace_back(new Dev<uint32_t>(b->w));
+    auto d = [&](int k) { return (const uint32_t*)P.sampled[(size_t)k]->get(); };
+    const mpe_gg20_nonces nn{d(0), d(1), d(2), d(3), d(4), d(5), d(6), d(7), d(8), d(9), d(10), d(11), d(12), d(13), d(14), d(15), d(16), d(17), d(18),
+                             d(19), d(20), nullptr};
+    check(mpe_gg20_session_create(ctx.get(), P.keys, batch, 1, &local, nullptr, &nn, 0, &P.sess, nullptr), "mpe_gg20_session_create");
+  }
+
+  uint16_t current_round() const { return round_; }                                   // 0..6, 7 once finished (sign.rs:300-312)
+  uint16_t party_ind() const { return (uint16_t)(p_->me + 1); }
+  uint16_t parties() const { return (uint16_t)p_->S; }
+  bool is_finished() const { return round_ == 7; }
+  std::vector<Msg>& message_queue() { return queue_; }
+
+  // `handle_incoming(msg)` (sign.rs:246-297): stores a peer's message for the round it belongs to — early messages wait in
+  // their round's store, a message for a round that is over is `ReceivedOutOfOrderMessage`
+  void handle_incoming(const Msg& m) {
+    if (m.round < 1 || m.round > 6 || m.round < round_)                               // the store of a finished round is gone
+      throw Error(Error::ReceivedOutOfOrderMessage, "didn't expect to receive message from round " + std::to_string(m.round) + " (being at round " +
+                                                        std::to_string(round_) + ")");
+    if (m.sender == 0 || m.sender > p_->S || m.sender == party_ind()) throw Error(Error::HandleMessage, "received message didn't pass pre-validation: sender");
+    if ((int)m.body.size() != p_->batch || m.body.words != p_->words(m.round - 1))
+      throw Error(Error::HandleMessage, "received message didn't pass pre-validation: record layout");
+    auto& st = store_[m.round];
+    if (st.count(m.sender)) throw Error(Error::HandleMessage, "received message didn't pass pre-validation: message overwrite");
+    st[m.sender] = m.body;
+  }
+
+  // `wants_to_proceed()` (sign.rs:299-311): round 0 always; round r once the S - 1 peers' messages for r are in
+  bool wants_to_proceed() const {
+    if (round_ == 7) return false;
+    if (round_ == 0) return true;
+    auto it = store_.find(round_);
+    return it != store_.end() && (int)it->second.size() == p_->S - 1;
+  }
+
+  // `proceed()` (sign.rs:313-316): RoundN::proceed for every session (rounds.rs:68,122,234,347,431,525,612); no-op when the
+  // round's messages are not all in.  The outgoing message is appended to message_queue().
+  void proceed() {
+    if (!wants_to_proceed()) return;
+    detail::Party& P = *p_;
+    const int r = round_;
+    if (r == 0) {
+      Dev<uint32_t> out((size_t)P.batch * P.words(0));
+      check(mpe_gg20_round0(P.sess, out.get(), nullptr), "mpe_gg20_round0");
+      emit(1, down(out, P.words(0)));
+    } else {
+      Dev<uint32_t> in = P.slab(P.mine.at(r), store_.at((uint16_t)r));
+      if (r < 6) {
+        Dev<uint32_t> out((size_t)P.batch * P.words(r));
+        using Fn = int (*)(mpe_gg20_session*, const uint32_t*, const int64_t*, uint32_t*, void*);
+        static const Fn fn[] = {nullptr, mpe_gg20_round1, mpe_gg20_round2, mpe_gg20_round3, mpe_gg20_round4, mpe_gg20_round5};
+        check(fn[r](P.sess, in.get(), nullptr, out.get(), nullptr), "mpe_gg20_roundN");
+        emit((uint16_t)(r + 1), down(out, P.words(r)));
+      } else {
+        check(mpe_gg20_round6(P.sess, in.get(), nullptr, nullptr), "mpe_gg20_round6");
+        P.ctx.sync();
+      }
+      store_.erase((uint16_t)r);
+    }
+    if (r == 5) P.sampled.clear();                                                    // round 5 has run: the sampled values are no longer read
+    round_ = (uint16_t)(r + 1);
+  }
+
+  // per-session status so far (0 = every check passed): the reference's Err(ProceedRound(..)) of that session
+  std::vector<int32_t> status() const {
+    Dev<int32_t> st((size_t)p_->batch);
+    check(mpe_gg20_session_result(p_->sess, st.get(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "mpe_gg20_session_result");
+    p_->ctx.sync();
+    return st.download();
+  }
+
+  // `pick_output()` (sign.rs:318-330): None while the stage is running, the output once, DoublePickOutput afterwards
+  std::optional<CompletedOfflineStage> pick_output() {
+    if (!is_finished()) return std::nullopt;
+    if (picked_) throw Error(Error::DoublePickOutput, "pick_output called twice");
+    picked_ = true;
+    return CompletedOfflineStage(p_);
+  }
+
+ private:
+  void emit(uint16_t consuming_round, Batch body) {
+    p_->ctx.sync();
+    p_->mine[consuming_round] = body;
+    queue_.push_back(Msg{party_ind(), consuming_round, std::move(body)});
+  }
+  std::shared_ptr<detail::Party> p_;
+  std::map<uint16_t, std::map<uint16_t, Batch>> store_;              // msgs1..msgs6 (sign.rs:52-57)
+  std::vector<Msg> queue_;
+  uint16_t round_ = 0;
+  bool picked_ = false;
+};
+
+// `PartialSignature` (rounds.rs:594) and `SignatureRecid{r, s, recid}` (party_i.rs:131-135), one per session; status[b] != 0:
+// the reference's Err(CompleteSigning(..)) for that session (701: the assembled signature does not verify)
+struct PartialSignature { Batch s_i; };
+struct SignatureRecid {
+  Batch r, s;
+  std::vector<int32_t> recid, status;
+  std::vector<uint32_t> bad_actors;
+};
+
+// `SignManual` (sign.rs:540-646)
+class SignManual {
+ public:
+  // `SignManual::new(message, completed_offline_stage) -> (SignManual, PartialSignature)` (sign.rs:551-558, Round7::new
+  // rounds.rs:612-660); message [batch][8]: the BigInt to sign, reduced mod q like Scalar::from (party_i.rs:857)
+  static std::pair<SignManual, PartialSignature> new_(const Batch& message, const CompletedOfflineStage& completed_offline_stage) {
+    std::shared_ptr<detail::Party> p = completed_offline_stage.p_;
+    if (p->signed_once) throw Error(Error::OfflineStageReused, "this offline stage has already signed a message");
+    if ((int)message.size() != p->batch || message.words != W_SCALAR) throw mpecdsa::Error("SignManual::new: message layout", MPE_E_ARG);
+    p->signed_once = true;
+    Dev<uint32_t> m = up(message), out((size_t)p->batch * W_SCALAR);
+    check(mpe_gg20_round7(p->sess, m.get(), out.get(), nullptr), "mpe_gg20_round7");
+    p->ctx.sync();
+    PartialSignature ps{down(out, W_SCALAR)};
+    p->mine[8] = ps.s_i;
+    return {SignManual(std::move(p)), std::move(ps)};
+  }
+  // `complete(self, sigs)` (sign.rs:562-568): sigs = the partial signatures of the OTHER parties, in any order
+  SignatureRecid complete(const std::vector<PartialSignature>& sigs) {
+    detail::Party& P = *p_;
+    if ((int)sigs.size() != P.S - 1) throw mpecdsa::Error("SignManual::complete: expected the other parties' partial signatures", MPE_E_ARG);
+    std::map<uint16_t, Batch> peers;
+    size_t k = 0;
+    for (int j = 0; j < P.S; ++j)
+      if (j != P.me) peers[(uint16_t)(j + 1)] = sigs[k++].s_i;
+    Dev<uint32_t> in = P.slab(P.mine.at(8), peers);
+    check(mpe_gg20_complete(P.sess, in.get(), nullptr, nullptr), "mpe_gg20_complete");
+    const size_t B = (size_t)P.batch;
+    Dev<int32_t> st(B), rec(B);
+    Dev<uint32_t> bad(B), r(B * W_SCALAR), s(B * W_SCALAR);
+    check(mpe_gg20_session_result(P.sess, st.get(), bad.get(), r.get(), s.get(), rec.get(), nullptr, nullptr), "mpe_gg20_session_result");
+    P.ctx.sync();
+    return SignatureRecid{down(r, W_SCALAR), down(s, W_SCALAR), rec.download(), st.download(), bad.download()};
+  }
+ private:
+  explicit SignManual(std::shared_ptr<detail::Party> p) : p_(std::move(p)) {}
+  std::shared_ptr<detail::Party> p_;
+};
+
+}  // namespace sign
+}  // namespace state_machine
+}  // namespace gg_2020
 
 }  // namespace mpecdsa

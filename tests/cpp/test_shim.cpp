@@ -5,6 +5,9 @@
 //   test_mta                           src/utilities/mta/test.rs:6-19            (alpha + beta == a * b)
 //   test_zk_pdl_with_slack             src/utilities/zk_pdl_with_slack/test.rs:12-68
 //   test_zk_pdl_with_slack_soundness   src/utilities/zk_pdl_with_slack/test.rs:70-129   (#[should_panic]: Enc(x + 1) must be refused)
+//   simulate_signing_t1_n2_s2 / _t1_n3_s2 / _t2_n3_s3   gg_2020/state_machine/sign.rs:667-762 (one OfflineStage per party, each with its
+//                                      own secrets only, a Simulation relaying their messages, then SignManual for every party)
+//   the constructor / message-store errors of sign.rs:77-101,246-330
 //
 // Inputs (keys, scalars, every value the reference samples from OsRng) come from a fixture file written by
 // tests/test_cpp_shim_gpu.py — the same seeded fixtures the Python tests use.  Test infrastructure: links the oracle and libgmp;
@@ -16,7 +19,9 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <string>
+#include <vector>
 
 #include "mpe_oracle.h"
 #include "mpecdsa.hpp"
@@ -26,6 +31,10 @@ using paillier::DecryptionKeys;
 using paillier::EncryptionKeys;
 using paillier::Paillier;
 using zk_paillier::DLogStatements;
+namespace sm = gg_2020::state_machine::sign;
+
+// oracle/ossl_check.c (libmpe_ossl.so): OpenSSL's ECDSA_do_verify over the interface words — the independent `verify`
+extern "C" int ossl_ecdsa_verify(int batch, const uint32_t* pub, int pub_stride, const uint32_t* msg, const uint32_t* r, const uint32_t* s, uint8_t* ok);
 
 static std::map<std::string, Batch> load_fixture(const char* path) {
   std::ifstream f(path, std::ios::binary);
@@ -187,6 +196,179 @@ static bool test_zk_pdl_with_slack(Context& ctx, const Fixture& F, const ProverK
   return true;
 }
 
+// ---- gg_2020/state_machine/sign.rs:667-762 ----------------------------------------------------------------------------------------
+// `round_based::dev::Simulation`: every party proceeds when it can, its outgoing messages are delivered to all the others
+struct Simulation {
+  std::vector<sm::OfflineStage*> parties;
+  std::map<std::pair<int, int>, Batch> sent;                       // (consuming round, sender ordinal) -> records, for the oracle comparison
+  void add_party(sm::OfflineStage& p) { parties.push_back(&p); }
+  std::vector<sm::CompletedOfflineStage> run() {
+    for (int guard = 0; guard < 64; ++guard) {
+      bool all = true;
+      for (auto* p : parties) {
+        if (p->wants_to_proceed()) p->proceed();
+        for (auto& m : p->message_queue()) {
+          sent[{m.round, m.sender - 1}] = m.body;
+          for (auto* q : parties)
+            if (q != p) q->handle_incoming(m);
+        }
+        p->message_queue().clear();
+        all = all && p->is_finished();
+      }
+      if (all) break;
+    }
+    std::vector<sm::CompletedOfflineStage> out;
+    for (auto* p : parties) out.push_back(p->pick_output().value());
+    return out;
+  }
+};
+
+struct SmCase {
+  int t, n, S, B;
+  std::vector<uint16_t> s_l;
+  std::string pre;
+  const Fixture& F;
+  const Batch& get(const char* f) const { return F[(pre + f).c_str()]; }
+  static Batch rows(const Batch& a, size_t first, size_t count) {
+    Batch b(count, a.words);
+    std::memcpy(b.w.data(), a.row(first), count * (size_t)a.words * 4);
+    return b;
+  }
+  gg_2020::LocalKey local_key(int party) const {                   // `local_keys[usize::from(keygen_i - 1)]`: only this party's secrets
+    gg_2020::LocalKey k;
+    k.i = (uint16_t)(party + 1); k.t = (uint16_t)t; k.n = (uint16_t)n;
+    k.paillier_key_vec = get("N"); k.n_tilde_vec = get("Nt"); k.h1_vec = get("h1"); k.h2_vec = get("h2"); k.y_sum_s = get("y"); k.pk_vec = get("X");
+    k.x_i = rows(get("x"), (size_t)party, 1); k.p = rows(get("p"), (size_t)party, 1); k.q = rows(get("q"), (size_t)party, 1);
+    return k;
+  }
+  Batch of_party(const char* f, int ord) const {                   // [B][S][per] -> [B][per] of signer ordinal `ord`
+    const Batch& a = get(f);
+    const size_t per = a.size() / ((size_t)B * S);
+    Batch b((size_t)B * per, a.words);
+    for (int s = 0; s < B; ++s) std::memcpy(b.row((size_t)s * per), a.row(((size_t)s * S + ord) * per), per * (size_t)a.words * 4);
+    return b;
+  }
+  gg_2020::SignNonces sampled(int ord) const {
+    auto g = [&](const char* f) { return of_party(f, ord); };
+    return gg_2020::SignNonces{g("k"), g("gamma"), g("blind"), g("r_a"), g("al_alpha"), g("al_beta"), g("al_gamma"), g("al_rho"), g("mb_beta_tag"),
+                               g("mb_r"), g("mb_nonce_b"), g("mb_nonce_bt"), g("l"), g("ped_s1"), g("ped_s2"), g("pdl_alpha"), g("pdl_beta"),
+                               g("pdl_rho"), g("pdl_gamma"), g("heg_s1"), g("heg_s2")};
+  }
+};
+
+static SmCase sm_case(const Fixture& F, int k) {
+  const std::string pre = "sm" + std::to_string(k) + "_";
+  const Batch& sh = F[(pre + "shape").c_str()];
+  SmCase c{(int)sh.w[0], (int)sh.w[1], (int)sh.w[2], (int)sh.w[3], {}, pre, F};
+  for (uint32_t v : F[(pre + "signers").c_str()].w) c.s_l.push_back((uint16_t)(v + 1));
+  return c;
+}
+
+// simulate_offline_stage + simulate_signing (sign.rs:673-724) for one signer set, `B` sessions at once
+static bool simulate_signing(Context& ctx, const SmCase& c) {
+  std::vector<std::unique_ptr<sm::OfflineStage>> stages;
+  Simulation simulation;
+  for (int i = 1; i <= c.S; ++i) {                                 // for (i, &keygen_i) in (1..).zip(s_l)
+    stages.emplace_back(new sm::OfflineStage(ctx, (uint16_t)i, c.s_l, c.local_key(c.s_l[(size_t)i - 1] - 1), c.B, c.sampled(i - 1)));
+    simulation.add_party(*stages.back());
+  }
+  const auto offline = simulation.run();                           // .unwrap()
+  for (auto& st : stages)
+    for (int32_t v : st->status()) REQUIRE(v == 0);
+  const Batch& message = c.get("msg");
+  const Batch pk = offline[0].public_key();
+  std::vector<sm::SignManual> parties;
+  std::vector<sm::PartialSignature> local_sigs;
+  for (auto& o : offline) {                                        // SignManual::new(message.clone(), o.clone())
+    auto made = sm::SignManual::new_(message, o);
+    parties.push_back(std::move(made.first));
+    local_sigs.push_back(std::move(made.second));
+  }
+  // the oracle's lock-step run of the same sessions: every message of every party and the signature
+  std::vector<int32_t> signers;
+  for (auto v : c.s_l) signers.push_back(v - 1);
+  const orc_gg20_keys K{c.t, c.n, c.S, 1, signers.data(), c.get("x").w.data(), c.get("p").w.data(), c.get("q").w.data(), c.get("N").w.data(),
+                        c.get("Nt").w.data(), c.get("h1").w.data(), c.get("h2").w.data(), c.get("y").w.data(), c.get("X").w.data()};
+  const orc_gg20_nonces Z{c.get("k").w.data(), c.get("gamma").w.data(), c.get("blind").w.data(), c.get("r_a").w.data(), c.get("al_alpha").w.data(),
+                          c.get("al_beta").w.data(), c.get("al_gamma").w.data(), c.get("al_rho").w.data(), c.get("mb_beta_tag").w.data(),
+                          c.get("mb_r").w.data(), c.get("mb_nonce_b").w.data(), c.get("mb_nonce_bt").w.data(), c.get("l").w.data(),
+                          c.get("ped_s1").w.data(), c.get("ped_s2").w.data(), c.get("pdl_alpha").w.data(), c.get("pdl_beta").w.data(),
+                          c.get("pdl_rho").w.data(), c.get("pdl_gamma").w.data(), c.get("heg_s1").w.data(), c.get("heg_s2").w.data(), message.w.data()};
+  std::vector<std::vector<uint32_t>> slab(7);
+  uint32_t* slabs[7];
+  const int emitting[7] = {0, 1, 2, 3, 4, 5, 7};
+  for (int m = 0; m < 7; ++m) {
+    slab[(size_t)m].assign((size_t)c.S * c.B * orc_gg20_msg_words(c.S, c.n, emitting[m]), 0u);
+    slabs[m] = slab[(size_t)m].data();
+  }
+  Batch wr(c.B, W_SCALAR), ws(c.B, W_SCALAR);
+  std::vector<int32_t> wrec((size_t)c.B), wst((size_t)c.B);
+  orc_gg20_sign_ex(&K, &Z, nullptr, c.B, 0, c.B, slabs, wr.w.data(), ws.w.data(), wrec.data(), nullptr, wst.data(), nullptr, nullptr);
+  for (int32_t v : wst) REQUIRE(v == 0);
+  for (int m = 0; m < 6; ++m)
+    for (int j = 0; j < c.S; ++j) {
+      const Batch& got = simulation.sent.at({m + 1, j});
+      const size_t blk = (size_t)c.B * got.words;
+      REQUIRE(got.words == orc_gg20_msg_words(c.S, c.n, m));
+      REQUIRE(std::memcmp(got.w.data(), slab[(size_t)m].data() + (size_t)j * blk, blk * 4) == 0);       // byte-identical round message
+    }
+  for (int j = 0; j < c.S; ++j) REQUIRE(std::memcmp(local_sigs[(size_t)j].s_i.w.data(), slab[6].data() + (size_t)j * c.B * 8, (size_t)c.B * 32) == 0);
+  // parties.into_iter().enumerate().map(|(i, p)| p.complete(&local_sigs_except(i)).unwrap()).all(|signature| verify(&signature, &pk, &message).is_ok())
+  for (int i = 0; i < c.S; ++i) {
+    std::vector<sm::PartialSignature> except;
+    for (int j = 0; j < c.S; ++j)
+      if (j != i) except.push_back(local_sigs[(size_t)j]);
+    const sm::SignatureRecid sig = parties[(size_t)i].complete(except);
+    for (int32_t v : sig.status) REQUIRE(v == 0);
+    std::vector<uint8_t> ok((size_t)c.B);
+    REQUIRE(ossl_ecdsa_verify(c.B, pk.w.data(), 0, message.w.data(), sig.r.w.data(), sig.s.w.data(), ok.data()) == c.B);
+    REQUIRE(sig.r == wr && sig.s == ws && sig.recid == wrec);
+  }
+  return true;
+}
+
+template <class F>
+static bool throws(sm::Error::Kind kind, F&& f) {
+  try { f(); } catch (const sm::Error& e) { return e.kind == kind; }
+  return false;
+}
+
+// OfflineStage::new's argument checks (sign.rs:78-101), the message stores (:246-297) and pick_output (:318-330)
+static bool state_machine_errors(Context& ctx, const SmCase& c) {
+  const auto key = c.local_key(c.s_l[0] - 1);
+  const auto nn = c.sampled(0);
+  REQUIRE(throws(sm::Error::TooFewParties, [&] { sm::OfflineStage(ctx, 1, {c.s_l[0]}, key, c.B, nn); }));
+  REQUIRE(throws(sm::Error::InvalidPartyIndex, [&] { sm::OfflineStage(ctx, 0, c.s_l, key, c.B, nn); }));
+  REQUIRE(throws(sm::Error::InvalidPartyIndex, [&] { sm::OfflineStage(ctx, (uint16_t)(c.S + 1), c.s_l, key, c.B, nn); }));
+  REQUIRE(throws(sm::Error::InvalidSl, [&] { sm::OfflineStage(ctx, 1, {c.s_l[0], (uint16_t)(c.n + 1)}, key, c.B, nn); }));
+  REQUIRE(throws(sm::Error::InvalidSl, [&] { sm::OfflineStage(ctx, 1, {c.s_l[0], 0}, key, c.B, nn); }));
+  REQUIRE(throws(sm::Error::InvalidSl, [&] { sm::OfflineStage(ctx, 1, {c.s_l[0], c.s_l[0]}, key, c.B, nn); }));
+  sm::OfflineStage a(ctx, 1, c.s_l, key, c.B, nn), b(ctx, 2, c.s_l, c.local_key(c.s_l[1] - 1), c.B, c.sampled(1));
+  REQUIRE(a.current_round() == 0 && a.party_ind() == 1 && a.parties() == c.S && !a.is_finished() && a.wants_to_proceed());
+  REQUIRE(!a.pick_output().has_value());                            // None while running
+  a.proceed();
+  b.proceed();
+  REQUIRE(a.current_round() == 1 && a.message_queue().size() == 1 && a.message_queue()[0].round == 1 && a.message_queue()[0].sender == 1);
+  REQUIRE(c.S > 2 || !a.wants_to_proceed());
+  const sm::Msg from_b = b.message_queue()[0];
+  REQUIRE(throws(sm::Error::HandleMessage, [&] { a.handle_incoming(a.message_queue()[0]); }));           // my own message
+  a.handle_incoming(from_b);
+  REQUIRE(throws(sm::Error::HandleMessage, [&] { a.handle_incoming(from_b); }));                          // overwrite
+  sm::Msg bad = from_b;
+  bad.sender = (uint16_t)(c.S + 1);
+  REQUIRE(throws(sm::Error::HandleMessage, [&] { a.handle_incoming(bad); }));
+  bad = from_b; bad.round = 7;
+  REQUIRE(throws(sm::Error::ReceivedOutOfOrderMessage, [&] { a.handle_incoming(bad); }));
+  if (c.S == 2) {
+    REQUIRE(a.wants_to_proceed());
+    a.proceed();
+    REQUIRE(a.current_round() == 2);
+    bad = from_b;                                                                                          // round 1 is over: its store is gone
+    REQUIRE(throws(sm::Error::ReceivedOutOfOrderMessage, [&] { a.handle_incoming(bad); }));
+  }
+  return true;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { std::fprintf(stderr, "usage: test_shim <fixture.bin>\n"); return 2; }
   Fixture F{load_fixture(argv[1])};
@@ -207,6 +389,33 @@ int main(int argc, char** argv) {
     for (auto& r : results) {
       std::printf("test %s ... %s\n", r.name, r.ok ? "ok" : "FAILED");
       failed += r.ok ? 0 : 1;
+    }
+    const int ncases = (int)F["sm_count"].w[0];
+    for (int k = 0; k < ncases; ++k) {
+      const SmCase c = sm_case(F, k);
+      const bool ok = simulate_signing(ctx, c);
+      std::printf("test simulate_signing_t%d_n%d_s%d [", c.t, c.n, c.S);
+      for (size_t j = 0; j < c.s_l.size(); ++j) std::printf("%s%d", j ? ", " : "", (int)c.s_l[j]);
+      std::printf("] ... %s\n", ok ? "ok" : "FAILED");
+      failed += ok ? 0 : 1;
+    }
+    {
+      const SmCase c = sm_case(F, 0);
+      bool ok = state_machine_errors(ctx, c);
+      // a completed offline stage signs one message only (a second signature with the same k_i would leak the key share)
+      std::vector<std::unique_ptr<sm::OfflineStage>> st;
+      Simulation sim;
+      for (int i = 1; i <= c.S; ++i) {
+        st.emplace_back(new sm::OfflineStage(ctx, (uint16_t)i, c.s_l, c.local_key(c.s_l[(size_t)i - 1] - 1), c.B, c.sampled(i - 1)));
+        sim.add_party(*st.back());
+      }
+      const auto done = sim.run();
+      ok = ok && throws(sm::Error::DoublePickOutput, [&] { (void)st[0]->pick_output(); });
+      (void)sm::SignManual::new_(c.get("msg"), done[0]);
+      const sm::CompletedOfflineStage copy = done[0];
+      ok = ok && throws(sm::Error::OfflineStageReused, [&] { (void)sm::SignManual::new_(c.get("msg"), copy); });
+      std::printf("test state_machine_errors ... %s\n", ok ? "ok" : "FAILED");
+      failed += ok ? 0 : 1;
     }
     // argument errors surface as exceptions carrying mpe_last_error()
     bool threw = false;

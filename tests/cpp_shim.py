@@ -10,17 +10,21 @@ import numpy as np
 import fixtures as F
 import pyref
 
+# the signer sets of the reference's state-machine tests (state_machine/sign.rs:726-762: t1_n2_s2, t1_n3_s2 x 3, t2_n3_s3)
+SM_CASES = [(1, 2, [0, 1]), (1, 3, [0, 1]), (1, 3, [0, 2]), (1, 3, [1, 2]), (2, 3, [0, 1, 2])]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def build(out_dir):
     exe = os.path.join(out_dir, "test_shim")
     lib, orc = os.path.join(ROOT, "multi_party_ecdsa_amd", "libmpecdsa_hip.so"), os.path.join(ROOT, "oracle", "libmpe_oracle.so")
+    ossl = os.path.join(ROOT, "oracle", "libmpe_ossl.so")             # OpenSSL's ECDSA_do_verify: the `verify(&signature, &pk, &message)` of sign.rs:712
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     gmp = next(p for p in ("/opt/conda/lib/libgmp.so", "/usr/lib/x86_64-linux-gnu/libgmp.so.10") if os.path.exists(p))
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"),
            "-I", "/opt/conda/include", "-I", os.path.join(rocm, "include"), os.path.join(ROOT, "tests", "cpp", "test_shim.cpp"), "-o", exe,
-           lib, orc, gmp, os.path.join(rocm, "lib", "libamdhip64.so"), "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath," + os.path.dirname(orc),
+           lib, orc, ossl, gmp, os.path.join(rocm, "lib", "libamdhip64.so"), "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath," + os.path.dirname(orc),
            "-Wl,-rpath," + os.path.join(rocm, "lib")]
     subprocess.check_call(cmd)
     return exe
@@ -50,8 +54,33 @@ def write_fixture(path, keys, B=6, seed="cpp-shim"):
         arrays["one_" + f] = F.words([n[f] for n in one], w)
         arrays["al_" + f] = F.words([n[f] for n in al], w)
         arrays["pdl_" + f] = F.words([n[f] for n in pd], w)
+    arrays.update(state_machine_cases(keys))
     with open(path, "wb") as f:
         for name, arr in arrays.items():
             arr = np.ascontiguousarray(arr, dtype=np.uint32)
             f.write(struct.pack("<I", len(name)) + name.encode() + struct.pack("<II", arr.shape[1], arr.shape[0]) + arr.tobytes())
     return arrays
+
+
+def state_machine_cases(keys, B=2):
+    """LocalKeys, sampled values and messages of the signer sets the reference's `simulate_signing_*` tests run, as "sm<k>_<field>"
+    arrays: the public vectors and every party's secrets (the C++ test gives each OfflineStage only its own), the nonce arrays in
+    the C-ABI's [B][S] layout, msg[0] = SHA-256("ZenGo") as in sign.rs:697-699"""
+    import hashlib
+    import gg20_fixture as G
+    out = {"sm_count": np.array([[len(SM_CASES)]], dtype=np.uint32)}
+    for k, (t, n, signers) in enumerate(SM_CASES):
+        lk = G.make_local_keys(keys, t, n, signers, seed=f"cpp-sm-keygen-{k}")
+        nn = G.make_nonces(lk, B, seed=f"cpp-sm-{k}")
+        a = lk["arrays"]
+        pre = f"sm{k}_"
+        out[pre + "shape"] = np.array([[t, n, len(signers), B]], dtype=np.uint32)
+        out[pre + "signers"] = np.array(signers, dtype=np.uint32).reshape(-1, 1)
+        for f in ("x", "p", "q", "Nt", "h1", "h2", "y", "X"):
+            out[pre + f] = a[f]
+        out[pre + "N"] = F.words([keys[i].N for i in range(n)], 64)
+        msg = np.array(nn["msg"], copy=True)
+        msg[0] = F.words([int.from_bytes(hashlib.sha256(b"ZenGo").digest(), "big") % pyref.Q], 8)[0]
+        for f in G.NONCE_FIELDS:
+            out[pre + f] = msg if f == "msg" else nn[f]
+    return out

@@ -1,8 +1,12 @@
 """-m gpu: the reference's own unit tests of the hot path — `alice_zkp` (mta/range_proofs.rs:614-633), `test_mta`
 (mta/test.rs:6-19: alpha + beta == a b), `test_zk_pdl_with_slack` and its `#[should_panic]` soundness twin
 (zk_pdl_with_slack/test.rs:12-129) — re-stated in C++ over include/mpecdsa.hpp (the host layer a maintainer would write over the
-C-ABI, with the reference's type and method names) and run on the GPU.  No Python, no torch in that process: a compiled host of
-the C-ABI.  Every value is also compared bit for bit with the CPU oracle inside the program."""
+C-ABI, with the reference's type and method names) and run on the GPU — and the reference's state-machine tests
+(`simulate_signing_t1_n2_s2`, `_t1_n3_s2` for [1,2], [1,3], [2,3], `_t2_n3_s3`; gg_2020/state_machine/sign.rs:667-762): one
+`OfflineStage` per party holding only its own secrets, a `Simulation` relaying their messages, `SignManual::new` / `complete` for
+every party; every round message and every signature byte-identical to the oracle, every signature accepted by OpenSSL's
+ECDSA_do_verify, and the constructor / message-store / pick_output errors of sign.rs:77-101,246-330.  No Python, no torch in that
+process: a compiled host of the C-ABI.  Every value is also compared bit for bit with the CPU oracle inside the program."""
 import os
 import subprocess
 
@@ -20,7 +24,9 @@ def test_reference_unit_tests_over_the_cpp_host_layer(tmp_path, keys):
     p = subprocess.run([exe, fx], capture_output=True, text=True, timeout=600)
     print(p.stdout)
     assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-2000:])
-    for name in ("alice_zkp", "test_mta", "test_zk_pdl_with_slack", "test_zk_pdl_with_slack_soundness", "error_mapping"):
+    for name in ("alice_zkp", "test_mta", "test_zk_pdl_with_slack", "test_zk_pdl_with_slack_soundness", "error_mapping", "state_machine_errors",
+                 "simulate_signing_t1_n2_s2 [1, 2]", "simulate_signing_t1_n3_s2 [1, 2]", "simulate_signing_t1_n3_s2 [1, 3]",
+                 "simulate_signing_t1_n3_s2 [2, 3]", "simulate_signing_t2_n3_s3 [1, 2, 3]"):
         assert f"test {name} ... ok" in p.stdout, name
     assert "all tests passed" in p.stdout
     maps_check = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
