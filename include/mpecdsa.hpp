@@ -7,6 +7,7 @@
 //
 //   paillier::Paillier::{encrypt_with_chosen_randomness, decrypt, add, mul}     src/utilities/mta/mod.rs:22-24,68-75,133-145,165
 //   mta::range_proofs::AliceProof::{generate, verify}                            src/utilities/mta/range_proofs.rs:105-193
+//   mta::range_proofs::{BobProof::{generate, verify}, BobProofExt::verify}       src/utilities/mta/range_proofs.rs:218-534
 //   mta::{MessageA::a_with_predefined_randomness, MessageB::b_with_predefined_randomness,
 //         MessageB::verify_proofs_get_alpha}                                     src/utilities/mta/mod.rs:62-179
 //   zk_pdl_with_slack::PDLwSlackProof::{prove, verify}                           src/utilities/zk_pdl_with_slack/mod.rs:68-179
@@ -54,7 +55,7 @@ inline void check_hip(hipError_t e, const char* what) {
 }
 
 // widths in 32-bit words (mpecdsa_hip.h)
-enum : int { W_SCALAR = 8, W_POINT = 16, W_Q3 = 24, W_S1 = 25, W_PRIME = 32, W_N = 64, W_RHO = 72, W_GAMMA = 88, W_S2 = 89, W_NN = 128 };
+enum : int { W_SCALAR = 8, W_POINT = 16, W_Q3 = 24, W_S1 = 25, W_PRIME = 32, W_N = 64, W_RHO = 72, W_Q2N = 80, W_T1 = 81, W_GAMMA = 88, W_S2 = 89, W_NN = 128 };
 
 // item-major batch of fixed-width little-endian integers (or affine points x[8] | y[8]) on the host
 struct Batch {
@@ -260,6 +261,64 @@ struct AliceProof {
     check(mpe_alice_verify(ctx.get(), alice_ek.get(), stm.get(), B, ki.get(), si.get(), dc.get(), &p, ok.get(), nullptr), "mpe_alice_verify");
     ctx.sync();
     return ok.download();
+  }
+};
+
+// the values `BobProof::generate` samples (range_proofs.rs:236-244): alpha < q^3, beta in Z*_N, gamma < q^2 N, rho, sigma < q N~,
+// rho_prim, tau < q^3 N~
+struct BobNonces { Batch alpha, beta, gamma, rho, rho_prim, sigma, tau; };
+
+// `BobProof{t, z, e, s, s1, s2, t1, t2}`   range_proofs.rs:218-228
+struct BobProof {
+  Batch t, z, e, s, s1, s2, t1, t2;
+  // `BobProof::generate(a_encrypted, mta_encrypted, b, beta_prim, alice_ek, dlog_statement, r, check) -> (BobProof, Option<Point>)`
+  // range_proofs.rs:231-319.  check = true also returns u = alpha G and hashes X = b G, u into the challenge (`BobProofExt`, :414-424).
+  template <class Keys>
+  static std::pair<BobProof, Batch> generate(Context& ctx, const Keys& alice_ek, const zk_paillier::DLogStatements& stm, const Index& key_idx,
+                                             const Index& st_idx, const Batch& a_encrypted, const Batch& mta_encrypted, const Batch& b,
+                                             const Batch& beta_prim, const Batch& r, const BobNonces& nn, bool check_) {
+    const int B = (int)b.size();
+    Dev<uint32_t> ae = up(a_encrypted), me = up(mta_encrypted), db = up(b), bp = up(beta_prim), dr = up(r), al = up(nn.alpha), be = up(nn.beta),
+                  ga = up(nn.gamma), rh = up(nn.rho), rp = up(nn.rho_prim), sg = up(nn.sigma), ta = up(nn.tau);
+    Dev<uint32_t> t((size_t)B * W_N), z((size_t)B * W_N), e((size_t)B * W_SCALAR), s((size_t)B * W_N), s1((size_t)B * W_S1), s2((size_t)B * W_S2),
+                  t1((size_t)B * W_T1), t2((size_t)B * W_S2), u((size_t)B * W_POINT);
+    Dev<int32_t> ki(key_idx), si(st_idx);
+    const mpe_bob_nonces n{al.get(), be.get(), ga.get(), rh.get(), rp.get(), sg.get(), ta.get()};
+    const mpe_bob_proof p{t.get(), z.get(), e.get(), s.get(), s1.get(), s2.get(), t1.get(), t2.get()};
+    mpecdsa::check(mpe_bob_generate(ctx.get(), alice_ek.get(), stm.get(), B, ki.get(), si.get(), ae.get(), me.get(), db.get(), bp.get(), dr.get(), &n,
+                                    check_ ? 1 : 0, &p, check_ ? u.get() : nullptr, nullptr), "mpe_bob_generate");
+    ctx.sync();
+    return {BobProof{down(t, W_N), down(z, W_N), down(e, W_SCALAR), down(s, W_N), down(s1, W_S1), down(s2, W_S2), down(t1, W_T1), down(t2, W_S2)},
+            check_ ? down(u, W_POINT) : Batch()};
+  }
+  // `BobProof::verify(&self, a_enc, mta_avc_out, alice_ek, dlog_statement, check: Option<&BobCheck>) -> bool`   range_proofs.rs:321-412
+  // (X, u both null: `None`)
+  template <class Keys>
+  Flags verify(Context& ctx, const Keys& alice_ek, const zk_paillier::DLogStatements& stm, const Index& key_idx, const Index& st_idx,
+               const Batch& a_enc, const Batch& mta_avc_out, const Batch* X = nullptr, const Batch* u = nullptr) const {
+    const int B = (int)t.size();
+    Dev<uint32_t> dt = up(t), dz = up(z), de = up(e), ds = up(s), d1 = up(s1), d2 = up(s2), e1 = up(t1), e2 = up(t2), ae = up(a_enc), me = up(mta_avc_out);
+    std::unique_ptr<Dev<uint32_t>> dX, du;
+    if (X && u) { dX.reset(new Dev<uint32_t>(X->w)); du.reset(new Dev<uint32_t>(u->w)); }
+    Dev<int32_t> ki(key_idx), si(st_idx);
+    Dev<uint8_t> ok((size_t)B);
+    const mpe_bob_proof p{dt.get(), dz.get(), de.get(), ds.get(), d1.get(), d2.get(), e1.get(), e2.get()};
+    mpecdsa::check(mpe_bob_verify(ctx.get(), alice_ek.get(), stm.get(), B, ki.get(), si.get(), ae.get(), me.get(), &p, dX ? dX->get() : nullptr,
+                                  du ? du->get() : nullptr, ok.get(), nullptr), "mpe_bob_verify");
+    ctx.sync();
+    return ok.download();
+  }
+};
+
+// `BobProofExt{proof, u}`   range_proofs.rs:414-424, 499-534
+struct BobProofExt {
+  BobProof proof;
+  Batch u;
+  // `BobProofExt::verify(&self, a_enc, mta_avc_out, alice_ek, dlog_statement, X) -> bool`
+  template <class Keys>
+  Flags verify(Context& ctx, const Keys& alice_ek, const zk_paillier::DLogStatements& stm, const Index& key_idx, const Index& st_idx,
+               const Batch& a_enc, const Batch& mta_avc_out, const Batch& X) const {
+    return proof.verify(ctx, alice_ek, stm, key_idx, st_idx, a_enc, mta_avc_out, &X, &u);
   }
 };
 }  // namespace range_proofs

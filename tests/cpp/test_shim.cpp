@@ -2,6 +2,7 @@
 // run on the GPU, batched; every value the GPU returns is also compared bit for bit with the CPU oracle (oracle/mpe_oracle.h).
 //
 //   alice_zkp                          src/utilities/mta/range_proofs.rs:614-633
+//   bob_zkp                            src/utilities/mta/range_proofs.rs:636-709 (MtA with BobProof, MtAwc with BobProofExt)
 //   test_mta                           src/utilities/mta/test.rs:6-19            (alpha + beta == a * b)
 //   test_zk_pdl_with_slack             src/utilities/zk_pdl_with_slack/test.rs:12-68
 //   test_zk_pdl_with_slack_soundness   src/utilities/zk_pdl_with_slack/test.rs:70-129   (#[should_panic]: Enc(x + 1) must be refused)
@@ -97,6 +98,54 @@ static bool alice_zkp(Context& ctx, const Fixture& F, const EncryptionKeys& ek, 
   bad.s1.row(1)[0] ^= 1u;                                                     // a tampered proof is `false`, the rest of the batch stays `true`
   const Flags v = bad.verify(ctx, ek, stm, ki, si, cipher);
   for (int i = 0; i < B; ++i) REQUIRE(v[i] == (i == 1 ? 0 : 1));
+  return true;
+}
+
+// range_proofs.rs:636-709: the 5 x 5 iterations are one batch of 25 items (fresh a, b, beta_prim, r and proof nonces each)
+static bool bob_zkp(Context& ctx, const Fixture& F, const EncryptionKeys& alice_public_key, const DLogStatements& dlog_statement) {
+  const Batch &a = F["bz_a"], &b = F["bz_b"], &beta_prim = F["bz_beta_prim"], &r = F["bz_r"], &N = F["N"];
+  const Index ki = as_index(F["bz_key_idx"]), si = as_index(F["bz_st_idx"]);
+  const int B = (int)b.size();
+  // Simulate Alice: encrypted_a = Paillier::encrypt(alice_public_key, a)
+  const Batch encrypted_a = Paillier::encrypt_with_chosen_randomness(ctx, alice_public_key, ki, a, F["bz_r_enc_a"]);
+  // Bob follows MtA: E(a) * b + E(beta_prim; r)
+  const Batch b_times_enc_a = Paillier::mul(ctx, alice_public_key, ki, encrypted_a, b);
+  const Batch enc_beta_prim = Paillier::encrypt_with_chosen_randomness(ctx, alice_public_key, ki, beta_prim, r);
+  const Batch mta_out = Paillier::add(ctx, alice_public_key, ki, b_times_enc_a, enc_beta_prim);
+  const mta::range_proofs::BobNonces nn{F["bz_alpha"], F["bz_beta"], F["bz_gamma"], F["bz_rho"], F["bz_rho_prim"], F["bz_sigma"], F["bz_tau"]};
+  auto oracle_proof = [&](int check, mta::range_proofs::BobProof& w, Batch& u) {
+    w = mta::range_proofs::BobProof{Batch(B, W_N), Batch(B, W_N), Batch(B, W_SCALAR), Batch(B, W_N), Batch(B, W_S1), Batch(B, W_S2), Batch(B, W_T1),
+                                    Batch(B, W_S2)};
+    u = Batch(B, W_POINT);
+    orc_bob_generate(B, (int)N.size(), N.w.data(), (int)F["Nt"].size(), F["Nt"].w.data(), F["h1"].w.data(), F["h2"].w.data(), ki.data(), si.data(),
+                     encrypted_a.w.data(), mta_out.w.data(), b.w.data(), beta_prim.w.data(), r.w.data(), nn.alpha.w.data(), nn.beta.w.data(),
+                     nn.gamma.w.data(), nn.rho.w.data(), nn.rho_prim.w.data(), nn.sigma.w.data(), nn.tau.w.data(), check, w.t.w.data(), w.z.w.data(),
+                     w.e.w.data(), w.s.w.data(), w.s1.w.data(), w.s2.w.data(), w.t1.w.data(), w.t2.w.data(), check ? u.w.data() : nullptr);
+  };
+  auto same = [](const mta::range_proofs::BobProof& x, const mta::range_proofs::BobProof& y) {
+    return x.t == y.t && x.z == y.z && x.e == y.e && x.s == y.s && x.s1 == y.s1 && x.s2 == y.s2 && x.t1 == y.t1 && x.t2 == y.t2;
+  };
+  mta::range_proofs::BobProof want;
+  Batch want_u;
+  // let (bob_proof, _) = BobProof::generate(.., false);  assert!(bob_proof.verify(.., None));
+  auto [bob_proof, none] = mta::range_proofs::BobProof::generate(ctx, alice_public_key, dlog_statement, ki, si, encrypted_a, mta_out, b, beta_prim, r, nn, false);
+  oracle_proof(0, want, want_u);
+  REQUIRE(none.size() == 0 && same(bob_proof, want));
+  REQUIRE(all_ones(bob_proof.verify(ctx, alice_public_key, dlog_statement, ki, si, encrypted_a, mta_out)));
+  // Bob follows MtAwc: X = G * b;  BobProofExt { proof, u };  assert!(bob_proof.verify(.., &X));
+  const Batch X = ec_mul_base(ctx, b);
+  auto [proof, u] = mta::range_proofs::BobProof::generate(ctx, alice_public_key, dlog_statement, ki, si, encrypted_a, mta_out, b, beta_prim, r, nn, true);
+  oracle_proof(1, want, want_u);
+  REQUIRE(same(proof, want) && u == want_u);
+  const mta::range_proofs::BobProofExt ext{proof, u};
+  REQUIRE(all_ones(ext.verify(ctx, alice_public_key, dlog_statement, ki, si, encrypted_a, mta_out, X)));
+  // the plain proof does not pass as an extended one (its challenge lacks X, u), and a wrong X is refused item by item
+  const mta::range_proofs::BobProofExt mixed{bob_proof, u};
+  for (auto v : mixed.verify(ctx, alice_public_key, dlog_statement, ki, si, encrypted_a, mta_out, X)) REQUIRE(v == 0);
+  Batch wrongX = X;
+  std::memcpy(wrongX.row(3), X.row(4), 64);
+  const Flags v = ext.verify(ctx, alice_public_key, dlog_statement, ki, si, encrypted_a, mta_out, wrongX);
+  for (int i = 0; i < B; ++i) REQUIRE(v[i] == (i == 3 ? 0 : 1));
   return true;
 }
 
@@ -380,6 +429,7 @@ int main(int argc, char** argv) {
     DLogStatements stm(ctx, F["Nt"], F["h1"], F["h2"]);
     struct { const char* name; bool ok; } results[] = {
         {"alice_zkp", alice_zkp(ctx, F, ek, stm)},
+        {"bob_zkp", bob_zkp(ctx, F, ek, stm)},
         {"test_mta", test_mta(ctx, F, ek, dk, stm)},
         {"test_zk_pdl_with_slack", test_zk_pdl_with_slack(ctx, F, ek, ek, stm, false)},
         {"test_zk_pdl_with_slack_soundness", test_zk_pdl_with_slack(ctx, F, ek, ek, stm, true)},

@@ -54,6 +54,7 @@ def write_fixture(path, keys, B=6, seed="cpp-shim"):
         arrays["one_" + f] = F.words([n[f] for n in one], w)
         arrays["al_" + f] = F.words([n[f] for n in al], w)
         arrays["pdl_" + f] = F.words([n[f] for n in pd], w)
+    arrays.update(bob_zkp_case(keys, ek, st))
     arrays.update(state_machine_cases(keys))
     with open(path, "wb") as f:
         for name, arr in arrays.items():
@@ -83,4 +84,20 @@ def state_machine_cases(keys, B=2):
         msg[0] = F.words([int.from_bytes(hashlib.sha256(b"ZenGo").digest(), "big") % pyref.Q], 8)[0]
         for f in G.NONCE_FIELDS:
             out[pre + f] = msg if f == "msg" else nn[f]
+    return out
+
+
+def bob_zkp_case(keys, ek, st, B=25):
+    """`bob_zkp` (range_proofs.rs:636-709): 5 x 5 runs of MtA / MtAwc with fresh inputs = one batch of 25; "bz_<field>" arrays"""
+    r = F.Rng("cpp-bob-zkp")
+    rs = lambda: r.below(pyref.Q - 1) + 1
+    kidx = [i % len(ek) for i in range(B)]
+    sidx = [(i // 5) % len(st) for i in range(B)]
+    nn = [F.bob_nonces(r, ek[kidx[i]], st[sidx[i]]) for i in range(B)]
+    out = {"bz_key_idx": np.array(kidx, dtype=np.uint32).reshape(B, 1), "bz_st_idx": np.array(sidx, dtype=np.uint32).reshape(B, 1),
+           "bz_a": F.words([rs() for _ in range(B)], 64), "bz_r_enc_a": F.words([r.coprime_below(ek[k].N) for k in kidx], 64),
+           "bz_b": F.words([rs() for _ in range(B)], 8), "bz_beta_prim": F.words([r.below(ek[k].N) for k in kidx], 64),
+           "bz_r": F.words([r.coprime_below(ek[k].N) for k in kidx], 64)}
+    for f, w in (("alpha", 24), ("beta", 64), ("gamma", 80), ("rho", 72), ("rho_prim", 88), ("sigma", 72), ("tau", 88)):
+        out["bz_" + f] = F.words([n[f] for n in nn], w)
     return out
