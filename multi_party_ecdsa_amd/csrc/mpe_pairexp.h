@@ -256,59 +256,9 @@ __device__ __forceinline__ void cios1q(uint32_t (&res)[C::L], uint64_t (&c)[C::L
   cios_finish<C>(res, c, ln);
 }
 
-template <class C>
-__device__ __forceinline__ void cios2q(uint32_t (&res)[C::L], uint64_t (&c)[C::L], const uint32_t (&a0)[C::L],
-                                       const uint32_t (&a1)[C::L], const uint32_t* __restrict__ bl0,
-                                       const uint32_t* __restrict__ bl1, const uint32_t (&n)[C::L], uint32_t n0inv,
-                                       const Lane& ln) {
-  constexpr int L = C::L, W = C::W;
-  static_assert(bq_layout_ok<C>(), "cios2q needs L % 6 == 0");
-  uint32_t maskv = C::MASK;
-  asm volatile("" : "+v"(maskv));
-  // two streams: pair h of stream 0 in x(h % 3), of stream 1 in y(h % 3); reads are issued x then y, so when pair h is due the
-  // reads younger than (x_h, y_h) are x_(h+1), y_(h+1), x_(h+2), y_(h+2): four may stay in flight
-  uint64_t x0, x1, x2, y0, y1, y2;
-  asm volatile("" : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(y0), "=v"(y1), "=v"(y2));
-  const uint32_t base0 = lds_byte_address(bl0), base1 = lds_byte_address(bl1);
-  bq_issue<0>(x0, base0); bq_issue<0>(y0, base1);
-  bq_issue<8>(x1, base0); bq_issue<8>(y1, base1);
-#pragma unroll 1
-  for (int jj = 0;; ++jj) {
-    const uint32_t at0 = base0 + (uint32_t)(jj * L * 4), at1 = base1 + (uint32_t)(jj * L * 4);
-    auto step = [&](auto rc) {
-      constexpr int r = decltype(rc)::value;
-      constexpr int h = r / 2;
-      if constexpr (r % 2 == 0) {
-        if constexpr ((h + 2) % 3 == 0) { bq_issue<8 * (h + 2)>(x0, at0); bq_issue<8 * (h + 2)>(y0, at1); }
-        else if constexpr ((h + 2) % 3 == 1) { bq_issue<8 * (h + 2)>(x1, at0); bq_issue<8 * (h + 2)>(y1, at1); }
-        else { bq_issue<8 * (h + 2)>(x2, at0); bq_issue<8 * (h + 2)>(y2, at1); }
-        // four younger reads (x, y of pairs h+1, h+2) may stay in flight
-        if constexpr (h % 3 == 0) bq_wait<4>(x0, y0); else if constexpr (h % 3 == 1) bq_wait<4>(x1, y1); else bq_wait<4>(x2, y2);
-      }
-      const uint64_t xv = (h % 3 == 0) ? x0 : ((h % 3 == 1) ? x1 : x2), yv = (h % 3 == 0) ? y0 : ((h % 3 == 1) ? y1 : y2);
-      const uint32_t b0j = (r & 1) ? (uint32_t)(xv >> 32) : (uint32_t)xv, b1j = (r & 1) ? (uint32_t)(yv >> 32) : (uint32_t)yv;
-      c[r] += (uint64_t)a0[0] * b1j;
-      c[r] += (uint64_t)a1[0] * b0j;
-      const uint32_t m = bcast0_masked<C::TPI>((uint32_t)c[r] * n0inv, maskv);
-#pragma unroll
-      for (int i = 1; i < L; ++i) {
-        c[(r + i) % L] += (uint64_t)a0[i] * b1j;
-        c[(r + i) % L] += (uint64_t)a1[i] * b0j;
-      }
-#pragma unroll
-      for (int i = 0; i < L; ++i) c[(r + i) % L] += (uint64_t)m * n[i];
-      c[(r + 1) % L] += c[r] >> W;
-      c[r] = (uint64_t)(pull_next((uint32_t)c[r]) & maskv);
-    };
-    static_for<0, C::STEPS % L>(step);
-    if (jj == C::STEPS / L) break;
-    static_for<C::STEPS % L, L>(step);
-  }
-  bq_wait<0>(x0, y0);
-  bq_wait<0>(x1, y1);
-  bq_wait<0>(x2, y2);
-  cios_finish<C>(res, c, ln);
-}
+// (The two-stream pass has no queued form: six live 64-bit slots do not survive the register allocator at 256 VGPRs — the checker
+// found copies of registers whose read was still in flight in every attempt, profiles/r04/README.md — so multiplications keep
+// cios2 under MPE_BQ.)
 
 // (r0, r1) = (a0, a1) * (y0, y1) R^-1 in Z/N^2.  The group's LDS region holds y0 in B0 and y1 in B1; for a squaring
 // (sq: y == a) B1 holds 2 y0 instead, so that pass B is the single stream a1 * (2 a0).
@@ -353,11 +303,7 @@ __device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::
     if (sq) {
       cios1q<C, false>(r1, c, a1, gl + PL::B1, gl + PL::M, n, n0inv, ln);     // pass B: a1 * (2 a0) - m
     } else {
-#ifdef MPE_BQ2
-      cios2q<C>(r1, c, a0, a1, gl + PL::B0, gl + PL::B1, n, n0inv, ln);       // pass B: a0 * y1 + a1 * y0 - m
-#else
-      cios2<C>(r1, c, a0, a1, gl + PL::B0, gl + PL::B1, n, n0inv, ln);
-#endif
+      cios2<C>(r1, c, a0, a1, gl + PL::B0, gl + PL::B1, n, n0inv, ln);        // pass B: a0 * y1 + a1 * y0 - m
     }
   } else
 #endif

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static check of the hand-issued multiplier reads of mpe_pairexp.h (cios1q / cios2q, MPE_BQ) in the EMITTED ISA.
+"""Static check of the hand-issued multiplier reads of mpe_pairexp.h (cios1q, MPE_BQ) in the EMITTED ISA.
 
 A `ds_read_b64 vD, ... ; BQ_ISSUE vD` lands in its destination some hundred cycles later; hipcc does not know (the read is an
 asm statement) and the program is only correct if NOTHING touches vD until the matching `s_waitcnt ... ; BQ_WAIT vD`: no read,
