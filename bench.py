@@ -715,6 +715,174 @@ def lindell_section(ctx, E, keys, F, cpu=True):
     return out
 
 
+def blame_section(ctx, E, G, keys, F, gen, B=4096, cpu=True, sample=16):
+    """identifiable abort (gg_2020/blame.rs) at scale.  B sessions (t=1, n=3, two signers) run on the round
+    engine with signer 0 corrupted the way the reference's own tests corrupt it (`mpe_gg20_session_fault_inject`: delta_i, sigma_i
+    or s_i doubled, gg_2020/test.rs:282-289,458-465,679-686); the failing check is the reference's (502 / 602 / 701) in every
+    session; then the openings every signer publishes go through `mpe_gg20_blame5/6/7`, which must name exactly signer 0 in every
+    session.  Timed: the blame calls alone (the openings are protocol traffic).  Phase-6 openings come from the device itself
+    (`mpe_gg20_session_blame6_state`, `mpe_paillier_open`), as a party would produce them.  Oracle: the first `sample` sessions."""
+    import pyref
+    dev = ctx.device
+    t, n, signers, S, P1, mask = 1, 3, [0, 1], 2, 1, 0b01
+    lk = G.make_local_keys(keys, t, n, signers)
+    gk = E.Gg20Keys(ctx, t, n, signers, lk["arrays"])
+    dn = make_device_nonces(gen, dev, B, S, S, n)
+    hn = _host(dn)
+    to_dev = lambda d: {f: torch.from_numpy(np.ascontiguousarray(v).view(np.int32)).to(dev) for f, v in d.items()}
+    head = lambda d, cnt: {f: np.ascontiguousarray(v[: cnt * (v.shape[0] // B)]) for f, v in d.items()}
+    out = {"sessions": B, "t": t, "n": n, "corrupted_signer": 0}
+
+    def run_faulty(step):
+        sess = E.Gg20Session(ctx, gk, B, list(range(S)), dn)
+        sess.fault_inject(step, mask)
+        slabs, prev = {}, None
+        for rnd in range(9):
+            o = sess.round(rnd, d_in=prev, msg=dn["msg"] if rnd == 7 else None)
+            if o is not None:
+                slabs[rnd] = o.cpu().numpy().view(np.uint32)
+                prev = o.reshape(-1)
+        res = sess.result()
+        torch.cuda.synchronize()
+        return sess, slabs, res
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, got.cpu().numpy().view(np.uint32)
+
+    def oracle(which, o):
+        if not cpu:
+            return {}
+        t0 = time.perf_counter()
+        want = G.oracle_blame(lk, which, head(o, sample), sample)
+        return {"oracle_sessions_per_s_1_thread": sample / (time.perf_counter() - t0), "want": want}
+
+    tr = lambda a: np.ascontiguousarray(np.transpose(a, (1, 0, 2)).reshape(B * S, a.shape[2]))          # [S][B][w] -> [B][S] rows
+    # phase 5 (blame.rs:116-224)
+    sess, slabs, res = run_faulty(5)
+    st5 = res["status"].cpu().numpy()
+    o5 = G.blame5_opened(lk, hn, slabs, B)
+    d5 = to_dev(o5)
+    dt, got = timed(lambda: E.gg20_blame5(ctx, gk, B, d5))
+    orc5 = oracle("b5", o5)
+    out["blame5"] = {"sessions_per_s": B / dt, "failing_check_is_502_everywhere": bool((st5 == 502).all()), "names_exactly_the_corrupted_signer": bool((got == mask).all())}
+    sess.close()
+    # phase 6 (blame.rs:322-421)
+    sess, slabs, res = run_faulty(6)
+    st6 = res["status"].cpu().numpy()
+    en = _scalar(gen, dev, B * S)
+    miu, a1, a2, z = sess.blame6_state(en)
+    dtr = lambda x: x.transpose(0, 1).reshape(B * S, -1).contiguous()
+    cb = G.blame6_cb(lk, slabs, B)
+    d_cb = torch.from_numpy(cb.view(np.int32)).to(dev)
+    sk_all = E.PaillierKeys(ctx, p=[k.p for k in lk["keys"]], q=[k.q for k in lk["keys"]])
+    kx = torch.tensor([signers[(r_ // P1) % S] for r_ in range(B * S * P1)], dtype=torch.int32, device=dev)
+    om, orr = E.paillier_open(ctx, sk_all, d_cb, kx)
+    torch.cuda.synchronize()
+    opens_agree = bool(torch.equal(om.reshape(-1, 64), miu.transpose(0, 1).reshape(-1, 64)))
+    d6 = dict(k=dn["k"], k_rand=dn["r_a"], miu=om, miu_rand=orr, a1=dtr(a1), a2=dtr(a2), z=dtr(z),
+              S=torch.from_numpy(tr(slabs[5][:, :, 0:16]).view(np.int32)).to(dev),
+              c_a=torch.from_numpy(tr(slabs[0][:, :, n * 256:n * 256 + 128]).view(np.int32)).to(dev), c_b=d_cb, R=res["R"][0].contiguous())
+    dt, got = timed(lambda: E.gg20_blame6(ctx, gk, B, d6))
+    o6 = {f: v.cpu().numpy().view(np.uint32) for f, v in d6.items()}
+    orc6 = oracle("b6", o6)
+    out["blame6"] = {"sessions_per_s": B / dt, "failing_check_is_602_everywhere": bool((st6 == 602).all()), "names_exactly_the_corrupted_signer": bool((got == mask).all()),
+                     "paillier_open_equals_the_sessions_own_miu": opens_agree}
+    got6 = got
+    sess.close()
+    # phase 7 (blame.rs:434-454)
+    sess, slabs, res = run_faulty(7)
+    st7 = res["status"].cpu().numpy()
+    Rr = res["R"][0].cpu().numpy().view(np.uint32)
+    o7 = dict(s=tr(slabs[7]), r=F.words([x % pyref.Q for x in F.ints(np.ascontiguousarray(Rr[:, :8]))], 8), R_dash=tr(slabs[4][:, :, 450 * (S - 1):450 * (S - 1) + 16]),
+              m=hn["msg"].copy(), R=Rr, S=tr(slabs[5][:, :, 0:16]))
+    d7 = to_dev(o7)
+    dt, got7 = timed(lambda: E.gg20_blame7(ctx, S, B, d7))
+    orc7 = oracle("b7", o7)
+    out["blame7"] = {"sessions_per_s": B / dt, "failing_check_is_701_everywhere": bool((st7 == 701).all()), "names_exactly_the_corrupted_signer": bool((got7 == mask).all())}
+    sess.close()
+    if cpu:
+        got5 = E.gg20_blame5(ctx, gk, B, d5).cpu().numpy().view(np.uint32)
+        for name, o_, g_ in (("blame5", orc5, got5), ("blame6", orc6, got6), ("blame7", orc7, got7)):
+            out[name]["oracle_sessions_per_s_1_thread"] = o_["oracle_sessions_per_s_1_thread"]
+            out[name]["parity_vs_oracle_on_sample"] = bool(list(o_["want"]) == list(g_[:sample]))
+        out["oracle_sample"] = sample
+    sk_all.close()
+    gk.close()
+    return out
+
+
+def keygen_verify_section(ctx, E, keys, F, B=8192, cpu=True):
+    """what every party checks about every other party's keygen messages (party_i.rs:260-438), batched over
+    (verifier, prover) pairs: `NiCorrectKeyProof::verify` (11 modular exponentiations with a 2048-bit exponent per proof),
+    `CompositeDLogProof::verify`, Feldman `validate_share`.  16 provers' real proofs (the oracle's prove side) tiled to B items, 1 %
+    of them corrupted: those and only those are refused.  Oracle: the 16 distinct items on one thread."""
+    import keygen_fixture as KF
+    import orc
+    dev = ctx.device
+    K, reps = len(keys), B // len(keys)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    bad_rows = np.arange(7, B, 100)
+    out = {"items": B, "corrupted": int(len(bad_rows))}
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ok = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, ok.cpu().numpy()
+
+    def verdict(ok):
+        want = np.ones(B, dtype=np.uint8)
+        want[bad_rows] = 0
+        return bool(np.array_equal(ok.astype(np.uint8), want))
+
+    N, sigma = KF.correct_key_case(keys)
+    Nb, sb = np.tile(N, (reps, 1)), np.tile(sigma.reshape(K, 11 * 64), (reps, 1))
+    sb[bad_rows, 64 * 3 + 5] ^= 2
+    dN, ds = up(Nb), up(sb.reshape(-1, 64))
+    dt, ok = timed(lambda: E.correct_key_verify(ctx, dN, ds))
+    out["correct_key_verify_per_s"] = B / dt
+    out["correct_key_exactly_the_corrupted_refused"] = verdict(ok)
+    Nw, gw, nw, x, y = KF.composite_dlog_case(keys)
+    tiles = [np.tile(a, (reps, 1)) for a in (Nw, gw, nw, x, y)]
+    tiles[4][bad_rows, 70] ^= 1
+    dc = [up(a) for a in tiles]
+    dt, ok = timed(lambda: E.composite_dlog_verify(ctx, *dc))
+    out["composite_dlog_verify_per_s"] = B / dt
+    out["composite_dlog_note"] = "every item brings its own modulus: its Montgomery constants and the two inversions of the gcd checks are part of the call"
+    out["composite_dlog_exactly_the_corrupted_refused"] = verdict(ok)
+    t_, n_, dealers = 2, 5, 16
+    commits, shares, index, _ = KF.vss_case(t_, n_, dealers, seed="bench-vss")
+    rv = B // (dealers * n_) + 1
+    cm, sh, ix = np.tile(commits, (rv, 1))[:B], np.tile(shares, (rv, 1))[:B], np.tile(index, rv)[:B]
+    sh = sh.copy()
+    sh[bad_rows, 1] ^= 1
+    dv = (up(cm), up(sh), torch.from_numpy(np.ascontiguousarray(ix, dtype=np.int32)).to(dev))
+    dt, ok = timed(lambda: E.vss_validate_share(ctx, t_ + 1, *dv))
+    out["vss_validate_share_per_s"] = B / dt
+    out["vss_exactly_the_corrupted_refused"] = verdict(ok)
+    if cpu:
+        w = np.zeros(K, dtype=np.uint8)
+        t0 = time.perf_counter()
+        orc.lib.orc_correct_key_verify(K, orc._p(N), orc._p(sigma), orc._p(w))
+        out["oracle_correct_key_verify_per_s_1_thread"] = K / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        orc.lib.orc_composite_dlog_verify(K, *[orc._p(a) for a in (Nw, gw, nw, x, y, w)])
+        out["oracle_composite_dlog_verify_per_s_1_thread"] = K / (time.perf_counter() - t0)
+        wv = np.zeros(dealers * n_, dtype=np.uint8)
+        t0 = time.perf_counter()
+        orc.lib.orc_vss_validate_share(dealers * n_, t_ + 1, orc._p(commits), orc._p(shares), orc._p(index), orc._p(wv))
+        out["oracle_vss_validate_share_per_s_1_thread"] = dealers * n_ / (time.perf_counter() - t0)
+        out["oracle_accepts_the_uncorrupted_items"] = bool(w.all() and wv.all())
+    return out
+
+
 class GpuRoundEngine:
     """dist.PartySharded engine over mpe_gg20_roundN: one session object per session block, local = the parties this rank
     hosts; the object lives across steps (mpe_gg20_session_rearm) and writes its records into the gather buffer"""
@@ -1206,7 +1374,11 @@ def main():
                 if only and not any(name.startswith(o) for o in only):
                     return
                 t_ = time.perf_counter()
-                cfg[name] = fn()
+                try:
+                    cfg[name] = fn()
+                except Exception as e_:                      # a secondary section never takes the headline line down: it reports its failure
+                    import traceback
+                    cfg[name] = {"error": f"{type(e_).__name__}: {e_}", "where": traceback.format_exc().strip().splitlines()[-3:]}
                 took[name] = round(time.perf_counter() - t_, 2)
             section("c2_paillier_65536", lambda: paillier_config2(ctx, E, keys, F, oracle_threads=0 if args.no_cpu_baseline else threads))
             section("c3_ec_pdl_262144", lambda: config3(ctx, E, keys, F, oracle=not args.no_cpu_baseline))
@@ -1239,6 +1411,8 @@ def main():
                                                               openssl=True))
             section("c4_multi_wallet_16384", lambda: [multi_wallet(ctx, E, G, keys, K_, 16384, gen) for K_ in (16, 1024)])
             section("lindell17", lambda: lindell_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline))
+            section("f2_blame_4096", lambda: blame_section(ctx, E, G, keys, F, gen, cpu=not args.no_cpu_baseline))
+            section("f3_keygen_verify_8192", lambda: keygen_verify_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline))
             if "lindell17" in cfg:
                 res["lindell17"] = cfg.pop("lindell17")
             res["configs"] = cfg

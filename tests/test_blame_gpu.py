@@ -145,3 +145,19 @@ def test_paillier_open_matches_oracle(gpu_ctx, keys):
     assert [i for i in range(B) if not np.array_equal(grw[i], wr[i])] == []
     for i in range(18):
         assert F.ints(wm[i:i + 1])[0] == m[i] and F.ints(wr[i:i + 1])[0] == rr[i]
+
+
+def test_blame_at_scale_the_bench_section(gpu_ctx, keys):
+    """bench.py's `f2_blame_4096` section at 96 sessions: every session fails with the reference's status after the injected
+    fault, the three blame calls name exactly the corrupted signer everywhere, the phase-6 openings a party derives on the device
+    (Paillier::open of what it received) equal its own miu, and the first sessions equal the oracle's blame"""
+    import bench
+    from multi_party_ecdsa_amd import engine as E
+    gen = torch.Generator(device=gpu_ctx.device)
+    gen.manual_seed(7)
+    res = bench.blame_section(gpu_ctx, E, G, keys, F, gen, B=96, cpu=True, sample=6)
+    for ph, code in (("blame5", 502), ("blame6", 602), ("blame7", 701)):
+        r = res[ph]
+        assert r[f"failing_check_is_{code}_everywhere"] and r["names_exactly_the_corrupted_signer"] and r["parity_vs_oracle_on_sample"], (ph, r)
+        assert r["sessions_per_s"] > 0
+    assert res["blame6"]["paillier_open_equals_the_sessions_own_miu"]

@@ -79,3 +79,14 @@ def test_keygen_prove_side_vs_oracle(gpu_ctx, keys):
     gpu_ctx.sync()
     assert np.array_equal(x.cpu().numpy().view(np.uint32), wx) and np.array_equal(y.cpu().numpy().view(np.uint32), wy)
     assert list(E.composite_dlog_verify(gpu_ctx, _dev(gpu_ctx, Nw), _dev(gpu_ctx, gw), _dev(gpu_ctx, nw), x, y).cpu().numpy()) == [1] * len(keys)
+
+
+def test_keygen_verification_at_scale_the_bench_section(gpu_ctx, keys):
+    """bench.py's `f3_keygen_verify_8192` section at 800 items: exactly the corrupted 1 % are refused by each of the three checks"""
+    import bench
+    from multi_party_ecdsa_amd import engine as E
+    res = bench.keygen_verify_section(gpu_ctx, E, keys, F, B=800, cpu=True)
+    assert res["corrupted"] == 8
+    for f in ("correct_key", "composite_dlog", "vss"):
+        assert res[f + "_exactly_the_corrupted_refused"], (f, res)
+    assert res["oracle_accepts_the_uncorrupted_items"]
