@@ -855,7 +855,7 @@ def keygen_verify_section(ctx, E, keys, F, B=8192, cpu=True):
     dc = [up(a) for a in tiles]
     dt, ok = timed(lambda: E.composite_dlog_verify(ctx, *dc))
     out["composite_dlog_verify_per_s"] = B / dt
-    out["composite_dlog_note"] = "every item brings its own modulus: its Montgomery constants and the two inversions of the gcd checks are part of the call"
+    out["composite_dlog_note"] = "every item brings its own modulus: its Montgomery constants and the inversion behind the gcd checks are part of the call"
     out["composite_dlog_exactly_the_corrupted_refused"] = verdict(ok)
     t_, n_, dealers = 2, 5, 16
     commits, shares, index, _ = KF.vss_case(t_, n_, dealers, seed="bench-vss")

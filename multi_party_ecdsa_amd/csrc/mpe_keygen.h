@@ -259,13 +259,12 @@ int mpe_composite_dlog_verify(mpe_ctx* ctx, int batch, const uint32_t* d_N, cons
   if (rc != MPE_OK) { mpe_modset_destroy(ms); return rc; }
   Seq q{ctx, st, batch};
   const Rows sel = rows(nullptr, 1);                                    // modulus i for item i
-  uint8_t *ok1 = q.flags(), *ok2 = q.flags();
+  uint8_t* ok1 = q.flags();
   hipLaunchKernelGGL(kg::cd_n_check_kernel, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, d_N, d_ok);
-  // gcd(g, N) == gcd(ni, N) == 1: through the inversions (their ok flags)
-  uint32_t* gr = q.modmul(ms, sel, rows(d_g, 64), rows(ms->one_words, 0, nullptr, 1));
-  uint32_t* nr = q.modmul(ms, sel, rows(d_ni, 64), rows(ms->one_words, 0, nullptr, 1));
-  (void)q.modinv(ms, sel, rows(gr, 64), ok1);
-  (void)q.modinv(ms, sel, rows(nr, 64), ok2);
+  // gcd(g, N) == gcd(ni, N) == 1  <=>  g ni is a unit modulo N: ONE inversion per item (its ok flag), not two — the moduli differ
+  // per item, so the inversions cannot share a Montgomery batch and are the larger part of this call
+  uint32_t* gn = q.modmul(ms, sel, rows(d_g, 64), rows(d_ni, 64));
+  (void)q.modinv(ms, sel, rows(gn, 64), ok1);
   // e = H(x, g, N, ni);  x == g^y ni^e mod N
   uint32_t* e = q.words(8);
   HashDesc d;
@@ -276,7 +275,7 @@ int mpe_composite_dlog_verify(mpe_ctx* ctx, int batch, const uint32_t* d_N, cons
   uint32_t* gy = q.modexp(ms, sel, rows(d_g, 64), rows(d_y, 73), 73);
   uint32_t* ne = q.modexp(ms, sel, rows(d_ni, 64), rows(e, 8), 8);
   uint32_t* pr = q.modmul(ms, sel, rows(gy, 64), rows(ne, 64));
-  if (q.rc == MPE_OK) hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, d_ok, ok1, ok2, pr, rows(d_x, 64), 64);
+  if (q.rc == MPE_OK) hipLaunchKernelGGL(and_flags_kernel, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, d_ok, ok1, (const uint8_t*)nullptr, pr, rows(d_x, 64), 64);
   rc = q.finish("mpe_composite_dlog_verify");
   (void)hipStreamSynchronize(st);
   mpe_modset_destroy(ms);
