@@ -1361,6 +1361,30 @@ def main():
             res["parity_vs_oracle_on_sample"] = parity
             res["parity_sample"] = sample
         if single:
+            # A host that hands its sampled values over for every batch instead of keeping them resident: the measured cost of moving
+            # the step's inputs in (pinned host memory -> HBM) and its signatures out.  Reported beside the line, never part of `value`.
+            try:
+                pinned = {f: torch.empty(v.shape, dtype=v.dtype, pin_memory=True).copy_(v) for f, v in nonces.items()}
+                outs = [torch.empty((B, 8), dtype=torch.int32, device=dev), torch.empty((B, 8), dtype=torch.int32, device=dev),
+                        torch.empty((B,), dtype=torch.int32, device=dev)]
+                host_out = [torch.empty(o.shape, dtype=o.dtype, pin_memory=True) for o in outs]
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for f, v in pinned.items():
+                    nonces[f].copy_(v, non_blocking=True)
+                for o, h in zip(outs, host_out):
+                    h.copy_(o, non_blocking=True)
+                torch.cuda.synchronize()
+                io_s = time.perf_counter() - t1
+                nin = sum(v.numel() * 4 for v in pinned.values())
+                nout = sum(o.numel() * 4 for o in outs)
+                step_s = elapsed / args.steps
+                res["host_handover"] = {"bytes_in_per_step": nin, "bytes_out_per_step": nout, "seconds": io_s, "GB_per_s": (nin + nout) / io_s / 1e9,
+                                        "signatures_per_s_if_not_overlapped": B / (step_s + io_s), "share_of_step": io_s / step_s,
+                                        "note": "pinned host memory over PCIe, serial with the step; `value` has its inputs resident in HBM"}
+                del pinned, host_out, outs
+            except RuntimeError as e_:
+                res["host_handover"] = {"error": str(e_)}
             # every signature of the timed batch under OpenSSL (not only "status == 0", which is the device's own verdict)
             res["openssl"] = openssl_verify_all(lk["arrays"]["y"][0], nonces["msg"], r, s, threads)
             res["openssl_verified"] = res["openssl"]["openssl_verified"]
