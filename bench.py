@@ -982,6 +982,39 @@ class PartyMode:
             e_.keys.close()
 
 
+def stream_child(args, device_index):
+    """`c4_stream_1024` in a CHILD process.  A signing service keeps several batches in flight on separate streams; the HIP runtime
+    multiplexes the streams of a process onto 4 hardware queues by default and streams that share a queue serialize.  Measured on this
+    section, 48 batches per run (profiles/r04/stream_sweep*.log): 4 queues 9.3 k signatures/s, 8 queues 11.1 k, 16 queues 12.6 k (3 in
+    flight) .. 14.1 k (10 in flight).  GPU_MAX_HW_QUEUES must be set before the runtime initialises, hence the child — and the DEVICE
+    has about 20 hardware queues for all processes together (20 or more in one process abort inside the runtime with
+    HSA_STATUS_ERROR_OUT_OF_RESOURCES; so does 16 here plus the 4 of a parent that has already used its own: seen once in round 4),
+    so main() runs this BEFORE it creates its own context, and a child that aborts is retried with fewer queues.  A failure is
+    reported in the section and cannot take the line down."""
+    import subprocess
+    tried = []
+    for queues in dict.fromkeys([args.stream_hw_queues, 12, 8]):
+        env = dict(os.environ)
+        env["GPU_MAX_HW_QUEUES"] = str(queues)
+        cmd = [sys.executable, os.path.abspath(__file__), "--stream-child", "--stream-inflight", str(args.stream_inflight), "--stream-batches",
+               str(args.stream_batches), "--device", str(device_index)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + \
+              (["--share-hint"] if args.share_hint else [])
+        try:
+            p_ = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        except subprocess.TimeoutExpired:
+            tried.append({"hw_queues": queues, "error": "child timed out"})
+            continue
+        lines_ = [ln for ln in p_.stdout.splitlines() if ln.startswith("{")]
+        if p_.returncode == 0 and lines_:
+            out = json.loads(lines_[-1])
+            out["hw_queues"] = queues
+            if tried:
+                out["failed_attempts"] = tried
+            return out
+        tried.append({"hw_queues": queues, "error": f"child exited {p_.returncode}", "stderr_tail": p_.stderr[-300:]})
+    return {"error": "every attempt failed", "attempts": tried}
+
+
 def respawn_under_torchrun(n, argv):
     """`python bench.py --gpus N` with no torch.distributed environment: this process becomes the launcher of N ranks, one
     per GPU (the same command line the driver would use), and exits with their status; rank 0 prints the JSON line."""
@@ -1081,9 +1114,17 @@ def main():
     from multi_party_ecdsa_amd import dist as mpe_dist
     from multi_party_ecdsa_amd import engine as E
     keys = F.load_keys()
+    T, N_PARTIES = args.t, args.n
+    early_stream = None
+    only_ = [x for x in args.only.split(",") if x]
+    if world == 1 and not distributed and args.mode == "session" and not args.no_configs and (T, N_PARTIES) == (1, 3) and \
+            (not only_ or any("c4_stream_1024".startswith(o) for o in only_)):
+        # before this process owns any hardware queue (see stream_child); sequential with everything timed below
+        t_ = time.perf_counter()
+        early_stream = stream_child(args, local_rank)
+        early_stream = (early_stream, round(time.perf_counter() - t_, 2))
     ctx = E.Context(local_rank)
     dev = ctx.device
-    T, N_PARTIES = args.t, args.n
     SIGNERS = list(range(T + 1))                               # parties 1..t+1 sign
     B, S, n = args.sessions, len(SIGNERS), N_PARTIES
     lk = G.make_local_keys(keys, T, N_PARTIES, SIGNERS)
@@ -1409,28 +1450,10 @@ def main():
             section("c3b_bob_65536", lambda: bob_section(ctx, E, keys, F, oracle=not args.no_cpu_baseline))
             section("c4_literal_1024", lambda: gg20_config(ctx, E, G, keys, 1, 3, 1024, 4, gen, parity_sample=0 if args.no_cpu_baseline else 128,
                                                            openssl=True))
-            def stream_section():
-                # A signing service keeps several batches in flight on separate streams; the HIP runtime multiplexes the streams of a
-                # process onto 4 hardware queues by default and streams that share a queue serialize.  Measured on this section, 48
-                # batches per run (profiles/r04/stream_sweep*.log): 4 queues 9.3 k signatures/s, 8 queues 11.1 k, 16 queues 12.6 k (3 in
-                # flight) .. 14.1 k (10 in flight); 20 or more abort inside the runtime (HSA_STATUS_ERROR_OUT_OF_RESOURCES).  The variable
-                # must be set before the runtime initialises, so the section runs in a CHILD process (this one keeps the defaults; a
-                # failure of the child is reported here and cannot take the line down).
-                import subprocess
-                env = dict(os.environ)
-                env["GPU_MAX_HW_QUEUES"] = str(args.stream_hw_queues)
-                cmd = [sys.executable, os.path.abspath(__file__), "--stream-child", "--stream-inflight", str(args.stream_inflight), "--stream-batches",
-                       str(args.stream_batches), "--device", str(local_rank)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + \
-                      (["--share-hint"] if args.share_hint else [])
-                try:
-                    p_ = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-                    lines_ = [ln for ln in p_.stdout.splitlines() if ln.startswith("{")]
-                    if p_.returncode != 0 or not lines_:
-                        return {"error": f"child exited {p_.returncode}", "stderr_tail": p_.stderr[-400:]}
-                    return json.loads(lines_[-1])
-                except subprocess.TimeoutExpired:
-                    return {"error": "child timed out"}
-            section("c4_stream_1024", stream_section)
+            if early_stream is not None:
+                cfg["c4_stream_1024"], took["c4_stream_1024"] = early_stream
+            else:                                            # under a launcher the process group came first: run it here, with the retries
+                section("c4_stream_1024", lambda: stream_child(args, local_rank))
             section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32,
                                                               openssl=True))
             section("c4_multi_wallet_16384", lambda: [multi_wallet(ctx, E, G, keys, K_, 16384, gen) for K_ in (16, 1024)])
