@@ -12,6 +12,8 @@
 //         MessageB::verify_proofs_get_alpha}                                     src/utilities/mta/mod.rs:62-179
 //   zk_pdl_with_slack::PDLwSlackProof::{prove, verify}                           src/utilities/zk_pdl_with_slack/mod.rs:68-179
 //   curv DLogProof::{prove, verify}                                              mta/mod.rs:147-148,170-171
+//   two_party_ecdsa::lindell_2017::{party_two::PartialSig::compute, party_one::Signature::compute_with_recid}
+//                                                                                 src/protocols/two_party_ecdsa/lindell_2017/party_two.rs:390-423, party_one.rs:519-565
 //   gg_2020::state_machine::sign::{OfflineStage, CompletedOfflineStage, SignManual}  gg_2020/state_machine/sign.rs:66-330,540-646
 //       (one party of `batch` concurrent signing sessions: `RoundN::proceed`, state_machine/sign/rounds.rs:68-692)
 //
@@ -442,6 +444,51 @@ inline Batch ec_mul_base(Context& ctx, const Batch& k) {
   ctx.sync();
   return down(o, W_POINT);
 }
+
+// ---- Lindell'17 two-party ECDSA, signing ----------------------------------------------------------------------------------------
+namespace two_party_ecdsa {
+namespace lindell_2017 {
+namespace party_two {
+// `PartialSig{c3}`   party_two.rs:383-388
+struct PartialSig {
+  Batch c3;
+  // `PartialSig::compute(ek, encrypted_secret_share, local_share, ephemeral_local_share, ephemeral_other_public_share, message)`
+  // party_two.rs:390-423.  ek = party ONE's Paillier key; x2 = party two's share, k2 its ephemeral secret, R1 = party one's ephemeral
+  // public share; rho (< q^2) and r (the randomness Paillier::encrypt draws) are what the reference samples.
+  template <class Keys>
+  static PartialSig compute(Context& ctx, const Keys& ek, const Index& key_idx, const Batch& encrypted_secret_share, const Batch& x2, const Batch& k2,
+                            const Batch& R1, const Batch& message, const Batch& rho, const Batch& r) {
+    const int B = (int)x2.size();
+    Dev<uint32_t> ck = up(encrypted_secret_share), dx = up(x2), dk = up(k2), dR = up(R1), dm = up(message), drho = up(rho), dr = up(r), c3((size_t)B * W_NN);
+    Dev<int32_t> ki(key_idx);
+    check(mpe_lindell_partial_sig(ctx.get(), ek.get(), B, ki.get(), ck.get(), dx.get(), dk.get(), dR.get(), dm.get(), drho.get(), dr.get(), c3.get(),
+                                  nullptr), "mpe_lindell_partial_sig");
+    ctx.sync();
+    return PartialSig{down(c3, W_NN)};
+  }
+};
+}  // namespace party_two
+namespace party_one {
+// `SignatureRecid{s, r, recid}`   party_one.rs:106-111
+struct SignatureRecid {
+  Batch r, s;
+  std::vector<int32_t> recid;
+  // `Signature::compute_with_recid(party_one_private, partial_sig_c3, ephemeral_local_share, ephemeral_other_public_share)`
+  // party_one.rs:519-565 (`Signature::compute`, :486-517, is the same without recid).  dk = party one's key; k1 its ephemeral secret,
+  // R2 = party two's ephemeral public share.  s is low: min(s, q - s).
+  static SignatureRecid compute_with_recid(Context& ctx, const paillier::DecryptionKeys& dk, const Index& key_idx, const Batch& partial_sig_c3,
+                                           const Batch& k1, const Batch& R2) {
+    const int B = (int)k1.size();
+    Dev<uint32_t> c3 = up(partial_sig_c3), dk1 = up(k1), dR = up(R2), r((size_t)B * W_SCALAR), s((size_t)B * W_SCALAR);
+    Dev<int32_t> ki(key_idx), rec((size_t)B);
+    check(mpe_lindell_sign(ctx.get(), dk.get(), B, ki.get(), c3.get(), dk1.get(), dR.get(), r.get(), s.get(), rec.get(), nullptr), "mpe_lindell_sign");
+    ctx.sync();
+    return SignatureRecid{down(r, W_SCALAR), down(s, W_SCALAR), rec.download()};
+  }
+};
+}  // namespace party_one
+}  // namespace lindell_2017
+}  // namespace two_party_ecdsa
 
 // ---- GG20 signing, the state-machine surface ------------------------------------------------------------------------------------
 namespace gg_2020 {

@@ -9,6 +9,7 @@
 //   simulate_signing_t1_n2_s2 / _t1_n3_s2 / _t2_n3_s3   gg_2020/state_machine/sign.rs:667-762 (one OfflineStage per party, each with its
 //                                      own secrets only, a Simulation relaying their messages, then SignManual for every party)
 //   the constructor / message-store errors of sign.rs:77-101,246-330
+//   test_two_party_sign                src/protocols/two_party_ecdsa/lindell_2017/test.rs:85-137
 //
 // Inputs (keys, scalars, every value the reference samples from OsRng) come from a fixture file written by
 // tests/test_cpp_shim_gpu.py — the same seeded fixtures the Python tests use.  Test infrastructure: links the oracle and libgmp;
@@ -245,6 +246,32 @@ static bool test_zk_pdl_with_slack(Context& ctx, const Fixture& F, const ProverK
   return true;
 }
 
+// lindell_2017/test.rs:85-137: keys and ephemeral shares exist (the fixture's), party two computes the partial signature, party one
+// completes it, `party_one::verify(&signature, &pubkey, &message)`
+static bool test_two_party_sign(Context& ctx, const Fixture& F) {
+  namespace l17 = two_party_ecdsa::lindell_2017;
+  const Index ki = as_index(F["l17_key_idx"]);
+  const Batch &N = F["l17_N"], &message = F["l17_msg"];
+  const int B = (int)message.size();
+  EncryptionKeys ek(ctx, N);                                                  // keypair.ek
+  DecryptionKeys dk(ctx, F["l17_p"], F["l17_q"]);                             // party1_private
+  const auto partial_sig = l17::party_two::PartialSig::compute(ctx, ek, ki, F["l17_c_key"], F["l17_x2"], F["l17_k2"], F["l17_R1"], message, F["l17_rho"],
+                                                               F["l17_r"]);
+  const auto signature = l17::party_one::SignatureRecid::compute_with_recid(ctx, dk, ki, partial_sig.c3, F["l17_k1"], F["l17_R2"]);
+  Batch want_c3(B, W_NN), wr(B, W_SCALAR), ws(B, W_SCALAR);
+  std::vector<int32_t> wrec((size_t)B);
+  orc_lindell_partial_sig(B, (int)N.size(), N.w.data(), ki.data(), F["l17_c_key"].w.data(), F["l17_x2"].w.data(), F["l17_k2"].w.data(),
+                          F["l17_R1"].w.data(), message.w.data(), F["l17_rho"].w.data(), F["l17_r"].w.data(), want_c3.w.data());
+  orc_lindell_sign(B, (int)N.size(), F["l17_p"].w.data(), F["l17_q"].w.data(), ki.data(), want_c3.w.data(), F["l17_k1"].w.data(), F["l17_R2"].w.data(),
+                   wr.w.data(), ws.w.data(), wrec.data());
+  REQUIRE(partial_sig.c3 == want_c3 && signature.r == wr && signature.s == ws && signature.recid == wrec);
+  // party_one::verify(&signature, &pubkey, &message).expect("Invalid signature"): pubkey = x1 x2 G, per item
+  std::vector<uint8_t> ok((size_t)B);
+  REQUIRE(ossl_ecdsa_verify(B, F["l17_pub"].w.data(), 16, message.w.data(), signature.r.w.data(), signature.s.w.data(), ok.data()) == B);
+  REQUIRE(message.row(0)[0] == 1234u);                                        // let message = BigInt::from(1234);
+  return true;
+}
+
 // ---- gg_2020/state_machine/sign.rs:667-762 ----------------------------------------------------------------------------------------
 // `round_based::dev::Simulation`: every party proceeds when it can, its outgoing messages are delivered to all the others
 struct Simulation {
@@ -439,6 +466,11 @@ int main(int argc, char** argv) {
     for (auto& r : results) {
       std::printf("test %s ... %s\n", r.name, r.ok ? "ok" : "FAILED");
       failed += r.ok ? 0 : 1;
+    }
+    {
+      const bool ok = test_two_party_sign(ctx, F);
+      std::printf("test test_two_party_sign ... %s\n", ok ? "ok" : "FAILED");
+      failed += ok ? 0 : 1;
     }
     const int ncases = (int)F["sm_count"].w[0];
     for (int k = 0; k < ncases; ++k) {

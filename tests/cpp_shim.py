@@ -55,6 +55,7 @@ def write_fixture(path, keys, B=6, seed="cpp-shim"):
         arrays["al_" + f] = F.words([n[f] for n in al], w)
         arrays["pdl_" + f] = F.words([n[f] for n in pd], w)
     arrays.update(bob_zkp_case(keys, ek, st))
+    arrays.update(lindell_case(keys))
     arrays.update(state_machine_cases(keys))
     with open(path, "wb") as f:
         for name, arr in arrays.items():
@@ -100,4 +101,16 @@ def bob_zkp_case(keys, ek, st, B=25):
            "bz_r": F.words([r.coprime_below(ek[k].N) for k in kidx], 64)}
     for f, w in (("alpha", 24), ("beta", 64), ("gamma", 80), ("rho", 72), ("rho_prim", 88), ("sigma", 72), ("tau", 88)):
         out["bz_" + f] = F.words([n[f] for n in nn], w)
+    return out
+
+
+def lindell_case(keys, B=8):
+    """`test_two_party_sign` (lindell_2017/test.rs:85-137), B pairs of parties at once; item 0 signs the reference's message 1234.
+    "l17_<field>" arrays; the Paillier keys are the fixture's 16 (party one's key of item i = key l17_key_idx[i])"""
+    import lindell_fixture as L
+    fx = L.make(keys, B, seed="cpp-lindell")
+    fx["msg"][0] = F.words([1234], 8)[0]
+    out = {"l17_" + f: np.ascontiguousarray(fx[f]) for f in ("N", "p", "q", "c_key", "x2", "k1", "k2", "R1", "R2", "msg", "rho", "r")}
+    out["l17_key_idx"] = np.array(fx["kidx"], dtype=np.uint32).reshape(B, 1)
+    out["l17_pub"] = F.point_words(fx["pub"])
     return out

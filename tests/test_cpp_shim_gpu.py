@@ -24,7 +24,7 @@ def test_reference_unit_tests_over_the_cpp_host_layer(tmp_path, keys):
     p = subprocess.run([exe, fx], capture_output=True, text=True, timeout=600)
     print(p.stdout)
     assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-2000:])
-    for name in ("alice_zkp", "bob_zkp", "test_mta", "test_zk_pdl_with_slack", "test_zk_pdl_with_slack_soundness", "error_mapping", "state_machine_errors",
+    for name in ("alice_zkp", "bob_zkp", "test_mta", "test_zk_pdl_with_slack", "test_zk_pdl_with_slack_soundness", "error_mapping", "state_machine_errors", "test_two_party_sign",
                  "simulate_signing_t1_n2_s2 [1, 2]", "simulate_signing_t1_n3_s2 [1, 2]", "simulate_signing_t1_n3_s2 [1, 3]",
                  "simulate_signing_t1_n3_s2 [2, 3]", "simulate_signing_t2_n3_s3 [1, 2, 3]"):
         assert f"test {name} ... ok" in p.stdout, name
