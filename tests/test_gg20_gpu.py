@@ -428,3 +428,35 @@ def test_scratch_is_wiped_after_signing(keys):
     assert list(status.cpu().numpy()) == [0, 0]
     nz, tot = ctx.scratch_audit()
     assert nz == 0 and tot > 0
+
+
+def test_sessions_at_the_edges_of_the_sampling_ranges(gpu_ctx, keys):
+    """the edge sessions of tests/test_oracle_edges_cpu.py (blinding factor 0, scalars 1 and q - 1, Paillier randomness 1, messages 0 /
+    q / 2^256 - 1, zero proof nonces, a beta_tag that makes the MtA wrap) as ONE batch on the round engine: every round message of
+    every party byte-identical to the oracle's, same statuses and bad actors, same signatures"""
+    from multi_party_ecdsa_amd import engine as E
+    import test_oracle_edges_cpu as TE
+    t, n, signers = 1, 3, [0, 2]
+    lk = G.make_local_keys(keys, t, n, signers)
+    names = list(TE.EDGE_SESSIONS)
+    parts = [TE._session_with(lk, "edge-" + nm, TE.EDGE_SESSIONS[nm]) for nm in names]
+    nonces = {f: np.concatenate([p[f] for p in parts]) for f in parts[0]}
+    B, S = len(names), len(signers)
+    want = G.oracle_sign_ex(lk, nonces, B)
+    gk = E.Gg20Keys(gpu_ctx, t, n, signers, lk["arrays"])
+    dn = {f: _dev(gpu_ctx, v) for f, v in nonces.items()}
+    sess = E.Gg20Session(gpu_ctx, gk, B, list(range(S)), dn)
+    prev = None
+    for rnd in range(9):
+        out = sess.round(rnd, d_in=prev, msg=dn["msg"] if rnd == 7 else None)
+        if out is not None:
+            assert np.array_equal(_u32(out), want["slabs"][rnd]), f"round {rnd}"
+            prev = out.reshape(-1)
+    res = sess.result()
+    gpu_ctx.sync()
+    st = res["status"].cpu().numpy()
+    assert np.array_equal(st, want["party_status"]) and np.array_equal(_u32(res["bad_actors"]), want["party_bad"])
+    failed = [names[b] for b in range(B) if st[:, b].any()]
+    assert failed == list(TE.EXPECTED_FAILURES)
+    for i in range(S):
+        assert np.array_equal(_u32(res["r"])[i], want["r"]) and np.array_equal(_u32(res["s"])[i], want["s"])
