@@ -348,6 +348,49 @@ typedef struct {
   const uint32_t *msg;
 } mpe_gg20_nonces;
 
+/* ---- the SAMPLING side of the trait surface ------------------------------------------------------------------------
+ * curv `Samplable::{sample, sample_below, sample_range}`, the reference's `SampleFromMultiplicativeGroup::from_modulo`
+ * (src/utilities/mta/range_proofs.rs:538-557) and `Scalar::<Secp256k1>::random()`, drawn ON THE DEVICE from a 32-byte seed.
+ * Item g of stream `stream_id` reads the ChaCha20 keystream (RFC 8439 block function) with key = seed, state[12] = block
+ * counter from 0, state[13] = g, state[14] | state[15] << 32 = stream_id, taking its bytes in order; the byte -> integer
+ * rules are curv's (recalled): sample(bits) = from_bytes_be(ceil(bits/8) bytes) >> (8 ceil(bits/8) - bits);
+ * sample_below(u) = repeat sample(bit_length(u)) until < u (every attempt takes fresh bytes).
+ * A (seed, stream_id) pair must never be used twice.  h_seed32: HOST pointer to 32 bytes.
+ *   mpe_sample_bits    d_out [batch][out_words] = BigInt::sample(bits)
+ *   mpe_sample_below   d_out = sample_below(bound row d_bound_idx[i] of d_bound [nbounds][bound_words]; NULL index: row 0 when
+ *                      nbounds == 1, else row i); flags: MPE_SAMPLE_NONZERO rejects 0, MPE_SAMPLE_PLUS_ONE returns 1 + the draw
+ *                      (sample_range(1, bound + 1)), MPE_SAMPLE_COPRIME = from_modulo: also repeat until gcd(x, bound) == 1
+ *                      (odd bounds of at most 2048 bits; an even bound counts as a failure)
+ *   mpe_sample_scalar  d_out [batch][8] = Scalar::random(): 32 bytes as a big-endian integer until 0 < x < q
+ * d_fail (may be NULL): incremented for every item that exhausted 128 attempts (probability < 2^-128; its row is zero). */
+#define MPE_SAMPLE_NONZERO 1
+#define MPE_SAMPLE_PLUS_ONE 2
+#define MPE_SAMPLE_COPRIME 4
+int mpe_sample_bits(mpe_ctx* ctx, int batch, const uint8_t* h_seed32, uint64_t stream_id, int bits, int out_words, uint32_t* d_out,
+                    void* stream);
+int mpe_sample_below(mpe_ctx* ctx, int batch, const uint8_t* h_seed32, uint64_t stream_id, const uint32_t* d_bound, int bound_words,
+                     int nbounds, const int32_t* d_bound_idx, int flags, int out_words, uint32_t* d_out, int32_t* d_fail, void* stream);
+int mpe_sample_scalar(mpe_ctx* ctx, int batch, const uint8_t* h_seed32, uint64_t stream_id, uint32_t* d_out, int32_t* d_fail,
+                      void* stream);
+/* Everything a batch of signing sessions draws from OsRng, with the reference's distributions, into the arrays of `out`
+ * (all fields but msg; the layout of mpe_gg20_nonces for `n_local` local parties h_local[]):
+ *   k, gamma, l, ped_s*, heg_s*, mb_nonce_*: Scalar::random() (party_i.rs:561-563,628; curv's sigma proofs; mta/mod.rs:147-148)
+ *   blind: BigInt::sample(256) (party_i.rs:574)     r_a: sample_below(N_i) (mta/mod.rs:57)
+ *   al_alpha < q^3, al_beta = from_modulo(N_i), al_gamma < q^3 N~_st, al_rho < q N~_st   (range_proofs.rs:48-51)
+ *   mb_beta_tag, mb_r < N_peer (mta/mod.rs:97-98)
+ *   pdl_alpha < q^3, pdl_beta = sample_range(1, N_i - 1), pdl_rho < q N~_peer, pdl_gamma < q^3 N~_peer (zk_pdl_with_slack/mod.rs:73-77)
+ * field f (its position in mpe_gg20_nonces, k = 0) of batch `batch_counter` (< 2^56) uses stream_id = batch_counter | f << 56 and
+ * item index = the field's row index.  from_modulo's gcd runs as ONE batched verdict (Montgomery's trick) and only failing
+ * items are redrawn lane by lane — the values equal those of the literal loop.  A (seed, batch_counter) pair signs ONE batch.
+ * mpe_gg20_nonces_alloc / _view / _free: one device allocation holding every field for (batch, n_local), zeroed when freed. */
+typedef struct mpe_gg20_nonce_buf mpe_gg20_nonce_buf;
+int mpe_gg20_nonces_alloc(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, int n_local, mpe_gg20_nonce_buf** out);
+int mpe_gg20_nonces_view(const mpe_gg20_nonce_buf* buf, mpe_gg20_nonces* out);
+int mpe_gg20_nonces_free(mpe_gg20_nonce_buf* buf);
+int mpe_gg20_sample_nonces(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, int n_local, const int32_t* h_local,
+                           const int32_t* d_keyset, const uint8_t* h_seed32, uint64_t batch_counter, const mpe_gg20_nonces* out,
+                           int32_t* d_fail, void* stream);
+
 /* GG20 round messages.  One fixed-size record of 32-bit words per (sender, session); a slab holds, for every sender,
  * a [B][W] block of records.  P2P messages travel like broadcast ones and are filtered by the receiver, exactly as the
  * reference's relay does (examples/gg20_sm_client.rs:35-40).  Points: x[8] | y[8]; all other fields little-endian words.

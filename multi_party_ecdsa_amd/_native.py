@@ -183,6 +183,13 @@ def _load():
         "mpe_paillier_decrypt": (ip, [vp, vp, ip, i32p, u32p, u32p, vp]),
         "mpe_paillier_add": (ip, [vp, vp, ip, i32p, u32p, u32p, u32p, vp]),
         "mpe_paillier_mul": (ip, [vp, vp, ip, i32p, u32p, u32p, ip, u32p, vp]),
+        "mpe_sample_bits": (ip, [vp, ip, C.c_char_p, C.c_uint64, ip, ip, u32p, vp]),
+        "mpe_sample_below": (ip, [vp, ip, C.c_char_p, C.c_uint64, u32p, ip, ip, i32p, ip, ip, u32p, i32p, vp]),
+        "mpe_sample_scalar": (ip, [vp, ip, C.c_char_p, C.c_uint64, u32p, i32p, vp]),
+        "mpe_gg20_nonces_alloc": (ip, [vp, vp, ip, ip, C.POINTER(vp)]),
+        "mpe_gg20_nonces_view": (ip, [vp, C.POINTER(Gg20Nonces)]),
+        "mpe_gg20_nonces_free": (ip, [vp]),
+        "mpe_gg20_sample_nonces": (ip, [vp, vp, ip, ip, C.POINTER(C.c_int32), i32p, C.c_char_p, C.c_uint64, C.POINTER(Gg20Nonces), i32p, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -211,7 +218,8 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_pedersen_verify", "mpe_heg_prove", "mpe_heg_verify", "mpe_hash_commit_point", "mpe_ctx_wipe", "mpe_ctx_scratch_audit", "mpe_gg20_session_fault_inject", "mpe_gg20_blame5",
             "mpe_gg20_blame6", "mpe_gg20_blame7", "mpe_correct_key_verify", "mpe_composite_dlog_verify", "mpe_vss_validate_share",
             "mpe_vss_point_commitment", "mpe_gg20_session_blame6_state", "mpe_ecddh_prove", "mpe_ecddh_verify",
-            "mpe_statements_create_wb", "mpe_gg20_session_rearm"]
+            "mpe_statements_create_wb", "mpe_gg20_session_rearm", "mpe_sample_bits", "mpe_sample_below", "mpe_sample_scalar",
+            "mpe_gg20_nonces_alloc", "mpe_gg20_nonces_view", "mpe_gg20_nonces_free", "mpe_gg20_sample_nonces"]
 
 
 def check(rc, what):

@@ -23,6 +23,31 @@
 
 #include "mpe_proofs.h"
 
+namespace mpe {
+namespace smp {
+// the bounds of the sampling ranges of a key object (mpe_sample.h): q, q^3 and per party N - 2, q N~, q^3 N~
+// (range_proofs.rs:48-51: q^3, q^3 N~, q N~;  zk_pdl_with_slack/mod.rs:69-77: the same and sample_range(1, N - 1) = 1 + below(N - 2))
+struct Bounds { uint32_t *q, *q3, *Nm2, *qNt, *q3Nt; };
+__global__ void bounds_kernel(int count, const uint32_t* __restrict__ N, const uint32_t* __restrict__ Nt, Bounds b) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > count) return;
+  const uint32_t q[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  uint32_t q2[16], q3[24];
+  sm::mul(q2, q, 8, q, 8);
+  sm::mul(q3, q2, 16, q, 8);
+  if (g == count) {                      // the two constants
+    for (int j = 0; j < 8; ++j) b.q[j] = q[j];
+    for (int j = 0; j < 24; ++j) b.q3[j] = q3[j];
+    return;
+  }
+  const uint32_t two[1] = {2u};
+  sm::sub(b.Nm2 + (size_t)g * 64, 64, N + (size_t)g * 64, 64, two, 1);
+  sm::mul(b.qNt + (size_t)g * 72, Nt + (size_t)g * 64, 64, q, 8);
+  sm::mul(b.q3Nt + (size_t)g * 88, Nt + (size_t)g * 64, 64, q3, 24);
+}
+}  // namespace smp
+}  // namespace mpe
+
 struct mpe_gg20_keys {
   int t = 0, n = 0, S = 0, K = 1, n_own = 0;
   int signers[8] = {0};
@@ -37,6 +62,7 @@ struct mpe_gg20_keys {
   uint32_t* X = nullptr;            // [K][n][16]     pk_vec
   uint32_t* y = nullptr;            // [K][16]        group public key
   uint32_t* gw = nullptr;           // [K][S][16]     g_w_vec = lambda_j X_j (SignKeys::g_w_vec, party_i.rs:527-544)
+  mpe::smp::Bounds bounds{};        // sampling ranges (mpe_sample.h): q [8], q^3 [24], N-2 [K*n][64], q N~ [K*n][72], q^3 N~ [K*n][88]
 };
 
 namespace mpe {
@@ -1105,11 +1131,14 @@ int mpe_gg20_keys_create(mpe_ctx* ctx, int t, int n, int n_signers, const int32_
   for (int i = 0; i < n_signers; ++i) K->signers[i] = h_signers[i];
   for (int i = 0; i < n_own; ++i) { K->own[i] = h_own[i]; K->own_slot[h_own[i]] = i; }
   const size_t kk = (size_t)nkeysets;
-  const size_t words = kk * n_own * 8 + kk * n * 16 + kk * 16 + kk * n_signers * 16;
+  const size_t words = kk * n_own * 8 + kk * n * 16 + kk * 16 + kk * n_signers * 16 + 32 + kk * n * (64 + 72 + 88);
   hipError_t e = hipMalloc(&K->blob, words * 4);
   if (e != hipSuccess) { delete K; mpe_set_error("hipMalloc(gg20 keys)", e); return MPE_E_NOMEM; }
   K->blob_bytes = words * 4;
   K->x = (uint32_t*)K->blob; K->X = K->x + kk * n_own * 8; K->y = K->X + kk * n * 16; K->gw = K->y + kk * 16;
+  K->bounds.q = K->gw + kk * n_signers * 16; K->bounds.q3 = K->bounds.q + 8; K->bounds.Nm2 = K->bounds.q3 + 24;
+  K->bounds.qNt = K->bounds.Nm2 + kk * n * 64; K->bounds.q3Nt = K->bounds.qNt + kk * n * 72;
+  hipLaunchKernelGGL(mpe::smp::bounds_kernel, dim3(mpe::blocks_for(nkeysets * n + 1, 64)), dim3(64), 0, st, nkeysets * n, d_N, d_Nt, K->bounds);
   (void)hipMemcpyAsync(K->x, d_x, kk * n_own * 8 * 4, hipMemcpyDeviceToDevice, st);
   (void)hipMemcpyAsync(K->X, d_X, kk * n * 16 * 4, hipMemcpyDeviceToDevice, st);
   (void)hipMemcpyAsync(K->y, d_y, kk * 16 * 4, hipMemcpyDeviceToDevice, st);

@@ -562,6 +562,64 @@ def gg20_sign(ctx, keys, nonces, B, dedup_verify=False, chunk=0, want_R=False, k
     return (r, s, recid, status, R) if want_R else (r, s, recid, status)
 
 
+# ---- the sampling side of the trait surface (mpe_sample.h): curv Samplable / from_modulo / Scalar::random on the device ----
+SAMPLE_NONZERO, SAMPLE_PLUS_ONE, SAMPLE_COPRIME = 1, 2, 4
+
+
+def _seed(seed):
+    b = bytes(seed)
+    if len(b) != 32:
+        raise ValueError("the sampler's seed is 32 bytes")
+    return b
+
+
+def sample_bits(ctx, batch, seed, stream_id, bits, out_words):
+    out = _new(ctx, batch, out_words)
+    N_.check(N_.lib.mpe_sample_bits(ctx.h, batch, _seed(seed), stream_id, bits, out_words, _ptr(out), ctx.stream()), "mpe_sample_bits")
+    return out
+
+
+def sample_below(ctx, batch, seed, stream_id, d_bound, out_words, d_bound_idx=None, flags=0):
+    """d_bound: device int32 [nbounds, bound_words]; returns (values [batch, out_words], failures as a device int32 [1])"""
+    out = _new(ctx, batch, out_words)
+    fail = torch.zeros((1,), dtype=torch.int32, device=ctx.device)
+    N_.check(N_.lib.mpe_sample_below(ctx.h, batch, _seed(seed), stream_id, _ptr(d_bound), d_bound.shape[1], d_bound.shape[0], _ptr(d_bound_idx), flags,
+                                     out_words, _ptr(out), _ptr(fail), ctx.stream()), "mpe_sample_below")
+    return out, fail
+
+
+def sample_scalar(ctx, batch, seed, stream_id):
+    out = _new(ctx, batch, 8)
+    fail = torch.zeros((1,), dtype=torch.int32, device=ctx.device)
+    N_.check(N_.lib.mpe_sample_scalar(ctx.h, batch, _seed(seed), stream_id, _ptr(out), _ptr(fail), ctx.stream()), "mpe_sample_scalar")
+    return out, fail
+
+
+def gg20_nonce_shapes(S, n, L, B):
+    """rows x words of every field of mpe_gg20_nonces (include/mpecdsa_hip.h) for B sessions x L local parties"""
+    P = L * (S - 1)
+    return dict(k=(B * L, 8), gamma=(B * L, 8), blind=(B * L, 8), r_a=(B * L, 64), al_alpha=(B * L * n, 24), al_beta=(B * L * n, 64),
+                al_gamma=(B * L * n, 88), al_rho=(B * L * n, 72), mb_beta_tag=(B * P * 2, 64), mb_r=(B * P * 2, 64), mb_nonce_b=(B * P * 2, 8),
+                mb_nonce_bt=(B * P * 2, 8), l=(B * L, 8), ped_s1=(B * L, 8), ped_s2=(B * L, 8), pdl_alpha=(B * P, 24), pdl_beta=(B * P, 64),
+                pdl_rho=(B * P, 72), pdl_gamma=(B * P, 88), heg_s1=(B * L, 8), heg_s2=(B * L, 8), msg=(B, 8))
+
+
+def gg20_sample_nonces(ctx, keys, B, seed, batch_counter, local=None, keyset=None, msg=None, out=None):
+    """mpe_gg20_sample_nonces: every value the local parties of B sessions draw while signing, from (seed, batch_counter).
+    Returns (dict of device tensors in the layout gg20_sign / Gg20Session take, failures [1]); `msg` (device [B, 8]) is passed through."""
+    local = list(range(keys.S)) if local is None else list(local)
+    if out is None:
+        out = {f: torch.zeros(shape, dtype=torch.int32, device=ctx.device) for f, shape in gg20_nonce_shapes(keys.S, keys.n, len(local), B).items()}
+    if msg is not None:
+        out["msg"] = msg
+    fail = torch.zeros((1,), dtype=torch.int32, device=ctx.device)
+    nn = _struct(N_.Gg20Nonces, out)
+    lc = (C.c_int32 * len(local))(*local)
+    N_.check(N_.lib.mpe_gg20_sample_nonces(ctx.h, keys.h, B, len(local), lc, _ptr(keyset), _seed(seed), int(batch_counter), C.byref(nn), _ptr(fail),
+                                           ctx.stream()), "mpe_gg20_sample_nonces")
+    return out, fail
+
+
 # ---- keygen verification math (gg_2020/party_i.rs:260-438) ----
 def correct_key_verify(ctx, d_N, d_sigma):
     ok = _flags(ctx, d_N.shape[0])

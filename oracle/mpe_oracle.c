@@ -815,3 +815,4 @@ void orc_nextprime(int k32, const uint32_t* start, uint32_t* out) {
 
 #include "gg20_oracle.c"
 #include "lindell_oracle.c"
+#include "sampler_oracle.c"

@@ -1,0 +1,188 @@
+/* sampler_oracle.c — CPU ORACLE (test infrastructure, NOT product code) of the device-side sampler
+ * (multi_party_ecdsa_amd/csrc/mpe_sample.h): curv's `Samplable` for BigInt, the reference's
+ * `SampleFromMultiplicativeGroup::from_modulo` and `Scalar::random()`, restated literally over libgmp with the
+ * SAME byte source the device uses (ChaCha20, RFC 8439 block function), so that the two expand one seed to identical
+ * arrays — rejected draws included.
+ *
+ *   curv-kzen 0.9 `arithmetic::traits::Samplable for BigInt` (un-vendored dependency, /root/reference/Cargo.toml:36; RECALLED):
+ *     sample(bit_size):       bytes = (bit_size - 1) / 8 + 1; buf = bytes fresh random bytes;
+ *                             BigInt::from_bytes(buf) >> (bytes * 8 - bit_size)
+ *     sample_below(upper):    bits = upper.bit_length(); loop { n = sample(bits); if n < upper { return n } }
+ *     sample_range(lo, hi):   lo + sample_below(hi - lo)
+ *   reference, src/utilities/mta/range_proofs.rs:544-552 `from_modulo(N)`:
+ *     loop { r = sample_below(N); if r.gcd(N) == 1 { return r } }
+ *   curv `Scalar::<Secp256k1>::random()` -> secp256k1 `SecretKey::new(rng)`: 32 random bytes (a big-endian integer) until
+ *     0 < x < q.
+ * The reference draws from OsRng, which cannot be replayed: what is pinned here is the device against this restatement
+ * (bit-exact) and the DISTRIBUTIONS against the reference's text.  PARITY UNPINNED for curv's byte -> integer rule itself.
+ * Compiled into libmpe_oracle.so by #include from mpe_oracle.c (shares its static helpers). */
+
+#define SMP_MAX_ATTEMPTS 128
+#define SMP_NONZERO 1
+#define SMP_PLUS_ONE 2
+#define SMP_COPRIME 4
+
+static uint32_t smp_rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+#define SMP_QR(a, b, c, d)                                              \
+  a += b; d ^= a; d = smp_rotl(d, 16); c += d; b ^= c; b = smp_rotl(b, 12); \
+  a += b; d ^= a; d = smp_rotl(d, 8);  c += d; b ^= c; b = smp_rotl(b, 7);
+/* RFC 8439 2.3: the ChaCha20 block function; out = 64 keystream bytes (the state words serialised little-endian) */
+void orc_chacha20_block(const uint8_t key[32], uint32_t counter, uint32_t n13, uint32_t n14, uint32_t n15, uint8_t out[64]) {
+  uint32_t in[16], x[16];
+  in[0] = 0x61707865u; in[1] = 0x3320646eu; in[2] = 0x79622d32u; in[3] = 0x6b206574u;
+  for (int j = 0; j < 8; ++j)
+    in[4 + j] = (uint32_t)key[4 * j] | ((uint32_t)key[4 * j + 1] << 8) | ((uint32_t)key[4 * j + 2] << 16) | ((uint32_t)key[4 * j + 3] << 24);
+  in[12] = counter; in[13] = n13; in[14] = n14; in[15] = n15;
+  memcpy(x, in, sizeof x);
+  for (int r = 0; r < 10; ++r) {
+    SMP_QR(x[0], x[4], x[8], x[12]) SMP_QR(x[1], x[5], x[9], x[13]) SMP_QR(x[2], x[6], x[10], x[14]) SMP_QR(x[3], x[7], x[11], x[15])
+    SMP_QR(x[0], x[5], x[10], x[15]) SMP_QR(x[1], x[6], x[11], x[12]) SMP_QR(x[2], x[7], x[8], x[13]) SMP_QR(x[3], x[4], x[9], x[14])
+  }
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t v = x[j] + in[j];
+    out[4 * j] = (uint8_t)v; out[4 * j + 1] = (uint8_t)(v >> 8); out[4 * j + 2] = (uint8_t)(v >> 16); out[4 * j + 3] = (uint8_t)(v >> 24);
+  }
+}
+
+/* the byte source of one item: `fill_bytes` of an RNG whose output is the item's keystream */
+typedef struct { const uint8_t* key; uint32_t item, lo, hi; uint64_t pos; uint8_t blk[64]; uint32_t cur; } smp_rng;
+static void smp_init(smp_rng* r, const uint8_t* key, uint32_t item, uint64_t sid) {
+  r->key = key; r->item = item; r->lo = (uint32_t)sid; r->hi = (uint32_t)(sid >> 32); r->pos = 0; r->cur = 0xffffffffu;
+}
+static void smp_fill(smp_rng* r, uint8_t* buf, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t b = (uint32_t)(r->pos >> 6);
+    if (b != r->cur) { orc_chacha20_block(r->key, b, r->item, r->lo, r->hi, r->blk); r->cur = b; }
+    buf[i] = r->blk[r->pos & 63];
+    r->pos++;
+  }
+}
+/* BigInt::sample(bit_size) */
+static void smp_sample(mpz_t out, smp_rng* r, size_t bit_size) {
+  if (bit_size == 0) { mpz_set_ui(out, 0); return; }
+  const size_t bytes = (bit_size - 1) / 8 + 1;
+  uint8_t buf[512];
+  if (bytes > sizeof buf) abort();
+  smp_fill(r, buf, bytes);
+  mpz_import(out, bytes, 1, 1, 0, 0, buf);                 /* BigInt::from_bytes: big-endian */
+  mpz_fdiv_q_2exp(out, out, bytes * 8 - bit_size);
+}
+/* sample_below with the variants the call sites use; returns 0 when SMP_MAX_ATTEMPTS draws were all refused */
+static int smp_below(mpz_t out, smp_rng* r, const mpz_t upper, int flags) {
+  const size_t bits = mpz_sizeinbase(upper, 2);
+  mpz_t g; mpz_init(g);
+  int ok = 0;
+  for (int attempt = 0; attempt < SMP_MAX_ATTEMPTS && !ok; ++attempt) {
+    smp_sample(out, r, bits);
+    ok = mpz_cmp(out, upper) < 0;
+    if (ok && (flags & SMP_NONZERO) && mpz_sgn(out) == 0) ok = 0;
+    if (ok && (flags & SMP_COPRIME)) { mpz_gcd(g, out, upper); ok = mpz_odd_p(upper) && mpz_cmp_ui(g, 1) == 0; }
+  }
+  mpz_clear(g);
+  if (!ok) mpz_set_ui(out, 0);
+  else if (flags & SMP_PLUS_ONE) mpz_add_ui(out, out, 1);
+  return ok;
+}
+
+/* the word interface of mpe_sample_bits / mpe_sample_below / mpe_sample_scalar (include/mpecdsa_hip.h); returns the failures */
+int orc_sample_bits(int batch, const uint8_t* seed, uint64_t sid, int bits, int out_words, uint32_t* out) {
+  mpz_t x; mpz_init(x);
+  for (int i = 0; i < batch; ++i) {
+    smp_rng r; smp_init(&r, seed, (uint32_t)i, sid);
+    smp_sample(x, &r, (size_t)bits);
+    zout(out + (size_t)i * out_words, out_words, x);
+  }
+  mpz_clear(x);
+  return 0;
+}
+int orc_sample_below(int batch, const uint8_t* seed, uint64_t sid, const uint32_t* bound, int bound_words, int nbounds, const int32_t* bound_idx,
+                     int flags, int out_words, uint32_t* out) {
+  mpz_t x, u; mpz_inits(x, u, NULL);
+  int fails = 0;
+  for (int i = 0; i < batch; ++i) {
+    smp_rng r; smp_init(&r, seed, (uint32_t)i, sid);
+    zin(u, bound + (size_t)pick(bound_idx, nbounds, i) * bound_words, bound_words);
+    if (mpz_sgn(u) <= 0 || !smp_below(x, &r, u, flags)) { fails++; mpz_set_ui(x, 0); }
+    zout(out + (size_t)i * out_words, out_words, x);
+  }
+  mpz_clears(x, u, NULL);
+  return fails;
+}
+int orc_sample_scalar(int batch, const uint8_t* seed, uint64_t sid, uint32_t* out) {
+  ec_setup();
+  mpz_t x; mpz_init(x);
+  int fails = 0;
+  for (int i = 0; i < batch; ++i) {
+    smp_rng r; smp_init(&r, seed, (uint32_t)i, sid);
+    if (!smp_below(x, &r, EC_Q, SMP_NONZERO)) fails++;
+    zout(out + (size_t)i * 8, 8, x);
+  }
+  mpz_clear(x);
+  return fails;
+}
+
+/* Everything a batch of signing sessions draws (mpe_gg20_sample_nonces): the arrays of `Z` (all fields but msg) for the L local
+ * parties `local[]` (signer ordinals) of sessions [0, B); field f of batch `counter` uses stream counter | f << 56. */
+int orc_gg20_sample_nonces(const orc_gg20_keys* K, int B, int L, const int32_t* local, const int32_t* keyset, const uint8_t* seed, uint64_t counter,
+                           const orc_gg20_nonces* Z) {
+  ec_setup();
+  const int S = K->S, n = K->n, P1 = S - 1;
+  mpz_t x, u, q3, t; mpz_inits(x, u, q3, t, NULL);
+  mpz_pow_ui(q3, EC_Q, 3);
+  int fails = 0;
+#define SID(f) (counter | ((uint64_t)(f) << 56))
+#define DRAW(f, item, dst, words, upper, flags)                                         \
+  do { smp_rng r_; smp_init(&r_, seed, (uint32_t)(item), SID(f));                        \
+       if (!smp_below(x, &r_, upper, flags)) fails++;                                    \
+       zout((uint32_t*)(dst) + (size_t)(item) * (words), words, x); } while (0)
+  for (int b = 0; b < B; ++b) {
+    const int ks = keyset ? keyset[b] : 0;
+    for (int li = 0; li < L; ++li) {
+      const int pi = b * L + li, i = local[li], me = ks * n + K->signers[i];
+      mpz_t Nme; mpz_init(Nme);
+      if (K->N) zin(Nme, K->N + (size_t)me * 64, 64);
+      else { zin(Nme, K->p + (size_t)me * 32, 32); zin(t, K->q + (size_t)me * 32, 32); mpz_mul(Nme, Nme, t); }
+      DRAW(0, pi, Z->k, 8, EC_Q, SMP_NONZERO);                                 /* party_i.rs:563 k_i = Scalar::random() */
+      DRAW(1, pi, Z->gamma, 8, EC_Q, SMP_NONZERO);                             /* :561 gamma_i */
+      { smp_rng r_; smp_init(&r_, seed, (uint32_t)pi, SID(2)); smp_sample(x, &r_, 256); zout((uint32_t*)Z->blind + (size_t)pi * 8, 8, x); }   /* :574 */
+      DRAW(3, pi, Z->r_a, 64, Nme, 0);                                         /* mta/mod.rs:57 */
+      for (int st = 0; st < n; ++st) {
+        const int ap = pi * n + st;
+        zin(t, K->Nt + (size_t)(ks * n + st) * 64, 64);
+        DRAW(4, ap, Z->al_alpha, 24, q3, 0);                                   /* range_proofs.rs:48 */
+        DRAW(5, ap, Z->al_beta, 64, Nme, SMP_COPRIME);                         /* :49, :544-552 */
+        mpz_mul(u, q3, t); DRAW(6, ap, Z->al_gamma, 88, u, 0);                 /* :50 */
+        mpz_mul(u, EC_Q, t); DRAW(7, ap, Z->al_rho, 72, u, 0);                 /* :51 */
+      }
+      for (int jj = 0; jj < P1; ++jj) {
+        const int pp = pi * P1 + jj, ind = ind_of(i, jj), peer = ks * n + K->signers[ind];
+        mpz_t Np; mpz_init(Np);
+        if (K->N) zin(Np, K->N + (size_t)peer * 64, 64);
+        else { zin(Np, K->p + (size_t)peer * 32, 32); zin(t, K->q + (size_t)peer * 32, 32); mpz_mul(Np, Np, t); }
+        for (int v = 0; v < 2; ++v) {
+          const int mb = pp * 2 + v;
+          DRAW(8, mb, Z->mb_beta_tag, 64, Np, 0);                              /* mta/mod.rs:97 */
+          DRAW(9, mb, Z->mb_r, 64, Np, 0);                                     /* :98 */
+          DRAW(10, mb, Z->mb_nonce_b, 8, EC_Q, SMP_NONZERO);                   /* :147 DLogProof::prove */
+          DRAW(11, mb, Z->mb_nonce_bt, 8, EC_Q, SMP_NONZERO);                  /* :148 */
+        }
+        zin(t, K->Nt + (size_t)peer * 64, 64);
+        DRAW(15, pp, Z->pdl_alpha, 24, q3, 0);                                 /* zk_pdl_with_slack/mod.rs:73 */
+        mpz_sub_ui(u, Nme, 2); DRAW(16, pp, Z->pdl_beta, 64, u, SMP_PLUS_ONE); /* :75 sample_range(1, N - 1) = 1 + sample_below(N - 2) */
+        mpz_mul(u, EC_Q, t); DRAW(17, pp, Z->pdl_rho, 72, u, 0);               /* :76 */
+        mpz_mul(u, q3, t); DRAW(18, pp, Z->pdl_gamma, 88, u, 0);               /* :77 */
+        mpz_clear(Np);
+      }
+      DRAW(12, pi, Z->l, 8, EC_Q, SMP_NONZERO);                                /* party_i.rs:628 l */
+      DRAW(13, pi, Z->ped_s1, 8, EC_Q, SMP_NONZERO);                           /* PedersenProof::prove */
+      DRAW(14, pi, Z->ped_s2, 8, EC_Q, SMP_NONZERO);
+      DRAW(19, pi, Z->heg_s1, 8, EC_Q, SMP_NONZERO);                           /* HomoELGamalProof::prove */
+      DRAW(20, pi, Z->heg_s2, 8, EC_Q, SMP_NONZERO);
+      mpz_clear(Nme);
+    }
+  }
+#undef DRAW
+#undef SID
+  mpz_clears(x, u, q3, t, NULL);
+  return fails;
+}

@@ -301,3 +301,31 @@ def oracle_blame(lk, which, opened, B, keyset=None):
         kset = None if keyset is None else np.ascontiguousarray(keyset, dtype=np.int32)
         getattr(orc.lib, "orc_gg20_blame5" if which == "b5" else "orc_gg20_blame6")(C.byref(ks), orc._p(kset), B, st, orc._p(bad))
     return bad
+
+
+NONCE_WIDTHS = dict(k=8, gamma=8, blind=8, r_a=64, al_alpha=24, al_beta=64, al_gamma=88, al_rho=72, mb_beta_tag=64, mb_r=64,
+                    mb_nonce_b=8, mb_nonce_bt=8, l=8, ped_s1=8, ped_s2=8, pdl_alpha=24, pdl_beta=64, pdl_rho=72, pdl_gamma=88,
+                    heg_s1=8, heg_s2=8, msg=8)
+
+
+def nonce_rows(S, n, L, B):
+    P = L * (S - 1)
+    return dict(k=B * L, gamma=B * L, blind=B * L, r_a=B * L, al_alpha=B * L * n, al_beta=B * L * n, al_gamma=B * L * n, al_rho=B * L * n,
+                mb_beta_tag=B * P * 2, mb_r=B * P * 2, mb_nonce_b=B * P * 2, mb_nonce_bt=B * P * 2, l=B * L, ped_s1=B * L, ped_s2=B * L,
+                pdl_alpha=B * P, pdl_beta=B * P, pdl_rho=B * P, pdl_gamma=B * P, heg_s1=B * L, heg_s2=B * L, msg=B)
+
+
+def oracle_sample_nonces(lk, B, seed, counter, local=None, keyset=None, msg=None):
+    """oracle/sampler_oracle.c: the arrays mpe_gg20_sample_nonces must produce for (seed, counter); returns (dict, failures)"""
+    import orc
+    S, n = lk["S"], lk["n"]
+    local = list(range(S)) if local is None else list(local)
+    rows = nonce_rows(S, n, len(local), B)
+    z = {f: np.zeros((rows[f], NONCE_WIDTHS[f]), dtype=np.uint32) for f in NONCE_FIELDS}
+    if msg is not None:
+        z["msg"] = np.ascontiguousarray(msg, dtype=np.uint32)
+    ks, ns = keys_struct(lk), nonces_struct(z)
+    lc = np.asarray(local, dtype=np.int32)
+    kset = None if keyset is None else np.ascontiguousarray(keyset, dtype=np.int32)
+    fails = orc.lib.orc_gg20_sample_nonces(C.byref(ks), B, len(local), orc._p(lc), orc._p(kset), bytes(seed), counter, C.byref(ns))
+    return z, fails

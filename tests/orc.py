@@ -262,3 +262,37 @@ def lindell_sign(p, q, c3, k1, R2, key_idx=None):
     r, s, recid = u32((B, 8)), u32((B, 8)), np.zeros(B, dtype=np.int32)
     lib.orc_lindell_sign(B, p.shape[0], _p(p), _p(q), _p(_idx(key_idx)), _p(c3), _p(k1), _p(R2), _p(r), _p(s), _p(recid))
     return r, s, recid
+
+
+# ---- the sampler's restatement (oracle/sampler_oracle.c): curv Samplable / from_modulo / Scalar::random over ChaCha20 ----
+lib.orc_sample_bits.argtypes = [C.c_int, C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+lib.orc_sample_below.argtypes = [C.c_int, C.c_char_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+lib.orc_sample_scalar.argtypes = [C.c_int, C.c_char_p, C.c_uint64, C.c_void_p]
+lib.orc_chacha20_block.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p]
+lib.orc_gg20_sample_nonces.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p]
+SAMPLE_NONZERO, SAMPLE_PLUS_ONE, SAMPLE_COPRIME = 1, 2, 4
+
+
+def chacha20_block(key, counter, n13, n14, n15):
+    out = C.create_string_buffer(64)
+    lib.orc_chacha20_block(bytes(key), counter, n13, n14, n15, out)
+    return out.raw
+
+
+def sample_bits(batch, seed, sid, bits, out_words):
+    out = u32((batch, out_words))
+    lib.orc_sample_bits(batch, bytes(seed), sid, bits, out_words, _p(out))
+    return out
+
+
+def sample_below(batch, seed, sid, bound, out_words, bound_idx=None, flags=0):
+    """bound: uint32 [nbounds, bound_words]; returns (values, failures)"""
+    out = u32((batch, out_words))
+    fails = lib.orc_sample_below(batch, bytes(seed), sid, _p(bound), bound.shape[1], bound.shape[0], _p(_idx(bound_idx)), flags, out_words, _p(out))
+    return out, fails
+
+
+def sample_scalar(batch, seed, sid):
+    out = u32((batch, 8))
+    fails = lib.orc_sample_scalar(batch, bytes(seed), sid, _p(out))
+    return out, fails
