@@ -507,6 +507,42 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int3
                   uint32_t* d_r, uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, int dedup_verify, int chunk,
                   void* stream);
 
+/* ---- a stream of batches: the pipelined engine ------------------------------------------------------------------------
+ * A signing service receives batch after batch of `batch` sessions (BASELINE config 4: 1 024) and one such batch alone is
+ * latency-bound (chains of ~2 048 dependent squarings at a fraction of the chip).  The reference runs many `OfflineStage`s
+ * concurrently on one executor (state_machine/sign.rs:667-691; rounds.rs:106,215,323 `is_expensive`).  Here:
+ * `group` consecutive batches are coalesced into ONE lock-step pass (every heavy launch carries the items of all of them) and
+ * `lanes` (1..4) such passes are in flight at once, each on one stream of its own with its own workspace — at most 4 streams,
+ * the runtime's default hardware queues, ONE host thread: submit only enqueues.  Results are bit-identical to mpe_gg20_sign.
+ *   submit         the caller's sampled values of ONE batch (layout of mpe_gg20_nonces with every signer local, as for
+ *                  mpe_gg20_sign) and where its results go: d_r, d_s [batch][8], d_recid, d_status [batch], d_R [batch][16] or NULL.
+ *                  `stream`: the stream that produced the inputs (the pipeline waits for it).  Inputs are copied and results
+ *                  written ASYNCHRONOUSLY: both sets of arrays must stay valid until the ticket completes.
+ *   submit_seeded  the same, but every sampled value is drawn on the device from (h_seed32, batch_counter) exactly as
+ *                  mpe_gg20_sample_nonces does; d_msg [batch][8] are the messages.  A (seed, batch_counter) pair signs ONE batch.
+ *   flush          sends the partly filled group to the device (a service calls it when its queue runs dry)
+ *   wait           blocks the host until the batch of `ticket` is complete (flushing its group if it is still open);
+ *   stream_wait    makes `stream` wait for it instead;  query: *done = 0 / 1 without blocking
+ *   latency_ms     device time from the submit call to the completion of that batch's results
+ * One pipeline object is driven by one host thread at a time.  Destroying it waits for the work in flight and wipes its staging. */
+typedef struct mpe_gg20_pipeline mpe_gg20_pipeline;
+int mpe_gg20_pipeline_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, int group, int lanes, int dedup_verify,
+                             mpe_gg20_pipeline** out);
+int mpe_gg20_pipeline_destroy(mpe_gg20_pipeline* p);
+int mpe_gg20_pipeline_submit(mpe_gg20_pipeline* p, const int32_t* d_keyset, const mpe_gg20_nonces* nonces, uint32_t* d_r, uint32_t* d_s,
+                             int32_t* d_recid, uint32_t* d_R, int32_t* d_status, void* stream, uint64_t* ticket);
+int mpe_gg20_pipeline_submit_seeded(mpe_gg20_pipeline* p, const int32_t* d_keyset, const uint8_t* h_seed32, uint64_t batch_counter,
+                                    const uint32_t* d_msg, uint32_t* d_r, uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status,
+                                    void* stream, uint64_t* ticket);
+int mpe_gg20_pipeline_flush(mpe_gg20_pipeline* p);
+int mpe_gg20_pipeline_query(mpe_gg20_pipeline* p, uint64_t ticket, int* done);
+int mpe_gg20_pipeline_wait(mpe_gg20_pipeline* p, uint64_t ticket);
+int mpe_gg20_pipeline_stream_wait(mpe_gg20_pipeline* p, uint64_t ticket, void* stream);
+int mpe_gg20_pipeline_latency_ms(mpe_gg20_pipeline* p, uint64_t ticket, float* ms);
+/* items of the seeded submissions whose rejection loops gave up (see mpe_sample_below); waits for the lanes */
+int mpe_gg20_pipeline_sampler_failures(mpe_gg20_pipeline* p, int32_t* h_out);
+
+
 /* ---- keygen VERIFICATION math (src/protocols/multi_party_ecdsa/gg_2020/party_i.rs:260-438) ----------------------- */
 /* What every party checks about every other party's first keygen messages and shares, batched over (verifier, prover)
  * pairs / wallets.  Every key is its own modulus: the moduli set is built per call.  The two zk-paillier 0.4.3 proofs are

@@ -189,6 +189,16 @@ def _load():
         "mpe_gg20_nonces_alloc": (ip, [vp, vp, ip, ip, C.POINTER(vp)]),
         "mpe_gg20_nonces_view": (ip, [vp, C.POINTER(Gg20Nonces)]),
         "mpe_gg20_nonces_free": (ip, [vp]),
+        "mpe_gg20_pipeline_create": (ip, [vp, vp, ip, ip, ip, ip, C.POINTER(vp)]),
+        "mpe_gg20_pipeline_destroy": (ip, [vp]),
+        "mpe_gg20_pipeline_submit": (ip, [vp, i32p, C.POINTER(Gg20Nonces), u32p, u32p, vp, u32p, vp, vp, C.POINTER(C.c_uint64)]),
+        "mpe_gg20_pipeline_submit_seeded": (ip, [vp, i32p, C.c_char_p, C.c_uint64, u32p, u32p, u32p, vp, u32p, vp, vp, C.POINTER(C.c_uint64)]),
+        "mpe_gg20_pipeline_flush": (ip, [vp]),
+        "mpe_gg20_pipeline_query": (ip, [vp, C.c_uint64, C.POINTER(C.c_int)]),
+        "mpe_gg20_pipeline_wait": (ip, [vp, C.c_uint64]),
+        "mpe_gg20_pipeline_stream_wait": (ip, [vp, C.c_uint64, vp]),
+        "mpe_gg20_pipeline_latency_ms": (ip, [vp, C.c_uint64, C.POINTER(C.c_float)]),
+        "mpe_gg20_pipeline_sampler_failures": (ip, [vp, C.POINTER(C.c_int32)]),
         "mpe_gg20_sample_nonces": (ip, [vp, vp, ip, ip, C.POINTER(C.c_int32), i32p, C.c_char_p, C.c_uint64, C.POINTER(Gg20Nonces), i32p, vp]),
     }
     for name, (res, args) in sig.items():
@@ -219,7 +229,10 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_gg20_blame6", "mpe_gg20_blame7", "mpe_correct_key_verify", "mpe_composite_dlog_verify", "mpe_vss_validate_share",
             "mpe_vss_point_commitment", "mpe_gg20_session_blame6_state", "mpe_ecddh_prove", "mpe_ecddh_verify",
             "mpe_statements_create_wb", "mpe_gg20_session_rearm", "mpe_sample_bits", "mpe_sample_below", "mpe_sample_scalar",
-            "mpe_gg20_nonces_alloc", "mpe_gg20_nonces_view", "mpe_gg20_nonces_free", "mpe_gg20_sample_nonces"]
+            "mpe_gg20_nonces_alloc", "mpe_gg20_nonces_view", "mpe_gg20_nonces_free", "mpe_gg20_sample_nonces",
+            "mpe_gg20_pipeline_create", "mpe_gg20_pipeline_destroy", "mpe_gg20_pipeline_submit", "mpe_gg20_pipeline_submit_seeded",
+            "mpe_gg20_pipeline_flush", "mpe_gg20_pipeline_query", "mpe_gg20_pipeline_wait", "mpe_gg20_pipeline_stream_wait",
+            "mpe_gg20_pipeline_latency_ms", "mpe_gg20_pipeline_sampler_failures"]
 
 
 def check(rc, what):

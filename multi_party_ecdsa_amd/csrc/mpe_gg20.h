@@ -908,6 +908,51 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   return round_exit(s, rc, "gg20 round0");
 }
 
+// dst[i][0..words) = row i of src (zero-extended from src.words): operands of different composites side by side for ONE launch
+__global__ void gather_rows_kernel(int n, Rows src, int src_words, int words, uint32_t* __restrict__ dst) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)n * words) return;
+  const int w = (int)(g % words), i = (int)(g / words);
+  dst[g] = w < src_words ? row_of(src, i)[w] : 0u;
+}
+// Round 1, large batches: the two-base ladders of the range-proof verifications, s^N (c^-1)^e (range_proofs.rs:134-141), and of the
+// MessageB ciphertexts, r^N c_a^b (mta/mod.rs:133-145), have the same shape — a 2048-bit base to the public exponent N times a
+// 4096-bit base to a 256-bit exponent, modulo N^2 of a peer's key — and go through ONE launch of the pair kernel: 12 + 4 items per
+// session instead of launches of 12 and of 4, so that e.g. 4 096 sessions are 65 536 items = two full passes of the chip where the
+// separate launches took 1.5 + 0.5 passes rounded up to whole trips (the pipelined engine's super-batches live at these sizes).
+// Operands are gathered into contiguous rows first (800 bytes per item against a ladder of ~2 500 multiplications modulo N^2).
+static size_t ws_need_round1_merged(const mpe_paillier* pk, size_t nVI, size_t nMB) {
+  return (nVI + nMB) * (size_t)(64 + 128 + 8 + 1 + 128) * 4 + nVI * (128 + 128 + 1) * 4 + modinv_ws_words(pk->ms_nn, (int)nVI) * 4 + 65536;
+}
+static int round1_merged_ladders(mpe_ctx* ctx, const mpe_paillier* pk, size_t nVI, const int32_t* kpub_vi, Rows cipher_vi, Rows s_vi, Rows e_vi,
+                                 size_t nMB, const int32_t* kpub_mb, Rows ca_mb, const uint32_t* bsel, const uint32_t* mb_r,
+                                 const uint32_t** m_vi, const uint8_t** inv_ok_vi, const uint32_t** x_mb, hipStream_t st) {
+  const size_t n = nVI + nMB;
+  Seq q{ctx, st, (int)nVI};
+  const Rows ksel = sel_of(kpub_vi, pk->nkeys);
+  uint8_t* inv_ok = q.flags();
+  uint32_t* cred = q.modmul(pk->ms_nn, ksel, cipher_vi, rows(pk->ms_nn->one_words, 0, nullptr, 1));      // c mod N^2
+  uint32_t* cinv = q.modinv(pk->ms_nn, ksel, rows(cred, 128), inv_ok);                                     // (c^e)^-1 = (c^-1)^e
+  if (q.rc != MPE_OK) return q.rc;
+  uint32_t* b1 = ws_array<uint32_t>(ctx, n * 64);
+  uint32_t* b2 = ws_array<uint32_t>(ctx, n * 128);
+  uint32_t* e2 = ws_array<uint32_t>(ctx, n * 8);
+  int32_t* key = ws_array<int32_t>(ctx, n);
+  uint32_t* out = ws_array<uint32_t>(ctx, n * 128);
+  if (!b1 || !b2 || !e2 || !key || !out) { mpe_set_error_msg("round1: workspace under-reserved"); return MPE_E_NOMEM; }
+  auto gather = [&](size_t cnt, Rows src, int sw, int words, uint32_t* dst) {
+    if (cnt) hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((cnt * words + 255) / 256)), dim3(256), 0, st, (int)cnt, src, sw, words, dst);
+  };
+  gather(nVI, s_vi, 64, 64, b1);              gather(nMB, rows(mb_r, 64), 64, 64, b1 + nVI * 64);
+  gather(nVI, rows(cinv, 128), 128, 128, b2); gather(nMB, ca_mb, 128, 128, b2 + nVI * 128);
+  gather(nVI, e_vi, 8, 8, e2);                gather(nMB, rows(bsel, 8), 8, 8, e2 + nVI * 8);
+  (void)hipMemcpyAsync(key, kpub_vi, nVI * 4, hipMemcpyDeviceToDevice, st);
+  (void)hipMemcpyAsync(key + nVI, kpub_mb, nMB * 4, hipMemcpyDeviceToDevice, st);
+  MPE_TRY(modexp_nn2(ctx, pk, (int)n, key_selector(pk, key), rows(b1, 64, nullptr, 64), key_rows(pk, pk->N, 64, key), 64, rows(b2, 128), rows(e2, 8), 8, out, st));
+  *m_vi = out; *inv_ok_vi = inv_ok; *x_mb = out + nVI * 128;
+  return MPE_OK;
+}
+
 // ---- Round1::proceed (rounds.rs:122-206) -----------------------------------------------------------------------------
 static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_off, uint32_t* d_out, hipStream_t st) {
   int rc = round_enter(s, 1, d_in, d_out, true, true);
@@ -929,26 +974,39 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   // (the reference runs them back to back inside MessageB::b) — two streams, one workspace reservation
   const bool par = ctx->allow_par && (int)c.nVI <= ctx->par_items;
   if (par && rc == MPE_OK) { rc = ws_reserve(ctx, ws_need_alice_verify((int)c.nVI) + ws_need_mul_add_enc((int)c.nMB), st); if (rc == MPE_OK) ctx->ws_hold++; }
-  const bool held = par && rc == MPE_OK;
-  Fork g(ctx, st, 2, held, 2);
+  bool held = par && rc == MPE_OK;
+  // large batches: the ladders of both halves of the round in ONE launch (round1_merged_ladders)
+  const bool merged = !par && ctx->merge_r1 && ctx->use_pair && ctx->use_multiexp && c.nVI > 0 && c.nMB > 0 && c.nVI + c.nMB < ((size_t)1 << 30);
+  const uint32_t *m_vi = nullptr, *x_mb = nullptr;
+  const uint8_t* inv_ok_vi = nullptr;
+  AliceProofRows pr{rows(d_in, SUB0, sub0_vi), rows(d_in + 64, SUB0, sub0_vi), rows(d_in + 72, SUB0, sub0_vi),
+                    rows(d_in + 136, SUB0, sub0_vi), rows(d_in + 161, SUB0, sub0_vi)};
+  if (merged && rc == MPE_OK) {
+    rc = ws_reserve(ctx, ws_need_alice_verify((int)c.nVI) + ws_need_mul_add_enc((int)c.nMB) + ws_need_round1_merged(K->pub, c.nVI, c.nMB), st);
+    if (rc == MPE_OK) { ctx->ws_hold++; held = true; }
+    if (rc == MPE_OK && c.nMB > 0)
+      hipLaunchKernelGGL(mb_prep_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st, d, s->gq, s->w, Z.mb_beta_tag, bsel, btq, s->beta);
+    if (rc == MPE_OK)
+      rc = round1_merged_ladders(ctx, K->pub, c.nVI, s->ix.kpub_vi, rows(s->ca_all, 128, s->ix.ca_vi), with_words(pr.s, 64), pr.e, c.nMB, s->ix.kpub_mb,
+                                 rows(s->ca_all, 128, s->ix.ca_mb), bsel, Z.mb_r, &m_vi, &inv_ok_vi, &x_mb, st);
+    gg_trace(st, "round 1 merged ladders", rc);
+  }
+  Fork g(ctx, st, 2, held && !merged, 2);
   {
     hipStream_t st2 = g.s(1);
-    if (rc == MPE_OK && c.nMB > 0)
+    if (rc == MPE_OK && c.nMB > 0 && !merged)
       hipLaunchKernelGGL(mb_prep_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, d, s->gq, s->w, Z.mb_beta_tag, bsel, btq, s->beta);
     if (rc == MPE_OK)                                                           // encrypt, Paillier::mul, Paillier::add :133-145
       rc = paillier_mul_add_enc(ctx, K->pub, (int)c.nMB, s->ix.kpub_mb, rows(s->ca_all, 128, s->ix.ca_mb), rows(bsel, 8), 8, Z.mb_beta_tag,
-                                Z.mb_r, c_b, st2);
+                                Z.mb_r, c_b, st2, x_mb);
     gg_trace(st2, "MessageB ciphertext", rc);
     if (rc == MPE_OK && c.nMB > 0) {
       hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, ctx->enc, bsel, Z.mb_nonce_b, Bpk, BR, Bz);      // :147
       hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, ctx->enc, btq, Z.mb_nonce_bt, BTpk, BTR, BTz);   // :148
     }
   }
-  if (rc == MPE_OK) {      // every range proof of every peer, for both MessageB::b calls (mta/mod.rs:119-131), read in place
-    AliceProofRows pr{rows(d_in, SUB0, sub0_vi), rows(d_in + 64, SUB0, sub0_vi), rows(d_in + 72, SUB0, sub0_vi),
-                      rows(d_in + 136, SUB0, sub0_vi), rows(d_in + 161, SUB0, sub0_vi)};
-    rc = alice_verify(ctx, K->pub, K->stm, (int)c.nVI, s->ix.kpub_vi, s->ix.st_vi, rows(s->ca_all, 128, s->ix.ca_vi), pr, ok_vi, st);
-  }
+  if (rc == MPE_OK)        // every range proof of every peer, for both MessageB::b calls (mta/mod.rs:119-131), read in place
+    rc = alice_verify(ctx, K->pub, K->stm, (int)c.nVI, s->ix.kpub_vi, s->ix.st_vi, rows(s->ca_all, 128, s->ix.ca_vi), pr, ok_vi, st, m_vi, inv_ok_vi);
   gg_trace(st, "alice_verify", rc);
   g.join();
   if (held) ctx->ws_hold--;

@@ -28,6 +28,7 @@ struct mpe_ctx {
                                   // heuristics below compare a launch with 1/device_share of the chip, not with all of it
   int xwide_div = 16;             // the 4x-lanes (5 limbs per lane) layout: xwide_div * batch <= the resident groups; 0 = off (MPE_XWIDE_DIV)
   bool merge_xn = true;           // round 0: every x^N of the key holders in ONE launch (MPE_NO_MERGE_XN switches it off)
+  bool merge_r1 = true;           // round 1, large batches: the ladders of the verifications and of the MessageBs in ONE launch (MPE_NO_MERGE_R1)
   size_t fb_budget_bytes = 0;     // memory budget of the fixed-base tables of a key object; 0 = a quarter of free HBM (MPE_FB_BUDGET_MB)
   int modexp_waves_per_cu = 8;    // 2 waves/SIMD: the montmul loop holds ~230 VGPRs and already issues back-to-back
   // window-table scratch, grown on demand: one buffer per stream slot (0 = the caller's stream, 1..3 = the auxiliary streams

@@ -263,6 +263,7 @@ static int launch_pair_modexp(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Ro
 #include "mpe_bob.h"
 #include "mpe_gg20.h"
 #include "mpe_sample.h"
+#include "mpe_pipeline.h"
 #include "mpe_sigma.h"
 #include "mpe_blame.h"
 #include "mpe_keygen.h"
@@ -332,6 +333,7 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   // every switch is read HERE, once: no entry point reads the environment afterwards (contexts on several host threads)
   if (const char* e = getenv("MPE_XWIDE_DIV")) { const int v = atoi(e); if (v >= 0) c->xwide_div = v; }
   if (getenv("MPE_NO_MERGE_XN")) c->merge_xn = false;
+  if (getenv("MPE_NO_MERGE_R1")) c->merge_r1 = false;
   if (const char* e = getenv("MPE_FB_BUDGET_MB")) c->fb_budget_bytes = (size_t)atoll(e) << 20;
   if (getenv("MPE_WINDOW_BITS")) { const int w = atoi(getenv("MPE_WINDOW_BITS")); if (w >= 4 && w <= 6) c->window_bits = w; }
   // comb tables of the two fixed secp256k1 generators: module globals, built ONCE per device (immutable afterwards — the only

@@ -360,14 +360,17 @@ static int paillier_encrypt(mpe_ctx* ctx, const mpe_paillier* pk, int B, const i
 // MessageB's ciphertext in one go: out = c_a^k * Enc(m; r) = c_a^k (1 + m N) r^N mod N^2   (mta/mod.rs:133-145:
 // Paillier::encrypt_with_chosen_randomness, Paillier::mul, Paillier::add).  The peer computes this under a key
 // it does not own; r^N and c_a^k share one ladder.
+// x_pre: c_a^k r^N mod N^2 already computed by the caller (Round 1 merges these ladders with those of its verifications)
 static int paillier_mul_add_enc(mpe_ctx* ctx, const mpe_paillier* pk, int B, const int32_t* key_idx, Rows c_a, Rows k, int kw,
-                                const uint32_t* d_m, const uint32_t* d_r, uint32_t* d_out, hipStream_t st) {
+                                const uint32_t* d_m, const uint32_t* d_r, uint32_t* d_out, hipStream_t st, const uint32_t* x_pre = nullptr) {
   MPE_TRY(ws_reserve(ctx, ws_need_mul_add_enc(B), st));
   uint32_t* x = ws_array<uint32_t>(ctx, (size_t)B * 128);
   uint32_t* gm = ws_array<uint32_t>(ctx, (size_t)B * 128);
   const Rows ksel = key_selector(pk, key_idx), Nrow = key_rows(pk, pk->N, 64, key_idx);
   MPE_LAUNCH_1D(enc_gm_kernel, B, st, B, pk->nkeys, d_m, key_idx, pk->N, gm);
-  if (ctx->use_multiexp) {
+  if (x_pre) {
+    x = const_cast<uint32_t*>(x_pre);
+  } else if (ctx->use_multiexp) {
     MPE_TRY(modexp_nn2(ctx, pk, B, ksel, rows(d_r, 64, nullptr, 64), Nrow, 64, c_a, k, kw, x, st));
   } else {
     uint32_t* y = ws_array<uint32_t>(ctx, (size_t)B * 128);

@@ -1,0 +1,286 @@
+// A signing SERVICE's view of the lock-step composition: batches of `batch` sessions arrive one after another (BASELINE config 4's
+// literal shape is a stream of 1 024-session batches) and must not be latency-bound one by one.  The reference runs many
+// `OfflineStage`s concurrently on one executor (round_based's AsyncProtocol; state_machine/sign.rs:667-691 runs its parties through
+// `Simulation`, and rounds.rs:106,215,323 mark the rounds `is_expensive` so that they go to a blocking pool); the device equivalent:
+//
+//   * `group` consecutive batches are coalesced into ONE pass of mpe_gg20_sign (a "super-batch"): every heavy launch carries the
+//     items of all of them, so the launches are large enough for the efficient lane layouts and fill whole passes of the chip
+//     (a 2048-bit ladder launch of 4 x 1 024 sessions is 49 152 + 16 384 items = two full passes of 32 768 resident groups);
+//   * `lanes` super-batches are in flight at once, each on ONE stream of its own (no forked streams inside a lane): the
+//     latency-bound stretches of one (EC kernels, short ladders, inversions) run under the throughput-bound ladders of another.
+//     lanes <= 4 streams in total, so the runtime's default 4 hardware queues never multiplex two lanes onto one queue —
+//     no GPU_MAX_HW_QUEUES, no child process (round 4 needed 16 queues for 13.5 k signatures/s; this design measured 16.0 k at
+//     2 lanes x 4 batches and 16.9 k at 2 x 8 with the defaults: profiles/r05/superbatch_sweep.jsonl);
+//   * ONE host thread feeds everything: submit() only enqueues (D2D copies or the device-side sampler into the lane's staging
+//     arrays, then — when the group is full — the pass and the copies of its results), and returns a ticket.
+// Results are bit-identical to mpe_gg20_sign on the same inputs: a session's outputs do not depend on its neighbours in a batch.
+// Included by mpe_lib.hip after mpe_sample.h.
+#pragma once
+#include "mpe_sample.h"
+
+struct mpe_gg20_pipeline {
+  static constexpr int MAX_LANES = 4, MAX_GROUP = 64, RING = 4096;
+  mpe_ctx* parent = nullptr;
+  const mpe_gg20_keys* K = nullptr;
+  int batch = 0, group = 0, lanes = 0, dedup = 0;
+  struct Out { uint32_t *r, *s, *R; int32_t *recid, *status; };
+  struct Lane {
+    mpe_ctx* ctx = nullptr;
+    hipStream_t st = nullptr;
+    mpe_gg20_nonce_buf* stage = nullptr;      // [group * batch] sessions, every signer local
+    void* blob = nullptr;                     // keyset | r | s | R | recid | status | fail staging
+    size_t blob_bytes = 0;
+    int32_t* keyset = nullptr;
+    Out res{};
+    int32_t* fail = nullptr;
+    int filled = 0;
+    bool any_keyset = false;
+    Out dst[MAX_GROUP];
+    uint64_t ticket[MAX_GROUP];
+  } lane[MAX_LANES];
+  struct Ticket { uint64_t id = 0; hipEvent_t submitted = nullptr, done = nullptr; int lane = -1; bool launched = false, used = false; };
+  Ticket ring[RING];
+  int cur = 0;
+  uint64_t next_ticket = 1;
+  uint64_t launched_groups = 0;
+};
+
+namespace mpe {
+namespace pipe {
+
+static mpe_gg20_pipeline::Ticket* ticket_of(mpe_gg20_pipeline* p, uint64_t id) {
+  if (id == 0 || id >= p->next_ticket) return nullptr;
+  mpe_gg20_pipeline::Ticket* t = &p->ring[id % mpe_gg20_pipeline::RING];
+  return (t->used && t->id == id) ? t : nullptr;
+}
+
+// the open group of lane `li` goes to the device: one pass over filled * batch sessions, then every batch's results to its owner
+static int launch_group(mpe_gg20_pipeline* p, int li) {
+  mpe_gg20_pipeline::Lane& L = p->lane[li];
+  if (L.filled == 0) return MPE_OK;
+  const int B = L.filled * p->batch;
+  mpe_gg20_nonces Z;
+  (void)mpe_gg20_nonces_view(L.stage, &Z);
+  int rc = mpe_gg20_sign(L.ctx, p->K, B, (p->K->K > 1 || L.any_keyset) ? L.keyset : nullptr, &Z, L.res.r, L.res.s, L.res.recid, L.res.R, L.res.status,
+                         p->dedup, 0, L.st);
+  for (int g = 0; g < L.filled; ++g) {
+    const size_t o = (size_t)g * p->batch, nb = (size_t)p->batch;
+    const mpe_gg20_pipeline::Out& d = L.dst[g];
+    if (rc == MPE_OK) {
+      (void)hipMemcpyAsync(d.r, L.res.r + o * 8, nb * 32, hipMemcpyDeviceToDevice, L.st);
+      (void)hipMemcpyAsync(d.s, L.res.s + o * 8, nb * 32, hipMemcpyDeviceToDevice, L.st);
+      (void)hipMemcpyAsync(d.recid, L.res.recid + o, nb * 4, hipMemcpyDeviceToDevice, L.st);
+      (void)hipMemcpyAsync(d.status, L.res.status + o, nb * 4, hipMemcpyDeviceToDevice, L.st);
+      if (d.R) (void)hipMemcpyAsync(d.R, L.res.R + o * 16, nb * 64, hipMemcpyDeviceToDevice, L.st);
+    }
+  }
+  // the staged nonces (k_i, gamma_i, Paillier randomness) and signatures of this group do not wait for the next one to overwrite them
+  (void)hipMemsetAsync(L.stage->blob, 0, L.stage->bytes, L.st);
+  for (int g = 0; g < L.filled; ++g) {
+    mpe_gg20_pipeline::Ticket* t = ticket_of(p, L.ticket[g]);
+    if (!t) continue;
+    (void)hipEventRecord(t->done, L.st);
+    t->launched = true;
+  }
+  L.filled = 0;
+  L.any_keyset = false;
+  p->launched_groups++;
+  p->cur = (li + 1) % p->lanes;
+  if (rc != MPE_OK) return rc;
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mpe_set_error("gg20 pipeline launch", e); return MPE_E_HIP; }
+  return MPE_OK;
+}
+
+// common part of the two submit forms: reserves slot g of the current lane, records the ticket
+static int open_slot(mpe_gg20_pipeline* p, uint32_t* d_r, uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, hipStream_t caller,
+                     int* lane_out, int* slot_out, uint64_t* ticket_out) {
+  if (!p || !d_r || !d_s || !d_recid || !d_status || !ticket_out) return MPE_E_ARG;
+  const uint64_t id = p->next_ticket;
+  mpe_gg20_pipeline::Ticket* t = &p->ring[id % mpe_gg20_pipeline::RING];
+  if (t->used && (!t->launched || hipEventQuery(t->done) != hipSuccess)) {
+    mpe_set_error_msg("gg20 pipeline: more than 4096 batches in flight");
+    return MPE_E_ARG;
+  }
+  if (!t->submitted) {
+    if (hipEventCreate(&t->submitted) != hipSuccess || hipEventCreate(&t->done) != hipSuccess) { mpe_set_error_msg("gg20 pipeline: hipEventCreate"); return MPE_E_HIP; }
+  }
+  const int li = p->cur;
+  mpe_gg20_pipeline::Lane& L = p->lane[li];
+  const int g = L.filled;
+  t->id = id; t->lane = li; t->launched = false; t->used = true;
+  // the lane reads the caller's arrays only after the caller's stream has produced them
+  (void)hipEventRecord(t->submitted, caller);
+  (void)hipStreamWaitEvent(L.st, t->submitted, 0);
+  L.dst[g] = mpe_gg20_pipeline::Out{d_r, d_s, d_R, d_recid, d_status};
+  L.ticket[g] = id;
+  p->next_ticket++;
+  *lane_out = li; *slot_out = g; *ticket_out = id;
+  return MPE_OK;
+}
+static int close_slot(mpe_gg20_pipeline* p, int li, const int32_t* d_keyset) {
+  mpe_gg20_pipeline::Lane& L = p->lane[li];
+  const size_t o = (size_t)L.filled * p->batch;
+  if (d_keyset) { (void)hipMemcpyAsync(L.keyset + o, d_keyset, (size_t)p->batch * 4, hipMemcpyDeviceToDevice, L.st); L.any_keyset = true; }
+  else (void)hipMemsetAsync(L.keyset + o, 0, (size_t)p->batch * 4, L.st);
+  L.filled++;
+  if (L.filled == p->group) return launch_group(p, li);
+  return MPE_OK;
+}
+
+}  // namespace pipe
+}  // namespace mpe
+
+extern "C" {
+
+int mpe_gg20_pipeline_destroy(mpe_gg20_pipeline* p);
+
+int mpe_gg20_pipeline_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, int group, int lanes, int dedup_verify, mpe_gg20_pipeline** out) {
+  if (!ctx || !keys || !out || batch <= 0 || group < 1 || group > mpe_gg20_pipeline::MAX_GROUP || lanes < 1 || lanes > mpe_gg20_pipeline::MAX_LANES)
+    return MPE_E_ARG;
+  for (int i = 0; i < keys->S; ++i) if (keys->own_slot[keys->signers[i]] < 0) { mpe_set_error_msg("gg20 pipeline: the key object must hold every signer's secrets"); return MPE_E_ARG; }
+  mpe_gg20_pipeline* p = new (std::nothrow) mpe_gg20_pipeline();
+  if (!p) return MPE_E_NOMEM;
+  p->parent = ctx; p->K = keys; p->batch = batch; p->group = group; p->lanes = lanes; p->dedup = dedup_verify ? 1 : 0;
+  const size_t GB = (size_t)group * batch;
+  int rc = MPE_OK;
+  for (int li = 0; li < lanes && rc == MPE_OK; ++li) {
+    mpe_gg20_pipeline::Lane& L = p->lane[li];
+    rc = mpe_ctx_create(&L.ctx, ctx->device);
+    if (rc != MPE_OK) break;
+    // a lane is the parent context with a workspace of its own and NO forked streams (one stream per lane: <= 4 in total)
+    mpe_ctx* c = L.ctx;
+    c->fb_window_bits = ctx->fb_window_bits; c->window_bits = ctx->window_bits; c->ec_lane_groups = ctx->ec_lane_groups;
+    c->adaptive_lanes = ctx->adaptive_lanes; c->use_pown = ctx->use_pown; c->use_pair = ctx->use_pair; c->use_multiexp = ctx->use_multiexp;
+    c->use_crt = ctx->use_crt; c->use_fixed_base = ctx->use_fixed_base; c->use_sliding = ctx->use_sliding; c->wide_div = ctx->wide_div;
+    c->xwide_div = ctx->xwide_div; c->merge_xn = ctx->merge_xn; c->merge_r1 = ctx->merge_r1; c->enc = ctx->enc;
+    c->allow_par = false;
+    if (hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking) != hipSuccess) { mpe_set_error_msg("gg20 pipeline: hipStreamCreate"); rc = MPE_E_HIP; break; }
+    rc = mpe_gg20_nonces_alloc(c, keys, (int)GB, keys->S, &L.stage);
+    if (rc != MPE_OK) break;
+    const size_t words = GB * (1 + 8 + 8 + 16 + 1 + 1) + 64;
+    L.blob_bytes = words * 4;
+    if (hipMalloc(&L.blob, L.blob_bytes) != hipSuccess) { mpe_set_error_msg("gg20 pipeline: hipMalloc(staging)"); rc = MPE_E_NOMEM; break; }
+    (void)hipMemset(L.blob, 0, L.blob_bytes);
+    uint32_t* w = (uint32_t*)L.blob;
+    L.keyset = (int32_t*)w; w += GB;
+    L.res.r = w; w += GB * 8; L.res.s = w; w += GB * 8; L.res.R = w; w += GB * 16;
+    L.res.recid = (int32_t*)w; w += GB; L.res.status = (int32_t*)w; w += GB;
+    L.fail = (int32_t*)w;
+  }
+  if (rc != MPE_OK) { mpe_gg20_pipeline_destroy(p); return rc; }
+  *out = p;
+  return MPE_OK;
+}
+
+int mpe_gg20_pipeline_destroy(mpe_gg20_pipeline* p) {
+  if (!p) return MPE_E_ARG;
+  for (int li = 0; li < p->lanes; ++li) {
+    mpe_gg20_pipeline::Lane& L = p->lane[li];
+    if (L.st) (void)hipStreamSynchronize(L.st);
+    if (L.stage) (void)mpe_gg20_nonces_free(L.stage);
+    if (L.blob) { (void)hipMemset(L.blob, 0, L.blob_bytes); (void)hipFree(L.blob); }
+    if (L.ctx) (void)mpe_ctx_destroy(L.ctx);
+    if (L.st) (void)hipStreamDestroy(L.st);
+  }
+  for (auto& t : p->ring) { if (t.submitted) (void)hipEventDestroy(t.submitted); if (t.done) (void)hipEventDestroy(t.done); }
+  delete p;
+  return MPE_OK;
+}
+
+int mpe_gg20_pipeline_submit(mpe_gg20_pipeline* p, const int32_t* d_keyset, const mpe_gg20_nonces* nonces, uint32_t* d_r, uint32_t* d_s, int32_t* d_recid,
+                             uint32_t* d_R, int32_t* d_status, void* stream, uint64_t* ticket) {
+  if (!p || !nonces) return MPE_E_ARG;
+  if (p->K->K > 1 && !d_keyset) return MPE_E_ARG;
+  int li = 0, g = 0;
+  MPE_TRY(mpe::pipe::open_slot(p, d_r, d_s, d_recid, d_R, d_status, (hipStream_t)stream, &li, &g, ticket));
+  mpe_gg20_pipeline::Lane& L = p->lane[li];
+  mpe_gg20_nonces src = *nonces;
+  for (int f = 0; f < mpe::smp::NF; ++f) {
+    const size_t w = L.stage->per_session[f] * (size_t)p->batch;
+    const uint32_t* from = *mpe::smp::nonce_field_ptr(&src, f);
+    uint32_t* to = const_cast<uint32_t*>(*mpe::smp::nonce_field_ptr(&L.stage->view, f)) + (size_t)g * w;
+    if (!from) { mpe_set_error_msg("gg20 pipeline: a nonce array is NULL"); return MPE_E_ARG; }
+    (void)hipMemcpyAsync(to, from, w * 4, hipMemcpyDeviceToDevice, L.st);
+  }
+  return mpe::pipe::close_slot(p, li, d_keyset);
+}
+
+int mpe_gg20_pipeline_submit_seeded(mpe_gg20_pipeline* p, const int32_t* d_keyset, const uint8_t* h_seed32, uint64_t batch_counter, const uint32_t* d_msg,
+                                    uint32_t* d_r, uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, void* stream, uint64_t* ticket) {
+  if (!p || !h_seed32 || !d_msg || (batch_counter >> 56) != 0) return MPE_E_ARG;
+  if (p->K->K > 1 && !d_keyset) return MPE_E_ARG;
+  int li = 0, g = 0;
+  MPE_TRY(mpe::pipe::open_slot(p, d_r, d_s, d_recid, d_R, d_status, (hipStream_t)stream, &li, &g, ticket));
+  mpe_gg20_pipeline::Lane& L = p->lane[li];
+  mpe_gg20_nonces dst = L.stage->view;
+  for (int f = 0; f < mpe::smp::NF; ++f) *mpe::smp::nonce_field_ptr(&dst, f) += (size_t)g * L.stage->per_session[f] * (size_t)p->batch;
+  (void)hipMemcpyAsync(const_cast<uint32_t*>(dst.msg), d_msg, (size_t)p->batch * 32, hipMemcpyDeviceToDevice, L.st);
+  int32_t local[8];
+  for (int i = 0; i < p->K->S; ++i) local[i] = i;
+  MPE_TRY(mpe::smp::sample_gg20(L.ctx, p->K, p->batch, p->K->S, local, d_keyset, h_seed32, batch_counter, &dst, L.fail, L.st));
+  return mpe::pipe::close_slot(p, li, d_keyset);
+}
+
+int mpe_gg20_pipeline_flush(mpe_gg20_pipeline* p) {
+  if (!p) return MPE_E_ARG;
+  int rc = MPE_OK;
+  for (int k = 0; k < p->lanes; ++k) {
+    const int li = (p->cur + k) % p->lanes;
+    if (p->lane[li].filled) { const int r = mpe::pipe::launch_group(p, li); if (rc == MPE_OK) rc = r; }
+  }
+  return rc;
+}
+
+int mpe_gg20_pipeline_query(mpe_gg20_pipeline* p, uint64_t ticket, int* done) {
+  if (!p || !done) return MPE_E_ARG;
+  mpe_gg20_pipeline::Ticket* t = mpe::pipe::ticket_of(p, ticket);
+  if (!t) return MPE_E_ARG;
+  *done = (t->launched && hipEventQuery(t->done) == hipSuccess) ? 1 : 0;
+  return MPE_OK;
+}
+
+int mpe_gg20_pipeline_wait(mpe_gg20_pipeline* p, uint64_t ticket) {
+  if (!p) return MPE_E_ARG;
+  mpe_gg20_pipeline::Ticket* t = mpe::pipe::ticket_of(p, ticket);
+  if (!t) return MPE_E_ARG;
+  if (!t->launched) MPE_TRY(mpe::pipe::launch_group(p, t->lane));       // its group is still open: it goes now, partly filled
+  const hipError_t e = hipEventSynchronize(t->done);
+  if (e != hipSuccess) { mpe_set_error("gg20 pipeline wait", e); return MPE_E_HIP; }
+  return MPE_OK;
+}
+
+int mpe_gg20_pipeline_stream_wait(mpe_gg20_pipeline* p, uint64_t ticket, void* stream) {
+  if (!p) return MPE_E_ARG;
+  mpe_gg20_pipeline::Ticket* t = mpe::pipe::ticket_of(p, ticket);
+  if (!t) return MPE_E_ARG;
+  if (!t->launched) MPE_TRY(mpe::pipe::launch_group(p, t->lane));
+  const hipError_t e = hipStreamWaitEvent((hipStream_t)stream, t->done, 0);
+  if (e != hipSuccess) { mpe_set_error("gg20 pipeline stream wait", e); return MPE_E_HIP; }
+  return MPE_OK;
+}
+
+int mpe_gg20_pipeline_latency_ms(mpe_gg20_pipeline* p, uint64_t ticket, float* ms) {
+  if (!p || !ms) return MPE_E_ARG;
+  mpe_gg20_pipeline::Ticket* t = mpe::pipe::ticket_of(p, ticket);
+  if (!t || !t->launched) return MPE_E_ARG;
+  hipError_t e = hipEventSynchronize(t->done);
+  if (e == hipSuccess) e = hipEventElapsedTime(ms, t->submitted, t->done);
+  if (e != hipSuccess) { mpe_set_error("gg20 pipeline latency", e); return MPE_E_HIP; }
+  return MPE_OK;
+}
+
+int mpe_gg20_pipeline_sampler_failures(mpe_gg20_pipeline* p, int32_t* h_out) {
+  if (!p || !h_out) return MPE_E_ARG;
+  int32_t tot = 0;
+  for (int li = 0; li < p->lanes; ++li) {
+    int32_t v = 0;
+    (void)hipStreamSynchronize(p->lane[li].st);
+    if (hipMemcpy(&v, p->lane[li].fail, 4, hipMemcpyDeviceToHost) != hipSuccess) return MPE_E_HIP;
+    tot += v;
+  }
+  *h_out = tot;
+  return MPE_OK;
+}
+
+}  // extern "C"

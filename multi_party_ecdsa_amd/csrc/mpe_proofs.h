@@ -341,10 +341,13 @@ static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statem
 // ---------------------------------------------------------------------------------------------
 // AliceProof::verify   (range_proofs.rs:105-156).  Small batches: the N~ side and the N^2 side on separate streams.
 // ---------------------------------------------------------------------------------------------
+// m_pre / inv_ok_pre: the caller already holds m = s^N (c^-1)^e mod N^2 and the verdict of the inversion of c (Round 1 computes the
+// ladders of its verifications and of its MessageBs in ONE launch, mpe_gg20.h round1_merged_ladders)
 static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
-                        const int32_t* st_idx, Rows cipher, const AliceProofRows& pr, uint8_t* ok, hipStream_t st) {
+                        const int32_t* st_idx, Rows cipher, const AliceProofRows& pr, uint8_t* ok, hipStream_t st,
+                        const uint32_t* m_pre = nullptr, const uint8_t* inv_ok_pre = nullptr) {
   MPE_TRY(ws_reserve(ctx, ws_need_alice_verify(B), st));
-  Fork f(ctx, st, 3, B <= ctx->par_items);
+  Fork f(ctx, st, 3, B <= ctx->par_items && !m_pre);
   Seq q{ctx, f.s(0), B}, q1{ctx, f.s(1), B}, q2{ctx, f.s(2), B};
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
@@ -361,7 +364,10 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
   uint32_t* gs1 = q.words(128);
   q.muladd(pr.s1, 25, Nrow, 64, no_rows(), 0, gs1, 128);
   uint32_t *u = nullptr, *b12 = nullptr, *cie = nullptr;
-  if (f.on) {
+  if (m_pre) {
+    inv_ok2 = const_cast<uint8_t*>(inv_ok_pre);
+    u = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(m_pre, 128));
+  } else if (f.on) {
     // small batch (latency-bound): the 2048-bit ladder s^N starts at once; the inversion of c and the short ladder
     // (c^-1)^e run beside it on the stream of the fixed-base side, and one more multiplication joins them
     uint32_t* sn = q.modexp_nn(pk, ksel, with_words(pr.s, 64), Nrow, 64, false);

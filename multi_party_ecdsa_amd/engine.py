@@ -562,6 +562,80 @@ def gg20_sign(ctx, keys, nonces, B, dedup_verify=False, chunk=0, want_R=False, k
     return (r, s, recid, status, R) if want_R else (r, s, recid, status)
 
 
+class Gg20Pipeline:
+    """mpe_gg20_pipeline_*: a stream of `batch`-session batches, `group` of them coalesced per pass, `lanes` passes in flight on one
+    stream each (include/mpecdsa_hip.h).  submit / submit_seeded return a ticket; the result tensors of a ticket are valid after
+    wait(ticket) (or after stream_wait on the consuming stream)."""
+
+    def __init__(self, ctx, keys, batch, group=4, lanes=2, dedup_verify=False):
+        self.ctx, self.keys, self.batch, self.group, self.lanes = ctx, keys, batch, group, lanes
+        h = C.c_void_p()
+        N_.check(N_.lib.mpe_gg20_pipeline_create(ctx.h, keys.h, batch, group, lanes, int(bool(dedup_verify)), C.byref(h)), "mpe_gg20_pipeline_create")
+        self.h = h
+        self._keep = {}                       # ticket -> the tensors the device still reads / writes
+
+    def _outs(self, want_R):
+        B = self.batch
+        r, s = _new(self.ctx, B, 8), _new(self.ctx, B, 8)
+        recid = torch.empty((B,), dtype=torch.int32, device=self.ctx.device)
+        status = torch.full((B,), -1, dtype=torch.int32, device=self.ctx.device)
+        R = _new(self.ctx, B, 16) if want_R else None
+        return r, s, recid, status, R
+
+    def submit(self, nonces, keyset=None, want_R=False):
+        r, s, recid, status, R = self._outs(want_R)
+        nn = _struct(N_.Gg20Nonces, nonces)
+        t = C.c_uint64(0)
+        N_.check(N_.lib.mpe_gg20_pipeline_submit(self.h, _ptr(keyset), C.byref(nn), _ptr(r), _ptr(s), _ptr(recid), _ptr(R), _ptr(status), self.ctx.stream(),
+                                                 C.byref(t)), "mpe_gg20_pipeline_submit")
+        self._keep[t.value] = (nonces, keyset, r, s, recid, status, R)
+        return t.value
+
+    def submit_seeded(self, seed, batch_counter, msg, keyset=None, want_R=False):
+        r, s, recid, status, R = self._outs(want_R)
+        t = C.c_uint64(0)
+        N_.check(N_.lib.mpe_gg20_pipeline_submit_seeded(self.h, _ptr(keyset), _seed(seed), int(batch_counter), _ptr(msg), _ptr(r), _ptr(s), _ptr(recid),
+                                                        _ptr(R), _ptr(status), self.ctx.stream(), C.byref(t)), "mpe_gg20_pipeline_submit_seeded")
+        self._keep[t.value] = (msg, keyset, r, s, recid, status, R)
+        return t.value
+
+    def flush(self):
+        N_.check(N_.lib.mpe_gg20_pipeline_flush(self.h), "mpe_gg20_pipeline_flush")
+
+    def done(self, ticket):
+        d = C.c_int(0)
+        N_.check(N_.lib.mpe_gg20_pipeline_query(self.h, ticket, C.byref(d)), "mpe_gg20_pipeline_query")
+        return bool(d.value)
+
+    def wait(self, ticket, want_R=False):
+        """blocks until the batch is complete; returns (r, s, recid, status[, R]) and forgets the ticket's tensors"""
+        N_.check(N_.lib.mpe_gg20_pipeline_wait(self.h, ticket), "mpe_gg20_pipeline_wait")
+        _, _, r, s, recid, status, R = self._keep.pop(ticket)
+        return (r, s, recid, status, R) if want_R else (r, s, recid, status)
+
+    def latency_ms(self, ticket):
+        ms = C.c_float(0)
+        N_.check(N_.lib.mpe_gg20_pipeline_latency_ms(self.h, ticket, C.byref(ms)), "mpe_gg20_pipeline_latency_ms")
+        return ms.value
+
+    def sampler_failures(self):
+        v = C.c_int32(0)
+        N_.check(N_.lib.mpe_gg20_pipeline_sampler_failures(self.h, C.byref(v)), "mpe_gg20_pipeline_sampler_failures")
+        return v.value
+
+    def close(self):
+        if self.h:
+            N_.lib.mpe_gg20_pipeline_destroy(self.h)
+            self.h = None
+            self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- the sampling side of the trait surface (mpe_sample.h): curv Samplable / from_modulo / Scalar::random on the device ----
 SAMPLE_NONZERO, SAMPLE_PLUS_ONE, SAMPLE_COPRIME = 1, 2, 4
 

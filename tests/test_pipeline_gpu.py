@@ -1,0 +1,129 @@
+"""The pipelined engine (mpe_gg20_pipeline_*, mpe_pipeline.h): a stream of small batches coalesced into passes that run on a few
+concurrent lanes gives, batch by batch, exactly what mpe_gg20_sign and the oracle give — whatever the grouping, partly filled groups
+and the order of waiting; the seeded form signs from values sampled on the device (mpe_sample.h) and equals the oracle expanding the
+same seed.  Reference shape: many OfflineStage instances side by side, state_machine/sign.rs:667-691."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import fixtures as F
+import gg20_fixture as G
+from multi_party_ecdsa_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+SEED = hashlib.sha256(b"pipeline").digest()
+
+
+def dv(ctx, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(ctx.device)
+
+
+def hv(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def wallet(gpu_ctx):
+    lk = G.make_local_keys(F.load_keys(), 1, 3, [0, 1])
+    gk = E.Gg20Keys(gpu_ctx, 1, 3, [0, 1], lk["arrays"])
+    yield lk, gk
+    gk.close()
+
+
+@pytest.mark.parametrize("group,lanes,nb", [(3, 2, 7), (1, 1, 2), (4, 3, 5)])
+def test_stream_of_batches_equals_batch_by_batch_signing(gpu_ctx, wallet, group, lanes, nb):
+    ctx = gpu_ctx
+    lk, gk = wallet
+    B = 6
+    host = [G.make_nonces(lk, B, seed="pipe-%d" % b) for b in range(nb)]
+    dev = [{f: dv(ctx, v) for f, v in h.items()} for h in host]
+    pipe = E.Gg20Pipeline(ctx, gk, B, group=group, lanes=lanes)
+    tickets = [pipe.submit(d, want_R=True) for d in dev]
+    assert tickets == list(range(1, nb + 1))
+    # waiting in reverse order: the last ticket sits in a partly filled group that wait() must flush
+    got = {}
+    for t in reversed(tickets):
+        got[t] = pipe.wait(t, want_R=True)
+        assert pipe.done(t)
+    assert all(pipe.latency_ms(t) > 0 for t in tickets)
+    for b, t in enumerate(tickets):
+        r, s, recid, status, R = got[t]
+        wr, ws, wrecid, wR, wstatus = G.oracle_sign(lk, host[b], B)
+        assert not wstatus.any() and not status.cpu().numpy().any()
+        assert np.array_equal(hv(r), wr) and np.array_equal(hv(s), ws) and np.array_equal(recid.cpu().numpy(), wrecid) and np.array_equal(hv(R), wR)
+    pipe.close()
+
+
+def test_a_tampered_batch_fails_alone(gpu_ctx, wallet):
+    """a batch whose values make a check fail (a Paillier randomness of 0: the ciphertext is 0, decryption and the proofs break) gets
+    its statuses; its neighbours in the same pass sign — exactly what mpe_gg20_sign says about the same arrays"""
+    ctx = gpu_ctx
+    lk, gk = wallet
+    B = 4
+    host = [G.make_nonces(lk, B, seed="pt-%d" % b) for b in range(3)]
+    host[1]["r_a"][2:4] = 0                                         # session 1 of batch 1: both parties encrypt with r = 0
+    dev = [{f: dv(ctx, v) for f, v in h.items()} for h in host]
+    pipe = E.Gg20Pipeline(ctx, gk, B, group=3, lanes=1)
+    tickets = [pipe.submit(d) for d in dev]
+    for b, t in enumerate(tickets):
+        r, s, recid, status = pipe.wait(t)
+        r1, s1, recid1, status1 = E.gg20_sign(ctx, gk, dev[b], B)
+        ctx.sync()
+        assert np.array_equal(status.cpu().numpy(), status1.cpu().numpy()) and np.array_equal(hv(r), hv(r1)) and np.array_equal(hv(s), hv(s1))
+        wstatus = G.oracle_sign(lk, host[b], B)[4]
+        assert np.array_equal(status.cpu().numpy(), wstatus)
+        assert (status.cpu().numpy() != 0).tolist() == ([False, True, False, False] if b == 1 else [False] * B)
+    pipe.close()
+
+
+def test_seeded_stream_equals_the_oracle_expanding_the_same_seed(gpu_ctx, wallet):
+    import ossl
+    ctx = gpu_ctx
+    lk, gk = wallet
+    B, nb = 5, 6
+    msgs = [F.words([int.from_bytes(hashlib.sha256(b"m %d %d" % (b, i)).digest(), "big") for i in range(B)], 8) for b in range(nb)]
+    pipe = E.Gg20Pipeline(ctx, gk, B, group=2, lanes=2)
+    tickets = [pipe.submit_seeded(SEED, 1000 + b, dv(ctx, msgs[b])) for b in range(nb)]
+    pipe.flush()
+    for b, t in enumerate(tickets):
+        r, s, recid, status = pipe.wait(t)
+        z, fails = G.oracle_sample_nonces(lk, B, SEED, 1000 + b, msg=msgs[b])
+        wr, ws, wrecid, _, wstatus = G.oracle_sign(lk, z, B)
+        assert fails == 0 and not wstatus.any() and not status.cpu().numpy().any()
+        assert np.array_equal(hv(r), wr) and np.array_equal(hv(s), ws) and np.array_equal(recid.cpu().numpy(), wrecid)
+        assert ossl.ecdsa_verify(lk["arrays"]["y"][0], msgs[b], wr, ws).all()
+    assert pipe.sampler_failures() == 0
+    pipe.close()
+
+
+def test_pipeline_with_key_sets_and_argument_errors(gpu_ctx):
+    ctx = gpu_ctx
+    keys = F.load_keys()
+    t, n, signers, K, B = 1, 3, [0, 1], 2, 4
+    lks = [G.make_local_keys(keys[3 * kk:3 * kk + 3], t, n, signers, seed="pw%d" % kk) for kk in range(K)]
+    arrays = {f: np.concatenate([lk["arrays"][f] for lk in lks]) for f in ("x", "p", "q", "Nt", "h1", "h2", "y", "X")}
+    arrays["signers"] = lks[0]["arrays"]["signers"]
+    lk = dict(t=t, n=n, S=2, arrays=arrays, nkeysets=K)
+    gk = E.Gg20Keys(ctx, t, n, signers, arrays, nkeysets=K)
+    pipe = E.Gg20Pipeline(ctx, gk, B, group=2, lanes=2)
+    msg = F.words([7 + i for i in range(B)], 8)
+    with pytest.raises(E.N_.MpeError):
+        pipe.submit_seeded(SEED, 1, dv(ctx, msg))                                  # several wallets: every session must name its key set
+    with pytest.raises(E.N_.MpeError):
+        pipe.submit_seeded(SEED, 1 << 56, dv(ctx, msg), keyset=dv(ctx, np.zeros(B, dtype=np.int32)))
+    sets = [np.array([0, 1, 1, 0], dtype=np.int32), np.array([1, 1, 0, 0], dtype=np.int32), np.array([0, 0, 0, 1], dtype=np.int32)]
+    tickets = [pipe.submit_seeded(SEED, 50 + b, dv(ctx, msg), keyset=dv(ctx, sets[b])) for b in range(3)]
+    for b, tk in enumerate(tickets):
+        r, s, recid, status = pipe.wait(tk)
+        z, _ = G.oracle_sample_nonces(lk, B, SEED, 50 + b, keyset=sets[b], msg=msg)
+        res = G.oracle_sign_ex(lk, z, B, keyset=sets[b])
+        assert not res["status"].any() and not status.cpu().numpy().any()
+        assert np.array_equal(hv(r), res["r"]) and np.array_equal(hv(s), res["s"])
+    with pytest.raises(E.N_.MpeError):
+        pipe.wait(99)
+    pipe.close()
+    with pytest.raises(E.N_.MpeError):
+        E.Gg20Pipeline(ctx, gk, B, group=2, lanes=5)
+    gk.close()
