@@ -512,8 +512,9 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int3
  * latency-bound (chains of ~2 048 dependent squarings at a fraction of the chip).  The reference runs many `OfflineStage`s
  * concurrently on one executor (state_machine/sign.rs:667-691; rounds.rs:106,215,323 `is_expensive`).  Here:
  * `group` consecutive batches are coalesced into ONE lock-step pass (every heavy launch carries the items of all of them) and
- * `lanes` (1..4) such passes are in flight at once, each on one stream of its own with its own workspace — at most 4 streams,
- * the runtime's default hardware queues, ONE host thread: submit only enqueues.  Results are bit-identical to mpe_gg20_sign.
+ * `lanes` (1..4) such passes are in flight at once, each on one stream of its own with its own workspace, plus ONE stream that stages
+ * the inputs of the next groups (copies or the device-side sampler) while the lanes compute: lanes <= 3 keeps every stream on a
+ * hardware queue of its own with the runtime's defaults.  ONE host thread: submit only enqueues.  Results are bit-identical to mpe_gg20_sign.
  *   submit         the caller's sampled values of ONE batch (layout of mpe_gg20_nonces with every signer local, as for
  *                  mpe_gg20_sign) and where its results go: d_r, d_s [batch][8], d_recid, d_status [batch], d_R [batch][16] or NULL.
  *                  `stream`: the stream that produced the inputs (the pipeline waits for it).  Inputs are copied and results
@@ -523,7 +524,8 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int3
  *   flush          sends the partly filled group to the device (a service calls it when its queue runs dry)
  *   wait           blocks the host until the batch of `ticket` is complete (flushing its group if it is still open);
  *   stream_wait    makes `stream` wait for it instead;  query: *done = 0 / 1 without blocking
- *   latency_ms     device time from the submit call to the completion of that batch's results
+ *   latency_ms     device time from the submit call to the completion of that batch's results (includes the time the batch waited
+ *                  for its group to fill and for a lane);  pass_ms: from the start of the pass that carried it to its completion
  * One pipeline object is driven by one host thread at a time.  Destroying it waits for the work in flight and wipes its staging. */
 typedef struct mpe_gg20_pipeline mpe_gg20_pipeline;
 int mpe_gg20_pipeline_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, int group, int lanes, int dedup_verify,
@@ -539,6 +541,7 @@ int mpe_gg20_pipeline_query(mpe_gg20_pipeline* p, uint64_t ticket, int* done);
 int mpe_gg20_pipeline_wait(mpe_gg20_pipeline* p, uint64_t ticket);
 int mpe_gg20_pipeline_stream_wait(mpe_gg20_pipeline* p, uint64_t ticket, void* stream);
 int mpe_gg20_pipeline_latency_ms(mpe_gg20_pipeline* p, uint64_t ticket, float* ms);
+int mpe_gg20_pipeline_pass_ms(mpe_gg20_pipeline* p, uint64_t ticket, float* ms);
 /* items of the seeded submissions whose rejection loops gave up (see mpe_sample_below); waits for the lanes */
 int mpe_gg20_pipeline_sampler_failures(mpe_gg20_pipeline* p, int32_t* h_out);
 
@@ -570,6 +573,24 @@ int mpe_vss_validate_share(mpe_ctx* ctx, int batch, int t1, const uint32_t* d_co
                            uint8_t* d_ok, void* stream);
 int mpe_vss_point_commitment(mpe_ctx* ctx, int batch, int t1, const uint32_t* d_commits, const int32_t* d_index, uint32_t* d_out,
                              void* stream);
+/* The two keygen verdicts AS THE REFERENCE COMPOSES THEM, batched over items = (keygen session, prover i): `n_parties` consecutive
+ * items form one session, d_ok [batch], d_bad_actors [batch / n_parties] = the reference's `ErrorType::bad_actors` as a bit mask
+ * over the provers of the session (may be NULL).
+ * mpe_keygen_verify_round1 = `phase1_verify_com_phase3_verify_correct_key_verify_dlog_phase2_distribute` (party_i.rs:260-320):
+ *   HashCommitment(y_i, blind_factor) == com  &&  NiCorrectKeyProof::verify(e)  &&  2047 <= e.n.bit_length() <= 2048  &&
+ *   2047 <= dlog_statement.N.bit_length() <= 2048 (PAILLIER_MIN/MAX_BIT_LENGTH, party_i.rs:49-50; a wider modulus does not fit the
+ *   64-word rows)  &&  composite_dlog_proof_base_h1.verify({N~, h1, h2})  &&  composite_dlog_proof_base_h2.verify({N~, h2, h1}).
+ *   Rows: y [16], blind [8], com [8], N [64], sigma [11][64], Nt / h1 / h2 [64], x_h1 / x_h2 [64], y_h1 / y_h2 [73].
+ * mpe_keygen_verify_round2 = the verdict of `phase2_verify_vss_construct_keypair_phase3_pok_dlog` (party_i.rs:322-367):
+ *   vss_scheme_vec[i].validate_share(share_i, index)  &&  vss_scheme_vec[i].commitments[0] == y_vec[i].
+ *   d_commits [batch][t1][16], d_share [batch][8], d_index [batch] (the VERIFIER's 1-based index), d_y [batch][16]. */
+typedef struct {
+  const uint32_t *y, *blind, *com, *N, *sigma, *Nt, *h1, *h2, *x_h1, *y_h1, *x_h2, *y_h2;
+} mpe_keygen_round1;
+int mpe_keygen_verify_round1(mpe_ctx* ctx, int batch, int n_parties, const mpe_keygen_round1* in, uint8_t* d_ok, uint32_t* d_bad_actors,
+                             void* stream);
+int mpe_keygen_verify_round2(mpe_ctx* ctx, int batch, int n_parties, int t1, const uint32_t* d_commits, const uint32_t* d_share,
+                             const int32_t* d_index, const uint32_t* d_y, uint8_t* d_ok, uint32_t* d_bad_actors, void* stream);
 
 /* ---- Lindell'17 two-party ECDSA, signing ---------------------------------------------- */
 /* Party two, `PartialSig::compute(ek, encrypted_secret_share, local_share, ephemeral_local_share,

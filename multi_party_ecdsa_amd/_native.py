@@ -71,6 +71,8 @@ GG20_NONCE_FIELDS = ["k", "gamma", "blind", "r_a", "al_alpha", "al_beta", "al_ga
                      "mb_nonce_b", "mb_nonce_bt", "l", "ped_s1", "ped_s2", "pdl_alpha", "pdl_beta", "pdl_rho", "pdl_gamma",
                      "heg_s1", "heg_s2", "msg"]
 Gg20Nonces = _ptr_struct("Gg20Nonces", GG20_NONCE_FIELDS)
+KEYGEN_ROUND1_FIELDS = ["y", "blind", "com", "N", "sigma", "Nt", "h1", "h2", "x_h1", "y_h1", "x_h2", "y_h2"]
+KeygenRound1 = _ptr_struct("KeygenRound1", KEYGEN_ROUND1_FIELDS)
 PedersenProof = _ptr_struct("PedersenProof", ["com", "e", "a1", "a2", "z1", "z2"])
 HegStatement = _ptr_struct("HegStatement", ["G", "H", "Y", "D", "E"])
 HegProof = _ptr_struct("HegProof", ["T", "A3", "z1", "z2"])
@@ -183,6 +185,8 @@ def _load():
         "mpe_paillier_decrypt": (ip, [vp, vp, ip, i32p, u32p, u32p, vp]),
         "mpe_paillier_add": (ip, [vp, vp, ip, i32p, u32p, u32p, u32p, vp]),
         "mpe_paillier_mul": (ip, [vp, vp, ip, i32p, u32p, u32p, ip, u32p, vp]),
+        "mpe_keygen_verify_round1": (ip, [vp, ip, ip, C.POINTER(KeygenRound1), vp, u32p, vp]),
+        "mpe_keygen_verify_round2": (ip, [vp, ip, ip, ip, u32p, u32p, i32p, u32p, vp, u32p, vp]),
         "mpe_sample_bits": (ip, [vp, ip, C.c_char_p, C.c_uint64, ip, ip, u32p, vp]),
         "mpe_sample_below": (ip, [vp, ip, C.c_char_p, C.c_uint64, u32p, ip, ip, i32p, ip, ip, u32p, i32p, vp]),
         "mpe_sample_scalar": (ip, [vp, ip, C.c_char_p, C.c_uint64, u32p, i32p, vp]),
@@ -198,6 +202,7 @@ def _load():
         "mpe_gg20_pipeline_wait": (ip, [vp, C.c_uint64]),
         "mpe_gg20_pipeline_stream_wait": (ip, [vp, C.c_uint64, vp]),
         "mpe_gg20_pipeline_latency_ms": (ip, [vp, C.c_uint64, C.POINTER(C.c_float)]),
+        "mpe_gg20_pipeline_pass_ms": (ip, [vp, C.c_uint64, C.POINTER(C.c_float)]),
         "mpe_gg20_pipeline_sampler_failures": (ip, [vp, C.POINTER(C.c_int32)]),
         "mpe_gg20_sample_nonces": (ip, [vp, vp, ip, ip, C.POINTER(C.c_int32), i32p, C.c_char_p, C.c_uint64, C.POINTER(Gg20Nonces), i32p, vp]),
     }
@@ -232,7 +237,7 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_gg20_nonces_alloc", "mpe_gg20_nonces_view", "mpe_gg20_nonces_free", "mpe_gg20_sample_nonces",
             "mpe_gg20_pipeline_create", "mpe_gg20_pipeline_destroy", "mpe_gg20_pipeline_submit", "mpe_gg20_pipeline_submit_seeded",
             "mpe_gg20_pipeline_flush", "mpe_gg20_pipeline_query", "mpe_gg20_pipeline_wait", "mpe_gg20_pipeline_stream_wait",
-            "mpe_gg20_pipeline_latency_ms", "mpe_gg20_pipeline_sampler_failures"]
+            "mpe_gg20_pipeline_latency_ms", "mpe_gg20_pipeline_pass_ms", "mpe_gg20_pipeline_sampler_failures", "mpe_keygen_verify_round1", "mpe_keygen_verify_round2"]
 
 
 def check(rc, what):

@@ -147,6 +147,34 @@ __global__ void cd_y_kernel(int B, const uint32_t* __restrict__ r, const uint32_
 }  // namespace kg
 }  // namespace mpe
 
+namespace mpe {
+namespace kg {
+// the verdict of phase1_verify_com_phase3_verify_correct_key_verify_dlog_phase2_distribute for one prover (party_i.rs:277-303), in the
+// reference's order of conjunction: commitment, NiCorrectKeyProof, bit lengths of e.n and dlog_statement.N, both CompositeDLogProofs
+__global__ void r1_verdict_kernel(int B, int n, const uint32_t* __restrict__ com_want, const uint32_t* __restrict__ com_got, const uint8_t* __restrict__ ck,
+                                  const uint32_t* __restrict__ N, const uint32_t* __restrict__ Nt, const uint8_t* __restrict__ cd1,
+                                  const uint8_t* __restrict__ cd2, uint8_t* __restrict__ ok, uint32_t* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  bool v = sm::cmp(com_want + (size_t)i * 8, 8, com_got + (size_t)i * 8, 8) == 0 && ck[i];
+  // PAILLIER_MIN_BIT_LENGTH = 2047 <= bit_length <= PAILLIER_MAX_BIT_LENGTH = 2048 (party_i.rs:49-50,287-290); a 64-word row cannot exceed 2048
+  v = v && (N[(size_t)i * 64 + 63] >> 30) != 0 && (Nt[(size_t)i * 64 + 63] >> 30) != 0;
+  v = v && cd1[i] && cd2[i];
+  ok[i] = v ? 1 : 0;
+  if (!v && bad) atomicOr(bad + i / n, 1u << (i % n));
+}
+// phase2_verify_vss_construct_keypair_phase3_pok_dlog (party_i.rs:337-343): validate_share && commitments[0] == y_vec[i]
+__global__ void r2_verdict_kernel(int B, int n, int t1, const uint32_t* __restrict__ commits, const uint32_t* __restrict__ y, const uint8_t* __restrict__ share_ok,
+                                  uint8_t* __restrict__ ok, uint32_t* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const bool v = share_ok[i] && sm::cmp(commits + (size_t)i * t1 * 16, 16, y + (size_t)i * 16, 16) == 0;
+  ok[i] = v ? 1 : 0;
+  if (!v && bad) atomicOr(bad + i / n, 1u << (i % n));
+}
+}  // namespace kg
+}  // namespace mpe
+
 extern "C" {
 
 // NiCorrectKeyProof::proof(dk, SALT_STRING) for every key of a private key set: sigma_i = rho_i^(N^-1 mod phi(N)) mod N, i < 11
@@ -294,6 +322,54 @@ int mpe_vss_point_commitment(mpe_ctx* ctx, int batch, int t1, const uint32_t* d_
   hipStream_t st = (hipStream_t)stream;
   MPE_LAUNCH_1D(mpe::kg::vss_kernel, batch, st, batch, t1, d_commits, (const uint32_t*)nullptr, d_index, (uint8_t*)nullptr, d_out);
   return MPE_OK;
+}
+
+
+// `Keys::phase1_verify_com_phase3_verify_correct_key_verify_dlog_phase2_distribute` (party_i.rs:260-320) as the reference composes it
+int mpe_keygen_verify_round1(mpe_ctx* ctx, int batch, int n_parties, const mpe_keygen_round1* in, uint8_t* d_ok, uint32_t* d_bad_actors, void* stream) {
+  if (!ctx || !in || !d_ok || batch < 0 || n_parties < 1 || n_parties > 32 || batch % n_parties) return MPE_E_ARG;
+  if (!in->y || !in->blind || !in->com || !in->N || !in->sigma || !in->Nt || !in->h1 || !in->h2 || !in->x_h1 || !in->y_h1 || !in->x_h2 || !in->y_h2) return MPE_E_ARG;
+  if (batch == 0) return MPE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  // the three verifiers use the context workspace one after another: their verdicts live in an allocation of this call
+  uint8_t* flags = nullptr;
+  if (hipMalloc((void**)&flags, (size_t)batch * (3 + 32) + 256) != hipSuccess) { mpe_set_error_msg("keygen round1: hipMalloc"); return MPE_E_NOMEM; }
+  uint8_t *ck = flags, *cd1 = flags + batch, *cd2 = flags + 2 * (size_t)batch;
+  uint32_t* com = (uint32_t*)(flags + (((size_t)3 * batch + 255) & ~(size_t)255));
+  int rc = mpe_hash_commit_point(ctx, batch, in->y, in->blind, com, stream);                                    // party_i.rs:278-283
+  if (rc == MPE_OK) rc = mpe_correct_key_verify(ctx, batch, in->N, in->sigma, ck, stream);                      // :284-287
+  if (rc == MPE_OK) rc = mpe_composite_dlog_verify(ctx, batch, in->Nt, in->h1, in->h2, in->x_h1, in->y_h1, cd1, stream);   // :292-295
+  if (rc == MPE_OK) rc = mpe_composite_dlog_verify(ctx, batch, in->Nt, in->h2, in->h1, in->x_h2, in->y_h2, cd2, stream);   // :296-299, g and ni swapped (:271-275)
+  if (rc == MPE_OK) {
+    if (d_bad_actors) (void)hipMemsetAsync(d_bad_actors, 0, (size_t)(batch / n_parties) * 4, st);
+    hipLaunchKernelGGL(mpe::kg::r1_verdict_kernel, dim3(mpe::blocks_for(batch, 64)), dim3(64), 0, st, batch, n_parties, in->com, com, ck, in->N, in->Nt, cd1, cd2,
+                       d_ok, d_bad_actors);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mpe_set_error("mpe_keygen_verify_round1", e); rc = MPE_E_HIP; }
+  }
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(flags);
+  return rc;
+}
+
+// `Keys::phase2_verify_vss_construct_keypair_phase3_pok_dlog`, the verdict (party_i.rs:322-367)
+int mpe_keygen_verify_round2(mpe_ctx* ctx, int batch, int n_parties, int t1, const uint32_t* d_commits, const uint32_t* d_share, const int32_t* d_index,
+                             const uint32_t* d_y, uint8_t* d_ok, uint32_t* d_bad_actors, void* stream) {
+  if (!ctx || !d_commits || !d_share || !d_index || !d_y || !d_ok || batch < 0 || n_parties < 1 || n_parties > 32 || batch % n_parties || t1 < 1 || t1 > 64) return MPE_E_ARG;
+  if (batch == 0) return MPE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  uint8_t* share_ok = nullptr;
+  if (hipMalloc((void**)&share_ok, (size_t)batch) != hipSuccess) { mpe_set_error_msg("keygen round2: hipMalloc"); return MPE_E_NOMEM; }
+  int rc = mpe_vss_validate_share(ctx, batch, t1, d_commits, d_share, d_index, share_ok, stream);
+  if (rc == MPE_OK) {
+    if (d_bad_actors) (void)hipMemsetAsync(d_bad_actors, 0, (size_t)(batch / n_parties) * 4, st);
+    hipLaunchKernelGGL(mpe::kg::r2_verdict_kernel, dim3(mpe::blocks_for(batch, 64)), dim3(64), 0, st, batch, n_parties, t1, d_commits, d_y, share_ok, d_ok, d_bad_actors);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mpe_set_error("mpe_keygen_verify_round2", e); rc = MPE_E_HIP; }
+  }
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(share_ok);
+  return rc;
 }
 
 }  // extern "C"

@@ -27,6 +27,7 @@ namespace smp {
 
 constexpr int MAX_ATTEMPTS = 128;        // a bound with its top bit set rejects with probability < 1/2 per attempt
 constexpr int F_NONZERO = 1, F_PLUS_ONE = 2, F_COPRIME = 4;
+constexpr int NF = 22;                 // fields of mpe_gg20_nonces, msg last
 
 struct Seed { uint32_t k[8]; };
 
@@ -95,38 +96,25 @@ __device__ inline bool coprime_odd(uint32_t* a, uint32_t* n, int w) {
   return o == 0;
 }
 
-// out[i] (out_words words, zero-extended) drawn below bound row sel(i); bits > 0: BigInt::sample(bits), no bound.
-// MAXW: words of the widest bound (private arrays of the coprimality check only).
+// one item: o[0..out_words) drawn below the bound row bd (bits > 0 and bd == nullptr: BigInt::sample(bits), no bound) from the item's stream.
+// COPRIME_W: words of the private arrays of the coprimality check (0: the flag is not honoured — the batched verdict is used instead).
 template <int COPRIME_W>
-__global__ void __launch_bounds__(64) sample_kernel(int batch, Seed key, uint32_t sid_lo, uint32_t sid_hi, int bits, const uint32_t* __restrict__ bound,
-                                                     int bound_words, const int32_t* __restrict__ bound_idx, int nbounds, int flags, int out_words,
-                                                     uint32_t* __restrict__ out, int32_t* __restrict__ fail, const uint8_t* __restrict__ skip_if) {
-  __shared__ uint32_t ks[64][17];
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= batch) return;
-  if (skip_if && skip_if[i]) return;       // from_modulo, second pass: only the items whose first candidate shares a factor with N
-  Stream s{&key, (uint32_t)i, sid_lo, sid_hi, ks[threadIdx.x], 0xffffffffu, 0ull};
-  const uint32_t* bd = bound ? bound + (size_t)(bound_idx ? bound_idx[i] : (nbounds == 1 ? 0 : i)) * bound_words : nullptr;
+__device__ __forceinline__ void draw_item(Stream& s, const uint32_t* __restrict__ bd, int bound_words, int bits, int flags, uint32_t* __restrict__ o,
+                                          int out_words, int32_t* __restrict__ fail) {
   const int L = bd ? bit_length(bd, bound_words) : bits;
-  uint32_t* o = out + (size_t)i * out_words;
   if (L <= 0 || L > 32 * out_words) { for (int j = 0; j < out_words; ++j) o[j] = 0; if (fail) atomicAdd(fail, 1); return; }
   const int nbytes = (L + 7) / 8, sh = nbytes * 8 - L, W = (L + 31) / 32;
   bool done = false;
   for (int attempt = 0; attempt < MAX_ATTEMPTS && !done; ++attempt) {
-    // the integer X = big-endian(bytes) >> sh; little-endian word j of X = bits [32 j + sh, 32 j + sh + 32) of the byte string.
-    // Bytes arrive most significant first: walk j downwards, carrying the byte that straddles two words.
+    // the integer X = big-endian(bytes) >> sh, L bits.  Bytes arrive most significant first: the first L - 32 (W - 1) bits are
+    // little-endian word W - 1 of X, every further 32 bits the next lower word, and the last sh bits of the string are shifted out.
     int state = 0;                       // comparison with the bound so far: 0 equal, -1 below, +1 above
     uint32_t any = 0;
-    unsigned long long acc = 0;          // bytes not yet emitted, most recent in the low bits
-    int have = 0;                        // bits in acc
-    // total bits of the byte string = 8 nbytes = L + sh; emit words from the top: the top word holds L - 32 (W-1) bits
-    int emitted_top = L - 32 * (W - 1);  // bits of word W-1
-    int taken = 0;                       // bytes read
+    unsigned long long acc = 0;          // bits read and not yet emitted, most recent in the low positions
+    int have = 0, taken = 0;             // bits in acc; bytes read
     for (int j = W - 1; j >= 0; --j) {
-      const int need = (j == W - 1 ? emitted_top : 32);
-      // the very first sh bits of the string are shifted out... they are the LOW bits of the LAST byte, handled at the end:
+      const int need = (j == W - 1 ? L - 32 * (W - 1) : 32);
       while (have < need + (j == 0 ? sh : 0) && taken < nbytes) { acc = (acc << 8) | s.next_byte(); have += 8; ++taken; }
-      // word j = the top `need` bits of what is held, once the final sh bits are excluded at j == 0
       const int drop = have - need;      // bits that stay for the lower words (j > 0), or the sh bits shifted out (j == 0)
       const uint32_t wv = (uint32_t)((acc >> drop) & (need == 32 ? 0xffffffffull : ((1ull << need) - 1)));
       acc &= drop ? ((1ull << drop) - 1) : 0ull;
@@ -149,6 +137,36 @@ __global__ void __launch_bounds__(64) sample_kernel(int batch, Seed key, uint32_
   for (int j = W; j < out_words; ++j) o[j] = 0;
   if (!done) { for (int j = 0; j < W; ++j) o[j] = 0; if (fail) atomicAdd(fail, 1); return; }
   if (flags & F_PLUS_ONE) { uint32_t c = 1; for (int j = 0; j < out_words && c; ++j) { const uint32_t v = o[j] + c; c = v < c ? 1u : 0u; o[j] = v; } }
+}
+
+// out[i] (out_words words, zero-extended) drawn below bound row sel(i); bits > 0: BigInt::sample(bits), no bound.
+template <int COPRIME_W>
+__global__ void __launch_bounds__(64) sample_kernel(int batch, Seed key, uint32_t sid_lo, uint32_t sid_hi, int bits, const uint32_t* __restrict__ bound,
+                                                     int bound_words, const int32_t* __restrict__ bound_idx, int nbounds, int flags, int out_words,
+                                                     uint32_t* __restrict__ out, int32_t* __restrict__ fail, const uint8_t* __restrict__ skip_if) {
+  __shared__ uint32_t ks[64][17];
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= batch) return;
+  if (skip_if && skip_if[i]) return;       // from_modulo, second pass: only the items whose first candidate shares a factor with N
+  Stream s{&key, (uint32_t)i, sid_lo, sid_hi, ks[threadIdx.x], 0xffffffffu, 0ull};
+  const uint32_t* bd = bound ? bound + (size_t)(bound_idx ? bound_idx[i] : (nbounds == 1 ? 0 : i)) * bound_words : nullptr;
+  draw_item<COPRIME_W>(s, bd, bound_words, bits, flags, out + (size_t)i * out_words, out_words, fail);
+}
+
+// every field of a batch's sampled values in ONE launch: thread g -> (field, item); field f of batch `counter` is stream counter | f << 56
+struct FieldDesc { uint32_t* out; const uint32_t* bound; const int32_t* idx; int bound_words, out_words, bits, flags, field; };
+struct FieldTable { FieldDesc f[NF]; unsigned start[NF + 1]; int n; };
+__global__ void __launch_bounds__(64) sample_fields_kernel(FieldTable t, Seed key, uint32_t ctr_lo, uint32_t ctr_hi, int32_t* __restrict__ fail) {
+  __shared__ uint32_t ks[64][17];
+  const unsigned g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= t.start[t.n]) return;
+  int f = 0;
+  while (g >= t.start[f + 1]) ++f;
+  const FieldDesc& d = t.f[f];
+  const unsigned i = g - t.start[f];
+  Stream s{&key, i, ctr_lo, ctr_hi | ((uint32_t)d.field << 24), ks[threadIdx.x], 0xffffffffu, 0ull};
+  const uint32_t* bd = d.bound ? d.bound + (size_t)(d.idx ? d.idx[i] : 0) * d.bound_words : nullptr;
+  draw_item<0>(s, bd, d.bound_words, d.bits, d.flags, d.out + (size_t)i * d.out_words, d.out_words, fail);
 }
 
 static Seed seed_of(const uint8_t* h) {
@@ -192,7 +210,6 @@ __global__ void sidx_kernel(gg::Dim d, SIdx x, int total) {
 }
 
 // words per session-party of every field of mpe_gg20_nonces, in declaration order (msg last: per session)
-constexpr int NF = 22;
 static void nonce_field_words(int S, int n, int L, size_t per_session[NF]) {
   const size_t P1 = (size_t)S - 1, l = (size_t)L;
   const size_t w[NF] = {l * 8, l * 8, l * 8, l * 64, l * n * 24, l * n * 64, l * n * 88, l * n * 72, l * P1 * 2 * 64, l * P1 * 2 * 64, l * P1 * 2 * 8, l * P1 * 2 * 8,
@@ -246,41 +263,44 @@ static int sample_gg20(mpe_ctx* ctx, const mpe_gg20_keys* K, int batch, int n_lo
   const Bounds& b = K->bounds;
   const int nk = K->K * K->n;
   const uint32_t* N = K->pub->N;
-  auto sid = [&](int field) { return counter | ((uint64_t)field << 56); };
   auto U = [](const uint32_t* p) { return const_cast<uint32_t*>(p); };
-  // field ids = the position in mpe_gg20_nonces (include/mpecdsa_hip.h)
-  auto scalar = [&](int f, const uint32_t* dst, size_t items) {          // Scalar::random()
-    return launch_sample((int)items, h_seed, sid(f), 0, b.q, 8, nullptr, 1, F_NONZERO, 8, U(dst), d_fail, st);
+  // field ids = the position in mpe_gg20_nonces (include/mpecdsa_hip.h); all fields in ONE launch
+  FieldTable t{};
+  t.n = 0; t.start[0] = 0;
+  auto add = [&](int f, const uint32_t* dst, size_t items, const uint32_t* bound, int bw, const int32_t* idx, int ow, int flags, int bits = 0) {
+    t.f[t.n] = FieldDesc{U(dst), bound, idx, bw, ow, bits, flags, f};
+    t.start[t.n + 1] = t.start[t.n] + (unsigned)items;
+    t.n++;
   };
-  auto below = [&](int f, const uint32_t* dst, size_t items, const uint32_t* bound, int bw, const int32_t* idx, int nb, int ow, int flags = 0) {
-    return launch_sample((int)items, h_seed, sid(f), 0, bound, bw, idx, nb, flags, ow, U(dst), d_fail, st);
-  };
-  MPE_TRY(scalar(0, out->k, nPI));                                                                      // party_i.rs:563 k_i
-  MPE_TRY(scalar(1, out->gamma, nPI));                                                                  // :561 gamma_i
-  MPE_TRY(launch_sample((int)nPI, h_seed, sid(2), 256, nullptr, 0, nullptr, 0, 0, 8, U(out->blind), d_fail, st));   // :574 BigInt::sample(SECURITY)
-  MPE_TRY(below(3, out->r_a, nPI, N, 64, x.own_pi, nk, 64));                                             // mta/mod.rs:57 sample_below(&alice_ek.n)
-  MPE_TRY(below(4, out->al_alpha, nAP, b.q3, 24, nullptr, 1, 24));                                       // range_proofs.rs:48 sample_below(q^3)
-  MPE_TRY(below(5, out->al_beta, nAP, N, 64, x.own_ap, nk, 64));                                         // :49 from_paillier_key -> from_modulo (:544-552)
-  {  // ... gcd(r, N) == 1: one batched verdict for all items (Montgomery's trick, mpe_modinv.h); whoever fails it — 2^-1023 per
-     // draw for an honest key — is redrawn by the lane-serial loop, which replays the item's stream with the gcd inside the loop
+  auto scalar = [&](int f, const uint32_t* dst, size_t items) { add(f, dst, items, b.q, 8, nullptr, 8, F_NONZERO); };      // Scalar::random()
+  scalar(0, out->k, nPI);                                                                      // party_i.rs:563 k_i
+  scalar(1, out->gamma, nPI);                                                                  // :561 gamma_i
+  add(2, out->blind, nPI, nullptr, 0, nullptr, 8, 0, 256);                                     // :574 BigInt::sample(SECURITY)
+  add(3, out->r_a, nPI, N, 64, x.own_pi, 64, 0);                                               // mta/mod.rs:57 sample_below(&alice_ek.n)
+  add(4, out->al_alpha, nAP, b.q3, 24, nullptr, 24, 0);                                        // range_proofs.rs:48 sample_below(q^3)
+  add(5, out->al_beta, nAP, N, 64, x.own_ap, 64, 0);                                           // :49 from_paillier_key -> from_modulo (:544-552)
+  add(6, out->al_gamma, nAP, b.q3Nt, 88, x.st_ap, 88, 0);                                      // :50 sample_below(q^3 N~)
+  add(7, out->al_rho, nAP, b.qNt, 72, x.st_ap, 72, 0);                                         // :51 sample_below(q N~)
+  add(8, out->mb_beta_tag, nMB, N, 64, x.peer_mb, 64, 0);                                      // mta/mod.rs:97 sample_below(&alice_ek.n)
+  add(9, out->mb_r, nMB, N, 64, x.peer_mb, 64, 0);                                             // :98
+  scalar(10, out->mb_nonce_b, nMB);                                                            // :147 DLogProof::prove(b)
+  scalar(11, out->mb_nonce_bt, nMB);                                                           // :148
+  scalar(12, out->l, nPI);                                                                     // party_i.rs:628 l
+  scalar(13, out->ped_s1, nPI);                                                                // PedersenProof::prove (:620-634)
+  scalar(14, out->ped_s2, nPI);
+  add(15, out->pdl_alpha, nPP, b.q3, 24, nullptr, 24, 0);                                      // zk_pdl_with_slack/mod.rs:73
+  add(16, out->pdl_beta, nPP, b.Nm2, 64, x.own_pp, 64, F_PLUS_ONE);                            // :75 sample_range(1, N - 1)
+  add(17, out->pdl_rho, nPP, b.qNt, 72, x.st_pp, 72, 0);                                       // :76
+  add(18, out->pdl_gamma, nPP, b.q3Nt, 88, x.st_pp, 88, 0);                                    // :77
+  scalar(19, out->heg_s1, nPI);                                                                // HomoELGamalProof::prove (:778-799)
+  scalar(20, out->heg_s2, nPI);
+  if ((size_t)t.start[t.n] != 7 * nPI + 4 * nAP + 4 * nMB + 4 * nPP) return MPE_E_ARG;          // a batch beyond 2^32 items
+  hipLaunchKernelGGL(sample_fields_kernel, dim3((t.start[t.n] + 63) / 64), dim3(64), 0, st, t, seed_of(h_seed), (uint32_t)counter, (uint32_t)(counter >> 32), d_fail);
+  {  // from_modulo: gcd(r, N) == 1 as ONE batched verdict for all items (Montgomery's trick, mpe_modinv.h); whoever fails it — 2^-1023
+     // per draw for an honest key — is redrawn by the lane-serial loop, which replays the item's stream with the gcd inside the loop
     MPE_TRY(launch_modinv(ctx, msn, (int)nAP, key_selector(K->pub, x.own_ap), rows(out->al_beta, 64), inv, ok, st));
-    MPE_TRY(launch_sample((int)nAP, h_seed, sid(5), 0, N, 64, x.own_ap, nk, F_COPRIME, 64, U(out->al_beta), d_fail, st, ok));
+    MPE_TRY(launch_sample((int)nAP, h_seed, counter | ((uint64_t)5 << 56), 0, N, 64, x.own_ap, nk, F_COPRIME, 64, U(out->al_beta), d_fail, st, ok));
   }
-  MPE_TRY(below(6, out->al_gamma, nAP, b.q3Nt, 88, x.st_ap, nk, 88));                                    // :50 sample_below(q^3 N~)
-  MPE_TRY(below(7, out->al_rho, nAP, b.qNt, 72, x.st_ap, nk, 72));                                       // :51 sample_below(q N~)
-  MPE_TRY(below(8, out->mb_beta_tag, nMB, N, 64, x.peer_mb, nk, 64));                                    // mta/mod.rs:97 sample_below(&alice_ek.n)
-  MPE_TRY(below(9, out->mb_r, nMB, N, 64, x.peer_mb, nk, 64));                                           // :98
-  MPE_TRY(scalar(10, out->mb_nonce_b, nMB));                                                             // :147 DLogProof::prove(b)
-  MPE_TRY(scalar(11, out->mb_nonce_bt, nMB));                                                            // :148
-  MPE_TRY(scalar(12, out->l, nPI));                                                                     // party_i.rs:628 l
-  MPE_TRY(scalar(13, out->ped_s1, nPI));                                                                // PedersenProof::prove (:620-634)
-  MPE_TRY(scalar(14, out->ped_s2, nPI));
-  MPE_TRY(below(15, out->pdl_alpha, nPP, b.q3, 24, nullptr, 1, 24));                                     // zk_pdl_with_slack/mod.rs:73
-  MPE_TRY(below(16, out->pdl_beta, nPP, b.Nm2, 64, x.own_pp, nk, 64, F_PLUS_ONE));                       // :75 sample_range(1, N - 1)
-  MPE_TRY(below(17, out->pdl_rho, nPP, b.qNt, 72, x.st_pp, nk, 72));                                     // :76
-  MPE_TRY(below(18, out->pdl_gamma, nPP, b.q3Nt, 88, x.st_pp, nk, 88));                                  // :77
-  MPE_TRY(scalar(19, out->heg_s1, nPI));                                                                // HomoELGamalProof::prove (:778-799)
-  MPE_TRY(scalar(20, out->heg_s2, nPI));
   // the verdict array and the discarded inverses are derived from secret values
   (void)hipMemsetAsync(inv, 0, nAP * 64 * 4, st);
   return MPE_OK;

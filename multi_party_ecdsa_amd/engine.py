@@ -618,6 +618,11 @@ class Gg20Pipeline:
         N_.check(N_.lib.mpe_gg20_pipeline_latency_ms(self.h, ticket, C.byref(ms)), "mpe_gg20_pipeline_latency_ms")
         return ms.value
 
+    def pass_ms(self, ticket):
+        ms = C.c_float(0)
+        N_.check(N_.lib.mpe_gg20_pipeline_pass_ms(self.h, ticket, C.byref(ms)), "mpe_gg20_pipeline_pass_ms")
+        return ms.value
+
     def sampler_failures(self):
         v = C.c_int32(0)
         N_.check(N_.lib.mpe_gg20_pipeline_sampler_failures(self.h, C.byref(v)), "mpe_gg20_pipeline_sampler_failures")
@@ -706,6 +711,27 @@ def composite_dlog_verify(ctx, d_N, d_g, d_ni, d_x, d_y):
     N_.check(N_.lib.mpe_composite_dlog_verify(ctx.h, d_N.shape[0], _ptr(d_N), _ptr(d_g), _ptr(d_ni), _ptr(d_x), _ptr(d_y), _ptr(ok),
                                               ctx.stream()), "mpe_composite_dlog_verify")
     return ok
+
+
+def keygen_verify_round1(ctx, n_parties, msgs):
+    """`phase1_verify_com_phase3_verify_correct_key_verify_dlog_phase2_distribute` (party_i.rs:260-320) over items = (session, prover):
+    msgs = dict of device tensors (fields _native.KEYGEN_ROUND1_FIELDS).  Returns (ok [B] uint8, bad_actors [B / n_parties] int32 masks)."""
+    B = msgs["N"].shape[0]
+    ok = _flags(ctx, B)
+    bad = torch.zeros((B // n_parties,), dtype=torch.int32, device=ctx.device)
+    st = _struct(N_.KeygenRound1, msgs)
+    N_.check(N_.lib.mpe_keygen_verify_round1(ctx.h, B, n_parties, C.byref(st), _ptr(ok), _ptr(bad), ctx.stream()), "mpe_keygen_verify_round1")
+    return ok, bad
+
+
+def keygen_verify_round2(ctx, n_parties, t1, d_commits, d_share, d_index, d_y):
+    """the verdict of `phase2_verify_vss_construct_keypair_phase3_pok_dlog` (party_i.rs:322-367)"""
+    B = d_share.shape[0]
+    ok = _flags(ctx, B)
+    bad = torch.zeros((B // n_parties,), dtype=torch.int32, device=ctx.device)
+    N_.check(N_.lib.mpe_keygen_verify_round2(ctx.h, B, n_parties, t1, _ptr(d_commits), _ptr(d_share), _ptr(d_index), _ptr(d_y), _ptr(ok), _ptr(bad),
+                                             ctx.stream()), "mpe_keygen_verify_round2")
+    return ok, bad
 
 
 def correct_key_prove(ctx, sk):

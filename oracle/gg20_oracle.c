@@ -1073,3 +1073,45 @@ void orc_vss_point_commitment(int batch, int t1, const uint32_t* commits, const 
   }
   pt_clear(&r);
 }
+
+/* ---- the two keygen verdicts as the reference composes them (gg_2020/party_i.rs:260-367) --------------------------------
+ * items = (keygen session, prover i), n_parties consecutive items per session; bad [batch / n_parties]: bit i = prover i of the
+ * session is in `bad_actors`.  Row widths as in orc_correct_key_verify / orc_composite_dlog_verify / orc_hash_commit_point. */
+#define ORC_PAILLIER_MIN_BIT_LENGTH 2047      /* party_i.rs:49 */
+#define ORC_PAILLIER_MAX_BIT_LENGTH 2048      /* party_i.rs:50 */
+void orc_keygen_verify_round1(int batch, int n_parties, const uint32_t* y, const uint32_t* blind, const uint32_t* com, const uint32_t* N,
+                              const uint32_t* sigma, const uint32_t* Nt, const uint32_t* h1, const uint32_t* h2, const uint32_t* x_h1,
+                              const uint32_t* y_h1, const uint32_t* x_h2, const uint32_t* y_h2, uint8_t* ok, uint32_t* bad) {
+  mpz_t n, nt; mpz_inits(n, nt, NULL);
+  if (bad) memset(bad, 0, (size_t)(batch / n_parties) * 4);
+  for (int i = 0; i < batch; ++i) {
+    uint32_t c[8];
+    uint8_t ck = 0, cd1 = 0, cd2 = 0;
+    orc_hash_commit_point(1, y + (size_t)i * 16, blind + (size_t)i * 8, c);                                  /* :278-283 */
+    orc_correct_key_verify(1, N + (size_t)i * 64, sigma + (size_t)i * 11 * 64, &ck);                         /* :284-287 */
+    zin(n, N + (size_t)i * 64, 64); zin(nt, Nt + (size_t)i * 64, 64);
+    orc_composite_dlog_verify(1, Nt + (size_t)i * 64, h1 + (size_t)i * 64, h2 + (size_t)i * 64, x_h1 + (size_t)i * 64, y_h1 + (size_t)i * 73, &cd1);   /* :292-295 */
+    /* dlog_statement_base_h2 = { N, g: ni, ni: g } (:271-275) */
+    orc_composite_dlog_verify(1, Nt + (size_t)i * 64, h2 + (size_t)i * 64, h1 + (size_t)i * 64, x_h2 + (size_t)i * 64, y_h2 + (size_t)i * 73, &cd2);   /* :296-299 */
+    const size_t bn = mpz_sgn(n) ? mpz_sizeinbase(n, 2) : 0, bt = mpz_sgn(nt) ? mpz_sizeinbase(nt, 2) : 0;
+    const int test_res = memcmp(c, com + (size_t)i * 8, 32) == 0 && ck &&
+                         bn >= ORC_PAILLIER_MIN_BIT_LENGTH && bn <= ORC_PAILLIER_MAX_BIT_LENGTH &&             /* :288-289 */
+                         bt >= ORC_PAILLIER_MIN_BIT_LENGTH && bt <= ORC_PAILLIER_MAX_BIT_LENGTH &&             /* :290-291 */
+                         cd1 && cd2;
+    ok[i] = test_res ? 1 : 0;
+    if (!test_res && bad) bad[i / n_parties] |= 1u << (i % n_parties);                                        /* :300-302 bad_actors_vec.push(i) */
+  }
+  mpz_clears(n, nt, NULL);
+}
+/* phase2_verify_vss_construct_keypair_phase3_pok_dlog, the verdict (:337-349) */
+void orc_keygen_verify_round2(int batch, int n_parties, int t1, const uint32_t* commits, const uint32_t* share, const int32_t* index,
+                              const uint32_t* y, uint8_t* ok, uint32_t* bad) {
+  if (bad) memset(bad, 0, (size_t)(batch / n_parties) * 4);
+  for (int i = 0; i < batch; ++i) {
+    uint8_t v = 0;
+    orc_vss_validate_share(1, t1, commits + (size_t)i * t1 * 16, share + (size_t)i * 8, index + i, &v);      /* :338-340 */
+    const int res = v && memcmp(commits + (size_t)i * t1 * 16, y + (size_t)i * 16, 64) == 0;                  /* :341 commitments[0] == y_vec[i] */
+    ok[i] = res ? 1 : 0;
+    if (!res && bad) bad[i / n_parties] |= 1u << (i % n_parties);
+  }
+}

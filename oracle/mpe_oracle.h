@@ -225,6 +225,14 @@ void orc_vss_validate_share(int batch, int t1, const uint32_t* commits /*[B][t1]
                             const int32_t* index /*[B]*/, uint8_t* ok);
 void orc_vss_point_commitment(int batch, int t1, const uint32_t* commits, const int32_t* index, uint32_t* out /*[B][16]*/);
 
+/* the two keygen verdicts as the reference composes them (party_i.rs:260-320, 322-367); items = (session, prover), n_parties per session;
+ * bad [batch / n_parties]: bit i = prover i is in `bad_actors` */
+void orc_keygen_verify_round1(int batch, int n_parties, const uint32_t* y, const uint32_t* blind, const uint32_t* com, const uint32_t* N,
+                              const uint32_t* sigma, const uint32_t* Nt, const uint32_t* h1, const uint32_t* h2, const uint32_t* x_h1,
+                              const uint32_t* y_h1, const uint32_t* x_h2, const uint32_t* y_h2, uint8_t* ok, uint32_t* bad);
+void orc_keygen_verify_round2(int batch, int n_parties, int t1, const uint32_t* commits, const uint32_t* share, const int32_t* index,
+                              const uint32_t* y, uint8_t* ok, uint32_t* bad);
+
 /* fixture helper (test key material only): smallest prime > start */
 void orc_nextprime(int k32, const uint32_t* start, uint32_t* out);
 

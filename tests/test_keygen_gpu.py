@@ -90,3 +90,44 @@ def test_keygen_verification_at_scale_the_bench_section(gpu_ctx, keys):
     for f in ("correct_key", "composite_dlog", "vss"):
         assert res[f + "_exactly_the_corrupted_refused"], (f, res)
     assert res["oracle_accepts_the_uncorrupted_items"]
+
+
+def test_round1_verdict_as_the_reference_composes_it_gpu(gpu_ctx, keys):
+    """mpe_keygen_verify_round1 == oracle/gg20_oracle.c:orc_keygen_verify_round1 == party_i.rs:260-320: commitment, NiCorrectKeyProof,
+    PAILLIER_MIN/MAX_BIT_LENGTH on e.n and dlog_statement.N, both CompositeDLogProofs, bad_actors — and the reference's
+    test_small_paillier (gg_2020/test.rs:764-783): a 2046-bit key with a valid proof is refused"""
+    from multi_party_ecdsa_amd import engine as E
+    n = 3
+    c = KF.round1_case(keys, n, 4)
+    _, _, Nsmall, sig_small = KF.small_paillier_key()
+    t = {f: a.copy() for f, a in c.items()}
+    t["com"][0, 3] ^= 1
+    t["blind"][4, 0] ^= 1
+    t["N"][5], t["sigma"][5] = Nsmall[0], sig_small[0]
+    t["sigma"][6, 70] ^= 1
+    t["y_h1"][7, 2] ^= 1
+    t["x_h2"][8, 9] ^= 1
+    t["Nt"][9, 63] &= 0x3fffffff
+    for case in (c, t):
+        want_ok, want_bad = KF.oracle_round1(case, n)
+        ok, bad = E.keygen_verify_round1(gpu_ctx, n, {f: _dev(gpu_ctx, a) for f, a in case.items()})
+        assert list(ok.cpu().numpy()) == list(want_ok) and list(bad.cpu().numpy().view(np.uint32)) == list(want_bad)
+    assert list(want_ok) == [0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1] and list(want_bad) == [0b001, 0b110, 0b111, 0b001]
+    one = {f: a[5:6].copy() for f, a in t.items()}                      # test_small_paillier: share_count = 1, the party checks itself
+    ok, bad = E.keygen_verify_round1(gpu_ctx, 1, {f: _dev(gpu_ctx, a) for f, a in one.items()})
+    assert list(ok.cpu().numpy()) == [0] and list(bad.cpu().numpy()) == [1]
+    # the proof of the small key is valid by itself: only the composed verdict stands in its way
+    assert list(E.correct_key_verify(gpu_ctx, _dev(gpu_ctx, Nsmall), _dev(gpu_ctx, sig_small)).cpu().numpy()) == [1]
+
+
+def test_round2_verdict_as_the_reference_composes_it_gpu(gpu_ctx):
+    from multi_party_ecdsa_amd import engine as E
+    t, n, B = 1, 3, 4
+    commits, shares, index, _ = KF.vss_case(t, n, B, seed="vss-r2")
+    y = np.ascontiguousarray(commits[:, :16]).copy()
+    shares[2, 0] ^= 1
+    y[7, 1] ^= 1
+    want_ok, want_bad = np.zeros(B * n, dtype=np.uint8), np.zeros(B, dtype=np.uint32)
+    orc.lib.orc_keygen_verify_round2(B * n, n, t + 1, orc._p(commits), orc._p(shares), orc._p(index), orc._p(y), orc._p(want_ok), orc._p(want_bad))
+    ok, bad = E.keygen_verify_round2(gpu_ctx, n, t + 1, _dev(gpu_ctx, commits), _dev(gpu_ctx, shares), torch.from_numpy(index).to(gpu_ctx.device), _dev(gpu_ctx, y))
+    assert list(ok.cpu().numpy()) == list(want_ok) and list(bad.cpu().numpy().view(np.uint32)) == list(want_bad) == [0b100, 0, 0b010, 0]

@@ -40,11 +40,12 @@ def main():
     outs = [pipe.wait(t) for t in ts]
     dt = time.perf_counter() - t0
     lat = sorted(pipe.latency_ms(t) for t in ts)
+    pas = sorted(pipe.pass_ms(t) for t in ts)
     ok = all(bool((o[3] == 0).all().item()) for o in outs)
     print(json.dumps({"lanes": a.lanes, "group": a.group, "batch": a.batch, "batches": a.batches, "seeded": not a.explicit,
                       "merge_r1": not os.environ.get("MPE_NO_MERGE_R1"),
                       "signatures_per_s": round(a.batches * a.batch / dt, 1), "host_enqueue_s": round(t_enq, 3), "seconds": round(dt, 3),
-                      "latency_ms_p50": round(lat[len(lat) // 2], 1), "latency_ms_max": round(lat[-1], 1), "all_signed": ok,
+                      "latency_ms_p50": round(lat[len(lat) // 2], 1), "latency_ms_max": round(lat[-1], 1), "pass_ms_p50": round(pas[len(pas) // 2], 1), "pass_ms_max": round(pas[-1], 1), "all_signed": ok,
                       "sampler_failures": pipe.sampler_failures()}))
     pipe.close()
 
