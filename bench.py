@@ -34,14 +34,15 @@ session mode — the node's Paillier ops/s.  --share-device: every rank on cuda:
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
-# (c4_stream_1024 runs in a child process with GPU_MAX_HW_QUEUES=16 — see stream_section(): the variable must be set before the HIP
-#  runtime initialises, and the headline path keeps the runtime's defaults)
+# (c4_stream_1024 runs in THIS process through mpe_gg20_pipeline with the runtime's default hardware queues — round 4's child process
+#  with GPU_MAX_HW_QUEUES=16 is gone)
 import numpy as np
 import torch
 
@@ -179,6 +180,17 @@ def secondary_rooflines(recs, elapsed):
         out.append({"kernel": name, "launches": len(rs), "seconds": t, "time_share_of_step": t / elapsed, "executed_TMAC_per_s": m / t / 1e12 if t else None,
                     "frac": m / t / PEAK_MAC_PER_S if t else None})
     return out
+
+
+def dominant_roofline(recs, elapsed):
+    """the same accounting as the headline's `roofline` for the launches modulo N^2 of another shape (c4_literal_1024, c5_share_t2n5_8192)"""
+    dom = [x for x in recs if x["kind"] in (3, 6) and x["bits"] == 4096]
+    if not dom:
+        return None
+    t = sum(x["ms"] for x in dom) * 1e-3
+    m = sum(x["batch"] * pair_modexp_macs(64, x["exp_words"], x.get("exp2_words", 0), sliding=slid(x)) for x in dom)
+    return {"kernel": "pair_modexp_kernel<Cfg<2048,...>> (all launches modulo N^2)", "launches": len(dom), "items": int(sum(x["batch"] for x in dom)),
+            "seconds": t, "time_share_of_step": t / elapsed, "executed_TMAC_per_s": m / t / 1e12, "frac": m / t / PEAK_MAC_PER_S}
 
 
 def executed_macs(recs):
@@ -536,18 +548,21 @@ def bob_section(ctx, E, keys, F, B=65536, prefix=1024, oracle=True, threads=None
 
 
 def gg20_config(ctx, E, G, keys, t, n, B, steps, gen, parity_sample=0, threads=None, openssl=False):
-    """one more GG20 shape on this GPU: sessions/s over `steps` passes of B sessions, optional parity sample vs the oracle"""
+    """one more GG20 shape on this GPU: sessions/s over `steps` passes of B sessions, every pass on values sampled on the device inside
+    the timed region (a fresh batch counter per pass); optional parity sample vs the oracle, which expands the last pass's seed itself"""
     dev = ctx.device
     signers = list(range(t + 1))
     lk = G.make_local_keys(keys, t, n, signers)
     gk = E.Gg20Keys(ctx, t, n, signers, lk["arrays"])
-    S = len(signers)
-    nonces = make_device_nonces(gen, dev, B, S, S, n)
+    seed = hashlib.sha256(b"bench.py gg20_config %d %d %d" % (t, n, B)).digest()
+    msg = rand_words(gen, dev, B, 8, 8)
+    nonces, _ = E.gg20_sample_nonces(ctx, gk, B, seed, 0, msg=msg)
     out = E.gg20_sign(ctx, gk, nonces, B)
     torch.cuda.synchronize()
     ctx.prof_enable(True)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for c_ in range(steps):
+        _, fail = E.gg20_sample_nonces(ctx, gk, B, seed, 1 + c_, out=nonces)
         out = E.gg20_sign(ctx, gk, nonces, B)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
@@ -555,102 +570,97 @@ def gg20_config(ctx, E, G, keys, t, n, B, steps, gen, parity_sample=0, threads=N
     ctx.prof_enable(False)
     r, s, recid, status = [o.cpu().numpy() for o in out]
     res = {"sessions": B, "t": t, "n": n, "signatures_per_s": B / dt, "ms_per_batch": dt * 1e3, "all_sessions_signed": bool((status == 0).all()),
-           "whole_step": whole_step(recs, dt * steps)}
+           "nonces": "sampled on the device inside the timed region, a fresh batch counter per pass", "sampler_rejection_loops_given_up": int(fail.item()),
+           "whole_step": whole_step(recs, dt * steps), "roofline_dominant": dominant_roofline(recs, dt * steps),
+           "roofline_secondary": secondary_rooflines(recs, dt * steps)}
     if parity_sample:
         threads = threads or min(host_cores()[0], 64)
-        hn = _host({f: v[: parity_sample * (v.shape[0] // B)] for f, v in nonces.items()})
+        hm = np.ascontiguousarray(msg[:parity_sample].cpu().numpy().view(np.uint32))
+        hn, wf = G.oracle_sample_nonces(lk, parity_sample, seed, steps, msg=hm)
         v, wr, ws, wrecid, wstatus = cpu_baseline_gg20(lk, hn, parity_sample, min(threads, parity_sample))
         res["parity_sample"] = parity_sample
-        res["parity_vs_oracle_on_sample"] = bool((wstatus == 0).all() and np.array_equal(r[:parity_sample].view(np.uint32), wr) and
+        res["parity_vs_oracle_on_sample"] = bool(wf == 0 and (wstatus == 0).all() and np.array_equal(r[:parity_sample].view(np.uint32), wr) and
                                                  np.array_equal(s[:parity_sample].view(np.uint32), ws) and np.array_equal(recid[:parity_sample], wrecid))
         res["oracle_signatures_per_s"] = v
     if openssl:
-        res["openssl"] = openssl_verify_all(lk["arrays"]["y"][0], nonces["msg"], r, s, threads or min(host_cores()[0], 64))
+        res["openssl"] = openssl_verify_all(lk["arrays"]["y"][0], msg, r, s, threads or min(host_cores()[0], 64))
     gk.close()
     return res
 
 
-def c4_stream(E, G, keys, dev_index, batches=12, B=1024, inflight=3, parity_sample=64, threads=None, oracle=True, share_hint=False):
-    """BASELINE config 4 as a SERVICE sees it: a stream of `batches` successive 1 024-session (t=1, n=3) batches, at most
-    `inflight` of them in flight, each on its own host thread with its own context and HIP stream (the §8b threading contract;
-    the reference runs its parties concurrently through `Simulation`, state_machine/sign.rs:667-691, and every round through
-    spawn_blocking).  One batch alone is latency-bound — four chains of ~2 048 dependent squarings at ~12 % occupancy
-    (profiles/r03/timeline_1024_sessions.json) — so the latency-bound rounds of one batch overlap the throughput-bound round 1
-    of another.  Every batch has its own freshly sampled nonces and messages.  Every signature is checked afterwards: all of
-    them under OpenSSL's ECDSA_do_verify, a sample of every batch bit for bit against the GMP oracle."""
-    import threading
+def c4_pipeline(ctx, E, G, keys, batches=96, B=1024, lanes=2, group=4, parity_sample=16, threads=None, oracle=True, verify=True):
+    """BASELINE config 4 as a SERVICE sees it: a stream of `batches` successive 1 024-session (t=1, n=3) batches through the pipelined
+    engine (mpe_gg20_pipeline_*, csrc/mpe_pipeline.h): `group` batches coalesced per lock-step pass, `lanes` passes in flight on one
+    stream each, inputs staged on one more stream — ONE context handle, ONE host thread, the runtime's default hardware queues, no child
+    process.  Every batch is signed from values sampled ON THE DEVICE from (seed, batch counter) (submit_seeded).  The client is a
+    closed loop: at most 2 x lanes x group batches outstanding (one group running and one queued per lane), a new batch goes in when
+    the oldest completes — so `latency_ms` is what a caller of a loaded service sees, not the depth of a flooded queue.
+    Afterwards every signature is checked under OpenSSL's ECDSA_do_verify and the first sessions of EVERY batch against the GMP oracle,
+    which re-expands the batch's (seed, counter) itself (oracle/sampler_oracle.c).  The reference runs many OfflineStage instances side
+    by side the same way (state_machine/sign.rs:667-691; rounds.rs:106,215,323 `is_expensive`)."""
     t, n, signers = 1, 3, [0, 1]
-    S = len(signers)
     lk = G.make_local_keys(keys, t, n, signers)
-    dev = torch.device("cuda", dev_index)
-    workers = []
-    for w in range(inflight):
-        ctx = E.Context(dev_index)
-        if share_hint:
-            ctx.set_device_share(inflight)         # the batches share the chip: keep the efficient lane layouts (mpe_ctx_set_device_share)
-        workers.append(dict(ctx=ctx, gk=E.Gg20Keys(ctx, t, n, signers, lk["arrays"]), stream=torch.cuda.Stream(device=dev)))
+    dev = ctx.device
+    gk = E.Gg20Keys(ctx, t, n, signers, lk["arrays"])
+    pipe = E.Gg20Pipeline(ctx, gk, B, group=group, lanes=lanes)
+    seed = hashlib.sha256(b"bench.py c4_stream_1024 lanes %d group %d" % (lanes, group)).digest()
     gen = torch.Generator(device=dev)
     gen.manual_seed(1024)
-    nonces = [make_device_nonces(gen, dev, B, S, S, n) for _ in range(batches)]
+    msgs = [rand_words(gen, dev, B, 8, 8) for _ in range(batches)]
+    window = 2 * lanes * group
+    # warm-up: both staging buffers of every lane, every allocation of the lanes' workspaces
+    warm = [pipe.submit_seeded(seed, (1 << 40) + i, msgs[i % batches]) for i in range(window)]
+    pipe.flush()
+    for tk in warm:
+        pipe.wait(tk)
     torch.cuda.synchronize()
-    results, errors = [None] * batches, []
-    go = threading.Barrier(inflight + 1)
-
-    def work(w, warm):
-        try:
-            wk = workers[w]
-            with torch.cuda.stream(wk["stream"]):
-                if warm:
-                    E.gg20_sign(wk["ctx"], wk["gk"], nonces[w % batches], B)
-                    wk["ctx"].sync()
-                    return
-                go.wait(timeout=300)
-                for b in range(w, batches, inflight):
-                    results[b] = E.gg20_sign(wk["ctx"], wk["gk"], nonces[b], B)
-                wk["ctx"].sync()
-        except Exception as e:                                   # noqa: BLE001
-            errors.append(repr(e))
-            try:
-                go.abort()
-            except Exception:                                    # noqa: BLE001
-                pass
-    for warm in (True, False):
-        ths = [threading.Thread(target=work, args=(w, warm)) for w in range(inflight)]
-        for th in ths:
-            th.start()
-        if not warm:
-            torch.cuda.synchronize()
-            go.wait(timeout=300)
-            t0 = time.perf_counter()
-        for th in ths:
-            th.join()
-        if not warm:
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-    if errors:
-        return {"error": errors}
-    res = {"batches": batches, "sessions_per_batch": B, "in_flight": inflight, "device_share_hint": bool(share_hint), "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-           "signatures_per_s": batches * B / dt, "seconds": dt,
-           "ms_per_batch_sustained": dt / batches * 1e3,
-           "what": f"{batches} successive {B}-session t=1 n=3 batches, {inflight} in flight on {inflight} host threads x contexts x streams"}
+    results, tickets = [None] * batches, [None] * batches
+    t0 = time.perf_counter()
+    head = 0
+    for b in range(batches):
+        if b - head >= window:                       # closed loop: the oldest outstanding batch completes before the next goes in
+            results[head] = pipe.wait(tickets[head])
+            head += 1
+        tickets[b] = pipe.submit_seeded(seed, b, msgs[b])
+    pipe.flush()
+    while head < batches:
+        results[head] = pipe.wait(tickets[head])
+        head += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lat = sorted(pipe.latency_ms(tk) for tk in tickets)
+    pas = sorted(pipe.pass_ms(tk) for tk in tickets)
+    res = {"batches": batches, "sessions_per_batch": B, "lanes": lanes, "batches_per_pass": group, "in_flight_bound": window,
+           "streams": lanes + 1, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES") or "runtime default", "host_threads": 1, "child_process": False,
+           "signatures_per_s": batches * B / dt, "seconds": dt, "ms_per_batch_sustained": dt / batches * 1e3,
+           "latency_ms": {"p50": lat[len(lat) // 2], "p95": lat[int(len(lat) * 0.95)], "max": lat[-1],
+                          "what": "device time from the submit call of a batch to its results, closed loop with the bound above"},
+           "pass_ms": {"p50": pas[len(pas) // 2], "max": pas[-1], "what": f"one lock-step pass over {group} x {B} sessions"},
+           "nonces": "sampled on the device per batch from (seed, batch counter): no value is used twice",
+           "sampler_rejection_loops_given_up": pipe.sampler_failures(),
+           "what": f"{batches} successive {B}-session t=1 n=3 batches through mpe_gg20_pipeline: {group} batches per pass, {lanes} passes in flight"}
     threads = threads or min(host_cores()[0], 64)
     signed, verified, parity = True, 0, True
     for b in range(batches):
         r, s_, recid, status = [o.cpu().numpy() for o in results[b]]
         signed = signed and bool((status == 0).all())
-        verified += openssl_verify_all(lk["arrays"]["y"][0], nonces[b]["msg"], r, s_, threads)["openssl_verified"]
+        if verify:
+            verified += openssl_verify_all(lk["arrays"]["y"][0], msgs[b], r, s_, threads)["openssl_verified"]
         if oracle and parity_sample:
             k = min(parity_sample, B)
-            hn = _host({f: v[: k * (v.shape[0] // B)] for f, v in nonces[b].items()})
-            _, wr, ws, wrecid, wstatus = cpu_baseline_gg20(lk, hn, k, min(threads, k))
-            parity = parity and bool((wstatus == 0).all() and np.array_equal(r[:k].view(np.uint32), wr) and np.array_equal(s_[:k].view(np.uint32), ws) and
-                                     np.array_equal(recid[:k], wrecid))
-    res.update(all_sessions_signed=signed, openssl_verified=verified, openssl_of=batches * B)
+            hm = np.ascontiguousarray(msgs[b][:k].cpu().numpy().view(np.uint32))
+            z, wf = G.oracle_sample_nonces(lk, k, seed, b, msg=hm)
+            _, wr, ws, wrecid, wstatus = cpu_baseline_gg20(lk, z, k, min(threads, k))
+            parity = parity and bool(wf == 0 and (wstatus == 0).all() and np.array_equal(r[:k].view(np.uint32), wr) and
+                                     np.array_equal(s_[:k].view(np.uint32), ws) and np.array_equal(recid[:k], wrecid))
+    res.update(all_sessions_signed=signed)
+    if verify:
+        res.update(openssl_verified=verified, openssl_of=batches * B)
     if oracle and parity_sample:
-        res.update(parity_vs_oracle_on_sample=parity, parity_sample_per_batch=min(parity_sample, B))
-    for wk in workers:
-        wk["gk"].close()
-        wk["ctx"].close()
+        res.update(parity_vs_oracle_on_sample=parity, parity_sample_per_batch=min(parity_sample, B),
+                   parity_what="the oracle expands each batch's (seed, counter) itself and signs: (r, s, recid) bit for bit")
+    pipe.close()
+    gk.close()
     return res
 
 
@@ -883,17 +893,43 @@ def keygen_verify_section(ctx, E, keys, F, B=8192, cpu=True):
     return out
 
 
+def make_comm(ctx, E, rank, world, share, distributed):
+    """the RCCL communicator of the round fan-out behind the C-ABI (mpe_comm_create): rank 0's id travels through the process group
+    that the launcher set up; ranks that share one device (--share-device, gloo) cannot use RCCL and keep the host-staged gather"""
+    if share:
+        return None
+    if not distributed:
+        return E.Comm(ctx, 0, 1)
+    import torch.distributed as dist
+
+    def exchange(ident):
+        box = [ident]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    return E.Comm(ctx, rank, world, exchange_id=exchange)
+
+
 class GpuRoundEngine:
     """dist.PartySharded engine over mpe_gg20_roundN: one session object per session block, local = the parties this rank
-    hosts; the object lives across steps (mpe_gg20_session_rearm) and writes its records into the gather buffer"""
+    hosts; the object lives across steps (mpe_gg20_session_rearm) and writes its records into the gather buffer.  Every step of
+    the timed region re-arms it with values sampled ON THE DEVICE for exactly its local parties from the engine's own seed and a
+    fresh batch counter (a party process owns its seed: no two parties, and no two batches, ever share a stream); `known` holds one
+    caller-made set for the parity pass against the oracle."""
     writes_in_place = True
 
-    def __init__(self, ctx, E, gk, Bblk, parties, nonces):
+    def __init__(self, ctx, E, gk, Bblk, parties, nonces, seed):
+        self.ctx, self.E, self.gk, self.B, self.parties = ctx, E, gk, Bblk, parties
         self.sess = E.Gg20Session(ctx, gk, Bblk, parties, nonces)
-        self.keep = nonces
+        self.known, self.seed, self.counter, self.fresh = nonces, seed, 0, None
 
-    def rearm(self):
-        self.sess.rearm(self.keep)
+    def rearm(self, known=False):
+        if known:
+            self.sess.rearm(self.known)
+            return
+        self.counter += 1
+        self.fresh, _ = self.E.gg20_sample_nonces(self.ctx, self.gk, self.B, self.seed, self.counter, local=self.parties, out=self.fresh,
+                                                  msg=self.known["msg"])
+        self.sess.rearm(self.fresh)
 
     def round(self, rnd, d_in, in_off, msg, out=None):
         return self.sess.round(rnd, d_in=d_in, in_off=in_off, msg=msg, out=out)
@@ -910,11 +946,13 @@ class PartyMode:
     (block, party) pairs of B sessions each, every round's records travel through ONE all-gather (dist.PartySharded).  The
     session objects live across steps, as a party process would keep them: a step re-arms them and runs the nine rounds.
 
-    BENCHMARK ONLY: every step re-arms a block with the SAME sampled values (`keep`) so that the timed region holds nothing but
-    protocol work.  A real party samples fresh k_i, gamma_i and Paillier randomness for every batch — re-using them across two
-    signatures leaks the key share (include/mpecdsa_hip.h: mpe_gg20_session_rearm)."""
+    Every timed step re-arms every hosted (block, parties) object with FRESHLY SAMPLED values (device-side sampler, the object's own
+    seed, a new batch counter): re-using k_i, gamma_i or a Paillier randomness across two signatures leaks the key share
+    (include/mpecdsa_hip.h: mpe_gg20_session_rearm), and round 4's bench did exactly that.  The warm-up step and the parity pass
+    (`step(known=True)`) use one caller-made set whose full-session view the oracle signs.
+    comm: engine.Comm — the per-round all-gathers then go through mpe_comm_all_gather (RCCL behind the C-ABI)."""
 
-    def __init__(self, ctx, E, G, mpe_dist, lk, arrays, T, n, signers, B, dev, world, parity_sessions=0):
+    def __init__(self, ctx, E, G, mpe_dist, lk, arrays, T, n, signers, B, dev, world, parity_sessions=0, comm=None):
         self.E, self.G, self.lk, self.B, self.S, self.n = E, G, lk, B, len(signers), n
         self.engines, self.block_nonces, self.block_sample = {}, {}, {}
         S = self.S
@@ -940,19 +978,19 @@ class PartyMode:
             # a key object per hosted (block, parties): ONLY those parties' x_i, p, q reach it (mpe_gg20_keys_create n_own / h_own),
             # as in the reference's deployment where a process holds one party's LocalKey
             gk_own = E.Gg20Keys(ctx, T, n, signers, arrays, own=[signers[p_] for p_ in parties])
-            self.engines[s] = GpuRoundEngine(ctx, E, gk_own, B, parties, mine)
+            seed = hashlib.sha256(b"bench.py party mode|block %d|parties %s|n %d" % (s, ",".join(map(str, parties)).encode(), n)).digest()
+            self.engines[s] = GpuRoundEngine(ctx, E, gk_own, B, parties, mine, seed)
             self.engines[s].keys = gk_own
-            self.engines[s].parties = parties
             return self.engines[s]
         self.ps = mpe_dist.PartySharded(S, B, lambda rnd: E.gg20_msg_words(S, n, rnd), make_engine, dev, placement="rotated",
-                                        colocate=world < S, timing=True)
+                                        colocate=world < S, timing=True, comm=comm)
         self.armed = True
         self.last = None
 
-    def step(self):
-        if not self.armed:
+    def step(self, known=False):
+        if not self.armed or not known:
             for _, e_ in self.ps.engines.values():
-                e_.rearm()
+                e_.rearm(known=known)
         self.armed = False
         res = self.ps.run({s: self.block_nonces[s]["msg"] for s in self.ps.engines})
         self.last = res
@@ -964,6 +1002,8 @@ class PartyMode:
         the GMP oracle's for the same sampled values (bit for bit) -> (ok, sessions compared)"""
         if not self.block_sample or self.last is None:
             return None, 0
+        self.step(known=True)                                  # one untimed pass on the caller-made values the oracle can sign too
+        torch.cuda.synchronize()
         s0 = sorted(self.block_sample)[0]
         host = self.block_sample[s0]
         k = host["msg"].shape[0]
@@ -980,39 +1020,6 @@ class PartyMode:
         for e_ in self.engines.values():
             e_.close()
             e_.keys.close()
-
-
-def stream_child(args, device_index):
-    """`c4_stream_1024` in a CHILD process.  A signing service keeps several batches in flight on separate streams; the HIP runtime
-    multiplexes the streams of a process onto 4 hardware queues by default and streams that share a queue serialize.  Measured on this
-    section, 48 batches per run (profiles/r04/stream_sweep*.log): 4 queues 9.3 k signatures/s, 8 queues 11.1 k, 16 queues 12.6 k (3 in
-    flight) .. 14.1 k (10 in flight).  GPU_MAX_HW_QUEUES must be set before the runtime initialises, hence the child — and the DEVICE
-    has about 20 hardware queues for all processes together (20 or more in one process abort inside the runtime with
-    HSA_STATUS_ERROR_OUT_OF_RESOURCES; so does 16 here plus the 4 of a parent that has already used its own: seen once in round 4),
-    so main() runs this BEFORE it creates its own context, and a child that aborts is retried with fewer queues.  A failure is
-    reported in the section and cannot take the line down."""
-    import subprocess
-    tried = []
-    for queues in dict.fromkeys([args.stream_hw_queues, 12, 8]):
-        env = dict(os.environ)
-        env["GPU_MAX_HW_QUEUES"] = str(queues)
-        cmd = [sys.executable, os.path.abspath(__file__), "--stream-child", "--stream-inflight", str(args.stream_inflight), "--stream-batches",
-               str(args.stream_batches), "--device", str(device_index)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + \
-              (["--share-hint"] if args.share_hint else [])
-        try:
-            p_ = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-        except subprocess.TimeoutExpired:
-            tried.append({"hw_queues": queues, "error": "child timed out"})
-            continue
-        lines_ = [ln for ln in p_.stdout.splitlines() if ln.startswith("{")]
-        if p_.returncode == 0 and lines_:
-            out = json.loads(lines_[-1])
-            out["hw_queues"] = queues
-            if tried:
-                out["failed_attempts"] = tried
-            return out
-        tried.append({"hw_queues": queues, "error": f"child exited {p_.returncode}", "stderr_tail": p_.stderr[-300:]})
-    return {"error": "every attempt failed", "attempts": tried}
 
 
 def respawn_under_torchrun(n, argv):
@@ -1044,14 +1051,9 @@ def main():
     ap.add_argument("--mode", choices=["session", "party"], default="session", help="multi-GPU layout (SURVEY.md 8e A / B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the c2 / c3 / c4 / c5 / Lindell sections")
-    ap.add_argument("--stream-inflight", default="3,2,8", help="c4_stream_1024: batches in flight (host threads x contexts x streams); a comma "
-                                                               "list: the first depth is the section's headline, the others are reported under other_depths")
-    ap.add_argument("--stream-batches", type=int, default=24)
-    ap.add_argument("--stream-hw-queues", type=int, default=16, help="GPU_MAX_HW_QUEUES of the child process that runs c4_stream_1024")
-    ap.add_argument("--stream-child", action="store_true", help="(internal) run only the c4_stream_1024 depths and print their JSON")
-    ap.add_argument("--device", type=int, default=0, help="(internal, --stream-child) device index")
-    ap.add_argument("--share-hint", action="store_true", help="c4_stream_1024: mpe_ctx_set_device_share(in flight) on every context — keeps the efficient "
-                                                              "lane layouts; measured neutral within the run-to-run noise (profiles/r04/stream_sweep.log)")
+    ap.add_argument("--stream-batches", type=int, default=96, help="c4_stream_1024: batches of 1 024 sessions in the stream")
+    ap.add_argument("--stream-lanes", type=int, default=2, help="c4_stream_1024: passes in flight (mpe_gg20_pipeline lanes)")
+    ap.add_argument("--stream-group", type=int, default=4, help="c4_stream_1024: batches coalesced per pass")
     ap.add_argument("--only", default="", help="comma list of config sections to run after the timed region (default: all)")
     ap.add_argument("--no-mode-b", action="store_true", help="N > 1, session mode: skip the party-sharded (config 5 shape) pass after the timed region")
     ap.add_argument("--mode-b-sessions", type=int, default=0, help="sessions per block of that pass (0 = min(8192, --sessions))")
@@ -1060,20 +1062,6 @@ def main():
                     help="all ranks use cuda:0 and talk through gloo (host-staged): exercises the N>1 code path on a 1-GPU box; "
                          "the ranks time-share one GPU, so `value` says nothing about a node")
     args = ap.parse_args()
-
-    if args.stream_child:
-        import fixtures as F
-        import gg20_fixture as G
-        from multi_party_ecdsa_amd import engine as E
-        keys = F.load_keys()
-        depths = [int(x) for x in str(args.stream_inflight).split(",") if x]
-        # the first depth with the full checks, then the others (fewer oracle sessions per batch)
-        main_ = c4_stream(E, G, keys, args.device, batches=args.stream_batches, B=1024, inflight=depths[0], oracle=not args.no_cpu_baseline,
-                          share_hint=args.share_hint, parity_sample=32)
-        main_["other_depths"] = {str(k_): c4_stream(E, G, keys, args.device, batches=args.stream_batches, B=1024, inflight=k_,
-                                                    oracle=not args.no_cpu_baseline, share_hint=args.share_hint, parity_sample=8) for k_ in depths[1:]}
-        print(json.dumps(main_))
-        return
 
     if "RANK" not in os.environ and args.gpus > 1:
         # no launcher around us: become it (N ranks, one per GPU, RCCL over xGMI)
@@ -1115,14 +1103,6 @@ def main():
     from multi_party_ecdsa_amd import engine as E
     keys = F.load_keys()
     T, N_PARTIES = args.t, args.n
-    early_stream = None
-    only_ = [x for x in args.only.split(",") if x]
-    if world == 1 and not distributed and args.mode == "session" and not args.no_configs and (T, N_PARTIES) == (1, 3) and \
-            (not only_ or any("c4_stream_1024".startswith(o) for o in only_)):
-        # before this process owns any hardware queue (see stream_child); sequential with everything timed below
-        t_ = time.perf_counter()
-        early_stream = stream_child(args, local_rank)
-        early_stream = (early_stream, round(time.perf_counter() - t_, 2))
     ctx = E.Context(local_rank)
     dev = ctx.device
     SIGNERS = list(range(T + 1))                               # parties 1..t+1 sign
@@ -1141,17 +1121,31 @@ def main():
     gen.manual_seed(4242 + rank)
     extra = {}
     gk = None
+    sampler = None
     if args.mode == "session":
         gk = E.Gg20Keys(ctx, T, N_PARTIES, SIGNERS, arrays)      # every signer local: the Simulation harness of the reference
-        nonces = make_device_nonces(gen, dev, B, S, S, n)
+        # Every value the reference draws from OsRng is drawn ON THE DEVICE, INSIDE the timed step, from (seed, step counter) with the
+        # reference's distributions (mpe_gg20_sample_nonces: sample_below by rejection, from_modulo with its gcd, Scalar::random):
+        # no step signs with the nonces of another, and what a host hands over per step is 32 bytes + the messages.
+        seed = hashlib.sha256(b"bench.py headline|rank %d" % rank).digest()
+        msg = rand_words(gen, dev, B, 8, 8)
+        nonces, fail0 = E.gg20_sample_nonces(ctx, gk, B, seed, 0, msg=msg)
         torch.cuda.synchronize()
+        sampler = {"seed": seed, "counter": 0, "events": [], "fail": fail0}
 
         def step():
+            sampler["counter"] += 1
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _, sampler["fail"] = E.gg20_sample_nonces(ctx, gk, B, seed, sampler["counter"], out=nonces)
+            e1.record()
+            sampler["events"].append((e0, e1))
             return E.gg20_sign(ctx, gk, nonces, B, dedup_verify=args.dedup, chunk=args.chunk)
     else:
         # party p of session block s on rank (s + p) % world: this rank hosts S (block, party) pairs of B sessions each —
         # the same per-GPU work as B whole sessions; the messages of every round travel through one all-gather
-        pm = PartyMode(ctx, E, G, mpe_dist, lk, arrays, T, N_PARTIES, SIGNERS, B, dev, world, parity_sessions=0 if args.no_cpu_baseline else 8)
+        comm = make_comm(ctx, E, rank, world, share, distributed)
+        pm = PartyMode(ctx, E, G, mpe_dist, lk, arrays, T, N_PARTIES, SIGNERS, B, dev, world, parity_sessions=0 if args.no_cpu_baseline else 8, comm=comm)
         engines = pm.engines
         gather_test = pm.ps.layout_self_test()                 # the gather layout on the real backend, before anything is timed
         ps_holder = {"ps": pm.ps}
@@ -1161,6 +1155,8 @@ def main():
         out = step()
     torch.cuda.synchronize()
     ctx.prof_enable(True)
+    if sampler is not None:
+        sampler["events"] = []
     if args.mode == "party":
         ps_holder["ps"].comm_seconds()                     # drop the warm-up's share
     comm_total = 0.0
@@ -1197,7 +1193,8 @@ def main():
         extra = {"bytes_all_gathered_per_round": {str(k): int(v) for k, v in ps.bytes_per_round.items()},
                  "rccl_time_share": comm_total / (elapsed if elapsed > 0 else 1.0), "placement": ps.placement,
                  "pairs_per_rank": ps.per_rank, "gather_mode": ps.gather_mode,
-                 "nonces": "benchmark only: every step re-arms a block with the same sampled values (a real party samples fresh ones per batch)"}
+                 "nonces": "every timed step re-arms every hosted (block, parties) object with values sampled on the device from its own seed and a fresh batch counter",
+                 "fan_out": "mpe_comm_all_gather (ncclAllGather behind the C-ABI)" if ps.comm is not None else "torch.distributed (host-staged under gloo)"}
 
     # (c) a parity sample against the GMP oracle on EVERY rank at N > 1 (at N = 1 the cpu_baseline leg below does it on 256+ sessions)
     rank_parity = None
@@ -1229,8 +1226,9 @@ def main():
             tb, nb, sg_b = 2, 5, [0, 1, 2]
             Bb = args.mode_b_sessions if args.mode_b_sessions else min(8192, B)
             lk_b = G.make_local_keys(keys, tb, nb, sg_b)
+            comm_b = make_comm(ctx, E, rank, world, share, distributed)
             pm_b = PartyMode(ctx, E, G, mpe_dist, lk_b, lk_b["arrays"], tb, nb, sg_b, Bb, dev, world,
-                             parity_sessions=0 if args.no_cpu_baseline else 4)
+                             parity_sessions=0 if args.no_cpu_baseline else 4, comm=comm_b)
             gather_layout = pm_b.ps.layout_self_test()
             pm_b.step()                                        # warm-up
             torch.cuda.synchronize()
@@ -1264,7 +1262,8 @@ def main():
                       "all_sessions_signed": all(float(t_[1]) == 1.0 for t_ in every_b),
                       "parity_sample_vs_oracle": None if args.no_cpu_baseline else all(float(t_[2]) == 1.0 for t_ in every_b),
                       "parity_sessions_per_rank": int(k_b),
-                      "nonces": "benchmark only: every step re-arms a block with the same sampled values"}
+                      "nonces": "fresh per step: device-side sampler, one seed per hosted (block, parties) object",
+                      "fan_out": "mpe_comm_all_gather (ncclAllGather behind the C-ABI)" if pm_b.ps.comm is not None else "torch.distributed (host-staged under gloo)"}
             pm_b.close()
         except Exception as e_b:                               # noqa: BLE001 — the Mode-A line must survive a Mode-B failure, and say so
             mode_b = {"error": repr(e_b)}
@@ -1352,13 +1351,13 @@ def main():
                          "executed_mac_per_launch": exe_macs / nl, "alg_unit_mac_per_launch": dom_macs / nl,
                          "kernel_time_share_of_step": dom_s / elapsed,
                          # the issue ceiling actually measured for this instruction (tools/ubench/valu_rate.hip): a stream of
-                         # v_mad_u64_u32 with VGPR operands sustains 31.2 T lane-ops/s at the kernel's 2 waves per SIMD, not
-                         # the 39.3 T of the 4-cycle issue model.  The kernel's VALU stream = the 29-bit-limb MACs it executes
-                         # (72 limbs x 71 CIOS steps per pass against MAC(64): LIMB_INFLATION = 1.238 x the ideal count) x 740/648
-                         # instructions per MAC in its loops.
-                         "issue_ceiling": ({"measured_T_lane_ops_per_s": 31.2, "source": "profiles/r01_valu_rate.json (mad_u64_u32_vv, 2 waves/SIMD)",
-                                            "kernel_valu_T_lane_ops_per_s": exe_macs * LIMB_INFLATION * 740 / 648 / dom_s / 1e12,
-                                            "frac_of_measured": exe_macs * LIMB_INFLATION * 740 / 648 / dom_s / 31.2e12,
+                         # v_mad_u64_u32 with VGPR operands sustains 31.2 T lane-ops/s at the kernel's 2 waves per SIMD, not the 39.3 T
+                         # of the 4-cycle issue model.  Against it stand the MACs the kernel REALLY executes: 29-bit limbs, 72 limbs x
+                         # 71 CIOS steps per pass (LIMB_INFLATION = 1.238 x the ideal count) — multiply instructions only; the ~14 %
+                         # cheaper non-MAC instructions of the loops are not priced at the MAC's rate (round 4 did, and got 1.01)
+                         "issue_ceiling": ({"measured_T_mac_per_s": 31.2, "source": "profiles/r01_valu_rate.json (mad_u64_u32_vv, 2 waves/SIMD)",
+                                            "executed_29bit_T_mac_per_s": exe_macs * LIMB_INFLATION / dom_s / 1e12,
+                                            "frac_of_measured": exe_macs * LIMB_INFLATION / dom_s / 31.2e12,
                                             "limb_inflation": LIMB_INFLATION}
                                            if pair and dom_s else None)},
             "breakdown": {"modexp4096_s_per_step": dom_s / args.steps, "modexp2048_s_per_step": sec_s / args.steps,
@@ -1401,8 +1400,23 @@ def main():
                                              f"{threads} threads of {os.cpu_count()} host CPUs)"}
             res["parity_vs_oracle_on_sample"] = parity
             res["parity_sample"] = sample
+        if sampler is not None:
+            samp_s = sum(a_.elapsed_time(b_) for a_, b_ in sampler["events"]) * 1e-3
+            res["sampling"] = {"where": "on the device, inside the timed step (mpe_gg20_sample_nonces: ChaCha20 keystream of a 32-byte seed, curv's "
+                                        "sample_below / sample_range / from_modulo / Scalar::random rules; a fresh batch counter per step)",
+                               "seconds_per_step": samp_s / max(1, len(sampler["events"])), "share_of_step": samp_s / elapsed,
+                               "steps_sampled": len(sampler["events"]), "rejection_loops_given_up": int(sampler["fail"].item()),
+                               "bytes_sampled_per_step": int(sum(v.numel() * 4 for f_, v in nonces.items() if f_ != "msg"))}
+            res["config"]["sampling_share_of_step"] = res["sampling"]["share_of_step"]
+            if single and not args.no_cpu_baseline:
+                # the oracle expands the SAME (seed, counter) of the last step: identical arrays (oracle/sampler_oracle.c)
+                k_ = min(B, 64)
+                want_, wf_ = G.oracle_sample_nonces(lk, k_, sampler["seed"], sampler["counter"])
+                got_ = _host({f_: v[: k_ * (v.shape[0] // B)] for f_, v in nonces.items() if f_ != "msg"})
+                res["sampling"]["oracle_expands_the_seed_to_the_same_values"] = bool(wf_ == 0 and all(np.array_equal(got_[f_], want_[f_]) for f_ in got_))
+                res["sampling"]["sessions_compared"] = k_
         if single:
-            # A host that hands its sampled values over for every batch instead of keeping them resident: the measured cost of moving
+            # A host that samples for itself and hands its values over for every batch (mpe_gg20_sign with caller arrays): the measured cost of moving
             # the step's inputs in (pinned host memory -> HBM) and its signatures out.  Reported beside the line, never part of `value`.
             try:
                 pinned = {f: torch.empty(v.shape, dtype=v.dtype, pin_memory=True).copy_(v) for f, v in nonces.items()}
@@ -1445,15 +1459,21 @@ def main():
                     import traceback
                     cfg[name] = {"error": f"{type(e_).__name__}: {e_}", "where": traceback.format_exc().strip().splitlines()[-3:]}
                 took[name] = round(time.perf_counter() - t_, 2)
-            section("c2_paillier_65536", lambda: paillier_config2(ctx, E, keys, F, oracle_threads=0 if args.no_cpu_baseline else threads))
+            section("c2_paillier_65536", lambda: paillier_config2(ctx, E, keys, F, oracle_threads=0 if args.no_cpu_baseline else threads, oracle_items=4096))
             section("c3_ec_pdl_262144", lambda: config3(ctx, E, keys, F, oracle=not args.no_cpu_baseline))
             section("c3b_bob_65536", lambda: bob_section(ctx, E, keys, F, oracle=not args.no_cpu_baseline))
             section("c4_literal_1024", lambda: gg20_config(ctx, E, G, keys, 1, 3, 1024, 4, gen, parity_sample=0 if args.no_cpu_baseline else 128,
                                                            openssl=True))
-            if early_stream is not None:
-                cfg["c4_stream_1024"], took["c4_stream_1024"] = early_stream
-            else:                                            # under a launcher the process group came first: run it here, with the retries
-                section("c4_stream_1024", lambda: stream_child(args, local_rank))
+            def stream_section():
+                main_ = c4_pipeline(ctx, E, G, keys, batches=args.stream_batches, lanes=args.stream_lanes, group=args.stream_group,
+                                    oracle=not args.no_cpu_baseline, parity_sample=16)
+                # the same stream with twice the batches per pass: more throughput for a longer pass
+                o_ = c4_pipeline(ctx, E, G, keys, batches=args.stream_batches, lanes=args.stream_lanes, group=2 * args.stream_group,
+                                 oracle=False, parity_sample=0)
+                main_["other_shapes"] = {f"{args.stream_lanes}x{2 * args.stream_group}": {k_: o_[k_] for k_ in
+                                         ("signatures_per_s", "latency_ms", "pass_ms", "all_sessions_signed", "openssl_verified", "openssl_of")}}
+                return main_
+            section("c4_stream_1024", stream_section)
             section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32,
                                                               openssl=True))
             section("c4_multi_wallet_16384", lambda: [multi_wallet(ctx, E, G, keys, K_, 16384, gen) for K_ in (16, 1024)])
@@ -1468,6 +1488,20 @@ def main():
             res["section_seconds"] = took
         if node_paillier is not None:
             res["paillier"] = node_paillier
+        # the scalars a reader of the truncated line needs, inside the two objects every consumer keeps
+        res["roofline"]["whole_step_frac"] = res["whole_step"]["frac"]
+        also = {"whole_step_frac": res["whole_step"]["frac"]}
+        cfgs = res.get("configs", {})
+        if isinstance(cfgs.get("c4_literal_1024"), dict) and "signatures_per_s" in cfgs["c4_literal_1024"]:
+            also["c4_literal_1024_signatures_per_s"] = cfgs["c4_literal_1024"]["signatures_per_s"]
+        if isinstance(cfgs.get("c4_stream_1024"), dict) and "signatures_per_s" in cfgs["c4_stream_1024"]:
+            also["c4_stream_1024_signatures_per_s"] = cfgs["c4_stream_1024"]["signatures_per_s"]
+            also["c4_stream_1024_latency_ms_p50"] = cfgs["c4_stream_1024"]["latency_ms"]["p50"]
+        if isinstance(cfgs.get("c5_share_t2n5_8192"), dict) and "signatures_per_s" in cfgs["c5_share_t2n5_8192"]:
+            also["c5_share_t2n5_8192_signatures_per_s"] = cfgs["c5_share_t2n5_8192"]["signatures_per_s"]
+        if isinstance(res.get("paillier"), dict) and "modexp4096_2048_per_s" in res["paillier"]:
+            also["paillier_2048_modexp_per_s"] = res["paillier"]["modexp4096_2048_per_s"]
+        res["config"]["also"] = also
         print(json.dumps(res))
     if distributed:
         dist.destroy_process_group()

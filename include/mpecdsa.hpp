@@ -743,6 +743,172 @@ class SignManual {
 
 }  // namespace sign
 }  // namespace state_machine
+// ---- party-sharded signing across GPUs: the round fan-out behind the C-ABI (mpe_comm_*, RCCL over xGMI) -----------------------------
+// In the reference a party broadcasts every message — P2P ones included — to the room and every client filters what is addressed
+// to it (examples/gg20_sm_client.rs:35-40); the state machine consumes them round by round (state_machine/sign.rs:252-438).  Here one
+// process per GPU hosts some (session block, party) pairs; a round's records are written by mpe_gg20_roundN straight into this rank's
+// rows of a gather buffer, ONE ncclAllGather per round (mpe_gg20_round_exchange) delivers everybody's rows, and the next round reads
+// the gathered buffer in place through h_in_off (mpe_gg20_shard_in_off) — no host copy of any message.
+namespace sharded {
+
+// the communicator: rank 0 makes the id, the HOST carries its bytes to the other ranks (a file, a socket, MPI, the relay)
+class Comm {
+ public:
+  static std::vector<uint8_t> unique_id() {
+    std::vector<uint8_t> id(MPE_COMM_ID_BYTES);
+    check(mpe_comm_unique_id(id.data()), "mpe_comm_unique_id");
+    return id;
+  }
+  Comm(Context& ctx, const std::vector<uint8_t>& id, int rank, int world) {
+    if (id.size() != MPE_COMM_ID_BYTES) throw Error("Comm: the id is MPE_COMM_ID_BYTES bytes", MPE_E_ARG);
+    check(mpe_comm_create(ctx.get(), id.data(), rank, world, &h_), "mpe_comm_create");
+  }
+  ~Comm() { if (h_) (void)mpe_comm_destroy(h_); }
+  Comm(const Comm&) = delete;
+  mpe_comm* get() const { return h_; }
+  int rank() const { return mpe_comm_rank(h_); }
+  int world() const { return mpe_comm_world(h_); }
+  // the gather layout on the real communicator, before any signing work; returns 0 (in place) / 1 (copy form)
+  int layout_self_test(int rows_per_rank) {
+    int mode = -1, ok = 0;
+    check(mpe_comm_layout_self_test(h_, rows_per_rank, &mode, &ok, nullptr), "mpe_comm_layout_self_test");
+    return mode;
+  }
+ private:
+  mpe_comm* h_ = nullptr;
+};
+
+// what one hosted (block, party) pair needs: the party's LocalKey (its own secrets only) and the values it samples for its block
+struct Hosted {
+  int block = 0, party = 0;                      // party: 0-based position in s_l
+  LocalKey local_key;
+  SignNonces sampled;
+  Batch message;                                 // [batch][8] the block's messages
+};
+struct PairResult {
+  int block = 0, party = 0;
+  Batch r, s;
+  std::vector<int32_t> recid, status;
+  std::vector<uint32_t> bad_actors;
+};
+
+class PartySharded {
+ public:
+  // placement: MPE_PLACE_PARTY / MPE_PLACE_ROTATED (mpecdsa_hip.h); `hosted`: exactly the pairs mpe_gg20_shard_where puts on this rank
+  PartySharded(Context& ctx, Comm& comm, int placement, const std::vector<uint16_t>& s_l, int batch, std::vector<Hosted> hosted)
+      : ctx_(ctx), comm_(comm), placement_(placement), S_((int)s_l.size()), batch_(batch) {
+    const int world = comm.world(), rank = comm.rank();
+    per_rank_ = mpe_gg20_shard_per_rank(placement, S_, world);
+    if (per_rank_ < 1 || (int)hosted.size() != per_rank_) throw Error("PartySharded: this rank hosts mpe_gg20_shard_per_rank pairs", MPE_E_ARG);
+    std::vector<int32_t> signers(s_l.begin(), s_l.end());
+    for (auto& v : signers) v -= 1;
+    for (Hosted& h : hosted) {
+      int r = -1, slot = -1;
+      check(mpe_gg20_shard_where(placement, S_, world, h.block, h.party, &r, &slot), "mpe_gg20_shard_where");
+      if (r != rank) throw Error("PartySharded: a pair that lives on another rank", MPE_E_ARG);
+      std::unique_ptr<Pair> P(new Pair(ctx));
+      P->block = h.block; P->party = h.party; P->slot = slot; P->message = std::move(h.message);
+      n_ = h.local_key.n;
+      const LocalKey& k = h.local_key;
+      const int32_t own = k.i - 1, local = h.party;
+      {
+        Dev<uint32_t> x = up(k.x_i), dp = up(k.p), dq = up(k.q), N = up(k.paillier_key_vec), Nt = up(k.n_tilde_vec), h1 = up(k.h1_vec), h2 = up(k.h2_vec),
+                      y = up(k.y_sum_s), X = up(k.pk_vec);
+        check(mpe_gg20_keys_create(ctx.get(), k.t, k.n, S_, signers.data(), 1, 1, &own, x.get(), dp.get(), dq.get(), N.get(), Nt.get(), h1.get(), h2.get(),
+                                   y.get(), X.get(), &P->keys, nullptr), "mpe_gg20_keys_create");
+        ctx.sync();
+      }
+      const SignNonces& z = h.sampled;
+      const Batch* f[] = {&z.k, &z.gamma, &z.blind, &z.r_a, &z.al_alpha, &z.al_beta, &z.al_gamma, &z.al_rho, &z.mb_beta_tag, &z.mb_r, &z.mb_nonce_b,
+                          &z.mb_nonce_bt, &z.l, &z.ped_s1, &z.ped_s2, &z.pdl_alpha, &z.pdl_beta, &z.pdl_rho, &z.pdl_gamma, &z.heg_s1, &z.heg_s2};
+      for (const Batch* b : f) P->sampled.emplace_back(new Dev<uint32_t>(b->w));
+      auto d = [&](int q) { return (const uint32_t*)P->sampled[(size_t)q]->get(); };
+      const mpe_gg20_nonces nn{d(0), d(1), d(2), d(3), d(4), d(5), d(6), d(7), d(8), d(9), d(10), d(11), d(12), d(13), d(14), d(15), d(16), d(17), d(18),
+                               d(19), d(20), nullptr};
+      check(mpe_gg20_session_create(ctx.get(), P->keys, batch, 1, &local, nullptr, &nn, 0, &P->sess, nullptr), "mpe_gg20_session_create");
+      check(mpe_gg20_shard_in_off(placement, S_, world, batch, h.block, P->in_off), "mpe_gg20_shard_in_off");
+      pairs_.push_back(std::move(P));
+    }
+    int maxw = 0;
+    for (int r = 0; r < 8; ++r) maxw = std::max(maxw, mpe_gg20_msg_words(S_, n_, r));
+    const size_t words = (size_t)world * per_rank_ * batch * maxw;
+    for (auto& b : buf_) b.reset(new Dev<uint32_t>(words));
+    gather_mode_ = comm.layout_self_test(per_rank_);
+  }
+
+  int gather_mode() const { return gather_mode_; }
+  // bytes every rank receives per round (all ranks' rows), by emitting round
+  std::map<int, size_t> bytes_per_round() const {
+    std::map<int, size_t> m;
+    for (int r : {0, 1, 2, 3, 4, 5, 7}) m[r] = (size_t)comm_.world() * per_rank_ * batch_ * mpe_gg20_msg_words(S_, n_, r) * 4;
+    return m;
+  }
+
+  // Round0..Round7 + SignManual::complete for every hosted pair, one all-gather after every emitting round
+  std::vector<PairResult> run() {
+    const uint32_t* gathered = nullptr;
+    int q = 0;
+    for (int rnd = 0; rnd <= 8; ++rnd) {
+      const int W = (rnd == 6 || rnd == 8) ? 0 : mpe_gg20_msg_words(S_, n_, rnd);
+      uint32_t* cur = W ? buf_[q & 1]->get() : nullptr;
+      for (auto& Pp : pairs_) {
+        Pair& P = *Pp;
+        uint32_t* mine = W ? cur + ((size_t)comm_.rank() * per_rank_ + P.slot) * (size_t)batch_ * W : nullptr;
+        int rc = MPE_OK;
+        switch (rnd) {
+          case 0: rc = mpe_gg20_round0(P.sess, mine, nullptr); break;
+          case 1: rc = mpe_gg20_round1(P.sess, gathered, P.in_off, mine, nullptr); break;
+          case 2: rc = mpe_gg20_round2(P.sess, gathered, P.in_off, mine, nullptr); break;
+          case 3: rc = mpe_gg20_round3(P.sess, gathered, P.in_off, mine, nullptr); break;
+          case 4: rc = mpe_gg20_round4(P.sess, gathered, P.in_off, mine, nullptr); break;
+          case 5: rc = mpe_gg20_round5(P.sess, gathered, P.in_off, mine, nullptr); break;
+          case 6: rc = mpe_gg20_round6(P.sess, gathered, P.in_off, nullptr); break;
+          case 7: { Dev<uint32_t> m = up(P.message); rc = mpe_gg20_round7(P.sess, m.get(), mine, nullptr); ctx_.sync(); break; }
+          default: rc = mpe_gg20_complete(P.sess, gathered, P.in_off, nullptr); break;
+        }
+        check(rc, "mpe_gg20_roundN");
+      }
+      if (W) {
+        check(mpe_gg20_round_exchange(comm_.get(), S_, n_, rnd, per_rank_, batch_, cur, nullptr), "mpe_gg20_round_exchange");
+        gathered = cur;
+        ++q;
+      }
+    }
+    std::vector<PairResult> out;
+    const size_t B = (size_t)batch_;
+    for (auto& Pp : pairs_) {
+      Dev<int32_t> st(B), rec(B);
+      Dev<uint32_t> bad(B), r(B * W_SCALAR), s(B * W_SCALAR);
+      check(mpe_gg20_session_result(Pp->sess, st.get(), bad.get(), r.get(), s.get(), rec.get(), nullptr, nullptr), "mpe_gg20_session_result");
+      ctx_.sync();
+      out.push_back(PairResult{Pp->block, Pp->party, down(r, W_SCALAR), down(s, W_SCALAR), rec.download(), st.download(), bad.download()});
+    }
+    return out;
+  }
+
+ private:
+  struct Pair {
+    Context& ctx;
+    int block = 0, party = 0, slot = 0;
+    mpe_gg20_keys* keys = nullptr;
+    mpe_gg20_session* sess = nullptr;
+    int64_t in_off[8] = {0};
+    Batch message;
+    std::vector<std::unique_ptr<Dev<uint32_t>>> sampled;
+    explicit Pair(Context& c) : ctx(c) {}
+    ~Pair() {
+      if (sess) (void)mpe_gg20_session_destroy(sess, nullptr);
+      if (keys) (void)mpe_gg20_keys_destroy(keys);
+    }
+  };
+  Context& ctx_;
+  Comm& comm_;
+  int placement_, S_, batch_, n_ = 0, per_rank_ = 0, gather_mode_ = -1;
+  std::vector<std::unique_ptr<Pair>> pairs_;
+  std::unique_ptr<Dev<uint32_t>> buf_[2];
+};
+
+}  // namespace sharded
 }  // namespace gg_2020
 
 }  // namespace mpecdsa

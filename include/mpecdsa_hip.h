@@ -546,6 +546,43 @@ int mpe_gg20_pipeline_pass_ms(mpe_gg20_pipeline* p, uint64_t ticket, float* ms);
 int mpe_gg20_pipeline_sampler_failures(mpe_gg20_pipeline* p, int32_t* h_out);
 
 
+/* ---- multi-GPU: the per-round message fan-out behind the C-ABI (RCCL over xGMI; SURVEY.md 8e B, BASELINE config 5) ------------
+ * Party-sharded signing: the parties of a session live on DIFFERENT GPUs (one process per GPU) and every round's messages travel
+ * through ONE all-gather, after which each party reads what is addressed to it — the reference's relay broadcasts every message,
+ * P2P ones included, to the room and the client filters (examples/gg20_sm_client.rs:35-40; state_machine/sign.rs:252-438).
+ *   mpe_comm_unique_id   ncclGetUniqueId: ONE rank calls it, the host carries the MPE_COMM_ID_BYTES bytes to the others (any channel)
+ *   mpe_comm_create      ncclCommInitRank on the context's device; blocks until all `world` ranks have called it
+ *   mpe_comm_all_gather  d_buf = [world][bytes_per_rank]; this rank's block already sits at rank * bytes_per_rank; one ncclAllGather
+ *                        queued on `stream` fills the others (in place; from a copy of the block when the self-test chose that form)
+ *   mpe_comm_layout_self_test  one all-gather of known row patterns on the REAL communicator before any signing work: in place
+ *                        first, then the copy form; all ranks agree (ncclAllReduce) on the first form that puts every row of every rank
+ *                        where h_in_off will look for it.  *h_mode = 0 in place / 1 copy, *h_ok = 1; an error when neither is right.
+ * Placement of party p (signer ordinal) of session block s:
+ *   MPE_PLACE_PARTY    rank p % world, slot p / world (world divides S; one block);
+ *   MPE_PLACE_ROTATED  world blocks; rank (s + p) % world, slot p — every rank hosts S (block, party) pairs for any world size, and
+ *                      with world >= S no two parties of a session share a GPU.
+ * The gather buffer is [world * per_rank] rows of [batch][W(round)] records; rank r owns rows [r * per_rank, (r + 1) * per_rank), row
+ * r * per_rank + slot = that pair's outgoing records (mpe_gg20_roundN's d_out points there).  mpe_gg20_shard_in_off gives, for a
+ * block, the record offset of every sender's row: the h_in_off argument of the next mpe_gg20_roundN, which reads the gathered
+ * buffer in place.  mpe_gg20_round_exchange = the all-gather of round `round`'s records (per_rank * batch * W words per rank). */
+#define MPE_COMM_ID_BYTES 128
+#define MPE_PLACE_PARTY 0
+#define MPE_PLACE_ROTATED 1
+typedef struct mpe_comm mpe_comm;
+int mpe_comm_unique_id(uint8_t* h_id);
+int mpe_comm_create(mpe_ctx* ctx, const uint8_t* h_id, int rank, int world, mpe_comm** out);
+int mpe_comm_destroy(mpe_comm* comm);
+int mpe_comm_rank(const mpe_comm* comm);
+int mpe_comm_world(const mpe_comm* comm);
+int mpe_comm_gather_mode(const mpe_comm* comm);
+int mpe_comm_all_gather(mpe_comm* comm, void* d_buf, size_t bytes_per_rank, void* stream);
+int mpe_comm_layout_self_test(mpe_comm* comm, int rows_per_rank, int* h_mode, int* h_ok, void* stream);
+int mpe_gg20_shard_where(int placement, int n_signers, int world, int block, int party, int* rank, int* slot);
+int mpe_gg20_shard_blocks(int placement, int n_signers, int world);
+int mpe_gg20_shard_per_rank(int placement, int n_signers, int world);
+int mpe_gg20_shard_in_off(int placement, int n_signers, int world, int batch, int block, int64_t* h_in_off);
+int mpe_gg20_round_exchange(mpe_comm* comm, int n_signers, int n, int round, int per_rank, int batch, uint32_t* d_slab, void* stream);
+
 /* ---- keygen VERIFICATION math (src/protocols/multi_party_ecdsa/gg_2020/party_i.rs:260-438) ----------------------- */
 /* What every party checks about every other party's first keygen messages and shares, batched over (verifier, prover)
  * pairs / wallets.  Every key is its own modulus: the moduli set is built per call.  The two zk-paillier 0.4.3 proofs are

@@ -187,6 +187,19 @@ def _load():
         "mpe_paillier_mul": (ip, [vp, vp, ip, i32p, u32p, u32p, ip, u32p, vp]),
         "mpe_keygen_verify_round1": (ip, [vp, ip, ip, C.POINTER(KeygenRound1), vp, u32p, vp]),
         "mpe_keygen_verify_round2": (ip, [vp, ip, ip, ip, u32p, u32p, i32p, u32p, vp, u32p, vp]),
+        "mpe_comm_unique_id": (ip, [C.c_char_p]),
+        "mpe_comm_create": (ip, [vp, C.c_char_p, ip, ip, C.POINTER(vp)]),
+        "mpe_comm_destroy": (ip, [vp]),
+        "mpe_comm_rank": (ip, [vp]),
+        "mpe_comm_world": (ip, [vp]),
+        "mpe_comm_gather_mode": (ip, [vp]),
+        "mpe_comm_all_gather": (ip, [vp, vp, C.c_size_t, vp]),
+        "mpe_comm_layout_self_test": (ip, [vp, ip, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]),
+        "mpe_gg20_shard_where": (ip, [ip, ip, ip, ip, ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "mpe_gg20_shard_blocks": (ip, [ip, ip, ip]),
+        "mpe_gg20_shard_per_rank": (ip, [ip, ip, ip]),
+        "mpe_gg20_shard_in_off": (ip, [ip, ip, ip, ip, ip, C.POINTER(C.c_int64)]),
+        "mpe_gg20_round_exchange": (ip, [vp, ip, ip, ip, ip, ip, u32p, vp]),
         "mpe_sample_bits": (ip, [vp, ip, C.c_char_p, C.c_uint64, ip, ip, u32p, vp]),
         "mpe_sample_below": (ip, [vp, ip, C.c_char_p, C.c_uint64, u32p, ip, ip, i32p, ip, ip, u32p, i32p, vp]),
         "mpe_sample_scalar": (ip, [vp, ip, C.c_char_p, C.c_uint64, u32p, i32p, vp]),
@@ -237,7 +250,10 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_gg20_nonces_alloc", "mpe_gg20_nonces_view", "mpe_gg20_nonces_free", "mpe_gg20_sample_nonces",
             "mpe_gg20_pipeline_create", "mpe_gg20_pipeline_destroy", "mpe_gg20_pipeline_submit", "mpe_gg20_pipeline_submit_seeded",
             "mpe_gg20_pipeline_flush", "mpe_gg20_pipeline_query", "mpe_gg20_pipeline_wait", "mpe_gg20_pipeline_stream_wait",
-            "mpe_gg20_pipeline_latency_ms", "mpe_gg20_pipeline_pass_ms", "mpe_gg20_pipeline_sampler_failures", "mpe_keygen_verify_round1", "mpe_keygen_verify_round2"]
+            "mpe_gg20_pipeline_latency_ms", "mpe_gg20_pipeline_pass_ms", "mpe_gg20_pipeline_sampler_failures", "mpe_keygen_verify_round1", "mpe_keygen_verify_round2",
+            "mpe_comm_unique_id", "mpe_comm_create", "mpe_comm_destroy", "mpe_comm_rank", "mpe_comm_world", "mpe_comm_gather_mode", "mpe_comm_all_gather",
+            "mpe_comm_layout_self_test", "mpe_gg20_shard_where", "mpe_gg20_shard_blocks", "mpe_gg20_shard_per_rank", "mpe_gg20_shard_in_off",
+            "mpe_gg20_round_exchange"]
 
 
 def check(rc, what):

@@ -264,6 +264,7 @@ static int launch_pair_modexp(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Ro
 #include "mpe_gg20.h"
 #include "mpe_sample.h"
 #include "mpe_pipeline.h"
+#include "mpe_comm.h"
 #include "mpe_sigma.h"
 #include "mpe_blame.h"
 #include "mpe_keygen.h"

@@ -294,7 +294,7 @@ static int sample_gg20(mpe_ctx* ctx, const mpe_gg20_keys* K, int batch, int n_lo
   add(18, out->pdl_gamma, nPP, b.q3Nt, 88, x.st_pp, 88, 0);                                    // :77
   scalar(19, out->heg_s1, nPI);                                                                // HomoELGamalProof::prove (:778-799)
   scalar(20, out->heg_s2, nPI);
-  if ((size_t)t.start[t.n] != 7 * nPI + 4 * nAP + 4 * nMB + 4 * nPP) return MPE_E_ARG;          // a batch beyond 2^32 items
+  if ((size_t)t.start[t.n] != 9 * nPI + 4 * nAP + 4 * nMB + 4 * nPP) { mpe_set_error_msg("gg20 sampler: more than 2^32 items in one batch"); return MPE_E_ARG; }          // a batch beyond 2^32 items
   hipLaunchKernelGGL(sample_fields_kernel, dim3((t.start[t.n] + 63) / 64), dim3(64), 0, st, t, seed_of(h_seed), (uint32_t)counter, (uint32_t)(counter >> 32), d_fail);
   {  // from_modulo: gcd(r, N) == 1 as ONE batched verdict for all items (Montgomery's trick, mpe_modinv.h); whoever fails it — 2^-1023
      // per draw for an honest key — is redrawn by the lane-serial loop, which replays the item's stream with the gcd inside the loop

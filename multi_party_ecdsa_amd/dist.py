@@ -24,7 +24,15 @@ gather buffer, the all-gather is queued behind them on the same stream (RCCL) an
 in place through `h_in_off` — no host synchronisation, no staging copy, two alternating buffers.  Under gloo (CPU tensors,
 or GPU engines that share one device in the tests) the slab is staged through host memory.
 
-Gather modes (`PartySharded.gather_mode`; MPE_DIST_GATHER in the environment forces one): "inplace" — the default on RCCL:
+The fan-out itself lives BEHIND THE C-ABI (round 5): `mpe_comm_*` / `mpe_gg20_round_exchange` / `mpe_gg20_shard_*` of
+include/mpecdsa_hip.h (csrc/mpe_comm.h: ncclAllGather on the round's stream, the placement arithmetic, the layout self-test) — what a
+compiled host binds (include/mpecdsa.hpp: PartySharded).  This module is the Python harness around the same entry points: pass
+`comm=engine.Comm(...)` and every collective of `run()` is `mpe_comm_all_gather` ("native" gather mode); the placement always comes
+from `mpe_gg20_shard_where`.  The torch.distributed modes below remain for the CPU tests (gloo, oracle engines) and for ranks that
+share one device (RCCL refuses two ranks on one GPU).
+
+Gather modes (`PartySharded.gather_mode`; MPE_DIST_GATHER in the environment forces one): "native" — the C-ABI communicator;
+"inplace" — torch.distributed on RCCL:
 the collective's input is this rank's slice of its output; "outofplace" — the input is a separate copy of that slice (what
 `layout_self_test` falls back to if the in-place form ever misplaces a row on some backend / version); "staged" — synchronise,
 copy through host memory (gloo with GPU engines; also the conservative fallback).  `layout_self_test()` runs one collective of
@@ -80,7 +88,9 @@ class PartySharded:
     there; the others return a tensor that is copied into the slot."""
 
     def __init__(self, S, Bblk, msg_words, make_engine, device, placement="rotated", rank=None, world=None, colocate=False,
-                 timing=False):
+                 timing=False, comm=None):
+        import multi_party_ecdsa_amd.engine as _E        # the placement arithmetic is the library's (host code: no GPU needed)
+        self.comm = comm                                 # engine.Comm: the collectives go through mpe_comm_all_gather
         self.S, self.Bblk, self.msg_words, self.device = S, Bblk, msg_words, torch.device(device)
         self.dist = dist.is_available() and dist.is_initialized()
         self.rank = (dist.get_rank() if self.dist else 0) if rank is None else rank
@@ -90,13 +100,13 @@ class PartySharded:
             if S % G:
                 raise ValueError("placement 'party' needs the world size to divide the number of signers")
             self.blocks = 1
-            self._where = lambda s, p: (p % G, p // G)
+            self._where = lambda s, p: _E.shard_where(_E.PLACE_PARTY, S, G, s, p)
         elif placement == "rotated":
             if G < S and not colocate:
                 raise ValueError(f"placement 'rotated' with world {G} < {S} signers puts two parties of a session on one rank "
                                  "(pass colocate=True to accept that)")
             self.blocks = G
-            self._where = lambda s, p: ((s + p) % G, p)
+            self._where = lambda s, p: _E.shard_where(_E.PLACE_ROTATED, S, G, s, p)
         else:
             raise ValueError(placement)
         self.placement = placement
@@ -119,6 +129,8 @@ class PartySharded:
         forced = os.environ.get("MPE_DIST_GATHER")
         if forced in ("inplace", "outofplace", "staged") and cuda:
             self.gather_mode = forced
+        if comm is not None:
+            self.gather_mode = "native"
         self.self_test = None
 
     def in_off(self, s):
@@ -137,7 +149,9 @@ class PartySharded:
         return self._bufs[q & 1][: rows * self.Bblk * W].view(rows, self.Bblk, W)
 
     def _collective(self, buf, mine, mode):
-        if mode == "inplace":                        # input = this rank's slice of the output
+        if mode == "native":                         # ncclAllGather behind the C-ABI, queued on the current stream
+            self.comm.all_gather(buf, mine.numel() * 4)
+        elif mode == "inplace":                      # input = this rank's slice of the output
             dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1))
         elif mode == "outofplace":
             dist.all_gather_into_tensor(buf.view(-1), mine.clone().reshape(-1))
@@ -149,7 +163,7 @@ class PartySharded:
     def _gather(self, buf, mine):
         """all ranks' slabs into `buf` (`mine` = this rank's rows of it, already written)"""
         cuda = buf.is_cuda
-        if not self.dist or (self.world == 1 and not (cuda and self.backend == "nccl")):
+        if self.comm is None and (not self.dist or (self.world == 1 and not (cuda and self.backend == "nccl"))):
             return                                   # (one RCCL rank still issues the collective: the same call path as N ranks)
         mode = self.gather_mode if cuda else "outofplace"
         if cuda and mode != "staged":
@@ -176,6 +190,10 @@ class PartySharded:
         the value (r * per_rank + k) * 65536 + column; after the collective every row of every rank must sit where `in_off`
         will look for it.  Tries the current mode first, then the remaining ones; all ranks settle on the first mode that is
         right everywhere (all-reduce MIN of the verdicts).  Returns and stores {"mode", "ok", "tried": {mode: ok}}."""
+        if getattr(self, "comm", None) is not None:  # mpe_comm_layout_self_test: the same pattern test on the C-ABI communicator
+            st = self.comm.layout_self_test(self.per_rank)
+            self.self_test = dict(mode="native:" + st["mode"], ok=st["ok"], tried={"native:" + st["mode"]: st["ok"]})
+            return self.self_test
         if not self.dist:
             self.self_test = dict(mode=self.gather_mode, ok=True, tried={}, skipped="no process group")
             return self.self_test

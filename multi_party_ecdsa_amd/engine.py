@@ -562,6 +562,61 @@ def gg20_sign(ctx, keys, nonces, B, dedup_verify=False, chunk=0, want_R=False, k
     return (r, s, recid, status, R) if want_R else (r, s, recid, status)
 
 
+PLACE_PARTY, PLACE_ROTATED = 0, 1
+
+
+class Comm:
+    """mpe_comm_*: the RCCL communicator of the round fan-out behind the C-ABI (include/mpecdsa_hip.h).  `exchange_id(id_or_None)`:
+    a callable that carries rank 0's 128 id bytes to every rank (e.g. a torch.distributed broadcast, a file, a socket)."""
+    ID_BYTES = 128
+
+    def __init__(self, ctx, rank, world, exchange_id=None):
+        self.ctx = ctx
+        buf = C.create_string_buffer(self.ID_BYTES)
+        if rank == 0:
+            N_.check(N_.lib.mpe_comm_unique_id(buf), "mpe_comm_unique_id")
+        ident = buf.raw
+        if world > 1 or exchange_id is not None:
+            ident = bytes(exchange_id(ident if rank == 0 else None))
+        h = C.c_void_p()
+        N_.check(N_.lib.mpe_comm_create(ctx.h, ident, rank, world, C.byref(h)), "mpe_comm_create")
+        self.h, self.rank, self.world = h, rank, world
+
+    def layout_self_test(self, rows_per_rank):
+        mode, ok = C.c_int(-1), C.c_int(0)
+        N_.check(N_.lib.mpe_comm_layout_self_test(self.h, rows_per_rank, C.byref(mode), C.byref(ok), self.ctx.stream()), "mpe_comm_layout_self_test")
+        return dict(mode=("inplace", "copy")[mode.value], ok=bool(ok.value))
+
+    def all_gather(self, buf, bytes_per_rank):
+        N_.check(N_.lib.mpe_comm_all_gather(self.h, _ptr(buf), bytes_per_rank, self.ctx.stream()), "mpe_comm_all_gather")
+
+    def round_exchange(self, S, n, rnd, per_rank, batch, slab):
+        N_.check(N_.lib.mpe_gg20_round_exchange(self.h, S, n, rnd, per_rank, batch, _ptr(slab), self.ctx.stream()), "mpe_gg20_round_exchange")
+
+    def close(self):
+        if self.h:
+            N_.lib.mpe_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_where(placement, S, world, block, party):
+    r, s = C.c_int(0), C.c_int(0)
+    N_.check(N_.lib.mpe_gg20_shard_where(placement, S, world, block, party, C.byref(r), C.byref(s)), "mpe_gg20_shard_where")
+    return r.value, s.value
+
+
+def shard_in_off(placement, S, world, batch, block):
+    off = (C.c_int64 * S)()
+    N_.check(N_.lib.mpe_gg20_shard_in_off(placement, S, world, batch, block, off), "mpe_gg20_shard_in_off")
+    return list(off)
+
+
 class Gg20Pipeline:
     """mpe_gg20_pipeline_*: a stream of `batch`-session batches, `group` of them coalesced per pass, `lanes` passes in flight on one
     stream each (include/mpecdsa_hip.h).  submit / submit_seeded return a ticket; the result tensors of a ticket are valid after

@@ -17,6 +17,7 @@
 #include <gmp.h>
 
 #include <cstdio>
+#include <ctime>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -403,6 +404,50 @@ static bool simulate_signing(Context& ctx, const SmCase& c) {
   return true;
 }
 
+// Party-sharded signing over the C-ABI's RCCL fan-out (mpe_comm_*, mpe_gg20_round_exchange; mpecdsa.hpp: sharded::PartySharded): every
+// hosted (block, party) pair ends with the oracle's signature.  world = 1: all pairs on this rank, the all-gathers still run on the real
+// communicator.  world > 1 (one process per GPU): rank r hosts party p of block s when (s + p) % world == r; block s signs the fixture's
+// sessions with its own messages (the fixture's, plus s in the lowest word) — every rank checks the pairs it hosts.
+static bool party_sharded(Context& ctx, const SmCase& c, int rank, int world, const std::vector<uint8_t>& id) {
+  namespace sh = gg_2020::sharded;
+  sh::Comm comm(ctx, id, rank, world);
+  std::vector<sh::Hosted> hosted;
+  const int blocks = mpe_gg20_shard_blocks(MPE_PLACE_ROTATED, c.S, world);
+  auto block_msg = [&](int s) { Batch m = c.get("msg"); for (size_t b = 0; b < m.size(); ++b) m.row(b)[0] ^= (uint32_t)s; return m; };
+  for (int s = 0; s < blocks; ++s)
+    for (int p = 0; p < c.S; ++p) {
+      int r = -1, slot = -1;
+      REQUIRE(mpe_gg20_shard_where(MPE_PLACE_ROTATED, c.S, world, s, p, &r, &slot) == MPE_OK);
+      if (r != rank) continue;
+      hosted.push_back(sh::Hosted{s, p, c.local_key(c.s_l[(size_t)p] - 1), c.sampled(p), block_msg(s)});
+    }
+  sh::PartySharded ps(ctx, comm, MPE_PLACE_ROTATED, c.s_l, c.B, std::move(hosted));
+  REQUIRE(ps.gather_mode() == 0 || ps.gather_mode() == 1);
+  const auto res = ps.run();
+  REQUIRE((int)res.size() == c.S);
+  std::vector<int32_t> signers;
+  for (auto v : c.s_l) signers.push_back(v - 1);
+  const orc_gg20_keys K{c.t, c.n, c.S, 1, signers.data(), c.get("x").w.data(), c.get("p").w.data(), c.get("q").w.data(), c.get("N").w.data(),
+                        c.get("Nt").w.data(), c.get("h1").w.data(), c.get("h2").w.data(), c.get("y").w.data(), c.get("X").w.data()};
+  for (const auto& pr : res) {
+    const Batch message = block_msg(pr.block);
+    const orc_gg20_nonces Z{c.get("k").w.data(), c.get("gamma").w.data(), c.get("blind").w.data(), c.get("r_a").w.data(), c.get("al_alpha").w.data(),
+                            c.get("al_beta").w.data(), c.get("al_gamma").w.data(), c.get("al_rho").w.data(), c.get("mb_beta_tag").w.data(),
+                            c.get("mb_r").w.data(), c.get("mb_nonce_b").w.data(), c.get("mb_nonce_bt").w.data(), c.get("l").w.data(),
+                            c.get("ped_s1").w.data(), c.get("ped_s2").w.data(), c.get("pdl_alpha").w.data(), c.get("pdl_beta").w.data(),
+                            c.get("pdl_rho").w.data(), c.get("pdl_gamma").w.data(), c.get("heg_s1").w.data(), c.get("heg_s2").w.data(), message.w.data()};
+    Batch wr(c.B, W_SCALAR), ws(c.B, W_SCALAR);
+    std::vector<int32_t> wrec((size_t)c.B), wst((size_t)c.B);
+    orc_gg20_sign(&K, &Z, 0, c.B, wr.w.data(), ws.w.data(), wrec.data(), nullptr, wst.data());
+    for (int32_t v : wst) REQUIRE(v == 0);
+    for (int32_t v : pr.status) REQUIRE(v == 0);
+    REQUIRE(pr.r == wr && pr.s == ws && pr.recid == wrec);
+    std::vector<uint8_t> ok((size_t)c.B);
+    REQUIRE(ossl_ecdsa_verify(c.B, c.get("y").w.data(), 0, message.w.data(), pr.r.w.data(), pr.s.w.data(), ok.data()) == c.B);
+  }
+  return true;
+}
+
 template <class F>
 static bool throws(sm::Error::Kind kind, F&& f) {
   try { f(); } catch (const sm::Error& e) { return e.kind == kind; }
@@ -449,6 +494,38 @@ int main(int argc, char** argv) {
   if (argc < 2) { std::fprintf(stderr, "usage: test_shim <fixture.bin>\n"); return 2; }
   Fixture F{load_fixture(argv[1])};
   int failed = 0;
+  if (argc == 7 && std::string(argv[2]) == "--sharded") {
+    // one rank of a multi-process party-sharded run: test_shim <fixture> --sharded <rank> <world> <id file> <case>; device = rank
+    const int rank = std::atoi(argv[3]), world = std::atoi(argv[4]), k = std::atoi(argv[6]);
+    try {
+      Context ctx(rank);
+      std::vector<uint8_t> id;
+      if (rank == 0) {
+        id = gg_2020::sharded::Comm::unique_id();
+        const std::string tmp = std::string(argv[5]) + ".tmp";
+        FILE* f = std::fopen(tmp.c_str(), "wb");
+        if (!f || std::fwrite(id.data(), 1, id.size(), f) != id.size()) return 3;
+        std::fclose(f);
+        std::rename(tmp.c_str(), argv[5]);                       // the other ranks see a complete file or none
+      } else {
+        for (int tries = 0; tries < 600 && id.empty(); ++tries) {
+          if (FILE* f = std::fopen(argv[5], "rb")) {
+            id.resize(MPE_COMM_ID_BYTES);
+            if (std::fread(id.data(), 1, id.size(), f) != id.size()) id.clear();
+            std::fclose(f);
+          }
+          if (id.empty()) { struct timespec ts = {0, 100000000}; nanosleep(&ts, nullptr); }
+        }
+        if (id.empty()) return 4;
+      }
+      const bool ok = party_sharded(ctx, sm_case(F, k), rank, world, id);
+      std::printf("rank %d of %d: party_sharded ... %s\n", rank, world, ok ? "ok" : "FAILED");
+      return ok ? 0 : 1;
+    } catch (const std::exception& e) {
+      std::printf("rank %d EXCEPTION %s\n", rank, e.what());
+      return 1;
+    }
+  }
   try {
     Context ctx(0);
     EncryptionKeys ek(ctx, F["N"]);
@@ -497,6 +574,12 @@ int main(int argc, char** argv) {
       const sm::CompletedOfflineStage copy = done[0];
       ok = ok && throws(sm::Error::OfflineStageReused, [&] { (void)sm::SignManual::new_(c.get("msg"), copy); });
       std::printf("test state_machine_errors ... %s\n", ok ? "ok" : "FAILED");
+      failed += ok ? 0 : 1;
+    }
+    for (int k : {1, 4}) {                                         // t=1 n=3 {1,2} and t=2 n=3 {1,2,3}: world 1, the collectives on the real RCCL communicator
+      const SmCase c = sm_case(F, k);
+      const bool ok = party_sharded(ctx, c, 0, 1, gg_2020::sharded::Comm::unique_id());
+      std::printf("test party_sharded_rccl_world1_t%d_n%d_s%d ... %s\n", c.t, c.n, c.S, ok ? "ok" : "FAILED");
       failed += ok ? 0 : 1;
     }
     // argument errors surface as exceptions carrying mpe_last_error()

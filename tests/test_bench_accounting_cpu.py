@@ -155,39 +155,13 @@ def test_self_spawn_command_line(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
-def test_stream_child_retries_with_fewer_hardware_queues(monkeypatch):
-    """the c4_stream child aborts inside the runtime when the device's hardware queues run out (seen once in round 4: 16 in the
-    child + 4 of the parent): it is retried with 12, then 8 queues; the section says which count worked and what failed before"""
-    import argparse
-    import subprocess
-    calls = []
-
-    class P:
-        def __init__(self, rc, out, err=""):
-            self.returncode, self.stdout, self.stderr = rc, out, err
-
-    def fake_run(cmd, env=None, capture_output=None, text=None, timeout=None):
-        q = int(env["GPU_MAX_HW_QUEUES"])
-        calls.append((q, cmd))
-        if q > fake_run.works_below:
-            return P(-6, "", "Aborting with error : HSA_STATUS_ERROR_OUT_OF_RESOURCES")
-        return P(0, 'noise\n{"signatures_per_s": 12345.0, "inflight": 3}\n')
-    monkeypatch.setattr(subprocess, "run", fake_run)
-    args = argparse.Namespace(stream_hw_queues=16, stream_inflight="3,2,8", stream_batches=24, no_cpu_baseline=True, share_hint=False)
-    fake_run.works_below = 16
-    out = B.stream_child(args, 0)
-    assert out["signatures_per_s"] == 12345.0 and out["hw_queues"] == 16 and "failed_attempts" not in out
-    assert [c[0] for c in calls] == [16] and "--stream-child" in calls[0][1] and "--no-cpu-baseline" in calls[0][1]
-    calls.clear()
-    fake_run.works_below = 12
-    out = B.stream_child(args, 0)
-    assert out["hw_queues"] == 12 and [a["hw_queues"] for a in out["failed_attempts"]] == [16] and [c[0] for c in calls] == [16, 12]
-    assert "OUT_OF_RESOURCES" in out["failed_attempts"][0]["stderr_tail"]
-    calls.clear()
-    fake_run.works_below = 0
-    out = B.stream_child(args, 0)
-    assert out["error"] == "every attempt failed" and [a["hw_queues"] for a in out["attempts"]] == [16, 12, 8]
-    calls.clear()
-    args.stream_hw_queues = 12                                  # a caller's own choice is tried first, without duplicates
-    B.stream_child(args, 0)
-    assert [c[0] for c in calls] == [12, 8]
+def test_the_stream_section_needs_no_child_process_and_no_queue_setting():
+    """round 4 ran c4_stream_1024 in a child with GPU_MAX_HW_QUEUES=16 and a retry chain; the pipelined engine runs it in this process
+    with the runtime's defaults: bench.py neither spawns for it nor touches the variable, and names the closed-loop client's bound"""
+    import inspect
+    src = inspect.getsource(B)
+    assert not hasattr(B, "stream_child") and "--stream-child" not in src
+    assert 'environ["GPU_MAX_HW_QUEUES"]' not in src and "env[\"GPU_MAX_HW_QUEUES\"]" not in src
+    body = inspect.getsource(B.c4_pipeline)
+    assert "Gg20Pipeline" in body and "submit_seeded" in body and "window = 2 * lanes * group" in body
+    assert "oracle_sample_nonces" in body and "openssl_verify_all" in body        # every batch: OpenSSL on all, the oracle on a sample
