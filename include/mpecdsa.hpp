@@ -72,15 +72,21 @@ struct Batch {
   bool operator!=(const Batch& o) const { return !(*this == o); }
 };
 
-// device buffer for the duration of a call
+// device buffer for the duration of a call.  secret = true: key material and sampled values (x_i, p, q, k_i, gamma_i, Paillier
+// randomness) — zeroed before the memory goes back to the allocator, as the C-ABI does with its own state (mpe_ctx_wipe, session
+// destroy / rearm) and as the reference zeroizes its round secrets (range_proofs.rs:26-36)
 template <class T>
 class Dev {
  public:
-  explicit Dev(size_t n) : n_(n) { check_hip(hipMalloc((void**)&p_, (n ? n : 1) * sizeof(T)), "hipMalloc"); }
-  explicit Dev(const std::vector<T>& h) : Dev(h.size()) {
+  explicit Dev(size_t n, bool secret = false) : n_(n), secret_(secret) { check_hip(hipMalloc((void**)&p_, (n ? n : 1) * sizeof(T)), "hipMalloc"); }
+  explicit Dev(const std::vector<T>& h, bool secret = false) : Dev(h.size(), secret) {
     if (!h.empty()) check_hip(hipMemcpy(p_, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D");
   }
-  ~Dev() { if (p_) (void)hipFree(p_); }
+  ~Dev() {
+    if (!p_) return;
+    if (secret_ && n_) (void)hipMemset(p_, 0, n_ * sizeof(T));
+    (void)hipFree(p_);
+  }
   Dev(const Dev&) = delete;
   Dev& operator=(const Dev&) = delete;
   T* get() const { return p_; }
@@ -92,8 +98,10 @@ class Dev {
  private:
   T* p_ = nullptr;
   size_t n_ = 0;
+  bool secret_ = false;
 };
 inline Dev<uint32_t> up(const Batch& b) { return Dev<uint32_t>(b.w); }
+inline Dev<uint32_t> up_secret(const Batch& b) { return Dev<uint32_t>(b.w, true); }
 inline Batch down(const Dev<uint32_t>& d, int words) { Batch b; b.words = words; b.w = d.download(); return b; }
 using Index = std::vector<int32_t>;       // per-item key / statement index
 using Flags = std::vector<uint8_t>;       // per-item verdict (1 = Ok / true)
@@ -592,7 +600,7 @@ class OfflineStage {
     for (auto& v : signers) v -= 1;
     const int32_t own = local_key.i - 1, local = P.me;
     {
-      Dev<uint32_t> x = up(local_key.x_i), dp = up(local_key.p), dq = up(local_key.q), N = up(local_key.paillier_key_vec), Nt = up(local_key.n_tilde_vec),
+      Dev<uint32_t> x = up_secret(local_key.x_i), dp = up_secret(local_key.p), dq = up_secret(local_key.q), N = up(local_key.paillier_key_vec), Nt = up(local_key.n_tilde_vec),
                     h1 = up(local_key.h1_vec), h2 = up(local_key.h2_vec), y = up(local_key.y_sum_s), X = up(local_key.pk_vec);
       check(mpe_gg20_keys_create(ctx.get(), local_key.t, local_key.n, P.S, signers.data(), 1, 1, &own, x.get(), dp.get(), dq.get(), N.get(), Nt.get(),
                                  h1.get(), h2.get(), y.get(), X.get(), &P.keys, nullptr), "mpe_gg20_keys_create");
@@ -601,7 +609,7 @@ class OfflineStage {
     const Batch* f[] = {&sampled.k, &sampled.gamma, &sampled.blind, &sampled.r_a, &sampled.al_alpha, &sampled.al_beta, &sampled.al_gamma, &sampled.al_rho,
                         &sampled.mb_beta_tag, &sampled.mb_r, &sampled.mb_nonce_b, &sampled.mb_nonce_bt, &sampled.l, &sampled.ped_s1, &sampled.ped_s2,
                         &sampled.pdl_alpha, &sampled.pdl_beta, &sampled.pdl_rho, &sampled.pdl_gamma, &sampled.heg_s1, &sampled.heg_s2};
-    for (const Batch* b : f) P.sampled.emplace_back(new Dev<uint32_t>(b->w));
+    for (const Batch* b : f) P.sampled.emplace_back(new Dev<uint32_t>(b->w, true));       // wiped when released (after round 5 / with the party)
     auto d = [&](int k) { return (const uint32_t*)P.sampled[(size_t)k]->get(); };
     const mpe_gg20_nonces nn{d(0), d(1), d(2), d(3), d(4), d(5), d(6), d(7), d(8), d(9), d(10), d(11), d(12), d(13), d(14), d(15), d(16), d(17), d(18),
                              d(19), d(20), nullptr};
@@ -812,7 +820,7 @@ class PartySharded {
       const LocalKey& k = h.local_key;
       const int32_t own = k.i - 1, local = h.party;
       {
-        Dev<uint32_t> x = up(k.x_i), dp = up(k.p), dq = up(k.q), N = up(k.paillier_key_vec), Nt = up(k.n_tilde_vec), h1 = up(k.h1_vec), h2 = up(k.h2_vec),
+        Dev<uint32_t> x = up_secret(k.x_i), dp = up_secret(k.p), dq = up_secret(k.q), N = up(k.paillier_key_vec), Nt = up(k.n_tilde_vec), h1 = up(k.h1_vec), h2 = up(k.h2_vec),
                       y = up(k.y_sum_s), X = up(k.pk_vec);
         check(mpe_gg20_keys_create(ctx.get(), k.t, k.n, S_, signers.data(), 1, 1, &own, x.get(), dp.get(), dq.get(), N.get(), Nt.get(), h1.get(), h2.get(),
                                    y.get(), X.get(), &P->keys, nullptr), "mpe_gg20_keys_create");
@@ -821,7 +829,7 @@ class PartySharded {
       const SignNonces& z = h.sampled;
       const Batch* f[] = {&z.k, &z.gamma, &z.blind, &z.r_a, &z.al_alpha, &z.al_beta, &z.al_gamma, &z.al_rho, &z.mb_beta_tag, &z.mb_r, &z.mb_nonce_b,
                           &z.mb_nonce_bt, &z.l, &z.ped_s1, &z.ped_s2, &z.pdl_alpha, &z.pdl_beta, &z.pdl_rho, &z.pdl_gamma, &z.heg_s1, &z.heg_s2};
-      for (const Batch* b : f) P->sampled.emplace_back(new Dev<uint32_t>(b->w));
+      for (const Batch* b : f) P->sampled.emplace_back(new Dev<uint32_t>(b->w, true));
       auto d = [&](int q) { return (const uint32_t*)P->sampled[(size_t)q]->get(); };
       const mpe_gg20_nonces nn{d(0), d(1), d(2), d(3), d(4), d(5), d(6), d(7), d(8), d(9), d(10), d(11), d(12), d(13), d(14), d(15), d(16), d(17), d(18),
                                d(19), d(20), nullptr};

@@ -439,8 +439,14 @@ int mpe_gg20_session_destroy(mpe_gg20_session* sess, void* stream);
  * start again at 0.  Results are identical to those of a freshly created session.
  * `nonces` MUST hold freshly sampled values (the same buffers refilled are fine): signing two batches with the same k_i,
  * gamma_i or Paillier randomness leaks the key share, and the library cannot detect it.  MPE_E_ARG when the previous batch is
- * half-way through the protocol (finish it with mpe_gg20_complete or destroy the object); MPE_E_HIP when the wipe fails. */
+ * half-way through the protocol and healthy (finish it with mpe_gg20_complete, or give it up with mpe_gg20_session_abort);
+ * MPE_E_HIP when the wipe fails. */
 int mpe_gg20_session_rearm(mpe_gg20_session* sess, const int32_t* d_keyset, const mpe_gg20_nonces* nonces, void* stream);
+/* Gives the running batch up (the caller stops after the offline stage, a peer vanished, a round call returned an error): the
+ * nonce-derived state is wiped at once, every round entry point refuses, and mpe_gg20_session_rearm starts the next batch.  A
+ * session whose round call FAILED (MPE_E_NOMEM, MPE_E_HIP) may also be re-armed directly: a long-lived party process is never
+ * left with an object it can only destroy. */
+int mpe_gg20_session_abort(mpe_gg20_session* sess, void* stream);
 int mpe_gg20_round0(mpe_gg20_session* sess, uint32_t* d_out, void* stream);
 int mpe_gg20_round1(mpe_gg20_session* sess, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream);
 int mpe_gg20_round2(mpe_gg20_session* sess, const uint32_t* d_in, const int64_t* h_in_off, uint32_t* d_out, void* stream);
@@ -512,15 +518,15 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int3
  * latency-bound (chains of ~2 048 dependent squarings at a fraction of the chip).  The reference runs many `OfflineStage`s
  * concurrently on one executor (state_machine/sign.rs:667-691; rounds.rs:106,215,323 `is_expensive`).  Here:
  * `group` consecutive batches are coalesced into ONE lock-step pass (every heavy launch carries the items of all of them) and
- * `lanes` (1..4) such passes are in flight at once, each on one stream of its own with its own workspace, plus ONE stream that stages
- * the inputs of the next groups (copies or the device-side sampler) while the lanes compute: lanes <= 3 keeps every stream on a
- * hardware queue of its own with the runtime's defaults.  ONE host thread: submit only enqueues.  Results are bit-identical to mpe_gg20_sign.
+ * `lanes` (1..4) such passes are in flight at once, each on one stream of its own with its own workspace — at most 4 streams,
+ * the runtime's default hardware queues, ONE host thread: submit only enqueues.  Results are bit-identical to mpe_gg20_sign.
  *   submit         the caller's sampled values of ONE batch (layout of mpe_gg20_nonces with every signer local, as for
  *                  mpe_gg20_sign) and where its results go: d_r, d_s [batch][8], d_recid, d_status [batch], d_R [batch][16] or NULL.
  *                  `stream`: the stream that produced the inputs (the pipeline waits for it).  Inputs are copied and results
  *                  written ASYNCHRONOUSLY: both sets of arrays must stay valid until the ticket completes.
  *   submit_seeded  the same, but every sampled value is drawn on the device from (h_seed32, batch_counter) exactly as
- *                  mpe_gg20_sample_nonces does; d_msg [batch][8] are the messages.  A (seed, batch_counter) pair signs ONE batch.
+ *                  mpe_gg20_sample_nonces does (one sampler launch per group, right before its pass; group <= 16); d_msg [batch][8]
+ *                  are the messages.  A (seed, batch_counter) pair signs ONE batch.  A group holds batches of one form only.
  *   flush          sends the partly filled group to the device (a service calls it when its queue runs dry)
  *   wait           blocks the host until the batch of `ticket` is complete (flushing its group if it is still open);
  *   stream_wait    makes `stream` wait for it instead;  query: *done = 0 / 1 without blocking

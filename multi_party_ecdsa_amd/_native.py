@@ -161,6 +161,7 @@ def _load():
         "mpe_hash_commit_point": (ip, [vp, ip, u32p, u32p, u32p, vp]),
         "mpe_gg20_session_fault_inject": (ip, [vp, ip, C.c_uint32]),
         "mpe_gg20_session_rearm": (ip, [vp, i32p, C.POINTER(Gg20Nonces), vp]),
+        "mpe_gg20_session_abort": (ip, [vp, vp]),
         "mpe_gg20_blame5": (ip, [vp, vp, ip, i32p, C.POINTER(Blame5In), u32p, vp]),
         "mpe_gg20_blame6": (ip, [vp, vp, ip, i32p, C.POINTER(Blame6In), u32p, vp]),
         "mpe_gg20_blame7": (ip, [vp, ip, ip, C.POINTER(Blame7In), u32p, vp]),
@@ -253,7 +254,7 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_gg20_pipeline_latency_ms", "mpe_gg20_pipeline_pass_ms", "mpe_gg20_pipeline_sampler_failures", "mpe_keygen_verify_round1", "mpe_keygen_verify_round2",
             "mpe_comm_unique_id", "mpe_comm_create", "mpe_comm_destroy", "mpe_comm_rank", "mpe_comm_world", "mpe_comm_gather_mode", "mpe_comm_all_gather",
             "mpe_comm_layout_self_test", "mpe_gg20_shard_where", "mpe_gg20_shard_blocks", "mpe_gg20_shard_per_rank", "mpe_gg20_shard_in_off",
-            "mpe_gg20_round_exchange"]
+            "mpe_gg20_round_exchange", "mpe_gg20_session_abort"]
 
 
 def check(rc, what):

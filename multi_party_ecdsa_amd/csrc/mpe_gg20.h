@@ -736,6 +736,7 @@ struct mpe_gg20_session {
   mpe_ctx* ctx = nullptr;
   const mpe_gg20_keys* K = nullptr;
   int B = 0, L = 0, dedup = 0, next_round = 0;
+  bool failed = false;             // a round call returned an error (MPE_E_NOMEM, a HIP failure): the batch cannot go on; rearm / abort start afresh
   mpe::gg::Dim d{};
   mpe_gg20_nonces Z{};
   void* mem = nullptr;
@@ -843,9 +844,9 @@ static int round_enter(mpe_gg20_session* s, int round, const void* in, const voi
   return MPE_OK;
 }
 static int round_exit(mpe_gg20_session* s, int rc, const char* what) {
-  if (rc != MPE_OK) return rc;
+  if (rc != MPE_OK) { s->failed = true; return rc; }
   const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { mpe_set_error(what, e); return MPE_E_HIP; }
+  if (e != hipSuccess) { s->failed = true; mpe_set_error(what, e); return MPE_E_HIP; }
   s->next_round++;
   return MPE_OK;
 }
@@ -1293,7 +1294,8 @@ int mpe_gg20_session_rearm(mpe_gg20_session* s, const int32_t* d_keyset, const m
   if (!s || !nonces) return MPE_E_ARG;
   if (s->K->K > 1 && !d_keyset) return MPE_E_ARG;
   // a batch that is half-way through the protocol is not silently thrown away: finish it (round 8 = complete) or destroy it
-  if (s->next_round != 0 && s->next_round <= 8) { mpe_set_error_msg("gg20 session rearm: the previous batch has not completed"); return MPE_E_ARG; }
+  // — unless a round call FAILED (MPE_E_NOMEM, a HIP error: the batch cannot go on) or the caller abandoned it (mpe_gg20_session_abort)
+  if (s->next_round != 0 && s->next_round <= 8 && !s->failed) { mpe_set_error_msg("gg20 session rearm: the previous batch has not completed (finish it, or mpe_gg20_session_abort)"); return MPE_E_ARG; }
   // The caller passes FRESHLY SAMPLED values for every batch (re-using k, gamma or a Paillier randomness leaks the key share);
   // the library cannot tell fresh from stale device arrays — the arrays may legitimately be the same buffers refilled.
   hipStream_t st = (hipStream_t)stream;
@@ -1301,7 +1303,7 @@ int mpe_gg20_session_rearm(mpe_gg20_session* s, const int32_t* d_keyset, const m
   // the state region after the index tables: secrets of the previous batch do not outlive it
   const hipError_t em = hipMemsetAsync(s->kq, 0, (size_t)((char*)s->mem + s->mem_bytes - (char*)s->kq), st);
   if (em != hipSuccess) { mpe_set_error("gg20 session rearm (wipe)", em); return MPE_E_HIP; }
-  s->Z = *nonces; s->d.ks = d_keyset; s->next_round = 0; s->fault_step = 0; s->fault_mask = 0;
+  s->Z = *nonces; s->d.ks = d_keyset; s->next_round = 0; s->failed = false; s->fault_step = 0; s->fault_mask = 0;
   size_t total = c.nVI;                 // the key indices follow the (possibly different) key-set choice
   if (c.nMB > total) total = c.nMB;
   if (c.nAP > total) total = c.nAP;
@@ -1310,6 +1312,17 @@ int mpe_gg20_session_rearm(mpe_gg20_session* s, const int32_t* d_keyset, const m
   hipLaunchKernelGGL(mpe::gg::idx_kernel, dim3(mpe::blocks_for((int)total, 64)), dim3(64), 0, st, s->d, s->ix, (int)total);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("gg20 session rearm", e); return MPE_E_HIP; }
+  return MPE_OK;
+}
+
+int mpe_gg20_session_abort(mpe_gg20_session* s, void* stream) {
+  // the caller gives the running batch up (it stopped after the offline stage, a peer vanished, a round call failed): everything
+  // nonce-derived is wiped now and the object waits for mpe_gg20_session_rearm; the round entry points refuse until then
+  if (!s) return MPE_E_ARG;
+  const hipError_t em = hipMemsetAsync(s->kq, 0, (size_t)((char*)s->mem + s->mem_bytes - (char*)s->kq), (hipStream_t)stream);
+  if (em != hipSuccess) { mpe_set_error("gg20 session abort (wipe)", em); return MPE_E_HIP; }
+  s->failed = true;
+  s->next_round = 9;
   return MPE_OK;
 }
 

@@ -272,7 +272,8 @@ static int launch_pair_modexp(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Ro
 
 extern "C" {
 
-const char* mpe_version(void) { return "mpecdsa-hip 0.3.0 (gfx950)"; }
+// 0.4: mpe_prof_rec grew (sliding_frac); 0.5: sampler, pipeline, comm, keygen verdicts, session abort
+const char* mpe_version(void) { return "mpecdsa-hip 0.5.0 (gfx950)"; }
 const char* mpe_last_error(void) { return g_last_error.c_str(); }
 
 void mpe_encoding_default(mpe_encoding* e) {
@@ -453,13 +454,16 @@ int mpe_prof_collect(mpe_ctx* ctx, mpe_prof_rec* out, int max_records, int* n_ou
   int n = 0;
   std::vector<uint32_t> ctr;
   size_t ix = 0;
+  // the audit kernels that fill the counters are queued AFTER each record's end event, possibly on non-blocking streams: the
+  // counters are final only when the device is idle (profiling runs only — never on the signing path)
+  if (ctx->prof_ctr && !ctx->prof.empty()) (void)hipDeviceSynchronize();
   for (auto& ev : ctx->prof) {
     const size_t my = ix++;
     if (n >= max_records) break;
     if (hipEventSynchronize(ev.b) != hipSuccess) continue;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ev.a, ev.b) != hipSuccess) continue;
-    if (ctr.empty() && ctx->prof_ctr) {               // every event up to here has completed: the counters are final
+    if (ctr.empty() && ctx->prof_ctr) {               // the device was synchronised above: the counters are final
       ctr.resize(ctx->prof.size() < (size_t)ctx->prof_ctr_cap ? ctx->prof.size() : (size_t)ctx->prof_ctr_cap);
       if (hipMemcpy(ctr.data(), ctx->prof_ctr, ctr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) ctr.assign(ctr.size(), 0u);
     }

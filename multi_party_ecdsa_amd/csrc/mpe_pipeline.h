@@ -5,15 +5,17 @@
 //
 //   * `group` consecutive batches are coalesced into ONE pass of mpe_gg20_sign (a "super-batch"): every heavy launch carries the
 //     items of all of them, so the launches are large enough for the efficient lane layouts and fill whole passes of the chip
-//     (a 2048-bit ladder launch of 4 x 1 024 sessions is 49 152 + 16 384 items = two full passes of 32 768 resident groups);
+//     (the merged round-1 ladder launch of 4 x 1 024 sessions is 49 152 + 16 384 items = two full passes of 32 768 resident groups);
 //   * `lanes` super-batches are in flight at once, each on ONE stream of its own (no forked streams inside a lane): the
 //     latency-bound stretches of one (EC kernels, short ladders, inversions) run under the throughput-bound ladders of another.
 //     lanes <= 4 streams in total, so the runtime's default 4 hardware queues never multiplex two lanes onto one queue —
-//     no GPU_MAX_HW_QUEUES, no child process (round 4 needed 16 queues for 13.5 k signatures/s; this design measured 16.0 k at
-//     2 lanes x 4 batches and 16.9 k at 2 x 8 with the defaults: profiles/r05/superbatch_sweep.jsonl);
-//   * ONE host thread feeds everything: submit() only enqueues and returns a ticket.  The inputs of a group — the caller's arrays
-//     copied, or every value drawn by the device-side sampler (mpe_sample.h) — are staged on ONE more stream into the lane's
-//     double-buffered staging arrays while the lane still runs its previous pass, so a lane never waits for its inputs.
+//     no GPU_MAX_HW_QUEUES, no child process (round 4 needed 16 queues and 8 host threads for 13.5 k signatures/s;
+//     profiles/r05/pipeline_sweep.jsonl has this design's numbers);
+//   * ONE host thread feeds everything: submit() only enqueues — the caller's arrays are copied into the lane's staging arrays
+//     behind the lane's running pass, or (submit_seeded) nothing is copied at all: the values of ALL batches of a group are drawn
+//     by ONE launch of the device-side sampler (mpe_sample.h) right before the pass.  (Staging the inputs on a stream of their own
+//     was built and measured: the sampler's small kernels starve behind the other lane's persistent ladders and the lanes wait for
+//     them — 14.8 k against 15.8 k signatures/s; dropped.)
 // Results are bit-identical to mpe_gg20_sign on the same inputs: a session's outputs do not depend on its neighbours in a batch.
 // Included by mpe_lib.hip after mpe_sample.h.
 #pragma once
@@ -28,25 +30,21 @@ struct mpe_gg20_pipeline {
   struct Lane {
     mpe_ctx* ctx = nullptr;
     hipStream_t st = nullptr;
-    mpe_gg20_nonce_buf* stage[2] = {nullptr, nullptr};   // [group * batch] sessions, every signer local; the open group fills stage[which]
-    int32_t* keyset[2] = {nullptr, nullptr};
-    hipEvent_t buf_free[2] = {nullptr, nullptr};         // the pass that read stage[b] is over (and the buffer is wiped)
-    bool buf_used[2] = {false, false};
-    int which = 0;
-    void* blob = nullptr;                     // keyset x2 | r | s | R | recid | status | fail staging
+    mpe_gg20_nonce_buf* stage = nullptr;      // [group * batch] sessions, every signer local
+    int32_t* keyset = nullptr;
+    void* blob = nullptr;                     // keyset | r | s | R | recid | status | fail staging
     size_t blob_bytes = 0;
     Out res{};
     int32_t* fail = nullptr;
-    int filled = 0;
+    int filled = 0, seeded = 0;               // seeded: slots of the open group whose values the sampler draws (all or none)
     bool any_keyset = false;
+    uint8_t seeds[32 * mpe::smp::MAX_SLOTS];
+    uint64_t counters[mpe::smp::MAX_SLOTS];
     Out dst[MAX_GROUP];
     uint64_t ticket[MAX_GROUP];
   } lane[MAX_LANES];
   struct Ticket { uint64_t id = 0, begin_of = 0; hipEvent_t submitted = nullptr, begin = nullptr, done = nullptr; int lane = -1; bool launched = false, used = false; };
   Ticket ring[RING];
-  mpe_ctx* sctx = nullptr;                    // the staging stream's own context (the sampler's workspace)
-  hipStream_t ss = nullptr;                   // inputs of every lane are staged here
-  hipEvent_t staged = nullptr;
   int cur = 0;
   uint64_t next_ticket = 1;
   uint64_t launched_groups = 0;
@@ -65,15 +63,19 @@ static mpe_gg20_pipeline::Ticket* ticket_of(mpe_gg20_pipeline* p, uint64_t id) {
 static int launch_group(mpe_gg20_pipeline* p, int li) {
   mpe_gg20_pipeline::Lane& L = p->lane[li];
   if (L.filled == 0) return MPE_OK;
-  const int B = L.filled * p->batch, w = L.which;
+  const int B = L.filled * p->batch;
   mpe_gg20_nonces Z;
-  (void)mpe_gg20_nonces_view(L.stage[w], &Z);
-  // the pass starts when its inputs are staged
-  (void)hipEventRecord(p->staged, p->ss);
-  (void)hipStreamWaitEvent(L.st, p->staged, 0);
+  (void)mpe_gg20_nonces_view(L.stage, &Z);
+  const int32_t* ks = (p->K->K > 1 || L.any_keyset) ? L.keyset : nullptr;
   if (mpe_gg20_pipeline::Ticket* t0 = ticket_of(p, L.ticket[0])) (void)hipEventRecord(t0->begin, L.st);
-  int rc = mpe_gg20_sign(L.ctx, p->K, B, (p->K->K > 1 || L.any_keyset) ? L.keyset[w] : nullptr, &Z, L.res.r, L.res.s, L.res.recid, L.res.R, L.res.status,
-                         p->dedup, 0, L.st);
+  int rc = MPE_OK;
+  if (L.seeded) {                               // every value of every batch of the group: one launch of the sampler
+    int32_t local[8];
+    for (int i = 0; i < p->K->S; ++i) local[i] = i;
+    rc = mpe::smp::sample_gg20(L.ctx, p->K, p->batch, L.filled, p->K->S, local, ks, L.seeds, L.counters, &Z, L.fail, L.st);
+  }
+  if (rc == MPE_OK)
+    rc = mpe_gg20_sign(L.ctx, p->K, B, ks, &Z, L.res.r, L.res.s, L.res.recid, L.res.R, L.res.status, p->dedup, 0, L.st);
   for (int g = 0; g < L.filled; ++g) {
     const size_t o = (size_t)g * p->batch, nb = (size_t)p->batch;
     const mpe_gg20_pipeline::Out& d = L.dst[g];
@@ -86,10 +88,7 @@ static int launch_group(mpe_gg20_pipeline* p, int li) {
     }
   }
   // the staged nonces (k_i, gamma_i, Paillier randomness) and signatures of this group do not wait for the next one to overwrite them
-  (void)hipMemsetAsync(L.stage[w]->blob, 0, L.stage[w]->bytes, L.st);
-  (void)hipEventRecord(L.buf_free[w], L.st);
-  L.buf_used[w] = true;
-  L.which = w ^ 1;
+  (void)hipMemsetAsync(L.stage->blob, 0, L.stage->bytes, L.st);
   mpe_gg20_pipeline::Ticket* t0 = ticket_of(p, L.ticket[0]);
   for (int g = 0; g < L.filled; ++g) {
     mpe_gg20_pipeline::Ticket* t = ticket_of(p, L.ticket[g]);
@@ -99,6 +98,7 @@ static int launch_group(mpe_gg20_pipeline* p, int li) {
     t->launched = true;
   }
   L.filled = 0;
+  L.seeded = 0;
   L.any_keyset = false;
   p->launched_groups++;
   p->cur = (li + 1) % p->lanes;
@@ -128,11 +128,9 @@ static int open_slot(mpe_gg20_pipeline* p, uint32_t* d_r, uint32_t* d_s, int32_t
   mpe_gg20_pipeline::Lane& L = p->lane[li];
   const int g = L.filled;
   t->id = id; t->begin_of = id; t->lane = li; t->launched = false; t->used = true;
-  // the staging stream reads the caller's arrays only after the caller's stream has produced them ...
+  // the lane reads the caller's arrays only after the caller's stream has produced them
   (void)hipEventRecord(t->submitted, caller);
-  (void)hipStreamWaitEvent(p->ss, t->submitted, 0);
-  // ... and writes a staging buffer only after the pass that last read it is over
-  if (g == 0 && L.buf_used[L.which]) (void)hipStreamWaitEvent(p->ss, L.buf_free[L.which], 0);
+  (void)hipStreamWaitEvent(L.st, t->submitted, 0);
   L.dst[g] = mpe_gg20_pipeline::Out{d_r, d_s, d_R, d_recid, d_status};
   L.ticket[g] = id;
   p->next_ticket++;
@@ -142,8 +140,8 @@ static int open_slot(mpe_gg20_pipeline* p, uint32_t* d_r, uint32_t* d_s, int32_t
 static int close_slot(mpe_gg20_pipeline* p, int li, const int32_t* d_keyset) {
   mpe_gg20_pipeline::Lane& L = p->lane[li];
   const size_t o = (size_t)L.filled * p->batch;
-  if (d_keyset) { (void)hipMemcpyAsync(L.keyset[L.which] + o, d_keyset, (size_t)p->batch * 4, hipMemcpyDeviceToDevice, p->ss); L.any_keyset = true; }
-  else (void)hipMemsetAsync(L.keyset[L.which] + o, 0, (size_t)p->batch * 4, p->ss);
+  if (d_keyset) { (void)hipMemcpyAsync(L.keyset + o, d_keyset, (size_t)p->batch * 4, hipMemcpyDeviceToDevice, L.st); L.any_keyset = true; }
+  else (void)hipMemsetAsync(L.keyset + o, 0, (size_t)p->batch * 4, L.st);
   L.filled++;
   if (L.filled == p->group) return launch_group(p, li);
   return MPE_OK;
@@ -177,28 +175,17 @@ int mpe_gg20_pipeline_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch,
     c->xwide_div = ctx->xwide_div; c->merge_xn = ctx->merge_xn; c->merge_r1 = ctx->merge_r1; c->enc = ctx->enc;
     c->allow_par = false;
     if (hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking) != hipSuccess) { mpe_set_error_msg("gg20 pipeline: hipStreamCreate"); rc = MPE_E_HIP; break; }
-    for (int b = 0; b < 2 && rc == MPE_OK; ++b) {
-      rc = mpe_gg20_nonces_alloc(c, keys, (int)GB, keys->S, &L.stage[b]);
-      if (rc == MPE_OK && hipEventCreateWithFlags(&L.buf_free[b], hipEventDisableTiming) != hipSuccess) { mpe_set_error_msg("gg20 pipeline: hipEventCreate"); rc = MPE_E_HIP; }
-    }
+    rc = mpe_gg20_nonces_alloc(c, keys, (int)GB, keys->S, &L.stage);
     if (rc != MPE_OK) break;
-    const size_t words = GB * (2 + 8 + 8 + 16 + 1 + 1) + 64;
+    const size_t words = GB * (1 + 8 + 8 + 16 + 1 + 1) + 64;
     L.blob_bytes = words * 4;
     if (hipMalloc(&L.blob, L.blob_bytes) != hipSuccess) { mpe_set_error_msg("gg20 pipeline: hipMalloc(staging)"); rc = MPE_E_NOMEM; break; }
     (void)hipMemset(L.blob, 0, L.blob_bytes);
     uint32_t* w = (uint32_t*)L.blob;
-    L.keyset[0] = (int32_t*)w; w += GB; L.keyset[1] = (int32_t*)w; w += GB;
+    L.keyset = (int32_t*)w; w += GB;
     L.res.r = w; w += GB * 8; L.res.s = w; w += GB * 8; L.res.R = w; w += GB * 16;
     L.res.recid = (int32_t*)w; w += GB; L.res.status = (int32_t*)w; w += GB;
     L.fail = (int32_t*)w;
-  }
-  if (rc == MPE_OK) rc = mpe_ctx_create(&p->sctx, ctx->device);
-  if (rc == MPE_OK) {
-    p->sctx->enc = ctx->enc; p->sctx->allow_par = false;
-    if (hipStreamCreateWithFlags(&p->ss, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->staged, hipEventDisableTiming) != hipSuccess) {
-      mpe_set_error_msg("gg20 pipeline: staging stream");
-      rc = MPE_E_HIP;
-    }
   }
   if (rc != MPE_OK) { mpe_gg20_pipeline_destroy(p); return rc; }
   *out = p;
@@ -207,19 +194,15 @@ int mpe_gg20_pipeline_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch,
 
 int mpe_gg20_pipeline_destroy(mpe_gg20_pipeline* p) {
   if (!p) return MPE_E_ARG;
-  if (p->ss) (void)hipStreamSynchronize(p->ss);
   for (int li = 0; li < p->lanes; ++li) {
     mpe_gg20_pipeline::Lane& L = p->lane[li];
     if (L.st) (void)hipStreamSynchronize(L.st);
-    for (int b = 0; b < 2; ++b) { if (L.stage[b]) (void)mpe_gg20_nonces_free(L.stage[b]); if (L.buf_free[b]) (void)hipEventDestroy(L.buf_free[b]); }
+    if (L.stage) (void)mpe_gg20_nonces_free(L.stage);
     if (L.blob) { (void)hipMemset(L.blob, 0, L.blob_bytes); (void)hipFree(L.blob); }
     if (L.ctx) (void)mpe_ctx_destroy(L.ctx);
     if (L.st) (void)hipStreamDestroy(L.st);
   }
   for (auto& t : p->ring) { if (t.submitted) (void)hipEventDestroy(t.submitted); if (t.begin) (void)hipEventDestroy(t.begin); if (t.done) (void)hipEventDestroy(t.done); }
-  if (p->sctx) (void)mpe_ctx_destroy(p->sctx);
-  if (p->ss) (void)hipStreamDestroy(p->ss);
-  if (p->staged) (void)hipEventDestroy(p->staged);
   delete p;
   return MPE_OK;
 }
@@ -231,14 +214,15 @@ int mpe_gg20_pipeline_submit(mpe_gg20_pipeline* p, const int32_t* d_keyset, cons
   int li = 0, g = 0;
   MPE_TRY(mpe::pipe::open_slot(p, d_r, d_s, d_recid, d_R, d_status, (hipStream_t)stream, &li, &g, ticket));
   mpe_gg20_pipeline::Lane& L = p->lane[li];
+  if (L.seeded) { mpe_set_error_msg("gg20 pipeline: a group holds seeded or caller-sampled batches, not both (flush between the two forms)"); return MPE_E_ARG; }
   mpe_gg20_nonces src = *nonces;
   for (int f = 0; f < mpe::smp::NF; ++f) {
-    mpe_gg20_nonce_buf* sb = L.stage[L.which];
+    mpe_gg20_nonce_buf* sb = L.stage;
     const size_t w = sb->per_session[f] * (size_t)p->batch;
     const uint32_t* from = *mpe::smp::nonce_field_ptr(&src, f);
     uint32_t* to = const_cast<uint32_t*>(*mpe::smp::nonce_field_ptr(&sb->view, f)) + (size_t)g * w;
     if (!from) { mpe_set_error_msg("gg20 pipeline: a nonce array is NULL"); return MPE_E_ARG; }
-    (void)hipMemcpyAsync(to, from, w * 4, hipMemcpyDeviceToDevice, p->ss);
+    (void)hipMemcpyAsync(to, from, w * 4, hipMemcpyDeviceToDevice, L.st);
   }
   return mpe::pipe::close_slot(p, li, d_keyset);
 }
@@ -246,17 +230,16 @@ int mpe_gg20_pipeline_submit(mpe_gg20_pipeline* p, const int32_t* d_keyset, cons
 int mpe_gg20_pipeline_submit_seeded(mpe_gg20_pipeline* p, const int32_t* d_keyset, const uint8_t* h_seed32, uint64_t batch_counter, const uint32_t* d_msg,
                                     uint32_t* d_r, uint32_t* d_s, int32_t* d_recid, uint32_t* d_R, int32_t* d_status, void* stream, uint64_t* ticket) {
   if (!p || !h_seed32 || !d_msg || (batch_counter >> 56) != 0) return MPE_E_ARG;
+  if (p->group > mpe::smp::MAX_SLOTS) { mpe_set_error_msg("gg20 pipeline: seeded submission needs group <= 16 (one sampler launch per group)"); return MPE_E_ARG; }
   if (p->K->K > 1 && !d_keyset) return MPE_E_ARG;
   int li = 0, g = 0;
   MPE_TRY(mpe::pipe::open_slot(p, d_r, d_s, d_recid, d_R, d_status, (hipStream_t)stream, &li, &g, ticket));
   mpe_gg20_pipeline::Lane& L = p->lane[li];
-  mpe_gg20_nonce_buf* sb = L.stage[L.which];
-  mpe_gg20_nonces dst = sb->view;
-  for (int f = 0; f < mpe::smp::NF; ++f) *mpe::smp::nonce_field_ptr(&dst, f) += (size_t)g * sb->per_session[f] * (size_t)p->batch;
-  (void)hipMemcpyAsync(const_cast<uint32_t*>(dst.msg), d_msg, (size_t)p->batch * 32, hipMemcpyDeviceToDevice, p->ss);
-  int32_t local[8];
-  for (int i = 0; i < p->K->S; ++i) local[i] = i;
-  MPE_TRY(mpe::smp::sample_gg20(p->sctx, p->K, p->batch, p->K->S, local, d_keyset, h_seed32, batch_counter, &dst, L.fail, p->ss));
+  if (L.filled != L.seeded) { mpe_set_error_msg("gg20 pipeline: a group holds seeded or caller-sampled batches, not both (flush between the two forms)"); return MPE_E_ARG; }
+  (void)hipMemcpyAsync(const_cast<uint32_t*>(L.stage->view.msg) + (size_t)g * p->batch * 8, d_msg, (size_t)p->batch * 32, hipMemcpyDeviceToDevice, L.st);
+  memcpy(L.seeds + 32 * g, h_seed32, 32);
+  L.counters[g] = batch_counter;
+  L.seeded++;
   return mpe::pipe::close_slot(p, li, d_keyset);
 }
 
@@ -325,7 +308,6 @@ int mpe_gg20_pipeline_sampler_failures(mpe_gg20_pipeline* p, int32_t* h_out) {
   int32_t tot = 0;
   for (int li = 0; li < p->lanes; ++li) {
     int32_t v = 0;
-    (void)hipStreamSynchronize(p->ss);
     (void)hipStreamSynchronize(p->lane[li].st);
     if (hipMemcpy(&v, p->lane[li].fail, 4, hipMemcpyDeviceToHost) != hipSuccess) return MPE_E_HIP;
     tot += v;

@@ -153,20 +153,27 @@ __global__ void __launch_bounds__(64) sample_kernel(int batch, Seed key, uint32_
   draw_item<COPRIME_W>(s, bd, bound_words, bits, flags, out + (size_t)i * out_words, out_words, fail);
 }
 
-// every field of a batch's sampled values in ONE launch: thread g -> (field, item); field f of batch `counter` is stream counter | f << 56
-struct FieldDesc { uint32_t* out; const uint32_t* bound; const int32_t* idx; int bound_words, out_words, bits, flags, field; };
+// every field of the sampled values of `nslots` consecutive batches in ONE launch: thread g -> (field, row); a field's rows are
+// slot-major (slot = row / rows-per-batch), and slot k draws from ITS batch's (seed, counter): field f of that batch is stream
+// counter | f << 56, item = the row index inside the batch.  One slot = mpe_gg20_sample_nonces; several = the pipelined engine's groups.
+constexpr int MAX_SLOTS = 16;
+struct FieldDesc { uint32_t* out; const uint32_t* bound; const int32_t* idx; unsigned per_slot; int bound_words, out_words, bits, flags, field; };
 struct FieldTable { FieldDesc f[NF]; unsigned start[NF + 1]; int n; };
-__global__ void __launch_bounds__(64) sample_fields_kernel(FieldTable t, Seed key, uint32_t ctr_lo, uint32_t ctr_hi, int32_t* __restrict__ fail) {
+struct SlotTable { Seed key[MAX_SLOTS]; uint32_t ctr_lo[MAX_SLOTS], ctr_hi[MAX_SLOTS]; };
+__global__ void __launch_bounds__(64) sample_fields_kernel(FieldTable t, SlotTable sl, int32_t* __restrict__ fail) {
   __shared__ uint32_t ks[64][17];
+  __shared__ SlotTable slots;                                // the per-slot keys are indexed per lane: LDS, not kernel-argument SGPRs
+  for (unsigned w = threadIdx.x; w < sizeof(SlotTable) / 4; w += 64) ((uint32_t*)&slots)[w] = ((const uint32_t*)&sl)[w];
+  __syncthreads();
   const unsigned g = blockIdx.x * 64 + threadIdx.x;
   if (g >= t.start[t.n]) return;
   int f = 0;
   while (g >= t.start[f + 1]) ++f;
   const FieldDesc& d = t.f[f];
-  const unsigned i = g - t.start[f];
-  Stream s{&key, i, ctr_lo, ctr_hi | ((uint32_t)d.field << 24), ks[threadIdx.x], 0xffffffffu, 0ull};
-  const uint32_t* bd = d.bound ? d.bound + (size_t)(d.idx ? d.idx[i] : 0) * d.bound_words : nullptr;
-  draw_item<0>(s, bd, d.bound_words, d.bits, d.flags, d.out + (size_t)i * d.out_words, d.out_words, fail);
+  const unsigned row = g - t.start[f], slot = row / d.per_slot, i = row % d.per_slot;
+  Stream s{&slots.key[slot], i, slots.ctr_lo[slot], slots.ctr_hi[slot] | ((uint32_t)d.field << 24), ks[threadIdx.x], 0xffffffffu, 0ull};
+  const uint32_t* bd = d.bound ? d.bound + (size_t)(d.idx ? d.idx[row] : 0) * d.bound_words : nullptr;
+  draw_item<0>(s, bd, d.bound_words, d.bits, d.flags, d.out + (size_t)row * d.out_words, d.out_words, fail);
 }
 
 static Seed seed_of(const uint8_t* h) {
@@ -237,11 +244,14 @@ struct mpe_gg20_nonce_buf {
 namespace mpe {
 namespace smp {
 
-static int sample_gg20(mpe_ctx* ctx, const mpe_gg20_keys* K, int batch, int n_local, const int32_t* h_local, const int32_t* d_keyset, const uint8_t* h_seed,
-                       uint64_t counter, const mpe_gg20_nonces* out, int32_t* d_fail, hipStream_t st) {
-  if (!ctx || !K || !h_local || !h_seed || !out || batch < 0 || n_local < 1 || n_local > K->S || (counter >> 56) != 0) return MPE_E_ARG;
+// `nslots` consecutive batches of `per_batch` sessions each (arrays slot-major), slot k drawn from (h_seeds + 32 k, h_counters[k])
+static int sample_gg20(mpe_ctx* ctx, const mpe_gg20_keys* K, int per_batch, int nslots, int n_local, const int32_t* h_local, const int32_t* d_keyset,
+                       const uint8_t* h_seeds, const uint64_t* h_counters, const mpe_gg20_nonces* out, int32_t* d_fail, hipStream_t st) {
+  if (!ctx || !K || !h_local || !h_seeds || !h_counters || !out || per_batch < 0 || nslots < 1 || nslots > MAX_SLOTS || n_local < 1 || n_local > K->S) return MPE_E_ARG;
+  for (int k = 0; k < nslots; ++k) if ((h_counters[k] >> 56) != 0) return MPE_E_ARG;
   if (K->K > 1 && !d_keyset) return MPE_E_ARG;
-  if (batch == 0) return MPE_OK;
+  if (per_batch == 0) return MPE_OK;
+  const int batch = per_batch * nslots;
   gg::Dim d{};
   d.B = batch; d.S = K->S; d.n = K->n; d.L = n_local; d.K = K->K; d.n_own = K->n_own; d.ks = d_keyset;
   for (int i = 0; i < 8; ++i) { d.loc[i] = i < n_local ? h_local[i] : 0; d.sg[i] = K->signers[i]; d.oslot[i] = K->own_slot[i] < 0 ? 0 : K->own_slot[i]; }
@@ -268,7 +278,7 @@ static int sample_gg20(mpe_ctx* ctx, const mpe_gg20_keys* K, int batch, int n_lo
   FieldTable t{};
   t.n = 0; t.start[0] = 0;
   auto add = [&](int f, const uint32_t* dst, size_t items, const uint32_t* bound, int bw, const int32_t* idx, int ow, int flags, int bits = 0) {
-    t.f[t.n] = FieldDesc{U(dst), bound, idx, bw, ow, bits, flags, f};
+    t.f[t.n] = FieldDesc{U(dst), bound, idx, (unsigned)(items / nslots), bw, ow, bits, flags, f};
     t.start[t.n + 1] = t.start[t.n] + (unsigned)items;
     t.n++;
   };
@@ -295,11 +305,16 @@ static int sample_gg20(mpe_ctx* ctx, const mpe_gg20_keys* K, int batch, int n_lo
   scalar(19, out->heg_s1, nPI);                                                                // HomoELGamalProof::prove (:778-799)
   scalar(20, out->heg_s2, nPI);
   if ((size_t)t.start[t.n] != 9 * nPI + 4 * nAP + 4 * nMB + 4 * nPP) { mpe_set_error_msg("gg20 sampler: more than 2^32 items in one batch"); return MPE_E_ARG; }          // a batch beyond 2^32 items
-  hipLaunchKernelGGL(sample_fields_kernel, dim3((t.start[t.n] + 63) / 64), dim3(64), 0, st, t, seed_of(h_seed), (uint32_t)counter, (uint32_t)(counter >> 32), d_fail);
+  SlotTable sl{};
+  for (int k = 0; k < nslots; ++k) { sl.key[k] = seed_of(h_seeds + 32 * k); sl.ctr_lo[k] = (uint32_t)h_counters[k]; sl.ctr_hi[k] = (uint32_t)(h_counters[k] >> 32); }
+  hipLaunchKernelGGL(sample_fields_kernel, dim3((t.start[t.n] + 63) / 64), dim3(64), 0, st, t, sl, d_fail);
   {  // from_modulo: gcd(r, N) == 1 as ONE batched verdict for all items (Montgomery's trick, mpe_modinv.h); whoever fails it — 2^-1023
      // per draw for an honest key — is redrawn by the lane-serial loop, which replays the item's stream with the gcd inside the loop
     MPE_TRY(launch_modinv(ctx, msn, (int)nAP, key_selector(K->pub, x.own_ap), rows(out->al_beta, 64), inv, ok, st));
-    MPE_TRY(launch_sample((int)nAP, h_seed, counter | ((uint64_t)5 << 56), 0, N, 64, x.own_ap, nk, F_COPRIME, 64, U(out->al_beta), d_fail, st, ok));
+    const size_t per = nAP / nslots;              // the redraw pass runs slot by slot: every slot has its own stream
+    for (int k = 0; k < nslots; ++k)
+      MPE_TRY(launch_sample((int)per, h_seeds + 32 * k, h_counters[k] | ((uint64_t)5 << 56), 0, N, 64, x.own_ap + k * per, nk, F_COPRIME, 64,
+                            U(out->al_beta) + k * per * 64, d_fail, st, ok + k * per));
   }
   // the verdict array and the discarded inverses are derived from secret values
   (void)hipMemsetAsync(inv, 0, nAP * 64 * 4, st);
@@ -360,7 +375,7 @@ int mpe_gg20_nonces_free(mpe_gg20_nonce_buf* nb) {
 }
 int mpe_gg20_sample_nonces(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, int n_local, const int32_t* h_local, const int32_t* d_keyset,
                            const uint8_t* h_seed32, uint64_t batch_counter, const mpe_gg20_nonces* out, int32_t* d_fail, void* stream) {
-  return mpe::smp::sample_gg20(ctx, keys, batch, n_local, h_local, d_keyset, h_seed32, batch_counter, out, d_fail, (hipStream_t)stream);
+  return mpe::smp::sample_gg20(ctx, keys, batch, 1, n_local, h_local, d_keyset, h_seed32, &batch_counter, out, d_fail, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -487,6 +487,10 @@ class Gg20Session:
         nn = _struct(N_.Gg20Nonces, self._nonces)
         N_.check(N_.lib.mpe_gg20_session_rearm(self.h, _ptr(keyset), C.byref(nn), self.ctx.stream()), "mpe_gg20_session_rearm")
 
+    def abort(self):
+        """mpe_gg20_session_abort: give the running batch up (state wiped now); rearm() starts the next one"""
+        N_.check(N_.lib.mpe_gg20_session_abort(self.h, self.ctx.stream()), "mpe_gg20_session_abort")
+
     def round(self, rnd, d_in=None, in_off=None, msg=None, out=None):
         """Runs round `rnd` (0..7, 8 = SignManual::complete).  d_in: the previous round's records of all S senders (device
         int32 tensor; sender j's [B][W] block at record in_off[j], default j*B).  Returns this object's outgoing records

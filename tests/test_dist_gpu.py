@@ -84,7 +84,15 @@ def _worker(rank, world, port, t, n, signers, B, placement, q, backend="gloo", r
             def rearm(self):
                 self.sess.rearm(self.keep)      # the same sampled values again: a test of the buffers, never a deployment pattern
 
-        ps = D.PartySharded(S, Bblk, lambda rnd: E.gg20_msg_words(S, n, rnd), Eng, ctx.device, placement=placement)
+        comm = None
+        if backend == "nccl":                   # the fan-out behind the C-ABI: rank 0's RCCL id travels through the process group
+
+            def exchange(ident):
+                box = [ident]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            comm = E.Comm(ctx, rank, world, exchange_id=exchange)
+        ps = D.PartySharded(S, Bblk, lambda rnd: E.gg20_msg_words(S, n, rnd), Eng, ctx.device, placement=placement, comm=comm)
         selftest = ps.layout_self_test() if backend == "nccl" else None
         msgs = {s: _dev(ctx, block_nonces(s)["msg"]) for s in ps.engines}
         res = ps.run(msgs)
@@ -178,13 +186,66 @@ def test_party_sharded_over_rccl_on_distinct_devices(world, t, n, signers, B, pl
     blocks = world if placement == "rotated" else 1
     Bblk = B // blocks
     for rank, hosted, out, nbytes, selftest in res:
-        assert selftest["ok"] is True and selftest["mode"] in ("inplace", "outofplace", "staged"), selftest
+        assert selftest["ok"] is True and selftest["mode"] in ("native:inplace", "native:copy"), selftest
         for s, parties in hosted.items():
             sl = slice(s * Bblk, (s + 1) * Bblk)
             for li, p in enumerate(parties):
                 assert out[s]["status"][li] == [0] * Bblk
                 assert np.array_equal(np.array(out[s]["r"][li], dtype=np.uint32), want["r"][sl])
                 assert np.array_equal(np.array(out[s]["s"][li], dtype=np.uint32), want["s"][sl])
+
+
+def test_party_sharded_through_the_c_abi_communicator_world1(gpu_ctx, keys):
+    """dist.PartySharded with comm=engine.Comm: every all-gather of run() is mpe_comm_all_gather (ncclAllGather behind the C-ABI) on a
+    real RCCL communicator of one rank — both parties of every session on this GPU (colocate), slabs read in place through
+    mpe_gg20_shard_in_off's offsets; signatures equal the oracle's.  The same call path the driver's N-GPU run takes."""
+    from multi_party_ecdsa_amd import dist as D
+    from multi_party_ecdsa_amd import engine as E
+    ctx = gpu_ctx
+    t, n, signers, B = 1, 3, [0, 2], 5
+    S = len(signers)
+    lk = G.make_local_keys(keys, t, n, signers)
+    nonces = G.make_nonces(lk, B, seed="native-comm-w1")
+    comm = E.Comm(ctx, 0, 1)
+    assert comm.layout_self_test(S) == dict(mode="inplace", ok=True) or comm.layout_self_test(S)["ok"]
+    made = []
+
+    class Eng:
+        writes_in_place = True
+
+        def __init__(self, s, parties):
+            self.gk = E.Gg20Keys(ctx, t, n, signers, lk["arrays"], own=[signers[p] for p in parties])
+            mine = {}
+            for f, v in nonces.items():
+                if f == "msg":
+                    mine[f] = v
+                else:
+                    per = v.shape[0] // (B * S)
+                    mine[f] = np.ascontiguousarray(v.reshape(B, S, per, v.shape[1])[:, parties].reshape(-1, v.shape[1]))
+            self.keep = {f: _dev(ctx, v) for f, v in mine.items()}
+            self.sess = E.Gg20Session(ctx, self.gk, B, parties, self.keep)
+            made.append(self)
+
+        def round(self, rnd, d_in, in_off, msg, out=None):
+            return self.sess.round(rnd, d_in=d_in, in_off=in_off, msg=msg, out=out)
+
+        def result(self):
+            return self.sess.result()
+    ps = D.PartySharded(S, B, lambda rnd: E.gg20_msg_words(S, n, rnd), Eng, ctx.device, placement="rotated", rank=0, world=1, colocate=True, comm=comm)
+    assert ps.gather_mode == "native" and ps.layout_self_test()["ok"]
+    assert ps.in_off(0) == E.shard_in_off(E.PLACE_ROTATED, S, 1, B, 0) == [0, B]
+    res = ps.run({0: _dev(ctx, nonces["msg"])})
+    ctx.sync()
+    want = G.oracle_sign_ex(lk, nonces, B)
+    parties, _ = ps.engines[0]
+    for li, p in enumerate(parties):
+        assert not res[0]["status"][li].cpu().numpy().any()
+        assert np.array_equal(_u32(res[0]["r"][li]), want["r"]) and np.array_equal(_u32(res[0]["s"][li]), want["s"])
+    assert set(ps.bytes_per_round) == {0, 1, 2, 3, 4, 5, 7}
+    for e in made:
+        e.sess.close()
+        e.gk.close()
+    comm.close()
 
 
 # ---- non-default h_in_off: permuted sender blocks with garbage between them --------------------------------------------
@@ -263,6 +324,41 @@ def test_rearmed_session_equals_a_fresh_one(gpu_ctx, keys):
     assert not res["status"].cpu().numpy().any()
     for i in range(S):
         assert np.array_equal(_u32(res["r"])[i], w2["r"]) and np.array_equal(_u32(res["s"])[i], w2["s"])
+
+
+def test_an_abandoned_batch_can_be_given_up_and_the_object_reused(gpu_ctx, keys):
+    """a party that stops after the offline stage (or whose peer vanished) is not left with an object it can only destroy:
+    a half-run batch refuses mpe_gg20_session_rearm, mpe_gg20_session_abort wipes it, the next batch equals a fresh session's"""
+    from multi_party_ecdsa_amd import engine as E
+    t, n, signers, B = 1, 3, [0, 1], 2
+    lk = G.make_local_keys(keys, t, n, signers)
+    S = len(signers)
+    gk = E.Gg20Keys(gpu_ctx, t, n, signers, lk["arrays"])
+    n1, n2 = G.make_nonces(lk, B, seed="abort-1"), G.make_nonces(lk, B, seed="abort-2")
+    w2 = G.oracle_sign_ex(lk, n2, B)
+    sess = E.Gg20Session(gpu_ctx, gk, B, list(range(S)), {f: _dev(gpu_ctx, v) for f, v in n1.items()})
+    prev = None
+    for rnd in range(3):                                              # rounds 0..2 only
+        prev = sess.round(rnd, d_in=prev).reshape(-1)
+    keep2 = {f: _dev(gpu_ctx, v) for f, v in n2.items()}
+    with pytest.raises(E.N_.MpeError):
+        sess.rearm(keep2)                                             # half-way through and healthy: refused
+    sess.abort()
+    with pytest.raises(E.N_.MpeError):
+        sess.round(3, d_in=prev)                                      # the abandoned batch cannot go on
+    sess.rearm(keep2)
+    prev = None
+    for rnd in range(9):
+        out = sess.round(rnd, d_in=prev, msg=_dev(gpu_ctx, n2["msg"]) if rnd == 7 else None)
+        if out is not None:
+            prev = out.reshape(-1)
+    res = sess.result()
+    gpu_ctx.sync()
+    assert not res["status"].cpu().numpy().any()
+    for i in range(S):
+        assert np.array_equal(_u32(res["r"])[i], w2["r"]) and np.array_equal(_u32(res["s"])[i], w2["s"])
+    sess.close()
+    gk.close()
 
 
 # ---- bench.py --gpus N spawns its own ranks -----------------------------------------------------------------------------
