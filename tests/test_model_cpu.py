@@ -53,3 +53,17 @@ def test_sliding_window_schedule_of_the_public_exponent():
     val, sq, mul = sm.ladder(3, e, (1 << 2048) - 159, 6, 64)
     assert val == pow(3, e, (1 << 2048) - 159)
     assert 2040 <= sq <= 2049 and 31 + 270 <= mul <= 31 + 315         # vs 2046 squarings + 62 + 342 multiplications on fixed windows
+
+
+def test_karatsuba_on_the_product_halves_does_not_pay_in_this_lane_layout():
+    """round-4 review item 3a: price one level of Karatsuba on the product halves of pass A / pass B with the real lane layout and build
+    it only if the model says >= 6 %.  tools/model/karatsuba_model.py: the 306 MACs per lane it saves are spent on re-laying the halves
+    out over the four lanes, re-normalising the 30-bit sums (the middle product would overflow the 64-bit columns), combining 64-bit
+    columns with carry pairs and folding the held product into the reduction — and the held product needs 36 more VGPRs at 255 of 256."""
+    km = _load("karatsuba_model")
+    p = km.price()
+    assert abs(p["today"]["total"] - 71 * 740 / 18) < 1e-6                      # the measured loop body: 740 VALU per 18 steps
+    assert p["karatsuba_relayout"]["product_mac"] == 3 * 36 * 9 < 71 * 18       # the product half does get cheaper ...
+    assert p["pass_gain"] < 0.06 and p["squaring_gain"] < 0.06                  # ... the pass does not: below the bar (in fact a loss)
+    assert p["pass_gain_no_relayout"] < p["pass_gain"]                          # leaving two lanes idle is worse still
+    assert p["karatsuba_relayout"]["vgpr_columns_held"] - 2 * km.L == 36
