@@ -588,7 +588,7 @@ def gg20_config(ctx, E, G, keys, t, n, B, steps, gen, parity_sample=0, threads=N
     return res
 
 
-def c4_pipeline(ctx, E, G, keys, batches=96, B=1024, lanes=2, group=4, parity_sample=16, threads=None, oracle=True, verify=True):
+def c4_pipeline(ctx, E, G, keys, batches=96, B=1024, lanes=2, group=4, parity_sample=16, threads=None, oracle=True, verify=True, window=None):
     """BASELINE config 4 as a SERVICE sees it: a stream of `batches` successive 1 024-session (t=1, n=3) batches through the pipelined
     engine (mpe_gg20_pipeline_*, csrc/mpe_pipeline.h): `group` batches coalesced per lock-step pass, `lanes` passes in flight on one
     stream each, inputs staged on one more stream — ONE context handle, ONE host thread, the runtime's default hardware queues, no child
@@ -607,7 +607,7 @@ def c4_pipeline(ctx, E, G, keys, batches=96, B=1024, lanes=2, group=4, parity_sa
     gen = torch.Generator(device=dev)
     gen.manual_seed(1024)
     msgs = [rand_words(gen, dev, B, 8, 8) for _ in range(batches)]
-    window = 2 * lanes * group
+    window = window or 2 * lanes * group
     # warm-up: both staging buffers of every lane, every allocation of the lanes' workspaces
     warm = [pipe.submit_seeded(seed, (1 << 40) + i, msgs[i % batches]) for i in range(window)]
     pipe.flush()
@@ -1470,8 +1470,13 @@ def main():
                 # the same stream with twice the batches per pass: more throughput for a longer pass
                 o_ = c4_pipeline(ctx, E, G, keys, batches=args.stream_batches, lanes=args.stream_lanes, group=2 * args.stream_group,
                                  oracle=False, parity_sample=0)
-                main_["other_shapes"] = {f"{args.stream_lanes}x{2 * args.stream_group}": {k_: o_[k_] for k_ in
-                                         ("signatures_per_s", "latency_ms", "pass_ms", "all_sessions_signed", "openssl_verified", "openssl_of")}}
+                keep_ = ("signatures_per_s", "in_flight_bound", "latency_ms", "pass_ms", "all_sessions_signed", "openssl_verified", "openssl_of")
+                main_["other_shapes"] = {f"{args.stream_lanes}x{2 * args.stream_group}": {k_: o_[k_] for k_ in keep_}}
+                # ... and with only ONE group outstanding per lane: a batch never waits behind a queued pass (about half the latency),
+                # the lanes idle while the host turns a completed group around
+                l_ = c4_pipeline(ctx, E, G, keys, batches=args.stream_batches, lanes=args.stream_lanes, group=args.stream_group,
+                                 oracle=False, parity_sample=0, window=args.stream_lanes * args.stream_group)
+                main_["other_shapes"][f"{args.stream_lanes}x{args.stream_group}_one_group_outstanding_per_lane"] = {k_: l_[k_] for k_ in keep_}
                 return main_
             section("c4_stream_1024", stream_section)
             section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32,

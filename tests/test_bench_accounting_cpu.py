@@ -163,5 +163,5 @@ def test_the_stream_section_needs_no_child_process_and_no_queue_setting():
     assert not hasattr(B, "stream_child") and "--stream-child" not in src
     assert 'environ["GPU_MAX_HW_QUEUES"]' not in src and "env[\"GPU_MAX_HW_QUEUES\"]" not in src
     body = inspect.getsource(B.c4_pipeline)
-    assert "Gg20Pipeline" in body and "submit_seeded" in body and "window = 2 * lanes * group" in body
+    assert "Gg20Pipeline" in body and "submit_seeded" in body and "window = window or 2 * lanes * group" in body
     assert "oracle_sample_nonces" in body and "openssl_verify_all" in body        # every batch: OpenSSL on all, the oracle on a sample
