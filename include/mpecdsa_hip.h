@@ -62,12 +62,13 @@ int mpe_ctx_wipe(mpe_ctx* ctx, void* stream);
 /* Audit of the wiping: the number of non-zero 32-bit words in every scratch region the context owns (window tables,
  * composite workspace, cached GG20 session arena and message slabs) and their total size.  Synchronises the stream. */
 int mpe_ctx_scratch_audit(mpe_ctx* ctx, uint64_t* nonzero_words, uint64_t* total_bytes, void* stream);
-/* A signing service keeps several batches in flight — one context, one host thread and one stream each (the reference runs
- * its parties concurrently: state_machine/sign.rs:667-691, every round through spawn_blocking).  A single small batch is
- * latency-bound, so by default a context spreads each big integer of a small launch over 2x / 4x the lanes (less efficient,
- * shorter).  `contexts` = how many contexts work on this device at the same time: the small-batch heuristics then compare a
- * launch with 1/contexts of the chip and keep the efficient layouts, because the other batches fill the idle lanes.
- * Results are identical whatever the value; default 1. */
+/* A hint for callers that run SEVERAL contexts on one device at the same time (one host thread and stream each).  A single small
+ * batch is latency-bound, so by default a context spreads each big integer of a small launch over 2x / 4x the lanes (less efficient,
+ * shorter); with `contexts` > 1 the small-batch heuristics compare a launch with 1/contexts of the chip and keep the efficient
+ * layouts.  MEASURED (profiles/r04/stream_sweep*.log): the hint LOSES 7-20 % at every depth from 2 to 24 contexts — concurrent small
+ * batches are bound by how many kernels run side by side, and the wide layouts fill the chip with fewer of them.  It is kept for
+ * experiments only (results are identical whatever the value; default 1).  The supported way to serve a stream of small batches is
+ * mpe_gg20_pipeline_* below: one handle, one host thread, batches coalesced per pass. */
 int mpe_ctx_set_device_share(mpe_ctx* ctx, int contexts);
 /* Blocks the host until everything queued on `stream` has finished (hipStreamSynchronize). */
 int mpe_sync(mpe_ctx* ctx, void* stream);

@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(64) fb_modexp_kernel(int batch, ModsetView ms,
   const int nwin = (exp_words * 32 + FB_WB - 1) / FB_WB;
 #pragma unroll 1
   for (int trip = 0; trip < trips; ++trip) {
+    if (trip * nslots + (int)blockIdx.x * C::GROUPS >= batch) break;       // no item left for this wave (wave-uniform)
     const int inst = trip * nslots + slot;
     const bool active = inst < batch;
     const int idx = active ? inst : batch - 1;

@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Ro
 
 #pragma unroll 1
   for (int trip = 0; trip < trips; ++trip) {
+    if (trip * nslots + (int)blockIdx.x * C::GROUPS >= batch) break;       // no item left for this wave (wave-uniform)
     const int inst = trip * nslots + slot;
     const bool active = inst < batch;
     const int idx = active ? inst : batch - 1;
@@ -378,6 +379,7 @@ __global__ void __launch_bounds__(64) modmul_kernel(int batch, ModsetView ms, Ro
   const int trips = (batch + nslots - 1) / nslots;
 #pragma unroll 1
   for (int trip = 0; trip < trips; ++trip) {
+    if (trip * nslots + (int)blockIdx.x * C::GROUPS >= batch) break;       // no item left for this wave (wave-uniform)
     const int inst = trip * nslots + slot;
     const bool active = inst < batch;
     const int idx = active ? inst : batch - 1;

@@ -108,11 +108,7 @@ static ModsetView view_of(const mpe_modset* ms) {
 // grid shrinks to the smallest one that still finishes in that many trips (no half-empty tail)
 template <class C>
 static int grid_for(const mpe_ctx* ctx, int batch, int waves_per_cu) {
-  const int need = (batch + C::GROUPS - 1) / C::GROUPS;
-  const int cap = ctx->cus * waves_per_cu;
-  if (need <= cap) return need;
-  const int trips = (need + cap - 1) / cap;
-  return (need + trips - 1) / trips;
+  return persistent_grid(ctx, (batch + C::GROUPS - 1) / C::GROUPS, ctx->cus * waves_per_cu);
 }
 
 template <class C>
@@ -336,6 +332,7 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   if (const char* e = getenv("MPE_XWIDE_DIV")) { const int v = atoi(e); if (v >= 0) c->xwide_div = v; }
   if (getenv("MPE_NO_MERGE_XN")) c->merge_xn = false;
   if (getenv("MPE_NO_MERGE_R1")) c->merge_r1 = false;
+  if (getenv("MPE_GRID_EQUAL")) c->grid_full = false;
   if (const char* e = getenv("MPE_FB_BUDGET_MB")) c->fb_budget_bytes = (size_t)atoll(e) << 20;
   if (getenv("MPE_WINDOW_BITS")) { const int w = atoi(getenv("MPE_WINDOW_BITS")); if (w >= 4 && w <= 6) c->window_bits = w; }
   // comb tables of the two fixed secp256k1 generators: module globals, built ONCE per device (immutable afterwards — the only

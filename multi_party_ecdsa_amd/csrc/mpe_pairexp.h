@@ -516,6 +516,7 @@ static __global__ void pair_slide_audit_kernel(int batch, int grid, int trips, i
   const int wt = blockIdx.x * blockDim.x + threadIdx.x;
   if (wt >= grid * trips) return;
   const int wave = wt % grid, trip = wt / grid, nslots = grid * groups;
+  if (trip * nslots + wave * groups >= batch) return;           // that wave had no item left in that trip: it exited
   const uint32_t* first = nullptr;
   bool same = true;
   for (int g = 0; g < groups; ++g) {
@@ -555,6 +556,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 #pragma unroll 1
   for (int trip = 0; trip < trips; ++trip) {
+    if (trip * nslots + (int)blockIdx.x * C::GROUPS >= batch) break;       // no item left for this wave (wave-uniform): it leaves its SIMD to the others
     const int inst = trip * nslots + slot;
     const bool active = inst < batch;
     const int pos = active ? inst : batch - 1;
@@ -800,9 +802,7 @@ int pairset_create_impl(int count, const uint32_t* d_moduli, mpe_pairset** out, 
 template <class C>
 int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
                      Rows base2, Rows exps2, int exp2_words, int half, uint32_t* d_out, hipStream_t st, int public_exp) {
-  const int need_w = (batch + C::GROUPS - 1) / C::GROUPS, cap = ctx->cus * ctx->modexp_waves_per_cu;
-  int grid = need_w;
-  if (need_w > cap) { const int trips = (need_w + cap - 1) / cap; grid = (need_w + trips - 1) / trips; }
+  const int grid = persistent_grid(ctx, (batch + C::GROUPS - 1) / C::GROUPS, ctx->cus * ctx->modexp_waves_per_cu);
   int wb = exp_words <= 8 ? 4 : (exp_words < 48 ? 5 : 6);
   if (ctx->window_bits) wb = ctx->window_bits;
   const bool dual = base2.p != nullptr;
@@ -844,7 +844,7 @@ int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
     // inside the hot kernel perturbs its register allocation (measured: +0.6 % kernel time, profiles/r04/ab_kernel_variants.json),
     // so the decision is REPLAYED by a one-thread-per-(wave, trip) audit kernel with the kernel's own rule and geometry.
     const int nslots = grid * C::GROUPS, trips = (batch + nslots - 1) / nslots;
-    if (uint32_t* ctr = prof_counter(ctx, grid * trips))
+    if (uint32_t* ctr = prof_counter(ctx, (batch + C::GROUPS - 1) / C::GROUPS))       // the (wave, trip) pairs that hold at least one item
       hipLaunchKernelGGL(pair_slide_audit_kernel, dim3(blocks_for(grid * trips, 64)), dim3(64), 0, st, batch, grid, trips, (int)C::GROUPS, exps,
                          exp_words, wb, dual ? exp2_words : 0, perm, ctr);
   }

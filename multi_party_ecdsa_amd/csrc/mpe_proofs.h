@@ -38,9 +38,7 @@ static int launch_fb_modexp(mpe_ctx* ctx, const mpe_statements* stm, int B, Rows
                             uint32_t* out, hipStream_t st) {
   if (B == 0) return MPE_OK;
   using C = Cfg2048;
-  const int need = (B + C::GROUPS - 1) / C::GROUPS, cap = ctx->cus * ctx->modexp_waves_per_cu;
-  int grid = need;
-  if (need > cap) { const int trips = (need + cap - 1) / cap; grid = (need + trips - 1) / trips; }
+  const int grid = persistent_grid(ctx, (B + C::GROUPS - 1) / C::GROUPS, ctx->cus * ctx->modexp_waves_per_cu);
   ModsetView v;
   v.n_limbs = stm->ms->n_limbs; v.one_limbs = stm->ms->one_limbs; v.r2_limbs = stm->ms->r2_limbs;
   v.r2h_limbs = stm->ms->r2h_limbs; v.n0inv = stm->ms->n0inv; v.count = stm->ms->count;
