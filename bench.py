@@ -1022,6 +1022,40 @@ class PartyMode:
             e_.keys.close()
 
 
+class PostTimingWatchdog:
+    """N > 1 only.  Armed when the timed region has ended; if the collective sections after it have not finished by the deadline,
+    rank 0 prints the line of the timed region (with `post_timing_sections` saying what happened) and EVERY rank leaves with status 0
+    at the same deadline, so the launcher returns instead of waiting on ranks stuck in a collective."""
+
+    def __init__(self, rank, seconds, line_fn=None):
+        import threading
+        self.rank, self.seconds, self.line_fn = rank, seconds, line_fn
+        self.where = "start"
+        self._done = threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def at(self, where):
+        self.where = where
+
+    def disarm(self):
+        self._done.set()
+
+    def _run(self):
+        if self._done.wait(self.seconds):
+            return
+        try:
+            if self.line_fn is not None:
+                res = self.line_fn()
+                res["post_timing_sections"] = {"completed": False, "gave_up_after_s": self.seconds, "stuck_in": self.where,
+                                               "note": "the timed region had ended and its numbers are final; the sections after it "
+                                                       "(per-rank oracle parity / party-sharded pass / config 2 on every GPU) did not finish"}
+                sys.stdout.write(json.dumps(res) + "\n")
+                sys.stdout.flush()
+        finally:
+            os._exit(0)
+
+
 def respawn_under_torchrun(n, argv):
     """`python bench.py --gpus N` with no torch.distributed environment: this process becomes the launcher of N ranks, one
     per GPU (the same command line the driver would use), and exits with their status; rank 0 prints the JSON line."""
@@ -1196,94 +1230,9 @@ def main():
                  "nonces": "every timed step re-arms every hosted (block, parties) object with values sampled on the device from its own seed and a fresh batch counter",
                  "fan_out": "mpe_comm_all_gather (ncclAllGather behind the C-ABI)" if ps.comm is not None else "torch.distributed (host-staged under gloo)"}
 
-    # (c) a parity sample against the GMP oracle on EVERY rank at N > 1 (at N = 1 the cpu_baseline leg below does it on 256+ sessions)
-    rank_parity = None
-    if distributed and not args.no_cpu_baseline:
-        if args.mode == "session":
-            k = min(B, 16)
-            host_n = _host({f: v[: k * (v.shape[0] // B)] for f, v in nonces.items()})
-            _, wr, ws, wrecid, wstatus = cpu_baseline_gg20(lk, host_n, k, min(rank_threads, k))
-            ok = bool((wstatus == 0).all() and np.array_equal(out[0][:k].cpu().numpy().view(np.uint32), wr) and
-                      np.array_equal(out[1][:k].cpu().numpy().view(np.uint32), ws) and np.array_equal(out[2][:k].cpu().numpy(), wrecid))
-        else:
-            ok, k = pm.parity(rank_threads)
-        flags = torch.tensor([1.0 if ok else 0.0, float(k)], dtype=torch.float64, device=coll_dev)
-        every_f = [torch.zeros_like(flags) for _ in range(world)]
-        dist.all_gather(every_f, flags)
-        rank_parity = {"ok_per_rank": [bool(float(t_[0])) for t_ in every_f], "sessions_per_rank": int(k),
-                       "all_ok": all(float(t_[0]) == 1.0 for t_ in every_f),
-                       "what": "(r, s, recid) of the first sessions of every rank's own batch, bit for bit against the GMP oracle"}
-        if per_rank is not None:
-            per_rank["parity_vs_oracle"] = rank_parity
-
-    # (b) Mode B in the SAME line: after the session-sharded timed region a short party-sharded pass at BASELINE config 5's
-    # per-GPU share (t=2, n=5: S=3 signers; party p of session block s on rank (s+p) % N; one all-gather per round), so that
-    # the driver's one command `bench.py --gpus N` exercises the RCCL data path and reports its rate beside Mode A's
-    mode_b = None
-    want_b = (world > 1 or os.environ.get("MPE_BENCH_FORCE_MODE_B")) and distributed and args.mode == "session" and not args.no_mode_b
-    if want_b:
-        try:
-            tb, nb, sg_b = 2, 5, [0, 1, 2]
-            Bb = args.mode_b_sessions if args.mode_b_sessions else min(8192, B)
-            lk_b = G.make_local_keys(keys, tb, nb, sg_b)
-            comm_b = make_comm(ctx, E, rank, world, share, distributed)
-            pm_b = PartyMode(ctx, E, G, mpe_dist, lk_b, lk_b["arrays"], tb, nb, sg_b, Bb, dev, world,
-                             parity_sessions=0 if args.no_cpu_baseline else 4, comm=comm_b)
-            gather_layout = pm_b.ps.layout_self_test()
-            pm_b.step()                                        # warm-up
-            torch.cuda.synchronize()
-            pm_b.ps.comm_seconds()
-            dist.barrier()
-            torch.cuda.synchronize()
-            tb0 = time.perf_counter()
-            for _ in range(args.mode_b_steps):
-                out_b = pm_b.step()
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-            own_b = time.perf_counter() - tb0
-            comm_b = pm_b.ps.comm_seconds()
-            el_b = mpe_dist.max_over_ranks(own_b, coll_dev)
-            ok_b, k_b = (None, 0) if args.no_cpu_baseline else pm_b.parity(rank_threads)
-            signed_b = bool((out_b[3] == 0).all().item())
-            mine_b = torch.tensor([Bb * args.mode_b_steps / own_b, 1.0 if signed_b else 0.0, 1.0 if (ok_b or ok_b is None) else 0.0, comm_b],
-                                  dtype=torch.float64, device=coll_dev)
-            every_b = [torch.zeros_like(mine_b) for _ in range(world)]
-            dist.all_gather(every_b, mine_b)
-            S_b = len(sg_b)
-            # a rank hosts S (block, party) pairs of Bb sessions: world blocks of Bb sessions are signed per step by the node
-            mode_b = {"workload": f"{Bb} sessions per GPU-share, t={tb} n={nb} (BASELINE config 5's shape), party-sharded: party p of session block s on "
-                                  f"rank (s+p)%{world}, {world} blocks, one {'gloo (host-staged)' if share else 'RCCL'} all-gather per round",
-                      "signatures_per_s": Bb * world * args.mode_b_steps / el_b, "ms_per_step": el_b / args.mode_b_steps * 1e3,
-                      "steps": args.mode_b_steps, "sessions_per_block": Bb, "blocks": world, "signers": S_b,
-                      "rccl_time_share": max(float(t_[3]) for t_ in every_b) / el_b,
-                      "bytes_all_gathered_per_round": {str(k_): int(v_) for k_, v_ in pm_b.ps.bytes_per_round.items()},
-                      "gather_mode": pm_b.ps.gather_mode, "per_rank_signatures_per_s": [float(t_[0]) for t_ in every_b],
-                      "all_sessions_signed": all(float(t_[1]) == 1.0 for t_ in every_b),
-                      "parity_sample_vs_oracle": None if args.no_cpu_baseline else all(float(t_[2]) == 1.0 for t_ in every_b),
-                      "parity_sessions_per_rank": int(k_b),
-                      "nonces": "fresh per step: device-side sampler, one seed per hosted (block, parties) object",
-                      "fan_out": "mpe_comm_all_gather (ncclAllGather behind the C-ABI)" if pm_b.ps.comm is not None else "torch.distributed (host-staged under gloo)"}
-            pm_b.close()
-        except Exception as e_b:                               # noqa: BLE001 — the Mode-A line must survive a Mode-B failure, and say so
-            mode_b = {"error": repr(e_b)}
-
-    # north_star asks for Paillier ops/s at 1, 2, 4 and 8 GPUs too: at N > 1 every rank runs BASELINE config 2 at the same time
-    # (after the timed signing region) and the rates add up; at N = 1 it is the c2 section below
-    node_paillier = None
-    if distributed and (world > 1 or os.environ.get("MPE_BENCH_FORCE_NODE_PAILLIER")) and args.mode == "session" and not args.no_configs:
-        dist.barrier()
-        p2 = paillier_config2(ctx, E, keys, F)
-        agg = torch.tensor([p2["ops_per_s"], p2["encrypt_per_s"], p2["decrypt_per_s"], p2["modexp4096_2048_per_s"]], dtype=torch.float64, device=coll_dev)
-        lo = agg.clone()
-        dist.all_reduce(agg)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        node_paillier = {"n_gpus": world, "batch_per_gpu": p2["batch"], "ops_per_s": float(agg[0]), "encrypt_per_s": float(agg[1]),
-                         "decrypt_per_s": float(agg[2]), "modexp4096_2048_per_s": float(agg[3]), "slowest_gpu_ops_per_s": float(lo[0]),
-                         "roundtrip_ok": bool(p2["roundtrip_ok"]), "note": "sum over ranks of BASELINE config 2 run concurrently on every GPU"}
-    if rank == 0:
-        r, s, recid, status = [o.cpu().numpy() for o in out]
-        all_signed = bool((status == 0).all())
+    def core_line():
+        """The Mode-A line proper: everything the timed region determines (rank 0)."""
+        all_signed = bool((out_host[3] == 0).all())
         # roofline of the dominant kernel: every launch modulo N^2 (4096 bit) of the timed region
         dom = [x for x in recs if x["kind"] in (0, 3, 6) and x["bits"] == 4096]
         dom_s = sum(x["ms"] for x in dom) * 1e-3
@@ -1305,7 +1254,7 @@ def main():
         # HBM traffic of the dominant kernel: measured in separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied) and committed under profiles/ — not re-measured here
         traffic, traffic_src = None, None
-        for rel in ("profiles/r04/pmc_traffic.json", "profiles/r03/pmc_traffic.json"):
+        for rel in ("profiles/r05/pmc_traffic.json", "profiles/r04/pmc_traffic.json", "profiles/r03/pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, rel)) as f:
                     pmc = json.load(f)
@@ -1373,10 +1322,116 @@ def main():
         if distributed:
             res["per_rank"] = per_rank
             res["all_sessions_signed"] = all_signed and per_rank["all_ranks_signed"]
+            res["rccl"] = dict(rccl) if rccl is not None else {"backend": "gloo", "note": "--share-device: every rank on cuda:0, collectives staged "
+                                                               "through host memory; the ranks time-share one GPU (a functional run, not a node figure)"}
+        return res
+
+    # The timed region is over and `elapsed` is final.  What follows at N > 1 (per-rank oracle parity, the party-sharded pass over the
+    # library's own RCCL communicator, config 2 on every GPU) is collective work that has never met more than one GPU before the
+    # driver's node: if any of it wedges, every rank gives up at the same deadline and rank 0 still prints the Mode-A line it has —
+    # marked as such — instead of the whole scaling run ending in the launcher's timeout with nothing.
+    out_host = [o.cpu().numpy() for o in out]
+    watchdog = PostTimingWatchdog(rank, float(os.environ.get("MPE_BENCH_POST_TIMEOUT_S", "420")), core_line if rank == 0 else None) if (distributed and world > 1) else None
+    # (c) a parity sample against the GMP oracle on EVERY rank at N > 1 (at N = 1 the cpu_baseline leg below does it on 256+ sessions)
+    rank_parity = None
+    if distributed and not args.no_cpu_baseline:
+        if watchdog is not None:
+            watchdog.at("per-rank oracle parity")
+        if args.mode == "session":
+            k = min(B, 16)
+            host_n = _host({f: v[: k * (v.shape[0] // B)] for f, v in nonces.items()})
+            _, wr, ws, wrecid, wstatus = cpu_baseline_gg20(lk, host_n, k, min(rank_threads, k))
+            ok = bool((wstatus == 0).all() and np.array_equal(out[0][:k].cpu().numpy().view(np.uint32), wr) and
+                      np.array_equal(out[1][:k].cpu().numpy().view(np.uint32), ws) and np.array_equal(out[2][:k].cpu().numpy(), wrecid))
+        else:
+            ok, k = pm.parity(rank_threads)
+        flags = torch.tensor([1.0 if ok else 0.0, float(k)], dtype=torch.float64, device=coll_dev)
+        every_f = [torch.zeros_like(flags) for _ in range(world)]
+        dist.all_gather(every_f, flags)
+        rank_parity = {"ok_per_rank": [bool(float(t_[0])) for t_ in every_f], "sessions_per_rank": int(k),
+                       "all_ok": all(float(t_[0]) == 1.0 for t_ in every_f),
+                       "what": "(r, s, recid) of the first sessions of every rank's own batch, bit for bit against the GMP oracle"}
+        if per_rank is not None:
+            per_rank["parity_vs_oracle"] = rank_parity
+
+    # (b) Mode B in the SAME line: after the session-sharded timed region a short party-sharded pass at BASELINE config 5's
+    # per-GPU share (t=2, n=5: S=3 signers; party p of session block s on rank (s+p) % N; one all-gather per round), so that
+    # the driver's one command `bench.py --gpus N` exercises the RCCL data path and reports its rate beside Mode A's
+    mode_b = None
+    want_b = (world > 1 or os.environ.get("MPE_BENCH_FORCE_MODE_B")) and distributed and args.mode == "session" and not args.no_mode_b
+    if want_b:
+        if watchdog is not None:
+            watchdog.at("mode_b (party-sharded pass over mpe_comm_*)")
+        try:
+            tb, nb, sg_b = 2, 5, [0, 1, 2]
+            Bb = args.mode_b_sessions if args.mode_b_sessions else min(8192, B)
+            lk_b = G.make_local_keys(keys, tb, nb, sg_b)
+            comm_b = make_comm(ctx, E, rank, world, share, distributed)
+            pm_b = PartyMode(ctx, E, G, mpe_dist, lk_b, lk_b["arrays"], tb, nb, sg_b, Bb, dev, world,
+                             parity_sessions=0 if args.no_cpu_baseline else 4, comm=comm_b)
+            gather_layout = pm_b.ps.layout_self_test()
+            pm_b.step()                                        # warm-up
+            torch.cuda.synchronize()
+            pm_b.ps.comm_seconds()
+            dist.barrier()
+            torch.cuda.synchronize()
+            tb0 = time.perf_counter()
+            for _ in range(args.mode_b_steps):
+                out_b = pm_b.step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            own_b = time.perf_counter() - tb0
+            comm_b = pm_b.ps.comm_seconds()
+            el_b = mpe_dist.max_over_ranks(own_b, coll_dev)
+            ok_b, k_b = (None, 0) if args.no_cpu_baseline else pm_b.parity(rank_threads)
+            signed_b = bool((out_b[3] == 0).all().item())
+            mine_b = torch.tensor([Bb * args.mode_b_steps / own_b, 1.0 if signed_b else 0.0, 1.0 if (ok_b or ok_b is None) else 0.0, comm_b],
+                                  dtype=torch.float64, device=coll_dev)
+            every_b = [torch.zeros_like(mine_b) for _ in range(world)]
+            dist.all_gather(every_b, mine_b)
+            S_b = len(sg_b)
+            # a rank hosts S (block, party) pairs of Bb sessions: world blocks of Bb sessions are signed per step by the node
+            mode_b = {"workload": f"{Bb} sessions per GPU-share, t={tb} n={nb} (BASELINE config 5's shape), party-sharded: party p of session block s on "
+                                  f"rank (s+p)%{world}, {world} blocks, one {'gloo (host-staged)' if share else 'RCCL'} all-gather per round",
+                      "signatures_per_s": Bb * world * args.mode_b_steps / el_b, "ms_per_step": el_b / args.mode_b_steps * 1e3,
+                      "steps": args.mode_b_steps, "sessions_per_block": Bb, "blocks": world, "signers": S_b,
+                      "rccl_time_share": max(float(t_[3]) for t_ in every_b) / el_b,
+                      "bytes_all_gathered_per_round": {str(k_): int(v_) for k_, v_ in pm_b.ps.bytes_per_round.items()},
+                      "gather_mode": pm_b.ps.gather_mode, "per_rank_signatures_per_s": [float(t_[0]) for t_ in every_b],
+                      "all_sessions_signed": all(float(t_[1]) == 1.0 for t_ in every_b),
+                      "parity_sample_vs_oracle": None if args.no_cpu_baseline else all(float(t_[2]) == 1.0 for t_ in every_b),
+                      "parity_sessions_per_rank": int(k_b),
+                      "nonces": "fresh per step: device-side sampler, one seed per hosted (block, parties) object",
+                      "fan_out": "mpe_comm_all_gather (ncclAllGather behind the C-ABI)" if pm_b.ps.comm is not None else "torch.distributed (host-staged under gloo)"}
+            pm_b.close()
+        except Exception as e_b:                               # noqa: BLE001 — the Mode-A line must survive a Mode-B failure, and say so
+            mode_b = {"error": repr(e_b)}
+
+    # north_star asks for Paillier ops/s at 1, 2, 4 and 8 GPUs too: at N > 1 every rank runs BASELINE config 2 at the same time
+    # (after the timed signing region) and the rates add up; at N = 1 it is the c2 section below
+    node_paillier = None
+    if distributed and (world > 1 or os.environ.get("MPE_BENCH_FORCE_NODE_PAILLIER")) and args.mode == "session" and not args.no_configs:
+        if watchdog is not None:
+            watchdog.at("config 2 on every GPU")
+        dist.barrier()
+        p2 = paillier_config2(ctx, E, keys, F)
+        agg = torch.tensor([p2["ops_per_s"], p2["encrypt_per_s"], p2["decrypt_per_s"], p2["modexp4096_2048_per_s"]], dtype=torch.float64, device=coll_dev)
+        lo = agg.clone()
+        dist.all_reduce(agg)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        node_paillier = {"n_gpus": world, "batch_per_gpu": p2["batch"], "ops_per_s": float(agg[0]), "encrypt_per_s": float(agg[1]),
+                         "decrypt_per_s": float(agg[2]), "modexp4096_2048_per_s": float(agg[3]), "slowest_gpu_ops_per_s": float(lo[0]),
+                         "roundtrip_ok": bool(p2["roundtrip_ok"]), "note": "sum over ranks of BASELINE config 2 run concurrently on every GPU"}
+    if watchdog is not None:
+        watchdog.disarm()
+    if rank == 0:
+        res = core_line()
+        r, s, recid, status = out_host
+        all_signed = bool((status == 0).all())
+        if distributed:
             if mode_b is not None:
                 res["mode_b"] = mode_b
-            res["rccl"] = rccl if rccl is not None else {"backend": "gloo", "note": "--share-device: every rank on cuda:0, collectives staged "
-                                                         "through host memory; the ranks time-share one GPU (a functional run, not a node figure)"}
             # the layout of the round all-gather checked on the real backend before any party-sharded work (dist.PartySharded.layout_self_test)
             res["rccl"]["all_gather_layout_self_test"] = gather_layout
         # the other configs and the CPU baseline belong to the single-GPU line (rank 0 at N=1 only): at N>1 the other ranks

@@ -165,3 +165,28 @@ def test_the_stream_section_needs_no_child_process_and_no_queue_setting():
     body = inspect.getsource(B.c4_pipeline)
     assert "Gg20Pipeline" in body and "submit_seeded" in body and "window = window or 2 * lanes * group" in body
     assert "oracle_sample_nonces" in body and "openssl_verify_all" in body        # every batch: OpenSSL on all, the oracle on a sample
+
+
+def test_post_timing_watchdog_prints_the_timed_line_and_leaves_with_status_0():
+    """N > 1: if a collective section after the timed region wedges, rank 0 still prints the Mode-A line (marked) and the rank exits 0
+    at the deadline (bench.py PostTimingWatchdog) — run in a child process, because the watchdog ends its process."""
+    import subprocess
+    import sys
+    code = ("import importlib.util, time, sys\n"
+            f"spec = importlib.util.spec_from_file_location('mpe_bench', {os.path.join(ROOT, 'bench.py')!r})\n"
+            "B = importlib.util.module_from_spec(spec); spec.loader.exec_module(B)\n"
+            "w = B.PostTimingWatchdog(0, 0.3, lambda: {'metric': 'm', 'value': 1.0})\n"
+            "w.at('mode_b')\n"
+            "time.sleep(30)\n"
+            "sys.exit(7)\n")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0
+    line = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["value"] == 1.0 and line["post_timing_sections"]["completed"] is False and line["post_timing_sections"]["stuck_in"] == "mode_b"
+    # a disarmed watchdog does nothing; a rank other than 0 prints nothing
+    code2 = code.replace("w.at('mode_b')\n", "w.disarm()\n").replace("time.sleep(30)", "time.sleep(1)")
+    p2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
+    assert p2.returncode == 7 and "{" not in p2.stdout
+    code3 = code.replace("PostTimingWatchdog(0, 0.3, lambda: {'metric': 'm', 'value': 1.0})", "PostTimingWatchdog(1, 0.3, None)")
+    p3 = subprocess.run([sys.executable, "-c", code3], capture_output=True, text=True, timeout=120)
+    assert p3.returncode == 0 and "{" not in p3.stdout
