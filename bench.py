@@ -1088,6 +1088,7 @@ def main():
     ap.add_argument("--stream-batches", type=int, default=96, help="c4_stream_1024: batches of 1 024 sessions in the stream")
     ap.add_argument("--stream-lanes", type=int, default=2, help="c4_stream_1024: passes in flight (mpe_gg20_pipeline lanes)")
     ap.add_argument("--stream-group", type=int, default=4, help="c4_stream_1024: batches coalesced per pass")
+    ap.add_argument("--dump-launches", action="store_true", help="add the timed region's heavy launches (kind, bits, batch, ms) to the line")
     ap.add_argument("--only", default="", help="comma list of config sections to run after the timed region (default: all)")
     ap.add_argument("--no-mode-b", action="store_true", help="N > 1, session mode: skip the party-sharded (config 5 shape) pass after the timed region")
     ap.add_argument("--mode-b-sessions", type=int, default=0, help="sessions per block of that pass (0 = min(8192, --sessions))")
@@ -1319,6 +1320,9 @@ def main():
             "device": {"name": torch.cuda.get_device_name(local_rank), "host": os.uname().nodename,
                        "note": "boxes of this pool differ by up to ~3 % in signatures/s (profiles/r03/README.md)"},
         }
+        if args.dump_launches:
+            res["launches_timed_region"] = [{"kind": x["kind"], "bits": x["bits"], "exp_words": x["exp_words"], "exp2_words": x.get("exp2_words", 0),
+                                             "batch": x["batch"], "ms": round(x["ms"], 3)} for x in recs]
         if distributed:
             res["per_rank"] = per_rank
             res["all_sessions_signed"] = all_signed and per_rank["all_ranks_signed"]

@@ -31,7 +31,7 @@ struct mpe_ctx {
   bool merge_r1 = true;           // round 1, large batches: the ladders of the verifications and of the MessageBs in ONE launch (MPE_NO_MERGE_R1)
   size_t fb_budget_bytes = 0;     // memory budget of the fixed-base tables of a key object; 0 = a quarter of free HBM (MPE_FB_BUDGET_MB)
   int modexp_waves_per_cu = 8;    // 2 waves/SIMD: the montmul loop holds ~230 VGPRs and already issues back-to-back
-  bool grid_full = true;          // a launch of n.f passes runs n full trips and a tail (MPE_GRID_EQUAL=1: n + 1 equal trips, rounds 1-4)
+  int grid_mode = 2;              // persistent_grid(): 0 = equal trips (rounds 1-4), 1 = full trips + tail, 2 = tail only when it fits one wave per SIMD (MPE_GRID=equal|full|hybrid)
   // window-table scratch, grown on demand: one buffer per stream slot (0 = the caller's stream, 1..3 = the auxiliary streams
   // on which small batches run independent launches concurrently)
   void* tables[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // slot 0: the caller's stream, 1..3: the auxiliary streams
@@ -156,13 +156,17 @@ inline T* ws_array(mpe_ctx* ctx, size_t count) { return (T*)ws_alloc(ctx, count 
 inline int blocks_for(int n, int threads) { return (n + threads - 1) / threads; }
 
 // Persistent grid of the ladder kernels: `need` waves of work on `cap` resident wave slots (2 per SIMD).  A wave runs as long as ONE
-// ladder whatever shares its SIMD, but a wave that is alone on its SIMD issues ~1.6x faster than one of two — so a launch of n.f passes is
-// best run as n full trips and ONE tail trip whose f * cap waves sit alone on their SIMDs (grid = cap: the hardware hands the workgroups
-// round-robin to the CUs, the low-numbered waves that own the tail items end up one per SIMD), not as n + 1 equal trips in each of which
-// some SIMDs hold two waves and set the pace (rounds 1-4; MPE_GRID_EQUAL switches back for A/B runs).  Waves with no item left exit.
+// ladder whatever shares its SIMD, but a wave that is alone on its SIMD issues ~1.6x faster than one of two.  So when the launch is
+// n.f passes with f <= 1/2, it is best run as n full trips and ONE tail trip whose f * cap waves sit alone on their SIMDs (grid = cap:
+// the hardware hands the workgroups round-robin to the CUs, the low-numbered waves that own the tail items end up one per SIMD): the
+// tail costs 0.6 of a trip instead of a whole one.  With f > 1/2 some SIMDs of the tail hold two waves and set its pace either way;
+// then n + 1 equal trips (rounds 1-4) keep fewer waves resident throughout.  Waves with no item left exit.
+// (MPE_GRID=equal | full | hybrid for A/B runs: profiles/r05/ab_grid.jsonl)
 inline int persistent_grid(const mpe_ctx* ctx, int need, int cap) {
   if (need <= cap) return need;
-  if (ctx->grid_full) return cap;
+  const int rem = need % cap;
+  if (rem == 0) return cap;
+  if (ctx->grid_mode == 1 || (ctx->grid_mode == 2 && 2 * rem <= cap)) return cap;
   const int trips = (need + cap - 1) / cap;
   return (need + trips - 1) / trips;
 }

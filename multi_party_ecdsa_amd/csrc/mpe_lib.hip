@@ -332,7 +332,9 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   if (const char* e = getenv("MPE_XWIDE_DIV")) { const int v = atoi(e); if (v >= 0) c->xwide_div = v; }
   if (getenv("MPE_NO_MERGE_XN")) c->merge_xn = false;
   if (getenv("MPE_NO_MERGE_R1")) c->merge_r1 = false;
-  if (getenv("MPE_GRID_EQUAL")) c->grid_full = false;
+  if (getenv("MPE_GRID_EQUAL")) c->grid_mode = 0;
+  if (const char* e = getenv("MPE_WAVES_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) c->modexp_waves_per_cu = v; }   // A/B: 4 = one ladder wave per SIMD
+  if (const char* e = getenv("MPE_GRID")) c->grid_mode = !strcmp(e, "equal") ? 0 : (!strcmp(e, "full") ? 1 : 2);
   if (const char* e = getenv("MPE_FB_BUDGET_MB")) c->fb_budget_bytes = (size_t)atoll(e) << 20;
   if (getenv("MPE_WINDOW_BITS")) { const int w = atoi(getenv("MPE_WINDOW_BITS")); if (w >= 4 && w <= 6) c->window_bits = w; }
   // comb tables of the two fixed secp256k1 generators: module globals, built ONCE per device (immutable afterwards — the only
