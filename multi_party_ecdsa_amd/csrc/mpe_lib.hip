@@ -1,5 +1,6 @@
 // libmpecdsa_hip.so — C-ABI (include/mpecdsa_hip.h) over the gfx950 kernels.  Single translation unit.
 #include <string.h>
+#include <initializer_list>
 #include <mutex>
 #include "mpe_internal.h"
 #include "mpe_ec.h"

@@ -118,12 +118,8 @@ static int open_slot(mpe_gg20_pipeline* p, uint32_t* d_r, uint32_t* d_s, int32_t
     mpe_set_error_msg("gg20 pipeline: more than 4096 batches in flight");
     return MPE_E_ARG;
   }
-  if (!t->submitted) {
-    if (hipEventCreate(&t->submitted) != hipSuccess || hipEventCreate(&t->begin) != hipSuccess || hipEventCreate(&t->done) != hipSuccess) {
-      mpe_set_error_msg("gg20 pipeline: hipEventCreate");
-      return MPE_E_HIP;
-    }
-  }
+  for (hipEvent_t* ev : {&t->submitted, &t->begin, &t->done})        // created once per ring slot (a failed creation is retried by the next use)
+    if (!*ev && hipEventCreate(ev) != hipSuccess) { *ev = nullptr; mpe_set_error_msg("gg20 pipeline: hipEventCreate"); return MPE_E_HIP; }
   const int li = p->cur;
   mpe_gg20_pipeline::Lane& L = p->lane[li];
   const int g = L.filled;
@@ -211,17 +207,19 @@ int mpe_gg20_pipeline_submit(mpe_gg20_pipeline* p, const int32_t* d_keyset, cons
                              uint32_t* d_R, int32_t* d_status, void* stream, uint64_t* ticket) {
   if (!p || !nonces) return MPE_E_ARG;
   if (p->K->K > 1 && !d_keyset) return MPE_E_ARG;
+  // every refusal comes BEFORE a slot and a ticket are taken: a refused call leaves the pipeline as it was
+  mpe_gg20_nonces src = *nonces;
+  for (int f = 0; f < mpe::smp::NF; ++f)
+    if (!*mpe::smp::nonce_field_ptr(&src, f)) { mpe_set_error_msg("gg20 pipeline: a nonce array is NULL"); return MPE_E_ARG; }
+  if (p->lane[p->cur].seeded) { mpe_set_error_msg("gg20 pipeline: a group holds seeded or caller-sampled batches, not both (flush between the two forms)"); return MPE_E_ARG; }
   int li = 0, g = 0;
   MPE_TRY(mpe::pipe::open_slot(p, d_r, d_s, d_recid, d_R, d_status, (hipStream_t)stream, &li, &g, ticket));
   mpe_gg20_pipeline::Lane& L = p->lane[li];
-  if (L.seeded) { mpe_set_error_msg("gg20 pipeline: a group holds seeded or caller-sampled batches, not both (flush between the two forms)"); return MPE_E_ARG; }
-  mpe_gg20_nonces src = *nonces;
   for (int f = 0; f < mpe::smp::NF; ++f) {
     mpe_gg20_nonce_buf* sb = L.stage;
     const size_t w = sb->per_session[f] * (size_t)p->batch;
     const uint32_t* from = *mpe::smp::nonce_field_ptr(&src, f);
     uint32_t* to = const_cast<uint32_t*>(*mpe::smp::nonce_field_ptr(&sb->view, f)) + (size_t)g * w;
-    if (!from) { mpe_set_error_msg("gg20 pipeline: a nonce array is NULL"); return MPE_E_ARG; }
     (void)hipMemcpyAsync(to, from, w * 4, hipMemcpyDeviceToDevice, L.st);
   }
   return mpe::pipe::close_slot(p, li, d_keyset);
@@ -232,10 +230,10 @@ int mpe_gg20_pipeline_submit_seeded(mpe_gg20_pipeline* p, const int32_t* d_keyse
   if (!p || !h_seed32 || !d_msg || (batch_counter >> 56) != 0) return MPE_E_ARG;
   if (p->group > mpe::smp::MAX_SLOTS) { mpe_set_error_msg("gg20 pipeline: seeded submission needs group <= 16 (one sampler launch per group)"); return MPE_E_ARG; }
   if (p->K->K > 1 && !d_keyset) return MPE_E_ARG;
+  if (p->lane[p->cur].filled != p->lane[p->cur].seeded) { mpe_set_error_msg("gg20 pipeline: a group holds seeded or caller-sampled batches, not both (flush between the two forms)"); return MPE_E_ARG; }
   int li = 0, g = 0;
   MPE_TRY(mpe::pipe::open_slot(p, d_r, d_s, d_recid, d_R, d_status, (hipStream_t)stream, &li, &g, ticket));
   mpe_gg20_pipeline::Lane& L = p->lane[li];
-  if (L.filled != L.seeded) { mpe_set_error_msg("gg20 pipeline: a group holds seeded or caller-sampled batches, not both (flush between the two forms)"); return MPE_E_ARG; }
   (void)hipMemcpyAsync(const_cast<uint32_t*>(L.stage->view.msg) + (size_t)g * p->batch * 8, d_msg, (size_t)p->batch * 32, hipMemcpyDeviceToDevice, L.st);
   memcpy(L.seeds + 32 * g, h_seed32, 32);
   L.counters[g] = batch_counter;

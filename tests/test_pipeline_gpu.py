@@ -127,3 +127,37 @@ def test_pipeline_with_key_sets_and_argument_errors(gpu_ctx):
     with pytest.raises(E.N_.MpeError):
         E.Gg20Pipeline(ctx, gk, B, group=2, lanes=5)
     gk.close()
+
+
+def test_a_refused_submission_takes_no_slot_and_no_ticket(gpu_ctx, wallet):
+    """a group holds seeded or caller-sampled batches, not both: the refused call must leave the open group, the ticket counter and the
+    ring as they were — the next accepted batch gets the next ticket and the group still signs (mpe_pipeline.h: every refusal comes
+    before a slot is taken)"""
+    ctx = gpu_ctx
+    lk, gk = wallet
+    B = 4
+    msg = F.words([11 + i for i in range(B)], 8)
+    host = G.make_nonces(lk, B, seed="refused")
+    dev = {f: dv(ctx, v) for f, v in host.items()}
+    pipe = E.Gg20Pipeline(ctx, gk, B, group=3, lanes=1)
+    t1 = pipe.submit_seeded(SEED, 7, dv(ctx, msg))
+    for _ in range(3):
+        with pytest.raises(E.N_.MpeError):
+            pipe.submit(dev)                                          # caller-sampled values into a group that holds a seeded batch
+    t2 = pipe.submit_seeded(SEED, 8, dv(ctx, msg))
+    assert (t1, t2) == (1, 2)
+    for b, t in ((7, t1), (8, t2)):
+        r, s, recid, status = pipe.wait(t)
+        z, fails = G.oracle_sample_nonces(lk, B, SEED, b, msg=msg)
+        wr, ws, wrecid, _, wstatus = G.oracle_sign(lk, z, B)
+        assert fails == 0 and not wstatus.any() and not status.cpu().numpy().any()
+        assert np.array_equal(hv(r), wr) and np.array_equal(hv(s), ws) and np.array_equal(recid.cpu().numpy(), wrecid)
+    # ... and the other way round: a seeded batch into a group that holds caller-sampled values
+    t3 = pipe.submit(dev)
+    with pytest.raises(E.N_.MpeError):
+        pipe.submit_seeded(SEED, 9, dv(ctx, msg))
+    assert t3 == 3
+    r, s, recid, status = pipe.wait(t3)
+    wr, ws, wrecid, _, wstatus = G.oracle_sign(lk, host, B)
+    assert not wstatus.any() and not status.cpu().numpy().any() and np.array_equal(hv(r), wr) and np.array_equal(hv(s), ws)
+    pipe.close()
