@@ -974,10 +974,17 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   // small batches: the verification of the peers' range proofs and the construction of my MessageBs are independent
   // (the reference runs them back to back inside MessageB::b) — two streams, one workspace reservation
   const bool par = ctx->allow_par && (int)c.nVI <= ctx->par_items;
-  if (par && rc == MPE_OK) { rc = ws_reserve(ctx, ws_need_alice_verify((int)c.nVI) + ws_need_mul_add_enc((int)c.nMB), st); if (rc == MPE_OK) ctx->ws_hold++; }
-  bool held = par && rc == MPE_OK;
-  // large batches: the ladders of both halves of the round in ONE launch (round1_merged_ladders)
-  const bool merged = !par && ctx->merge_r1 && ctx->use_pair && ctx->use_multiexp && c.nVI > 0 && c.nMB > 0 && c.nVI + c.nMB < ((size_t)1 << 30);
+  // the ladders of both halves of the round in ONE launch (round1_merged_ladders): always for large batches, and for a small batch (par)
+  // when its two ladder launches on forked streams would overfill the chip (more than 3/4 of the resident groups between them) — then
+  // the longer one sets the pace and the merged launch wins although the inversion of c moves in front of it (2 048 sessions:
+  // 55.2 || 90.8 ms against 63.5 ms, +9 % on the batch).  Below that the forked launches overlap and merging only serialises the
+  // inversion (1 536 sessions: -1.4 %; 1 024: no change; 512: -7.5 %) — profiles/r05/ab_merge_small_batches.jsonl.  What remains of the two halves (the N~ side of the
+  // verification, MessageB's encryption tail and DLog proofs) runs on forked streams behind the merged launch.
+  const size_t resident_groups = (size_t)ctx->cus * ctx->modexp_waves_per_cu * 16 / ctx->device_share;
+  const bool merged = ctx->merge_r1 && ctx->use_pair && ctx->use_multiexp && c.nVI > 0 && c.nMB > 0 && c.nVI + c.nMB < ((size_t)1 << 30) &&
+                      (!par || 4 * (c.nVI + c.nMB) > 3 * resident_groups);
+  if (par && !merged && rc == MPE_OK) { rc = ws_reserve(ctx, ws_need_alice_verify((int)c.nVI) + ws_need_mul_add_enc((int)c.nMB), st); if (rc == MPE_OK) ctx->ws_hold++; }
+  bool held = par && !merged && rc == MPE_OK;
   const uint32_t *m_vi = nullptr, *x_mb = nullptr;
   const uint8_t* inv_ok_vi = nullptr;
   AliceProofRows pr{rows(d_in, SUB0, sub0_vi), rows(d_in + 64, SUB0, sub0_vi), rows(d_in + 72, SUB0, sub0_vi),
@@ -992,7 +999,7 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
                                  rows(s->ca_all, 128, s->ix.ca_mb), bsel, Z.mb_r, &m_vi, &inv_ok_vi, &x_mb, st);
     gg_trace(st, "round 1 merged ladders", rc);
   }
-  Fork g(ctx, st, 2, held && !merged, 2);
+  Fork g(ctx, st, 2, held && par, 2);
   {
     hipStream_t st2 = g.s(1);
     if (rc == MPE_OK && c.nMB > 0 && !merged)

@@ -345,7 +345,7 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
                         const int32_t* st_idx, Rows cipher, const AliceProofRows& pr, uint8_t* ok, hipStream_t st,
                         const uint32_t* m_pre = nullptr, const uint8_t* inv_ok_pre = nullptr) {
   MPE_TRY(ws_reserve(ctx, ws_need_alice_verify(B), st));
-  Fork f(ctx, st, 3, B <= ctx->par_items && !m_pre);
+  Fork f(ctx, st, 3, B <= ctx->par_items);          // (with m_pre the N^2 side is one multiplication: the two N~ branches still fork)
   Seq q{ctx, f.s(0), B}, q1{ctx, f.s(1), B}, q2{ctx, f.s(2), B};
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
   const Rows h1 = tab_rows(stm->h1, 64, st_idx, stm->count), h2 = tab_rows(stm->h2, 64, st_idx, stm->count);
@@ -388,7 +388,7 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
   }
   f.join();
   q.rc = merge_rc(q, q1, q2);
-  if (f.on) u = q.modmul(pk->ms_nn, ksel, rows(b12, 128), rows(cie, 128));
+  if (f.on && !m_pre) u = q.modmul(pk->ms_nn, ksel, rows(b12, 128), rows(cie, 128));
   uint32_t* w = q.modmul(stm->ms, ssel, rows(a12, 64), rows(zei, 64));
   // e' = H(N, N+1, c, z, u', w') == e                                                              :143-153
   uint32_t* e2 = q.words(8);
