@@ -31,6 +31,10 @@ session mode — the node's Paillier ops/s.  --share-device: every rank on cuda:
   --mode session (default): sessions sharded across ranks, no data-path collective (independent units, SURVEY.md §8e A);
   --mode party: the parties of a session live on different GPUs (party p of session block s on rank (s + p) % N) and
   every round's messages travel through one all-gather (BASELINE config 5); same per-GPU work.
+At N > 1 the line of the timed region is assembled before the collective sections that follow it (per-rank oracle parity, `mode_b{}`, config 2 on
+every GPU); if one of those wedges, a per-rank watchdog (MPE_BENCH_POST_TIMEOUT_S, default 420 s) makes rank 0 print that line with
+`post_timing_sections{completed: false}` and every rank leave with status 0.
+--dump-launches adds the timed region's profiled launches (kind, modulus bits, exponent words, batch, ms) — what tools/ab_*.sh compare.
 Prints ONE JSON line (rank 0).
 """
 import argparse
