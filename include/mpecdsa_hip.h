@@ -70,6 +70,20 @@ int mpe_ctx_scratch_audit(mpe_ctx* ctx, uint64_t* nonzero_words, uint64_t* total
  * experiments only (results are identical whatever the value; default 1).  The supported way to serve a stream of small batches is
  * mpe_gg20_pipeline_* below: one handle, one host thread, batches coalesced per pass. */
 int mpe_ctx_set_device_share(mpe_ctx* ctx, int contexts);
+/* Run-time options: the A/B switches every "x vs y" figure of DESIGN.md was measured with.  The library reads NO environment
+ * variable; a context starts with the shipped defaults and changes only through this call (before the objects that depend on the
+ * option are created: e.g. fb_window_bits before mpe_statements_create / mpe_gg20_keys_create).  None changes a result.
+ *   0/1 switches   no_fixed_base no_crt no_multiexp no_pair no_pown no_sliding no_par no_wide no_ec_lane_groups
+ *                  no_adaptive_lanes (= no_wide + no_ec_lane_groups) no_merge_xn no_merge_r1 gg20_trace
+ *   integers       fb_window_bits 4..16 | window_bits 0 (auto), 4..6 | wide_div 1..64 | xwide_div 0 (off).. | waves_per_cu 1..8
+ *                  fb_budget_mb | fb_split 0 (auto)..64 | sampler_max_attempts 1.. (default 128)
+ *   names          grid = equal | full | hybrid
+ * MPE_E_ARG (and mpe_last_error) for an unknown key or a value out of range.  mpe_ctx_get_option returns the integer form;
+ * mpe_ctx_option_count / _name enumerate the integer-valued keys. */
+int mpe_ctx_set_option(mpe_ctx* ctx, const char* key, const char* value);
+int mpe_ctx_get_option(const mpe_ctx* ctx, const char* key, long* value);
+int mpe_ctx_option_count(void);
+const char* mpe_ctx_option_name(int i);
 /* Blocks the host until everything queued on `stream` has finished (hipStreamSynchronize). */
 int mpe_sync(mpe_ctx* ctx, void* stream);
 
@@ -425,11 +439,16 @@ int mpe_gg20_msg_words(int n_signers, int n, int round);
  *   303 T_i != proof.com (rounds.rs:366) | 301 delta not invertible | 302 PedersenProof::verify
  *   401 phase4 "bad gamma_i decommit" | 501 "Bad PDLwSlack proof" | 502 phase5_check_R_dash_sum
  *   601 phase6_verify_proof | 602 phase6_check_S_i_sum | 701 output_signature: verify failed
+ *   91 (MPE_GG20_STATUS_BAD_NONCE, round 0) k_i or gamma_i is not a value `Scalar::random()` returns (0 < x < q): the device sampler
+ *      marks the party of a session one of whose rejection loops gave up this way (mpe_gg20_sample_nonces: after
+ *      sampler_max_attempts candidates, default 128 — probability < 2^-128 per draw; curv's loops are unbounded, a deliberate
+ *      divergence) so that a session NEVER signs on zeroed values; a caller's own out-of-range k_i / gamma_i is refused alike
  * with `bad_actors` (a bit mask over signer ordinals, the reference's `ErrorType::bad_actors`, gg_2020/mod.rs:23-27) set
  * for 401 (the peers whose decommitment is bad), 501 (the first failing prover) and 601 (every failing prover).
  * mpe_gg20_session_result: d_status, d_bad_actors, d_recid [n_local][batch]; d_r, d_s [n_local][batch][8] (after
  * mpe_gg20_complete; zero unless status == 0); d_R [n_local][batch][16] (after round 4).  Any pointer may be NULL.
  * Destroying a session zeroes its state (k_i, gamma_i, w_i, sigma_i, ...). */
+#define MPE_GG20_STATUS_BAD_NONCE 91
 typedef struct mpe_gg20_session mpe_gg20_session;
 int mpe_gg20_session_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, int n_local, const int32_t* h_local,
                             const int32_t* d_keyset, const mpe_gg20_nonces* nonces, int dedup_verify, mpe_gg20_session** out,
@@ -549,6 +568,29 @@ int mpe_gg20_pipeline_wait(mpe_gg20_pipeline* p, uint64_t ticket);
 int mpe_gg20_pipeline_stream_wait(mpe_gg20_pipeline* p, uint64_t ticket, void* stream);
 int mpe_gg20_pipeline_latency_ms(mpe_gg20_pipeline* p, uint64_t ticket, float* ms);
 int mpe_gg20_pipeline_pass_ms(mpe_gg20_pipeline* p, uint64_t ticket, float* ms);
+/* Failure contract.  A failing CHECK of a session is that session's status (above), never an error.  When the PASS that carries a
+ * group fails as a whole (MPE_E_NOMEM / MPE_E_HIP from the sampler or the lock-step composition), every batch of that group is
+ * told: its d_status array is filled with MPE_GG20_STATUS_PASS_FAILED(rc), its d_r / d_s / d_recid (/ d_R) are zeroed (on the
+ * lane's stream, ordered before the ticket completes), and wait / stream_wait / latency_ms / pass_ms — and query once the ticket
+ * is done — return that rc for EACH of its tickets.  submit itself returns MPE_OK when the batch was accepted: an error belongs
+ * to the batches of the failed pass, not to the caller whose submission happened to close the group.  Later groups are unaffected.
+ * (The reference reports per session and never drops an error: gg_2020/mod.rs:23-27, state_machine/sign/rounds.rs:696-713.)
+ *   ticket_rc      *launched = 0 while the batch's group is still open; otherwise *rc = the pass's return code
+ *   inject_fault   test hook: the next `passes` passes fail with rc (MPE_E_NOMEM or MPE_E_HIP) after their inputs were staged */
+#define MPE_GG20_STATUS_PASS_FAILED(rc) (9000 - (rc))        /* 9001 MPE_E_ARG, 9002 MPE_E_HIP, 9003 MPE_E_NOMEM */
+int mpe_gg20_pipeline_ticket_rc(mpe_gg20_pipeline* p, uint64_t ticket, int* launched, int* rc);
+int mpe_gg20_pipeline_inject_fault(mpe_gg20_pipeline* p, int passes, int rc);
+/* When a part-filled group goes to the device: when it is full, on flush / wait, and — evaluated inside every submit / query /
+ * poll call of the ONE host thread that drives the pipeline, there is no hidden thread —
+ *   set_deadline_us   when its oldest batch has waited `us` microseconds of host time (us < 0: never, the default);
+ *   set_eager         as soon as the lane it would run on is idle: arrival-driven grouping — a trickle of batches starts at once,
+ *                     under load the lanes are busy and the groups fill by themselves (off by default);
+ *   poll              applies both rules now (a service calls it from its loop); *launched = 1 if a group went.
+ * counters: groups launched in total / by the deadline / by an idle lane / failed passes. */
+int mpe_gg20_pipeline_set_deadline_us(mpe_gg20_pipeline* p, int64_t us);
+int mpe_gg20_pipeline_set_eager(mpe_gg20_pipeline* p, int on);
+int mpe_gg20_pipeline_poll(mpe_gg20_pipeline* p, int* launched);
+int mpe_gg20_pipeline_counters(const mpe_gg20_pipeline* p, uint64_t* groups, uint64_t* by_deadline, uint64_t* by_idle, uint64_t* failed);
 /* items of the seeded submissions whose rejection loops gave up (see mpe_sample_below); waits for the lanes */
 int mpe_gg20_pipeline_sampler_failures(mpe_gg20_pipeline* p, int32_t* h_out);
 
@@ -579,6 +621,12 @@ typedef struct mpe_comm mpe_comm;
 int mpe_comm_unique_id(uint8_t* h_id);
 int mpe_comm_create(mpe_ctx* ctx, const uint8_t* h_id, int rank, int world, mpe_comm** out);
 int mpe_comm_destroy(mpe_comm* comm);
+/* RCCL is bound at run time (dlopen) by the first communicator call — libmpecdsa_hip.so itself does not link it, so single-GPU
+ * users need no librccl.  A copy the process ALREADY holds (PyTorch loads its own librccl.so.1) is adopted, so a process never
+ * runs two RCCL instances; otherwise librccl.so.1 is searched on the loader path, then under $ROCM_PATH/lib (/opt/rocm/lib).
+ * mpe_comm_library: the bound file (path_buf, NUL-terminated, may be NULL), *adopted = 1 if it was already loaded, *version =
+ * ncclGetVersion.  MPE_E_HIP (and mpe_last_error) when no RCCL can be found. */
+int mpe_comm_library(char* path_buf, size_t path_cap, int* adopted, int* version);
 int mpe_comm_rank(const mpe_comm* comm);
 int mpe_comm_world(const mpe_comm* comm);
 int mpe_comm_gather_mode(const mpe_comm* comm);

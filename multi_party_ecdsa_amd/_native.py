@@ -11,6 +11,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPE_LIB_PATH") or os.path.join(_HERE, "libmpecdsa_hip.so")
 
 MPE_OK, MPE_E_ARG, MPE_E_HIP, MPE_E_NOMEM = 0, -1, -2, -3
+GG20_STATUS_BAD_NONCE = 91                    # include/mpecdsa_hip.h MPE_GG20_STATUS_BAD_NONCE
+
+
+def gg20_status_pass_failed(rc):              # MPE_GG20_STATUS_PASS_FAILED(rc)
+    return 9000 - rc
+
 
 
 class MpeError(RuntimeError):
@@ -97,6 +103,17 @@ def _load():
         "mpe_ctx_destroy": (ip, [vp]),
         "mpe_sync": (ip, [vp, vp]),
         "mpe_ctx_set_device_share": (ip, [vp, ip]),
+        "mpe_ctx_set_option": (ip, [vp, C.c_char_p, C.c_char_p]),
+        "mpe_ctx_get_option": (ip, [vp, C.c_char_p, C.POINTER(C.c_long)]),
+        "mpe_ctx_option_count": (ip, []),
+        "mpe_ctx_option_name": (C.c_char_p, [ip]),
+        "mpe_comm_library": (ip, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "mpe_gg20_pipeline_ticket_rc": (ip, [vp, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "mpe_gg20_pipeline_inject_fault": (ip, [vp, ip, ip]),
+        "mpe_gg20_pipeline_set_deadline_us": (ip, [vp, C.c_int64]),
+        "mpe_gg20_pipeline_set_eager": (ip, [vp, ip]),
+        "mpe_gg20_pipeline_poll": (ip, [vp, C.POINTER(C.c_int)]),
+        "mpe_gg20_pipeline_counters": (ip, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mpe_encoding_default": (None, [C.POINTER(Encoding)]),
         "mpe_ctx_set_encoding": (ip, [vp, C.POINTER(Encoding)]),
         "mpe_ctx_get_encoding": (ip, [vp, C.POINTER(Encoding)]),
@@ -254,7 +271,9 @@ EXPORTED = ["mpe_version", "mpe_last_error", "mpe_ctx_create", "mpe_ctx_destroy"
             "mpe_gg20_pipeline_latency_ms", "mpe_gg20_pipeline_pass_ms", "mpe_gg20_pipeline_sampler_failures", "mpe_keygen_verify_round1", "mpe_keygen_verify_round2",
             "mpe_comm_unique_id", "mpe_comm_create", "mpe_comm_destroy", "mpe_comm_rank", "mpe_comm_world", "mpe_comm_gather_mode", "mpe_comm_all_gather",
             "mpe_comm_layout_self_test", "mpe_gg20_shard_where", "mpe_gg20_shard_blocks", "mpe_gg20_shard_per_rank", "mpe_gg20_shard_in_off",
-            "mpe_gg20_round_exchange", "mpe_gg20_session_abort"]
+            "mpe_gg20_round_exchange", "mpe_gg20_session_abort", "mpe_ctx_set_option", "mpe_ctx_get_option", "mpe_ctx_option_count",
+            "mpe_ctx_option_name", "mpe_comm_library", "mpe_gg20_pipeline_ticket_rc", "mpe_gg20_pipeline_inject_fault",
+            "mpe_gg20_pipeline_set_deadline_us", "mpe_gg20_pipeline_set_eager", "mpe_gg20_pipeline_poll", "mpe_gg20_pipeline_counters"]
 
 
 def check(rc, what):

@@ -12,8 +12,16 @@
 //                      (block, party) pairs for any world size; with world >= S no two parties of a session share a GPU.
 // Rank r's slab = rows [r * per_rank, (r + 1) * per_rank) of the gather buffer, a row = one (block, party) pair's [batch][W] records.
 // Included by mpe_lib.hip.
+//
+// RCCL is bound at RUN time (dlopen), the first time a communicator entry point is called: a single-GPU user of the library — and
+// every host-only helper (mpe_gg20_shard_*) — needs no librccl at all, and a process that already holds a copy (PyTorch ships its
+// own librccl.so and loads it with torch.distributed) gets THAT copy: two RCCL instances in one process would each own a set of
+// proxy threads and IPC handles for the same devices.  <rccl/rccl.h> is included for its types only; nothing links against it.
 #pragma once
+#include <dlfcn.h>
 #include <rccl/rccl.h>
+
+#include <mutex>
 
 #include "mpe_gg20.h"
 
@@ -30,8 +38,64 @@ struct mpe_comm {
 namespace mpe {
 namespace cm {
 
+struct Rccl {
+  void* handle = nullptr;
+  bool adopted = false;            // the copy was already in the process (RTLD_NOLOAD found it)
+  std::string path, error;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+};
+// nullptr + the error message set when no RCCL can be found
+static Rccl* rccl() {
+  static Rccl R;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    for (const char* nm : names) {                             // a copy the process already holds wins (PyTorch's own)
+      R.handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+      if (R.handle) { R.adopted = true; break; }
+    }
+    if (!R.handle) {
+      std::string tried;
+      const char* rocm = getenv("ROCM_PATH");                  // a search path, not a code-path switch
+      const std::string dirs[] = {"", std::string(rocm ? rocm : "/opt/rocm") + "/lib/"};
+      for (const std::string& d : dirs) {
+        for (const char* nm : names) {
+          R.handle = dlopen((d + nm).c_str(), RTLD_NOW | RTLD_LOCAL);
+          if (R.handle) break;
+          tried += std::string(tried.empty() ? "" : "; ") + dlerror();
+        }
+        if (R.handle) break;
+      }
+      if (!R.handle) { R.error = "mpe_comm: no RCCL in this process and none could be loaded (" + tried + ")"; return; }
+    }
+    auto sym = [&](const char* n) -> void* {
+      void* f = dlsym(R.handle, n);
+      if (!f && R.error.empty()) R.error = std::string("mpe_comm: librccl lacks ") + n;
+      return f;
+    };
+    R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
+    R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
+    R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+    R.AllGather = (decltype(R.AllGather))sym("ncclAllGather");
+    R.AllReduce = (decltype(R.AllReduce))sym("ncclAllReduce");
+    R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+    R.GetVersion = (decltype(R.GetVersion))sym("ncclGetVersion");
+    Dl_info di;
+    if (R.AllGather && dladdr((void*)R.AllGather, &di) && di.dli_fname) R.path = di.dli_fname;
+  });
+  if (!R.error.empty()) { mpe_set_error_msg(R.error.c_str()); return nullptr; }
+  return &R;
+}
+
 static int nccl_fail(const char* what, ncclResult_t r) {
-  mpe_set_error_msg((std::string(what) + ": " + ncclGetErrorString(r)).c_str());
+  Rccl* R = rccl();
+  mpe_set_error_msg((std::string(what) + ": " + (R ? R->GetErrorString(r) : "no RCCL")).c_str());
   return MPE_E_HIP;
 }
 __global__ void pattern_kernel(uint32_t* buf, int rows_per_rank, int rank, int cols) {       // row id * 65536 + column, this rank's rows only
@@ -58,7 +122,9 @@ static int all_gather(mpe_comm* c, void* d_buf, size_t bytes_per_rank, hipStream
     (void)hipMemcpyAsync(c->copy, mine, bytes_per_rank, hipMemcpyDeviceToDevice, st);
     src = c->copy;
   }
-  const ncclResult_t r = ncclAllGather(src, d_buf, bytes_per_rank, ncclUint8, c->comm, st);
+  Rccl* R = rccl();
+  if (!R) return MPE_E_HIP;
+  const ncclResult_t r = R->AllGather(src, d_buf, bytes_per_rank, ncclUint8, c->comm, st);
   if (r != ncclSuccess) return nccl_fail("ncclAllGather", r);
   return MPE_OK;
 }
@@ -86,8 +152,10 @@ extern "C" {
 int mpe_comm_unique_id(uint8_t* h_id) {
   if (!h_id) return MPE_E_ARG;
   static_assert(MPE_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id travels as MPE_COMM_ID_BYTES opaque bytes");
+  mpe::cm::Rccl* R = mpe::cm::rccl();
+  if (!R) return MPE_E_HIP;
   ncclUniqueId id;
-  const ncclResult_t r = ncclGetUniqueId(&id);
+  const ncclResult_t r = R->GetUniqueId(&id);
   if (r != ncclSuccess) return mpe::cm::nccl_fail("ncclGetUniqueId", r);
   memcpy(h_id, id.internal, NCCL_UNIQUE_ID_BYTES);
   return MPE_OK;
@@ -95,13 +163,15 @@ int mpe_comm_unique_id(uint8_t* h_id) {
 
 int mpe_comm_create(mpe_ctx* ctx, const uint8_t* h_id, int rank, int world, mpe_comm** out) {
   if (!ctx || !h_id || !out || world < 1 || rank < 0 || rank >= world) return MPE_E_ARG;
+  mpe::cm::Rccl* R = mpe::cm::rccl();
+  if (!R) return MPE_E_HIP;
   mpe_comm* c = new (std::nothrow) mpe_comm();
   if (!c) return MPE_E_NOMEM;
   c->ctx = ctx; c->rank = rank; c->world = world;
   (void)hipSetDevice(ctx->device);
   ncclUniqueId id;
   memcpy(id.internal, h_id, NCCL_UNIQUE_ID_BYTES);
-  const ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+  const ncclResult_t r = R->CommInitRank(&c->comm, world, id, rank);
   if (r != ncclSuccess) { delete c; return mpe::cm::nccl_fail("ncclCommInitRank", r); }
   *out = c;
   return MPE_OK;
@@ -109,9 +179,19 @@ int mpe_comm_create(mpe_ctx* ctx, const uint8_t* h_id, int rank, int world, mpe_
 
 int mpe_comm_destroy(mpe_comm* c) {
   if (!c) return MPE_E_ARG;
-  if (c->comm) (void)ncclCommDestroy(c->comm);
+  if (c->comm) if (mpe::cm::Rccl* R = mpe::cm::rccl()) (void)R->CommDestroy(c->comm);
   if (c->copy) (void)hipFree(c->copy);
   delete c;
+  return MPE_OK;
+}
+// Which RCCL the communicator entry points are bound to: its file (dladdr of ncclAllGather), whether that copy was already in
+// the process when the library first needed it (*adopted = 1: e.g. PyTorch's), and ncclGetVersion.  Binds RCCL if nothing has yet.
+int mpe_comm_library(char* path_buf, size_t path_cap, int* adopted, int* version) {
+  mpe::cm::Rccl* R = mpe::cm::rccl();
+  if (!R) return MPE_E_HIP;
+  if (path_buf && path_cap) { strncpy(path_buf, R->path.c_str(), path_cap - 1); path_buf[path_cap - 1] = 0; }
+  if (adopted) *adopted = R->adopted ? 1 : 0;
+  if (version) { int v = 0; (void)R->GetVersion(&v); *version = v; }
   return MPE_OK;
 }
 int mpe_comm_rank(const mpe_comm* c) { return c ? c->rank : MPE_E_ARG; }
@@ -148,7 +228,7 @@ int mpe_comm_layout_self_test(mpe_comm* c, int rows_per_rank, int* h_mode, int* 
     if (rc != MPE_OK) break;
     hipLaunchKernelGGL(mpe::cm::pattern_check_kernel, dim3(mpe::blocks_for(rows * cols, 256)), dim3(256), 0, st, buf, rows, cols, flag);
     // every rank's count of misplaced words, summed: zero = right everywhere
-    const ncclResult_t r = ncclAllReduce(flag, flag + 1, 1, ncclInt32, ncclSum, c->comm, st);
+    const ncclResult_t r = mpe::cm::rccl()->AllReduce(flag, flag + 1, 1, ncclInt32, ncclSum, c->comm, st);      // (all_gather above succeeded: RCCL is bound)
     if (r != ncclSuccess) { rc = mpe::cm::nccl_fail("ncclAllReduce", r); break; }
     int32_t h[2] = {0, 0};
     if (hipMemcpyAsync(h, flag, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { mpe_set_error_msg("mpe_comm self-test: copy"); rc = MPE_E_HIP; break; }

@@ -105,19 +105,21 @@ __global__ void __launch_bounds__(64) fb_fill_kernel(int nrows, ModsetView ms, i
 template <class C>
 __global__ void __launch_bounds__(64) fb_modexp_kernel(int batch, ModsetView ms, Rows st_sel, int which,
                                                        const uint32_t* __restrict__ tab, int wb, Rows exps, int exp_words,
-                                                       uint32_t* __restrict__ out) {
+                                                       uint32_t* __restrict__ out, SchedArgs sched) {
   const int FB_WB = wb, FB_TE = 1 << wb, FB_MAX_WINDOWS = fb_windows(wb);
   __shared__ __attribute__((aligned(16))) uint32_t lds[C::LDS_WORDS];
   const Lane ln = make_lane<C>();
   uint32_t* gl = lds + ln.g * C::STRIDE;
   const int slot = blockIdx.x * C::GROUPS + ln.g;
   const int nslots = gridDim.x * C::GROUPS;
-  const int trips = (batch + nslots - 1) / nslots;
   const int nwin = (exp_words * 32 + FB_WB - 1) / FB_WB;
+  WaveSched ws;                                          // mpe_sched.h: which unit this wave runs next
+  ws.init(sched);
 #pragma unroll 1
-  for (int trip = 0; trip < trips; ++trip) {
-    if (trip * nslots + (int)blockIdx.x * C::GROUPS >= batch) break;       // no item left for this wave (wave-uniform)
-    const int inst = trip * nslots + slot;
+  for (;;) {
+    int ubase;
+    if (!ws.next(sched, batch, nslots, C::GROUPS, ubase)) break;           // nothing left for this wave (wave-uniform)
+    const int inst = ubase + ln.g;
     const bool active = inst < batch;
     const int idx = active ? inst : batch - 1;
     const int st = sel_index(st_sel, idx);

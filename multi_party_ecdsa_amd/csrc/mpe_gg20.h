@@ -260,10 +260,15 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC gw_kernel(Dim d, const uint32_t
 __global__ void __launch_bounds__(64) MPE_EC_OCC r0_kernel(Dim d, const uint32_t* __restrict__ xs, const uint32_t* __restrict__ k_in,
                           const uint32_t* __restrict__ gamma_in, const uint32_t* __restrict__ blind, uint32_t* __restrict__ kq,
                           uint32_t* __restrict__ gq, uint32_t* __restrict__ w, uint32_t* __restrict__ k64, uint32_t* __restrict__ g_gamma,
-                          uint32_t* __restrict__ com) {
+                          uint32_t* __restrict__ com, int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
   const int i = d.loc[pi % d.L], b = pi / d.L;
+  // k_i, gamma_i are `Scalar::random()` (party_i.rs:561-563): non-zero and below q.  Anything else is not a value the reference can
+  // hold — it is what the device sampler leaves when a rejection loop gave up (mpe_sample.h), or a caller's mistake — and the
+  // party stops here: status MPE_GG20_STATUS_BAD_NONCE, no message leaves it
+  const bool k_ok = ec::sc_is_canonical_nonzero(k_in + (size_t)pi * 8), g_ok = ec::sc_is_canonical_nonzero(gamma_in + (size_t)pi * 8);
+  if (!k_ok || !g_ok) fail(status, bad, pi, MPE_GG20_STATUS_BAD_NONCE, 0);
   const ec::U256 k = ec::sc_reduce(k_in + (size_t)pi * 8, 8), g = ec::sc_reduce(gamma_in + (size_t)pi * 8, 8);
   const ec::U256 wi = ec::sc_mul(lagrange0(d.sg, d.S, i), ec::sc_reduce(xs + (size_t)kown(d, b, i) * 8, 8));
   ec::u256_store(kq + (size_t)pi * 8, k);
@@ -761,10 +766,9 @@ struct mpe_gg20_session {
 namespace mpe {
 namespace gg {
 
-// MPE_GG20_TRACE=1 in the environment: synchronise after every step and report it on stderr (debug aid)
-static void gg_trace(hipStream_t st, const char* what, int rc) {
-  static const bool on = getenv("MPE_GG20_TRACE") != nullptr;
-  if (!on) return;
+// option gg20_trace (mpe_ctx_set_option): synchronise after every step and report it on stderr (debug aid)
+static void gg_trace(const mpe_ctx* ctx, hipStream_t st, const char* what, int rc) {
+  if (!ctx->gg20_trace) return;
   const hipError_t e = hipStreamSynchronize(st);
   fprintf(stderr, "[gg20] %-28s rc=%d sync=%s\n", what, rc, hipGetErrorString(e));
   fflush(stderr);
@@ -773,7 +777,7 @@ static void gg_trace(hipStream_t st, const char* what, int rc) {
   do {                                                                                                    \
     if (rc == MPE_OK && (nitems) > 0)                                                                     \
       hipLaunchKernelGGL(kernel, dim3(blocks_for((int)(nitems), 64)), dim3(64), 0, st, __VA_ARGS__);      \
-    gg_trace(st, #kernel, rc);                                                                            \
+    gg_trace(s->ctx, st, #kernel, rc);                                                                            \
   } while (0)
 
 struct Bump {
@@ -863,7 +867,7 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   mpe_ctx* ctx = s->ctx; const mpe_gg20_keys* K = s->K; const Dim& d = s->d; const Counts c = counts_of(d); const mpe_gg20_nonces& Z = s->Z;
   const int n = d.n;
   (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)msg_words(d.S, n, 0) * 4, st);
-  GG_LAUNCH(r0_kernel, c.nPI, d, K->x, Z.k, Z.gamma, Z.blind, s->kq, s->gq, s->w, s->k64, s->g_gamma, s->com);
+  GG_LAUNCH(r0_kernel, c.nPI, d, K->x, Z.k, Z.gamma, Z.blind, s->kq, s->gq, s->w, s->k64, s->g_gamma, s->com, STAT(0), BADR(0));
   // small batches: the encryption of k_i runs beside the first half of the range proofs (the proofs need c only for their
   // transcript hash); both composites draw from ONE workspace reservation
   const bool par = ctx->allow_par && (int)c.nAP <= ctx->par_items;
@@ -893,7 +897,7 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   }
   Fork g(ctx, st, 2, held, 2);
   if (rc == MPE_OK) rc = paillier_encrypt(ctx, K->prv, (int)c.nPI, s->ix.kown_pi, s->k64, Z.r_a, s->c_a, true, g.s(1), rn_pre);      // MessageA.c
-  gg_trace(st, "encrypt k", rc);
+  gg_trace(s->ctx, st, "encrypt k", rc);
   Bump t(s->tmp);
   mpe_alice_proof ap{t.w(c.nAP * 64), t.w(c.nAP * 8), t.w(c.nAP * 64), t.w(c.nAP * 25), t.w(c.nAP * 89)};
   mpe_alice_nonces an{Z.al_alpha, Z.al_beta, Z.al_gamma, Z.al_rho};
@@ -902,7 +906,7 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
                         rows(s->c_a, 128, s->ix.pi_ap), rows(Z.r_a, 64, s->ix.pi_ap), &an, &ap, st, &g, bn_pre);
   else g.join();
   if (held) ctx->ws_hold--;
-  gg_trace(st, "alice_generate", rc);
+  gg_trace(s->ctx, st, "alice_generate", rc);
   PACK(c.nAP, n, n + 1, 0, SUB0, 0, ap.z, 64); PACK(c.nAP, n, n + 1, 0, SUB0, 64, ap.e, 8); PACK(c.nAP, n, n + 1, 0, SUB0, 72, ap.s, 64);
   PACK(c.nAP, n, n + 1, 0, SUB0, 136, ap.s1, 25); PACK(c.nAP, n, n + 1, 0, SUB0, 161, ap.s2, 89);
   PACK(c.nPI, 1, n + 1, n, SUB0, 0, s->c_a, 128); PACK(c.nPI, 1, n + 1, n, SUB0, 128, s->com, 8);
@@ -982,7 +986,7 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   // verification, MessageB's encryption tail and DLog proofs) runs on forked streams behind the merged launch.
   const size_t resident_groups = (size_t)ctx->cus * ctx->modexp_waves_per_cu * 16 / ctx->device_share;
   const bool merged = ctx->merge_r1 && ctx->use_pair && ctx->use_multiexp && c.nVI > 0 && c.nMB > 0 && c.nVI + c.nMB < ((size_t)1 << 30) &&
-                      (!par || 4 * (c.nVI + c.nMB) > 3 * resident_groups);
+                      (!par || 4 * (c.nVI + c.nMB) > (size_t)ctx->merge_r1_quarters * resident_groups);
   if (par && !merged && rc == MPE_OK) { rc = ws_reserve(ctx, ws_need_alice_verify((int)c.nVI) + ws_need_mul_add_enc((int)c.nMB), st); if (rc == MPE_OK) ctx->ws_hold++; }
   bool held = par && !merged && rc == MPE_OK;
   const uint32_t *m_vi = nullptr, *x_mb = nullptr;
@@ -997,7 +1001,7 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
     if (rc == MPE_OK)
       rc = round1_merged_ladders(ctx, K->pub, c.nVI, s->ix.kpub_vi, rows(s->ca_all, 128, s->ix.ca_vi), with_words(pr.s, 64), pr.e, c.nMB, s->ix.kpub_mb,
                                  rows(s->ca_all, 128, s->ix.ca_mb), bsel, Z.mb_r, &m_vi, &inv_ok_vi, &x_mb, st);
-    gg_trace(st, "round 1 merged ladders", rc);
+    gg_trace(s->ctx, st, "round 1 merged ladders", rc);
   }
   Fork g(ctx, st, 2, held && par, 2);
   {
@@ -1007,7 +1011,7 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
     if (rc == MPE_OK)                                                           // encrypt, Paillier::mul, Paillier::add :133-145
       rc = paillier_mul_add_enc(ctx, K->pub, (int)c.nMB, s->ix.kpub_mb, rows(s->ca_all, 128, s->ix.ca_mb), rows(bsel, 8), 8, Z.mb_beta_tag,
                                 Z.mb_r, c_b, st2, x_mb);
-    gg_trace(st2, "MessageB ciphertext", rc);
+    gg_trace(s->ctx, st2, "MessageB ciphertext", rc);
     if (rc == MPE_OK && c.nMB > 0) {
       hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, ctx->enc, bsel, Z.mb_nonce_b, Bpk, BR, Bz);      // :147
       hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, ctx->enc, btq, Z.mb_nonce_bt, BTpk, BTR, BTz);   // :148
@@ -1015,7 +1019,7 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   }
   if (rc == MPE_OK)        // every range proof of every peer, for both MessageB::b calls (mta/mod.rs:119-131), read in place
     rc = alice_verify(ctx, K->pub, K->stm, (int)c.nVI, s->ix.kpub_vi, s->ix.st_vi, rows(s->ca_all, 128, s->ix.ca_vi), pr, ok_vi, st, m_vi, inv_ok_vi);
-  gg_trace(st, "alice_verify", rc);
+  gg_trace(s->ctx, st, "alice_verify", rc);
   g.join();
   if (held) ctx->ws_hold--;
   GG_LAUNCH(status1_kernel, c.nPI, d, ok_vi, STAT(1), BADR(1));
@@ -1042,7 +1046,7 @@ static int round2(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   GG_LAUNCH(idx2_kernel, c.nMB, d, in1, sub1_rv);
   if (rc == MPE_OK)      // Paillier::decrypt of the incoming c_b with my key (mta/mod.rs:165), in place
     rc = paillier_decrypt(ctx, K->prv, (int)c.nMB, s->ix.kown_mb, rows(d_in, SUB1, sub1_rv), alpha_full, st);
-  gg_trace(st, "decrypt", rc);
+  gg_trace(s->ctx, st, "decrypt", rc);
   const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 / ctx->device_share : 0;      // two waves per SIMD
   if (c.nMB * 4 <= lanes_fit) GG_LAUNCH(r2a_group_kernel, c.nMB * 4, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
   else GG_LAUNCH(r2a_kernel, c.nMB, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
@@ -1092,7 +1096,7 @@ static int round4(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
     rc = pdl_prove(ctx, K->prv, K->stm, (int)c.nPP, s->ix.kown_pp, s->ix.st_pp, rows(s->c_a, 128, s->ix.pi_pp), rows(s->Rbar, 16, s->ix.pi_pp),
                    rows(s->R, 16, s->ix.pi_pp), rows(s->kq, 8, s->ix.pi_pp), rows(Z.r_a, 64, s->ix.pi_pp), &pn, &pp, st, &g);
   else g.join();
-  gg_trace(st, "pdl_prove", rc);
+  gg_trace(s->ctx, st, "pdl_prove", rc);
   PACK(c.nPP, P1, S, 0, SUB4, 0, pp.z, 64); PACK(c.nPP, P1, S, 0, SUB4, 64, pp.u1, 16); PACK(c.nPP, P1, S, 0, SUB4, 80, pp.u2, 128);
   PACK(c.nPP, P1, S, 0, SUB4, 208, pp.u3, 64); PACK(c.nPP, P1, S, 0, SUB4, 272, pp.s1, 25); PACK(c.nPP, P1, S, 0, SUB4, 297, pp.s2, 64);
   PACK(c.nPP, P1, S, 0, SUB4, 361, pp.s3, 89);
@@ -1122,7 +1126,7 @@ static int round5(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   if (rc == MPE_OK)      // phase5_verify_pdl for every prover (mine included), G = the VERIFIER's R (rounds.rs:546-558)
     rc = pdl_verify(ctx, K->pub, K->stm, (int)c.nPV, s->ix.kpub_pv, s->ix.st_pv, rows(s->ca_all, 128, s->ix.ca_pv), rows(d_in, SUB4, rdash_pv),
                     rows(s->R, 16, s->ix.pi_pv), pr, ok_pv, st);
-  gg_trace(st, "pdl_verify", rc);
+  gg_trace(s->ctx, st, "pdl_verify", rc);
   g.join();
   GG_LAUNCH(r5_status_kernel, c.nPI, d, in4, ok_pv, STAT(5), BADR(5));
   PACK(c.nPI, 1, 1, 0, W5, 0, heg.S, 16); PACK(c.nPI, 1, 1, 0, W5, 16, heg.T, 16); PACK(c.nPI, 1, 1, 0, W5, 32, heg.A3, 16);

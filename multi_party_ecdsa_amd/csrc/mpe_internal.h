@@ -9,6 +9,7 @@
 
 #include "../../include/mpecdsa_hip.h"
 #include "mpe_kernels_heavy.h"
+#include "mpe_sched.h"
 
 struct mpe_ctx {
   int device = 0;
@@ -28,10 +29,15 @@ struct mpe_ctx {
                                   // heuristics below compare a launch with 1/device_share of the chip, not with all of it
   int xwide_div = 16;             // the 4x-lanes (5 limbs per lane) layout: xwide_div * batch <= the resident groups; 0 = off (MPE_XWIDE_DIV)
   bool merge_xn = true;           // round 0: every x^N of the key holders in ONE launch (MPE_NO_MERGE_XN switches it off)
+  int merge_r1_quarters = 3;      // small batches merge round 1's two ladder launches when together they exceed this many QUARTERS of the resident groups (option)
   bool merge_r1 = true;           // round 1, large batches: the ladders of the verifications and of the MessageBs in ONE launch (MPE_NO_MERGE_R1)
   size_t fb_budget_bytes = 0;     // memory budget of the fixed-base tables of a key object; 0 = a quarter of free HBM (MPE_FB_BUDGET_MB)
   int modexp_waves_per_cu = 8;    // 2 waves/SIMD: the montmul loop holds ~230 VGPRs and already issues back-to-back
-  int grid_mode = 2;              // persistent_grid(): 0 = equal trips (rounds 1-4), 1 = full trips + tail, 2 = tail only when it fits one wave per SIMD (MPE_GRID=equal|full|hybrid)
+  int fb_split = 0;               // fixed-base ladders: lane groups that share one item's windows (0 = chosen per launch, mpe_fixedbase.h)
+  int gg20_trace = 0;             // option gg20_trace: synchronise and report after every composite of a round
+  int sampler_max_attempts = 128; // rejection loops of the device sampler give up after this many candidates (mpe_sample.h)
+  int no_elect = 0;               // option no_elect: the dispatcher's placement is taken as it comes (rounds 1-5), mpe_sched.h
+  int grid_mode = 2;              // persistent_grid(): 0 = equal trips (rounds 1-4), 1 = full trips + tail, 2 = tail only when it fits one wave per SIMD (option grid = equal|full|hybrid)
   // window-table scratch, grown on demand: one buffer per stream slot (0 = the caller's stream, 1..3 = the auxiliary streams
   // on which small batches run independent launches concurrently)
   void* tables[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // slot 0: the caller's stream, 1..3: the auxiliary streams
@@ -113,6 +119,8 @@ int launch_modmul(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, R
                   hipStream_t st);
 int modset_create_dev(mpe_ctx* ctx, int bits, int count, const uint32_t* d_moduli, mpe_modset** out, hipStream_t st);
 
+// dst takes every run-time option (mpe_ctx_set_option) of src; defined beside the option table in mpe_lib.hip
+void ctx_copy_options(mpe_ctx* dst, const mpe_ctx* src);
 // per-launch timing records (mpe_prof_*), defined in mpe_lib.hip
 void prof_begin(mpe_ctx* ctx, hipStream_t st, int kind, int bits, int exp_words, int batch, int exp2_words = 0);
 void prof_end(mpe_ctx* ctx, hipStream_t st);
@@ -155,13 +163,37 @@ inline T* ws_array(mpe_ctx* ctx, size_t count) { return (T*)ws_alloc(ctx, count 
 
 inline int blocks_for(int n, int threads) { return (n + threads - 1) / threads; }
 
-// Persistent grid of the ladder kernels: `need` waves of work on `cap` resident wave slots (2 per SIMD).  A wave runs as long as ONE
-// ladder whatever shares its SIMD, but a wave that is alone on its SIMD issues ~1.6x faster than one of two.  So when the launch is
-// n.f passes with f <= 1/2, it is best run as n full trips and ONE tail trip whose f * cap waves sit alone on their SIMDs (grid = cap:
-// the hardware hands the workgroups round-robin to the CUs, the low-numbered waves that own the tail items end up one per SIMD): the
-// tail costs 0.6 of a trip instead of a whole one.  With f > 1/2 some SIMDs of the tail hold two waves and set its pace either way;
-// then n + 1 equal trips (rounds 1-4) keep fewer waves resident throughout.  Waves with no item left exit.
-// (MPE_GRID=equal | full | hybrid for A/B runs: profiles/r05/ab_grid.jsonl)
+// Persistent grid of the ladder kernels: `units` wave-units of work on `cap` resident wave slots (2 per SIMD).  What the per-wave
+// trace says (mpe_sched.h): a SIMD favours its older wave, two waves deliver 1.19x the units of one, and a launch lasts as long as
+// its slowest wave.  Hence
+//   units <= cap / 2          up to 2 x units workgroups start, the first arrival on every SIMD is its PRIMARY and only primaries take
+//                             units (a queue): never two units of the launch side by side on one SIMD, whatever the dispatcher does;
+//   cap / 2 < units <= cap    one workgroup per unit (most SIMDs hold two either way);
+//   n.f passes, f <= 1/2      n full trips on static units, then the primaries — the favoured wave of every SIMD — drain the tail
+//                             queue (`hybrid`, the default; `full`: for every f);
+//   n.f passes, f > 1/2       n + 1 EQUAL trips on a shrunk grid (rounds 1-4), which keeps fewer waves resident throughout
+//                             (`equal`: always).  Option no_elect = 1 restores the static tails and lone launches of round 5.
+// (option grid = equal | full | hybrid; A/B files: profiles/r05/ab_grid_three_modes.jsonl, profiles/r06/)
+inline bool ladder_tail_mode(const mpe_ctx* ctx, int units, int cap) {
+  const int rem = units % cap;
+  return units > cap && rem != 0 && (ctx->grid_mode == 1 || (ctx->grid_mode == 2 && 2 * rem <= cap));
+}
+inline int ladder_grid(const mpe_ctx* ctx, int units, int cap) {
+  if (units <= cap) return (!ctx->no_elect && 2 * units <= cap) ? 2 * units : units;
+  if (units % cap == 0 || ladder_tail_mode(ctx, units, cap)) return cap;
+  const int trips = (units + cap - 1) / cap;
+  return (units + trips - 1) / trips;
+}
+// the scheduler arguments of that launch; `state` (SCHED_WORDS ints of device scratch the launch owns) is zeroed on `st` when used
+inline SchedArgs ladder_sched(const mpe_ctx* ctx, int units, int cap, int32_t* state, hipStream_t st) {
+  SchedArgs a{nullptr, 0, 0};
+  if (ctx->no_elect || !state) return a;
+  if (2 * units <= cap) { a.state = state; a.full_trips = 0; a.tail_units = units; }
+  else if (ladder_tail_mode(ctx, units, cap)) { a.state = state; a.full_trips = units / cap; a.tail_units = units % cap; }
+  if (a.state) (void)hipMemsetAsync(a.state, 0, SCHED_WORDS * sizeof(int32_t), st);
+  return a;
+}
+// kernels WITHOUT the scheduler (modmul, the inversion sweeps): static units, the low block indices own the tail
 inline int persistent_grid(const mpe_ctx* ctx, int need, int cap) {
   if (need <= cap) return need;
   const int rem = need % cap;

@@ -2,6 +2,7 @@
 // (device code only; the C-ABI wrappers live in mpe_lib.hip)
 #pragma once
 #include "mpe_bigint.h"
+#include "mpe_sched.h"
 
 namespace mpe {
 
@@ -222,7 +223,7 @@ template <class C>
 __global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Rows mod_sel, Rows base_lo, Rows base_hi,
                                                     Rows exps, int exp_words, int wb, Rows base2, Rows exps2,
                                                     int exp2_words, uint32_t* __restrict__ out,
-                                                    uint32_t* __restrict__ tables) {
+                                                    uint32_t* __restrict__ tables, SchedArgs sched) {
   __shared__ uint32_t lds[C::LDS_WORDS];
   const Lane ln = make_lane<C>();
   uint32_t* gl = lds + ln.g * C::STRIDE;
@@ -233,7 +234,6 @@ __global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Ro
   // this group's window tables: tab[0..TE-1] = Mont(base^d); tab2[1..15] = Mont(base2^d) (digit 0 uses tab[0] = Mont(1))
   uint32_t* tab = tables + (size_t)slot * (TE + (dual ? 16 : 0)) * C::K;
   uint32_t* tab2 = tab + (size_t)TE * C::K;
-  const int trips = (batch + nslots - 1) / nslots;
   const int nwin = (exp_words * 32 + wb - 1) / wb;
   const int nwin2 = dual ? exp2_words * 8 : 0;
   const int top_bit = (nwin - 1) * wb;                   // the ladder squares top_bit times
@@ -247,10 +247,13 @@ __global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Ro
   //                        tab2[window] where a 4-bit window of exp2 starts
   //   PH_FINAL           : cur = cur * 1               -> leaves the Montgomery domain
 
+  WaveSched ws;                                          // mpe_sched.h: which unit this wave runs next
+  ws.init(sched);
 #pragma unroll 1
-  for (int trip = 0; trip < trips; ++trip) {
-    if (trip * nslots + (int)blockIdx.x * C::GROUPS >= batch) break;       // no item left for this wave (wave-uniform)
-    const int inst = trip * nslots + slot;
+  for (;;) {
+    int ubase;
+    if (!ws.next(sched, batch, nslots, C::GROUPS, ubase)) break;           // nothing left for this wave (wave-uniform)
+    const int inst = ubase + ln.g;
     const bool active = inst < batch;
     const int idx = active ? inst : batch - 1;
     const int mi = sel_index(mod_sel, idx);

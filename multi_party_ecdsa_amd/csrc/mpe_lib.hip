@@ -153,7 +153,8 @@ int modset_create_dev(mpe_ctx* ctx, int bits, int count, const uint32_t* d_modul
 template <class C>
 static int modexp_impl(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows base_lo, Rows base_hi, Rows exps,
                        int exp_words, Rows base2, Rows exps2, int exp2_words, uint32_t* d_out, hipStream_t st) {
-  const int grid = grid_for<C>(ctx, batch, ctx->modexp_waves_per_cu);
+  const int units = (batch + C::GROUPS - 1) / C::GROUPS, cap = ctx->cus * ctx->modexp_waves_per_cu;
+  const int grid = ladder_grid(ctx, units, cap);
   // window width: multiplications = E + E/wb + 2^wb; 4 bits up to 256-bit exponents, 5 up to ~1500, 6 beyond
   int wb = exp_words <= 8 ? 4 : (exp_words < 48 ? 5 : 6);
   if (ctx->window_bits) wb = ctx->window_bits;
@@ -163,11 +164,12 @@ static int modexp_impl(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_s
     return MPE_E_ARG;
   }
   const size_t need = (size_t)grid * C::GROUPS * (((size_t)1 << wb) + (dual ? 16 : 0)) * C::K * sizeof(uint32_t);
-  uint32_t* tabs = tables_for(ctx, need, st);
+  uint32_t* tabs = tables_for(ctx, need + SCHED_WORDS * sizeof(int32_t), st);
   if (!tabs) return MPE_E_NOMEM;
+  const SchedArgs sched = ladder_sched(ctx, units, cap, (int32_t*)((char*)tabs + need), st);
   prof_begin(ctx, st, 0, C::BITS, exp_words, batch, dual ? exp2_words : 0);
   hipLaunchKernelGGL(modexp_kernel<C>, dim3(grid), dim3(64), 0, st, batch, view_of(ms), mod_sel, base_lo, base_hi, exps,
-                     exp_words, wb, base2, exps2, exp2_words, d_out, tabs);
+                     exp_words, wb, base2, exps2, exp2_words, d_out, tabs, sched);
   prof_end(ctx, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("modexp_kernel", e); return MPE_E_HIP; }
@@ -306,6 +308,84 @@ int mpe_ctx_get_encoding(const mpe_ctx* ctx, mpe_encoding* out) {
   return MPE_OK;
 }
 
+// ---- run-time options (A/B switches of the measurements; none changes a result) -----------------------------------------------
+namespace mpe {
+struct CtxOption {
+  const char* key;
+  long lo, hi;                                   // accepted integer range (lo == hi == 0: an enumerated string)
+  void (*set)(mpe_ctx*, long);
+  long (*get)(const mpe_ctx*);
+};
+#define MPE_OPT_BOOL_OFF(name, field) {name, 0, 1, [](mpe_ctx* c, long v) { c->field = !v; }, [](const mpe_ctx* c) -> long { return c->field ? 0 : 1; }}
+#define MPE_OPT_INT(name, lo, hi, field) {name, lo, hi, [](mpe_ctx* c, long v) { c->field = (decltype(c->field))v; }, [](const mpe_ctx* c) -> long { return (long)c->field; }}
+static const CtxOption kCtxOptions[] = {
+    MPE_OPT_BOOL_OFF("no_fixed_base", use_fixed_base),       // no window tables for h1, h2
+    MPE_OPT_BOOL_OFF("no_crt", use_crt),                     // the key holder computes like a peer
+    MPE_OPT_BOOL_OFF("no_multiexp", use_multiexp),           // no two-base ladders
+    MPE_OPT_BOOL_OFF("no_pair", use_pair),                   // 4096-bit Montgomery kernel instead of the N-adic pair engine
+    MPE_OPT_BOOL_OFF("no_pown", use_pown),                   // no x^N = a^p shortcut
+    MPE_OPT_BOOL_OFF("no_sliding", use_sliding),             // fixed windows for the public exponent too
+    MPE_OPT_BOOL_OFF("no_par", allow_par),                   // one stream, no forks
+    MPE_OPT_BOOL_OFF("no_wide", adaptive_lanes),             // 18 limbs per lane always
+    MPE_OPT_BOOL_OFF("no_ec_lane_groups", ec_lane_groups),   // one item per lane in the EC round kernels
+    MPE_OPT_BOOL_OFF("no_merge_xn", merge_xn),               // round 0's x^N in separate launches
+    MPE_OPT_BOOL_OFF("no_merge_r1", merge_r1),               // round 1's verification and MessageB ladders in separate launches
+    MPE_OPT_INT("fb_window_bits", 4, 16, fb_window_bits),
+    MPE_OPT_INT("window_bits", 0, 6, window_bits),           // 0 = per exponent length
+    MPE_OPT_INT("wide_div", 1, 64, wide_div),
+    MPE_OPT_INT("merge_r1_quarters", 0, 64, merge_r1_quarters),
+    MPE_OPT_INT("xwide_div", 0, 1 << 20, xwide_div),
+    MPE_OPT_INT("waves_per_cu", 1, 8, modexp_waves_per_cu),
+    MPE_OPT_INT("grid_mode", 0, 2, grid_mode),               // 0 equal trips, 1 full trips + tail, 2 hybrid ("grid" takes the names)
+    MPE_OPT_INT("fb_split", 0, 64, fb_split),                // lane groups per fixed-base item (0 = chosen per launch)
+    MPE_OPT_INT("gg20_trace", 0, 1, gg20_trace),             // synchronise and report after every composite of a round (stderr)
+    MPE_OPT_INT("sampler_max_attempts", 1, 1 << 20, sampler_max_attempts),
+    MPE_OPT_INT("no_elect", 0, 1, no_elect),                 // ladder launches take the dispatcher's placement as it comes (mpe_sched.h)
+    {"fb_budget_mb", 0, 1 << 20, [](mpe_ctx* c, long v) { c->fb_budget_bytes = (size_t)v << 20; }, [](const mpe_ctx* c) -> long { return (long)(c->fb_budget_bytes >> 20); }},
+};
+#undef MPE_OPT_BOOL_OFF
+#undef MPE_OPT_INT
+extern "C++" void ctx_copy_options(mpe_ctx* dst, const mpe_ctx* src) {      // (this block sits inside the file's extern "C")
+  for (const CtxOption& o : kCtxOptions) o.set(dst, o.get(src));
+}
+}  // namespace mpe
+
+int mpe_ctx_set_option(mpe_ctx* ctx, const char* key, const char* value) {
+  if (!ctx || !key || !value) return MPE_E_ARG;
+  if (!strcmp(key, "grid")) {
+    const int m = !strcmp(value, "equal") ? 0 : (!strcmp(value, "full") ? 1 : (!strcmp(value, "hybrid") ? 2 : -1));
+    if (m < 0) { mpe_set_error_msg("mpe_ctx_set_option: grid = equal | full | hybrid"); return MPE_E_ARG; }
+    ctx->grid_mode = m;
+    return MPE_OK;
+  }
+  if (!strcmp(key, "no_adaptive_lanes")) {                    // = no_wide + no_ec_lane_groups
+    const bool off = atoi(value) != 0;
+    ctx->adaptive_lanes = !off; ctx->ec_lane_groups = !off;
+    return MPE_OK;
+  }
+  for (const mpe::CtxOption& o : mpe::kCtxOptions) {
+    if (strcmp(key, o.key)) continue;
+    char* end = nullptr;
+    const long v = strtol(value, &end, 10);
+    if (end == value || *end || v < o.lo || v > o.hi) {
+      mpe_set_error_msg((std::string("mpe_ctx_set_option: ") + key + " takes an integer in [" + std::to_string(o.lo) + ", " + std::to_string(o.hi) + "]").c_str());
+      return MPE_E_ARG;
+    }
+    o.set(ctx, v);
+    return MPE_OK;
+  }
+  mpe_set_error_msg((std::string("mpe_ctx_set_option: unknown option ") + key).c_str());
+  return MPE_E_ARG;
+}
+int mpe_ctx_get_option(const mpe_ctx* ctx, const char* key, long* value) {
+  if (!ctx || !key || !value) return MPE_E_ARG;
+  for (const mpe::CtxOption& o : mpe::kCtxOptions)
+    if (!strcmp(key, o.key)) { *value = o.get(ctx); return MPE_OK; }
+  return MPE_E_ARG;
+}
+int mpe_ctx_option_count(void) { return (int)(sizeof(mpe::kCtxOptions) / sizeof(mpe::kCtxOptions[0])); }
+const char* mpe_ctx_option_name(int i) { return (i >= 0 && i < mpe_ctx_option_count()) ? mpe::kCtxOptions[i].key : nullptr; }
+
 int mpe_ctx_create(mpe_ctx** out, int device) {
   if (!out) return MPE_E_ARG;
   hipError_t e = hipSetDevice(device);
@@ -318,26 +398,8 @@ int mpe_ctx_create(mpe_ctx** out, int device) {
   c->device = device;
   c->cus = prop.multiProcessorCount;
   mpe_encoding_default(&c->enc);
-  if (getenv("MPE_NO_FIXED_BASE")) c->use_fixed_base = false;     // A/B switches for measurements
-  if (getenv("MPE_NO_CRT")) c->use_crt = false;
-  if (getenv("MPE_NO_MULTIEXP")) c->use_multiexp = false;
-  if (getenv("MPE_NO_PAIR")) c->use_pair = false;
-  if (getenv("MPE_FB_WINDOW_BITS")) { const int w = atoi(getenv("MPE_FB_WINDOW_BITS")); if (w >= 4 && w <= 16) c->fb_window_bits = w; }
-  if (getenv("MPE_NO_POWN")) c->use_pown = false;
-  if (getenv("MPE_NO_SLIDING")) c->use_sliding = false;
-  if (getenv("MPE_NO_PAR")) c->allow_par = false;
-  if (getenv("MPE_NO_ADAPTIVE_LANES")) { c->adaptive_lanes = false; c->ec_lane_groups = false; }
-  if (getenv("MPE_NO_WIDE")) c->adaptive_lanes = false;
-  if (const char* e = getenv("MPE_WIDE_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->wide_div = v; }
-  // every switch is read HERE, once: no entry point reads the environment afterwards (contexts on several host threads)
-  if (const char* e = getenv("MPE_XWIDE_DIV")) { const int v = atoi(e); if (v >= 0) c->xwide_div = v; }
-  if (getenv("MPE_NO_MERGE_XN")) c->merge_xn = false;
-  if (getenv("MPE_NO_MERGE_R1")) c->merge_r1 = false;
-  if (getenv("MPE_GRID_EQUAL")) c->grid_mode = 0;
-  if (const char* e = getenv("MPE_WAVES_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) c->modexp_waves_per_cu = v; }   // A/B: 4 = one ladder wave per SIMD
-  if (const char* e = getenv("MPE_GRID")) c->grid_mode = !strcmp(e, "equal") ? 0 : (!strcmp(e, "full") ? 1 : 2);
-  if (const char* e = getenv("MPE_FB_BUDGET_MB")) c->fb_budget_bytes = (size_t)atoll(e) << 20;
-  if (getenv("MPE_WINDOW_BITS")) { const int w = atoi(getenv("MPE_WINDOW_BITS")); if (w >= 4 && w <= 6) c->window_bits = w; }
+  // (the library reads NO environment variable: every A/B switch of the measurements is an option set through
+  //  mpe_ctx_set_option below — the Python harness maps its MPE_* variables onto it, tests and tools call it directly)
   // comb tables of the two fixed secp256k1 generators: module globals, built ONCE per device (immutable afterwards — the only
   // process-wide state of the library; a second context never rewrites them under the kernels of the first)
   static std::once_flag comb_once[64];

@@ -29,3 +29,8 @@ int pair_modexp_1024(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
 }
 
 }  // namespace mpe
+
+#ifdef MPE_WAVE_TRACE
+extern "C" int mpe_wave_trace_arm_1024(void* d_buf, unsigned cap) { return mpe::wave_trace_arm_impl(d_buf, cap); }
+extern "C" int mpe_wave_trace_count_1024(unsigned* n) { return mpe::wave_trace_count_impl(n); }
+#endif

@@ -29,3 +29,8 @@ int pair_modexp_2048(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
 }
 
 }  // namespace mpe
+
+#ifdef MPE_WAVE_TRACE
+extern "C" int mpe_wave_trace_arm_2048(void* d_buf, unsigned cap) { return mpe::wave_trace_arm_impl(d_buf, cap); }
+extern "C" int mpe_wave_trace_count_2048(unsigned* n) { return mpe::wave_trace_count_impl(n); }
+#endif

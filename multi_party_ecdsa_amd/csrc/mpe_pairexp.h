@@ -173,93 +173,6 @@ __device__ __forceinline__ void cios2(uint32_t (&res)[C::L], uint64_t (&c)[C::L]
   cios_finish<C>(res, c, ln);
 }
 
-// ---- the same passes with the multiplier limbs QUEUED two steps ahead (MPE_BQ) ---------------------------------------------------
-// Where the waiting is (profiles/r03/pmc_stall_wave_cycles.json: 13.6 % of the wave cycles in s_waitcnt; the ISA of the loops
-// above): hipcc issues the ds_read of a trip's first multiplier limbs at the TOP of the 18-step trip and waits for them three
-// instructions later — a full LDS latency, 7 times per pass (more in the two-stream pass) — and when both waves of a SIMD sit
-// there the multiplier idles (VALU port 87.5 % busy).  Source-level software pipelining does not survive the compiler (it sinks
-// the loop-carried reads back to the loop top: tried, profiles/r04/README.md).  So the reads are issued BY HAND: limbs travel in
-// pairs (one ds_read_b64 per two steps) through three 64-bit registers; at the first step of pair h the read of pair h+2 is
-// issued and `s_waitcnt lgkmcnt(2)` lets exactly the two youngest reads stay in flight — LDS operations of a wave complete in
-// order, so pair h has landed whatever else the compiler queued in between (its own ds_writes of the quotient digits only make
-// the wait longer, never shorter).  The wait is tied to the destination register ("+v"), so no use can be scheduled above it.
-// hipcc does not know the register is pending between the two statements: tools/check_bq_isa.py verifies in the emitted ISA that
-// nothing reads, writes, copies or spills a destination between its ds_read and its wait (build.sh runs it).
-template <int OFF>
-__device__ __forceinline__ void bq_issue(uint64_t& d, uint32_t lds_addr) {
-  // "+v": the destination is TIED to the register the previous pair of this slot lived in — one register per slot for the whole
-  // pass, so the loop-carried value needs no copy (a copy of a register whose read is still in flight would copy stale bits)
-  asm volatile("ds_read_b64 %0, %1 offset:%2 ; BQ_ISSUE %0" : "+v"(d) : "v"(lds_addr), "n"(OFF) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void bq_wait(uint64_t& d) {         // at most the N youngest LDS operations may still be in flight
-  asm volatile("s_waitcnt lgkmcnt(%1) ; BQ_WAIT %0" : "+v"(d) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void bq_wait(uint64_t& d, uint64_t& e) {
-  asm volatile("s_waitcnt lgkmcnt(%2) ; BQ_WAIT %0 ; BQ_WAIT %1" : "+v"(d), "+v"(e) : "n"(N));
-}
-__device__ __forceinline__ uint32_t lds_byte_address(const uint32_t* p) {
-  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)p;
-}
-template <class C>
-constexpr bool bq_layout_ok() { return C::L % 6 == 0; }       // pairs of limbs, three registers: L/2 pairs per trip, a multiple of 3
-
-template <class C, bool STORE_M>
-__device__ __forceinline__ void cios1q(uint32_t (&res)[C::L], uint64_t (&c)[C::L], const uint32_t (&a)[C::L],
-                                       const uint32_t* __restrict__ bl, uint32_t* __restrict__ ml,
-                                       const uint32_t (&n)[C::L], uint32_t n0inv, const Lane& ln) {
-  constexpr int L = C::L, W = C::W;
-  static_assert(bq_layout_ok<C>(), "cios1q needs L % 6 == 0");
-  uint32_t maskv = C::MASK;
-  asm volatile("" : "+v"(maskv));
-  uint64_t q0, q1, q2;                                         // pair h of a trip lives in q(h % 3)
-  asm volatile("" : "=v"(q0), "=v"(q1), "=v"(q2));             // (defined, contents irrelevant: the first issue overwrites them)
-  const uint32_t base = lds_byte_address(bl);
-  bq_issue<0>(q0, base);
-  bq_issue<8>(q1, base);
-#pragma unroll 1
-  for (int jj = 0;; ++jj) {
-    uint32_t* mp = ml + jj * L;
-    const uint32_t at = base + (uint32_t)(jj * L * 4);
-    auto step = [&](auto rc) {
-      constexpr int r = decltype(rc)::value;
-      constexpr int h = r / 2;
-      if constexpr (r % 2 == 0) {
-        // pair h + 2 (pairs L/2 and L/2 + 1 are the first two of the next trip: the limbs are contiguous; in the last trip they are
-        // reads past the multiplier, into the group's own LDS region — harmless, drained after the loop).  ALWAYS issued: every
-        // slot is re-armed right after its last use, on every path, so its register is one unbroken live range
-        if constexpr ((h + 2) % 3 == 0) bq_issue<8 * (h + 2)>(q0, at); else if constexpr ((h + 2) % 3 == 1) bq_issue<8 * (h + 2)>(q1, at); else bq_issue<8 * (h + 2)>(q2, at);
-        // pair h is due: exactly two younger reads are in flight
-        if constexpr (h % 3 == 0) bq_wait<2>(q0); else if constexpr (h % 3 == 1) bq_wait<2>(q1); else bq_wait<2>(q2);
-      }
-      const uint64_t qv = (h % 3 == 0) ? q0 : ((h % 3 == 1) ? q1 : q2);
-      const uint32_t bj = (r & 1) ? (uint32_t)(qv >> 32) : (uint32_t)qv;
-      c[r] += (uint64_t)a[0] * bj;
-      const uint32_t m = bcast0_masked<C::TPI>((uint32_t)c[r] * n0inv, maskv);
-      if (STORE_M) mp[r] = m;                    // every lane of the group writes the same word
-#pragma unroll
-      for (int i = 1; i < L; ++i) c[(r + i) % L] += (uint64_t)a[i] * bj;
-#pragma unroll
-      for (int i = 0; i < L; ++i) c[(r + i) % L] += (uint64_t)m * n[i];
-      c[(r + 1) % L] += c[r] >> W;
-      c[r] = (uint64_t)(pull_next((uint32_t)c[r]) & maskv);
-    };
-    static_for<0, C::STEPS % L>(step);
-    if (jj == C::STEPS / L) break;                            // the ONLY exit: after STEPS steps (R = 2^(W STEPS))
-    static_for<C::STEPS % L, L>(step);
-  }
-  // the reads the last pairs of the last trip asked for are still in flight: let them land before their registers are reused
-  static_assert((C::STEPS % C::L) >= C::L - 2 || (C::STEPS % C::L) == 0, "the exit must lie in the trip's last pair");
-  bq_wait<0>(q0, q1);
-  bq_wait<0>(q2);
-  cios_finish<C>(res, c, ln);
-}
-
-// (The two-stream pass has no queued form: six live 64-bit slots do not survive the register allocator at 256 VGPRs — the checker
-// found copies of registers whose read was still in flight in every attempt, profiles/r04/README.md — so multiplications keep
-// cios2 under MPE_BQ.)
-
 // (r0, r1) = (a0, a1) * (y0, y1) R^-1 in Z/N^2.  The group's LDS region holds y0 in B0 and y1 in B1; for a squaring
 // (sq: y == a) B1 holds 2 y0 instead, so that pass B is the single stream a1 * (2 a0).
 // Column bound: a pass-B column absorbs per lane block 18 x (2^59.01 + 2^58.01) (squaring: the doubled stream) or
@@ -273,10 +186,6 @@ __device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::
   uint64_t c[L];
 #pragma unroll
   for (int i = 0; i < L; ++i) c[i] = 0;
-#ifdef MPE_BQ
-  if constexpr (bq_layout_ok<C>()) cios1q<C, true>(r0, c, a0, gl + PL::B0, gl + PL::M, n, n0inv, ln);
-  else
-#endif
   cios1<C, true>(r0, c, a0, gl + PL::B0, gl + PL::M, n, n0inv, ln);           // pass A: u, digits -> M
   wave_lds_sync();
   if (half) {                                      // arithmetic modulo N only: the x1 components stay 0
@@ -298,15 +207,6 @@ __device__ __forceinline__ void pairmul(uint32_t (&r0)[C::L], uint32_t (&r1)[C::
   // u waits in the M region (its digits are consumed) so that pass B does not carry 18 more live registers
 #pragma unroll
   for (int i = 0; i < L; ++i) gl[PL::M + ln.t * L + i] = r0[i];
-#ifdef MPE_BQ
-  if constexpr (bq_layout_ok<C>()) {
-    if (sq) {
-      cios1q<C, false>(r1, c, a1, gl + PL::B1, gl + PL::M, n, n0inv, ln);     // pass B: a1 * (2 a0) - m
-    } else {
-      cios2<C>(r1, c, a0, a1, gl + PL::B0, gl + PL::B1, n, n0inv, ln);        // pass B: a0 * y1 + a1 * y0 - m
-    }
-  } else
-#endif
   if (sq) {
     cios1<C, false>(r1, c, a1, gl + PL::B1, gl + PL::M, n, n0inv, ln);        // pass B: a1 * (2 a0) - m
   } else {
@@ -509,18 +409,17 @@ static __global__ void __launch_bounds__(256) key_scatter_kernel(int batch, Rows
   if (mi >= 0) perm[sh[nkeys + mi] + local] = i;
 }
 
-// The sliding decision of pair_modexp_kernel<C, true>, replayed per (wave, trip) for the profiler (mpe_prof_rec.sliding_frac): a
-// wave slides iff its GROUPS exponentiations read the same exponent row and the first window stays above a second exponent.
-static __global__ void pair_slide_audit_kernel(int batch, int grid, int trips, int groups, Rows exps, int exp_words, int wb, int exp2_words,
+// The sliding decision of pair_modexp_kernel<C, true>, replayed per UNIT (the `groups` consecutive positions one wave carries through
+// one ladder — whichever wave the scheduler gives it to) for the profiler (mpe_prof_rec.sliding_frac): a unit slides iff its
+// exponentiations read the same exponent row and the first window stays above a second exponent.
+static __global__ void pair_slide_audit_kernel(int batch, int groups, Rows exps, int exp_words, int wb, int exp2_words,
                                                const int32_t* __restrict__ perm, uint32_t* __restrict__ ctr) {
-  const int wt = blockIdx.x * blockDim.x + threadIdx.x;
-  if (wt >= grid * trips) return;
-  const int wave = wt % grid, trip = wt / grid, nslots = grid * groups;
-  if (trip * nslots + wave * groups >= batch) return;           // that wave had no item left in that trip: it exited
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u * groups >= batch) return;
   const uint32_t* first = nullptr;
   bool same = true;
   for (int g = 0; g < groups; ++g) {
-    const int inst = trip * nslots + wave * groups + g;
+    const int inst = u * groups + g;
     const int pos = inst < batch ? inst : batch - 1;
     const uint32_t* ex = row_of(exps, perm ? perm[pos] : pos);
     if (g == 0) first = ex; else same = same && ex == first;
@@ -532,11 +431,21 @@ static __global__ void pair_slide_audit_kernel(int batch, int grid, int trips, i
   atomicAdd(ctr, 1u);
 }
 
+#ifdef MPE_WAVE_TRACE
+// PROFILING BUILD ONLY (build.sh -DMPE_WAVE_TRACE -> a library of its own, loaded through MPE_LIB_PATH by tools/trace_waves.py; never
+// shipped): every (wave, trip) of the ladder kernel leaves one record — where it ran (HW_ID, XCC_ID) and when (s_memtime = the
+// shader-clock counter, s_memrealtime = the constant 100 MHz counter; their ratio is the clock the wave really saw).  Written to
+// settle round 5's open question: why a FRESH launch of <= 1 024 ladder waves runs its trip at 0.95 of a shared trip while the
+// TAIL of a full grid runs it at 0.49 — placement, clock, or issue arbitration.
+static __device__ unsigned long long* g_wave_trace;
+static __device__ unsigned g_wave_trace_cap, g_wave_trace_n;
+#endif
+
 template <class C, bool SLIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) pair_modexp_kernel(int batch, PairsetView ps, Rows mod_sel, Rows base, Rows exps,
                                                          int exp_words, int wb, Rows base2, Rows exps2, int exp2_words,
                                                          int half, uint32_t* __restrict__ out, uint32_t* __restrict__ tables,
-                                                         const int32_t* __restrict__ perm, int slide) {
+                                                         const int32_t* __restrict__ perm, int slide, SchedArgs sched) {
   using PL = PairLds<C>;
   __shared__ __attribute__((aligned(16))) uint32_t lds[PL::WORDS];
   const Lane ln = make_lane<C>();
@@ -548,16 +457,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int TE = 1 << wb;
   uint32_t* tab = tables + (size_t)slot * (TE + (dual ? 16 : 0)) * K2;
   uint32_t* tab2 = tab + (size_t)TE * K2;
-  const int trips = (batch + nslots - 1) / nslots;
   const int nwin = (exp_words * 32 + wb - 1) / wb;
   const int nwin2 = dual ? exp2_words * 8 : 0;
   const int top_bit = (nwin - 1) * wb;
   const int words1 = base.words ? base.words : 2 * C::K32, words2 = base2.words ? base2.words : 2 * C::K32;
+  WaveSched ws;                                                // mpe_sched.h: static trips, then (primaries only) the queue of tail units
+  ws.init(sched);
 
 #pragma unroll 1
-  for (int trip = 0; trip < trips; ++trip) {
-    if (trip * nslots + (int)blockIdx.x * C::GROUPS >= batch) break;       // no item left for this wave (wave-uniform): it leaves its SIMD to the others
-    const int inst = trip * nslots + slot;
+  for (;;) {
+    int ubase;
+    if (!ws.next(sched, batch, nslots, C::GROUPS, ubase)) break;           // nothing left for this wave (wave-uniform): it leaves its SIMD to the others
+#ifdef MPE_WAVE_TRACE
+    const int trip = ws.trip - 1;
+    const unsigned long long wt_m0 = __builtin_amdgcn_s_memtime(), wt_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int inst = ubase + ln.g;
     const bool active = inst < batch;
     const int pos = active ? inst : batch - 1;
     const int idx = (SLIDE && perm) ? perm[pos] : pos;        // perm: the launch's items ordered by key (sliding windows)
@@ -750,6 +665,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     store_limbs_as_words<C>(out + (size_t)idx * 2 * C::K32, gl, cur0, active, ln);
     store_limbs_as_words<C>(out + (size_t)idx * 2 * C::K32 + C::K32, gl, cur1, active, ln);
+#ifdef MPE_WAVE_TRACE
+    if (g_wave_trace && threadIdx.x == 0) {
+      const unsigned long long wt_m1 = __builtin_amdgcn_s_memtime(), wt_r1 = __builtin_amdgcn_s_memrealtime();
+      const unsigned at = atomicAdd(&g_wave_trace_n, 1u);
+      if (at < g_wave_trace_cap) {
+        unsigned long long* w = g_wave_trace + (size_t)at * 8;
+        w[0] = ((unsigned long long)gridDim.x << 32) | blockIdx.x;
+        w[1] = ((unsigned long long)(unsigned)batch << 32) | ((unsigned)trip << 16) | ((unsigned)C::L << 8) | ((unsigned)(ws.role != 0) << 2) | ((unsigned)(half != 0) << 1) | (unsigned)(SLIDE ? 1 : 0);
+        w[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID | HW_ID
+        w[3] = wt_m0; w[4] = wt_m1; w[5] = wt_r0; w[6] = wt_r1;
+        w[7] = ((unsigned long long)(unsigned)C::BITS << 32) | (unsigned)exp_words;
+      }
+    }
+#endif
   }
 }
 
@@ -771,6 +700,20 @@ __global__ void pair_finish_kernel(int B, Rows mod_sel, const uint32_t* __restri
 
 // host side: template implementations, instantiated by mpe_pair2048.hip / mpe_pair1024.hip ----------------
 namespace mpe {
+
+#ifdef MPE_WAVE_TRACE
+// arm (buf = device memory for cap records of 8 x u64; nullptr switches the trace off) / read back the record count of THIS unit
+static int wave_trace_arm_impl(void* buf, unsigned cap) {
+  const unsigned zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_trace), &buf, sizeof buf) != hipSuccess) return MPE_E_HIP;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_trace_cap), &cap, sizeof cap) != hipSuccess) return MPE_E_HIP;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_trace_n), &zero, sizeof zero) != hipSuccess) return MPE_E_HIP;
+  return MPE_OK;
+}
+static int wave_trace_count_impl(unsigned* n) {
+  return hipMemcpyFromSymbol(n, HIP_SYMBOL(g_wave_trace_n), sizeof *n) == hipSuccess ? MPE_OK : MPE_E_HIP;
+}
+#endif
 
 template <class C>
 int pairset_create_impl(int count, const uint32_t* d_moduli, mpe_pairset** out, hipStream_t st) {
@@ -802,7 +745,8 @@ int pairset_create_impl(int count, const uint32_t* d_moduli, mpe_pairset** out, 
 template <class C>
 int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
                      Rows base2, Rows exps2, int exp2_words, int half, uint32_t* d_out, hipStream_t st, int public_exp) {
-  const int grid = persistent_grid(ctx, (batch + C::GROUPS - 1) / C::GROUPS, ctx->cus * ctx->modexp_waves_per_cu);
+  const int units = (batch + C::GROUPS - 1) / C::GROUPS;
+  const int grid = ladder_grid(ctx, units, ctx->cus * ctx->modexp_waves_per_cu);
   int wb = exp_words <= 8 ? 4 : (exp_words < 48 ? 5 : 6);
   if (ctx->window_bits) wb = ctx->window_bits;
   const bool dual = base2.p != nullptr;
@@ -815,9 +759,10 @@ int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
   // share it.  With several keys in the launch the items are first ordered by key (perm): three small kernels.
   const int slide = (public_exp && ctx->use_sliding && !half && exp_words >= 16 && wb >= 5) ? 1 : 0;
   const bool by_key = slide && ps->count > 1 && (mod_sel.idx || mod_sel.stride) && ps->count <= 4096 && batch > C::GROUPS;
-  const size_t extra = by_key ? ((size_t)batch + 2 * (size_t)ps->count + 64) * sizeof(int32_t) : 0;
+  const size_t extra = (by_key ? ((size_t)batch + 2 * (size_t)ps->count + 64) * sizeof(int32_t) : 0) + SCHED_WORDS * sizeof(int32_t);
   uint32_t* tabs = tables_for(ctx, need + extra, st);
   if (!tabs) return MPE_E_NOMEM;
+  const SchedArgs sched = ladder_sched(ctx, units, ctx->cus * ctx->modexp_waves_per_cu, (int32_t*)((char*)tabs + need + extra) - SCHED_WORDS, st);
   const int32_t* perm = nullptr;
   if (by_key) {
     int32_t* pm = (int32_t*)((char*)tabs + need);
@@ -834,18 +779,17 @@ int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
   prof_begin(ctx, st, half ? 4 : (slide ? 6 : 3), half ? C::BITS : 2 * C::BITS, exp_words, batch, dual ? exp2_words : 0);
   if (slide)
     hipLaunchKernelGGL((pair_modexp_kernel<C, true>), dim3(grid), dim3(64), 0, st, batch, v, mod_sel, base, exps, exp_words, wb, base2,
-                       exps2, exp2_words, half, d_out, tabs, perm, slide);
+                       exps2, exp2_words, half, d_out, tabs, perm, slide, sched);
   else
     hipLaunchKernelGGL((pair_modexp_kernel<C, false>), dim3(grid), dim3(64), 0, st, batch, v, mod_sel, base, exps, exp_words, wb, base2,
-                       exps2, exp2_words, half, d_out, tabs, perm, slide);
+                       exps2, exp2_words, half, d_out, tabs, perm, slide, sched);
   prof_end(ctx, st);
   if (slide) {
     // profiling only: "kind 6" says the launch was ALLOWED to slide; whether a wave does is decided at run time.  A counter
     // inside the hot kernel perturbs its register allocation (measured: +0.6 % kernel time, profiles/r04/ab_kernel_variants.json),
     // so the decision is REPLAYED by a one-thread-per-(wave, trip) audit kernel with the kernel's own rule and geometry.
-    const int nslots = grid * C::GROUPS, trips = (batch + nslots - 1) / nslots;
-    if (uint32_t* ctr = prof_counter(ctx, (batch + C::GROUPS - 1) / C::GROUPS))       // the (wave, trip) pairs that hold at least one item
-      hipLaunchKernelGGL(pair_slide_audit_kernel, dim3(blocks_for(grid * trips, 64)), dim3(64), 0, st, batch, grid, trips, (int)C::GROUPS, exps,
+    if (uint32_t* ctr = prof_counter(ctx, units))                                      // the units of the launch
+      hipLaunchKernelGGL(pair_slide_audit_kernel, dim3(blocks_for(units, 64)), dim3(64), 0, st, batch, (int)C::GROUPS, exps,
                          exp_words, wb, dual ? exp2_words : 0, perm, ctr);
   }
   hipLaunchKernelGGL(pair_finish_kernel<C::K32>, dim3(blocks_for(batch, 64)), dim3(64), 0, st, batch, mod_sel, ps->mod_words, d_out);

@@ -17,8 +17,22 @@
 //     was built and measured: the sampler's small kernels starve behind the other lane's persistent ladders and the lanes wait for
 //     them — 14.8 k against 15.8 k signatures/s; dropped.)
 // Results are bit-identical to mpe_gg20_sign on the same inputs: a session's outputs do not depend on its neighbours in a batch.
+//
+// Failure contract (round 6; the reference reports per session and never loses an error: gg_2020/mod.rs:23-27, rounds.rs:696-713):
+// when the pass of a group fails as a whole (MPE_E_NOMEM / MPE_E_HIP from the sampler or from mpe_gg20_sign) EVERY batch of the
+// group learns it — its d_status is filled with MPE_GG20_STATUS_PASS_FAILED(rc) and its r / s / recid (/ R) zeroed on the lane's
+// stream, the ticket keeps rc, and wait / query / stream_wait / latency_ms / pass_ms of that ticket return it.  The next group is
+// not affected.  mpe_gg20_pipeline_inject_fault makes the next passes fail that way (tests).
+//
+// When does a part-filled group go?  (1) full; (2) flush / wait on one of its tickets; (3) `deadline`: its oldest batch has
+// waited T microseconds of host time; (4) `eager`: the lane it would run on is idle — arrival-driven grouping: under a trickle
+// every batch starts at once (lowest latency), under load the lanes are busy and the groups fill by themselves.  (3) and (4)
+// are evaluated inside every submit / query / poll call — the ONE host thread that drives the pipeline; there is no hidden thread.
+// A new group opens on an idle lane if there is one, otherwise on the next lane in turn.
 // Included by mpe_lib.hip after mpe_sample.h.
 #pragma once
+#include <chrono>
+
 #include "mpe_sample.h"
 
 struct mpe_gg20_pipeline {
@@ -26,6 +40,10 @@ struct mpe_gg20_pipeline {
   mpe_ctx* parent = nullptr;
   const mpe_gg20_keys* K = nullptr;
   int batch = 0, group = 0, lanes = 0, dedup = 0;
+  int64_t deadline_us = -1;                   // < 0: no deadline
+  int eager = 0;                              // launch a part-filled group as soon as its lane is idle
+  int fail_next = 0, fail_rc = MPE_E_NOMEM;   // fault injection: that many next passes fail with fail_rc
+  using Clock = std::chrono::steady_clock;
   struct Out { uint32_t *r, *s, *R; int32_t *recid, *status; };
   struct Lane {
     mpe_ctx* ctx = nullptr;
@@ -42,12 +60,14 @@ struct mpe_gg20_pipeline {
     uint64_t counters[mpe::smp::MAX_SLOTS];
     Out dst[MAX_GROUP];
     uint64_t ticket[MAX_GROUP];
+    uint64_t last_ticket = 0;                 // the last batch of the last pass queued on this lane (idle test)
+    Clock::time_point oldest;                 // host time of the open group's first submission
   } lane[MAX_LANES];
-  struct Ticket { uint64_t id = 0, begin_of = 0; hipEvent_t submitted = nullptr, begin = nullptr, done = nullptr; int lane = -1; bool launched = false, used = false; };
+  struct Ticket { uint64_t id = 0, begin_of = 0; hipEvent_t submitted = nullptr, begin = nullptr, done = nullptr; int lane = -1, rc = MPE_OK; bool launched = false, used = false; };
   Ticket ring[RING];
   int cur = 0;
   uint64_t next_ticket = 1;
-  uint64_t launched_groups = 0;
+  uint64_t launched_groups = 0, launched_by_deadline = 0, launched_by_idle = 0, failed_groups = 0;
 };
 
 namespace mpe {
@@ -57,6 +77,22 @@ static mpe_gg20_pipeline::Ticket* ticket_of(mpe_gg20_pipeline* p, uint64_t id) {
   if (id == 0 || id >= p->next_ticket) return nullptr;
   mpe_gg20_pipeline::Ticket* t = &p->ring[id % mpe_gg20_pipeline::RING];
   return (t->used && t->id == id) ? t : nullptr;
+}
+
+// every ticket of a failed pass reports it: status = MPE_GG20_STATUS_PASS_FAILED(rc) for every session, no signature
+__global__ void fill_i32_kernel(int32_t* __restrict__ p, int n, int32_t v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+static void wipe_bytes(void* p, size_t n) {                   // not elidable
+  volatile uint8_t* v = (volatile uint8_t*)p;
+  for (size_t i = 0; i < n; ++i) v[i] = 0;
+}
+static bool lane_idle(mpe_gg20_pipeline* p, int li) {
+  mpe_gg20_pipeline::Lane& L = p->lane[li];
+  if (!L.last_ticket) return true;
+  mpe_gg20_pipeline::Ticket* t = ticket_of(p, L.last_ticket);
+  return !t || !t->launched || hipEventQuery(t->done) == hipSuccess;      // (a recycled ring slot: that pass ended long ago)
 }
 
 // the open group of lane `li` goes to the device: one pass over filled * batch sessions, then every batch's results to its owner
@@ -73,9 +109,24 @@ static int launch_group(mpe_gg20_pipeline* p, int li) {
     int32_t local[8];
     for (int i = 0; i < p->K->S; ++i) local[i] = i;
     rc = mpe::smp::sample_gg20(L.ctx, p->K, p->batch, L.filled, p->K->S, local, ks, L.seeds, L.counters, &Z, L.fail, L.st);
+    // the seeds derive every nonce of their batches: as sensitive as the key share, gone from host memory once the sampler is queued
+    // (the kernel arguments were copied at launch)
+    wipe_bytes(L.seeds, sizeof L.seeds);
+    wipe_bytes(L.counters, sizeof L.counters);
+  }
+  if (rc == MPE_OK && p->fail_next > 0) {       // fault injection (tests): the pass fails as a whole, after its inputs were staged
+    --p->fail_next;
+    rc = p->fail_rc;
+    mpe_set_error_msg("gg20 pipeline: injected pass failure");
   }
   if (rc == MPE_OK)
     rc = mpe_gg20_sign(L.ctx, p->K, B, ks, &Z, L.res.r, L.res.s, L.res.recid, L.res.R, L.res.status, p->dedup, 0, L.st);
+  if (rc == MPE_OK) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mpe_set_error("gg20 pipeline launch", e); rc = MPE_E_HIP; }
+  } else {
+    (void)hipGetLastError();
+  }
   for (int g = 0; g < L.filled; ++g) {
     const size_t o = (size_t)g * p->batch, nb = (size_t)p->batch;
     const mpe_gg20_pipeline::Out& d = L.dst[g];
@@ -85,27 +136,55 @@ static int launch_group(mpe_gg20_pipeline* p, int li) {
       (void)hipMemcpyAsync(d.recid, L.res.recid + o, nb * 4, hipMemcpyDeviceToDevice, L.st);
       (void)hipMemcpyAsync(d.status, L.res.status + o, nb * 4, hipMemcpyDeviceToDevice, L.st);
       if (d.R) (void)hipMemcpyAsync(d.R, L.res.R + o * 16, nb * 64, hipMemcpyDeviceToDevice, L.st);
+    } else {                                    // the owner of EVERY batch of the group reads the failure in its own arrays
+      hipLaunchKernelGGL(fill_i32_kernel, dim3(mpe::blocks_for((int)nb, 256)), dim3(256), 0, L.st, d.status, (int)nb, (int32_t)MPE_GG20_STATUS_PASS_FAILED(rc));
+      (void)hipMemsetAsync(d.r, 0, nb * 32, L.st);
+      (void)hipMemsetAsync(d.s, 0, nb * 32, L.st);
+      (void)hipMemsetAsync(d.recid, 0, nb * 4, L.st);
+      if (d.R) (void)hipMemsetAsync(d.R, 0, nb * 64, L.st);
     }
   }
-  // the staged nonces (k_i, gamma_i, Paillier randomness) and signatures of this group do not wait for the next one to overwrite them
+  // the staged sampled values (k_i, gamma_i, Paillier randomness) of this group do not wait for the next one to overwrite them,
+  // nor do the lane's copies of the signatures (the owners have theirs)
   (void)hipMemsetAsync(L.stage->blob, 0, L.stage->bytes, L.st);
+  (void)hipMemsetAsync(L.res.r, 0, (size_t)B * 8 * 4, L.st);
+  (void)hipMemsetAsync(L.res.s, 0, (size_t)B * 8 * 4, L.st);
   mpe_gg20_pipeline::Ticket* t0 = ticket_of(p, L.ticket[0]);
   for (int g = 0; g < L.filled; ++g) {
     mpe_gg20_pipeline::Ticket* t = ticket_of(p, L.ticket[g]);
     if (!t) continue;
     (void)hipEventRecord(t->done, L.st);
     if (g && t0) t->begin_of = t0->id;
+    t->rc = rc;
     t->launched = true;
   }
+  L.last_ticket = L.ticket[L.filled - 1];
   L.filled = 0;
   L.seeded = 0;
   L.any_keyset = false;
   p->launched_groups++;
-  p->cur = (li + 1) % p->lanes;
-  if (rc != MPE_OK) return rc;
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { mpe_set_error("gg20 pipeline launch", e); return MPE_E_HIP; }
-  return MPE_OK;
+  if (rc != MPE_OK) p->failed_groups++;
+  // the next group opens on an idle lane if there is one, otherwise on the next lane in turn
+  int next = (li + 1) % p->lanes;
+  for (int k = 0; k < p->lanes; ++k) {
+    const int c = (li + 1 + k) % p->lanes;
+    if (lane_idle(p, c)) { next = c; break; }
+  }
+  p->cur = next;
+  return rc;
+}
+
+// rules (3) and (4) of the header comment for the open group; *launched += 1 when it went
+static int poll_open_group(mpe_gg20_pipeline* p, int* launched) {
+  mpe_gg20_pipeline::Lane& L = p->lane[p->cur];
+  if (L.filled == 0) return MPE_OK;
+  bool go = false;
+  if (p->eager && lane_idle(p, p->cur)) { go = true; p->launched_by_idle++; }
+  if (!go && p->deadline_us >= 0 &&
+      std::chrono::duration_cast<std::chrono::microseconds>(mpe_gg20_pipeline::Clock::now() - L.oldest).count() >= p->deadline_us) { go = true; p->launched_by_deadline++; }
+  if (!go) return MPE_OK;
+  if (launched) ++*launched;
+  return launch_group(p, p->cur);
 }
 
 // common part of the two submit forms: reserves slot g of the current lane, records the ticket
@@ -123,7 +202,8 @@ static int open_slot(mpe_gg20_pipeline* p, uint32_t* d_r, uint32_t* d_s, int32_t
   const int li = p->cur;
   mpe_gg20_pipeline::Lane& L = p->lane[li];
   const int g = L.filled;
-  t->id = id; t->begin_of = id; t->lane = li; t->launched = false; t->used = true;
+  t->id = id; t->begin_of = id; t->lane = li; t->rc = MPE_OK; t->launched = false; t->used = true;
+  if (g == 0) L.oldest = mpe_gg20_pipeline::Clock::now();
   // the lane reads the caller's arrays only after the caller's stream has produced them
   (void)hipEventRecord(t->submitted, caller);
   (void)hipStreamWaitEvent(L.st, t->submitted, 0);
@@ -139,7 +219,10 @@ static int close_slot(mpe_gg20_pipeline* p, int li, const int32_t* d_keyset) {
   if (d_keyset) { (void)hipMemcpyAsync(L.keyset + o, d_keyset, (size_t)p->batch * 4, hipMemcpyDeviceToDevice, L.st); L.any_keyset = true; }
   else (void)hipMemsetAsync(L.keyset + o, 0, (size_t)p->batch * 4, L.st);
   L.filled++;
-  if (L.filled == p->group) return launch_group(p, li);
+  // a pass that fails is reported through the tickets of its batches (each owner learns it from wait / query and from its
+  // status array), not through whichever submit happened to close the group: the submission itself succeeded
+  if (L.filled == p->group) (void)launch_group(p, li);
+  else (void)poll_open_group(p, nullptr);
   return MPE_OK;
 }
 
@@ -165,10 +248,8 @@ int mpe_gg20_pipeline_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch,
     if (rc != MPE_OK) break;
     // a lane is the parent context with a workspace of its own and NO forked streams (one stream per lane: <= 4 in total)
     mpe_ctx* c = L.ctx;
-    c->fb_window_bits = ctx->fb_window_bits; c->window_bits = ctx->window_bits; c->ec_lane_groups = ctx->ec_lane_groups;
-    c->adaptive_lanes = ctx->adaptive_lanes; c->use_pown = ctx->use_pown; c->use_pair = ctx->use_pair; c->use_multiexp = ctx->use_multiexp;
-    c->use_crt = ctx->use_crt; c->use_fixed_base = ctx->use_fixed_base; c->use_sliding = ctx->use_sliding; c->wide_div = ctx->wide_div;
-    c->xwide_div = ctx->xwide_div; c->merge_xn = ctx->merge_xn; c->merge_r1 = ctx->merge_r1; c->enc = ctx->enc;
+    mpe::ctx_copy_options(c, ctx);            // every option of the parent (mpe_ctx_set_option), then:
+    c->enc = ctx->enc;
     c->allow_par = false;
     if (hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking) != hipSuccess) { mpe_set_error_msg("gg20 pipeline: hipStreamCreate"); rc = MPE_E_HIP; break; }
     rc = mpe_gg20_nonces_alloc(c, keys, (int)GB, keys->S, &L.stage);
@@ -197,6 +278,8 @@ int mpe_gg20_pipeline_destroy(mpe_gg20_pipeline* p) {
     if (L.blob) { (void)hipMemset(L.blob, 0, L.blob_bytes); (void)hipFree(L.blob); }
     if (L.ctx) (void)mpe_ctx_destroy(L.ctx);
     if (L.st) (void)hipStreamDestroy(L.st);
+    mpe::pipe::wipe_bytes(L.seeds, sizeof L.seeds);
+    mpe::pipe::wipe_bytes(L.counters, sizeof L.counters);
   }
   for (auto& t : p->ring) { if (t.submitted) (void)hipEventDestroy(t.submitted); if (t.begin) (void)hipEventDestroy(t.begin); if (t.done) (void)hipEventDestroy(t.done); }
   delete p;
@@ -211,6 +294,7 @@ int mpe_gg20_pipeline_submit(mpe_gg20_pipeline* p, const int32_t* d_keyset, cons
   mpe_gg20_nonces src = *nonces;
   for (int f = 0; f < mpe::smp::NF; ++f)
     if (!*mpe::smp::nonce_field_ptr(&src, f)) { mpe_set_error_msg("gg20 pipeline: a nonce array is NULL"); return MPE_E_ARG; }
+  (void)mpe::pipe::poll_open_group(p, nullptr);
   if (p->lane[p->cur].seeded) { mpe_set_error_msg("gg20 pipeline: a group holds seeded or caller-sampled batches, not both (flush between the two forms)"); return MPE_E_ARG; }
   int li = 0, g = 0;
   MPE_TRY(mpe::pipe::open_slot(p, d_r, d_s, d_recid, d_R, d_status, (hipStream_t)stream, &li, &g, ticket));
@@ -230,6 +314,7 @@ int mpe_gg20_pipeline_submit_seeded(mpe_gg20_pipeline* p, const int32_t* d_keyse
   if (!p || !h_seed32 || !d_msg || (batch_counter >> 56) != 0) return MPE_E_ARG;
   if (p->group > mpe::smp::MAX_SLOTS) { mpe_set_error_msg("gg20 pipeline: seeded submission needs group <= 16 (one sampler launch per group)"); return MPE_E_ARG; }
   if (p->K->K > 1 && !d_keyset) return MPE_E_ARG;
+  (void)mpe::pipe::poll_open_group(p, nullptr);
   if (p->lane[p->cur].filled != p->lane[p->cur].seeded) { mpe_set_error_msg("gg20 pipeline: a group holds seeded or caller-sampled batches, not both (flush between the two forms)"); return MPE_E_ARG; }
   int li = 0, g = 0;
   MPE_TRY(mpe::pipe::open_slot(p, d_r, d_s, d_recid, d_R, d_status, (hipStream_t)stream, &li, &g, ticket));
@@ -255,28 +340,30 @@ int mpe_gg20_pipeline_query(mpe_gg20_pipeline* p, uint64_t ticket, int* done) {
   if (!p || !done) return MPE_E_ARG;
   mpe_gg20_pipeline::Ticket* t = mpe::pipe::ticket_of(p, ticket);
   if (!t) return MPE_E_ARG;
+  if (!t->launched) (void)mpe::pipe::poll_open_group(p, nullptr);
   *done = (t->launched && hipEventQuery(t->done) == hipSuccess) ? 1 : 0;
-  return MPE_OK;
+  return (*done && t->rc != MPE_OK) ? t->rc : MPE_OK;           // a completed batch whose pass failed says so
 }
 
 int mpe_gg20_pipeline_wait(mpe_gg20_pipeline* p, uint64_t ticket) {
   if (!p) return MPE_E_ARG;
   mpe_gg20_pipeline::Ticket* t = mpe::pipe::ticket_of(p, ticket);
   if (!t) return MPE_E_ARG;
-  if (!t->launched) MPE_TRY(mpe::pipe::launch_group(p, t->lane));       // its group is still open: it goes now, partly filled
+  if (!t->launched) (void)mpe::pipe::launch_group(p, t->lane);          // its group is still open: it goes now, partly filled
   const hipError_t e = hipEventSynchronize(t->done);
   if (e != hipSuccess) { mpe_set_error("gg20 pipeline wait", e); return MPE_E_HIP; }
-  return MPE_OK;
+  if (t->rc != MPE_OK) mpe_set_error_msg("gg20 pipeline: the pass that carried this batch failed (status arrays hold MPE_GG20_STATUS_PASS_FAILED)");
+  return t->rc;
 }
 
 int mpe_gg20_pipeline_stream_wait(mpe_gg20_pipeline* p, uint64_t ticket, void* stream) {
   if (!p) return MPE_E_ARG;
   mpe_gg20_pipeline::Ticket* t = mpe::pipe::ticket_of(p, ticket);
   if (!t) return MPE_E_ARG;
-  if (!t->launched) MPE_TRY(mpe::pipe::launch_group(p, t->lane));
+  if (!t->launched) (void)mpe::pipe::launch_group(p, t->lane);
   const hipError_t e = hipStreamWaitEvent((hipStream_t)stream, t->done, 0);
   if (e != hipSuccess) { mpe_set_error("gg20 pipeline stream wait", e); return MPE_E_HIP; }
-  return MPE_OK;
+  return t->rc;                                                          // known at launch time: the failure is not asynchronous
 }
 
 int mpe_gg20_pipeline_latency_ms(mpe_gg20_pipeline* p, uint64_t ticket, float* ms) {
@@ -286,7 +373,7 @@ int mpe_gg20_pipeline_latency_ms(mpe_gg20_pipeline* p, uint64_t ticket, float* m
   hipError_t e = hipEventSynchronize(t->done);
   if (e == hipSuccess) e = hipEventElapsedTime(ms, t->submitted, t->done);
   if (e != hipSuccess) { mpe_set_error("gg20 pipeline latency", e); return MPE_E_HIP; }
-  return MPE_OK;
+  return t->rc;
 }
 
 int mpe_gg20_pipeline_pass_ms(mpe_gg20_pipeline* p, uint64_t ticket, float* ms) {
@@ -298,6 +385,46 @@ int mpe_gg20_pipeline_pass_ms(mpe_gg20_pipeline* p, uint64_t ticket, float* ms) 
   hipError_t e = hipEventSynchronize(t->done);
   if (e == hipSuccess) e = hipEventElapsedTime(ms, t0->begin, t->done);
   if (e != hipSuccess) { mpe_set_error("gg20 pipeline pass time", e); return MPE_E_HIP; }
+  return t->rc;
+}
+
+int mpe_gg20_pipeline_ticket_rc(mpe_gg20_pipeline* p, uint64_t ticket, int* launched, int* rc) {
+  if (!p || !rc) return MPE_E_ARG;
+  mpe_gg20_pipeline::Ticket* t = mpe::pipe::ticket_of(p, ticket);
+  if (!t) return MPE_E_ARG;
+  if (launched) *launched = t->launched ? 1 : 0;
+  *rc = t->launched ? t->rc : MPE_OK;
+  return MPE_OK;
+}
+
+int mpe_gg20_pipeline_set_deadline_us(mpe_gg20_pipeline* p, int64_t us) {
+  if (!p) return MPE_E_ARG;
+  p->deadline_us = us < 0 ? -1 : us;
+  return MPE_OK;
+}
+int mpe_gg20_pipeline_set_eager(mpe_gg20_pipeline* p, int on) {
+  if (!p) return MPE_E_ARG;
+  p->eager = on ? 1 : 0;
+  return MPE_OK;
+}
+int mpe_gg20_pipeline_poll(mpe_gg20_pipeline* p, int* launched) {
+  if (!p) return MPE_E_ARG;
+  if (launched) *launched = 0;
+  (void)mpe::pipe::poll_open_group(p, launched);                // a failed pass is its tickets' news
+  return MPE_OK;
+}
+int mpe_gg20_pipeline_inject_fault(mpe_gg20_pipeline* p, int passes, int rc) {
+  if (!p || passes < 0 || (rc != MPE_E_NOMEM && rc != MPE_E_HIP)) return MPE_E_ARG;
+  p->fail_next = passes;
+  p->fail_rc = rc;
+  return MPE_OK;
+}
+int mpe_gg20_pipeline_counters(const mpe_gg20_pipeline* p, uint64_t* groups, uint64_t* by_deadline, uint64_t* by_idle, uint64_t* failed) {
+  if (!p) return MPE_E_ARG;
+  if (groups) *groups = p->launched_groups;
+  if (by_deadline) *by_deadline = p->launched_by_deadline;
+  if (by_idle) *by_idle = p->launched_by_idle;
+  if (failed) *failed = p->failed_groups;
   return MPE_OK;
 }
 

@@ -38,12 +38,16 @@ static int launch_fb_modexp(mpe_ctx* ctx, const mpe_statements* stm, int B, Rows
                             uint32_t* out, hipStream_t st) {
   if (B == 0) return MPE_OK;
   using C = Cfg2048;
-  const int grid = persistent_grid(ctx, (B + C::GROUPS - 1) / C::GROUPS, ctx->cus * ctx->modexp_waves_per_cu);
+  const int units = (B + C::GROUPS - 1) / C::GROUPS, cap = ctx->cus * ctx->modexp_waves_per_cu;
+  const int grid = ladder_grid(ctx, units, cap);
+  int32_t* sst = (int32_t*)tables_for(ctx, SCHED_WORDS * sizeof(int32_t), st);       // the scheduler's state lives in the stream slot's scratch
+  if (!sst) return MPE_E_NOMEM;
+  const SchedArgs sched = ladder_sched(ctx, units, cap, sst, st);
   ModsetView v;
   v.n_limbs = stm->ms->n_limbs; v.one_limbs = stm->ms->one_limbs; v.r2_limbs = stm->ms->r2_limbs;
   v.r2h_limbs = stm->ms->r2h_limbs; v.n0inv = stm->ms->n0inv; v.count = stm->ms->count;
   prof_begin(ctx, st, 5, C::BITS, ew, B, stm->fb_wb);          // kind 5: fixed-base ladder; exp2_words carries the window width
-  hipLaunchKernelGGL(fb_modexp_kernel<C>, dim3(grid), dim3(64), 0, st, B, v, st_sel, which, stm->fb_tab, stm->fb_wb, exps, ew, out);
+  hipLaunchKernelGGL(fb_modexp_kernel<C>, dim3(grid), dim3(64), 0, st, B, v, st_sel, which, stm->fb_tab, stm->fb_wb, exps, ew, out, sched);
   prof_end(ctx, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("fb_modexp_kernel", e); return MPE_E_HIP; }

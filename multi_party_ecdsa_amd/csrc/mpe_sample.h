@@ -18,6 +18,10 @@
 // consuming bytes in order; every attempt of a rejection loop takes fresh bytes (rejected draws are part of the stream:
 // oracle/sampler_oracle.c expands the same seed to the same arrays, attempts included).
 // A (seed, sid) pair must never be used twice — the caller's contract, like a nonce.
+// On the GG20 path the ITEM index of a row is the index that row has in the layout with EVERY signer local — ((session * S +
+// signer ordinal) * items per party + sub-item) — whatever subset of the signers the calling object hosts: two objects that hold
+// different parties of the same batch and are handed the same (seed, batch counter) draw DIFFERENT streams by construction (and an
+// object hosting one party draws exactly what the all-local object draws for that party).
 // Included by mpe_lib.hip after mpe_gg20.h.
 #pragma once
 #include "mpe_gg20.h"
@@ -25,7 +29,13 @@
 namespace mpe {
 namespace smp {
 
-constexpr int MAX_ATTEMPTS = 128;        // a bound with its top bit set rejects with probability < 1/2 per attempt
+// Rejection loops give up after `max_attempts` candidates (mpe_ctx option sampler_max_attempts, default 128: a bound with its top
+// bit set rejects with probability < 1/2 per attempt, so an honest draw gives up with probability < 2^-128).  DELIBERATE DIVERGENCE:
+// curv's sample_below / from_modulo / Scalar::random loop forever (range_proofs.rs:538-557); a GPU lane must not.
+// A draw that gives up writes zeros, counts in *fail, and — on the GG20 path — flags its (session, party): sample_gg20 then makes
+// that party's k_i an INVALID scalar (all ones >= q), which round 0 reports as status MPE_GG20_STATUS_BAD_NONCE.  A session never
+// signs on zeroed values, whether or not the caller reads *fail.
+constexpr int DEFAULT_MAX_ATTEMPTS = 128;
 constexpr int F_NONZERO = 1, F_PLUS_ONE = 2, F_COPRIME = 4;
 constexpr int NF = 22;                 // fields of mpe_gg20_nonces, msg last
 
@@ -100,12 +110,12 @@ __device__ inline bool coprime_odd(uint32_t* a, uint32_t* n, int w) {
 // COPRIME_W: words of the private arrays of the coprimality check (0: the flag is not honoured — the batched verdict is used instead).
 template <int COPRIME_W>
 __device__ __forceinline__ void draw_item(Stream& s, const uint32_t* __restrict__ bd, int bound_words, int bits, int flags, uint32_t* __restrict__ o,
-                                          int out_words, int32_t* __restrict__ fail) {
+                                          int out_words, int max_attempts, int32_t* __restrict__ fail, int32_t* __restrict__ owner_bad) {
   const int L = bd ? bit_length(bd, bound_words) : bits;
-  if (L <= 0 || L > 32 * out_words) { for (int j = 0; j < out_words; ++j) o[j] = 0; if (fail) atomicAdd(fail, 1); return; }
+  if (L <= 0 || L > 32 * out_words) { for (int j = 0; j < out_words; ++j) o[j] = 0; if (fail) atomicAdd(fail, 1); if (owner_bad) *owner_bad = 1; return; }
   const int nbytes = (L + 7) / 8, sh = nbytes * 8 - L, W = (L + 31) / 32;
   bool done = false;
-  for (int attempt = 0; attempt < MAX_ATTEMPTS && !done; ++attempt) {
+  for (int attempt = 0; attempt < max_attempts && !done; ++attempt) {
     // the integer X = big-endian(bytes) >> sh, L bits.  Bytes arrive most significant first: the first L - 32 (W - 1) bits are
     // little-endian word W - 1 of X, every further 32 bits the next lower word, and the last sh bits of the string are shifted out.
     int state = 0;                       // comparison with the bound so far: 0 equal, -1 below, +1 above
@@ -135,30 +145,38 @@ __device__ __forceinline__ void draw_item(Stream& s, const uint32_t* __restrict_
     done = good;
   }
   for (int j = W; j < out_words; ++j) o[j] = 0;
-  if (!done) { for (int j = 0; j < W; ++j) o[j] = 0; if (fail) atomicAdd(fail, 1); return; }
+  if (!done) { for (int j = 0; j < W; ++j) o[j] = 0; if (fail) atomicAdd(fail, 1); if (owner_bad) *owner_bad = 1; return; }
   if (flags & F_PLUS_ONE) { uint32_t c = 1; for (int j = 0; j < out_words && c; ++j) { const uint32_t v = o[j] + c; c = v < c ? 1u : 0u; o[j] = v; } }
 }
 
+// row -> stream item of the GG20 arrays (L = 0: the row index itself): rows are [session][local party][per_owner sub-items]
+struct ItemMap { int L, S; unsigned per_owner; uint32_t loc_packed; };       // loc_packed: signer ordinal of local party li in bits [4 li, 4 li + 4)
+__device__ __forceinline__ uint32_t stream_item(const ItemMap& m, unsigned row) {
+  if (m.L == 0) return row;
+  const unsigned pil = row / m.per_owner, sub = row % m.per_owner, b = pil / (unsigned)m.L, li = pil % (unsigned)m.L;
+  return (b * (unsigned)m.S + ((m.loc_packed >> (4 * li)) & 15u)) * m.per_owner + sub;
+}
 // out[i] (out_words words, zero-extended) drawn below bound row sel(i); bits > 0: BigInt::sample(bits), no bound.
 template <int COPRIME_W>
 __global__ void __launch_bounds__(64) sample_kernel(int batch, Seed key, uint32_t sid_lo, uint32_t sid_hi, int bits, const uint32_t* __restrict__ bound,
                                                      int bound_words, const int32_t* __restrict__ bound_idx, int nbounds, int flags, int out_words,
-                                                     uint32_t* __restrict__ out, int32_t* __restrict__ fail, const uint8_t* __restrict__ skip_if) {
+                                                     uint32_t* __restrict__ out, int32_t* __restrict__ fail, const uint8_t* __restrict__ skip_if,
+                                                     int max_attempts, int32_t* __restrict__ owner_bad, ItemMap map) {
   __shared__ uint32_t ks[64][17];
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= batch) return;
   if (skip_if && skip_if[i]) return;       // from_modulo, second pass: only the items whose first candidate shares a factor with N
-  Stream s{&key, (uint32_t)i, sid_lo, sid_hi, ks[threadIdx.x], 0xffffffffu, 0ull};
+  Stream s{&key, stream_item(map, (unsigned)i), sid_lo, sid_hi, ks[threadIdx.x], 0xffffffffu, 0ull};
   const uint32_t* bd = bound ? bound + (size_t)(bound_idx ? bound_idx[i] : (nbounds == 1 ? 0 : i)) * bound_words : nullptr;
-  draw_item<COPRIME_W>(s, bd, bound_words, bits, flags, out + (size_t)i * out_words, out_words, fail);
+  draw_item<COPRIME_W>(s, bd, bound_words, bits, flags, out + (size_t)i * out_words, out_words, max_attempts, fail, owner_bad ? owner_bad + (unsigned)i / map.per_owner : nullptr);
 }
 
 // every field of the sampled values of `nslots` consecutive batches in ONE launch: thread g -> (field, row); a field's rows are
 // slot-major (slot = row / rows-per-batch), and slot k draws from ITS batch's (seed, counter): field f of that batch is stream
 // counter | f << 56, item = the row index inside the batch.  One slot = mpe_gg20_sample_nonces; several = the pipelined engine's groups.
 constexpr int MAX_SLOTS = 16;
-struct FieldDesc { uint32_t* out; const uint32_t* bound; const int32_t* idx; unsigned per_slot; int bound_words, out_words, bits, flags, field; };
-struct FieldTable { FieldDesc f[NF]; unsigned start[NF + 1]; int n; };
+struct FieldDesc { uint32_t* out; const uint32_t* bound; const int32_t* idx; unsigned per_slot, per_owner; int bound_words, out_words, bits, flags, field; };
+struct FieldTable { FieldDesc f[NF]; unsigned start[NF + 1]; int n; int max_attempts; int32_t* owner_bad; int L, S; uint32_t loc_packed; };    // owner_bad [session-parties]: a draw of theirs gave up
 struct SlotTable { Seed key[MAX_SLOTS]; uint32_t ctr_lo[MAX_SLOTS], ctr_hi[MAX_SLOTS]; };
 __global__ void __launch_bounds__(64) sample_fields_kernel(FieldTable t, SlotTable sl, int32_t* __restrict__ fail) {
   __shared__ uint32_t ks[64][17];
@@ -171,9 +189,17 @@ __global__ void __launch_bounds__(64) sample_fields_kernel(FieldTable t, SlotTab
   while (g >= t.start[f + 1]) ++f;
   const FieldDesc& d = t.f[f];
   const unsigned row = g - t.start[f], slot = row / d.per_slot, i = row % d.per_slot;
-  Stream s{&slots.key[slot], i, slots.ctr_lo[slot], slots.ctr_hi[slot] | ((uint32_t)d.field << 24), ks[threadIdx.x], 0xffffffffu, 0ull};
+  const ItemMap map{t.L, t.S, d.per_owner, t.loc_packed};
+  Stream s{&slots.key[slot], stream_item(map, i), slots.ctr_lo[slot], slots.ctr_hi[slot] | ((uint32_t)d.field << 24), ks[threadIdx.x], 0xffffffffu, 0ull};
   const uint32_t* bd = d.bound ? d.bound + (size_t)(d.idx ? d.idx[row] : 0) * d.bound_words : nullptr;
-  draw_item<0>(s, bd, d.bound_words, d.bits, d.flags, d.out + (size_t)row * d.out_words, d.out_words, fail);
+  draw_item<0>(s, bd, d.bound_words, d.bits, d.flags, d.out + (size_t)row * d.out_words, d.out_words, t.max_attempts, fail,
+               t.owner_bad ? t.owner_bad + row / d.per_owner : nullptr);
+}
+// the party of a session one of whose draws gave up must not sign: its k_i becomes an invalid scalar (>= q), round 0 reports it
+__global__ void poison_kernel(int nPI, const int32_t* __restrict__ owner_bad, uint32_t* __restrict__ k) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nPI * 8) return;
+  if (owner_bad[g >> 3]) k[g] = 0xFFFFFFFFu;
 }
 
 static Seed seed_of(const uint8_t* h) {
@@ -183,7 +209,8 @@ static Seed seed_of(const uint8_t* h) {
 }
 
 static int launch_sample(int batch, const uint8_t* h_seed, uint64_t sid, int bits, const uint32_t* d_bound, int bound_words, const int32_t* d_bound_idx,
-                         int nbounds, int flags, int out_words, uint32_t* d_out, int32_t* d_fail, hipStream_t st, const uint8_t* d_skip_if = nullptr) {
+                         int nbounds, int flags, int out_words, uint32_t* d_out, int32_t* d_fail, hipStream_t st, const uint8_t* d_skip_if = nullptr,
+                         int max_attempts = DEFAULT_MAX_ATTEMPTS, int32_t* d_owner_bad = nullptr, ItemMap map = ItemMap{0, 0, 1u, 0u}) {
   if (batch == 0) return MPE_OK;
   if (!h_seed || !d_out || out_words <= 0 || (d_bound ? (bound_words <= 0 || bound_words > out_words || nbounds < 1) : (bits <= 0 || bits > 32 * out_words)))
     return MPE_E_ARG;
@@ -192,10 +219,10 @@ static int launch_sample(int batch, const uint8_t* h_seed, uint64_t sid, int bit
   const dim3 grid(blocks_for(batch, 64)), block(64);
   if (flags & F_COPRIME)
     hipLaunchKernelGGL(sample_kernel<64>, grid, block, 0, st, batch, key, (uint32_t)sid, (uint32_t)(sid >> 32), bits, d_bound, bound_words, d_bound_idx,
-                       nbounds, flags, out_words, d_out, d_fail, d_skip_if);
+                       nbounds, flags, out_words, d_out, d_fail, d_skip_if, max_attempts, d_owner_bad, map);
   else
     hipLaunchKernelGGL(sample_kernel<0>, grid, block, 0, st, batch, key, (uint32_t)sid, (uint32_t)(sid >> 32), bits, d_bound, bound_words, d_bound_idx,
-                       nbounds, flags, out_words, d_out, d_fail, d_skip_if);
+                       nbounds, flags, out_words, d_out, d_fail, d_skip_if, max_attempts, d_owner_bad, map);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("sample_kernel", e); return MPE_E_HIP; }
   return MPE_OK;
@@ -259,14 +286,16 @@ static int sample_gg20(mpe_ctx* ctx, const mpe_gg20_keys* K, int per_batch, int 
   const size_t P1 = (size_t)K->S - 1, nPI = (size_t)batch * n_local, nAP = nPI * K->n, nPP = nPI * P1, nMB = nPP * 2;
   // workspace: the bound-row index of every item + the batched coprimality verdict of from_modulo
   const mpe_modset* msn = K->pub->ms_n;
-  const size_t idx_words = nPI + 2 * nAP + nMB + 2 * nPP + 64;
+  const size_t idx_words = 2 * nPI + 2 * nAP + nMB + 2 * nPP + 64;
   const size_t inv_bytes = (modinv_ws_words(msn, (int)nAP) + nAP * 64) * 4 + nAP + 4096;
   MPE_TRY(ws_reserve(ctx, idx_words * 4 + inv_bytes + 16 * 256, st));
   SIdx x{ws_array<int32_t>(ctx, nPI), ws_array<int32_t>(ctx, nAP), ws_array<int32_t>(ctx, nAP), ws_array<int32_t>(ctx, nMB), ws_array<int32_t>(ctx, nPP),
          ws_array<int32_t>(ctx, nPP)};
   uint32_t* inv = ws_array<uint32_t>(ctx, nAP * 64);
   uint8_t* ok = ws_array<uint8_t>(ctx, nAP);
-  if (!x.own_pi || !x.own_ap || !x.st_ap || !x.peer_mb || !x.own_pp || !x.st_pp || !inv || !ok) return MPE_E_NOMEM;
+  int32_t* owner_bad = ws_array<int32_t>(ctx, nPI);           // a draw of this (session, party) gave up
+  if (!x.own_pi || !x.own_ap || !x.st_ap || !x.peer_mb || !x.own_pp || !x.st_pp || !inv || !ok || !owner_bad) return MPE_E_NOMEM;
+  (void)hipMemsetAsync(owner_bad, 0, nPI * 4, st);
   size_t total = nMB > nAP ? nMB : nAP;
   if (total < nPI) total = nPI;
   hipLaunchKernelGGL(sidx_kernel, dim3(blocks_for((int)total, 64)), dim3(64), 0, st, d, x, (int)total);
@@ -276,9 +305,11 @@ static int sample_gg20(mpe_ctx* ctx, const mpe_gg20_keys* K, int per_batch, int 
   auto U = [](const uint32_t* p) { return const_cast<uint32_t*>(p); };
   // field ids = the position in mpe_gg20_nonces (include/mpecdsa_hip.h); all fields in ONE launch
   FieldTable t{};
-  t.n = 0; t.start[0] = 0;
+  t.n = 0; t.start[0] = 0; t.max_attempts = ctx->sampler_max_attempts; t.owner_bad = owner_bad;
+  t.L = n_local; t.S = K->S; t.loc_packed = 0;
+  for (int i = 0; i < n_local; ++i) t.loc_packed |= (uint32_t)h_local[i] << (4 * i);
   auto add = [&](int f, const uint32_t* dst, size_t items, const uint32_t* bound, int bw, const int32_t* idx, int ow, int flags, int bits = 0) {
-    t.f[t.n] = FieldDesc{U(dst), bound, idx, (unsigned)(items / nslots), bw, ow, bits, flags, f};
+    t.f[t.n] = FieldDesc{U(dst), bound, idx, (unsigned)(items / nslots), (unsigned)(items / nPI), bw, ow, bits, flags, f};
     t.start[t.n + 1] = t.start[t.n] + (unsigned)items;
     t.n++;
   };
@@ -314,10 +345,15 @@ static int sample_gg20(mpe_ctx* ctx, const mpe_gg20_keys* K, int per_batch, int 
     const size_t per = nAP / nslots;              // the redraw pass runs slot by slot: every slot has its own stream
     for (int k = 0; k < nslots; ++k)
       MPE_TRY(launch_sample((int)per, h_seeds + 32 * k, h_counters[k] | ((uint64_t)5 << 56), 0, N, 64, x.own_ap + k * per, nk, F_COPRIME, 64,
-                            U(out->al_beta) + k * per * 64, d_fail, st, ok + k * per));
+                            U(out->al_beta) + k * per * 64, d_fail, st, ok + k * per, ctx->sampler_max_attempts, owner_bad + k * (per / K->n),
+                            ItemMap{n_local, K->S, (unsigned)K->n, t.loc_packed}));
   }
+  hipLaunchKernelGGL(poison_kernel, dim3(blocks_for((int)nPI * 8, 256)), dim3(256), 0, st, (int)nPI, owner_bad, U(out->k));
   // the verdict array and the discarded inverses are derived from secret values
   (void)hipMemsetAsync(inv, 0, nAP * 64 * 4, st);
+  (void)hipMemsetAsync(ok, 0, nAP, st);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mpe_set_error("gg20 sampler", e); return MPE_E_HIP; }
   return MPE_OK;
 }
 
@@ -328,12 +364,13 @@ extern "C" {
 
 int mpe_sample_bits(mpe_ctx* ctx, int batch, const uint8_t* h_seed32, uint64_t stream_id, int bits, int out_words, uint32_t* d_out, void* stream) {
   if (!ctx) return MPE_E_ARG;
-  return mpe::smp::launch_sample(batch, h_seed32, stream_id, bits, nullptr, 0, nullptr, 0, 0, out_words, d_out, nullptr, (hipStream_t)stream);
+  return mpe::smp::launch_sample(batch, h_seed32, stream_id, bits, nullptr, 0, nullptr, 0, 0, out_words, d_out, nullptr, (hipStream_t)stream, nullptr, ctx->sampler_max_attempts);
 }
 int mpe_sample_below(mpe_ctx* ctx, int batch, const uint8_t* h_seed32, uint64_t stream_id, const uint32_t* d_bound, int bound_words, int nbounds,
                      const int32_t* d_bound_idx, int flags, int out_words, uint32_t* d_out, int32_t* d_fail, void* stream) {
   if (!ctx || !d_bound || (flags & ~7)) return MPE_E_ARG;
-  return mpe::smp::launch_sample(batch, h_seed32, stream_id, 0, d_bound, bound_words, d_bound_idx, nbounds, flags, out_words, d_out, d_fail, (hipStream_t)stream);
+  return mpe::smp::launch_sample(batch, h_seed32, stream_id, 0, d_bound, bound_words, d_bound_idx, nbounds, flags, out_words, d_out, d_fail, (hipStream_t)stream, nullptr,
+                                 ctx->sampler_max_attempts);
 }
 int mpe_sample_scalar(mpe_ctx* ctx, int batch, const uint8_t* h_seed32, uint64_t stream_id, uint32_t* d_out, int32_t* d_fail, void* stream) {
   if (!ctx) return MPE_E_ARG;
@@ -342,7 +379,8 @@ int mpe_sample_scalar(mpe_ctx* ctx, int batch, const uint8_t* h_seed32, uint64_t
   uint32_t* dq = mpe::ws_array<uint32_t>(ctx, 8);
   if (!dq) return MPE_E_NOMEM;
   (void)hipMemcpyAsync(dq, q, 32, hipMemcpyHostToDevice, (hipStream_t)stream);
-  return mpe::smp::launch_sample(batch, h_seed32, stream_id, 0, dq, 8, nullptr, 1, mpe::smp::F_NONZERO, 8, d_out, d_fail, (hipStream_t)stream);
+  return mpe::smp::launch_sample(batch, h_seed32, stream_id, 0, dq, 8, nullptr, 1, mpe::smp::F_NONZERO, 8, d_out, d_fail, (hipStream_t)stream, nullptr,
+                                 ctx->sampler_max_attempts);
 }
 
 int mpe_gg20_nonces_alloc(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, int n_local, mpe_gg20_nonce_buf** out) {

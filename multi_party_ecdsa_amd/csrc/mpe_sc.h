@@ -111,6 +111,14 @@ MPE_HD U256 sc_reduce512(const uint32_t (&t)[16]) {
   else if (u256_ge(r, FQ)) u256_sub_m(r, r, FQ);
   return r;
 }
+// 8 words: a value `Scalar::random()` can return — 0 < x < q
+MPE_HD bool sc_is_canonical_nonzero(const uint32_t* x) {
+  const U256 v = u256_load(x);
+  uint32_t any = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) any |= v.w[i];
+  return any != 0 && !u256_ge(v, FQ);
+}
 // an n-word integer mod q: Horner over 256-bit groups from the top
 MPE_HD U256 sc_reduce(const uint32_t* x, int n) {
   const int top = n > 0 ? ((n - 1) >> 3) << 3 : 0;

@@ -1,0 +1,84 @@
+// Which wave runs which unit of a ladder launch (a "unit" = the C::GROUPS exponentiations one wave carries through one ladder).
+//
+// What the per-wave trace of round 6 showed (profiles/r06/wave_trace.jsonl, tools/trace_waves.py: HW_ID, s_memtime, s_memrealtime of
+// every (wave, trip) of pair_modexp_kernel):
+//   * a SIMD does not share fairly: the OLDER of two resident ladder waves runs at 0.92 of its lone speed and the younger one in
+//     what is left (a 2048-bit ladder: 35 ms alone; 38 and 64 ms for two that start together; three units on one SIMD: 88 ms).
+//     Two waves per SIMD deliver 1.19x the units of one — throughput launches keep two — but a launch lasts as long as its
+//     SLOWEST wave, so a launch that has at most one unit per SIMD must put exactly one wave on each;
+//   * the dispatcher does not guarantee that.  A launch of <= 1 024 single-wave workgroups lands one per SIMD when the chip is
+//     idle and quiet (round 5's probe), but behind the tail of a previous kernel, or beside kernels of a forked stream, 5 - 25 % of
+//     its waves share a SIMD (1 024 waves: 978 alone + 23 pairs; inside a signing step: 424 alone + 44 pairs of 512, 792 + 116 pairs
+//     of 1 024) — and the pairs set the launch's time: 58.9 ms instead of 35.6, 40.4 instead of 28.  That — placement, not clocks
+//     (2.35 - 2.40 GHz for lone waves, 2.10 - 2.25 GHz with every SIMD doubled) nor issue arbitration of a lone wave — is the
+//     "fresh launch of lone waves at 0.95 of a shared trip" round 5 could not explain, and why the TAIL of a full grid looked
+//     different: there every SIMD already held exactly two waves.
+// So placement is taken out of the dispatcher's hands.  A launch with units to spare for at most half the resident waves starts
+// up to TWICE as many workgroups as it has units; every wave reads HW_ID / XCC_ID and draws a ticket of ITS SIMD (one atomic):
+// the first arrival on a SIMD is that SIMD's PRIMARY, everybody else a secondary.  Only primaries take units — from a queue, one
+// atomic per unit — so no SIMD ever runs two units of the launch side by side; secondaries hold their slot until the whole grid
+// has arrived (then every SIMD has had its chance to get a primary; 30 us at most) and leave.  The same election serves the tail
+// of a launch of n.f passes (f <= 1/2): all waves run the n full trips on their static units, then the primaries — the older
+// wave of every SIMD, the one the arbiter favours anyway — drain the tail queue.
+// Static launches (state == nullptr) behave exactly as in rounds 1-5.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mpe {
+
+constexpr int SCHED_SIMD_IDS = 8192;                 // (xcc 0..7, se 0..7, sh 0..1, cu 0..15, simd 0..3) -> a dense id
+constexpr int SCHED_WORDS = 2 + SCHED_SIMD_IDS;      // [0] waves arrived, [1] next tail unit, [2 + id] arrivals on that SIMD
+
+struct SchedArgs {
+  int32_t* state;       // SCHED_WORDS zeroed words, or nullptr: static assignment only
+  int full_trips;       // trips every wave runs on its static unit (trip * nslots + blockIdx.x * GROUPS)
+  int tail_units;       // units after the full trips, taken by the primaries from the queue
+};
+
+__device__ __forceinline__ int sched_simd_id() {
+  const unsigned h = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID: simd 5:4, cu 11:8, sh 12, se 15:13
+  const unsigned x = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;    // HW_REG_XCC_ID 3:0
+  return (int)((((x * 8u + ((h >> 13) & 7u)) * 2u + ((h >> 12) & 1u)) * 16u + ((h >> 8) & 15u)) * 4u + ((h >> 4) & 3u));
+}
+
+struct WaveSched {
+  int trip = 0;
+  int role = 0;         // 0: this SIMD's primary (or a static launch), > 0: a later arrival
+  __device__ __forceinline__ void init(const SchedArgs& a) {
+    if (!a.state) return;
+    int r = 0;
+    if (threadIdx.x == 0) {
+      r = atomicAdd(a.state + 2 + sched_simd_id(), 1);
+      atomicAdd(a.state, 1);
+    }
+    role = __builtin_amdgcn_readfirstlane(r);
+    if (role != 0 && a.full_trips == 0) {
+      // a secondary of a launch that has no static trips never works.  It keeps its slot until the whole grid is resident — the
+      // dispatcher then cannot hand this SIMD a third and fourth workgroup while another SIMD has none — or 30 us have passed
+      // (other kernels hold slots: the grid will not be resident at once, and need not be)
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x &&
+             __builtin_amdgcn_s_memrealtime() - t0 < 3000ull)
+        __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  // first item position of this wave's next unit; false: nothing left for this wave (wave-uniform)
+  __device__ __forceinline__ bool next(const SchedArgs& a, int batch, int nslots, int groups, int& ubase) {
+    if (!a.state || trip < a.full_trips) {
+      ubase = trip * nslots + (int)blockIdx.x * groups;
+      ++trip;
+      return ubase < batch;
+    }
+    if (role != 0) return false;
+    int u = 0;
+    if (threadIdx.x == 0) u = atomicAdd(a.state + 1, 1);
+    u = __builtin_amdgcn_readfirstlane(u);
+    if (u >= a.tail_units) return false;
+    ubase = a.full_trips * nslots + u * groups;
+    ++trip;
+    return true;
+  }
+};
+
+}  // namespace mpe

@@ -2,6 +2,7 @@
 u32 words), every compute call goes to libmpecdsa_hip.so.  Mirrors curv's `BigInt::mod_pow` /
 `mod_mul` in batched form."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -20,10 +21,31 @@ def _to_np_u32(t):
     return t.detach().cpu().numpy().view(np.uint32)
 
 
+# The LIBRARY reads no environment variable (mpe_ctx_set_option is the only way to change an A/B switch).  This harness — tests,
+# bench.py, tools/ — keeps the MPE_* variables of the earlier rounds' measurement scripts working by translating them into options
+# when it creates a context: MPE_NO_PAR=1 -> ("no_par", "1"), MPE_WIDE_DIV=4 -> ("wide_div", "4"), MPE_GRID=full -> ("grid", "full").
+_ENV_OPTIONS = ["no_fixed_base", "no_crt", "no_multiexp", "no_pair", "no_pown", "no_sliding", "no_par", "no_wide", "no_adaptive_lanes",
+                "no_merge_xn", "no_merge_r1", "fb_window_bits", "window_bits", "wide_div", "xwide_div", "waves_per_cu", "grid", "fb_budget_mb",
+                "fb_split", "gg20_trace", "sampler_max_attempts", "no_elect", "merge_r1_quarters"]
+
+
+def options_from_env(env=None):
+    env = os.environ if env is None else env
+    out = {}
+    for k in _ENV_OPTIONS:
+        v = env.get("MPE_" + k.upper())
+        if v is not None and v != "":
+            out[k] = v
+    if env.get("MPE_GRID_EQUAL"):
+        out["grid"] = "equal"
+    return out
+
+
 class Context:
-    def __init__(self, device=0, encoding=None):
+    def __init__(self, device=0, encoding=None, options=None):
         """encoding: None (the defaults of include/mpecdsa_hip.h) or a dict / N.Encoding — the profile of the recalled
-        curv / zk-paillier byte conventions this context hashes with (mpe_ctx_set_encoding)"""
+        curv / zk-paillier byte conventions this context hashes with (mpe_ctx_set_encoding).
+        options: {key: value} for mpe_ctx_set_option, applied on top of the harness's MPE_* environment translation."""
         if not torch.cuda.is_available():
             raise N.MpeError("no GPU visible: the HIP path cannot run (there is no CPU fallback)")
         self.device = torch.device("cuda", device)
@@ -32,6 +54,19 @@ class Context:
         self.h = h
         if encoding is not None:
             self.set_encoding(encoding)
+        self.options = {}
+        for k, v in {**options_from_env(), **(options or {})}.items():
+            self.set_option(k, v)
+
+    def set_option(self, key, value):
+        """mpe_ctx_set_option: an A/B switch of the measurements (none changes a result); before the dependent objects are created"""
+        N.check(N.lib.mpe_ctx_set_option(self.h, str(key).encode(), str(int(value) if isinstance(value, bool) else value).encode()), f"mpe_ctx_set_option({key})")
+        self.options[key] = value
+
+    def get_option(self, key):
+        v = C.c_long(0)
+        N.check(N.lib.mpe_ctx_get_option(self.h, str(key).encode(), C.byref(v)), f"mpe_ctx_get_option({key})")
+        return v.value
 
     def set_device_share(self, contexts):
         """this many contexts work on the device at the same time (mpe_ctx_set_device_share): keep the efficient lane layouts"""
@@ -659,18 +694,51 @@ class Gg20Pipeline:
         return t.value
 
     def flush(self):
-        N_.check(N_.lib.mpe_gg20_pipeline_flush(self.h), "mpe_gg20_pipeline_flush")
+        """sends the open group; a pass that fails is reported by its tickets (wait / ticket_rc), not here"""
+        N_.lib.mpe_gg20_pipeline_flush(self.h)
 
     def done(self, ticket):
+        """True once the batch is complete — also when its pass FAILED (ticket_rc / wait tell)"""
         d = C.c_int(0)
-        N_.check(N_.lib.mpe_gg20_pipeline_query(self.h, ticket, C.byref(d)), "mpe_gg20_pipeline_query")
+        N_.lib.mpe_gg20_pipeline_query(self.h, ticket, C.byref(d))
         return bool(d.value)
 
-    def wait(self, ticket, want_R=False):
-        """blocks until the batch is complete; returns (r, s, recid, status[, R]) and forgets the ticket's tensors"""
-        N_.check(N_.lib.mpe_gg20_pipeline_wait(self.h, ticket), "mpe_gg20_pipeline_wait")
+    def ticket_rc(self, ticket):
+        """(launched, rc) of the pass that carries the batch (rc = MPE_OK while its group is still open)"""
+        la, rc = C.c_int(0), C.c_int(0)
+        N_.check(N_.lib.mpe_gg20_pipeline_ticket_rc(self.h, ticket, C.byref(la), C.byref(rc)), "mpe_gg20_pipeline_ticket_rc")
+        return bool(la.value), rc.value
+
+    def wait(self, ticket, want_R=False, check=True):
+        """blocks until the batch is complete; returns (r, s, recid, status[, R]) and forgets the ticket's tensors.  A batch whose PASS
+        failed raises MpeError (check=True) or returns its arrays — status = MPE_GG20_STATUS_PASS_FAILED(rc), no signature — with
+        check=False"""
+        rc = N_.lib.mpe_gg20_pipeline_wait(self.h, ticket)
+        if ticket not in self._keep:
+            N_.check(rc if rc != N_.MPE_OK else N_.MPE_E_ARG, "mpe_gg20_pipeline_wait (unknown ticket)")
         _, _, r, s, recid, status, R = self._keep.pop(ticket)
+        if check:
+            N_.check(rc, "mpe_gg20_pipeline_wait")
         return (r, s, recid, status, R) if want_R else (r, s, recid, status)
+
+    def set_deadline_us(self, us):
+        N_.check(N_.lib.mpe_gg20_pipeline_set_deadline_us(self.h, int(us)), "mpe_gg20_pipeline_set_deadline_us")
+
+    def set_eager(self, on=True):
+        N_.check(N_.lib.mpe_gg20_pipeline_set_eager(self.h, int(bool(on))), "mpe_gg20_pipeline_set_eager")
+
+    def poll(self):
+        la = C.c_int(0)
+        N_.check(N_.lib.mpe_gg20_pipeline_poll(self.h, C.byref(la)), "mpe_gg20_pipeline_poll")
+        return bool(la.value)
+
+    def inject_fault(self, passes=1, rc=N_.MPE_E_NOMEM):
+        N_.check(N_.lib.mpe_gg20_pipeline_inject_fault(self.h, int(passes), int(rc)), "mpe_gg20_pipeline_inject_fault")
+
+    def counters(self):
+        v = [C.c_uint64(0) for _ in range(4)]
+        N_.check(N_.lib.mpe_gg20_pipeline_counters(self.h, *[C.byref(x) for x in v]), "mpe_gg20_pipeline_counters")
+        return dict(zip(("groups", "by_deadline", "by_idle", "failed"), (x.value for x in v)))
 
     def latency_ms(self, ticket):
         ms = C.c_float(0)

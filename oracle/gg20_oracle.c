@@ -305,8 +305,13 @@ static void gg_round0(orc_gg20_party* P, int b, uint32_t* out) {
   const size_t pi = (size_t)b * P->L + P->li;
   mpz_t k, g, lam, x, w, blind, com; mpz_inits(k, g, lam, x, w, blind, com, NULL);
   pt_t G, gg; pt_init(&G); pt_init(&gg); pt_gen(&G);
-  zin(k, P->Z.k + pi * 8, 8); sc_mod(k); zout(s->k, 8, k);
-  zin(g, P->Z.gamma + pi * 8, 8); sc_mod(g); zout(s->gamma, 8, g);
+  zin(k, P->Z.k + pi * 8, 8);
+  zin(g, P->Z.gamma + pi * 8, 8);
+  /* k_i, gamma_i = Scalar::random() (party_i.rs:561-563): 0 < x < q.  Anything else is the mark the device sampler leaves when a
+   * rejection loop gave up (or a caller's mistake): the party stops, status 91 (MPE_GG20_STATUS_BAD_NONCE, include/mpecdsa_hip.h) */
+  if (mpz_sgn(k) == 0 || mpz_cmp(k, EC_Q) >= 0 || mpz_sgn(g) == 0 || mpz_cmp(g, EC_Q) >= 0) gg_fail(s, 91, 0);
+  sc_mod(k); zout(s->k, 8, k);
+  sc_mod(g); zout(s->gamma, 8, g);
   memcpy(s->blind, P->Z.blind + pi * 8, 32);
   memcpy(s->ra, P->Z.r_a + pi * 64, 256);
   lagrange_at_zero(lam, K->signers, S, i);                              /* party_i.rs:553-557 */

@@ -17,7 +17,10 @@
  * (bit-exact) and the DISTRIBUTIONS against the reference's text.  PARITY UNPINNED for curv's byte -> integer rule itself.
  * Compiled into libmpe_oracle.so by #include from mpe_oracle.c (shares its static helpers). */
 
-#define SMP_MAX_ATTEMPTS 128
+/* rejection loops give up after this many candidates, as the device sampler does (mpe_ctx option sampler_max_attempts; curv's loops
+ * are unbounded — a deliberate divergence, include/mpecdsa_hip.h status 91); a test lowers it to make exhaustion observable */
+static int SMP_MAX_ATTEMPTS = 128;
+void orc_sampler_set_max_attempts(int n) { SMP_MAX_ATTEMPTS = n > 0 ? n : 128; }
 #define SMP_NONZERO 1
 #define SMP_PLUS_ONE 2
 #define SMP_COPRIME 4
@@ -131,28 +134,31 @@ int orc_gg20_sample_nonces(const orc_gg20_keys* K, int B, int L, const int32_t* 
   mpz_pow_ui(q3, EC_Q, 3);
   int fails = 0;
 #define SID(f) (counter | ((uint64_t)(f) << 56))
-#define DRAW(f, item, dst, words, upper, flags)                                         \
-  do { smp_rng r_; smp_init(&r_, seed, (uint32_t)(item), SID(f));                        \
-       if (!smp_below(x, &r_, upper, flags)) fails++;                                    \
+/* `item` = the row in THIS object's arrays; its stream is the one the row has in the all-local layout (G = item + (gpi - pi) * per):
+ * the signer ordinal is part of the stream identity, so objects hosting different parties never share a stream (mpe_sample.h) */
+#define DRAW(f, item, per, dst, words, upper, flags)                                    \
+  do { smp_rng r_; smp_init(&r_, seed, (uint32_t)((item) + (gpi - pi) * (per)), SID(f)); \
+       if (!smp_below(x, &r_, upper, flags)) { fails++; bad = 1; }                        \
        zout((uint32_t*)(dst) + (size_t)(item) * (words), words, x); } while (0)
   for (int b = 0; b < B; ++b) {
     const int ks = keyset ? keyset[b] : 0;
     for (int li = 0; li < L; ++li) {
-      const int pi = b * L + li, i = local[li], me = ks * n + K->signers[i];
+      const int pi = b * L + li, i = local[li], me = ks * n + K->signers[i], gpi = b * S + i;
+      int bad = 0;
       mpz_t Nme; mpz_init(Nme);
       if (K->N) zin(Nme, K->N + (size_t)me * 64, 64);
       else { zin(Nme, K->p + (size_t)me * 32, 32); zin(t, K->q + (size_t)me * 32, 32); mpz_mul(Nme, Nme, t); }
-      DRAW(0, pi, Z->k, 8, EC_Q, SMP_NONZERO);                                 /* party_i.rs:563 k_i = Scalar::random() */
-      DRAW(1, pi, Z->gamma, 8, EC_Q, SMP_NONZERO);                             /* :561 gamma_i */
-      { smp_rng r_; smp_init(&r_, seed, (uint32_t)pi, SID(2)); smp_sample(x, &r_, 256); zout((uint32_t*)Z->blind + (size_t)pi * 8, 8, x); }   /* :574 */
-      DRAW(3, pi, Z->r_a, 64, Nme, 0);                                         /* mta/mod.rs:57 */
+      DRAW(0, pi, 1, Z->k, 8, EC_Q, SMP_NONZERO);                                 /* party_i.rs:563 k_i = Scalar::random() */
+      DRAW(1, pi, 1, Z->gamma, 8, EC_Q, SMP_NONZERO);                             /* :561 gamma_i */
+      { smp_rng r_; smp_init(&r_, seed, (uint32_t)gpi, SID(2)); smp_sample(x, &r_, 256); zout((uint32_t*)Z->blind + (size_t)pi * 8, 8, x); }   /* :574 */
+      DRAW(3, pi, 1, Z->r_a, 64, Nme, 0);                                         /* mta/mod.rs:57 */
       for (int st = 0; st < n; ++st) {
         const int ap = pi * n + st;
         zin(t, K->Nt + (size_t)(ks * n + st) * 64, 64);
-        DRAW(4, ap, Z->al_alpha, 24, q3, 0);                                   /* range_proofs.rs:48 */
-        DRAW(5, ap, Z->al_beta, 64, Nme, SMP_COPRIME);                         /* :49, :544-552 */
-        mpz_mul(u, q3, t); DRAW(6, ap, Z->al_gamma, 88, u, 0);                 /* :50 */
-        mpz_mul(u, EC_Q, t); DRAW(7, ap, Z->al_rho, 72, u, 0);                 /* :51 */
+        DRAW(4, ap, n, Z->al_alpha, 24, q3, 0);                                   /* range_proofs.rs:48 */
+        DRAW(5, ap, n, Z->al_beta, 64, Nme, SMP_COPRIME);                         /* :49, :544-552 */
+        mpz_mul(u, q3, t); DRAW(6, ap, n, Z->al_gamma, 88, u, 0);                 /* :50 */
+        mpz_mul(u, EC_Q, t); DRAW(7, ap, n, Z->al_rho, 72, u, 0);                 /* :51 */
       }
       for (int jj = 0; jj < P1; ++jj) {
         const int pp = pi * P1 + jj, ind = ind_of(i, jj), peer = ks * n + K->signers[ind];
@@ -161,23 +167,25 @@ int orc_gg20_sample_nonces(const orc_gg20_keys* K, int B, int L, const int32_t* 
         else { zin(Np, K->p + (size_t)peer * 32, 32); zin(t, K->q + (size_t)peer * 32, 32); mpz_mul(Np, Np, t); }
         for (int v = 0; v < 2; ++v) {
           const int mb = pp * 2 + v;
-          DRAW(8, mb, Z->mb_beta_tag, 64, Np, 0);                              /* mta/mod.rs:97 */
-          DRAW(9, mb, Z->mb_r, 64, Np, 0);                                     /* :98 */
-          DRAW(10, mb, Z->mb_nonce_b, 8, EC_Q, SMP_NONZERO);                   /* :147 DLogProof::prove */
-          DRAW(11, mb, Z->mb_nonce_bt, 8, EC_Q, SMP_NONZERO);                  /* :148 */
+          DRAW(8, mb, 2 * P1, Z->mb_beta_tag, 64, Np, 0);                              /* mta/mod.rs:97 */
+          DRAW(9, mb, 2 * P1, Z->mb_r, 64, Np, 0);                                     /* :98 */
+          DRAW(10, mb, 2 * P1, Z->mb_nonce_b, 8, EC_Q, SMP_NONZERO);                   /* :147 DLogProof::prove */
+          DRAW(11, mb, 2 * P1, Z->mb_nonce_bt, 8, EC_Q, SMP_NONZERO);                  /* :148 */
         }
         zin(t, K->Nt + (size_t)peer * 64, 64);
-        DRAW(15, pp, Z->pdl_alpha, 24, q3, 0);                                 /* zk_pdl_with_slack/mod.rs:73 */
-        mpz_sub_ui(u, Nme, 2); DRAW(16, pp, Z->pdl_beta, 64, u, SMP_PLUS_ONE); /* :75 sample_range(1, N - 1) = 1 + sample_below(N - 2) */
-        mpz_mul(u, EC_Q, t); DRAW(17, pp, Z->pdl_rho, 72, u, 0);               /* :76 */
-        mpz_mul(u, q3, t); DRAW(18, pp, Z->pdl_gamma, 88, u, 0);               /* :77 */
+        DRAW(15, pp, P1, Z->pdl_alpha, 24, q3, 0);                                 /* zk_pdl_with_slack/mod.rs:73 */
+        mpz_sub_ui(u, Nme, 2); DRAW(16, pp, P1, Z->pdl_beta, 64, u, SMP_PLUS_ONE); /* :75 sample_range(1, N - 1) = 1 + sample_below(N - 2) */
+        mpz_mul(u, EC_Q, t); DRAW(17, pp, P1, Z->pdl_rho, 72, u, 0);               /* :76 */
+        mpz_mul(u, q3, t); DRAW(18, pp, P1, Z->pdl_gamma, 88, u, 0);               /* :77 */
         mpz_clear(Np);
       }
-      DRAW(12, pi, Z->l, 8, EC_Q, SMP_NONZERO);                                /* party_i.rs:628 l */
-      DRAW(13, pi, Z->ped_s1, 8, EC_Q, SMP_NONZERO);                           /* PedersenProof::prove */
-      DRAW(14, pi, Z->ped_s2, 8, EC_Q, SMP_NONZERO);
-      DRAW(19, pi, Z->heg_s1, 8, EC_Q, SMP_NONZERO);                           /* HomoELGamalProof::prove */
-      DRAW(20, pi, Z->heg_s2, 8, EC_Q, SMP_NONZERO);
+      DRAW(12, pi, 1, Z->l, 8, EC_Q, SMP_NONZERO);                                /* party_i.rs:628 l */
+      DRAW(13, pi, 1, Z->ped_s1, 8, EC_Q, SMP_NONZERO);                           /* PedersenProof::prove */
+      DRAW(14, pi, 1, Z->ped_s2, 8, EC_Q, SMP_NONZERO);
+      DRAW(19, pi, 1, Z->heg_s1, 8, EC_Q, SMP_NONZERO);                           /* HomoELGamalProof::prove */
+      DRAW(20, pi, 1, Z->heg_s2, 8, EC_Q, SMP_NONZERO);
+      /* a draw that gave up (SMP_MAX_ATTEMPTS; curv would loop on): the party's k_i becomes an invalid scalar, round 0 answers 91 */
+      if (bad) memset((uint32_t*)Z->k + (size_t)pi * 8, 0xff, 32);
       mpz_clear(Nme);
     }
   }

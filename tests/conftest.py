@@ -32,14 +32,9 @@ def gpu_ctx():
 def gpu_ctx_serial():
     """A context pinned to the code paths LARGE batches take — one stream (no forks), 18 limbs per lane, one item per lane in
     the EC round kernels, two-base ladders in the verifiers — so that the small parity cases cover those paths too (the
-    switches are read when a context is created)."""
+    library reads no environment: the switches are options of the context, mpe_ctx_set_option)."""
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU is visible (the HIP path has no CPU fallback)")
     from multi_party_ecdsa_amd import engine
-    os.environ["MPE_NO_PAR"] = "1"
-    os.environ["MPE_NO_ADAPTIVE_LANES"] = "1"
-    try:
-        return engine.Context(0)
-    finally:
-        del os.environ["MPE_NO_PAR"], os.environ["MPE_NO_ADAPTIVE_LANES"]
+    return engine.Context(0, options={"no_par": 1, "no_adaptive_lanes": 1})

@@ -268,6 +268,8 @@ def lindell_sign(p, q, c3, k1, R2, key_idx=None):
 lib.orc_sample_bits.argtypes = [C.c_int, C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
 lib.orc_sample_below.argtypes = [C.c_int, C.c_char_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 lib.orc_sample_scalar.argtypes = [C.c_int, C.c_char_p, C.c_uint64, C.c_void_p]
+lib.orc_sampler_set_max_attempts.argtypes = [C.c_int]
+lib.orc_sampler_set_max_attempts.restype = None
 lib.orc_chacha20_block.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p]
 lib.orc_gg20_sample_nonces.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p]
 SAMPLE_NONZERO, SAMPLE_PLUS_ONE, SAMPLE_COPRIME = 1, 2, 4

@@ -116,8 +116,8 @@ def test_config2_full_size_roundtrip(pk, keys, gpu_ctx):
     assert np.array_equal(np.ascontiguousarray(c[sel].cpu().numpy().view(np.uint32)), want)
 
 
-@pytest.mark.parametrize("env", [{"MPE_NO_PAIR": "1"}, {"MPE_NO_CRT": "1"}, {"MPE_NO_POWN": "1"}, {"MPE_NO_PAIR": "1", "MPE_NO_CRT": "1"},
-                                 {"MPE_WINDOW_BITS": "4"}, {"MPE_WINDOW_BITS": "5"}, {"MPE_NO_ADAPTIVE_LANES": "1"}])
+@pytest.mark.parametrize("env", [{"no_pair": 1}, {"no_crt": 1}, {"no_pown": 1}, {"no_pair": 1, "no_crt": 1},
+                                 {"window_bits": 4}, {"window_bits": 5}, {"no_adaptive_lanes": 1}])
 def test_every_arithmetic_route_gives_the_same_ciphertexts(pk, keys, env):
     """The A/B switches select different algorithms for the same residues (N-adic pairs vs the 4096-bit kernel, the
     holder's p^2|q^2 halves, x^N through a^p, window widths): all of them must agree with the default route, which
@@ -129,16 +129,7 @@ def test_every_arithmetic_route_gives_the_same_ciphertexts(pk, keys, env):
     m = [r.below(keys[kidx[i]].N) for i in range(B)]
     rr = [r.below(keys[kidx[i]].N) for i in range(B)]
     want = pk.encrypt(m, rr, kidx)
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        ctx2 = E.Context(0)                                  # the switches are read when a context is created
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    ctx2 = E.Context(0, options=env)                         # mpe_ctx_set_option: the library itself reads no environment
     sk2 = E.PaillierKeys(ctx2, p=[k.p for k in keys], q=[k.q for k in keys])
     pk2 = E.PaillierKeys(ctx2, N=[k.N for k in keys])
     assert sk2.encrypt(m, rr, kidx) == want                  # key holder
@@ -196,15 +187,11 @@ def test_holder_paths_on_degenerate_randomness(pk, keys, gpu_ctx):
 @pytest.mark.parametrize("B", [1, 15, 16, 17, 333])
 def test_public_exponent_sliding_windows_equal_fixed_windows_and_the_oracle(gpu_ctx, keys, B):
     """x^N for the PUBLIC exponent N runs on sliding windows with the launch ordered by key (mpe_pairexp.h); a context created
-    under MPE_NO_SLIDING=1 keeps the fixed windows.  Peer-side encryption (r^N mod N^2) and the two-base MessageB ciphertext
+    with option no_sliding keeps the fixed windows.  Peer-side encryption (r^N mod N^2) and the two-base MessageB ciphertext
     c_a^b r^N over 16 keys in an order that makes every wave straddle key boundaries: both contexts and the GMP oracle agree
     bit for bit, at batch sizes around the wave's 16 groups."""
     from multi_party_ecdsa_amd import engine as E
-    os.environ["MPE_NO_SLIDING"] = "1"
-    try:
-        ctx_fixed = E.Context(0)
-    finally:
-        del os.environ["MPE_NO_SLIDING"]
+    ctx_fixed = E.Context(0, options={"no_sliding": 1})
     r = F.Rng(f"sliding-{B}")
     kidx = [(5 * i + i // 7) % len(keys) for i in range(B)]
     m = [r.below(keys[k].N) for k in kidx]

@@ -33,16 +33,11 @@ def test_tamper_matrix_on_the_large_batch_paths(gpu_ctx_serial, keys, name, rnd,
 
 @pytest.mark.parametrize("xdiv", ["0", "1000000"])
 def test_sign_matches_oracle_on_each_small_batch_lane_layout(keys, xdiv):
-    """Tiny batches take the 5-limbs-per-lane layout of the pair engine (16 / 8 lanes per integer); MPE_XWIDE_DIV=0 (read when
-    a context is created, like every switch) sends them to the 9-limb layout instead, a huge value sends every launch below the
+    """Tiny batches take the 5-limbs-per-lane layout of the pair engine (16 / 8 lanes per integer); option xwide_div = 0
+    (mpe_ctx_set_option) sends them to the 9-limb layout instead, a huge value sends every launch below the
     2x threshold to the 5-limb one: the three layouts share the per-modulus constants and must produce the oracle's bytes."""
-    import os
     from multi_party_ecdsa_amd import engine as E
-    os.environ["MPE_XWIDE_DIV"] = xdiv
-    try:
-        gpu_ctx = E.Context(0)
-    finally:
-        del os.environ["MPE_XWIDE_DIV"]
+    gpu_ctx = E.Context(0, options={"xwide_div": xdiv})
     if True:
         for t, n, signers, B in [(1, 3, [0, 1], 4), (2, 5, [0, 2, 4], 2)]:
             lk, nonces, (r, s, recid, status, R) = _run(gpu_ctx, keys, t, n, signers, B, f"lanes-{xdiv}-{t}-{n}")

@@ -161,3 +161,87 @@ def test_a_refused_submission_takes_no_slot_and_no_ticket(gpu_ctx, wallet):
     wr, ws, wrecid, _, wstatus = G.oracle_sign(lk, host, B)
     assert not wstatus.any() and not status.cpu().numpy().any() and np.array_equal(hv(r), wr) and np.array_equal(hv(s), ws)
     pipe.close()
+
+
+def test_a_failed_pass_is_every_tickets_news_and_the_next_group_signs(gpu_ctx, wallet):
+    """the pass of a group fails as a whole (fault injection: MPE_E_NOMEM after the inputs were staged): EVERY ticket of that group —
+    not only the one whose submit closed it — reports the error from wait / ticket_rc / done, its status array holds
+    MPE_GG20_STATUS_PASS_FAILED(rc) for every session and its signature arrays are zero; the submissions themselves succeeded; the
+    next group signs and equals the oracle.  (The reference reports per session and never drops an error: gg_2020/mod.rs:23-27,
+    rounds.rs:696-713.)"""
+    ctx = gpu_ctx
+    lk, gk = wallet
+    B, group = 4, 3
+    msgs = [F.words([int.from_bytes(hashlib.sha256(b"fp %d %d" % (b, i)).digest(), "big") for i in range(B)], 8) for b in range(2 * group)]
+    for rc in (E.N_.MPE_E_NOMEM, E.N_.MPE_E_HIP):
+        pipe = E.Gg20Pipeline(ctx, gk, B, group=group, lanes=2)
+        pipe.inject_fault(1, rc)
+        tickets = [pipe.submit_seeded(SEED, 300 + b, dv(ctx, msgs[b]), want_R=True) for b in range(2 * group)]     # no submit raises
+        want_status = E.N_.gg20_status_pass_failed(rc)
+        for b, t in enumerate(tickets):
+            failed = b < group
+            assert pipe.ticket_rc(t) == (True, rc if failed else 0)
+            if failed:
+                keep = pipe._keep[t]
+                with pytest.raises(E.N_.MpeError):
+                    pipe.wait(t)
+                _, _, r, s, recid, status, R = keep
+                assert pipe.done(t)
+                assert (status.cpu().numpy() == want_status).all() and not hv(r).any() and not hv(s).any() and not recid.cpu().numpy().any() and not hv(R).any()
+            else:
+                r, s, recid, status, R = pipe.wait(t, want_R=True)
+                z, fails = G.oracle_sample_nonces(lk, B, SEED, 300 + b, msg=msgs[b])
+                wr, ws, wrecid, wR, wstatus = G.oracle_sign(lk, z, B)
+                assert fails == 0 and not wstatus.any() and not status.cpu().numpy().any()
+                assert np.array_equal(hv(r), wr) and np.array_equal(hv(s), ws) and np.array_equal(recid.cpu().numpy(), wrecid) and np.array_equal(hv(R), wR)
+        assert pipe.counters()["failed"] == 1 and pipe.counters()["groups"] == 2
+        # check=False hands the failed batch's arrays over instead of raising
+        pipe.inject_fault(1, rc)
+        t = pipe.submit_seeded(SEED, 399, dv(ctx, msgs[0]))
+        r, s, recid, status = pipe.wait(t, check=False)
+        assert (status.cpu().numpy() == want_status).all() and not hv(r).any()
+        pipe.close()
+
+
+def test_deadline_and_idle_lane_launch_part_filled_groups(gpu_ctx, wallet):
+    """arrival-driven grouping: with `eager` a batch that finds its lane idle starts at once (group of one); with a deadline a
+    part-filled group goes when its oldest batch has waited that long — checked inside submit / done / poll of the one host thread.
+    Results do not depend on how the batches were grouped."""
+    import time
+    ctx = gpu_ctx
+    lk, gk = wallet
+    B = 4
+    msgs = [F.words([int.from_bytes(hashlib.sha256(b"dl %d %d" % (b, i)).digest(), "big") for i in range(B)], 8) for b in range(6)]
+
+    def check(pipe, tickets, first):
+        for b, t in enumerate(tickets):
+            r, s, recid, status = pipe.wait(t)
+            z, _ = G.oracle_sample_nonces(lk, B, SEED, first + b, msg=msgs[b])
+            wr, ws, wrecid, _, wstatus = G.oracle_sign(lk, z, B)
+            assert not wstatus.any() and not status.cpu().numpy().any() and np.array_equal(hv(r), wr) and np.array_equal(hv(s), ws)
+
+    # eager: the first batch finds lane 0 idle and goes alone; the second finds lane 1 idle and goes alone; further batches find both
+    # lanes busy and share a group until something makes it go
+    pipe = E.Gg20Pipeline(ctx, gk, B, group=4, lanes=2)
+    pipe.set_eager(True)
+    t = [pipe.submit_seeded(SEED, 500 + b, dv(ctx, msgs[b])) for b in range(5)]
+    assert pipe.ticket_rc(t[0])[0] and pipe.ticket_rc(t[1])[0]
+    c = pipe.counters()
+    assert c["by_idle"] >= 2 and c["groups"] >= 2
+    check(pipe, t, 500)
+    pipe.close()
+    # deadline: nothing goes at submit time (group of 4, 2 batches), poll() before the deadline launches nothing, after it the group goes
+    pipe = E.Gg20Pipeline(ctx, gk, B, group=4, lanes=1)
+    pipe.set_deadline_us(200_000)
+    t = [pipe.submit_seeded(SEED, 600 + b, dv(ctx, msgs[b])) for b in range(2)]
+    assert not pipe.ticket_rc(t[0])[0] and not pipe.poll()
+    time.sleep(0.25)
+    assert pipe.poll() and pipe.ticket_rc(t[0])[0] and pipe.ticket_rc(t[1])[0]
+    assert pipe.counters()["by_deadline"] == 1
+    # ... and done() alone drives it too: a service that only polls its tickets never strands a batch
+    t2 = pipe.submit_seeded(SEED, 602, dv(ctx, msgs[2]))
+    time.sleep(0.25)
+    pipe.done(t2)
+    assert pipe.ticket_rc(t2)[0] and pipe.counters()["by_deadline"] == 2
+    check(pipe, t + [t2], 600)
+    pipe.close()

@@ -2,6 +2,7 @@
 curv `Samplable` (sample, sample_below, sample_range), the reference's `from_modulo` (src/utilities/mta/range_proofs.rs:538-557),
 `Scalar::random` — over ChaCha20 (RFC 8439 block function, pinned by the RFC's own test vector), and the distributions the
 signing path needs (range_proofs.rs:48-51; zk_pdl_with_slack/mod.rs:73-77; mta/mod.rs:57,97-98; party_i.rs:561-563,574,628)."""
+import hashlib
 import math
 import struct
 
@@ -154,15 +155,60 @@ def test_gg20_nonces_follow_the_references_ranges():
                         assert v["mb_beta_tag"][pp * 2 + w] < peer.N and v["mb_r"][pp * 2 + w] < peer.N
                     assert v["pdl_alpha"][pp] < Q ** 3 and 1 <= v["pdl_beta"][pp] <= me.N - 2
                     assert v["pdl_rho"][pp] < Q * peer.Nt and v["pdl_gamma"][pp] < Q ** 3 * peer.Nt
-        # the composition is the primitives: field f of batch counter c is stream c | f << 56, item = the field's row
-        assert F.ints(z["k"]) == [PyStream(SEED, i, 5 | (0 << 56)).below(Q, nonzero=True) for i in range(B * L)]
-        assert v["pdl_gamma"][-1] == PyStream(SEED, B * L * P1 - 1, 5 | (18 << 56)).below(Q ** 3 * keys[signers[(lambda i, jj: jj if jj < i else jj + 1)(loc[-1], P1 - 1)]].Nt)
+        # the composition is the primitives: field f of batch counter c is stream c | f << 56, item = the row's index in the layout
+        # with EVERY signer local, (session * S + signer ordinal) * items per party + sub-item — the ordinal is part of the stream
+        assert F.ints(z["k"]) == [PyStream(SEED, (pi // L) * S + loc[pi % L], 5 | (0 << 56)).below(Q, nonzero=True) for pi in range(B * L)]
+        assert v["pdl_gamma"][-1] == PyStream(SEED, ((B - 1) * S + loc[-1]) * P1 + P1 - 1, 5 | (18 << 56)).below(Q ** 3 * keys[signers[(lambda i, jj: jj if jj < i else jj + 1)(loc[-1], P1 - 1)]].Nt)
         # deterministic in (seed, counter); another counter or seed gives other values everywhere
         z2, _ = G.oracle_sample_nonces(lk, B, SEED, 5, local=local)
         z3, _ = G.oracle_sample_nonces(lk, B, SEED, 6, local=local)
         z4, _ = G.oracle_sample_nonces(lk, B, bytes(32), 5, local=local)
         for f in G.NONCE_FIELDS[:-1]:
             assert np.array_equal(z[f], z2[f]) and not np.array_equal(z[f], z3[f]) and not np.array_equal(z[f], z4[f]), f
+
+
+def test_objects_hosting_different_parties_never_share_a_stream():
+    """two objects that hold different parties of one batch and get the SAME (seed, counter) draw different values, and each draws
+    exactly what the all-local object draws for its party (the signer ordinal is part of the stream identity)"""
+    keys = F.load_keys()
+    t, n, signers = 2, 5, [0, 2, 4]
+    lk = G.make_local_keys(keys, t, n, signers)
+    B, S = 3, len(signers)
+    P1 = S - 1
+    full, _ = G.oracle_sample_nonces(lk, B, SEED, 9)
+    per = {"k": 1, "gamma": 1, "blind": 1, "r_a": 1, "al_alpha": n, "al_beta": n, "al_gamma": n, "al_rho": n, "mb_beta_tag": 2 * P1, "mb_r": 2 * P1,
+           "mb_nonce_b": 2 * P1, "mb_nonce_bt": 2 * P1, "l": 1, "ped_s1": 1, "ped_s2": 1, "pdl_alpha": P1, "pdl_beta": P1, "pdl_rho": P1,
+           "pdl_gamma": P1, "heg_s1": 1, "heg_s2": 1}
+    seen = {}
+    for ordinal in range(S):
+        one, _ = G.oracle_sample_nonces(lk, B, SEED, 9, local=[ordinal])
+        for f, m in per.items():
+            a = full[f].reshape(B, S, m, -1)[:, ordinal]
+            assert np.array_equal(one[f].reshape(B, m, -1), a), (f, ordinal)
+        seen[ordinal] = one["k"].tobytes()
+    assert len(set(seen.values())) == S
+
+
+def test_a_rejection_loop_that_gives_up_poisons_the_partys_k():
+    """with one attempt per draw (curv would loop on: a deliberate divergence) many draws below N give up: the value is zero, the
+    failure is counted, and the k_i of that (session, party) becomes an invalid scalar — the signing oracle answers status 91"""
+    keys = F.load_keys()
+    lk = G.make_local_keys(keys, 1, 3, [0, 1])
+    B = 16
+    msg = F.words([int.from_bytes(hashlib.sha256(b"give up %d" % b).digest(), "big") for b in range(B)], 8)
+    try:
+        orc.lib.orc_sampler_set_max_attempts(1)
+        z, fails = G.oracle_sample_nonces(lk, B, SEED, 3, msg=msg)
+    finally:
+        orc.lib.orc_sampler_set_max_attempts(128)
+    assert fails > 0
+    k = F.ints(z["k"])
+    poisoned = [pi for pi in range(B * 2) if k[pi] == (1 << 256) - 1]
+    assert poisoned and all(0 < k[pi] < Q for pi in range(B * 2) if pi not in poisoned)
+    r, s, recid, R, status = G.oracle_sign(lk, z, B)
+    bad_sessions = sorted({pi // 2 for pi in poisoned})
+    assert [b for b in range(B) if status[b] != 0] == bad_sessions and all(status[b] == 91 for b in bad_sessions)
+    assert not r[bad_sessions].any() and not s[bad_sessions].any()
 
 
 def test_sessions_signed_from_sampled_nonces_verify():

@@ -134,3 +134,66 @@ def test_sessions_signed_from_device_sampled_nonces(gpu_ctx):
     for f in ("k", "gamma", "r_a", "mb_r"):
         assert not np.intersect1d(hv(nonces[f])[:, :2].copy().view(np.uint64), hv(n2[f])[:, :2].copy().view(np.uint64)).size
     gk.close()
+
+
+def test_a_rejection_loop_that_gives_up_is_the_sessions_status(gpu_ctx):
+    """curv's sample_below / from_modulo / Scalar::random loop until a candidate fits (range_proofs.rs:538-557); a GPU lane stops after
+    sampler_max_attempts (default 128: < 2^-128 per draw) — a deliberate divergence that must never let a session sign on the zeros a
+    given-up draw leaves.  With ONE attempt per draw many draws below N give up: the device and the oracle agree on every array, the
+    party's k_i is the invalid scalar 2^256 - 1, mpe_gg20_sign answers MPE_GG20_STATUS_BAD_NONCE (91) for exactly those sessions —
+    no signature — and every other session of the batch signs and equals the oracle's."""
+    keys = F.load_keys()
+    lk = G.make_local_keys(keys, 1, 3, [0, 1])
+    B = 24
+    msg = F.words([int.from_bytes(hashlib.sha256(b"gives up %d" % b).digest(), "big") for b in range(B)], 8)
+    ctx = E.Context(0, options={"sampler_max_attempts": 1})
+    assert ctx.get_option("sampler_max_attempts") == 1
+    gk = E.Gg20Keys(ctx, 1, 3, [0, 1], lk["arrays"])
+    # the primitive: a bound that rejects EVERY candidate (sample_below(1) with "non-zero") fails for every item, zeros out
+    got, fail = E.sample_below(ctx, 9, SEED, 700, dv(ctx, F.words([1], 1)), 1, flags=E.SAMPLE_NONZERO)
+    assert int(fail.item()) == 9 and not hv(got).any()
+    try:
+        orc.lib.orc_sampler_set_max_attempts(1)
+        z, wf = G.oracle_sample_nonces(lk, B, SEED, 4242, msg=msg)
+    finally:
+        orc.lib.orc_sampler_set_max_attempts(128)
+    nonces, fail = E.gg20_sample_nonces(ctx, gk, B, SEED, 4242, msg=dv(ctx, msg))
+    assert wf > 0 and int(fail.item()) >= wf            # (the device counts a from_modulo item in both of its passes)
+    for f in G.NONCE_FIELDS[:-1]:
+        assert np.array_equal(hv(nonces[f]), z[f]), f
+    k = F.ints(z["k"])
+    bad = sorted({pi // 2 for pi in range(2 * B) if k[pi] == (1 << 256) - 1})
+    assert bad and len(bad) < B
+    r, s, recid, status = E.gg20_sign(ctx, gk, nonces, B)
+    ctx.sync()
+    wr, ws, wrecid, _, wstatus = G.oracle_sign(lk, z, B)
+    st = status.cpu().numpy()
+    assert np.array_equal(st, wstatus) and [b for b in range(B) if st[b]] == bad and all(st[b] == E.N_.GG20_STATUS_BAD_NONCE for b in bad)
+    assert np.array_equal(hv(r), wr) and np.array_equal(hv(s), ws) and not hv(r)[bad].any() and not hv(s)[bad].any()
+    # a caller's own out-of-range k_i is refused the same way (Scalar::random never returns it)
+    host = G.make_nonces(lk, 4, seed="bad k")
+    host["gamma"][3] = 0                                                # session 1, party 1: gamma_i = 0
+    host["k"][4] = np.array([0xFFFFFFFF] * 8, dtype=np.uint32)          # session 2, party 0: k_i >= q
+    r, s, recid, status = E.gg20_sign(ctx, gk, {f: dv(ctx, v) for f, v in host.items()}, 4)
+    ctx.sync()
+    assert status.cpu().numpy().tolist() == [0, 91, 91, 0] and np.array_equal(status.cpu().numpy(), G.oracle_sign(lk, host, 4)[4])
+    gk.close()
+
+
+def test_options_are_the_only_switch(gpu_ctx):
+    """the library reads no environment variable: an unknown key or a value out of range is refused, every key round-trips"""
+    ctx = E.Context(0)
+    with pytest.raises(E.N_.MpeError):
+        ctx.set_option("no_such_option", 1)
+    with pytest.raises(E.N_.MpeError):
+        ctx.set_option("wide_div", 0)
+    with pytest.raises(E.N_.MpeError):
+        ctx.set_option("grid", "diagonal")
+    n = E.N_.lib.mpe_ctx_option_count()
+    names = [E.N_.lib.mpe_ctx_option_name(i).decode() for i in range(n)]
+    assert {"no_par", "wide_div", "fb_window_bits", "sampler_max_attempts", "grid_mode"} <= set(names)
+    for key, val in (("no_par", 1), ("wide_div", 4), ("xwide_div", 0), ("fb_window_bits", 10), ("waves_per_cu", 4), ("no_sliding", 1)):
+        ctx.set_option(key, val)
+        assert ctx.get_option(key) == val
+    ctx.set_option("grid", "full")
+    assert ctx.get_option("grid_mode") == 1
