@@ -668,6 +668,79 @@ def c4_pipeline(ctx, E, G, keys, batches=96, B=1024, lanes=2, group=4, parity_sa
     return res
 
 
+def c4_open_loop(ctx, E, G, keys, capacity_sig_s, loads=(0.5, 0.9), batches=64, B=1024, lanes=2, group=4, deadline_us=20000, threads=None):
+    """The stream of 1 024-session batches as an OPEN loop: batches arrive as a Poisson process at `load` x the closed-loop capacity,
+    whether or not the service keeps up (a closed loop hides queueing: its client waits).  The pipeline groups by ARRIVAL
+    (mpe_gg20_pipeline_set_eager: a part-filled group goes as soon as its lane is idle; set_deadline_us: or when its oldest batch has
+    waited that long), driven by this one host thread's poll() — at a low load a batch starts at once and costs a lone batch's latency,
+    near capacity the lanes are busy and the groups fill by themselves.  Latency = host time from a batch's ARRIVAL to the moment
+    its completion is seen (the loop polls every ~50 us).  Every batch signed from device-sampled values; all of them under OpenSSL."""
+    import random
+    t, n, signers = 1, 3, [0, 1]
+    lk = G.make_local_keys(keys, t, n, signers)
+    dev = ctx.device
+    gk = E.Gg20Keys(ctx, t, n, signers, lk["arrays"])
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2048)
+    msgs = [rand_words(gen, dev, B, 8, 8) for _ in range(batches)]
+    out = {"capacity_signatures_per_s": capacity_sig_s, "sessions_per_batch": B, "lanes": lanes, "max_batches_per_pass": group,
+           "deadline_us": deadline_us, "eager": True, "arrivals": "Poisson (exponential gaps, seed 7), open loop", "runs": []}
+    threads = threads or min(host_cores()[0], 64)
+    for load in loads:
+        pipe = E.Gg20Pipeline(ctx, gk, B, group=group, lanes=lanes)
+        seed = hashlib.sha256(b"bench.py c4 open loop %d" % int(load * 100)).digest()
+        warm = [pipe.submit_seeded(seed, (1 << 40) + i, msgs[i % batches]) for i in range(lanes * group)]
+        pipe.flush()
+        for tk in warm:
+            pipe.wait(tk)
+        torch.cuda.synchronize()
+        pipe.set_eager(True)
+        pipe.set_deadline_us(deadline_us)
+        rng = random.Random(7)
+        lam = load * capacity_sig_s / B                      # batches per second
+        arrive, acc = [], 0.0
+        for _ in range(batches):
+            acc += rng.expovariate(lam)
+            arrive.append(acc)
+        tickets, done_at, pending = [None] * batches, [None] * batches, []
+        nxt = 0
+        t0 = time.perf_counter()
+        while nxt < batches or pending:
+            now = time.perf_counter() - t0
+            if nxt < batches and now >= arrive[nxt]:
+                tickets[nxt] = pipe.submit_seeded(seed, nxt, msgs[nxt])
+                pending.append(nxt)
+                nxt += 1
+                continue
+            pipe.poll()
+            still = []
+            for b in pending:
+                if pipe.done(tickets[b]):
+                    done_at[b] = time.perf_counter() - t0
+                else:
+                    still.append(b)
+            pending = still
+            if nxt >= batches and pending and not pipe.ticket_rc(tickets[pending[-1]])[0]:
+                pipe.flush()                                 # the stream has ended: nothing more will fill the last group
+            time.sleep(0.00005)
+        total = max(done_at)
+        lat = sorted((done_at[b] - arrive[b]) * 1e3 for b in range(batches))
+        signed, ver = True, 0
+        for b in range(batches):
+            r, s_, recid, status = [o.cpu().numpy() for o in pipe.wait(tickets[b])]
+            signed = signed and bool((status == 0).all())
+            ver += openssl_verify_all(lk["arrays"]["y"][0], msgs[b], r, s_, threads)["openssl_verified"]
+        c = pipe.counters()
+        out["runs"].append({"load": load, "offered_signatures_per_s": lam * B, "achieved_signatures_per_s": batches * B / total,
+                            "latency_ms": {"p50": lat[len(lat) // 2], "p90": lat[int(len(lat) * 0.9)], "p99": lat[min(len(lat) - 1, int(len(lat) * 0.99))], "max": lat[-1]},
+                            "passes": c["groups"], "mean_batches_per_pass": batches / max(1, c["groups"]), "passes_started_by_an_idle_lane": c["by_idle"],
+                            "passes_started_by_the_deadline": c["by_deadline"], "all_sessions_signed": signed, "openssl_verified": ver,
+                            "openssl_of": batches * B})
+        pipe.close()
+    gk.close()
+    return out
+
+
 def multi_wallet(ctx, E, G, keys, K, B, gen, t=1, n=3):
     """One batch whose sessions belong to K different wallets (key sets), round-robin — SURVEY.md 8d config 4 allows "16
     fixtures round-robin".  The 16 Paillier / N~ fixtures are reused cyclically for the K * n key slots (the per-key state
@@ -682,16 +755,134 @@ def multi_wallet(ctx, E, G, keys, K, B, gen, t=1, n=3):
     torch.cuda.synchronize()
     t_keys = time.perf_counter() - t0
     keyset = (torch.arange(B, device=dev, dtype=torch.int32) % K).contiguous()
-    nonces = make_device_nonces(gen, dev, B, S, S, n)
+    seed = hashlib.sha256(b"bench.py multi_wallet %d %d" % (K, B)).digest()
+    msg = rand_words(gen, dev, B, 8, 8)
+    nonces, _ = E.gg20_sample_nonces(ctx, gk, B, seed, 0, msg=msg, keyset=keyset)           # warm-up pass on its own values
     out = E.gg20_sign(ctx, gk, nonces, B, keyset=keyset)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    _, fail = E.gg20_sample_nonces(ctx, gk, B, seed, 1, out=nonces, keyset=keyset)          # the timed pass samples on the device, fresh counter
     out = E.gg20_sign(ctx, gk, nonces, B, keyset=keyset)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     status = out[3].cpu().numpy()
     res = {"wallets": K, "sessions": B, "signatures_per_s": B / dt, "fb_window_bits": gk.fb_window_bits(), "key_setup_s": t_keys,
-           "all_sessions_signed": bool((status == 0).all())}
+           "all_sessions_signed": bool((status == 0).all()), "sampler_rejection_loops_given_up": int(fail.item()),
+           "nonces": "sampled on the device inside the timed pass, a fresh batch counter"}
+    gk.close()
+    return res
+
+
+def mint_distinct_moduli(count, threads, seed=b"bench.py distinct wallets"):
+    """`count` pairwise distinct 2048-bit Paillier moduli N = p q and as many distinct (N~, h1, h2), derived from a POOL of fresh 1 024-bit
+    primes (mpz_nextprime from a SHA-256 stream, the way tests/golden/make_keys.py mints the fixtures) taken in pairs: P primes give
+    P (P - 1) / 2 distinct products, so 320 primes serve 51 040 moduli in ~20 s where 2 x 49 152 primes of their own would take half an
+    hour of host time.  Distinct as NUMBERS — which is what the device's per-key state (Montgomery / pair constants, CRT idempotents,
+    window tables, key-ordered launches) depends on; two moduli may share a prime, which no kernel can tell.  h1 = r^2, h2 = h1^alpha
+    (alpha of 64 bits: signing never uses the relation, only keygen's proof does).  Returns word arrays p, q [count][32], Nt, h1, h2 [count][64]."""
+    import concurrent.futures as cf
+    import orc
+    import fixtures as F
+    P = 2
+    while P * (P - 1) // 2 < count:
+        P += 1
+    P += P % 2
+
+    def prime(i):
+        start = int.from_bytes(hashlib.sha512(seed + b"|%d" % i).digest() * 2, "big") | (1 << 1023) | (1 << 1022)
+        out = np.zeros((1, 32), dtype=np.uint32)
+        orc.lib.orc_nextprime(32, orc._p(F.words([start], 32)), orc._p(out))
+        return F.ints(out)[0]
+    orc.lib.orc_nextprime.restype = None
+    with cf.ThreadPoolExecutor(max(1, threads)) as ex:
+        pool = list(ex.map(prime, range(2 * P)))
+    pa, pb = pool[:P], pool[P:]                                  # Paillier primes | N~ primes
+    pairs = [(i, j) for i in range(P) for j in range(i + 1, P)][:count]
+    rs = F.Rng("distinct wallets h1")
+    ps, qs, nts, h1s, h2s = [], [], [], [], []
+    for (i, j) in pairs:
+        ps.append(pa[i]); qs.append(pa[j])
+        nt = pb[i] * pb[j]
+        h1 = pow(rs.below(nt - 2) + 2, 2, nt)
+        nts.append(nt); h1s.append(h1); h2s.append(pow(h1, rs.bits(64) | 1, nt))
+    assert len({a * b for a, b in zip(ps, qs)}) == count and len(set(nts)) == count
+    return F.words(ps, 32), F.words(qs, 32), F.words(nts, 64), F.words(h1s, 64), F.words(h2s, 64), 2 * P
+
+
+def multi_wallet_distinct(ctx, E, G, keys, K, B, gen, threads, t=1, n=3, parity_sample=16, cache=None):
+    """EVERY session its own wallet (the reference takes an arbitrary LocalKey per OfflineStage, state_machine/sign.rs:78;
+    keygen/rounds.rs:311-322): B sessions over K wallets whose K n Paillier moduli and K n (N~, h1, h2) are pairwise DISTINCT
+    (mint_distinct_moduli); the Shamir material (x_i, X_i, y) cycles through 16 wallets.  Values sampled on the device inside the timed
+    pass; an oracle parity sample and OpenSSL on every signature afterwards."""
+    dev = ctx.device
+    signers = list(range(t + 1))
+    t0 = time.perf_counter()
+    if cache is not None and cache.get("count", 0) >= K * n:
+        pw, qw, ntw, h1w, h2w, nprimes = cache["arrays"]
+    else:
+        pw, qw, ntw, h1w, h2w, nprimes = mint_distinct_moduli(K * n, threads)
+        if cache is not None:
+            cache.update(count=K * n, arrays=(pw, qw, ntw, h1w, h2w, nprimes))
+    t_mint = time.perf_counter() - t0
+    lks = [G.make_local_keys(keys[(kk * n) % len(keys):] + keys[:(kk * n) % len(keys)], t, n, signers, seed=f"wallet-{kk}") for kk in range(16)]
+    arrays = {f: np.concatenate([lks[kk % 16]["arrays"][f] for kk in range(K)]) for f in ("x", "y", "X")}
+    arrays.update(p=np.ascontiguousarray(pw[:K * n]), q=np.ascontiguousarray(qw[:K * n]), Nt=np.ascontiguousarray(ntw[:K * n]),
+                  h1=np.ascontiguousarray(h1w[:K * n]), h2=np.ascontiguousarray(h2w[:K * n]), signers=lks[0]["arrays"]["signers"])
+    lk = dict(t=t, n=n, S=len(signers), arrays=arrays, nkeysets=K)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    t0 = time.perf_counter()
+    gk = E.Gg20Keys(ctx, t, n, signers, arrays, nkeysets=K)
+    torch.cuda.synchronize()
+    t_keys = time.perf_counter() - t0
+    key_bytes = free0 - torch.cuda.mem_get_info()[0]
+    keyset_h = (np.arange(B, dtype=np.int32) % K).astype(np.int32)
+    keyset = torch.from_numpy(keyset_h).to(dev)
+    seed = hashlib.sha256(b"bench.py multi_wallet_distinct %d %d" % (K, B)).digest()
+    msg = rand_words(gen, dev, B, 8, 8)
+    nonces, _ = E.gg20_sample_nonces(ctx, gk, B, seed, 0, msg=msg, keyset=keyset)
+    out = E.gg20_sign(ctx, gk, nonces, B, keyset=keyset)
+    torch.cuda.synchronize()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    _, fail = E.gg20_sample_nonces(ctx, gk, B, seed, 1, out=nonces, keyset=keyset)
+    out = E.gg20_sign(ctx, gk, nonces, B, keyset=keyset)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    recs = ctx.prof_collect(16384)
+    ctx.prof_enable(False)
+    r, s_, recid, status = [o.cpu().numpy() for o in out]
+    by_kind = {}
+    for x in recs:
+        k_ = (x["kind"], x["bits"])
+        by_kind.setdefault(k_, [0, 0.0])
+        by_kind[k_][0] += 1
+        by_kind[k_][1] += x["ms"]
+    slide = [slid(x) for x in recs if x["kind"] == 6]
+    res = {"wallets": K, "sessions": B, "distinct_paillier_moduli": K * n, "distinct_ntilde": K * n, "primes_minted": nprimes,
+           "moduli_from": "pairwise products of a pool of fresh 1024-bit primes (mpz_nextprime): distinct numbers, primes shared between pairs",
+           "signatures_per_s": B / dt, "ms_per_batch": dt * 1e3, "fb_window_bits": gk.fb_window_bits(), "key_setup_s": t_keys,
+           "key_setup_s_amortised_per_signature": t_keys / B, "key_object_device_bytes": int(key_bytes), "host_mint_s": t_mint,
+           "all_sessions_signed": bool((status == 0).all()), "sampler_rejection_loops_given_up": int(fail.item()),
+           "nonces": "sampled on the device inside the timed pass (mpe_gg20_sample_nonces with the sessions' key sets)",
+           "share_of_sliding_ladder_waves_that_slide": (sum(slide) / len(slide)) if slide else None,
+           "whole_step": whole_step(recs, dt),
+           "launch_table": [{"kind": k_[0], "bits": k_[1], "launches": v[0], "ms": round(v[1], 2), "share": round(v[1] * 1e-3 / dt, 4)}
+                            for k_, v in sorted(by_kind.items(), key=lambda kv: -kv[1][1])]}
+    if parity_sample:
+        k = min(parity_sample, B)
+        hm = np.ascontiguousarray(msg[:k].cpu().numpy().view(np.uint32))
+        z, wf = G.oracle_sample_nonces(lk, k, seed, 1, keyset=keyset_h[:k], msg=hm)
+        w = G.oracle_sign_ex(lk, z, k, keyset=keyset_h[:k])
+        res["parity_sample"] = k
+        res["parity_vs_oracle_on_sample"] = bool(wf == 0 and (w["status"] == 0).all() and np.array_equal(r[:k].view(np.uint32), w["r"]) and
+                                                 np.array_equal(s_[:k].view(np.uint32), w["s"]) and np.array_equal(recid[:k], w["recid"]))
+    ver = 0
+    for wl in range(16):                                   # the public key y cycles through 16 Shamir wallets
+        sel = np.nonzero(keyset_h % 16 == wl)[0]
+        if len(sel):
+            ver += openssl_verify_all(lks[wl]["arrays"]["y"][0], msg.cpu().numpy()[sel], r[sel], s_[sel], threads)["openssl_verified"]
+    res.update(openssl_verified=ver, openssl_of=B)
     gk.close()
     return res
 
@@ -1100,7 +1291,14 @@ def main():
     ap.add_argument("--share-device", action="store_true",
                     help="all ranks use cuda:0 and talk through gloo (host-staged): exercises the N>1 code path on a 1-GPU box; "
                          "the ranks time-share one GPU, so `value` says nothing about a node")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE config 5 at its literal shape as the TIMED region: 65 536 concurrent t=2 n=5 sessions over the node "
+                         "(65536 / N per GPU), party-sharded, one RCCL all-gather per round (= --t 2 --n 5 --mode party --sessions 65536/N)")
     args = ap.parse_args()
+    if args.config5:
+        args.t, args.n, args.mode = 2, 5, "party"
+        if args.sessions == 65536:                              # (an explicit --sessions keeps a smoke run small)
+            args.sessions = max(1, 65536 // max(1, args.gpus))
 
     if "RANK" not in os.environ and args.gpus > 1:
         # no launcher around us: become it (N ranks, one per GPU, RCCL over xGMI)
@@ -1259,7 +1457,7 @@ def main():
         # HBM traffic of the dominant kernel: measured in separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied) and committed under profiles/ — not re-measured here
         traffic, traffic_src = None, None
-        for rel in ("profiles/r05/pmc_traffic.json", "profiles/r04/pmc_traffic.json", "profiles/r03/pmc_traffic.json"):
+        for rel in ("profiles/r06/pmc_traffic.json", "profiles/r05/pmc_traffic.json", "profiles/r04/pmc_traffic.json", "profiles/r03/pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, rel)) as f:
                     pmc = json.load(f)
@@ -1295,6 +1493,10 @@ def main():
                                           "because the pair arithmetic computes the same residues with ~0.46x those MACs",
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE; separate rocprofv3 --pmc passes)",
                          "traffic_source": traffic_src,
+                         # flat, because consumers that keep only roofline's scalars drop the object above: the figure is QUOTED from a
+                         # committed PMC pass of this command (rocprofv3 --pmc cannot run inside this process), never measured by this run
+                         "traffic_measured_in_this_run": False, "traffic_quoted_from": traffic_src["file"] if traffic_src else None,
+                         "traffic_quoted_commit": traffic_src["commit"] if traffic_src else None,
                          "kernel": ("mpe::pair_modexp_kernel<Cfg<2048,29,18,4>>" if pair else "mpe::modexp_kernel<Cfg<4096,29,18,8>>") +
                                    " (all launches modulo N^2 of the timed region)",
                          "launches": len(dom), "launches_on_sliding_windows": n_sliding,
@@ -1540,11 +1742,20 @@ def main():
                 l_ = c4_pipeline(ctx, E, G, keys, batches=args.stream_batches, lanes=args.stream_lanes, group=args.stream_group,
                                  oracle=False, parity_sample=0, window=args.stream_lanes * args.stream_group)
                 main_["other_shapes"][f"{args.stream_lanes}x{args.stream_group}_one_group_outstanding_per_lane"] = {k_: l_[k_] for k_ in keep_}
+                # group = 2: half the pass, half the latency (the review's shape)
+                g2_ = c4_pipeline(ctx, E, G, keys, batches=args.stream_batches, lanes=args.stream_lanes, group=2, oracle=False, parity_sample=0)
+                main_["other_shapes"][f"{args.stream_lanes}x2"] = {k_: g2_[k_] for k_ in keep_}
+                # the same service under an OPEN loop: Poisson arrivals at 50 % and 90 % of the closed-loop capacity, arrival-driven grouping
+                main_["open_loop"] = c4_open_loop(ctx, E, G, keys, main_["signatures_per_s"], lanes=args.stream_lanes, group=args.stream_group)
                 return main_
             section("c4_stream_1024", stream_section)
             section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32,
                                                               openssl=True))
             section("c4_multi_wallet_16384", lambda: [multi_wallet(ctx, E, G, keys, K_, 16384, gen) for K_ in (16, 1024)])
+            mint_cache = {}
+            section("c4_every_session_its_own_wallet", lambda: [multi_wallet_distinct(ctx, E, G, keys, K_, B_, gen, threads, cache=mint_cache,
+                                                                                     parity_sample=0 if args.no_cpu_baseline else 16)
+                                                                for K_, B_ in ((16384, 16384), (4096, 4096), (4096, 16384))])
             section("lindell17", lambda: lindell_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline))
             section("f2_blame_4096", lambda: blame_section(ctx, E, G, keys, F, gen, cpu=not args.no_cpu_baseline))
             section("f3_keygen_verify_8192", lambda: keygen_verify_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline))
@@ -1570,6 +1781,8 @@ def main():
         if isinstance(res.get("paillier"), dict) and "modexp4096_2048_per_s" in res["paillier"]:
             also["paillier_2048_modexp_per_s"] = res["paillier"]["modexp4096_2048_per_s"]
         res["config"]["also"] = also
+        for k_, v_ in also.items():                          # ... and flat inside roofline{}, whose scalars every consumer keeps
+            res["roofline"].setdefault(k_, v_)
         print(json.dumps(res))
     if distributed:
         dist.destroy_process_group()

@@ -1228,6 +1228,9 @@ int mpe_gg20_keys_create(mpe_ctx* ctx, int t, int n, int n_signers, const int32_
     const size_t budget = ctx->fb_budget_bytes ? ctx->fb_budget_bytes : free_b / 4;
     int wb = ctx->fb_window_bits;
     while (wb > 4 && mpe_statements_table_bytes(nkeysets * n, wb) > budget) --wb;
+    // thousands of wallets with moduli of their own: even 4-bit tables (3.2 MB per base) do not fit — no tables at all, the powers of
+    // h1, h2 run on the variable-base ladder modulo N~ (mpe_statements_create_wb(wb = 0)); mpe_gg20_keys_fb_window_bits then says 0
+    if (mpe_statements_table_bytes(nkeysets * n, wb) > budget) wb = 0;
     rc = mpe_statements_create_wb(ctx, nkeysets * n, d_Nt, d_h1, d_h2, wb, &K->stm, stream);
   }
   if (rc != MPE_OK) { mpe_gg20_keys_destroy(K); return rc; }

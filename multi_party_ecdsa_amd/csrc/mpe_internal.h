@@ -166,30 +166,25 @@ inline int blocks_for(int n, int threads) { return (n + threads - 1) / threads; 
 // Persistent grid of the ladder kernels: `units` wave-units of work on `cap` resident wave slots (2 per SIMD).  What the per-wave
 // trace says (mpe_sched.h): a SIMD favours its older wave, two waves deliver 1.19x the units of one, and a launch lasts as long as
 // its slowest wave.  Hence
-//   units <= cap / 2          up to 2 x units workgroups start, the first arrival on every SIMD is its PRIMARY and only primaries take
-//                             units (a queue): never two units of the launch side by side on one SIMD, whatever the dispatcher does;
-//   cap / 2 < units <= cap    one workgroup per unit (most SIMDs hold two either way);
-//   n.f passes, f <= 1/2      n full trips on static units, then the primaries — the favoured wave of every SIMD — drain the tail
-//                             queue (`hybrid`, the default; `full`: for every f);
-//   n.f passes, f > 1/2       n + 1 EQUAL trips on a shrunk grid (rounds 1-4), which keeps fewer waves resident throughout
-//                             (`equal`: always).  Option no_elect = 1 restores the static tails and lone launches of round 5.
-// (option grid = equal | full | hybrid; A/B files: profiles/r05/ab_grid_three_modes.jsonl, profiles/r06/)
-inline bool ladder_tail_mode(const mpe_ctx* ctx, int units, int cap) {
-  const int rem = units % cap;
-  return units > cap && rem != 0 && (ctx->grid_mode == 1 || (ctx->grid_mode == 2 && 2 * rem <= cap));
-}
+//   units <= cap / 2          up to 2 x units workgroups start, the first arrival on every SIMD is its PRIMARY and the primaries take the
+//                             units from a queue: never two units of the launch side by side on one SIMD, whatever the dispatcher does;
+//   cap / 2 < units <= cap    one workgroup per unit, static (most SIMDs hold two either way);
+//   units > cap               cap workgroups, EVERY unit from the queue: both waves of a SIMD stay busy until the queue is dry (with
+//                             static units the favoured wave left early and the other ran on alone), tails balance themselves.
+// Option no_elect = 1 restores round 5: static units, `grid` = equal | full | hybrid deciding how a launch of n.f passes is cut
+// (A/B files: profiles/r05/ab_grid_three_modes.jsonl, profiles/r06/).
+inline int persistent_grid(const mpe_ctx* ctx, int need, int cap);
 inline int ladder_grid(const mpe_ctx* ctx, int units, int cap) {
-  if (units <= cap) return (!ctx->no_elect && 2 * units <= cap) ? 2 * units : units;
-  if (units % cap == 0 || ladder_tail_mode(ctx, units, cap)) return cap;
-  const int trips = (units + cap - 1) / cap;
-  return (units + trips - 1) / trips;
+  if (ctx->no_elect) return persistent_grid(ctx, units, cap);
+  if (units <= cap) return 2 * units <= cap ? 2 * units : units;
+  return cap;
 }
 // the scheduler arguments of that launch; `state` (SCHED_WORDS ints of device scratch the launch owns) is zeroed on `st` when used
 inline SchedArgs ladder_sched(const mpe_ctx* ctx, int units, int cap, int32_t* state, hipStream_t st) {
-  SchedArgs a{nullptr, 0, 0};
+  SchedArgs a{nullptr, SCHED_STATIC, units};
   if (ctx->no_elect || !state) return a;
-  if (2 * units <= cap) { a.state = state; a.full_trips = 0; a.tail_units = units; }
-  else if (ladder_tail_mode(ctx, units, cap)) { a.state = state; a.full_trips = units / cap; a.tail_units = units % cap; }
+  if (2 * units <= cap) { a.state = state; a.mode = SCHED_PRIMARIES; }
+  else if (units > cap) { a.state = state; a.mode = SCHED_ALL; }
   if (a.state) (void)hipMemsetAsync(a.state, 0, SCHED_WORDS * sizeof(int32_t), st);
   return a;
 }

@@ -38,7 +38,14 @@ static int launch_fb_modexp(mpe_ctx* ctx, const mpe_statements* stm, int B, Rows
                             uint32_t* out, hipStream_t st) {
   if (B == 0) return MPE_OK;
   using C = Cfg2048;
-  const int units = (B + C::GROUPS - 1) / C::GROUPS, cap = ctx->cus * ctx->modexp_waves_per_cu;
+  const int cap = ctx->cus * ctx->modexp_waves_per_cu;
+  // lane groups per item (mpe_fixedbase.h): the widest split that still leaves one wave per SIMD, so that the chain of
+  // multiplications — which is all a small launch's time — is as short as the chip's idle lanes allow; 1 for large launches
+  int split = 1;
+  if (ctx->fb_split > 0) { while (split * 2 <= ctx->fb_split && split * 2 <= (int)C::GROUPS) split *= 2; }
+  else if (ctx->adaptive_lanes) { while (split * 2 <= (int)C::GROUPS && ((long)B * split * 2 + C::GROUPS - 1) / C::GROUPS <= cap / 2) split *= 2; }
+  const int per_wave = C::GROUPS / split;
+  const int units = (B + per_wave - 1) / per_wave;
   const int grid = ladder_grid(ctx, units, cap);
   int32_t* sst = (int32_t*)tables_for(ctx, SCHED_WORDS * sizeof(int32_t), st);       // the scheduler's state lives in the stream slot's scratch
   if (!sst) return MPE_E_NOMEM;
@@ -47,7 +54,7 @@ static int launch_fb_modexp(mpe_ctx* ctx, const mpe_statements* stm, int B, Rows
   v.n_limbs = stm->ms->n_limbs; v.one_limbs = stm->ms->one_limbs; v.r2_limbs = stm->ms->r2_limbs;
   v.r2h_limbs = stm->ms->r2h_limbs; v.n0inv = stm->ms->n0inv; v.count = stm->ms->count;
   prof_begin(ctx, st, 5, C::BITS, ew, B, stm->fb_wb);          // kind 5: fixed-base ladder; exp2_words carries the window width
-  hipLaunchKernelGGL(fb_modexp_kernel<C>, dim3(grid), dim3(64), 0, st, B, v, st_sel, which, stm->fb_tab, stm->fb_wb, exps, ew, out, sched);
+  hipLaunchKernelGGL(fb_modexp_kernel<C>, dim3(grid), dim3(64), 0, st, B, v, st_sel, which, stm->fb_tab, stm->fb_wb, exps, ew, out, sched, split);
   prof_end(ctx, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mpe_set_error("fb_modexp_kernel", e); return MPE_E_HIP; }
@@ -555,6 +562,7 @@ int mpe_statements_create_wb(mpe_ctx* ctx, int count, const uint32_t* d_Nt, cons
   (void)hipMemcpyAsync(s->h2, d_h2, w * 4, hipMemcpyDeviceToDevice, st);
   int rc = mpe::modset_create_dev(ctx, 2048, count, s->Nt, &s->ms, st);
   if (rc != MPE_OK) { (void)hipFree(s->blob); delete s; return rc; }
+  s->fb_wb = 0;                                  // no tables unless they are built below
   if (ctx->use_fixed_base && wb != 0) {
     // fixed-base window tables of h1, h2 (26 MB per base at 8-bit windows), built on the GPU once per statement set:
     // the window bases one after the other (squarings), then every window's multiples in parallel

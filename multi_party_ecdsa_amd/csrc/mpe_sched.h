@@ -13,14 +13,19 @@
 //     (2.35 - 2.40 GHz for lone waves, 2.10 - 2.25 GHz with every SIMD doubled) nor issue arbitration of a lone wave — is the
 //     "fresh launch of lone waves at 0.95 of a shared trip" round 5 could not explain, and why the TAIL of a full grid looked
 //     different: there every SIMD already held exactly two waves.
-// So placement is taken out of the dispatcher's hands.  A launch with units to spare for at most half the resident waves starts
-// up to TWICE as many workgroups as it has units; every wave reads HW_ID / XCC_ID and draws a ticket of ITS SIMD (one atomic):
-// the first arrival on a SIMD is that SIMD's PRIMARY, everybody else a secondary.  Only primaries take units — from a queue, one
-// atomic per unit — so no SIMD ever runs two units of the launch side by side; secondaries hold their slot until the whole grid
-// has arrived (then every SIMD has had its chance to get a primary; 30 us at most) and leave.  The same election serves the tail
-// of a launch of n.f passes (f <= 1/2): all waves run the n full trips on their static units, then the primaries — the older
-// wave of every SIMD, the one the arbiter favours anyway — drain the tail queue.
-// Static launches (state == nullptr) behave exactly as in rounds 1-5.
+// Two consequences, both about WHO runs WHICH unit:
+//   * a launch with at most one unit per SIMD (units <= half the resident waves) takes placement out of the dispatcher's hands.
+//     It starts up to TWICE as many workgroups as it has units; every wave reads HW_ID / XCC_ID and draws a ticket of ITS SIMD (one
+//     atomic): the first arrival on a SIMD is that SIMD's PRIMARY, everybody else a secondary.  Primaries take units from a queue
+//     (one atomic per unit), so no SIMD runs two units of the launch side by side.  A secondary holds its slot while units are
+//     still unclaimed — the dispatcher then has to put the workgroups it has not placed yet on OTHER SIMDs — and leaves when the
+//     queue is empty; if units are STILL unclaimed after 50 us (SIMDs held by kernels of a forked stream never got a workgroup)
+//     it takes one itself: two units on that SIMD, 38 + 64 ms, instead of a primary running two in a row;
+//   * a launch of several passes hands out EVERY unit from the queue, to every wave (MODE_ALL).  With static units (trip x grid +
+//     block, rounds 1-5) the favoured wave of a SIMD finished its units at 0.63 of the launch and left, and the other one ran the rest
+//     alone at the lone rate; pulling keeps both resident until the queue is dry — the favoured wave simply takes more units —
+//     and a tail (n.f passes) balances itself the same way.
+// MODE_STATIC (state == nullptr) behaves exactly as in rounds 1-5.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,10 +35,11 @@ namespace mpe {
 constexpr int SCHED_SIMD_IDS = 8192;                 // (xcc 0..7, se 0..7, sh 0..1, cu 0..15, simd 0..3) -> a dense id
 constexpr int SCHED_WORDS = 2 + SCHED_SIMD_IDS;      // [0] waves arrived, [1] next tail unit, [2 + id] arrivals on that SIMD
 
+enum { SCHED_STATIC = 0, SCHED_ALL = 1, SCHED_PRIMARIES = 2 };
 struct SchedArgs {
-  int32_t* state;       // SCHED_WORDS zeroed words, or nullptr: static assignment only
-  int full_trips;       // trips every wave runs on its static unit (trip * nslots + blockIdx.x * GROUPS)
-  int tail_units;       // units after the full trips, taken by the primaries from the queue
+  int32_t* state;       // SCHED_WORDS zeroed words, or nullptr: static units (trip * nslots + blockIdx.x * GROUPS)
+  int mode;             // SCHED_ALL: every wave pulls units from the queue; SCHED_PRIMARIES: the first arrival of every SIMD does
+  int units;            // units of the launch (queue length)
 };
 
 __device__ __forceinline__ int sched_simd_id() {
@@ -44,38 +50,41 @@ __device__ __forceinline__ int sched_simd_id() {
 
 struct WaveSched {
   int trip = 0;
-  int role = 0;         // 0: this SIMD's primary (or a static launch), > 0: a later arrival
+  int role = 0;         // 0: this SIMD's primary (or a launch without election), > 0: a later arrival
   __device__ __forceinline__ void init(const SchedArgs& a) {
-    if (!a.state) return;
+    if (!a.state || a.mode != SCHED_PRIMARIES) return;
     int r = 0;
     if (threadIdx.x == 0) {
       r = atomicAdd(a.state + 2 + sched_simd_id(), 1);
       atomicAdd(a.state, 1);
     }
     role = __builtin_amdgcn_readfirstlane(r);
-    if (role != 0 && a.full_trips == 0) {
-      // a secondary of a launch that has no static trips never works.  It keeps its slot until the whole grid is resident — the
-      // dispatcher then cannot hand this SIMD a third and fourth workgroup while another SIMD has none — or 30 us have passed
-      // (other kernels hold slots: the grid will not be resident at once, and need not be)
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (__hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x &&
-             __builtin_amdgcn_s_memrealtime() - t0 < 3000ull)
-        __builtin_amdgcn_s_sleep(8);
-    }
+  }
+  __device__ __forceinline__ int pull(const SchedArgs& a) {
+    int u = 0;
+    if (threadIdx.x == 0) u = atomicAdd(a.state + 1, 1);
+    return __builtin_amdgcn_readfirstlane(u);
   }
   // first item position of this wave's next unit; false: nothing left for this wave (wave-uniform)
   __device__ __forceinline__ bool next(const SchedArgs& a, int batch, int nslots, int groups, int& ubase) {
-    if (!a.state || trip < a.full_trips) {
+    if (!a.state) {
       ubase = trip * nslots + (int)blockIdx.x * groups;
       ++trip;
       return ubase < batch;
     }
-    if (role != 0) return false;
-    int u = 0;
-    if (threadIdx.x == 0) u = atomicAdd(a.state + 1, 1);
-    u = __builtin_amdgcn_readfirstlane(u);
-    if (u >= a.tail_units) return false;
-    ubase = a.full_trips * nslots + u * groups;
+    if (a.mode == SCHED_PRIMARIES && role != 0) {
+      // a secondary: stay (asleep) while units are unclaimed, leave when the queue is dry, help out after 50 us
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        if (__hip_atomic_load(a.state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.units) return false;
+        if (__builtin_amdgcn_s_memrealtime() - t0 >= 5000ull) break;
+        __builtin_amdgcn_s_sleep(16);
+      }
+      role = 0;                                        // from now on it pulls like a primary
+    }
+    const int u = pull(a);
+    if (u >= a.units) return false;
+    ubase = u * groups;
     ++trip;
     return true;
   }

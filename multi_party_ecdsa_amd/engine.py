@@ -644,6 +644,15 @@ class Comm:
             pass
 
 
+def comm_library():
+    """mpe_comm_library: {"path": the librccl the communicator entry points are bound to, "adopted": it was already in the process
+    (PyTorch's own copy), "version": ncclGetVersion}"""
+    buf = C.create_string_buffer(4096)
+    ad, ver = C.c_int(0), C.c_int(0)
+    N_.check(N_.lib.mpe_comm_library(buf, 4096, C.byref(ad), C.byref(ver)), "mpe_comm_library")
+    return dict(path=buf.value.decode(), adopted=bool(ad.value), version=ver.value)
+
+
 def shard_where(placement, S, world, block, party):
     r, s = C.c_int(0), C.c_int(0)
     N_.check(N_.lib.mpe_gg20_shard_where(placement, S, world, block, party, C.byref(r), C.byref(s)), "mpe_gg20_shard_where")

@@ -253,6 +253,8 @@ void orc_chacha20_block(const uint8_t key[32], uint32_t counter, uint32_t n13, u
 int orc_sample_bits(int batch, const uint8_t* seed, uint64_t sid, int bits, int out_words, uint32_t* out);
 /* rejection loops give up after n candidates (default 128), as the device sampler's option sampler_max_attempts */
 void orc_sampler_set_max_attempts(int n);
+/* BigInt::sample(bits) on given bytes: from_bytes_be(buf) >> (8 nbytes - bits) */
+void orc_sample_rule(const uint8_t* buf, int nbytes, int bits, int out_words, uint32_t* out);
 /* flags: 1 reject zero, 2 return 1 + draw (sample_range(1, bound + 1)), 4 from_modulo (repeat until gcd(x, bound) == 1); returns failures */
 int orc_sample_below(int batch, const uint8_t* seed, uint64_t sid, const uint32_t* bound, int bound_words, int nbounds, const int32_t* bound_idx,
                      int flags, int out_words, uint32_t* out);

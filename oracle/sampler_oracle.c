@@ -87,6 +87,17 @@ static int smp_below(mpz_t out, smp_rng* r, const mpz_t upper, int flags) {
   return ok;
 }
 
+/* curv's BigInt::sample(bits) applied to GIVEN bytes (what smp_sample does with the bytes its generator delivers): lets a dump of
+ * the real crate — which can only draw from OsRng — pin the byte -> integer rule on known strings (tools/rust_vectors/dump_vectors.rs
+ * "sampler.known_bytes", tests/test_ref_vectors_cpu.py) */
+void orc_sample_rule(const uint8_t* buf, int nbytes, int bits, int out_words, uint32_t* out) {
+  mpz_t x; mpz_init(x);
+  mpz_import(x, (size_t)nbytes, 1, 1, 0, 0, buf);
+  mpz_fdiv_q_2exp(x, x, (mp_bitcnt_t)(nbytes * 8 - bits));
+  zout(out, out_words, x);
+  mpz_clear(x);
+}
+
 /* the word interface of mpe_sample_bits / mpe_sample_below / mpe_sample_scalar (include/mpecdsa_hip.h); returns the failures */
 int orc_sample_bits(int batch, const uint8_t* seed, uint64_t sid, int bits, int out_words, uint32_t* out) {
   mpz_t x; mpz_init(x);

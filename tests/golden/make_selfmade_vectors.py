@@ -49,6 +49,20 @@ def dlog_json(pk, Rr, z):
     return {"pk": W.point_to_json(pk, STYLE), "pk_t_rand_commitment": W.point_to_json(Rr, STYLE), "challenge_response": W.scalar_to_json(z, STYLE)}
 
 
+def sampler_record(r, N):
+    """the same record tools/rust_vectors/dump_vectors.rs emits: the byte rule of BigInt::sample on known strings + draws in range"""
+    known = []
+    for ln, bits in ((32, 256), (1, 7), (1, 1), (2, 9), (5, 33), (256, 2047), (256, 2048), (257, 2050), (352, 2816)):
+        buf = bytes((((i * 167 + 13 + ln) & 0xFF) | (0x80 if i == 0 else 0)) for i in range(ln))
+        known.append({"bytes": buf.hex(), "bits": bits, "value": hx(int.from_bytes(buf, "big") >> (ln * 8 - bits))})
+    u = (1 << 300) + 12345
+    return {"known_bytes": known,
+            "sample_bits": {"bits": 7, "draws": [hx(r.bits(7)) for _ in range(64)]},
+            "sample_below": {"upper": hx(u), "draws": [hx(r.below(u)) for _ in range(64)]},
+            "sample_range": {"lo": "1", "hi": hx(N - 1), "draws": [hx(1 + r.below(N - 2)) for _ in range(16)]},
+            "scalar_random": [hx(1 + r.below(R.Q - 1)) for _ in range(16)]}
+
+
 def main():
     global STYLE
     for profile, style, fname, ncases, seed in (("default", W.DEFAULT_STYLE, "selfmade_vectors.json", 4, "selfmade-vectors-v1"),
@@ -126,6 +140,7 @@ def write_file(profile, fname, ncases, seed):
             "open": {"c": hx(c), "m": hx(om), "r": hx(orr)},
             "hash_commitment": {"point": pt(g_gamma), "blind": hx(blind), "com": hx(com)},
             "base_point2": pt(R.H2),
+            "sampler": sampler_record(r, N),
         })
     doc = {"schema": 1, "crate": "SELF-MADE (tests/golden/make_selfmade_vectors.py over tests/pyref*.py) - NOT multi-party-ecdsa / curv / kzen-paillier",
            "selfmade_profile": profile, "cases": cases}

@@ -281,6 +281,17 @@ def chacha20_block(key, counter, n13, n14, n15):
     return out.raw
 
 
+lib.orc_sample_rule.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+lib.orc_sample_rule.restype = None
+
+
+def sample_rule(buf, bits, out_words):
+    """curv's BigInt::sample(bits) on GIVEN bytes (from_bytes_be >> (8 len - bits)), as the sampler oracle applies it"""
+    out = u32((1, out_words))
+    lib.orc_sample_rule(bytes(buf), len(buf), bits, out_words, _p(out))
+    return out
+
+
 def sample_bits(batch, seed, sid, bits, out_words):
     out = u32((batch, out_words))
     lib.orc_sample_bits(batch, bytes(seed), sid, bits, out_words, _p(out))

@@ -408,3 +408,55 @@ def test_the_drivers_one_command_tells_both_modes_and_checks_itself():
     assert set(mb["bytes_all_gathered_per_round"]) == {"0", "1", "2", "3", "4", "5", "7"}
     assert 0 <= mb["rccl_time_share"] < 1 and mb["signatures_per_s"] > 0 and len(mb["per_rank_signatures_per_s"]) == 2
     assert abs(mb["signatures_per_s"] - 2 * 32 * 1 / (mb["ms_per_step"] * 1e-3)) < 1e-6 * mb["signatures_per_s"]
+
+
+_COEXIST = r"""
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT={port!r}, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import torch, torch.distributed as dist
+order = {order!r}
+from multi_party_ecdsa_amd import engine as E
+ctx = E.Context(0)
+def torch_side():
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    x = torch.ones(4, device="cuda:0"); dist.all_reduce(x); torch.cuda.synchronize()
+    assert x.tolist() == [1.0] * 4
+def mpe_side():
+    comm = E.Comm(ctx, 0, 1)
+    st = comm.layout_self_test(2)
+    buf = torch.arange(1024, dtype=torch.int32, device="cuda:0")
+    comm.all_gather(buf, 4096); ctx.sync()
+    assert st["ok"] and buf.cpu().tolist() == list(range(1024))
+    return comm
+if order == "torch_first":
+    torch_side(); comm = mpe_side()
+else:
+    comm = mpe_side(); torch_side()
+# both stay usable side by side
+y = torch.full((8,), 2.0, device="cuda:0"); dist.all_reduce(y); torch.cuda.synchronize()
+comm.all_gather(torch.zeros(256, dtype=torch.int32, device="cuda:0"), 1024); ctx.sync()
+mapped = sorted({{ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln}})
+print("RESULT " + json.dumps(dict(lib=E.comm_library(), mapped=mapped, torch_dir=os.path.dirname(torch.__file__))))
+comm.close(); dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("order", ["torch_first", "mpe_first"])
+def test_the_c_abi_communicator_shares_rccl_with_torch_distributed(order):
+    """First contact with a node where torch.distributed's nccl group and mpe_comm_* live in ONE process (bench.py --mode party under
+    torchrun): the library binds RCCL at run time and must ADOPT the copy the process already holds — PyTorch loads its own
+    librccl.so with `import torch` — so that the process maps exactly one librccl and both communicators work side by side, in either
+    order of creation.  Two copies would mean two sets of proxy threads and IPC handles for the same device; fail loudly."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _COEXIST.format(root=root, port=str(29650 + (order == "mpe_first")), order=order)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert len(res["mapped"]) == 1, f"two RCCL copies in one process: {res['mapped']}"
+    assert res["lib"]["adopted"] is True and os.path.realpath(res["lib"]["path"]) == os.path.realpath(res["mapped"][0])
+    assert res["lib"]["version"] > 0

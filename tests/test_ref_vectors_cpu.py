@@ -81,9 +81,28 @@ def test_diagnoser_recovers_a_non_default_profile_and_the_oracle_follows_it():
         check_cases(doc["cases"])                    # defaults: the transcripts differ, so the proofs are rejected
 
 
+def check_sampler(rec, N):
+    """the sampling side (mpe_sample.h / oracle/sampler_oracle.c restate curv's `Samplable`): the byte -> integer rule on the dump's
+    known strings must be the oracle's, and the crate's real draws must lie in the ranges the restatement samples from"""
+    for kb in rec["known_bytes"]:
+        buf, bits = bytes.fromhex(kb["bytes"]), kb["bits"]
+        words = (bits + 31) // 32
+        assert F.ints(orc.sample_rule(buf, bits, words))[0] == H(kb["value"]), ("BigInt::sample byte rule", bits)
+    sb = rec["sample_bits"]
+    draws = [H(v) for v in sb["draws"]]
+    assert all(0 <= v < (1 << sb["bits"]) for v in draws) and max(v.bit_length() for v in draws) == sb["bits"]
+    u = H(rec["sample_below"]["upper"])
+    assert all(0 <= H(v) < u for v in rec["sample_below"]["draws"])
+    lo, hi = H(rec["sample_range"]["lo"]), H(rec["sample_range"]["hi"])
+    assert hi == N - 1 and all(lo <= H(v) < hi for v in rec["sample_range"]["draws"])
+    assert all(0 < H(v) < pyref.Q for v in rec["scalar_random"])
+
+
 def check_cases(cases):
     assert cases
     for c in cases:
+        if "sampler" in c:
+            check_sampler(c["sampler"], H(c["keys"]["N"]))
         k = c["keys"]
         N, p, q, Nt, h1, h2 = (H(k[f]) for f in ("N", "p", "q", "Nt", "h1", "h2"))
         assert p * q == N

@@ -139,21 +139,21 @@ def test_sessions_signed_from_device_sampled_nonces(gpu_ctx):
 def test_a_rejection_loop_that_gives_up_is_the_sessions_status(gpu_ctx):
     """curv's sample_below / from_modulo / Scalar::random loop until a candidate fits (range_proofs.rs:538-557); a GPU lane stops after
     sampler_max_attempts (default 128: < 2^-128 per draw) — a deliberate divergence that must never let a session sign on the zeros a
-    given-up draw leaves.  With ONE attempt per draw many draws below N give up: the device and the oracle agree on every array, the
+    given-up draw leaves.  With THREE attempts per draw some draws below N give up: the device and the oracle agree on every array, the
     party's k_i is the invalid scalar 2^256 - 1, mpe_gg20_sign answers MPE_GG20_STATUS_BAD_NONCE (91) for exactly those sessions —
     no signature — and every other session of the batch signs and equals the oracle's."""
     keys = F.load_keys()
     lk = G.make_local_keys(keys, 1, 3, [0, 1])
     B = 24
     msg = F.words([int.from_bytes(hashlib.sha256(b"gives up %d" % b).digest(), "big") for b in range(B)], 8)
-    ctx = E.Context(0, options={"sampler_max_attempts": 1})
-    assert ctx.get_option("sampler_max_attempts") == 1
+    ctx = E.Context(0, options={"sampler_max_attempts": 3})
+    assert ctx.get_option("sampler_max_attempts") == 3
     gk = E.Gg20Keys(ctx, 1, 3, [0, 1], lk["arrays"])
     # the primitive: a bound that rejects EVERY candidate (sample_below(1) with "non-zero") fails for every item, zeros out
     got, fail = E.sample_below(ctx, 9, SEED, 700, dv(ctx, F.words([1], 1)), 1, flags=E.SAMPLE_NONZERO)
     assert int(fail.item()) == 9 and not hv(got).any()
     try:
-        orc.lib.orc_sampler_set_max_attempts(1)
+        orc.lib.orc_sampler_set_max_attempts(3)
         z, wf = G.oracle_sample_nonces(lk, B, SEED, 4242, msg=msg)
     finally:
         orc.lib.orc_sampler_set_max_attempts(128)

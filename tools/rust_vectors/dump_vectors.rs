@@ -68,6 +68,30 @@ fn statement_and_keys() -> (DLogStatement, EncryptionKey, DecryptionKey, BigInt)
     (DLogStatement { g: h1, ni: h2, N: ek_tilde.n }, ek, dk, &phi - &xhi)
 }
 
+// The sampling side (the device-side sampler restates curv's `Samplable for BigInt` and `Scalar::random`, mpe_sample.h).  curv
+// draws from OsRng inside `sample` — no public entry point takes a caller's RngCore — so a seeded replay is impossible; what CAN
+// be pinned: (1) the byte -> integer arithmetic of `sample(bits)` on KNOWN byte strings, computed here with the crate's own
+// `from_bytes` and shift exactly as its source does (`BigInt::from_bytes(&buf) >> (bytes * 8 - bits)`); (2) the RANGES the crate's
+// real draws fall in: sample(bits) < 2^bits and reaches bit `bits` - 1, sample_below(u) < u, sample_range(1, N - 1) in [1, N - 2],
+// Scalar::random() in [1, q).
+fn sampler_record(n: &BigInt) -> Value {
+    let mut known = Vec::<Value>::new();
+    for (len, bits) in [(32usize, 256usize), (1, 7), (1, 1), (2, 9), (5, 33), (256, 2047), (256, 2048), (257, 2050), (352, 2816)] {
+        let buf: Vec<u8> = (0..len).map(|i| (i * 167 + 13 + len) as u8 | if i == 0 { 0x80 } else { 0 }).collect();
+        let v = BigInt::from_bytes(&buf) >> (len * 8 - bits);
+        known.push(json!({"bytes": hex::encode(&buf), "bits": bits, "value": hex(&v)}));
+    }
+    let u = (BigInt::one() << 300) + BigInt::from(12345u32);
+    let nm1 = n - &BigInt::one();
+    json!({
+        "known_bytes": known,
+        "sample_bits": {"bits": 7, "draws": (0..64).map(|_| hex(&BigInt::sample(7))).collect::<Vec<_>>()},
+        "sample_below": {"upper": hex(&u), "draws": (0..64).map(|_| hex(&BigInt::sample_below(&u))).collect::<Vec<_>>()},
+        "sample_range": {"lo": "1", "hi": hex(&nm1), "draws": (0..16).map(|_| hex(&BigInt::sample_range(&BigInt::one(), &nm1))).collect::<Vec<_>>()},
+        "scalar_random": (0..16).map(|_| hex(&Scalar::<Secp256k1>::random().to_bigint())).collect::<Vec<_>>(),
+    })
+}
+
 #[test]
 fn dump_vectors() {
     let mut out = Vec::<Value>::new();
@@ -143,6 +167,7 @@ fn dump_vectors() {
             "open": {"c": hex(&c), "m": hex(&open_m.0.into_owned()), "r": hex(&open_r.0)},
             "hash_commitment": {"point": pt(&g_gamma), "blind": hex(&blind), "com": hex(&com)},
             "base_point2": pt(&Point::<Secp256k1>::base_point2().clone()),
+            "sampler": sampler_record(&ek.n),
         }));
     }
     println!("{}", serde_json::to_string(&json!({"schema": 1, "crate": "multi-party-ecdsa 0.8.1", "cases": out})).unwrap());

@@ -29,7 +29,8 @@ def main():
         gap = max(0, s - prev_end)
         if gap > 20e6:                      # the step is over: what follows is the teardown of the bench process
             break
-        out.append({"t_ms": (s - t0) / 1e6, "dur_ms": (e - s) / 1e6, "gap_ms": gap / 1e6, "kernel": short(r["Kernel_Name"])})
+        out.append({"t_ms": round((s - t0) / 1e6, 3), "dur_ms": round((e - s) / 1e6, 3), "gap_ms": round(gap / 1e6, 3), "kernel": short(r["Kernel_Name"]),
+                    "queue": r.get("Queue_Id"), "stream": r.get("Stream_Id"), "grid": r.get("Grid_Size_X") or r.get("Grid_Size")})
         if e > prev_end:
             busy += e - max(s, prev_end)
             prev_end = e
