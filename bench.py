@@ -668,7 +668,7 @@ def c4_pipeline(ctx, E, G, keys, batches=96, B=1024, lanes=2, group=4, parity_sa
     return res
 
 
-def c4_open_loop(ctx, E, G, keys, capacity_sig_s, loads=(0.5, 0.9), batches=64, B=1024, lanes=2, group=4, deadline_us=20000, threads=None):
+def c4_open_loop(ctx, E, G, keys, capacity_sig_s, loads=(0.5, 0.9), batches=64, B=1024, lanes=2, group=4, deadline_us=250000, threads=None):
     """The stream of 1 024-session batches as an OPEN loop: batches arrive as a Poisson process at `load` x the closed-loop capacity,
     whether or not the service keeps up (a closed loop hides queueing: its client waits).  The pipeline groups by ARRIVAL
     (mpe_gg20_pipeline_set_eager: a part-filled group goes as soon as its lane is idle; set_deadline_us: or when its oldest batch has

@@ -996,18 +996,23 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   if (merged && rc == MPE_OK) {
     rc = ws_reserve(ctx, ws_need_alice_verify((int)c.nVI) + ws_need_mul_add_enc((int)c.nMB) + ws_need_round1_merged(K->pub, c.nVI, c.nMB), st);
     if (rc == MPE_OK) { ctx->ws_hold++; held = true; }
-    if (rc == MPE_OK && c.nMB > 0)
-      hipLaunchKernelGGL(mb_prep_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st, d, s->gq, s->w, Z.mb_beta_tag, bsel, btq, s->beta);
-    if (rc == MPE_OK)
-      rc = round1_merged_ladders(ctx, K->pub, c.nVI, s->ix.kpub_vi, rows(s->ca_all, 128, s->ix.ca_vi), with_words(pr.s, 64), pr.e, c.nMB, s->ix.kpub_mb,
-                                 rows(s->ca_all, 128, s->ix.ca_mb), bsel, Z.mb_r, &m_vi, &inv_ok_vi, &x_mb, st);
-    gg_trace(s->ctx, st, "round 1 merged ladders", rc);
   }
+  // small batches: the merged ladder launch goes to the forked stream, in front of MessageB's tail (which needs its x_mb), and the
+  // verification's N~ side — fixed-base powers, z^e, an inversion: ~6 ms of short kernels at 1 024 sessions — starts at once on the
+  // caller's stream BESIDE it: the ladder's waves are the older ones on their SIMDs and keep 0.92 of their speed (mpe_sched.h), the
+  // short kernels run in what is left.  The verification waits for the ladder's output only where it multiplies it in (ev_mid).
   Fork g(ctx, st, 2, held && par, 2);
+  hipEvent_t m_ready = nullptr;
   {
     hipStream_t st2 = g.s(1);
-    if (rc == MPE_OK && c.nMB > 0 && !merged)
+    if (rc == MPE_OK && c.nMB > 0)
       hipLaunchKernelGGL(mb_prep_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, d, s->gq, s->w, Z.mb_beta_tag, bsel, btq, s->beta);
+    if (merged && rc == MPE_OK) {
+      rc = round1_merged_ladders(ctx, K->pub, c.nVI, s->ix.kpub_vi, rows(s->ca_all, 128, s->ix.ca_vi), with_words(pr.s, 64), pr.e, c.nMB, s->ix.kpub_mb,
+                                 rows(s->ca_all, 128, s->ix.ca_mb), bsel, Z.mb_r, &m_vi, &inv_ok_vi, &x_mb, st2);
+      if (rc == MPE_OK && g.on) { (void)hipEventRecord(ctx->ev_mid, st2); m_ready = ctx->ev_mid; }
+      gg_trace(s->ctx, st2, "round 1 merged ladders", rc);
+    }
     if (rc == MPE_OK)                                                           // encrypt, Paillier::mul, Paillier::add :133-145
       rc = paillier_mul_add_enc(ctx, K->pub, (int)c.nMB, s->ix.kpub_mb, rows(s->ca_all, 128, s->ix.ca_mb), rows(bsel, 8), 8, Z.mb_beta_tag,
                                 Z.mb_r, c_b, st2, x_mb);
@@ -1018,7 +1023,7 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
     }
   }
   if (rc == MPE_OK)        // every range proof of every peer, for both MessageB::b calls (mta/mod.rs:119-131), read in place
-    rc = alice_verify(ctx, K->pub, K->stm, (int)c.nVI, s->ix.kpub_vi, s->ix.st_vi, rows(s->ca_all, 128, s->ix.ca_vi), pr, ok_vi, st, m_vi, inv_ok_vi);
+    rc = alice_verify(ctx, K->pub, K->stm, (int)c.nVI, s->ix.kpub_vi, s->ix.st_vi, rows(s->ca_all, 128, s->ix.ca_vi), pr, ok_vi, st, m_vi, inv_ok_vi, m_ready);
   gg_trace(s->ctx, st, "alice_verify", rc);
   g.join();
   if (held) ctx->ws_hold--;

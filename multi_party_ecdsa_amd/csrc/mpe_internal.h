@@ -24,12 +24,14 @@ struct mpe_ctx {
   bool use_crt = true;            // key holders compute x^e mod N^2 through p^2 | q^2 (mpe_paillier.h modexp_nn)
   bool use_fixed_base = true;     // h1/h2 exponentiations through per-statement window tables (mpe_fixedbase.h)
   bool use_sliding = true;        // x^N with the PUBLIC exponent N: items ordered by key, sliding windows per wave (mpe_pairexp.h)
-  int wide_div = 2;               // the 2x-lanes layout is used when wide_div * batch <= the resident groups (MPE_WIDE_DIV)
+  int wide_div = 4;               // the 2x-lanes layout is used when wide_div * batch <= the resident groups: 4 = while its units fit ONE wave per
+                                  // SIMD (lone 9-limb ladder 24 ms); up to twice that the 18-limb layout still runs lone (35 ms) where 9 limbs
+                                  // would put two waves on every SIMD (38 ms) — re-measured with the scheduler of round 6 (rounds 2-5: 2)
   int device_share = 1;           // contexts expected to run on this device AT THE SAME TIME (mpe_ctx_set_device_share): the small-batch
                                   // heuristics below compare a launch with 1/device_share of the chip, not with all of it
   int xwide_div = 16;             // the 4x-lanes (5 limbs per lane) layout: xwide_div * batch <= the resident groups; 0 = off (MPE_XWIDE_DIV)
   bool merge_xn = true;           // round 0: every x^N of the key holders in ONE launch (MPE_NO_MERGE_XN switches it off)
-  int merge_r1_quarters = 3;      // small batches merge round 1's two ladder launches when together they exceed this many QUARTERS of the resident groups (option)
+  int merge_r1_quarters = 1;      // small batches merge round 1's two ladder launches when together they exceed this many QUARTERS of the resident groups (option)
   bool merge_r1 = true;           // round 1, large batches: the ladders of the verifications and of the MessageBs in ONE launch (MPE_NO_MERGE_R1)
   size_t fb_budget_bytes = 0;     // memory budget of the fixed-base tables of a key object; 0 = a quarter of free HBM (MPE_FB_BUDGET_MB)
   int modexp_waves_per_cu = 8;    // 2 waves/SIMD: the montmul loop holds ~230 VGPRs and already issues back-to-back
@@ -46,6 +48,7 @@ struct mpe_ctx {
   // run on auxiliary streams, forked from and joined to the caller's stream with events (mpe::Fork).
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_mid = nullptr;    // "the merged ladder launch of round 1 is queued" (mpe_gg20.h round1)
   // background streams of the lock-step composition (small batches): the pure verifications of rounds 1 and 5 run there,
   // each with its own workspace, and are joined when the signature is completed
   bool aux_ready = false;

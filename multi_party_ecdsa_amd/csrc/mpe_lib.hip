@@ -57,6 +57,7 @@ bool ensure_aux(mpe_ctx* ctx) {
   for (int i = 0; i < 3; ++i) if (hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) != hipSuccess) return false;
   for (int i = 0; i < 2; ++i) if (hipEventCreateWithFlags(&ctx->ev_fork[i], hipEventDisableTiming) != hipSuccess) return false;
   for (int i = 0; i < 3; ++i) if (hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) != hipSuccess) return false;
+  if (hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming) != hipSuccess) return false;
   ctx->aux_ready = true;
   return true;
 }
@@ -476,6 +477,7 @@ int mpe_ctx_destroy(mpe_ctx* ctx) {
   if (ctx->aux_ready) {
     for (int i = 0; i < 3; ++i) { (void)hipStreamDestroy(ctx->aux[i]); (void)hipEventDestroy(ctx->ev_join[i]); }
     for (int i = 0; i < 2; ++i) (void)hipEventDestroy(ctx->ev_fork[i]);
+    if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
   }
   for (auto& ev : ctx->prof) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   if (ctx->prof_ctr) (void)hipFree(ctx->prof_ctr);

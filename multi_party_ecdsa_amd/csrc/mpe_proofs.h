@@ -354,7 +354,8 @@ static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statem
 // ladders of its verifications and of its MessageBs in ONE launch, mpe_gg20.h round1_merged_ladders)
 static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
                         const int32_t* st_idx, Rows cipher, const AliceProofRows& pr, uint8_t* ok, hipStream_t st,
-                        const uint32_t* m_pre = nullptr, const uint8_t* inv_ok_pre = nullptr) {
+                        const uint32_t* m_pre = nullptr, const uint8_t* inv_ok_pre = nullptr, hipEvent_t m_pre_ready = nullptr) {
+  // m_pre: s^N (c^-1)^e already computed (or queued on another stream: then m_pre_ready says when) by the caller's merged ladder launch
   MPE_TRY(ws_reserve(ctx, ws_need_alice_verify(B), st));
   Fork f(ctx, st, 3, B <= ctx->par_items);          // (with m_pre the N^2 side is one multiplication: the two N~ branches still fork)
   Seq q{ctx, f.s(0), B}, q1{ctx, f.s(1), B}, q2{ctx, f.s(2), B};
@@ -375,6 +376,7 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
   uint32_t *u = nullptr, *b12 = nullptr, *cie = nullptr;
   if (m_pre) {
     inv_ok2 = const_cast<uint8_t*>(inv_ok_pre);
+    if (m_pre_ready) (void)hipStreamWaitEvent(f.s(0), m_pre_ready, 0);
     u = q.modmul(pk->ms_nn, ksel, rows(gs1, 128), rows(m_pre, 128));
   } else if (f.on) {
     // small batch (latency-bound): the 2048-bit ladder s^N starts at once; the inversion of c and the short ladder

@@ -19,8 +19,12 @@
 //     atomic): the first arrival on a SIMD is that SIMD's PRIMARY, everybody else a secondary.  Primaries take units from a queue
 //     (one atomic per unit), so no SIMD runs two units of the launch side by side.  A secondary holds its slot while units are
 //     still unclaimed — the dispatcher then has to put the workgroups it has not placed yet on OTHER SIMDs — and leaves when the
-//     queue is empty; if units are STILL unclaimed after 50 us (SIMDs held by kernels of a forked stream never got a workgroup)
-//     it takes one itself: two units on that SIMD, 38 + 64 ms, instead of a primary running two in a row;
+//     queue is empty; if units are STILL unclaimed when the whole grid has arrived (SIMDs held by kernels of a forked stream never
+//     got a workgroup) it takes one itself: two units on that SIMD, 38 + 64 ms, instead of a primary running two in a row.  ("Arrived"
+//     counts a primary only AFTER its first pull: counted on arrival, a late primary lost its unit to an early secondary of another SIMD
+//     and the launch doubled up everywhere — 60 ms.  A
+//     50 us time-out instead of "the whole grid has arrived" fired while the dispatcher was still placing workgroups: 1 - 9 SIMDs
+//     of 1 024 doubled up and the launch took 59 ms instead of 35.7, profiles/r06/wave_trace_sched2.jsonl);
 //   * a launch of several passes hands out EVERY unit from the queue, to every wave (MODE_ALL).  With static units (trip x grid +
 //     block, rounds 1-5) the favoured wave of a SIMD finished its units at 0.63 of the launch and left, and the other one ran the rest
 //     alone at the lone rate; pulling keeps both resident until the queue is dry — the favoured wave simply takes more units —
@@ -51,14 +55,16 @@ __device__ __forceinline__ int sched_simd_id() {
 struct WaveSched {
   int trip = 0;
   int role = 0;         // 0: this SIMD's primary (or a launch without election), > 0: a later arrival
+  bool first_pull = false;
   __device__ __forceinline__ void init(const SchedArgs& a) {
     if (!a.state || a.mode != SCHED_PRIMARIES) return;
     int r = 0;
     if (threadIdx.x == 0) {
       r = atomicAdd(a.state + 2 + sched_simd_id(), 1);
-      atomicAdd(a.state, 1);
+      if (r != 0) atomicAdd(a.state, 1);               // a secondary has "arrived" now; a primary only after its first pull (next())
     }
     role = __builtin_amdgcn_readfirstlane(r);
+    first_pull = role == 0;
   }
   __device__ __forceinline__ int pull(const SchedArgs& a) {
     int u = 0;
@@ -73,16 +79,23 @@ struct WaveSched {
       return ubase < batch;
     }
     if (a.mode == SCHED_PRIMARIES && role != 0) {
-      // a secondary: stay (asleep) while units are unclaimed, leave when the queue is dry, help out after 50 us
+      // a secondary: stay (asleep) while units are unclaimed and workgroups of the grid are still to come — each of them may be the
+      // primary of a SIMD that has none yet; leave when the queue is dry; help out when the whole grid has arrived and units are
+      // STILL unclaimed (no primary will come for them), or after 10 ms (the rest of the grid is stuck behind other kernels)
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       for (;;) {
         if (__hip_atomic_load(a.state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.units) return false;
-        if (__builtin_amdgcn_s_memrealtime() - t0 >= 5000ull) break;
-        __builtin_amdgcn_s_sleep(16);
+        if (__hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 >= 1000000ull) break;
+        __builtin_amdgcn_s_sleep(32);
       }
       role = 0;                                        // from now on it pulls like a primary
     }
     const int u = pull(a);
+    if (first_pull) {                                  // (SCHED_PRIMARIES) state[0] == gridDim.x now means: every primary HAS taken its first unit
+      first_pull = false;
+      if (threadIdx.x == 0) atomicAdd(a.state, 1);
+    }
     if (u >= a.units) return false;
     ubase = u * groups;
     ++trip;

@@ -100,3 +100,16 @@ def test_issue_budget_the_multiplier_issue_rate_explains_the_dominant_launch():
     # even with NO instruction other than the multiplies the launch would take >= 0.89 of today's time
     floor = ib.predict(c, items, k["effective_clock_GHz"], c_mad=c_mad, c_other=0.0)["seconds"] * 1e3
     assert floor / k["avg_ms"] > 0.89
+
+
+def test_lone_ladder_model_prices_the_delayed_quotient_before_anyone_builds_it():
+    """round-5 review item 1b (model first): from the per-wave trace's unit times a lone 18-limb ladder wave is issue-bound (<= 8 % exposed), the
+    9-limb layout waits for its own quotient-digit chain ~23 % of a step, and Orup's delayed quotient — two of eight chain links gone, one more
+    limb per lane to issue — would shorten a lone 9-limb ladder by 12 - 18 %: 6 - 10 ms of a 124 ms lone batch, never the 29 ms that 95 ms needs"""
+    m = _load("lone_ladder_model")
+    t = {r["limbs_per_lane"]: r for r in m.table()}
+    assert t[18]["exposed_share"] < 0.08 and t[18]["orup_gain"] < 0.03
+    assert 0.18 < t[9]["exposed_share"] < 0.28 and 0.12 < t[9]["orup_gain"] < 0.18
+    assert t[5]["exposed_share"] > 0.7 and t[5]["orup_unit_ms"] > t[9]["unit_ms"]          # even improved, 5 limbs per lane lose to 9 as they are
+    assert abs(m.issue_cycles(9) - (18 * 5.66 + 5.1 * 4.2)) < 1e-9
+    assert 6.0 < m.lone_batch_gain_ms() < 10.0 < 124.2 - 95.0
