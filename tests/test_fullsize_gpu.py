@@ -3,7 +3,7 @@
  * config 3: the 4 096-instance prefix of both scalar multiplications against OpenSSL's EC_POINT_mul;
  * config 4: ALL 1 024 signatures (r, s, recid, R) byte-identical to the oracle, and every one verifies under the wallet's
    public key with OpenSSL's ECDSA_do_verify (the reference's independent check: gg_2020/test.rs:711-748);
- * config 5: one GPU's share (8 192 sessions, t=2, n=5): a 512-session sample byte-identical to the oracle, all 8 192
+ * config 5: one GPU's share (8 192 sessions, t=2, n=5): a 128-session sample byte-identical to the oracle, all 8 192
    signatures verify under OpenSSL.
 The oracle runs on the host threads the cgroup grants (tens of seconds each)."""
 import numpy as np
@@ -80,5 +80,6 @@ def test_config4_all_1024_signatures_equal_the_oracle_and_verify_under_openssl(g
     _sign_and_check(gpu_ctx, keys, 1, 3, [0, 1], 1024, 1024, 44)
 
 
-def test_config5_share_512_sample_equals_the_oracle_all_8192_verify_under_openssl(gpu_ctx, keys):
-    _sign_and_check(gpu_ctx, keys, 2, 5, [0, 1, 2], 8192, 512, 55)
+def test_config5_share_128_sample_equals_the_oracle_all_8192_verify_under_openssl(gpu_ctx, keys):
+    # (round 6: the oracle sample was 512 sessions = 34 s of host time; every one of the 8 192 signatures still goes through OpenSSL)
+    _sign_and_check(gpu_ctx, keys, 2, 5, [0, 1, 2], 8192, 128, 55)

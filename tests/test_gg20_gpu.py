@@ -242,8 +242,8 @@ def tamper_case(gpu_ctx, keys, name, rnd, sender, word, kind):
     (2, 5, [0, 2, 4], 3, {}),
     (2, 4, [1, 2, 3], 2, {"dedup_verify": True}),
     (2, 5, [0, 2, 3, 4], 2, {}),                     # S = 4 > t+1 (gg_2020/test.rs:60-63)
-    (5, 8, [0, 1, 3, 4, 6, 7], 1, {}),               # six of eight (n = 8 is the widest shape the library takes; all eight
-                                                     # signing was run once: 18 s of oracle time, byte-identical)
+    # (n = 8 is the widest shape the library takes: (5, 8, six signers) ran in the suite until round 5 — 9.5 s — and all eight
+    #  signing was run once: 18 s of oracle time, byte-identical; the reference's own (4, 8) shape above stays)
 ])
 def test_sign_matches_oracle(gpu_ctx, keys, t, n, signers, B, kw):
     lk, nonces, (r, s, recid, status, R) = _run(gpu_ctx, keys, t, n, signers, B, f"gpu-{t}-{n}-{signers}", **kw)
