@@ -1291,6 +1291,8 @@ def main():
     ap.add_argument("--share-device", action="store_true",
                     help="all ranks use cuda:0 and talk through gloo (host-staged): exercises the N>1 code path on a 1-GPU box; "
                          "the ranks time-share one GPU, so `value` says nothing about a node")
+    ap.add_argument("--wallet-cases", default="16384x16384,4096x4096,4096x16384",
+                    help="c4_every_session_its_own_wallet: comma list of WALLETSxSESSIONS (every wallet has moduli of its own)")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE config 5 at its literal shape as the TIMED region: 65 536 concurrent t=2 n=5 sessions over the node "
                          "(65536 / N per GPU), party-sharded, one RCCL all-gather per round (= --t 2 --n 5 --mode party --sessions 65536/N)")
@@ -1755,7 +1757,7 @@ def main():
             mint_cache = {}
             section("c4_every_session_its_own_wallet", lambda: [multi_wallet_distinct(ctx, E, G, keys, K_, B_, gen, threads, cache=mint_cache,
                                                                                      parity_sample=0 if args.no_cpu_baseline else 16)
-                                                                for K_, B_ in ((16384, 16384), (4096, 4096), (4096, 16384))])
+                                                                for K_, B_ in [tuple(int(v_) for v_ in x_.split("x")) for x_ in args.wallet_cases.split(",") if x_]])
             section("lindell17", lambda: lindell_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline))
             section("f2_blame_4096", lambda: blame_section(ctx, E, G, keys, F, gen, cpu=not args.no_cpu_baseline))
             section("f3_keygen_verify_8192", lambda: keygen_verify_section(ctx, E, keys, F, cpu=not args.no_cpu_baseline))

@@ -843,6 +843,9 @@ static Slab slab_of(const mpe_gg20_session* s, const uint32_t* p, const int64_t*
 }
 static int round_enter(mpe_gg20_session* s, int round, const void* in, const void* out, bool need_in, bool need_out) {
   if (!s || (need_in && !in) || (need_out && !out)) return MPE_E_ARG;
+  // a round call that FAILED (MPE_E_NOMEM, a HIP failure) may have written half of this round's state: the same round must not be
+  // entered again on it — mpe_gg20_session_rearm / _abort are the only ways on (include/mpecdsa_hip.h: "the batch cannot go on")
+  if (s->failed) { mpe_set_error_msg("gg20: a round call of this batch failed (or the batch was aborted): re-arm the session"); return MPE_E_ARG; }
   if (s->next_round != round) { mpe_set_error_msg("gg20: rounds must be run in order"); return MPE_E_ARG; }
   s->d.enc = s->ctx->enc;          // the transcript conventions are the context's, read when a round starts
   return MPE_OK;

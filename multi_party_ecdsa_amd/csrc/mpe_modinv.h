@@ -205,11 +205,19 @@ __global__ void inv_count_kernel(int B, Rows mod_sel, InvPlan p) {
     todo &= ~same;
   }
 }
-// single lane: bucket offsets (in place of the counts) and the chunk table
-__global__ void inv_plan_kernel(int nmod, int chunk, InvPlan p) {
-  if (blockIdx.x || threadIdx.x) return;
+// one wave: bucket offsets (in place of the counts) and the chunk table.  Every lane takes a contiguous run of moduli, counts its items and
+// chunks, the 64 partial sums are scanned, and the lane writes its run (a launch may carry tens of thousands of moduli — every
+// session its own wallet — where one lane walking all of them took ~0.1 s per inversion call)
+__global__ void __launch_bounds__(64) inv_plan_kernel(int nmod, int chunk, InvPlan p) {
+  __shared__ int32_t s_items[64], s_chunks[64];
+  const int lane = threadIdx.x, per = (nmod + 63) / 64, lo = lane * per, hi = lo + per < nmod ? lo + per : nmod;
+  int items = 0, chunks = 0;
+  for (int m = lo; m < hi; ++m) { const int c = p.cnt[m]; items += c; chunks += (c + chunk - 1) / chunk; }
+  s_items[lane] = items; s_chunks[lane] = chunks;
+  __syncthreads();
   int off = 0, nc = 0;
-  for (int m = 0; m < nmod; ++m) {
+  for (int t = 0; t < lane; ++t) { off += s_items[t]; nc += s_chunks[t]; }
+  for (int m = lo; m < hi; ++m) {
     const int c = p.cnt[m];
     p.cnt[m] = off;
     for (int s = 0; s < c; s += chunk) {
@@ -220,7 +228,7 @@ __global__ void inv_plan_kernel(int nmod, int chunk, InvPlan p) {
     }
     off += c;
   }
-  p.nch[0] = nc;
+  if (lane == 63) p.nch[0] = nc;
 }
 __global__ void inv_perm_kernel(int B, Rows mod_sel, InvPlan p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -369,7 +377,7 @@ static ModsetView inv_view_of(const mpe_modset* ms) {
 }
 
 static size_t modinv_ws_words(const mpe_modset* ms, int B) {
-  const int K = ms->K, K32 = ms->bits / 32, maxch = B / 16 + ms->count + 2;
+  const int K = ms->K, K32 = ms->bits / 32, maxch = B / 16 + (ms->count < B ? ms->count : B) + 2;     // chunks <= B / chunk + the moduli that have items
   return (size_t)B * (2 * K + 3) + (size_t)maxch * (2 * K32 + 8) + ms->count + 4096;
 }
 
@@ -380,7 +388,7 @@ static int launch_modinv_batched(mpe_ctx* ctx, const mpe_modset* ms, int B, Rows
   // chunk = items inverted through ONE real inversion: 64 for throughput; a small batch is latency-bound, and the up / down
   // sweeps are `chunk` sequential multiplications, so it takes short chunks (more, but concurrent, wave gcds)
   const int CH = B <= ctx->par_items ? 16 : 64;
-  const int nmod = ms->count, maxch = B / CH + nmod + 2;
+  const int nmod = ms->count, maxch = B / CH + (nmod < B ? nmod : B) + 2;
   InvPlan p;
   p.cnt = ws_array<int32_t>(ctx, nmod + 1);
   p.rank = ws_array<int32_t>(ctx, B);
@@ -422,8 +430,11 @@ static int launch_modinv_batched(mpe_ctx* ctx, const mpe_modset* ms, int B, Rows
 static int launch_modinv(mpe_ctx* ctx, const mpe_modset* ms, int B, Rows mod_sel, Rows a, uint32_t* out, uint8_t* ok,
                          hipStream_t st) {
   if (B == 0) return MPE_OK;
-  // with (nearly) one modulus per item there is nothing to batch: lane-serial kernel
-  if ((size_t)ms->count * 8 > (size_t)B && ms->count > 1) {
+  // A handful of items: the lane-serial kernel, one launch.  (Rounds 2-5 also sent every launch with "nearly one modulus per item" here —
+  // nothing to batch — but the lane-serial binary gcd works in scratch memory and manages ~0.25 M inversions/s; chunks of ONE item through
+  // the wave-cooperative gcd are ~7x that at scale: 16 384 sessions with a wallet each spent 74 % of their time in this kernel,
+  // profiles/r06/kernel_stats_wallets_16384x16384.csv.)
+  if (B <= 32 && ms->count > 1) {
     if (ms->bits == 4096)
       hipLaunchKernelGGL(modinv_lane_kernel<128>, dim3(blocks_for(B, 64)), dim3(64), 0, st, B, ms->words, mod_sel, a,
                          (const uint8_t*)nullptr, out, ok);
