@@ -883,22 +883,28 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   // ... and every x^N the key holders compute this round (the randomness of MessageA.c, the beta of each range proof) goes
   // through ONE launch: two concurrent launches of a few hundred waves each start on the same SIMDs of every CU and take
   // 15 ms where one launch of 1 024 waves takes 11.5
+  // (round 6) ... on the FORKED stream, in front of the encryption's tail that needs it: the range proofs' N~ side (four fixed-base
+  // powers per proof) starts at once on the caller's stream beside the ladders instead of behind them; the proofs wait for beta^N only
+  // where they multiply it in (ev_mid)
   const uint32_t *rn_pre = nullptr, *bn_pre = nullptr;
+  Fork g(ctx, st, 2, held, 2);
+  hipEvent_t xn_ready = nullptr;
   if (held && ctx->merge_xn) {
+    hipStream_t sx = g.s(1);
     uint32_t* xs = ws_array<uint32_t>(ctx, nXN * 64);
     uint32_t* xn = ws_array<uint32_t>(ctx, nXN * 128);
     int32_t* kx = ws_array<int32_t>(ctx, nXN);
     if (!xs || !xn || !kx) rc = MPE_E_NOMEM;
     if (rc == MPE_OK) {
-      (void)hipMemcpyAsync(xs, Z.r_a, c.nPI * 64 * 4, hipMemcpyDeviceToDevice, st);
-      (void)hipMemcpyAsync(xs + c.nPI * 64, Z.al_beta, c.nAP * 64 * 4, hipMemcpyDeviceToDevice, st);
-      (void)hipMemcpyAsync(kx, s->ix.kown_pi, c.nPI * 4, hipMemcpyDeviceToDevice, st);
-      (void)hipMemcpyAsync(kx + c.nPI, s->ix.kown_ap, c.nAP * 4, hipMemcpyDeviceToDevice, st);
-      rc = modexp_nn(ctx, K->prv, (int)nXN, key_selector(K->prv, kx), rows(xs, 64, nullptr, 64), key_rows(K->prv, K->prv->N, 64, kx), 64, true, xn, st, true);
+      (void)hipMemcpyAsync(xs, Z.r_a, c.nPI * 64 * 4, hipMemcpyDeviceToDevice, sx);
+      (void)hipMemcpyAsync(xs + c.nPI * 64, Z.al_beta, c.nAP * 64 * 4, hipMemcpyDeviceToDevice, sx);
+      (void)hipMemcpyAsync(kx, s->ix.kown_pi, c.nPI * 4, hipMemcpyDeviceToDevice, sx);
+      (void)hipMemcpyAsync(kx + c.nPI, s->ix.kown_ap, c.nAP * 4, hipMemcpyDeviceToDevice, sx);
+      rc = modexp_nn(ctx, K->prv, (int)nXN, key_selector(K->prv, kx), rows(xs, 64, nullptr, 64), key_rows(K->prv, K->prv->N, 64, kx), 64, true, xn, sx, true);
       rn_pre = xn; bn_pre = xn + c.nPI * 128;
+      if (rc == MPE_OK && g.on) { (void)hipEventRecord(ctx->ev_mid, sx); xn_ready = ctx->ev_mid; }
     }
   }
-  Fork g(ctx, st, 2, held, 2);
   if (rc == MPE_OK) rc = paillier_encrypt(ctx, K->prv, (int)c.nPI, s->ix.kown_pi, s->k64, Z.r_a, s->c_a, true, g.s(1), rn_pre);      // MessageA.c
   gg_trace(s->ctx, st, "encrypt k", rc);
   Bump t(s->tmp);
@@ -906,7 +912,7 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   mpe_alice_nonces an{Z.al_alpha, Z.al_beta, Z.al_gamma, Z.al_rho};
   if (rc == MPE_OK)
     rc = alice_generate(ctx, K->prv, K->stm, (int)c.nAP, s->ix.kown_ap, s->ix.st_ap, rows(s->kq, 8, s->ix.pi_ap),
-                        rows(s->c_a, 128, s->ix.pi_ap), rows(Z.r_a, 64, s->ix.pi_ap), &an, &ap, st, &g, bn_pre);
+                        rows(s->c_a, 128, s->ix.pi_ap), rows(Z.r_a, 64, s->ix.pi_ap), &an, &ap, st, &g, bn_pre, xn_ready);
   else g.join();
   if (held) ctx->ws_hold--;
   gg_trace(s->ctx, st, "alice_generate", rc);
@@ -1233,7 +1239,10 @@ int mpe_gg20_keys_create(mpe_ctx* ctx, int t, int n, int n_signers, const int32_
     // 13 bits (0.5 GB per base) for a handful of key sets, narrower when a batch carries many wallets
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    const size_t budget = ctx->fb_budget_bytes ? ctx->fb_budget_bytes : free_b / 4;
+    size_t budget = ctx->fb_budget_bytes ? ctx->fb_budget_bytes : free_b / 4;
+    // thousands of wallets: rather half of the free memory for 4-bit tables (704 multiplications per power) than none at all (a
+    // 2816-bit variable-base ladder: 4.8x the multiplications) — K = 4 096 wallets x 3 parties: 80 GB
+    if (!ctx->fb_budget_bytes && mpe_statements_table_bytes(nkeysets * n, 4) > budget && mpe_statements_table_bytes(nkeysets * n, 4) <= free_b / 2) budget = free_b / 2;
     int wb = ctx->fb_window_bits;
     while (wb > 4 && mpe_statements_table_bytes(nkeysets * n, wb) > budget) --wb;
     // thousands of wallets with moduli of their own: even 4-bit tables (3.2 MB per base) do not fit — no tables at all, the powers of

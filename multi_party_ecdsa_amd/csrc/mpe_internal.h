@@ -38,6 +38,7 @@ struct mpe_ctx {
   int fb_split = 0;               // fixed-base ladders: lane groups that share one item's windows (0 = chosen per launch, mpe_fixedbase.h)
   int gg20_trace = 0;             // option gg20_trace: synchronise and report after every composite of a round
   int sampler_max_attempts = 128; // rejection loops of the device sampler give up after this many candidates (mpe_sample.h)
+  int no_primaries = 0;           // option no_primaries: launches with at most one unit per SIMD keep static units (the queue of multi-pass launches stays)
   int no_elect = 0;               // option no_elect: the dispatcher's placement is taken as it comes (rounds 1-5), mpe_sched.h
   int grid_mode = 2;              // persistent_grid(): 0 = equal trips (rounds 1-4), 1 = full trips + tail, 2 = tail only when it fits one wave per SIMD (option grid = equal|full|hybrid)
   // window-table scratch, grown on demand: one buffer per stream slot (0 = the caller's stream, 1..3 = the auxiliary streams
@@ -179,14 +180,14 @@ inline int blocks_for(int n, int threads) { return (n + threads - 1) / threads; 
 inline int persistent_grid(const mpe_ctx* ctx, int need, int cap);
 inline int ladder_grid(const mpe_ctx* ctx, int units, int cap) {
   if (ctx->no_elect) return persistent_grid(ctx, units, cap);
-  if (units <= cap) return 2 * units <= cap ? 2 * units : units;
+  if (units <= cap) return (2 * units <= cap && !ctx->no_primaries) ? 2 * units : units;
   return cap;
 }
 // the scheduler arguments of that launch; `state` (SCHED_WORDS ints of device scratch the launch owns) is zeroed on `st` when used
 inline SchedArgs ladder_sched(const mpe_ctx* ctx, int units, int cap, int32_t* state, hipStream_t st) {
   SchedArgs a{nullptr, SCHED_STATIC, units};
   if (ctx->no_elect || !state) return a;
-  if (2 * units <= cap) { a.state = state; a.mode = SCHED_PRIMARIES; }
+  if (2 * units <= cap) { if (!ctx->no_primaries) { a.state = state; a.mode = SCHED_PRIMARIES; } }
   else if (units > cap) { a.state = state; a.mode = SCHED_ALL; }
   if (a.state) (void)hipMemsetAsync(a.state, 0, SCHED_WORDS * sizeof(int32_t), st);
   return a;

@@ -272,8 +272,9 @@ static int launch_pair_modexp(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Ro
 
 extern "C" {
 
-// 0.4: mpe_prof_rec grew (sliding_frac); 0.5: sampler, pipeline, comm, keygen verdicts, session abort
-const char* mpe_version(void) { return "mpecdsa-hip 0.5.0 (gfx950)"; }
+// 0.4: mpe_prof_rec grew (sliding_frac); 0.5: sampler, pipeline, comm, keygen verdicts, session abort; 0.6: options instead of
+// environment switches, per-ticket pass status + grouping rules of the pipeline, status 91, RCCL bound at run time, mpe_comm_library
+const char* mpe_version(void) { return "mpecdsa-hip 0.6.0 (gfx950)"; }
 const char* mpe_last_error(void) { return g_last_error.c_str(); }
 
 void mpe_encoding_default(mpe_encoding* e) {
@@ -341,6 +342,7 @@ static const CtxOption kCtxOptions[] = {
     MPE_OPT_INT("fb_split", 0, 64, fb_split),                // lane groups per fixed-base item (0 = chosen per launch)
     MPE_OPT_INT("gg20_trace", 0, 1, gg20_trace),             // synchronise and report after every composite of a round (stderr)
     MPE_OPT_INT("sampler_max_attempts", 1, 1 << 20, sampler_max_attempts),
+    MPE_OPT_INT("no_primaries", 0, 1, no_primaries),         // lone launches keep static units; multi-pass launches still pull from the queue
     MPE_OPT_INT("no_elect", 0, 1, no_elect),                 // ladder launches take the dispatcher's placement as it comes (mpe_sched.h)
     {"fb_budget_mb", 0, 1 << 20, [](mpe_ctx* c, long v) { c->fb_budget_bytes = (size_t)v << 20; }, [](const mpe_ctx* c) -> long { return (long)(c->fb_budget_bytes >> 20); }},
 };

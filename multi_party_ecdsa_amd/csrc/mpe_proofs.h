@@ -310,7 +310,9 @@ static int merge_rc(const Seq& a, const Seq& b, const Seq& c) { return a.rc != M
 static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
                           const int32_t* st_idx, Rows a, Rows cipher, Rows r,
                           const mpe_alice_nonces* nn, const mpe_alice_proof* out, hipStream_t st, Fork* outer = nullptr,
-                          const uint32_t* bn_pre = nullptr) {      // bn_pre: beta^N mod N^2 when the caller already has it
+                          const uint32_t* bn_pre = nullptr, hipEvent_t bn_pre_ready = nullptr) {      // bn_pre: beta^N mod N^2 when the caller
+                                                                                                      // already has it (or has queued it
+                                                                                                      // elsewhere: bn_pre_ready)
   MPE_TRY(ws_reserve(ctx, ws_need_alice_generate(B), st));
   Fork f(ctx, st, 3, B <= ctx->par_items);
   Seq q{ctx, f.s(0), B}, q1{ctx, f.s(1), B}, q2{ctx, f.s(2), B};
@@ -324,6 +326,7 @@ static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statem
   // u = (alpha N + 1) beta^N mod N^2                                            :53-55
   uint32_t* gu = q.words(128);
   q.muladd(rows(nn->alpha, 24), 24, Nrow, 64, no_rows(), 0, gu, 128);
+  if (bn_pre && bn_pre_ready) (void)hipStreamWaitEvent(f.s(0), bn_pre_ready, 0);
   const uint32_t* bn = bn_pre ? bn_pre : q.modexp_nn(pk, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64, true, true);   // the prover owns the key
   uint32_t* u = q.modmul(pk->ms_nn, ksel, rows(gu, 128), rows(bn, 128));
   // w = h1^alpha h2^gamma mod N~                                                :56-57

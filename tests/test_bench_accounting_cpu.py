@@ -190,3 +190,15 @@ def test_post_timing_watchdog_prints_the_timed_line_and_leaves_with_status_0():
     code3 = code.replace("PostTimingWatchdog(0, 0.3, lambda: {'metric': 'm', 'value': 1.0})", "PostTimingWatchdog(1, 0.3, None)")
     p3 = subprocess.run([sys.executable, "-c", code3], capture_output=True, text=True, timeout=120)
     assert p3.returncode == 0 and "{" not in p3.stdout
+
+
+def test_distinct_wallet_moduli_are_distinct_and_well_formed():
+    """bench.py's c4_every_session_its_own_wallet: K n pairwise distinct Paillier moduli and N~ from a pool of fresh primes"""
+    import bench
+    import fixtures as F
+    p, q, nt, h1, h2, nprimes = bench.mint_distinct_moduli(21, 4)
+    P, Q_, NT, H1, H2 = F.ints(p), F.ints(q), F.ints(nt), F.ints(h1), F.ints(h2)
+    assert len({a * b for a, b in zip(P, Q_)}) == 21 and len(set(NT)) == 21 and nprimes == 16
+    for a, b, n, x, y in zip(P, Q_, NT, H1, H2):
+        assert a.bit_length() == 1024 and b.bit_length() == 1024 and (a * b).bit_length() in (2047, 2048) and a != b
+        assert n.bit_length() in (2047, 2048) and 1 < x < n and 1 < y < n

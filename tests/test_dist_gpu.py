@@ -145,7 +145,7 @@ def _spawn(world, args, **kw):
     (2, 1, 3, [0, 2], 4, "party"),            # one party per rank: the reference's deployment
     (2, 1, 3, [1, 2], 6, "rotated"),          # party p of block s on rank (s + p) % 2
     (3, 2, 5, [0, 2, 4], 3, "rotated"),       # BASELINE config 5's shape, three ranks
-    (3, 2, 4, [0, 1, 3], 2, "party"),
+    # ((3, 2, 4, [0, 1, 3], 2, "party") ran until round 5; the CPU suite keeps that placement at world 3 under gloo)
 ])
 def test_party_sharded_gpu_engines_over_gloo(world, t, n, signers, B, placement):
     res = _spawn(world, (t, n, signers, B, placement), runs=2)       # two batches on the same sessions and gather buffers
@@ -362,9 +362,9 @@ def test_an_abandoned_batch_can_be_given_up_and_the_object_reused(gpu_ctx, keys)
 
 
 # ---- bench.py --gpus N spawns its own ranks -----------------------------------------------------------------------------
-@pytest.mark.parametrize("mode,shape", [("session", []), ("party", []), ("party", ["--t", "2", "--n", "5"])])
+@pytest.mark.parametrize("mode,shape", [("session", []), ("party", ["--t", "2", "--n", "5"])])
 def test_bench_self_spawns_two_ranks(mode, shape):
-    """(the third case: three signers on two ranks — two parties of a session share a rank, `colocate` — and bench flags that
+    """(the second case: three signers on two ranks — two parties of a session share a rank, `colocate` — and bench flags that
     are prefixes of the launcher's own options, which must reach bench.py untouched)"""
     env = dict(os.environ)
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)

@@ -32,7 +32,7 @@ def wallet(gpu_ctx):
     gk.close()
 
 
-@pytest.mark.parametrize("group,lanes,nb", [(3, 2, 7), (1, 1, 2)])     # (a third shape, (4, 3, 5), ran until round 5: 10 s, nothing the first does not cover)
+@pytest.mark.parametrize("group,lanes,nb", [(3, 2, 5), (1, 1, 2)])     # (a third shape, (4, 3, 5), ran until round 5: 10 s, nothing the first does not cover)
 def test_stream_of_batches_equals_batch_by_batch_signing(gpu_ctx, wallet, group, lanes, nb):
     ctx = gpu_ctx
     lk, gk = wallet
