@@ -1744,9 +1744,10 @@ def main():
                 l_ = c4_pipeline(ctx, E, G, keys, batches=args.stream_batches, lanes=args.stream_lanes, group=args.stream_group,
                                  oracle=False, parity_sample=0, window=args.stream_lanes * args.stream_group)
                 main_["other_shapes"][f"{args.stream_lanes}x{args.stream_group}_one_group_outstanding_per_lane"] = {k_: l_[k_] for k_ in keep_}
-                # group = 2: half the pass, half the latency (the review's shape)
-                g2_ = c4_pipeline(ctx, E, G, keys, batches=args.stream_batches, lanes=args.stream_lanes, group=2, oracle=False, parity_sample=0)
-                main_["other_shapes"][f"{args.stream_lanes}x2"] = {k_: g2_[k_] for k_ in keep_}
+                # group = 2: half the pass, half the latency (the review's shape) — with FOUR lanes: 4 x 2 keeps as many sessions in flight as
+                # 2 x 4 in passes half as long (profiles/r06/ab_stream12.jsonl: 2 x 2 12.4 - 14.0 k at p50 0.58 - 0.66 s, 4 x 2 15.5 k at 0.50 - 0.54 s)
+                g2_ = c4_pipeline(ctx, E, G, keys, batches=args.stream_batches, lanes=4, group=2, oracle=False, parity_sample=0)
+                main_["other_shapes"]["4x2"] = {k_: g2_[k_] for k_ in keep_}
                 # the same service under an OPEN loop: Poisson arrivals at 50 % and 90 % of the closed-loop capacity, arrival-driven grouping
                 main_["open_loop"] = c4_open_loop(ctx, E, G, keys, main_["signatures_per_s"], lanes=args.stream_lanes, group=args.stream_group)
                 return main_
