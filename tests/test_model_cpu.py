@@ -113,3 +113,17 @@ def test_lone_ladder_model_prices_the_delayed_quotient_before_anyone_builds_it()
     assert t[5]["exposed_share"] > 0.7 and t[5]["orup_unit_ms"] > t[9]["unit_ms"]          # even improved, 5 limbs per lane lose to 9 as they are
     assert abs(m.issue_cycles(9) - (18 * 5.66 + 5.1 * 4.2)) < 1e-9
     assert 6.0 < m.lone_batch_gain_ms() < 10.0 < 124.2 - 95.0
+
+
+def test_scheduling_model_static_units_against_the_unit_queue():
+    """why the headline moved in round 6 with no change to the arithmetic: one SIMD, two ladder waves, the arbiter's measured preference for the
+    older one (profiles/r06/wave_trace*.jsonl).  With STATIC units the older wave finishes its half at 0.6 of the launch and leaves; with the
+    unit QUEUE it keeps pulling — 30 of a SIMD's 40 units — and the launch ends 6 % earlier (measured: 1 234 -> 1 144 ms, 7.3 %)"""
+    m = _load("sched_model")
+    t = {r["units_per_simd"]: r for r in m.table()}
+    for u in (4, 40):
+        assert abs(t[u]["static_ms"] / t[u]["static_measured_ms"][0] - 1) < 0.05 and abs(t[u]["queue_ms"] / t[u]["queue_measured_ms"] - 1) < 0.06
+    assert 0.05 < t[40]["gain"] < 0.08 and t[40]["units_run_by_the_older_wave"] >= 29
+    assert 88.0 <= t[3]["static_ms"] <= 96.0
+    assert 1.15 < (m.R_O + m.R_Y) / m.R_L < 1.25                                  # two waves deliver ~1.2x the units of one
+    assert m.simulate(1, True)[0] == m.LONE and m.simulate(2, True)[0] > m.simulate(1, True)[0]
