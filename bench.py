@@ -1281,7 +1281,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the c2 / c3 / c4 / c5 / Lindell sections")
     ap.add_argument("--stream-batches", type=int, default=96, help="c4_stream_1024: batches of 1 024 sessions in the stream")
-    ap.add_argument("--stream-lanes", type=int, default=2, help="c4_stream_1024: passes in flight (mpe_gg20_pipeline lanes)")
+    ap.add_argument("--stream-lanes", type=int, default=4, help="c4_stream_1024: passes in flight (mpe_gg20_pipeline lanes; 4 since round 6: "
+                    "16.85 k signatures/s at p50 0.97 s against 16.1 - 16.3 k at 1.02 s with 2, profiles/r06/ab_stream12.jsonl)")
     ap.add_argument("--stream-group", type=int, default=4, help="c4_stream_1024: batches coalesced per pass")
     ap.add_argument("--dump-launches", action="store_true", help="add the timed region's heavy launches (kind, bits, batch, ms) to the line")
     ap.add_argument("--only", default="", help="comma list of config sections to run after the timed region (default: all)")
@@ -1748,8 +1749,12 @@ def main():
                 # 2 x 4 in passes half as long (profiles/r06/ab_stream12.jsonl: 2 x 2 12.4 - 14.0 k at p50 0.58 - 0.66 s, 4 x 2 15.5 k at 0.50 - 0.54 s)
                 g2_ = c4_pipeline(ctx, E, G, keys, batches=args.stream_batches, lanes=4, group=2, oracle=False, parity_sample=0)
                 main_["other_shapes"]["4x2"] = {k_: g2_[k_] for k_ in keep_}
+                if args.stream_lanes != 2:                   # rounds 4-5's shape, for continuity
+                    r5_ = c4_pipeline(ctx, E, G, keys, batches=args.stream_batches, lanes=2, group=args.stream_group, oracle=False, parity_sample=0)
+                    main_["other_shapes"][f"2x{args.stream_group}"] = {k_: r5_[k_] for k_ in keep_}
                 # the same service under an OPEN loop: Poisson arrivals at 50 % and 90 % of the closed-loop capacity, arrival-driven grouping
                 main_["open_loop"] = c4_open_loop(ctx, E, G, keys, main_["signatures_per_s"], lanes=args.stream_lanes, group=args.stream_group)
+                main_["open_loop_2_lanes"] = c4_open_loop(ctx, E, G, keys, main_["signatures_per_s"], loads=(0.5,), lanes=2, group=args.stream_group)
                 return main_
             section("c4_stream_1024", stream_section)
             section("c5_share_t2n5_8192", lambda: gg20_config(ctx, E, G, keys, 2, 5, 8192, 1, gen, parity_sample=0 if args.no_cpu_baseline else 32,

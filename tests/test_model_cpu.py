@@ -127,3 +127,16 @@ def test_scheduling_model_static_units_against_the_unit_queue():
     assert 88.0 <= t[3]["static_ms"] <= 96.0
     assert 1.15 < (m.R_O + m.R_Y) / m.R_L < 1.25                                  # two waves deliver ~1.2x the units of one
     assert m.simulate(1, True)[0] == m.LONE and m.simulate(2, True)[0] > m.simulate(1, True)[0]
+
+
+def test_orup_model_the_residues_are_right_and_the_values_are_29_bits_too_large():
+    """the delayed-free quotient digit (q = low limb, no multiplication) written as a bit-level model BEFORE any kernel: the pair residues come
+    out right with the SAME Montgomery radix, the columns stay far below 2^64 — and the results are bounded by N N', not by 2N (Orup reduces
+    modulo N~): the 9-limb layout of the 1024-bit halves overflows its 36 limbs, the others would need R = r^(n+1) and a plain reduction
+    before the final normalisation.  The finding that kept the kernel unwritten this round (tools/model/orup_model.py)."""
+    m = _load("orup_model")
+    for case in m.CASES:
+        st = m.run(*case, 2, 5, False)
+        assert st["maxcol"] < (1 << 62)
+        assert (1 << 20) < st["maxval_over_N"] < (1 << 29)                      # ~ N' times larger than a Montgomery result
+    assert m.overflows()
