@@ -115,6 +115,9 @@ class Context {
   mpe_ctx* get() const { return h_; }
   void sync() const { check(mpe_sync(h_, nullptr), "mpe_sync"); }
   void set_encoding(const mpe_encoding& e) { check(mpe_ctx_set_encoding(h_, &e), "mpe_ctx_set_encoding"); }
+  // the library reads no environment variable: an A/B switch of the measurements is an option of the context (mpecdsa_hip.h)
+  void set_option(const char* key, const char* value) { check(mpe_ctx_set_option(h_, key, value), "mpe_ctx_set_option"); }
+  long option(const char* key) const { long v = 0; check(mpe_ctx_get_option(h_, key, &v), "mpe_ctx_get_option"); return v; }
  private:
   mpe_ctx* h_ = nullptr;
 };

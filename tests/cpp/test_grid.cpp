@@ -32,6 +32,29 @@ int main() {
   }
   mpe_ctx dflt;
   if (dflt.grid_mode != 2) { std::printf("FAILED: the default is not hybrid\n"); return 1; }
+  // round 6: the ladder kernels' scheduler (mpe_sched.h, ladder_grid / ladder_sched) — at most one unit per SIMD: election on twice the
+  // workgroups; more units than resident waves: the whole chip and the unit queue; in between and under no_elect: static units.
+  // (state = a dummy non-null pointer: ladder_sched only zeroes it through the HIP runtime when it uses it — host-only builds have no
+  //  device, so the memset call fails harmlessly and its result is ignored)
+  static int32_t dummy[mpe::SCHED_WORDS];
+  for (int cap : {2048, 8}) {
+    for (int need = 1; need <= 5 * cap + 1; ++need) {
+      int mode = 0;
+      mpe_ctx c;
+      const int grid = mpe::ladder_grid(&c, need, cap);
+      const mpe::SchedArgs a = mpe::ladder_sched(&c, need, cap, dummy, nullptr);
+      ++cases;
+      CHECK(a.units == need);
+      if (2 * need <= cap) { CHECK(grid == 2 * need && a.state == dummy && a.mode == mpe::SCHED_PRIMARIES); }
+      else if (need <= cap) { CHECK(grid == need && a.state == nullptr && a.mode == mpe::SCHED_STATIC); }
+      else { CHECK(grid == cap && a.state == dummy && a.mode == mpe::SCHED_ALL); }
+      mpe_ctx np; np.no_primaries = 1;
+      const mpe::SchedArgs b = mpe::ladder_sched(&np, need, cap, dummy, nullptr);
+      if (need <= cap) { CHECK(mpe::ladder_grid(&np, need, cap) == need && b.state == nullptr); } else { CHECK(b.mode == mpe::SCHED_ALL); }
+      mpe_ctx ne; ne.no_elect = 1;
+      CHECK(mpe::ladder_grid(&ne, need, cap) == mpe::persistent_grid(&ne, need, cap) && mpe::ladder_sched(&ne, need, cap, dummy, nullptr).state == nullptr);
+    }
+  }
   std::printf("OK %ld cases\n", cases);
   return 0;
 }

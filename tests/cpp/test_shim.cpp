@@ -528,6 +528,15 @@ int main(int argc, char** argv) {
   }
   try {
     Context ctx(0);
+    {  // options are the context's, not the environment's: an unknown key is refused, a known one round-trips
+      bool refused = false;
+      try { ctx.set_option("no_such_option", "1"); } catch (const mpecdsa::Error&) { refused = true; }
+      ctx.set_option("fb_window_bits", "10");
+      const bool ok = refused && ctx.option("fb_window_bits") == 10 && ctx.option("sampler_max_attempts") == 128;
+      ctx.set_option("fb_window_bits", "13");
+      std::printf("test context_options ... %s\n", ok ? "ok" : "FAILED");
+      failed += ok ? 0 : 1;
+    }
     EncryptionKeys ek(ctx, F["N"]);
     DecryptionKeys dk(ctx, F["p"], F["q"]);
     DLogStatements stm(ctx, F["Nt"], F["h1"], F["h2"]);
