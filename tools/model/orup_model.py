@@ -15,7 +15,7 @@ method reduces modulo N~.  Consequences for this engine: operands of K limbs no 
 (36 x 29 = 1 044 bits < 1 024 + 29 + 2), R has to grow to r^(n+1) > 4 N~ — other per-key constants than the 18-limb layout's, so launches of
 different layouts could not share them — and the exact normalisation at the end of an exponentiation needs one plain CIOS reduction first.
 That is the "one more limb of R" of the literature, and it is what tools/model/lone_ladder_model.py prices (+1 limb per lane); together with a
-gain of at most ~8 - 17 ms on a 122 ms lone batch it is why the kernel was NOT written this round.
+gain of ~18 ms on a 122 ms lone batch (95 ms asked for) it is why the kernel was NOT written this round.
 
 The pair arithmetic needs the integer M with x0 y0 + M N = u R.  Pass A starts from c = 0, hence q_0 = 0 and M = (Q / r) N' where
 Q / r = q_1 + q_2 r + ... — not a digit string any more.  Pass B therefore adds, at step i, the single product  (r - q_(i+1)) * N'  to lane 0's
