@@ -3,10 +3,10 @@ waves wait for their own quotient-digit chain (9 and 5 limbs per lane: tools/mod
 mpe_pairexp.h `cios1o` / `cios2o`, in pure Python ints, written and checked BEFORE the kernel.
 
 Plain CIOS (what the 18-limb layout keeps):   c += a * b_j;  m = lo(c) * n0inv mod r;  c += m * n;  c >>= W
-    chain per step: mad(a0 b_j) -> v_mul_lo -> DPP broadcast -> mad(m n0) -> shift -> add -> next mad            (8 links)
+    chain per step: mad(a0 b_j) -> v_mul_lo -> DPP broadcast -> mad(m n0) -> shift -> add -> next mad            (6 - 9 links)
 Here:   N~ = N * N' with N' = -N^-1 mod r, so N~ = -1 (mod r);  Np = (N~ + 1) / r  (K limbs, < N).  Per step
     q = lo(c) mod r  (NO multiplication);   c = (c >> W) + q * Np + b_j * a
-    chain per step: v_and / DPP broadcast -> mad(q Np0) -> next                                                 (3 links)
+    chain per step: v_and / DPP broadcast -> mad(q Np0) -> next                                                 (2 - 4 links)
 Exactness: r * S_(i+1) = S_i + q_i N~ + b_i A r, so after n + 1 steps with b_n = 0 the pass returns S = (c_in / r + A B + Q N~ / r) / r^n:
 the SAME Montgomery radix R = r^n as the n-step CIOS (n = 71 for 2048-bit moduli, 36 for the 1024-bit halves), and the residues are right
 (checked below).  **What the model found before any kernel was written: the VALUES are not.**  Every step adds q * Np with q < r and
@@ -14,8 +14,9 @@ Np ~ N N' / r, so S settles at ~ r (Np + A) / ... ~ N N': the results are bounde
 method reduces modulo N~.  Consequences for this engine: operands of K limbs no longer fit the 1024-bit halves at 9 limbs per lane
 (36 x 29 = 1 044 bits < 1 024 + 29 + 2), R has to grow to r^(n+1) > 4 N~ — other per-key constants than the 18-limb layout's, so launches of
 different layouts could not share them — and the exact normalisation at the end of an exponentiation needs one plain CIOS reduction first.
-That is the "one more limb of R" of the literature, and it is what tools/model/lone_ladder_model.py prices (+1 limb per lane); together with a
-gain of ~18 ms on a 122 ms lone batch (95 ms asked for) it is why the kernel was NOT written this round.
+That is the "one more limb of R" of the literature, and it is what tools/model/lone_ladder_model.py prices (+1 limb per lane).  The timing side
+(tools/ubench/chain_latency.hip): the chain falls from 51 / 65 to 31 / 43 cycles per step, but a lone wave is bound by ~5.5 cycles per issued
+instruction and the instruction count does not fall — at most ~6 ms of a 122 ms lone batch.  The kernel was NOT written.
 
 The pair arithmetic needs the integer M with x0 y0 + M N = u R.  Pass A starts from c = 0, hence q_0 = 0 and M = (Q / r) N' where
 Q / r = q_1 + q_2 r + ... — not a digit string any more.  Pass B therefore adds, at step i, the single product  (r - q_(i+1)) * N'  to lane 0's
