@@ -189,27 +189,29 @@ TAMPERS = [
 ]
 
 
-@pytest.mark.parametrize("name,rnd,sender,word,kind", TAMPERS, ids=[t[0] for t in TAMPERS])
-def test_tampered_message_gives_the_oracles_status_and_bad_actors(gpu_ctx, keys, name, rnd, sender, word, kind):
-    tamper_case(gpu_ctx, keys, name, rnd, sender, word, kind)
+def test_tampered_messages_give_the_oracles_status_and_bad_actors(gpu_ctx, keys):
+    """the whole matrix in ONE batch: session 0 clean, session k carries TAMPERS[k - 1] (one oracle run and one GPU run instead of 23 of each;
+    the per-case form ran in the suite until round 6; tests/test_paths_gpu.py runs the same batch on the large-batch code paths)"""
+    tamper_cases(gpu_ctx, keys, TAMPERS)
 
 
-def tamper_case(gpu_ctx, keys, name, rnd, sender, word, kind):
+def tamper_cases(gpu_ctx, keys, cases):
     from multi_party_ecdsa_amd import engine as E
-    t, n, signers, B = 1, 3, [0, 2], 2
+    t, n, signers, B = 1, 3, [0, 2], 1 + len(cases)
     lk = G.make_local_keys(keys, t, n, signers)
     nonces = G.make_nonces(lk, B, seed="tamper")
     S = len(signers)
 
     def tamper(r, slab):
-        if r != rnd:
-            return
-        if kind == "zero":
-            slab[sender, 1, word:word + 16] = 0
-        elif kind == "flip":
-            slab[sender, 1, word] ^= 4                                      # session 1 only; session 0 stays clean
-        else:
-            slab[sender, 1, word:word + 16] = _other_point(slab[sender, 1, word:word + 16])
+        for k, (name, rnd, sender, word, kind) in enumerate(cases, start=1):      # session k only; session 0 stays clean
+            if r != rnd:
+                continue
+            if kind == "zero":
+                slab[sender, k, word:word + 16] = 0
+            elif kind == "flip":
+                slab[sender, k, word] ^= 4
+            else:
+                slab[sender, k, word:word + 16] = _other_point(slab[sender, k, word:word + 16])
     orc_parties = [G.OracleParty(lk, i, B, G.party_nonces(nonces, lk, i)) for i in range(S)]
     G.run_rounds(orc_parties, nonces["msg"], tamper)
     gk = E.Gg20Keys(gpu_ctx, t, n, signers, lk["arrays"])
@@ -222,15 +224,18 @@ def tamper_case(gpu_ctx, keys, name, rnd, sender, word, kind):
             return None if o is None else o[0]
     gpu_parties = [One(i) for i in range(S)]
     G.run_rounds(gpu_parties, nonces["msg"], tamper)
-    seen = set()
+    seen = [set() for _ in range(B)]
     for i in range(S):
         w, g = orc_parties[i].result(), gpu_parties[i].p.result()
-        assert list(g["status"][0]) == list(w["status"]), (name, i)
-        assert list(g["bad_actors"][0]) == list(w["bad_actors"]), (name, i)
+        for k in range(B):
+            name = "clean" if k == 0 else cases[k - 1][0]
+            assert int(g["status"][0][k]) == int(w["status"][k]), (name, i)
+            assert int(g["bad_actors"][0][k]) == int(w["bad_actors"][k]), (name, i)
+            seen[k].add(int(w["status"][k]))
         assert np.array_equal(g["r"][0], w["r"]) and np.array_equal(g["s"][0], w["s"])
         assert w["status"][0] == 0                                          # the clean session signs
-        seen.add(int(w["status"][1]))
-    assert seen != {0}, "the tampering must be detected by somebody"
+    for k in range(1, B):
+        assert seen[k] != {0}, (cases[k - 1][0], "the tampering must be detected by somebody")
 
 
 @pytest.mark.parametrize("t,n,signers,B,kw", [

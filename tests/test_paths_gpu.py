@@ -7,7 +7,7 @@ import pytest
 import fixtures as F
 import gg20_fixture as G
 import pyref
-from test_gg20_gpu import TAMPERS, _run, tamper_case
+from test_gg20_gpu import TAMPERS, _run, tamper_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -23,12 +23,9 @@ def test_sign_matches_oracle_on_the_large_batch_paths(gpu_ctx_serial, keys, t, n
         assert pyref.ecdsa_verify(lk["y"], F.ints(nonces["msg"][b:b + 1])[0], F.ints(wr[b:b + 1])[0], F.ints(ws[b:b + 1])[0])
 
 
-SOME = TAMPERS[::3]                     # every third case: each round's checks appear once (the full matrix ran on these paths once, 22 / 22)
-
-
-@pytest.mark.parametrize("name,rnd,sender,word,kind", SOME, ids=[t[0] for t in SOME])
-def test_tamper_matrix_on_the_large_batch_paths(gpu_ctx_serial, keys, name, rnd, sender, word, kind):
-    tamper_case(gpu_ctx_serial, keys, name, rnd, sender, word, kind)
+def test_tamper_matrix_on_the_large_batch_paths(gpu_ctx_serial, keys):
+    """the full matrix of tests/test_gg20_gpu.py (one session per case in one batch) on the code paths large batches take"""
+    tamper_cases(gpu_ctx_serial, keys, TAMPERS)
 
 
 @pytest.mark.parametrize("xdiv", ["0", "1000000"])

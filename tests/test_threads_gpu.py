@@ -29,7 +29,7 @@ def _u32(t):
 def test_concurrent_contexts_on_distinct_streams(keys):
     from multi_party_ecdsa_amd import engine as E
     from test_gg20_gpu import GpuParty
-    jobs = [dict(kind="sign", t=1, n=3, signers=[0, 1], B=24, seed="thr-a", shift=0),
+    jobs = [dict(kind="sign", t=1, n=3, signers=[0, 1], B=12, seed="thr-a", shift=0),
             dict(kind="sign", t=2, n=5, signers=[0, 2, 4], B=6, seed="thr-b", shift=5, share=4),      # mpe_ctx_set_device_share: other lane layouts, same bytes
             dict(kind="rounds", t=1, n=3, signers=[1, 2], B=5, seed="thr-c", shift=9),
             dict(kind="paillier", B=96, seed="thr-d")]
