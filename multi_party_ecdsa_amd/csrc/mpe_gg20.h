@@ -757,6 +757,11 @@ struct mpe_gg20_session {
   int32_t *status = nullptr, *sig_recid = nullptr;
   int32_t *sub0_vi = nullptr, *sub4_pv = nullptr, *rdash_pv = nullptr;
   uint8_t *ok_vi = nullptr, *ok_pv = nullptr;
+  // lock-step signing of a small batch (mpe_gg20_sign: every signer local, the rounds chained inside the library): round 0 already inverts
+  // the ciphertexts round 1's verifiers will need, beside the tail of the range proofs (round1_inversion_ahead)
+  bool lockstep = false, cinv_ahead = false;
+  uint32_t* cinv_pre = nullptr;    // [vi][128] c^-1 mod N^2 of every (verifier, sender, statement) of round 1; small batches only
+  uint8_t* cinv_ok_pre = nullptr;  // [vi]
   int fault_step = 0;              // fault injection of the reference's tests (gg_2020/test.rs:282-289,458-465,679-686): 5 / 6 / 7
   uint32_t fault_mask = 0;         // signer ordinals that double their delta_i / sigma_i / s_i
   char* tmp = nullptr;             // per-round scratch (dense outputs of the composites before they are packed)
@@ -831,6 +836,8 @@ static size_t layout(mpe_gg20_session* s, char* base) {
   s->status = m.i(c.nPI * NR); s->sig_recid = m.i(c.nPI);
   // index tables and verdicts of the two verification rounds
   s->sub0_vi = m.i(c.nVI); s->ok_vi = m.f(c.nVI); s->sub4_pv = m.i(c.nPV); s->rdash_pv = m.i(c.nPV); s->ok_pv = m.f(c.nPV);
+  const bool small = s->ctx->allow_par && c.nVI <= (size_t)s->ctx->par_items;       // the batches whose composites fork
+  s->cinv_pre = small ? m.w(c.nVI * 128) : nullptr; s->cinv_ok_pre = small ? m.f(c.nVI) : nullptr;
   s->tmp_bytes = tmp_bytes_of(c);
   s->tmp = (char*)m.take(s->tmp_bytes);
   return m.off;
@@ -863,6 +870,26 @@ static int round_exit(mpe_gg20_session* s, int rc, const char* what) {
   GG_LAUNCH(pack_field_kernel, (size_t)(nitems) * (words), (int)(nitems), (int)(per), d.L, d.B, (int)(nsub), (int)(sub0), (int)(subw),  \
             (int)(dst_off), (const uint32_t*)(src), (int)(words), s->status, s->next_round, d_out)
 
+// does round 1 run the ladders of its verifications and of its MessageBs in ONE launch (round1_merged_ladders)?  Round 0 asks too:
+// only then is the inversion of the ciphertexts in front of a ladder that everything waits for
+static bool round1_merges(const mpe_ctx* ctx, const Counts& c) {
+  const bool par = ctx->allow_par && (int)c.nVI <= ctx->par_items;
+  const size_t resident_groups = (size_t)ctx->cus * ctx->modexp_waves_per_cu * 16 / ctx->device_share;
+  return ctx->merge_r1 && ctx->use_pair && ctx->use_multiexp && c.nVI > 0 && c.nMB > 0 && c.nVI + c.nMB < ((size_t)1 << 30) &&
+         (!par || 4 * (c.nVI + c.nMB) > (size_t)ctx->merge_r1_quarters * resident_groups);
+}
+// every signer local, local slot l = signer ordinal l (mpe_gg20_sign): ca_all[ind][b] = c_a[b][ind] — what round 1's gather_field_kernel
+// will read out of round 0's message slab, before the slab is written
+__global__ void ca_all_from_local_kernel(int S, int B, const uint32_t* __restrict__ c_a, uint32_t* __restrict__ ca_all) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)S * B * 128) return;
+  const int w = (int)(g % 128);
+  const size_t jb = g / 128;
+  const int ind = (int)(jb / B), b = (int)(jb % B);
+  ca_all[g] = c_a[((size_t)b * S + ind) * 128 + w];
+}
+static size_t ws_need_inversion_ahead(const mpe_paillier* pk, size_t nVI) { return nVI * (128 + 128 + 1) * 4 + modinv_ws_words(pk->ms_nn, (int)nVI) * 4 + 16384; }
+
 // ---- Round0::proceed (rounds.rs:68-104) ------------------------------------------------------------------------------
 static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   int rc = round_enter(s, 0, nullptr, d_out, false, true);
@@ -875,8 +902,17 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   // transcript hash); both composites draw from ONE workspace reservation
   const bool par = ctx->allow_par && (int)c.nAP <= ctx->par_items;
   const size_t nXN = c.nPI + c.nAP;
+  // (round 6) lock-step signing: the inversion of the ciphertexts that round 1's verifiers need (6.7 ms of dependent short launches at
+  // 1 024 sessions, in front of the ladder the whole round waits for) starts HERE, on the forked stream behind the encryption, beside the
+  // tail of the range proofs (transcript hash, r^e, the linear responses: 4 ms on the caller's stream).  Same inputs, same kernels, same
+  // verdicts — round 1 finds them done.  Only where the message slab cannot change between the two rounds: mpe_gg20_sign.
+  bool all_local_in_order = d.L == d.S;           // local slot l IS signer ordinal l (ca_all_from_local_kernel)
+  for (int l = 0; l < d.L && all_local_in_order; ++l) all_local_in_order = d.loc[l] == l;
+  const bool ahead = par && s->lockstep && s->cinv_pre && all_local_in_order && !ctx->no_r1_inversion_ahead && round1_merges(ctx, c);
+  s->cinv_ahead = false;
   if (par && rc == MPE_OK) {
-    rc = ws_reserve(ctx, ws_need_encrypt((int)c.nPI) + ws_need_alice_generate((int)c.nAP) + nXN * (64 + 128 + 1 + CRT_WS_WORDS) * 4 + 65536, st);
+    rc = ws_reserve(ctx, ws_need_encrypt((int)c.nPI) + ws_need_alice_generate((int)c.nAP) + nXN * (64 + 128 + 1 + CRT_WS_WORDS) * 4 + 65536 +
+                         (ahead ? ws_need_inversion_ahead(K->pub, c.nVI) : 0), st);
     if (rc == MPE_OK) ctx->ws_hold++;
   }
   const bool held = par && rc == MPE_OK;
@@ -907,13 +943,33 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   }
   if (rc == MPE_OK) rc = paillier_encrypt(ctx, K->prv, (int)c.nPI, s->ix.kown_pi, s->k64, Z.r_a, s->c_a, true, g.s(1), rn_pre);      // MessageA.c
   gg_trace(s->ctx, st, "encrypt k", rc);
+  hipEvent_t c_ready = nullptr;
+  if (ahead && held && g.on && xn_ready && rc == MPE_OK) {
+    hipStream_t sx = g.s(1);
+    // the proofs wait for the CIPHERTEXTS from here on (their transcript hash reads them; beta^N came earlier on the same stream), not for
+    // whatever else this stream gets: the event moves behind the encryption's two short tail kernels
+    (void)hipEventRecord(ctx->ev_mid, sx); c_ready = ctx->ev_mid;
+    hipLaunchKernelGGL(ca_all_from_local_kernel, dim3((unsigned)((c.SB * 128 + 255) / 256)), dim3(256), 0, sx, d.S, d.B, s->c_a, s->ca_all);
+    Seq q{ctx, sx, (int)c.nVI};
+    const Rows ksel = sel_of(s->ix.kpub_vi, K->pub->nkeys);
+    uint8_t* ok = q.flags();
+    uint32_t* cred = q.modmul(K->pub->ms_nn, ksel, rows(s->ca_all, 128, s->ix.ca_vi), rows(K->pub->ms_nn->one_words, 0, nullptr, 1));
+    uint32_t* cinv = q.modinv(K->pub->ms_nn, ksel, rows(cred, 128), ok);
+    rc = q.rc;
+    if (rc == MPE_OK) {
+      (void)hipMemcpyAsync(s->cinv_pre, cinv, c.nVI * 128 * 4, hipMemcpyDeviceToDevice, sx);
+      (void)hipMemcpyAsync(s->cinv_ok_pre, ok, c.nVI, hipMemcpyDeviceToDevice, sx);
+      s->cinv_ahead = true;
+    }
+    gg_trace(s->ctx, sx, "round 1's inversion, ahead", rc);
+  }
   Bump t(s->tmp);
   mpe_alice_proof ap{t.w(c.nAP * 64), t.w(c.nAP * 8), t.w(c.nAP * 64), t.w(c.nAP * 25), t.w(c.nAP * 89)};
   mpe_alice_nonces an{Z.al_alpha, Z.al_beta, Z.al_gamma, Z.al_rho};
   if (rc == MPE_OK)
     rc = alice_generate(ctx, K->prv, K->stm, (int)c.nAP, s->ix.kown_ap, s->ix.st_ap, rows(s->kq, 8, s->ix.pi_ap),
-                        rows(s->c_a, 128, s->ix.pi_ap), rows(Z.r_a, 64, s->ix.pi_ap), &an, &ap, st, &g, bn_pre, xn_ready);
-  else g.join();
+                        rows(s->c_a, 128, s->ix.pi_ap), rows(Z.r_a, 64, s->ix.pi_ap), &an, &ap, st, &g, bn_pre, c_ready ? c_ready : xn_ready, c_ready);
+  g.join();                                       // (again: with c_ready the proofs waited for the event only)
   if (held) ctx->ws_hold--;
   gg_trace(s->ctx, st, "alice_generate", rc);
   PACK(c.nAP, n, n + 1, 0, SUB0, 0, ap.z, 64); PACK(c.nAP, n, n + 1, 0, SUB0, 64, ap.e, 8); PACK(c.nAP, n, n + 1, 0, SUB0, 72, ap.s, 64);
@@ -940,13 +996,19 @@ static size_t ws_need_round1_merged(const mpe_paillier* pk, size_t nVI, size_t n
 }
 static int round1_merged_ladders(mpe_ctx* ctx, const mpe_paillier* pk, size_t nVI, const int32_t* kpub_vi, Rows cipher_vi, Rows s_vi, Rows e_vi,
                                  size_t nMB, const int32_t* kpub_mb, Rows ca_mb, const uint32_t* bsel, const uint32_t* mb_r,
-                                 const uint32_t** m_vi, const uint8_t** inv_ok_vi, const uint32_t** x_mb, hipStream_t st) {
+                                 const uint32_t** m_vi, const uint8_t** inv_ok_vi, const uint32_t** x_mb, hipStream_t st,
+                                 const uint32_t* cinv_pre = nullptr, const uint8_t* cinv_ok_pre = nullptr) {
   const size_t n = nVI + nMB;
   Seq q{ctx, st, (int)nVI};
   const Rows ksel = sel_of(kpub_vi, pk->nkeys);
-  uint8_t* inv_ok = q.flags();
-  uint32_t* cred = q.modmul(pk->ms_nn, ksel, cipher_vi, rows(pk->ms_nn->one_words, 0, nullptr, 1));      // c mod N^2
-  uint32_t* cinv = q.modinv(pk->ms_nn, ksel, rows(cred, 128), inv_ok);                                     // (c^e)^-1 = (c^-1)^e
+  const uint8_t* inv_ok = cinv_ok_pre;
+  const uint32_t* cinv = cinv_pre;
+  if (!cinv_pre) {                                                                                         // (round 0 did it: round1_inversion_ahead)
+    uint8_t* ok = q.flags();
+    uint32_t* cred = q.modmul(pk->ms_nn, ksel, cipher_vi, rows(pk->ms_nn->one_words, 0, nullptr, 1));      // c mod N^2
+    cinv = q.modinv(pk->ms_nn, ksel, rows(cred, 128), ok);                                                 // (c^e)^-1 = (c^-1)^e
+    inv_ok = ok;
+  }
   if (q.rc != MPE_OK) return q.rc;
   uint32_t* b1 = ws_array<uint32_t>(ctx, n * 64);
   uint32_t* b2 = ws_array<uint32_t>(ctx, n * 128);
@@ -993,9 +1055,9 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   // 55.2 || 90.8 ms against 63.5 ms, +9 % on the batch).  Below that the forked launches overlap and merging only serialises the
   // inversion (1 536 sessions: -1.4 %; 1 024: no change; 512: -7.5 %) — profiles/r05/ab_merge_small_batches.jsonl.  What remains of the two halves (the N~ side of the
   // verification, MessageB's encryption tail and DLog proofs) runs on forked streams behind the merged launch.
-  const size_t resident_groups = (size_t)ctx->cus * ctx->modexp_waves_per_cu * 16 / ctx->device_share;
-  const bool merged = ctx->merge_r1 && ctx->use_pair && ctx->use_multiexp && c.nVI > 0 && c.nMB > 0 && c.nVI + c.nMB < ((size_t)1 << 30) &&
-                      (!par || 4 * (c.nVI + c.nMB) > (size_t)ctx->merge_r1_quarters * resident_groups);
+  const bool merged = round1_merges(ctx, c);
+  const bool ahead = merged && s->cinv_ahead;                 // round 0 inverted the ciphertexts already (lock-step signing of a small batch)
+  s->cinv_ahead = false;
   if (par && !merged && rc == MPE_OK) { rc = ws_reserve(ctx, ws_need_alice_verify((int)c.nVI) + ws_need_mul_add_enc((int)c.nMB), st); if (rc == MPE_OK) ctx->ws_hold++; }
   bool held = par && !merged && rc == MPE_OK;
   const uint32_t *m_vi = nullptr, *x_mb = nullptr;
@@ -1010,15 +1072,30 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   // verification's N~ side — fixed-base powers, z^e, an inversion: ~6 ms of short kernels at 1 024 sessions — starts at once on the
   // caller's stream BESIDE it: the ladder's waves are the older ones on their SIMDs and keep 0.92 of their speed (mpe_sched.h), the
   // short kernels run in what is left.  The verification waits for the ladder's output only where it multiplies it in (ev_mid).
+  // MessageB's scalars are prepared BEFORE the fork (both branches read them)
+  if (rc == MPE_OK && c.nMB > 0)
+    hipLaunchKernelGGL(mb_prep_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st, d, s->gq, s->w, Z.mb_beta_tag, bsel, btq, s->beta);
   Fork g(ctx, st, 2, held && par, 2);
   hipEvent_t m_ready = nullptr;
+  auto dlog_proofs = [&](hipStream_t sd) {
+    if (rc != MPE_OK || c.nMB == 0) return;
+    hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, sd, (int)c.nMB, ctx->enc, bsel, Z.mb_nonce_b, Bpk, BR, Bz);      // :147
+    hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, sd, (int)c.nMB, ctx->enc, btq, Z.mb_nonce_bt, BTpk, BTR, BTz);   // :148
+  };
+  // With the inversion done ahead the ladder launch is the first thing the forked stream gets: it has to reach the chip BEFORE the N~ side's
+  // kernels take register space on its SIMDs (a SIMD that already holds two of those cannot take a 256-register ladder wave, its unit starts
+  // late as the younger wave: +10 ms at 1 024 sessions, +25 ms at 2 048 — profiles/r06/ab_prep18.jsonl).  The two DLog proofs of MessageB
+  // (64 - 128 EC waves, ~4 ms, needed only when the round packs its message) go FIRST on the caller's stream: useful work that holds the
+  // N~ side back while the ladder's workgroups are placed.  Without the inversion ahead the ladder starts ~7 ms into the round and the
+  // same proofs would run into it: they stay behind it.
+  const bool dlog_first = ahead && g.on && !ctx->no_r1_dlog_first;
+  if (dlog_first) dlog_proofs(st);
   {
     hipStream_t st2 = g.s(1);
-    if (rc == MPE_OK && c.nMB > 0)
-      hipLaunchKernelGGL(mb_prep_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, d, s->gq, s->w, Z.mb_beta_tag, bsel, btq, s->beta);
     if (merged && rc == MPE_OK) {
       rc = round1_merged_ladders(ctx, K->pub, c.nVI, s->ix.kpub_vi, rows(s->ca_all, 128, s->ix.ca_vi), with_words(pr.s, 64), pr.e, c.nMB, s->ix.kpub_mb,
-                                 rows(s->ca_all, 128, s->ix.ca_mb), bsel, Z.mb_r, &m_vi, &inv_ok_vi, &x_mb, st2);
+                                 rows(s->ca_all, 128, s->ix.ca_mb), bsel, Z.mb_r, &m_vi, &inv_ok_vi, &x_mb, st2,
+                                 ahead ? s->cinv_pre : nullptr, ahead ? s->cinv_ok_pre : nullptr);
       if (rc == MPE_OK && g.on) { (void)hipEventRecord(ctx->ev_mid, st2); m_ready = ctx->ev_mid; }
       gg_trace(s->ctx, st2, "round 1 merged ladders", rc);
     }
@@ -1026,10 +1103,7 @@ static int round1(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
       rc = paillier_mul_add_enc(ctx, K->pub, (int)c.nMB, s->ix.kpub_mb, rows(s->ca_all, 128, s->ix.ca_mb), rows(bsel, 8), 8, Z.mb_beta_tag,
                                 Z.mb_r, c_b, st2, x_mb);
     gg_trace(s->ctx, st2, "MessageB ciphertext", rc);
-    if (rc == MPE_OK && c.nMB > 0) {
-      hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, ctx->enc, bsel, Z.mb_nonce_b, Bpk, BR, Bz);      // :147
-      hipLaunchKernelGGL(dlog_prove_kernel, dim3(blocks_for((int)c.nMB, 64)), dim3(64), 0, st2, (int)c.nMB, ctx->enc, btq, Z.mb_nonce_bt, BTpk, BTR, BTz);   // :148
-    }
+    if (!dlog_first) dlog_proofs(st2);
   }
   if (rc == MPE_OK)        // every range proof of every peer, for both MessageB::b calls (mta/mod.rs:119-131), read in place
     rc = alice_verify(ctx, K->pub, K->stm, (int)c.nVI, s->ix.kpub_vi, s->ix.st_vi, rows(s->ca_all, 128, s->ix.ca_vi), pr, ok_vi, st, m_vi, inv_ok_vi, m_ready);
@@ -1464,6 +1538,7 @@ int mpe_gg20_sign(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch, const int3
     mpe_gg20_session* s = nullptr;
     int rc = mpe_gg20_session_create(ctx, keys, B, S, local, d_keyset ? d_keyset + b0 : nullptr, &Z, dedup_verify, &s, stream);
     if (rc != MPE_OK) return rc;
+    s->lockstep = true;                           // the message slabs never leave the library between two rounds
     rc = mpe::gg::round0(s, M[0], st);
     if (rc == MPE_OK) rc = mpe::gg::round1(s, M[0], nullptr, M[1], st);
     if (rc == MPE_OK) rc = mpe::gg::round2(s, M[1], nullptr, M[2], st);

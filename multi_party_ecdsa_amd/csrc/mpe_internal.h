@@ -31,6 +31,9 @@ struct mpe_ctx {
                                   // heuristics below compare a launch with 1/device_share of the chip, not with all of it
   int xwide_div = 16;             // the 4x-lanes (5 limbs per lane) layout: xwide_div * batch <= the resident groups; 0 = off (MPE_XWIDE_DIV)
   bool merge_xn = true;           // round 0: every x^N of the key holders in ONE launch (MPE_NO_MERGE_XN switches it off)
+  int wide_modexp = 0;            // 2048-bit modexp_kernel on 9 limbs per lane for small launches (option; measured: no gain, see mpe_lib.hip)
+  int no_r1_dlog_first = 0;       // with the inversion ahead: MessageB's DLog proofs behind the ladders again, not in front of the N~ side (option)
+  int no_r1_inversion_ahead = 0;  // lock-step signing of small batches: round 1 inverts the ciphertexts itself, as the per-round calls do (option)
   int merge_r1_quarters = 1;      // small batches merge round 1's two ladder launches when together they exceed this many QUARTERS of the resident groups (option)
   bool merge_r1 = true;           // round 1, large batches: the ladders of the verifications and of the MessageBs in ONE launch (MPE_NO_MERGE_R1)
   size_t fb_budget_bytes = 0;     // memory budget of the fixed-base tables of a key object; 0 = a quarter of free HBM (MPE_FB_BUDGET_MB)

@@ -310,9 +310,12 @@ static int merge_rc(const Seq& a, const Seq& b, const Seq& c) { return a.rc != M
 static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
                           const int32_t* st_idx, Rows a, Rows cipher, Rows r,
                           const mpe_alice_nonces* nn, const mpe_alice_proof* out, hipStream_t st, Fork* outer = nullptr,
-                          const uint32_t* bn_pre = nullptr, hipEvent_t bn_pre_ready = nullptr) {      // bn_pre: beta^N mod N^2 when the caller
-                                                                                                      // already has it (or has queued it
-                                                                                                      // elsewhere: bn_pre_ready)
+                          const uint32_t* bn_pre = nullptr, hipEvent_t bn_pre_ready = nullptr,        // bn_pre: beta^N mod N^2 when the caller
+                          hipEvent_t cipher_ready = nullptr) {                                        // already has it (or has queued it
+                                                                                                      // elsewhere: bn_pre_ready);
+                                                                                                      // cipher_ready: the outer branch goes on
+                                                                                                      // with other work — wait for this event
+                                                                                                      // instead of joining it
   MPE_TRY(ws_reserve(ctx, ws_need_alice_generate(B), st));
   Fork f(ctx, st, 3, B <= ctx->par_items);
   Seq q{ctx, f.s(0), B}, q1{ctx, f.s(1), B}, q2{ctx, f.s(2), B};
@@ -334,7 +337,8 @@ static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statem
   uint32_t* w2 = q2.fb_modexp(stm, ssel, 1, h2,rows(nn->gamma, 88), 88);
   uint32_t* w = q2.modmul(stm->ms, ssel, rows(w1, 64), rows(w2, 64));
   f.join();
-  if (outer) outer->join();
+  if (cipher_ready) (void)hipStreamWaitEvent(st, cipher_ready, 0);
+  else if (outer) outer->join();
   q.rc = merge_rc(q, q1, q2);
   // e = H(N, N+1, c, z, u, w)                                                   :175-182
   HashDesc d;

@@ -26,7 +26,8 @@ def _to_np_u32(t):
 # when it creates a context: MPE_NO_PAR=1 -> ("no_par", "1"), MPE_WIDE_DIV=4 -> ("wide_div", "4"), MPE_GRID=full -> ("grid", "full").
 _ENV_OPTIONS = ["no_fixed_base", "no_crt", "no_multiexp", "no_pair", "no_pown", "no_sliding", "no_par", "no_wide", "no_adaptive_lanes",
                 "no_merge_xn", "no_merge_r1", "fb_window_bits", "window_bits", "wide_div", "xwide_div", "waves_per_cu", "grid", "fb_budget_mb",
-                "fb_split", "gg20_trace", "sampler_max_attempts", "no_elect", "no_primaries", "merge_r1_quarters"]
+                "fb_split", "gg20_trace", "sampler_max_attempts", "no_elect", "no_primaries", "merge_r1_quarters",
+                "no_r1_inversion_ahead", "wide_modexp", "no_r1_dlog_first"]
 
 
 def options_from_env(env=None):

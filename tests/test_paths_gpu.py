@@ -42,3 +42,26 @@ def test_sign_matches_oracle_on_each_small_batch_lane_layout(keys, xdiv):
             assert list(status) == [0] * B == list(wstatus)
             assert np.array_equal(r.view(np.uint32), wr) and np.array_equal(s.view(np.uint32), ws) and list(recid) == list(wrecid)
             assert np.array_equal(R.view(np.uint32), wR)
+
+
+def test_round1_inversion_started_in_round0_gives_the_same_bytes(keys):
+    """Lock-step signing of a small batch (mpe_gg20_sign) starts the inversion of the ciphertexts that round 1's verifiers need in round 0,
+    behind the encryption, and sends MessageB's DLog proofs in front of the N~ side (mpe_gg20.h round0 / round1).  That happens
+    when round 1 merges its ladder launches — above 512 sessions with the shipped thresholds (tests/test_fullsize_gpu.py's config 4, the
+    bench), at ANY size with merge_r1_quarters = 0: the small parity cases here, against the oracle and against a context with the
+    schedule switched off."""
+    from multi_party_ecdsa_amd import engine as E
+    ahead = E.Context(0, options={"merge_r1_quarters": 0})
+    plain = E.Context(0, options={"merge_r1_quarters": 0, "no_r1_inversion_ahead": 1})
+    behind = E.Context(0, options={"merge_r1_quarters": 0, "no_r1_dlog_first": 1})
+    assert ahead.get_option("no_r1_inversion_ahead") == 0 and plain.get_option("no_r1_inversion_ahead") == 1
+    for t, n, signers, B, kw in [(2, 5, [0, 2, 4], 2, {}), (1, 3, [1, 2], 3, {"dedup_verify": True}), (1, 3, [0, 1], 5, {"chunk": 2})]:
+        seed = f"ahead-{t}-{n}-{signers}-{sorted(kw)}"
+        lk, nonces, (r, s, recid, status, R) = _run(ahead, keys, t, n, signers, B, seed, **kw)
+        wr, ws, wrecid, wR, wstatus = G.oracle_sign(lk, nonces, B)
+        assert list(status) == [0] * B == list(wstatus)
+        assert np.array_equal(r.view(np.uint32), wr) and np.array_equal(s.view(np.uint32), ws) and list(recid) == list(wrecid)
+        assert np.array_equal(R.view(np.uint32), wR)
+        for other in ((plain, behind) if t == 1 and not kw.get("dedup_verify") else (plain,)):
+            _, _, (r2, s2, recid2, status2, R2) = _run(other, keys, t, n, signers, B, seed, **kw)
+            assert np.array_equal(r, r2) and np.array_equal(s, s2) and np.array_equal(R, R2) and list(status2) == [0] * B
