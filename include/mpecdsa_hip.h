@@ -76,7 +76,9 @@ int mpe_ctx_set_device_share(mpe_ctx* ctx, int contexts);
  *   0/1 switches   no_fixed_base no_crt no_multiexp no_pair no_pown no_sliding no_par no_wide no_ec_lane_groups
  *                  no_adaptive_lanes (= no_wide + no_ec_lane_groups) no_merge_xn no_merge_r1 gg20_trace
  *                  no_r1_inversion_ahead no_r1_dlog_first (mpe_gg20_sign on small batches: round 0 no longer inverts the ciphertexts
- *                  round 1 needs / MessageB's DLog proofs go behind the ladders again)  wide_modexp (9 limbs per lane in small
+ *                  round 1 needs / MessageB's DLog proofs go behind the ladders again)  no_pdl_ahead (round 4 computes the PDL
+ *                  proofs' beta^N itself instead of finding it done)  no_prio (no s_setprio in the ladder kernels)
+ *                  wide_modexp (9 limbs per lane in small
  *                  2048-bit modexp launches; off: no measurable gain)
  *   integers       fb_window_bits 4..16 | window_bits 0 (auto), 4..6 | wide_div 1..64 | xwide_div 0 (off).. | waves_per_cu 1..8
  *                  fb_budget_mb | fb_split 0 (auto)..64 | sampler_max_attempts 1.. (default 128)

@@ -142,6 +142,7 @@ __global__ void idx_kernel(Dim d, Idx x, int total) {
 
 // dst[(j*B + b)*words + w] = record(j, b)[src_off + w]: keeps a field of every sender's message (m_a_vec, bc_vec, t_vec)
 __global__ void gather_field_kernel(Slab s, int S, int B, int src_off, int words, uint32_t* __restrict__ dst) {
+  MPE_FOREGROUND();
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)S * B * words) return;
   const int w = (int)(g % words);
@@ -170,6 +171,7 @@ __device__ __forceinline__ int resolve_status(const int32_t* status, size_t nPI,
 __global__ void pack_field_kernel(int nitems, int per, int L, int B, int nsub, int sub0, int subw, int dst_off,
                                   const uint32_t* __restrict__ src, int words, const int32_t* __restrict__ status, int round,
                                   uint32_t* __restrict__ out) {
+  MPE_FOREGROUND();
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)nitems * words) return;
   const int w = (int)(g % words), item = (int)(g / words), pi = item / per, li = pi % L, b = pi / L;
@@ -181,6 +183,7 @@ __global__ void pack_field_kernel(int nitems, int per, int L, int B, int nsub, i
 // becomes 100*round + 90 with bad_actors = the senders, BEFORE any secret scalar is multiplied into such a point.
 __device__ __forceinline__ bool pt_ok(const uint32_t* p) { return ec::aff_valid(ec::aff_load(p)); }
 __global__ void __launch_bounds__(64) validate_kernel(Dim d, Slab in, int round, int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
+  MPE_FOREGROUND();
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
   const int i = d.loc[pi % d.L], b = pi / d.L, P1 = d.S - 1;
@@ -315,6 +318,7 @@ __global__ void status1_kernel(Dim d, const uint8_t* __restrict__ ok_vi, int32_t
 // ---- Round 2 -------------------------------------------------------------------------------------------------------
 // receiver view: sub-record (in the incoming M1 slab) of the MessageB that peer `ind` built for me
 __global__ void idx2_kernel(Dim d, Slab in1, int32_t* __restrict__ sub1_rv) {
+  MPE_FOREGROUND();
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int P1 = d.S - 1;
   if (g >= d.B * d.L * P1 * 2) return;
@@ -333,6 +337,7 @@ __device__ __forceinline__ void r2a_finish(const Dim& d, int rv, int v, int pp, 
 __global__ void __launch_bounds__(64) MPE_EC_OCC r2a_kernel(Dim d, const int32_t* __restrict__ sub1_rv, const uint32_t* __restrict__ in1,
                            const uint32_t* __restrict__ alpha_full, const uint32_t* __restrict__ kq, const uint32_t* __restrict__ gw,
                            uint32_t* __restrict__ alpha, uint32_t* __restrict__ bpk_in, uint8_t* __restrict__ code) {
+  MPE_FOREGROUND();
   const int rv = blockIdx.x * blockDim.x + threadIdx.x;
   const int P1 = d.S - 1;
   if (rv >= d.B * d.L * P1 * 2) return;
@@ -363,6 +368,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r2b_kernel(Dim d, const uint32_
                            uint32_t* __restrict__ delta_i, uint32_t* __restrict__ sigma_i, uint32_t* __restrict__ lq, Ped p,
                            int32_t* __restrict__ status, uint32_t* __restrict__ bad, const uint32_t* __restrict__ alpha_full,
                            uint32_t* __restrict__ miu, int fault_step, uint32_t fault_mask) {
+  MPE_FOREGROUND();
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
   const int P1 = d.S - 1;
@@ -417,6 +423,7 @@ __device__ __forceinline__ void r3_finish(int pi, bool com_ok, bool ped_ok, cons
 }
 __global__ void __launch_bounds__(64) MPE_EC_OCC r3_kernel(Dim d, Slab in2, uint32_t* __restrict__ dinv, int32_t* __restrict__ status,
                                                 uint32_t* __restrict__ bad) {
+  MPE_FOREGROUND();
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
   const int b = pi / d.L;
@@ -442,6 +449,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r3_kernel(Dim d, Slab in2, uint
 __global__ void __launch_bounds__(64) MPE_EC_OCC r4_kernel(Dim d, Slab in3, const uint32_t* __restrict__ dinv, const uint32_t* __restrict__ com_all,
                           const uint32_t* __restrict__ bpk_in, const uint32_t* __restrict__ kq, uint32_t* __restrict__ R,
                           uint32_t* __restrict__ Rbar, int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
+  MPE_FOREGROUND();
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
   const int P1 = d.S - 1, i = d.loc[pi % d.L], b = pi / d.L;
@@ -549,6 +557,7 @@ struct JacSlots { ec::Jac v[64]; };
 __global__ void __launch_bounds__(64) MPE_EC_OCC r2a_group_kernel(Dim d, const int32_t* __restrict__ sub1_rv, const uint32_t* __restrict__ in1,
                            const uint32_t* __restrict__ alpha_full, const uint32_t* __restrict__ kq, const uint32_t* __restrict__ gw,
                            uint32_t* __restrict__ alpha, uint32_t* __restrict__ bpk_in, uint8_t* __restrict__ code) {
+  MPE_FOREGROUND();
   // 4 lanes per incoming MessageB: lanes 0..2 do  k_i B | c1 B | c2 B'  (variable base), then  alpha G | z G | z' G
   __shared__ JacSlots vs, fs;
   const int gid = blockIdx.x * 64 + threadIdx.x, rv = gid >> 2, sub = gid & 3, base = (int)threadIdx.x - sub;
@@ -581,6 +590,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r2a_group_kernel(Dim d, const i
 // G lanes per party (a power of two >= 2 S): lane 2j | 2j+1 does z1_j G | z2_j H, lane j also e_j com_j
 __global__ void __launch_bounds__(64) MPE_EC_OCC r3_group_kernel(Dim d, int G, Slab in2, uint32_t* __restrict__ dinv, int32_t* __restrict__ status,
                                                       uint32_t* __restrict__ bad) {
+  MPE_FOREGROUND();
   __shared__ JacSlots vs, fs;
   const int gid = blockIdx.x * 64 + threadIdx.x, pi = gid / G, sub = gid % G, base = (int)threadIdx.x - sub;
   const bool live = pi < d.B * d.L;
@@ -762,6 +772,11 @@ struct mpe_gg20_session {
   bool lockstep = false, cinv_ahead = false;
   uint32_t* cinv_pre = nullptr;    // [vi][128] c^-1 mod N^2 of every (verifier, sender, statement) of round 1; small batches only
   uint8_t* cinv_ok_pre = nullptr;  // [vi]
+  // ... and round 2 starts the beta^N mod N^2 of round 4's PDL proofs (the prover's own nonce under its own key: no input of any round)
+  // as a BACKGROUND launch — wave priority 0 beside the decryption ladder at 2 and the EC kernels of rounds 2 and 3 at 1 (mpe_sched.h)
+  bool pdl_ahead = false;
+  uint32_t* pdl_bn = nullptr;      // [pp][128]
+  uint32_t* pdl_scratch = nullptr; // modexp_nn_scratch_words(pp)
   int fault_step = 0;              // fault injection of the reference's tests (gg_2020/test.rs:282-289,458-465,679-686): 5 / 6 / 7
   uint32_t fault_mask = 0;         // signer ordinals that double their delta_i / sigma_i / s_i
   char* tmp = nullptr;             // per-round scratch (dense outputs of the composites before they are packed)
@@ -838,6 +853,7 @@ static size_t layout(mpe_gg20_session* s, char* base) {
   s->sub0_vi = m.i(c.nVI); s->ok_vi = m.f(c.nVI); s->sub4_pv = m.i(c.nPV); s->rdash_pv = m.i(c.nPV); s->ok_pv = m.f(c.nPV);
   const bool small = s->ctx->allow_par && c.nVI <= (size_t)s->ctx->par_items;       // the batches whose composites fork
   s->cinv_pre = small ? m.w(c.nVI * 128) : nullptr; s->cinv_ok_pre = small ? m.f(c.nVI) : nullptr;
+  s->pdl_bn = small ? m.w(c.nPP * 128) : nullptr; s->pdl_scratch = small ? m.w(modexp_nn_scratch_words(c.nPP)) : nullptr;
   s->tmp_bytes = tmp_bytes_of(c);
   s->tmp = (char*)m.take(s->tmp_bytes);
   return m.off;
@@ -1132,9 +1148,31 @@ static int round2(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   uint8_t* code = t.f(c.nMB);
   Ped ped{s->pedT, t.w(c.nPI * 8), t.w(c.nPI * 16), t.w(c.nPI * 16), t.w(c.nPI * 8), t.w(c.nPI * 8)};
   GG_LAUNCH(idx2_kernel, c.nMB, d, in1, sub1_rv);
+  const bool pdl_ahead = rc == MPE_OK && s->lockstep && s->pdl_bn && ctx->use_prio && !ctx->no_pdl_ahead && ctx->use_pair && ctx->use_crt &&
+                         ctx->use_pown && ctx->allow_par && (int)c.nPP <= ctx->par_items && c.nPP > 0 && ensure_aux(ctx);
+  if (pdl_ahead) {                                              // the auxiliary stream goes on from HERE: behind round 1, beside the decryption
+    (void)hipEventRecord(ctx->ev_fork[0], st);
+    (void)hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork[0], 0);
+  }
   if (rc == MPE_OK)      // Paillier::decrypt of the incoming c_b with my key (mta/mod.rs:165), in place
     rc = paillier_decrypt(ctx, K->prv, (int)c.nMB, s->ix.kown_mb, rows(d_in, SUB1, sub1_rv), alpha_full, st);
   gg_trace(s->ctx, st, "decrypt", rc);
+  // (round 6) lock-step signing of a small batch: the two dependent 1024-bit ladders behind beta^N mod N^2 of round 4's PDL proofs
+  // (10 ms at 1 024 sessions, on that round's critical path) need nothing but the prover's nonce and key.  They start HERE on an auxiliary
+  // stream, at wave priority 0: the decryption ladder (2) and the EC kernels of rounds 2 and 3 (1) keep their speed whichever SIMD they
+  // share with them, and the chip — half empty during these 13 ms — does the work.  Round 4 waits for the event, not for the ladders.
+  s->pdl_ahead = false;
+  if (pdl_ahead && rc == MPE_OK) {
+    hipStream_t sa = ctx->aux[1];
+    const Rows ksel = sel_of(s->ix.kown_pp, K->prv->nkeys);
+    const int keep = ctx->ladder_prio;
+    ctx->ladder_prio = 0;
+    const int rca = modexp_nn(ctx, K->prv, (int)c.nPP, ksel, rows(Z.pdl_beta, 64, nullptr, 64), tab_rows(K->prv->N, 64, s->ix.kown_pp, K->prv->nkeys), 64,
+                              true, s->pdl_bn, sa, true, s->pdl_scratch);
+    ctx->ladder_prio = keep;
+    if (rca == MPE_OK) { (void)hipEventRecord(ctx->ev_ahead, sa); s->pdl_ahead = true; } else rc = rca;
+    gg_trace(s->ctx, sa, "PDL beta^N, ahead", rc);
+  }
   const size_t lanes_fit = ctx->ec_lane_groups ? (size_t)ctx->cus * 4 * 64 * 2 / ctx->device_share : 0;      // two waves per SIMD
   if (c.nMB * 4 <= lanes_fit) GG_LAUNCH(r2a_group_kernel, c.nMB * 4, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
   else GG_LAUNCH(r2a_kernel, c.nMB, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
@@ -1182,8 +1220,10 @@ static int round4(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   mpe_pdl_nonces pn{Z.pdl_alpha, Z.pdl_beta, Z.pdl_rho, Z.pdl_gamma};
   if (rc == MPE_OK)                                                                                            // phase5_proof_pdl
     rc = pdl_prove(ctx, K->prv, K->stm, (int)c.nPP, s->ix.kown_pp, s->ix.st_pp, rows(s->c_a, 128, s->ix.pi_pp), rows(s->Rbar, 16, s->ix.pi_pp),
-                   rows(s->R, 16, s->ix.pi_pp), rows(s->kq, 8, s->ix.pi_pp), rows(Z.r_a, 64, s->ix.pi_pp), &pn, &pp, st, &g);
+                   rows(s->R, 16, s->ix.pi_pp), rows(s->kq, 8, s->ix.pi_pp), rows(Z.r_a, 64, s->ix.pi_pp), &pn, &pp, st, &g,
+                   s->pdl_ahead ? s->pdl_bn : nullptr, s->pdl_ahead ? ctx->ev_ahead : nullptr);
   else g.join();
+  if (rc == MPE_OK) s->pdl_ahead = false;                    // consumed (otherwise session_release waits for it)
   gg_trace(s->ctx, st, "pdl_prove", rc);
   PACK(c.nPP, P1, S, 0, SUB4, 0, pp.z, 64); PACK(c.nPP, P1, S, 0, SUB4, 64, pp.u1, 16); PACK(c.nPP, P1, S, 0, SUB4, 80, pp.u2, 128);
   PACK(c.nPP, P1, S, 0, SUB4, 208, pp.u3, 64); PACK(c.nPP, P1, S, 0, SUB4, 272, pp.s1, 25); PACK(c.nPP, P1, S, 0, SUB4, 297, pp.s2, 64);
@@ -1257,6 +1297,7 @@ static int complete(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_
 
 static void session_release(mpe_gg20_session* s, hipStream_t st) {
   if (!s) return;
+  if (s->pdl_ahead && s->ctx->ev_ahead) { (void)hipStreamWaitEvent(st, s->ctx->ev_ahead, 0); s->pdl_ahead = false; }    // started, never consumed (a failed round)
   if (s->mem) {
     // secrets (k_i, gamma_i, w_i, sigma_i, nonce-derived intermediates) do not outlive the object (range_proofs.rs:26-36 zeroizes)
     (void)hipMemsetAsync(s->mem, 0, s->mem_bytes, st);

@@ -31,6 +31,10 @@ struct mpe_ctx {
                                   // heuristics below compare a launch with 1/device_share of the chip, not with all of it
   int xwide_div = 16;             // the 4x-lanes (5 limbs per lane) layout: xwide_div * batch <= the resident groups; 0 = off (MPE_XWIDE_DIV)
   bool merge_xn = true;           // round 0: every x^N of the key holders in ONE launch (MPE_NO_MERGE_XN switches it off)
+  int use_prio = 1;               // wave priorities in the small-batch schedule (option no_prio; the pipelined engine's lanes run without)
+  int ladder_prio = 1;            // s_setprio of the NEXT ladder launches (mpe_sched.h wave_priority): 1 = the default of ladders, 2 = the pair
+                                  // engine's launches (the stretches a small batch waits for), 0 = work started ahead of its round
+  int no_pdl_ahead = 0;           // lock-step signing of small batches: round 4 computes the PDL proofs' beta^N itself (option)
   int wide_modexp = 0;            // 2048-bit modexp_kernel on 9 limbs per lane for small launches (option; measured: no gain, see mpe_lib.hip)
   int no_r1_dlog_first = 0;       // with the inversion ahead: MessageB's DLog proofs behind the ladders again, not in front of the N~ side (option)
   int no_r1_inversion_ahead = 0;  // lock-step signing of small batches: round 1 inverts the ciphertexts itself, as the per-round calls do (option)
@@ -52,6 +56,7 @@ struct mpe_ctx {
   // run on auxiliary streams, forked from and joined to the caller's stream with events (mpe::Fork).
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_ahead = nullptr;  // "the PDL proofs' beta^N, started in round 2, is done" (mpe_gg20.h round2 / round4)
   hipEvent_t ev_mid = nullptr;    // "the merged ladder launch of round 1 is queued" (mpe_gg20.h round1)
   // background streams of the lock-step composition (small batches): the pure verifications of rounds 1 and 5 run there,
   // each with its own workspace, and are joined when the signature is completed
@@ -188,7 +193,7 @@ inline int ladder_grid(const mpe_ctx* ctx, int units, int cap) {
 }
 // the scheduler arguments of that launch; `state` (SCHED_WORDS ints of device scratch the launch owns) is zeroed on `st` when used
 inline SchedArgs ladder_sched(const mpe_ctx* ctx, int units, int cap, int32_t* state, hipStream_t st) {
-  SchedArgs a{nullptr, SCHED_STATIC, units};
+  SchedArgs a{nullptr, SCHED_STATIC, units, ctx->use_prio ? ctx->ladder_prio : 0};
   if (ctx->no_elect || !state) return a;
   if (2 * units <= cap) { if (!ctx->no_primaries) { a.state = state; a.mode = SCHED_PRIMARIES; } }
   else if (units > cap) { a.state = state; a.mode = SCHED_ALL; }

@@ -374,6 +374,7 @@ __global__ void __launch_bounds__(64) modexp_kernel(int batch, ModsetView ms, Ro
 template <class C>
 __global__ void __launch_bounds__(64) modmul_kernel(int batch, ModsetView ms, Rows mod_sel, Rows A, Rows B,
                                                     uint32_t* __restrict__ out) {
+  MPE_FOREGROUND();
   __shared__ uint32_t lds[C::LDS_WORDS];
   const Lane ln = make_lane<C>();
   uint32_t* gl = lds + ln.g * C::STRIDE;

@@ -58,6 +58,7 @@ bool ensure_aux(mpe_ctx* ctx) {
   for (int i = 0; i < 2; ++i) if (hipEventCreateWithFlags(&ctx->ev_fork[i], hipEventDisableTiming) != hipSuccess) return false;
   for (int i = 0; i < 3; ++i) if (hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) != hipSuccess) return false;
   if (hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming) != hipSuccess) return false;
+  if (hipEventCreateWithFlags(&ctx->ev_ahead, hipEventDisableTiming) != hipSuccess) return false;
   ctx->aux_ready = true;
   return true;
 }
@@ -352,6 +353,8 @@ static const CtxOption kCtxOptions[] = {
     MPE_OPT_INT("merge_r1_quarters", 0, 64, merge_r1_quarters),
     MPE_OPT_INT("no_r1_inversion_ahead", 0, 1, no_r1_inversion_ahead),
     MPE_OPT_INT("wide_modexp", 0, 1, wide_modexp),
+    MPE_OPT_BOOL_OFF("no_prio", use_prio),                   // no s_setprio anywhere
+    MPE_OPT_INT("no_pdl_ahead", 0, 1, no_pdl_ahead),
     MPE_OPT_INT("no_r1_dlog_first", 0, 1, no_r1_dlog_first),
     MPE_OPT_INT("xwide_div", 0, 1 << 20, xwide_div),
     MPE_OPT_INT("waves_per_cu", 1, 8, modexp_waves_per_cu),
@@ -497,6 +500,7 @@ int mpe_ctx_destroy(mpe_ctx* ctx) {
     for (int i = 0; i < 3; ++i) { (void)hipStreamDestroy(ctx->aux[i]); (void)hipEventDestroy(ctx->ev_join[i]); }
     for (int i = 0; i < 2; ++i) (void)hipEventDestroy(ctx->ev_fork[i]);
     if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
+    if (ctx->ev_ahead) (void)hipEventDestroy(ctx->ev_ahead);
   }
   for (auto& ev : ctx->prof) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   if (ctx->prof_ctr) (void)hipFree(ctx->prof_ctr);

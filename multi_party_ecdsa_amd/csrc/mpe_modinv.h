@@ -125,6 +125,7 @@ template <typename LT>
 __global__ void __launch_bounds__(64) modinv_wave_kernel(const int32_t* __restrict__ n_items, const uint32_t* __restrict__ mod_words,
                                                          const int32_t* __restrict__ mod_of, const uint32_t* __restrict__ a,
                                                          uint32_t* __restrict__ out, uint8_t* __restrict__ ok) {
+  MPE_FOREGROUND();
   using WI = WaveInt<LT>;
   constexpr int WPL = sizeof(LT) / 4;            // interface words per lane
   constexpr int K32 = 64 * WPL;
@@ -189,6 +190,7 @@ __device__ __forceinline__ int mod_index(const Rows& sel, int i) { return sel_in
 // wave are grouped by modulus with ballots and ONE lane per (wave, modulus) does the atomic: 64x fewer colliding
 // atomics than one per item.
 __global__ void inv_count_kernel(int B, Rows mod_sel, InvPlan p) {
+  MPE_FOREGROUND();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < B;
   const int m = live ? mod_index(mod_sel, i) : -1;
@@ -209,6 +211,7 @@ __global__ void inv_count_kernel(int B, Rows mod_sel, InvPlan p) {
 // chunks, the 64 partial sums are scanned, and the lane writes its run (a launch may carry tens of thousands of moduli — every
 // session its own wallet — where one lane walking all of them took ~0.1 s per inversion call)
 __global__ void __launch_bounds__(64) inv_plan_kernel(int nmod, int chunk, InvPlan p) {
+  MPE_FOREGROUND();
   __shared__ int32_t s_items[64], s_chunks[64];
   const int lane = threadIdx.x, per = (nmod + 63) / 64, lo = lane * per, hi = lo + per < nmod ? lo + per : nmod;
   int items = 0, chunks = 0;
@@ -231,6 +234,7 @@ __global__ void __launch_bounds__(64) inv_plan_kernel(int nmod, int chunk, InvPl
   if (lane == 63) p.nch[0] = nc;
 }
 __global__ void inv_perm_kernel(int B, Rows mod_sel, InvPlan p) {
+  MPE_FOREGROUND();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   p.perm[p.cnt[mod_index(mod_sel, i)] + p.rank[i]] = i;
@@ -243,6 +247,7 @@ __global__ void inv_perm_kernel(int B, Rows mod_sel, InvPlan p) {
 template <class C>
 __global__ void __launch_bounds__(64) inv_up_kernel(ModsetView ms, Rows A, InvPlan p, int maxch, uint32_t* __restrict__ xm,
                                                     uint32_t* __restrict__ pre, uint32_t* __restrict__ T) {
+  MPE_FOREGROUND();
   __shared__ uint32_t lds[C::LDS_WORDS];
   const Lane ln = make_lane<C>();
   uint32_t* gl = lds + ln.g * C::STRIDE;
@@ -303,6 +308,7 @@ __global__ void __launch_bounds__(64) inv_down_kernel(ModsetView ms, InvPlan p, 
                                                       const uint32_t* __restrict__ pre, const uint32_t* __restrict__ Tinv,
                                                       const uint8_t* __restrict__ Tok, uint32_t* __restrict__ out,
                                                       uint8_t* __restrict__ ok, uint8_t* __restrict__ need_fallback) {
+  MPE_FOREGROUND();
   __shared__ uint32_t lds[C::LDS_WORDS];
   const Lane ln = make_lane<C>();
   uint32_t* gl = lds + ln.g * C::STRIDE;

@@ -128,6 +128,7 @@ __global__ void sk_setup_c_kernel(int nk2, const uint32_t* __restrict__ sq64, co
 
 // CRT plumbing for x^e mod N^2: half item j = 2i + side uses modulus 2 key(i) + side of ms_pp
 __global__ void crt_half_kernel(int B2, Rows ksel, int32_t* __restrict__ half_of) {
+  MPE_FOREGROUND();
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= B2) return;
   half_of[j] = 2 * sel_index(ksel, j >> 1) + (j & 1);
@@ -135,6 +136,7 @@ __global__ void crt_half_kernel(int B2, Rows ksel, int32_t* __restrict__ half_of
 // out = y[2i] + y[2i+1] mod N^2
 __global__ void crt_add_kernel(int B, Rows ksel, const uint32_t* __restrict__ NN, const uint32_t* __restrict__ y,
                                uint32_t* __restrict__ out) {
+  MPE_FOREGROUND();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   uint32_t a[129], b[128];
@@ -162,6 +164,7 @@ __global__ void enc_gm_kernel(int B, int nkeys, const uint32_t* __restrict__ m, 
 // decrypt plumbing: item j = 2i + half
 __global__ void dec_index_kernel(int B2, int nkeys, const int32_t* __restrict__ key_idx, int32_t* __restrict__ item_of,
                                  int32_t* __restrict__ half_of, int32_t* __restrict__ keyj) {
+  MPE_FOREGROUND();
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= B2) return;
   const int i = j >> 1, k = key_of(key_idx, nkeys, i);
@@ -172,6 +175,7 @@ __global__ void dec_index_kernel(int B2, int nkeys, const int32_t* __restrict__ 
 // t = (u - 1) / prime  (exact) = ((u - 1) mod 2^1024) * prime^-1 mod 2^1024     [L function]
 __global__ void dec_lfunc_kernel(int B2, const uint32_t* __restrict__ u, const int32_t* __restrict__ half_of,
                                  const uint32_t* __restrict__ inv2, uint32_t* __restrict__ t) {
+  MPE_FOREGROUND();
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= B2) return;
   uint32_t a[32], iv[32], r[32], one[1] = {1};
@@ -184,6 +188,7 @@ __global__ void dec_lfunc_kernel(int B2, const uint32_t* __restrict__ u, const i
 // m = y[2i] + y[2i+1] mod N
 __global__ void dec_combine_kernel(int B, int nkeys, const uint32_t* __restrict__ y, const int32_t* __restrict__ key_idx,
                                    const uint32_t* __restrict__ N, uint32_t* __restrict__ m) {
+  MPE_FOREGROUND();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   uint32_t a[65], b[64], n[64];
@@ -296,17 +301,20 @@ constexpr size_t CRT_WS_WORDS = 2 + 2 * 64 + 2 * 128 + 192;
 // pow_n: the exponent is N itself.  Then x^N = (x^q)^p and x^q = a (mod p) with a = x^(q mod (p-1)) mod p gives
 // x^N = a^p (mod p^2): a 1024-bit exponentiation modulo p (one pass per squaring) and one modulo p^2 (two passes)
 // instead of a 2048-bit one modulo p^2 — a quarter less work, the same residue.
+// scratch: 2 B x (1 + 64 + 128) words of the caller's own (a launch that outlives the workspace reservation it was queued under: the PDL
+// proofs' beta^N started rounds ahead, mpe_gg20.h round2); nullptr: the context workspace
+static inline size_t modexp_nn_scratch_words(size_t B) { return 2 * B * (1 + 64 + 128) + 256; }
 static int modexp_nn(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Rows base, Rows exps, int ew, bool holder,
-                     uint32_t* out, hipStream_t st, bool pow_n = false) {
+                     uint32_t* out, hipStream_t st, bool pow_n = false, uint32_t* scratch = nullptr) {
   if (!(holder && pk->has_private && ctx->use_crt)) {
     // the exponent rows ARE the public-key table: x^N for a public N (r^N, s^N) — the one case that may run on sliding windows
     if (ctx->use_pair) return launch_pair_modexp(ctx, pk->ps_nn, B, ksel, base, exps, ew, no_rows(), no_rows(), 0, out, st, 0, exps.p == pk->N);
     return launch_modexp(ctx, pk->ms_nn, B, ksel, base, no_rows(), exps, ew, out, st);
   }
   const int B2 = 2 * B;
-  int32_t* half_of = ws_array<int32_t>(ctx, B2);
-  uint32_t* u = ws_array<uint32_t>(ctx, (size_t)B2 * 64);
-  uint32_t* y = ws_array<uint32_t>(ctx, (size_t)B2 * 128);
+  int32_t* half_of = scratch ? (int32_t*)scratch : ws_array<int32_t>(ctx, B2);
+  uint32_t* u = scratch ? scratch + (((size_t)B2 + 63) & ~(size_t)63) : ws_array<uint32_t>(ctx, (size_t)B2 * 64);
+  uint32_t* y = scratch ? u + (size_t)B2 * 64 : ws_array<uint32_t>(ctx, (size_t)B2 * 128);
   if (!half_of || !u || !y) { mpe_set_error_msg("workspace under-reserved (modexp_nn)"); return MPE_E_NOMEM; }
   MPE_LAUNCH_1D(crt_half_kernel, B2, st, B2, ksel, half_of);
   const int bw = base.words ? base.words : 128;

@@ -685,6 +685,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // out[i] (2H words) = z0 + z1 * N   (z0 | z1 as left by pair_modexp_kernel; one item per lane)
 template <int H>
 __global__ void pair_finish_kernel(int B, Rows mod_sel, const uint32_t* __restrict__ mod_words, uint32_t* __restrict__ out) {
+  MPE_FOREGROUND();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   uint32_t z0[H], z1[H], nn[H], r[2 * H];
@@ -762,7 +763,8 @@ int pair_modexp_impl(mpe_ctx* ctx, const mpe_pairset* ps, int batch, Rows mod_se
   const size_t extra = (by_key ? ((size_t)batch + 2 * (size_t)ps->count + 64) * sizeof(int32_t) : 0) + SCHED_WORDS * sizeof(int32_t);
   uint32_t* tabs = tables_for(ctx, need + extra, st);
   if (!tabs) return MPE_E_NOMEM;
-  const SchedArgs sched = ladder_sched(ctx, units, ctx->cus * ctx->modexp_waves_per_cu, (int32_t*)((char*)tabs + need + extra) - SCHED_WORDS, st);
+  SchedArgs sched = ladder_sched(ctx, units, ctx->cus * ctx->modexp_waves_per_cu, (int32_t*)((char*)tabs + need + extra) - SCHED_WORDS, st);
+  if (sched.prio == 1) sched.prio = 2;          // the pair engine's launches are the stretches a small batch waits for (mpe_sched.h wave_priority)
   const int32_t* perm = nullptr;
   if (by_key) {
     int32_t* pm = (int32_t*)((char*)tabs + need);

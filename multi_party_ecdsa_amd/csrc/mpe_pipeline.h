@@ -251,6 +251,7 @@ int mpe_gg20_pipeline_create(mpe_ctx* ctx, const mpe_gg20_keys* keys, int batch,
     mpe::ctx_copy_options(c, ctx);            // every option of the parent (mpe_ctx_set_option), then:
     c->enc = ctx->enc;
     c->allow_par = false;
+    c->use_prio = 0;                          // the lanes' ladders compete with each other, not with side work of their own pass
     if (hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking) != hipSuccess) { mpe_set_error_msg("gg20 pipeline: hipStreamCreate"); rc = MPE_E_HIP; break; }
     rc = mpe_gg20_nonces_alloc(c, keys, (int)GB, keys->S, &L.stage);
     if (rc != MPE_OK) break;

@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC dlog_verify_kernel(int B, ec::E
 // ---------------------------------------------------------------------------------------------
 // r[nr] = a[na] * b[nb] + c[nc]      (plain integers; nr >= na + nb)
 __global__ void muladd_kernel(int B, Rows a, int na, Rows b, int nb, Rows c, int nc, uint32_t* __restrict__ r, int nr) {
+  MPE_FOREGROUND();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   uint32_t x[90], y[90], t[180];
@@ -142,6 +143,7 @@ enum { HF_BIGINT = 0, HF_BIGINT_PLUS1 = 1, HF_POINT_COMPRESSED = 2 };
 struct HashField { Rows r; int words; int kind; };
 struct HashDesc { HashField f[14]; int n; };
 __global__ void __launch_bounds__(64) MPE_EC_OCC hash_kernel(int B, ec::Enc enc, HashDesc d, uint32_t* __restrict__ out) {
+  MPE_FOREGROUND();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   ec::Sha256 s;
@@ -202,6 +204,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC pdl_u1_check_kernel(int B, Rows
 }
 // out = (k mod q) * P with per-item rows (P.p == nullptr -> generator)
 __global__ void __launch_bounds__(64) MPE_EC_OCC ec_mul_rows_kernel(int B, Rows k, int kw, Rows P, uint32_t* __restrict__ out) {
+  MPE_FOREGROUND();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const ec::U256 s = ec::sc_reduce(row_of(k, i), kw);
@@ -427,9 +430,10 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
 // ---------------------------------------------------------------------------------------------
 static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
                      const int32_t* st_idx, Rows cipher, Rows Qp, Rows Gp, Rows x, Rows r, const mpe_pdl_nonces* nn,
-                     const mpe_pdl_proof* out, hipStream_t st, Fork* outer = nullptr) {
+                     const mpe_pdl_proof* out, hipStream_t st, Fork* outer = nullptr, const uint32_t* bn_pre = nullptr,
+                     hipEvent_t bn_pre_ready = nullptr) {
   // outer: a fork of the CALLER whose branch 1 produces the statement points Q, G concurrently (Round 4: R, R_dash); only u1
-  // and the transcript hash need them
+  // and the transcript hash need them.  bn_pre: beta^N mod N^2 when the caller has queued it elsewhere (done at bn_pre_ready)
   MPE_TRY(ws_reserve(ctx, (size_t)B * (1400 + CRT_WS_WORDS) * 4 + 65536, st));
   Fork f(ctx, st, 3, B <= ctx->par_items);
   Seq q{ctx, f.s(0), B}, q1{ctx, f.s(1), B}, q2{ctx, f.s(2), B};
@@ -446,7 +450,8 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
   // u2 = (N+1)^alpha beta^N mod N^2; (N+1)^alpha = 1 + alpha N (mod N^2), alpha N + 1 < N^2      :87-93
   uint32_t* ga = q.words(128);
   q.muladd(rows(nn->alpha, 24), 24, Nrow, 64, no_rows(), 0, ga, 128);
-  uint32_t* bn = q.modexp_nn(pk, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64, true, true);   // the prover owns the key
+  if (bn_pre && bn_pre_ready) (void)hipStreamWaitEvent(f.s(0), bn_pre_ready, 0);
+  const uint32_t* bn = bn_pre ? bn_pre : q.modexp_nn(pk, ksel, rows(nn->beta, 64, nullptr, 64), Nrow, 64, true, true);   // the prover owns the key
   q.modmul_to(pk->ms_nn, ksel, rows(ga, 128), rows(bn, 128), out->u2);
   // u3 = h1^alpha h2^gamma mod N~                                               :94-100
   uint32_t* w1 = q2.fb_modexp(stm, ssel, 0, h1,rows(nn->alpha, 24), 24);

@@ -44,7 +44,21 @@ struct SchedArgs {
   int32_t* state;       // SCHED_WORDS zeroed words, or nullptr: static units (trip * nslots + blockIdx.x * GROUPS)
   int mode;             // SCHED_ALL: every wave pulls units from the queue; SCHED_PRIMARIES: the first arrival of every SIMD does
   int units;            // units of the launch (queue length)
+  int prio;             // s_setprio of the launch's waves (0 = the hardware's default): see wave_priority below
 };
+
+// Wave priority (s_setprio, 0..3).  Among waves of EQUAL priority a SIMD serves the older one first (the trace above); a wave of HIGHER
+// priority wins whatever its age — measured (tools/ubench/setprio.hip, profiles/r06/setprio.json: two multiply-add streams on one SIMD):
+//     equal priorities        older 0.95 - 1.0 of its lone speed, younger what is left (0.37 while both run)
+//     younger at 1, older 0   younger 1.0, older what is left — any gap of priority does it (1 against 0 like 3 against 0)
+// Used by the small-batch schedule (mpe_gg20.h): a launch that is NOT on the critical path (the PDL proofs' beta^N started two rounds
+// ahead) runs at 0 beside short kernels that raise themselves to 1 and ladders of the path at 2.  The immediate of s_setprio is a literal:
+#define MPE_FOREGROUND() __builtin_amdgcn_s_setprio(1)     /* first statement of the short kernels of rounds 2 and 3 */
+__device__ __forceinline__ void wave_priority(int prio) {
+  if (prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (prio == 3) __builtin_amdgcn_s_setprio(3);
+}
 
 __device__ __forceinline__ int sched_simd_id() {
   const unsigned h = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID: simd 5:4, cu 11:8, sh 12, se 15:13
@@ -57,6 +71,7 @@ struct WaveSched {
   int role = 0;         // 0: this SIMD's primary (or a launch without election), > 0: a later arrival
   bool first_pull = false;
   __device__ __forceinline__ void init(const SchedArgs& a) {
+    wave_priority(a.prio);
     if (!a.state || a.mode != SCHED_PRIMARIES) return;
     int r = 0;
     if (threadIdx.x == 0) {

@@ -51,6 +51,12 @@ int main() {
       mpe_ctx np; np.no_primaries = 1;
       const mpe::SchedArgs b = mpe::ladder_sched(&np, need, cap, dummy, nullptr);
       if (need <= cap) { CHECK(mpe::ladder_grid(&np, need, cap) == need && b.state == nullptr); } else { CHECK(b.mode == mpe::SCHED_ALL); }
+      // wave priority of the launch (mpe_sched.h wave_priority): ladders 1, work started ahead of its round 0, nothing without use_prio
+      CHECK(a.prio == 1);
+      mpe_ctx bg; bg.ladder_prio = 0;
+      CHECK(mpe::ladder_sched(&bg, need, cap, dummy, nullptr).prio == 0);
+      mpe_ctx off; off.use_prio = 0; off.ladder_prio = 2;
+      CHECK(mpe::ladder_sched(&off, need, cap, dummy, nullptr).prio == 0);
       mpe_ctx ne; ne.no_elect = 1;
       CHECK(mpe::ladder_grid(&ne, need, cap) == mpe::persistent_grid(&ne, need, cap) && mpe::ladder_sched(&ne, need, cap, dummy, nullptr).state == nullptr);
     }
