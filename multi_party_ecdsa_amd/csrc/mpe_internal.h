@@ -34,6 +34,7 @@ struct mpe_ctx {
   int use_prio = 1;               // wave priorities in the small-batch schedule (option no_prio; the pipelined engine's lanes run without)
   int ladder_prio = 1;            // s_setprio of the NEXT ladder launches (mpe_sched.h wave_priority): 1 = the default of ladders, 2 = the pair
                                   // engine's launches (the stretches a small batch waits for), 0 = work started ahead of its round
+  int use_crt_n = 1;              // the provers' r^e mod N through p | q (mpe_paillier.h modexp_n_holder; option no_crt_n)
   int no_pdl_ahead = 0;           // lock-step signing of small batches: round 4 computes the PDL proofs' beta^N itself (option)
   int wide_modexp = 0;            // 2048-bit modexp_kernel on 9 limbs per lane for small launches (option; measured: no gain, see mpe_lib.hip)
   int no_r1_dlog_first = 0;       // with the inversion ahead: MessageB's DLog proofs behind the ladders again, not in front of the N~ side (option)

@@ -355,6 +355,7 @@ static const CtxOption kCtxOptions[] = {
     MPE_OPT_INT("wide_modexp", 0, 1, wide_modexp),
     MPE_OPT_BOOL_OFF("no_prio", use_prio),                   // no s_setprio anywhere
     MPE_OPT_INT("no_pdl_ahead", 0, 1, no_pdl_ahead),
+    MPE_OPT_BOOL_OFF("no_crt_n", use_crt_n),                 // the provers' r^e mod N on the 2048-bit ladder
     MPE_OPT_INT("no_r1_dlog_first", 0, 1, no_r1_dlog_first),
     MPE_OPT_INT("xwide_div", 0, 1 << 20, xwide_div),
     MPE_OPT_INT("waves_per_cu", 1, 8, modexp_waves_per_cu),

@@ -346,6 +346,28 @@ static int modexp_nn2(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Ro
   return launch_modexp2(ctx, pk->ms_nn, B, ksel, base, exps, ew, base2, exps2, ew2, out, st);
 }
 
+// x^e mod N for the HOLDER of N = p q (the provers' s = r^e beta mod N: range_proofs.rs:84, zk_pdl_with_slack/mod.rs:113): x^e mod p and
+// x^e mod q in half mode on the 1024-bit pair engine (one pass per multiplication on half the limbs: a quarter of the multiply-adds of the
+// 2048-bit ladder, and 36 instead of 72 steps of latency per multiplication for a small batch), recombined with the CRT idempotents as in
+// paillier_decrypt.  Same residue.  Scratch: MODEXP_N_HOLDER_WS_WORDS words per item from the context workspace.
+constexpr size_t MODEXP_N_HOLDER_WS_WORDS = 2 * (3 + 64 + 64) + 64;
+static int modexp_n_holder(mpe_ctx* ctx, const mpe_paillier* pk, int B, const int32_t* key_idx, Rows base, Rows exps, int ew, uint32_t* out,
+                           hipStream_t st) {
+  const int B2 = 2 * B;
+  int32_t* item_of = ws_array<int32_t>(ctx, B2);
+  int32_t* half_of = ws_array<int32_t>(ctx, B2);
+  int32_t* keyj = ws_array<int32_t>(ctx, B2);
+  uint32_t* u = ws_array<uint32_t>(ctx, (size_t)B2 * 64);
+  uint32_t* y = ws_array<uint32_t>(ctx, (size_t)B2 * 64);
+  if (!item_of || !half_of || !keyj || !u || !y) { mpe_set_error_msg("workspace under-reserved (modexp_n_holder)"); return MPE_E_NOMEM; }
+  MPE_LAUNCH_1D(dec_index_kernel, B2, st, B2, pk->nkeys, key_idx, item_of, half_of, keyj);
+  MPE_TRY(launch_pair_modexp(ctx, pk->ps_pp, B2, Rows{nullptr, half_of, 0, 0}, Rows{base.p, base.idx, base.stride, base.words ? base.words : 64, 1},
+                             Rows{exps.p, exps.idx, exps.stride, exps.words, 1}, ew, no_rows(), no_rows(), 0, u, st, 1));
+  MPE_TRY(launch_modmul(ctx, pk->ms_n, B2, Rows{nullptr, keyj, 0, 0}, rows(u, 64, nullptr, 32), rows(pk->ab64, 64, half_of), y, st));
+  MPE_LAUNCH_1D(dec_combine_kernel, B, st, B, pk->nkeys, y, key_idx, pk->N, out);
+  return MPE_OK;
+}
+
 // workspace needs of the composites (a caller that runs several of them concurrently reserves the sum once)
 static inline size_t ws_need_encrypt(int B) { return (size_t)B * (256 + CRT_WS_WORDS) * 4 + 8192; }
 static inline size_t ws_need_mul_add_enc(int B) { return (size_t)B * 128 * 4 * 3 + 8192; }

@@ -253,6 +253,13 @@ struct Seq {
     if (rc == MPE_OK) rc = mpe::modexp_nn2(ctx, pk, B, sel, base, exps, ew, base2, exps2, ew2, o, st);
     return o;
   }
+  // x^e mod N of the key's holder: through p | q when the context may (modexp_n_holder), else the 2048-bit ladder
+  uint32_t* modexp_n(const mpe_paillier* pk, const int32_t* key_idx, Rows sel, Rows base, Rows exps, int ew) {
+    if (!(pk->has_private && ctx->use_crt && ctx->use_pair && ctx->use_crt_n)) return modexp(pk->ms_n, sel, base, exps, ew);
+    uint32_t* o = words(64);
+    if (rc == MPE_OK) rc = mpe::modexp_n_holder(ctx, pk, B, key_idx, base, exps, ew, o, st);
+    return o;
+  }
   uint32_t* modmul(const mpe_modset* ms, Rows sel, Rows a, Rows b) {
     uint32_t* o = words(ms->bits / 32);
     if (rc == MPE_OK) rc = launch_modmul(ctx, ms, B, sel, a, b, o, st);
@@ -306,7 +313,7 @@ static Rows with_words(Rows r, int words) { r.words = words; return r; }
 // Small batches: z, u and w are independent and run on three streams (mpe::Fork); `outer`: a fork of the CALLER that
 // produces `cipher` concurrently (Round 0 encrypts k_i on another stream) — joined right before the transcript hash.
 // ---------------------------------------------------------------------------------------------
-static inline size_t ws_need_alice_generate(int B) { return (size_t)B * (1400 + CRT_WS_WORDS) * 4 + 65536; }
+static inline size_t ws_need_alice_generate(int B) { return (size_t)B * (1400 + CRT_WS_WORDS + MODEXP_N_HOLDER_WS_WORDS) * 4 + 65536; }
 static inline size_t ws_need_alice_verify(int B) { return (size_t)B * 2200 * 4 + 65536; }
 static int merge_rc(const Seq& a, const Seq& b, const Seq& c) { return a.rc != MPE_OK ? a.rc : (b.rc != MPE_OK ? b.rc : c.rc); }
 
@@ -350,7 +357,7 @@ static int alice_generate(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statem
   d.f[3] = hf(rows(out->z, 64), 64); d.f[4] = hf(rows(u, 128), 128); d.f[5] = hf(rows(w, 64), 64);
   q.hash(d, out->e);
   // s = r^e beta mod N ; s1 = e a + alpha ; s2 = e rho + gamma                  :84-88
-  uint32_t* re = q.modexp(pk->ms_n, ksel, r, rows(out->e, 8), 8);
+  uint32_t* re = q.modexp_n(pk, key_idx, ksel, r, rows(out->e, 8), 8);
   q.modmul_to(pk->ms_n, ksel, rows(re, 64), rows(nn->beta, 64), out->s);
   q.muladd(rows(out->e, 8), 8, a, 8, rows(nn->alpha, 24), 24, out->s1, 25);
   q.muladd(rows(out->e, 8), 8, rows(nn->rho, 72), 72, rows(nn->gamma, 88), 88, out->s2, 89);
@@ -434,7 +441,7 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
                      hipEvent_t bn_pre_ready = nullptr) {
   // outer: a fork of the CALLER whose branch 1 produces the statement points Q, G concurrently (Round 4: R, R_dash); only u1
   // and the transcript hash need them.  bn_pre: beta^N mod N^2 when the caller has queued it elsewhere (done at bn_pre_ready)
-  MPE_TRY(ws_reserve(ctx, (size_t)B * (1400 + CRT_WS_WORDS) * 4 + 65536, st));
+  MPE_TRY(ws_reserve(ctx, (size_t)B * (1400 + CRT_WS_WORDS + MODEXP_N_HOLDER_WS_WORDS) * 4 + 65536, st));
   Fork f(ctx, st, 3, B <= ctx->par_items);
   Seq q{ctx, f.s(0), B}, q1{ctx, f.s(1), B}, q2{ctx, f.s(2), B};
   const Rows ksel = sel_of(key_idx, pk->nkeys), ssel = sel_of(st_idx, stm->count);
@@ -471,7 +478,7 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
   q.hash(d, e);
   // s1 = e x + alpha ; s2 = r^e beta mod N ; s3 = e rho + gamma                :112-114
   q.muladd(rows(e, 8), 8, x, 8, rows(nn->alpha, 24), 24, out->s1, 25);
-  uint32_t* re = q.modexp(pk->ms_n, ksel, r, rows(e, 8), 8);
+  uint32_t* re = q.modexp_n(pk, key_idx, ksel, r, rows(e, 8), 8);
   q.modmul_to(pk->ms_n, ksel, rows(re, 64), rows(nn->beta, 64), out->s2);
   q.muladd(rows(e, 8), 8, rows(nn->rho, 72), 72, rows(nn->gamma, 88), 88, out->s3, 89);
   return q.finish("pdl_prove");
