@@ -79,8 +79,6 @@ int mpe_ctx_set_device_share(mpe_ctx* ctx, int contexts);
  *                  round 1 needs / MessageB's DLog proofs go behind the ladders again)  no_pdl_ahead (round 4 computes the PDL
  *                  proofs' beta^N itself instead of finding it done)  no_prio (no s_setprio in the ladder kernels)
  *                  no_crt_n (the provers' r^e mod N on the 2048-bit ladder instead of through p | q)
- *                  wide_modexp (9 limbs per lane in small
- *                  2048-bit modexp launches; off: no measurable gain)
  *   integers       fb_window_bits 4..16 | window_bits 0 (auto), 4..6 | wide_div 1..64 | xwide_div 0 (off).. | waves_per_cu 1..8
  *                  fb_budget_mb | fb_split 0 (auto)..64 | sampler_max_attempts 1.. (default 128)
  *   names          grid = equal | full | hybrid

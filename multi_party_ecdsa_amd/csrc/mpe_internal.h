@@ -36,7 +36,6 @@ struct mpe_ctx {
                                   // engine's launches (the stretches a small batch waits for), 0 = work started ahead of its round
   int use_crt_n = 1;              // the provers' r^e mod N through p | q (mpe_paillier.h modexp_n_holder; option no_crt_n)
   int no_pdl_ahead = 0;           // lock-step signing of small batches: round 4 computes the PDL proofs' beta^N itself (option)
-  int wide_modexp = 0;            // 2048-bit modexp_kernel on 9 limbs per lane for small launches (option; measured: no gain, see mpe_lib.hip)
   int no_r1_dlog_first = 0;       // with the inversion ahead: MessageB's DLog proofs behind the ladders again, not in front of the N~ side (option)
   int no_r1_inversion_ahead = 0;  // lock-step signing of small batches: round 1 inverts the ciphertexts itself, as the per-round calls do (option)
   int merge_r1_quarters = 1;      // small batches merge round 1's two ladder launches when together they exceed this many QUARTERS of the resident groups (option)

@@ -184,23 +184,11 @@ static int modexp_impl(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_s
   return MPE_OK;
 }
 
-// A launch lasts as long as ONE exponentiation however few there are (mpe_pair2048.hip has the same rule for the pair engine): a 2048-bit
-// batch below 1 / wide_div of the resident groups spreads every integer over twice the lanes — 9 limbs per lane, the same limb arrays and
-// per-modulus constants, 29 instead of 44 instructions per CIOS step for the lone wave (tools/model/lone_ladder_model.py).  The proofs'
-// r^e mod N between two rounds' ladders are such launches (2.3 -> 1.5 ms each on the critical path of a 1 024-session batch).
-using Wide2048 = Cfg<2048, MPE_W, MPE_L / 2, 8>;
-static_assert(Wide2048::K == Cfg2048::K, "the two layouts share the limb arrays");
-static bool modexp_takes_wide_lanes(const mpe_ctx* ctx, int batch) {
-  const long resident = (long)ctx->cus * ctx->modexp_waves_per_cu * Cfg2048::GROUPS / ctx->device_share;
-  return ctx->wide_modexp && ctx->adaptive_lanes && (long)ctx->wide_div * batch <= resident;
-}
 int launch_modexp2(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, Rows base, Rows exps, int exp_words,
                    Rows base2, Rows exps2, int exp2_words, uint32_t* out, hipStream_t st) {
   if (batch == 0) return MPE_OK;
   if (ms->bits == 4096)
     return modexp_impl<Cfg4096>(ctx, ms, batch, mod_sel, base, no_rows(), exps, exp_words, base2, exps2, exp2_words, out, st);
-  if (ms->bits == 2048 && modexp_takes_wide_lanes(ctx, batch))
-    return modexp_impl<Wide2048>(ctx, ms, batch, mod_sel, base, no_rows(), exps, exp_words, base2, exps2, exp2_words, out, st);
   if (ms->bits == 2048)
     return modexp_impl<Cfg2048>(ctx, ms, batch, mod_sel, base, no_rows(), exps, exp_words, base2, exps2, exp2_words, out, st);
   return MPE_E_ARG;
@@ -210,8 +198,6 @@ int launch_modexp(mpe_ctx* ctx, const mpe_modset* ms, int batch, Rows mod_sel, R
   if (batch == 0) return MPE_OK;
   if (ms->bits == 4096)
     return modexp_impl<Cfg4096>(ctx, ms, batch, mod_sel, base_lo, base_hi, exps, exp_words, no_rows(), no_rows(), 0, out, st);
-  if (ms->bits == 2048 && modexp_takes_wide_lanes(ctx, batch))
-    return modexp_impl<Wide2048>(ctx, ms, batch, mod_sel, base_lo, base_hi, exps, exp_words, no_rows(), no_rows(), 0, out, st);
   if (ms->bits == 2048)
     return modexp_impl<Cfg2048>(ctx, ms, batch, mod_sel, base_lo, base_hi, exps, exp_words, no_rows(), no_rows(), 0, out, st);
   return MPE_E_ARG;
@@ -352,7 +338,6 @@ static const CtxOption kCtxOptions[] = {
     MPE_OPT_INT("wide_div", 1, 64, wide_div),
     MPE_OPT_INT("merge_r1_quarters", 0, 64, merge_r1_quarters),
     MPE_OPT_INT("no_r1_inversion_ahead", 0, 1, no_r1_inversion_ahead),
-    MPE_OPT_INT("wide_modexp", 0, 1, wide_modexp),
     MPE_OPT_BOOL_OFF("no_prio", use_prio),                   // no s_setprio anywhere
     MPE_OPT_INT("no_pdl_ahead", 0, 1, no_pdl_ahead),
     MPE_OPT_BOOL_OFF("no_crt_n", use_crt_n),                 // the provers' r^e mod N on the 2048-bit ladder

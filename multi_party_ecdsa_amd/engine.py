@@ -27,7 +27,7 @@ def _to_np_u32(t):
 _ENV_OPTIONS = ["no_fixed_base", "no_crt", "no_multiexp", "no_pair", "no_pown", "no_sliding", "no_par", "no_wide", "no_adaptive_lanes",
                 "no_merge_xn", "no_merge_r1", "fb_window_bits", "window_bits", "wide_div", "xwide_div", "waves_per_cu", "grid", "fb_budget_mb",
                 "fb_split", "gg20_trace", "sampler_max_attempts", "no_elect", "no_primaries", "merge_r1_quarters",
-                "no_r1_inversion_ahead", "wide_modexp", "no_r1_dlog_first", "no_prio", "no_pdl_ahead", "no_crt_n"]
+                "no_r1_inversion_ahead", "no_r1_dlog_first", "no_prio", "no_pdl_ahead", "no_crt_n"]
 
 
 def options_from_env(env=None):
