@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r3_kernel(Dim d, Slab in2, uint
 // M3 record: blind 0 | g_gamma 8
 __global__ void __launch_bounds__(64) MPE_EC_OCC r4_kernel(Dim d, Slab in3, const uint32_t* __restrict__ dinv, const uint32_t* __restrict__ com_all,
                           const uint32_t* __restrict__ bpk_in, const uint32_t* __restrict__ kq, uint32_t* __restrict__ R,
-                          uint32_t* __restrict__ Rbar, int32_t* __restrict__ status, uint32_t* __restrict__ bad) {
+                          uint32_t* __restrict__ Rbar, int32_t* __restrict__ status, uint32_t* __restrict__ bad, int with_rbar) {
   MPE_FOREGROUND();
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
@@ -467,7 +467,14 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r4_kernel(Dim d, Slab in3, cons
   for (int j = 0; j < d.S; ++j) acc = ec::jac_add(acc, ec::jac_from_aff(ec::aff_load(rec_of(in3, j, b) + 8)));
   const ec::Aff Rp = mul_aff(ec::u256_load(dinv + (size_t)pi * 8), ec::jac_to_aff(acc));
   ec::aff_store(R + (size_t)pi * 16, Rp);
-  ec::aff_store(Rbar + (size_t)pi * 16, mul_aff(ec::u256_load(kq + (size_t)pi * 8), Rp));
+  if (with_rbar) ec::aff_store(Rbar + (size_t)pi * 16, mul_aff(ec::u256_load(kq + (size_t)pi * 8), Rp));
+}
+// R_dash = k_i R in a launch of its own: a small batch runs it BESIDE u1 = alpha R of the PDL proofs (both need R only)
+__global__ void __launch_bounds__(64) MPE_EC_OCC r4_rbar_kernel(Dim d, const uint32_t* __restrict__ kq, const uint32_t* __restrict__ R, uint32_t* __restrict__ Rbar) {
+  MPE_FOREGROUND();
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= d.B * d.L) return;
+  ec::aff_store(Rbar + (size_t)pi * 16, mul_aff(ec::u256_load(kq + (size_t)pi * 8), ec::aff_load(R + (size_t)pi * 16)));
 }
 
 // ---- Round 5 -------------------------------------------------------------------------------------------------------
@@ -774,7 +781,7 @@ struct mpe_gg20_session {
   uint8_t* cinv_ok_pre = nullptr;  // [vi]
   // ... and round 2 starts the beta^N mod N^2 of round 4's PDL proofs (the prover's own nonce under its own key: no input of any round)
   // as a BACKGROUND launch — wave priority 0 beside the decryption ladder at 2 and the EC kernels of rounds 2 and 3 at 1 (mpe_sched.h)
-  bool pdl_ahead = false;
+  bool pdl_ahead = false, pdl_phase1 = false;      // pdl_phase1: the first of its two ladders already ran between rounds 0 and 1
   uint32_t* pdl_bn = nullptr;      // [pp][128]
   uint32_t* pdl_scratch = nullptr; // modexp_nn_scratch_words(pp)
   int fault_step = 0;              // fault injection of the reference's tests (gg_2020/test.rs:282-289,458-465,679-686): 5 / 6 / 7
@@ -986,6 +993,22 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
     rc = alice_generate(ctx, K->prv, K->stm, (int)c.nAP, s->ix.kown_ap, s->ix.st_ap, rows(s->kq, 8, s->ix.pi_ap),
                         rows(s->c_a, 128, s->ix.pi_ap), rows(Z.r_a, 64, s->ix.pi_ap), &an, &ap, st, &g, bn_pre, c_ready ? c_ready : xn_ready, c_ready);
   g.join();                                       // (again: with c_ready the proofs waited for the event only)
+  // ... and the FIRST of the two ladders behind the PDL proofs' beta^N (round 2 starts the rest, round 4 needs it): at priority 0 on the
+  // stream of the range proofs' shortest branch, from the moment the ciphertexts are there — the 5 ms before round 1's ladder in which
+  // the chip runs an inversion and a hash
+  s->pdl_phase1 = false;
+  if (rc == MPE_OK && c_ready && s->pdl_bn && ctx->use_prio && !ctx->no_pdl_ahead && ctx->use_pair && ctx->use_crt && ctx->use_pown && c.nPP > 0 &&
+      (int)c.nPP <= ctx->par_items) {
+    hipStream_t sa = ctx->aux[1];
+    (void)hipStreamWaitEvent(sa, c_ready, 0);
+    const int keep = ctx->ladder_prio;
+    ctx->ladder_prio = 0;
+    const int rca = modexp_nn(ctx, K->prv, (int)c.nPP, sel_of(s->ix.kown_pp, K->prv->nkeys), rows(Z.pdl_beta, 64, nullptr, 64),
+                              tab_rows(K->prv->N, 64, s->ix.kown_pp, K->prv->nkeys), 64, true, s->pdl_bn, sa, true, s->pdl_scratch, 1);
+    ctx->ladder_prio = keep;
+    if (rca == MPE_OK) s->pdl_phase1 = true; else rc = rca;
+    gg_trace(s->ctx, sa, "PDL beta^N, first ladder, ahead", rc);
+  }
   if (held) ctx->ws_hold--;
   gg_trace(s->ctx, st, "alice_generate", rc);
   PACK(c.nAP, n, n + 1, 0, SUB0, 0, ap.z, 64); PACK(c.nAP, n, n + 1, 0, SUB0, 64, ap.e, 8); PACK(c.nAP, n, n + 1, 0, SUB0, 72, ap.s, 64);
@@ -1168,8 +1191,9 @@ static int round2(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
     const int keep = ctx->ladder_prio;
     ctx->ladder_prio = 0;
     const int rca = modexp_nn(ctx, K->prv, (int)c.nPP, ksel, rows(Z.pdl_beta, 64, nullptr, 64), tab_rows(K->prv->N, 64, s->ix.kown_pp, K->prv->nkeys), 64,
-                              true, s->pdl_bn, sa, true, s->pdl_scratch);
+                              true, s->pdl_bn, sa, true, s->pdl_scratch, s->pdl_phase1 ? 2 : 0);
     ctx->ladder_prio = keep;
+    s->pdl_phase1 = false;
     if (rca == MPE_OK) { (void)hipEventRecord(ctx->ev_ahead, sa); s->pdl_ahead = true; } else rc = rca;
     gg_trace(s->ctx, sa, "PDL beta^N, ahead", rc);
   }
@@ -1212,16 +1236,22 @@ static int round4(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   GG_LAUNCH(validate_kernel, c.nPI, d, in3, 4, STAT(4), BADR(4));
   // small batches: R and R_dash (two dependent scalar multiplications) beside the Paillier / N~ half of the PDL proofs
   Fork g(ctx, st, 2, ctx->allow_par && (int)c.nPP <= ctx->par_items, 2);
-  if (rc == MPE_OK && c.nPI > 0)
+  hipEvent_t R_ready = nullptr;
+  if (rc == MPE_OK && c.nPI > 0) {
     hipLaunchKernelGGL(r4_kernel, dim3(blocks_for((int)c.nPI, 64)), dim3(64), 0, g.s(1), d, in3, s->dinv, s->com_all, s->bpk_in, s->kq, s->R, s->Rbar,
-                       STAT(4), BADR(4));
+                       STAT(4), BADR(4), g.on ? 0 : 1);
+    if (g.on) {                       // R is there: u1 of the PDL proofs may start (pdl_prove), R_dash follows on this branch
+      (void)hipEventRecord(ctx->ev_mid, g.s(1)); R_ready = ctx->ev_mid;
+      hipLaunchKernelGGL(r4_rbar_kernel, dim3(blocks_for((int)c.nPI, 64)), dim3(64), 0, g.s(1), d, s->kq, s->R, s->Rbar);
+    }
+  }
   Bump t(s->tmp);
   mpe_pdl_proof pp{t.w(c.nPP * 64), t.w(c.nPP * 16), t.w(c.nPP * 128), t.w(c.nPP * 64), t.w(c.nPP * 25), t.w(c.nPP * 64), t.w(c.nPP * 89)};
   mpe_pdl_nonces pn{Z.pdl_alpha, Z.pdl_beta, Z.pdl_rho, Z.pdl_gamma};
   if (rc == MPE_OK)                                                                                            // phase5_proof_pdl
     rc = pdl_prove(ctx, K->prv, K->stm, (int)c.nPP, s->ix.kown_pp, s->ix.st_pp, rows(s->c_a, 128, s->ix.pi_pp), rows(s->Rbar, 16, s->ix.pi_pp),
                    rows(s->R, 16, s->ix.pi_pp), rows(s->kq, 8, s->ix.pi_pp), rows(Z.r_a, 64, s->ix.pi_pp), &pn, &pp, st, &g,
-                   s->pdl_ahead ? s->pdl_bn : nullptr, s->pdl_ahead ? ctx->ev_ahead : nullptr);
+                   s->pdl_ahead ? s->pdl_bn : nullptr, s->pdl_ahead ? ctx->ev_ahead : nullptr, R_ready);
   else g.join();
   if (rc == MPE_OK) s->pdl_ahead = false;                    // consumed (otherwise session_release waits for it)
   gg_trace(s->ctx, st, "pdl_prove", rc);
@@ -1298,6 +1328,11 @@ static int complete(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_
 static void session_release(mpe_gg20_session* s, hipStream_t st) {
   if (!s) return;
   if (s->pdl_ahead && s->ctx->ev_ahead) { (void)hipStreamWaitEvent(st, s->ctx->ev_ahead, 0); s->pdl_ahead = false; }    // started, never consumed (a failed round)
+  if (s->pdl_phase1 && s->ctx->ev_ahead && s->ctx->aux_ready) {                                                            // its first ladder may still run
+    (void)hipEventRecord(s->ctx->ev_ahead, s->ctx->aux[1]);
+    (void)hipStreamWaitEvent(st, s->ctx->ev_ahead, 0);
+    s->pdl_phase1 = false;
+  }
   if (s->mem) {
     // secrets (k_i, gamma_i, w_i, sigma_i, nonce-derived intermediates) do not outlive the object (range_proofs.rs:26-36 zeroizes)
     (void)hipMemsetAsync(s->mem, 0, s->mem_bytes, st);

@@ -305,7 +305,8 @@ constexpr size_t CRT_WS_WORDS = 2 + 2 * 64 + 2 * 128 + 192;
 // proofs' beta^N started rounds ahead, mpe_gg20.h round2); nullptr: the context workspace
 static inline size_t modexp_nn_scratch_words(size_t B) { return 2 * B * (1 + 64 + 128) + 256; }
 static int modexp_nn(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Rows base, Rows exps, int ew, bool holder,
-                     uint32_t* out, hipStream_t st, bool pow_n = false, uint32_t* scratch = nullptr) {
+                     uint32_t* out, hipStream_t st, bool pow_n = false, uint32_t* scratch = nullptr, int phase = 0) {
+  // phase (the key holder's x^N with scratch of the caller's): 1 = the first of the two ladders only, 2 = the rest, 0 = everything
   if (!(holder && pk->has_private && ctx->use_crt)) {
     // the exponent rows ARE the public-key table: x^N for a public N (r^N, s^N) — the one case that may run on sliding windows
     if (ctx->use_pair) return launch_pair_modexp(ctx, pk->ps_nn, B, ksel, base, exps, ew, no_rows(), no_rows(), 0, out, st, 0, exps.p == pk->N);
@@ -316,15 +317,17 @@ static int modexp_nn(mpe_ctx* ctx, const mpe_paillier* pk, int B, Rows ksel, Row
   uint32_t* u = scratch ? scratch + (((size_t)B2 + 63) & ~(size_t)63) : ws_array<uint32_t>(ctx, (size_t)B2 * 64);
   uint32_t* y = scratch ? u + (size_t)B2 * 64 : ws_array<uint32_t>(ctx, (size_t)B2 * 128);
   if (!half_of || !u || !y) { mpe_set_error_msg("workspace under-reserved (modexp_nn)"); return MPE_E_NOMEM; }
-  MPE_LAUNCH_1D(crt_half_kernel, B2, st, B2, ksel, half_of);
+  if (phase != 2) MPE_LAUNCH_1D(crt_half_kernel, B2, st, B2, ksel, half_of);
   const int bw = base.words ? base.words : 128;
   Rows lo{base.p, base.idx, base.stride, bw < 64 ? bw : 64, 1};
   Rows hi = bw > 64 ? Rows{base.p + 64, base.idx, base.stride, bw - 64, 1} : no_rows();
   Rows ex{exps.p, exps.idx, exps.stride, exps.words, 1};
   if (ctx->use_pair && pow_n && ctx->use_pown) {
     const Rows hsel{nullptr, half_of, 0, 0};
-    MPE_TRY(launch_pair_modexp(ctx, pk->ps_pp, B2, hsel, Rows{base.p, base.idx, base.stride, bw, 1}, rows(pk->eq1, 32, half_of), 32,
-                               no_rows(), no_rows(), 0, y, st, 1));                        // a = x^(q mod (p-1)) mod p
+    if (phase != 2)
+      MPE_TRY(launch_pair_modexp(ctx, pk->ps_pp, B2, hsel, Rows{base.p, base.idx, base.stride, bw, 1}, rows(pk->eq1, 32, half_of), 32,
+                                 no_rows(), no_rows(), 0, y, st, 1));                      // a = x^(q mod (p-1)) mod p
+    if (phase == 1) return MPE_OK;
     MPE_TRY(launch_pair_modexp(ctx, pk->ps_pp, B2, hsel, rows(y, 64, nullptr, 32), rows(pk->pq32, 32, half_of), 32,
                                no_rows(), no_rows(), 0, u, st));                           // a^p mod p^2
   } else if (ctx->use_pair) {

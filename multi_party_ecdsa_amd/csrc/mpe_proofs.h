@@ -438,7 +438,7 @@ static int alice_verify(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statemen
 static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements* stm, int B, const int32_t* key_idx,
                      const int32_t* st_idx, Rows cipher, Rows Qp, Rows Gp, Rows x, Rows r, const mpe_pdl_nonces* nn,
                      const mpe_pdl_proof* out, hipStream_t st, Fork* outer = nullptr, const uint32_t* bn_pre = nullptr,
-                     hipEvent_t bn_pre_ready = nullptr) {
+                     hipEvent_t bn_pre_ready = nullptr, hipEvent_t G_ready = nullptr) {      // G_ready: G is there although branch 1 goes on
   // outer: a fork of the CALLER whose branch 1 produces the statement points Q, G concurrently (Round 4: R, R_dash); only u1
   // and the transcript hash need them.  bn_pre: beta^N mod N^2 when the caller has queued it elsewhere (done at bn_pre_ready)
   MPE_TRY(ws_reserve(ctx, (size_t)B * (1400 + CRT_WS_WORDS + MODEXP_N_HOLDER_WS_WORDS) * 4 + 65536, st));
@@ -452,7 +452,8 @@ static int pdl_prove(mpe_ctx* ctx, const mpe_paillier* pk, const mpe_statements*
   uint32_t* z2 = q1.fb_modexp(stm, ssel, 1, h2,rows(nn->rho, 72), 72);
   q1.modmul_to(stm->ms, ssel, rows(z1, 64), rows(z2, 64), out->z);
   // u1 = (alpha mod q) G                                                        :86
-  if (outer) outer->branch_done_wait(1, f.s(1));
+  if (G_ready) (void)hipStreamWaitEvent(f.s(1), G_ready, 0);
+  else if (outer) outer->branch_done_wait(1, f.s(1));
   if (B > 0) hipLaunchKernelGGL(ec_mul_rows_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, f.s(1), B, rows(nn->alpha, 24), 24, Gp, out->u1);
   // u2 = (N+1)^alpha beta^N mod N^2; (N+1)^alpha = 1 + alpha N (mod N^2), alpha N + 1 < N^2      :87-93
   uint32_t* ga = q.words(128);
