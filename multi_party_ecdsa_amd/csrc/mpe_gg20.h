@@ -359,6 +359,17 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r2a_kernel(Dim d, const int32_t
   r2a_finish(d, rv, v, pp, b, ind, Bpk, good, gw, bpk_in, code);
 }
 
+// the three fixed-base multiplications of Round 2's T_i and PedersenProof::prove that need the party's nonces only (l H | s1 G | s2 H,
+// affine, 48 words per party): Round 0 runs them beside its ladders, off the EC chain a small batch waits for between rounds 2 and 4
+__global__ void __launch_bounds__(64) MPE_EC_OCC ped_ahead_kernel(Dim d, const uint32_t* __restrict__ l_in, const uint32_t* __restrict__ s1_in,
+                                                       const uint32_t* __restrict__ s2_in, uint32_t* __restrict__ ped_pre) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= d.B * d.L) return;
+  uint32_t* o = ped_pre + (size_t)pi * 48;
+  ec::aff_store(o, ec::jac_to_aff(ec::jac_mul_h2(ec::sc_reduce(l_in + (size_t)pi * 8, 8))));
+  ec::aff_store(o + 16, ec::jac_to_aff(ec::jac_mul_gen(ec::sc_reduce(s1_in + (size_t)pi * 8, 8))));
+  ec::aff_store(o + 32, ec::jac_to_aff(ec::jac_mul_h2(ec::sc_reduce(s2_in + (size_t)pi * 8, 8))));
+}
 // delta_i, sigma_i, T_i + PedersenProof::prove (party_i.rs:591-634); the party's status of this round
 struct Ped { uint32_t *T, *e, *a1, *a2, *z1, *z2; };       // [pi]
 __global__ void __launch_bounds__(64) MPE_EC_OCC r2b_kernel(Dim d, const uint32_t* __restrict__ kq, const uint32_t* __restrict__ gq,
@@ -367,7 +378,7 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r2b_kernel(Dim d, const uint32_
                            const uint32_t* __restrict__ s1_in, const uint32_t* __restrict__ s2_in,
                            uint32_t* __restrict__ delta_i, uint32_t* __restrict__ sigma_i, uint32_t* __restrict__ lq, Ped p,
                            int32_t* __restrict__ status, uint32_t* __restrict__ bad, const uint32_t* __restrict__ alpha_full,
-                           uint32_t* __restrict__ miu, int fault_step, uint32_t fault_mask) {
+                           uint32_t* __restrict__ miu, int fault_step, uint32_t fault_mask, const uint32_t* __restrict__ ped_pre) {
   MPE_FOREGROUND();
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= d.B * d.L) return;
@@ -393,9 +404,11 @@ __global__ void __launch_bounds__(64) MPE_EC_OCC r2b_kernel(Dim d, const uint32_
   const ec::U256 l = ec::sc_reduce(l_in + (size_t)pi * 8, 8);
   ec::u256_store(lq + (size_t)pi * 8, l);
   const ec::Aff G = ec::aff_gen(), H = ec::aff_h2();
-  const ec::Aff T = ec::jac_to_aff(ec::jac_add(ec::jac_mul_gen(si), ec::jac_mul_h2(l)));
+  // l H, a1 = s1 G, a2 = s2 H depend on the party's own nonces only: Round 0 computed them beside its ladders (ped_ahead_kernel)
+  const uint32_t* pre = ped_pre ? ped_pre + (size_t)pi * 48 : nullptr;
+  const ec::Aff T = ec::jac_to_aff(ec::jac_add(ec::jac_mul_gen(si), pre ? ec::jac_from_aff(ec::aff_load(pre)) : ec::jac_mul_h2(l)));
   const ec::U256 s1 = ec::sc_reduce(s1_in + (size_t)pi * 8, 8), s2 = ec::sc_reduce(s2_in + (size_t)pi * 8, 8);
-  const ec::Aff a1 = ec::jac_to_aff(ec::jac_mul_gen(s1)), a2 = ec::jac_to_aff(ec::jac_mul_h2(s2));
+  const ec::Aff a1 = pre ? ec::aff_load(pre + 16) : ec::jac_to_aff(ec::jac_mul_gen(s1)), a2 = pre ? ec::aff_load(pre + 32) : ec::jac_to_aff(ec::jac_mul_h2(s2));
   const ec::Aff hp[5] = {G, H, T, a1, a2};
   const ec::U256 e = hash_points(hp, d.enc, d.enc.ord_pedersen);
   ec::aff_store(p.T + (size_t)pi * 16, T);
@@ -781,6 +794,7 @@ struct mpe_gg20_session {
   uint8_t* cinv_ok_pre = nullptr;  // [vi]
   // ... and round 2 starts the beta^N mod N^2 of round 4's PDL proofs (the prover's own nonce under its own key: no input of any round)
   // as a BACKGROUND launch — wave priority 0 beside the decryption ladder at 2 and the EC kernels of rounds 2 and 3 at 1 (mpe_sched.h)
+  uint32_t* ped_pre = nullptr;     // [pi][48] l H | s1 G | s2 H of Round 2 (ped_ahead_kernel, Round 0)
   bool pdl_ahead = false, pdl_phase1 = false;      // pdl_phase1: the first of its two ladders already ran between rounds 0 and 1
   uint32_t* pdl_bn = nullptr;      // [pp][128]
   uint32_t* pdl_scratch = nullptr; // modexp_nn_scratch_words(pp)
@@ -860,6 +874,7 @@ static size_t layout(mpe_gg20_session* s, char* base) {
   s->sub0_vi = m.i(c.nVI); s->ok_vi = m.f(c.nVI); s->sub4_pv = m.i(c.nPV); s->rdash_pv = m.i(c.nPV); s->ok_pv = m.f(c.nPV);
   const bool small = s->ctx->allow_par && c.nVI <= (size_t)s->ctx->par_items;       // the batches whose composites fork
   s->cinv_pre = small ? m.w(c.nVI * 128) : nullptr; s->cinv_ok_pre = small ? m.f(c.nVI) : nullptr;
+  s->ped_pre = m.w(c.nPI * 48);
   s->pdl_bn = small ? m.w(c.nPP * 128) : nullptr; s->pdl_scratch = small ? m.w(modexp_nn_scratch_words(c.nPP)) : nullptr;
   s->tmp_bytes = tmp_bytes_of(c);
   s->tmp = (char*)m.take(s->tmp_bytes);
@@ -947,6 +962,7 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   // where they multiply it in (ev_mid)
   const uint32_t *rn_pre = nullptr, *bn_pre = nullptr;
   Fork g(ctx, st, 2, held, 2);
+  GG_LAUNCH(ped_ahead_kernel, c.nPI, d, Z.l, Z.ped_s1, Z.ped_s2, s->ped_pre);      // Round 2's nonce-only points, beside this round's ladders
   hipEvent_t xn_ready = nullptr;
   if (held && ctx->merge_xn) {
     hipStream_t sx = g.s(1);
@@ -1201,7 +1217,7 @@ static int round2(mpe_gg20_session* s, const uint32_t* d_in, const int64_t* h_of
   if (c.nMB * 4 <= lanes_fit) GG_LAUNCH(r2a_group_kernel, c.nMB * 4, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
   else GG_LAUNCH(r2a_kernel, c.nMB, d, sub1_rv, d_in, alpha_full, s->kq, K->gw, alpha, s->bpk_in, code);
   GG_LAUNCH(r2b_kernel, c.nPI, d, s->kq, s->gq, s->w, alpha, s->beta, code, Z.l, Z.ped_s1, Z.ped_s2, s->delta_i, s->sigma_i, s->lq, ped,
-            STAT(2), BADR(2), alpha_full, s->miu, s->fault_step, s->fault_mask);
+            STAT(2), BADR(2), alpha_full, s->miu, s->fault_step, s->fault_mask, s->ped_pre);
   PACK(c.nPI, 1, 1, 0, W2, 0, s->delta_i, 8); PACK(c.nPI, 1, 1, 0, W2, 8, ped.T, 16); PACK(c.nPI, 1, 1, 0, W2, 24, ped.e, 8);
   PACK(c.nPI, 1, 1, 0, W2, 32, ped.a1, 16); PACK(c.nPI, 1, 1, 0, W2, 48, ped.a2, 16); PACK(c.nPI, 1, 1, 0, W2, 64, ped.T, 16);
   PACK(c.nPI, 1, 1, 0, W2, 80, ped.z1, 8); PACK(c.nPI, 1, 1, 0, W2, 88, ped.z2, 8);
