@@ -935,7 +935,8 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   mpe_ctx* ctx = s->ctx; const mpe_gg20_keys* K = s->K; const Dim& d = s->d; const Counts c = counts_of(d); const mpe_gg20_nonces& Z = s->Z;
   const int n = d.n;
   (void)hipMemsetAsync(d_out, 0, c.nPI * (size_t)msg_words(d.S, n, 0) * 4, st);
-  GG_LAUNCH(r0_kernel, c.nPI, d, K->x, Z.k, Z.gamma, Z.blind, s->kq, s->gq, s->w, s->k64, s->g_gamma, s->com, STAT(0), BADR(0));
+  // (r0_kernel — k_i, g^gamma_i, the commitments: 0.9 ms of EC — is launched BEHIND the fork below: the x^N ladders of a small batch need
+  //  the nonces only and start at once; the encryption's tail waits for k_i through an event)
   // small batches: the encryption of k_i runs beside the first half of the range proofs (the proofs need c only for their
   // transcript hash); both composites draw from ONE workspace reservation
   const bool par = ctx->allow_par && (int)c.nAP <= ctx->par_items;
@@ -962,6 +963,8 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
   // where they multiply it in (ev_mid)
   const uint32_t *rn_pre = nullptr, *bn_pre = nullptr;
   Fork g(ctx, st, 2, held, 2);
+  GG_LAUNCH(r0_kernel, c.nPI, d, K->x, Z.k, Z.gamma, Z.blind, s->kq, s->gq, s->w, s->k64, s->g_gamma, s->com, STAT(0), BADR(0));
+  if (g.on) (void)hipEventRecord(ctx->ev_fork[0], st);                             // "k_i is there" (waited for in front of the encryption's tail)
   GG_LAUNCH(ped_ahead_kernel, c.nPI, d, Z.l, Z.ped_s1, Z.ped_s2, s->ped_pre);      // Round 2's nonce-only points, beside this round's ladders
   hipEvent_t xn_ready = nullptr;
   if (held && ctx->merge_xn) {
@@ -980,6 +983,7 @@ static int round0(mpe_gg20_session* s, uint32_t* d_out, hipStream_t st) {
       if (rc == MPE_OK && g.on) { (void)hipEventRecord(ctx->ev_mid, sx); xn_ready = ctx->ev_mid; }
     }
   }
+  if (g.on) (void)hipStreamWaitEvent(g.s(1), ctx->ev_fork[0], 0);                  // k_i (r0_kernel on the caller's stream): long done by now
   if (rc == MPE_OK) rc = paillier_encrypt(ctx, K->prv, (int)c.nPI, s->ix.kown_pi, s->k64, Z.r_a, s->c_a, true, g.s(1), rn_pre);      // MessageA.c
   gg_trace(s->ctx, st, "encrypt k", rc);
   hipEvent_t c_ready = nullptr;
